@@ -1,0 +1,190 @@
+/*
+ * lscqp.h — C ABI of the MI355X-native batched trajectory-QP solver.
+ *
+ * This is the drop-in boundary for the ONE hot path of qwerty35/lsc_dr_planner:
+ * the per-agent, per-replan trajectory QP that the reference builds in
+ * TrajOptimizer::populatebyrow (src/traj_optimizer.cpp:216-514) and solves with
+ * CPLEX in TrajOptimizer::solve (src/traj_optimizer.cpp:18-156).
+ *
+ * The reference has no FFI of its own (everything is one statically linked C++
+ * executable), so the boundary is a C++ class surface.  The C++ shim in
+ * lsc_dr_planner_amd/shim/ keeps that surface (TrajOptimizer /
+ * CollisionConstraints / Trajectory, namespace DynamicPlanning) and calls the
+ * entry points below; nothing but plain pointers and sizes crosses this ABI.
+ *
+ * Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   P  = M*(n+1) control points per axis, n = 5, phi = 3 (the only values the
+ *        reference supports, src/traj_optimizer.cpp:184-201).
+ *   nv = dim*P decision variables, index x[k*P + m*(n+1) + i]  (axis-major, then
+ *        segment, then control point — src/traj_optimizer.cpp:55-57,220-221,241).
+ *   All floating-point payloads are fp64.  Inputs that are float32 in the
+ *   reference (octomap::point3d) are widened by the caller.
+ */
+#ifndef LSCQP_H
+#define LSCQP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSCQP_VERSION_MAJOR 0
+#define LSCQP_VERSION_MINOR 1
+
+/* ---- return codes of the API calls themselves (misuse / runtime errors) ---- */
+enum {
+    LSCQP_OK = 0,
+    LSCQP_ERR_INVALID_ARGUMENT = 1, /* mirrors std::invalid_argument in the reference ctor
+                                       (src/traj_optimizer.cpp:200) and populatebyrow (:249) */
+    LSCQP_ERR_UNSUPPORTED = 2,      /* class shape has no compiled kernel instance */
+    LSCQP_ERR_NO_DEVICE = 3,        /* no HIP device / HIP runtime error: the product path has
+                                       no CPU fallback and fails loudly */
+    LSCQP_ERR_HIP = 4
+};
+
+/* ---- per-instance solve status (status_out[]) ----
+ * The reference signals every non-success as `throw PlanningReport::QPFAILED`
+ * (src/traj_optimizer.cpp:143,152); the shim maps status != OPTIMAL to that throw. */
+enum {
+    LSCQP_STATUS_OPTIMAL = 0,
+    LSCQP_STATUS_INFEASIBLE = 1, /* CPLEX Infeasible / InfeasibleOrUnbounded, :105-106 */
+    LSCQP_STATUS_ITER_LIMIT = 2,
+    LSCQP_STATUS_NUMERIC = 3
+};
+
+/* PlannerMode values the QP reads (include/sp_const.hpp:19-26).  Only LSC adds the
+ * end-of-horizon stop rows (src/traj_optimizer.cpp:502-511). */
+enum {
+    LSCQP_PLANNER_DLSC = 0,
+    LSCQP_PLANNER_LSC = 1,
+    LSCQP_PLANNER_BVC = 2
+};
+
+/* Problem class: everything TrajOptimizer caches from Param/Mission at construction
+ * (src/traj_optimizer.cpp:4-16) plus the Param fields populatebyrow reads. */
+typedef struct lscqp_class_desc {
+    int32_t M;            /* param.M   — number of segments, >= 2 */
+    int32_t n;            /* param.n   — must be 5 */
+    int32_t phi;          /* param.phi — must be 3 */
+    int32_t phi_n;        /* param.phi_n — must be 1 */
+    int32_t dim;          /* param.world_dimension, 2 or 3 */
+    int32_t planner_mode; /* LSCQP_PLANNER_* */
+    int32_t use_sfc;      /* param.world_use_octomap: SFC rows present (:372) */
+    int32_t reserved0;
+    double dt;                   /* param.dt */
+    double control_input_weight; /* param.control_input_weight (:294) */
+    double terminal_weight;      /* param.terminal_weight (:304) */
+    double communication_range;  /* param.communication_range; <= 0 disables rows (:478) */
+    double world_min[3];         /* mission.world_min — variable lower bounds (:252) */
+    double world_max[3];         /* mission.world_max — variable upper bounds (:253) */
+    /* solver controls (0 selects the default) */
+    int32_t max_iter; /* default 60 */
+    int32_t reserved1;
+    double tol;       /* scaled KKT tolerance, default 1e-9 */
+} lscqp_class_desc;
+
+/* Per-QP header: the fields of Agent (include/sp_const.hpp:146-160) that populatebyrow reads.
+ * Exactly 256 bytes. */
+typedef struct lscqp_header {
+    double p0[3];             /* agent.current_state.position      (:321) */
+    double v0[3];             /* agent.current_state.velocity      (:332) */
+    double a0[3];             /* agent.current_state.acceleration  (:338) */
+    double goal[3];           /* agent.current_goal_point          (:305-313) */
+    double next_waypoint[3];  /* agent.next_waypoint               (:494-497) */
+    double vmax[3];           /* agent.max_vel[k]                  (:450) */
+    double amax[3];           /* agent.max_acc[k]                  (:466) */
+    double radius;            /* agent.radius                      (:484) */
+    double nominal_velocity;  /* agent.nominal_velocity            (:533) */
+    int32_t n_obs;            /* constraints.getObsSize()          (:219) */
+    int32_t terminal_segments;/* getTerminalSegments_old(agent) (:530-538) computed by the caller with the
+                                 reference's float32 semantics; <= 0: the solver computes it in fp64 */
+    uint32_t reserved[2];
+    double pad[6];
+} lscqp_header;
+
+/* One packed LSC half-space: the constraint  nx*cx + ny*cy + nz*cz >= b  on one control point.
+ * From the reference LSC{obs_control_point p, normal_vector nrm, d}
+ * (include/collision_constraints.hpp:19-33; row built at src/traj_optimizer.cpp:413-429):
+ *     nrm.(c - p) - d >= 0   <=>   nrm.c >= d + nrm.p =: b.
+ * Rows with ||nrm|| < 1e-5 are skipped as in the reference (:409-411).  32 bytes. */
+typedef struct lscqp_row {
+    double nx, ny, nz, b;
+} lscqp_row;
+
+/* One SFC box per segment (Box{box_min, box_max}, include/collision_constraints.hpp:39-46;
+ * faces via Box::convertToLSCs, src/collision_constraints.cpp:37-59). 48 bytes. */
+typedef struct lscqp_box {
+    double bmin[3];
+    double bmax[3];
+} lscqp_box;
+
+/* Optional per-instance solver diagnostics. 32 bytes. */
+typedef struct lscqp_info {
+    int32_t iterations;
+    int32_t reserved;
+    double res_primal; /* max inequality violation, metres */
+    double res_dual;   /* inf-norm of the reduced stationarity residual, scaled */
+    double gap;        /* complementarity: mean s*lambda, scaled */
+} lscqp_info;
+
+typedef struct lscqp_solver* lscqp_handle;
+
+/* Replaces TrajOptimizer::TrajOptimizer (src/traj_optimizer.cpp:4-16): validates (n,phi)==(5,3) like
+ * buildAeqBase (:198-201), precomputes Q_base (:163-178) and the continuity structure (:180-214),
+ * uploads class constants to the device. */
+int lscqp_create(const lscqp_class_desc* desc, lscqp_handle* out);
+
+/* Replaces TrajOptimizer::updateParam (src/traj_optimizer.cpp:158-160): re-derive class constants. */
+int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc);
+
+int lscqp_destroy(lscqp_handle h);
+
+/* nv = dim*M*(n+1): number of doubles per instance in x_out. */
+int lscqp_num_variables(lscqp_handle h);
+
+/* Replaces TrajOptimizer::solve (src/traj_optimizer.cpp:18-156) for a batch of n independent agents
+ * (the sequential loop at src/multi_sync_simulator.cpp:354-362 issues n == 1).
+ * HOST pointers; synchronous; copies in, launches the HIP kernel, copies out.
+ *   hdr          [n]
+ *   rows         packed LSC rows; instance q owns rows[row_offsets[q] .. row_offsets[q] + hdr[q].n_obs*P),
+ *                ordered [oi][m][i] exactly like CollisionConstraints::lscs (include/collision_constraints.hpp:173)
+ *                (the m==0,i<3 entries are present and ignored, :404-406)
+ *   row_offsets  [n+1] in units of rows (uint64)
+ *   sfc          [n*M] boxes, or NULL when !use_sfc
+ *   x_out        [n*nv]  raw fp64 control points, reference variable order (no float32 truncation)
+ *   obj_out      [n]     objective INCLUDING the constant terminal term, == cplex.getObjValue() (:100)
+ *   status_out   [n]     LSCQP_STATUS_*
+ *   info_out     [n] or NULL
+ */
+int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                      const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
+                      int32_t* status_out, lscqp_info* info_out);
+
+/* Same, DEVICE pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ * Inputs must already be resident in HBM; nothing is copied. */
+int lscqp_solve_batch_device(lscqp_handle h, int64_t n, const lscqp_header* d_hdr, const lscqp_row* d_rows,
+                             const uint64_t* d_row_offsets, const lscqp_box* d_sfc, double* d_x_out,
+                             double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, void* stream);
+
+/* Optional: multipliers of the last-mentioned formulation are exported in the REFERENCE row order so KKT
+ * residuals can be evaluated on the reference's own row-for-row model.  d_lambda_out must hold
+ * lscqp_num_inequalities(h, n_obs_max) doubles per instance (stride returned by that call). */
+int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);
+
+/* Algorithmic HBM bytes of one instance: rows + boxes + header in, x/obj/status out. */
+int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs);
+
+/* Human-readable description of the last error on this thread. */
+const char* lscqp_last_error(void);
+
+/* "lscqp 0.1 gfx950 ..." */
+const char* lscqp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSCQP_H */

@@ -1,0 +1,117 @@
+/*
+ * lscqp_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, fp64) of the trajectory-QP hot path of qwerty35/lsc_dr_planner.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and only as the
+ * checker / the timed CPU baseline.  The product (lsc_dr_planner_amd/) never links or calls it.
+ *
+ * What it follows (paths relative to the reference checkout):
+ *   Bernstein matrix            include/polynomial.hpp:9-20,281-294
+ *   derivative coefficients     include/polynomial.hpp:90-100
+ *   Q_base                      src/traj_optimizer.cpp:163-178
+ *   Aeq_base                    src/traj_optimizer.cpp:180-214
+ *   model rows                  src/traj_optimizer.cpp:216-514   (populatebyrow, row for row, same order)
+ *   terminal segments           src/traj_optimizer.cpp:530-538
+ *   box -> half-spaces          src/collision_constraints.cpp:37-59
+ *   LSC row semantics           include/collision_constraints.hpp:17-33
+ *   trajectory evaluation       src/trajectory.cpp:111-199
+ *
+ * The QP ARITHMETIC of the reference lives in IBM ILOG CPLEX Optimization Studio 20.1 (Concert C++ API,
+ * CMakeLists.txt:34-51), a proprietary dependency that is absent from the reference checkout and from this
+ * image, so the reference path cannot be compiled here (no oracle/_ref).  The solver below is an
+ * independent dense primal-dual interior point on the UNREDUCED model (numerical null space by
+ * Householder QR, every reference row kept as its own row) — deliberately a different formulation from
+ * the product's kernel.
+ *
+ * PARITY PINNING: the reference has no tests for this path.  The oracle is pinned against
+ *   (1) the reference-authored result log log/simulation_1663743693.650981_LSC_10agents.csv
+ *       (first replan of forest10_10: rows t=0.1 and t=0.2, agents 0 and 1 -> tests/golden/kat_log.json),
+ *   (2) the closed form of Q_base and the row-count table of SURVEY.md §8,
+ *   (3) scipy `trust-constr` solutions of the same assembled models (tests/golden/scipy_*.json, made by
+ *       tools/make_golden.py in the build container).
+ */
+#ifndef LSCQP_ORACLE_H
+#define LSCQP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_class {
+    int M, n, phi, phi_n, dim;
+    int planner_lsc;  /* param.planner_mode == PlannerMode::LSC */
+    int use_sfc;      /* param.world_use_octomap */
+    double dt, w_c, w_t, comm_range;
+    double world_min[3], world_max[3];
+} orc_class;
+
+typedef struct orc_agent {
+    double p0[3], v0[3], a0[3], goal[3], next_waypoint[3];
+    double vmax[3], amax[3];
+    double radius, nominal_velocity;
+    int n_obs;
+} orc_agent;
+
+/* reference LSC: obs_control_point, normal_vector, d */
+typedef struct orc_lsc {
+    double p[3], nrm[3], d;
+} orc_lsc;
+
+typedef struct orc_box {
+    double bmin[3], bmax[3];
+} orc_box;
+
+typedef struct orc_sizes {
+    int nv;    /* variables */
+    int neq;   /* equality rows */
+    int nineq; /* inequality rows (excluding variable bounds) */
+    int n_sfc, n_lsc, n_vel, n_acc, n_comm; /* sub-counts of nineq, in reference order */
+    int n_lsc_skipped;                      /* rows dropped by the ||normal|| < 1e-5 test */
+} orc_sizes;
+
+void orc_bernstein(int n, double* B /* (n+1)^2 row-major */);
+void orc_q_base(int n, int phi, int phi_n, double dt, double* Q /* (n+1)^2 */);
+/* returns 0, or -1 when (n,phi) != (5,3) like the reference's std::invalid_argument */
+int orc_aeq_base(int M, int n, int phi, double dt, double* Aeq /* ((M-2)*phi) x (M*(n+1)) */);
+int orc_terminal_segments(const orc_class* c, const orc_agent* a);
+
+/* Count rows exactly as populatebyrow would add them. lsc may be NULL when n_obs == 0. */
+void orc_count(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, orc_sizes* out);
+
+/* Dense model in the reference's row order:
+ *   minimise  x'Px + q'x + r      (NO 1/2: src/traj_optimizer.cpp:285-316)
+ *   s.t.      Aeq x = beq,  G x <= h,  lb <= x <= ub
+ * ">=" rows of the reference are stored negated so that every inequality is "<=". */
+void orc_assemble(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const orc_box* sfc, double* P,
+                  double* q, double* r, double* Aeq, double* beq, double* G, double* h, double* lb, double* ub);
+
+/* Solve. Outputs: x[nv], obj, multipliers y[neq], lam[nineq], mu_lb[nv], mu_ub[nv] (any may be NULL).
+ * Returns status 0 optimal, 1 infeasible, 2 iteration limit, 3 numerical failure. */
+int orc_solve(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const orc_box* sfc, double tol,
+              int max_iter, double* x, double* obj, double* y, double* lam, double* mu_lb, double* mu_ub,
+              int* iters);
+
+/* KKT residuals of (x, y, lam, mu_lb, mu_ub) on the assembled reference model.
+ * res[0] stationarity inf-norm / (1 + |grad f|_inf), res[1] equality violation, res[2] inequality+bound
+ * violation, res[3] most negative multiplier (as positive number), res[4] max complementarity product,
+ * res[5] objective x'Px+q'x+r. */
+void orc_kkt(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const orc_box* sfc, const double* x,
+             const double* y, const double* lam, const double* mu_lb, const double* mu_ub, double* res);
+
+/* Given only a primal point: objective, max equality violation, max inequality/bound violation. */
+void orc_primal_check(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const orc_box* sfc,
+                      const double* x, double* obj, double* eq_viol, double* ineq_viol);
+
+/* Trajectory<point3d>::getStateAt (src/trajectory.cpp:156-199) on raw fp64 control points x[nv]. */
+void orc_state_at(const orc_class* c, const double* x, double t, double* pos, double* vel, double* acc);
+
+/* Batch driver used as the timed CPU baseline: solves n instances, optionally with OpenMP threads.
+ * lsc rows of instance q start at lsc_off[q] (units of orc_lsc). Returns number of non-optimal. */
+int orc_solve_batch(const orc_class* c, int n, const orc_agent* agents, const orc_lsc* lsc,
+                    const long long* lsc_off, const orc_box* sfc, double tol, int max_iter, int threads,
+                    double* x, double* obj, int* status, int* iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU oracle (oracle/lscqp_oracle.c).
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+bench.py may import this module.  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblscqp_oracle.so")
+
+
+class OrcClass(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("n", C.c_int), ("phi", C.c_int), ("phi_n", C.c_int), ("dim", C.c_int),
+        ("planner_lsc", C.c_int), ("use_sfc", C.c_int),
+        ("dt", C.c_double), ("w_c", C.c_double), ("w_t", C.c_double), ("comm_range", C.c_double),
+        ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
+    ]
+
+
+class OrcAgent(C.Structure):
+    _fields_ = [
+        ("p0", C.c_double * 3), ("v0", C.c_double * 3), ("a0", C.c_double * 3), ("goal", C.c_double * 3),
+        ("next_waypoint", C.c_double * 3), ("vmax", C.c_double * 3), ("amax", C.c_double * 3),
+        ("radius", C.c_double), ("nominal_velocity", C.c_double), ("n_obs", C.c_int),
+    ]
+
+
+class OrcSizes(C.Structure):
+    _fields_ = [(k, C.c_int) for k in
+                ("nv", "neq", "nineq", "n_sfc", "n_lsc", "n_vel", "n_acc", "n_comm", "n_lsc_skipped")]
+
+
+AGENT_DTYPE = np.dtype([
+    ("p0", "f8", 3), ("v0", "f8", 3), ("a0", "f8", 3), ("goal", "f8", 3), ("next_waypoint", "f8", 3),
+    ("vmax", "f8", 3), ("amax", "f8", 3), ("radius", "f8"), ("nominal_velocity", "f8"), ("n_obs", "i4"),
+], align=True)
+LSC_DTYPE = np.dtype([("p", "f8", 3), ("nrm", "f8", 3), ("d", "f8")], align=True)   # 56 B, reference LSC
+BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)], align=True)
+
+assert AGENT_DTYPE.itemsize == C.sizeof(OrcAgent)
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    src = os.path.join(_HERE, "lscqp_oracle.c")
+    hdr = os.path.join(_HERE, "lscqp_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liblscqp_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        _lib.orc_solve.restype = C.c_int
+        _lib.orc_solve.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                   dp, dp, dp, dp, dp, dp, ip]
+        _lib.orc_count.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, C.POINTER(OrcSizes)]
+        _lib.orc_assemble.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, C.c_void_p] + [dp] * 9
+        _lib.orc_kkt.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, C.c_void_p, dp, dp, dp, dp, dp, dp]
+        _lib.orc_state_at.argtypes = [C.POINTER(OrcClass), dp, C.c_double, dp, dp, dp]
+        _lib.orc_terminal_segments.restype = C.c_int
+        _lib.orc_terminal_segments.argtypes = [C.POINTER(OrcClass), C.c_void_p]
+        _lib.orc_q_base.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, dp]
+        _lib.orc_aeq_base.restype = C.c_int
+        _lib.orc_aeq_base.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, dp]
+        _lib.orc_bernstein.argtypes = [C.c_int, dp]
+        _lib.orc_solve_batch.restype = C.c_int
+        _lib.orc_solve_batch.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_class(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_lsc=True, use_sfc=True,
+               world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1):
+    c = OrcClass()
+    c.M, c.n, c.phi, c.phi_n, c.dim = M, n, phi, phi_n, dim
+    c.planner_lsc, c.use_sfc = int(planner_lsc), int(use_sfc)
+    c.dt, c.w_c, c.w_t, c.comm_range = dt, w_c, w_t, comm_range
+    for k in range(3):
+        c.world_min[k] = world_min[k]
+        c.world_max[k] = world_max[k]
+    return c
+
+
+def make_agent(p0, goal, v0=(0, 0, 0), a0=(0, 0, 0), next_waypoint=None, vmax=(1, 1, 1), amax=(2, 2, 2),
+               radius=0.15, nominal_velocity=1.0, n_obs=0):
+    a = np.zeros((), AGENT_DTYPE)
+    a["p0"], a["v0"], a["a0"], a["goal"] = p0, v0, a0, goal
+    a["next_waypoint"] = goal if next_waypoint is None else next_waypoint
+    a["vmax"], a["amax"] = vmax, amax
+    a["radius"], a["nominal_velocity"], a["n_obs"] = radius, nominal_velocity, n_obs
+    return a
+
+
+def count(cls, agent, lsc=None):
+    s = OrcSizes()
+    lib().orc_count(C.byref(cls), _vp(agent), _vp(lsc), C.byref(s))
+    return s
+
+
+def assemble(cls, agent, lsc=None, sfc=None):
+    s = count(cls, agent, lsc)
+    nv, neq, mi = s.nv, s.neq, s.nineq
+    P = np.zeros((nv, nv)); q = np.zeros(nv); r = np.zeros(1)
+    Aeq = np.zeros((max(neq, 1), nv)); beq = np.zeros(max(neq, 1))
+    G = np.zeros((max(mi, 1), nv)); h = np.zeros(max(mi, 1))
+    lb = np.zeros(nv); ub = np.zeros(nv)
+    lib().orc_assemble(C.byref(cls), _vp(agent), _vp(lsc), _vp(sfc), _dp(P), _dp(q), _dp(r), _dp(Aeq), _dp(beq),
+                       _dp(G), _dp(h), _dp(lb), _dp(ub))
+    return dict(P=P, q=q, r=float(r[0]), Aeq=Aeq[:neq], beq=beq[:neq], G=G[:mi], h=h[:mi], lb=lb, ub=ub, sizes=s)
+
+
+def solve(cls, agent, lsc=None, sfc=None, tol=1e-11, max_iter=200):
+    s = count(cls, agent, lsc)
+    x = np.zeros(s.nv); obj = np.zeros(1)
+    y = np.zeros(max(s.neq, 1)); lam = np.zeros(max(s.nineq, 1)); mlb = np.zeros(s.nv); mub = np.zeros(s.nv)
+    it = C.c_int(0)
+    st = lib().orc_solve(C.byref(cls), _vp(agent), _vp(lsc), _vp(sfc), tol, max_iter, _dp(x), _dp(obj), _dp(y),
+                         _dp(lam), _dp(mlb), _dp(mub), C.byref(it))
+    return dict(status=st, x=x, obj=float(obj[0]), y=y[:s.neq], lam=lam[:s.nineq], mu_lb=mlb, mu_ub=mub,
+                iters=it.value)
+
+
+def kkt(cls, agent, lsc, sfc, x, y=None, lam=None, mu_lb=None, mu_ub=None):
+    res = np.zeros(6)
+    null = C.POINTER(C.c_double)()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lib().orc_kkt(C.byref(cls), _vp(agent), _vp(lsc), _vp(sfc), _dp(x),
+                  null if y is None else _dp(y), null if lam is None else _dp(lam),
+                  null if mu_lb is None else _dp(mu_lb), null if mu_ub is None else _dp(mu_ub), _dp(res))
+    return dict(stationarity=res[0], eq=res[1], ineq=res[2], neg_mult=res[3], comp=res[4], obj=res[5])
+
+
+def state_at(cls, x, t):
+    p = np.zeros(3); v = np.zeros(3); a = np.zeros(3)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lib().orc_state_at(C.byref(cls), _dp(x), float(t), _dp(p), _dp(v), _dp(a))
+    return p[:cls.dim], v[:cls.dim], a[:cls.dim]
+
+
+def terminal_segments(cls, agent):
+    return lib().orc_terminal_segments(C.byref(cls), _vp(agent))
+
+
+def q_base(n=5, phi=3, phi_n=1, dt=0.2):
+    Q = np.zeros((n + 1, n + 1))
+    lib().orc_q_base(n, phi, phi_n, dt, _dp(Q))
+    return Q
+
+
+def aeq_base(M, n=5, phi=3, dt=0.2):
+    A = np.zeros((max((M - 2) * phi, 1), M * (n + 1)))
+    rc = lib().orc_aeq_base(M, n, phi, dt, _dp(A))
+    return rc, A[:(M - 2) * phi]
+
+
+def bernstein(n=5):
+    B = np.zeros((n + 1, n + 1))
+    lib().orc_bernstein(n, _dp(B))
+    return B
+
+
+def solve_batch(cls, agents, lsc=None, lsc_off=None, sfc=None, tol=1e-11, max_iter=200, threads=1):
+    """agents: AGENT_DTYPE[n]; lsc: LSC_DTYPE[total]; lsc_off: int64[n] start index per agent; sfc: BOX_DTYPE[n*M]."""
+    n = len(agents)
+    nv = cls.dim * cls.M * (cls.n + 1)
+    x = np.zeros((n, nv)); obj = np.zeros(n)
+    status = np.zeros(n, dtype=np.int32); iters = np.zeros(n, dtype=np.int32)
+    agents = np.ascontiguousarray(agents)
+    if lsc_off is not None:
+        lsc_off = np.ascontiguousarray(lsc_off, dtype=np.int64)
+    bad = lib().orc_solve_batch(C.byref(cls), n, _vp(agents), _vp(lsc), _vp(lsc_off), _vp(sfc), tol, max_iter,
+                                threads, _dp(x), _dp(obj), status.ctypes.data_as(C.POINTER(C.c_int)),
+                                iters.ctypes.data_as(C.POINTER(C.c_int)))
+    return dict(x=x, obj=obj, status=status, iters=iters, bad=bad)

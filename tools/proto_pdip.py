@@ -1,0 +1,212 @@
+"""Development aid (NOT product, NOT oracle): numpy prototype of the formulation the HIP kernel uses.
+
+Same maths as lsc_dr_planner_amd/csrc/lscqp_kernel.hip, written densely for one instance so the algorithm
+(analytic null space, merged interval rows, two-sided rows, Mehrotra predictor-corrector, stopping rule) can be
+debugged on the CPU against the oracle before it is hand-mapped onto a wavefront.
+"""
+import numpy as np
+
+TB = np.array([[0.0, 0.0, 1.0], [0.0, -1.0, 2.0], [1.0, -4.0, 4.0]])  # (c0,c1,c2)^{m+1} = TB (c3,c4,c5)^m
+
+
+def q_base(dt):
+    Q = np.array([[720, -1800, 1200, 0, 0, -120], [-1800, 4800, -3600, 0, 600, 0], [1200, -3600, 3600, -1200, 0, 0],
+                  [0, 0, -1200, 3600, -3600, 1200], [0, 600, 0, -3600, 4800, -1800], [-120, 0, 0, 1200, -1800, 720]],
+                 dtype=float)
+    return Q * dt ** -5
+
+
+def build_T(M, end_stop):
+    """Per-axis map  c = c_fixed + T z  (P x nzA)."""
+    nzA = 3 * (M - 1) + (1 if end_stop else 3)
+    T = np.zeros((6 * M, nzA))
+    for m in range(M):
+        last = (m == M - 1) and end_stop
+        for j in range(3):
+            T[6 * m + 3 + j, 3 * m + (0 if last else j)] = 1.0
+        if m >= 1:
+            for i in range(3):
+                for j in range(3):
+                    T[6 * m + i, 3 * (m - 1) + j] = TB[i, j]
+    return T, nzA
+
+
+def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
+          tol=1e-10, max_iter=60, verbose=False):
+    """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
+    sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
+    P = 6 * M
+    # ---- translate the origin to p0 (conditioning: every quantity becomes O(1 m)) ----
+    org = np.array(hdr["p0"], dtype=float).copy()
+    hdr = dict(hdr)
+    hdr["goal"] = np.asarray(hdr["goal"], float) - org
+    hdr["next_waypoint"] = np.asarray(hdr["next_waypoint"], float) - org
+    hdr["p0"] = np.zeros(3)
+    world_min = np.asarray(world_min, float) - org
+    world_max = np.asarray(world_max, float) - org
+    if sfc is not None:
+        sfc = np.asarray(sfc, float) - org[None, None, :]
+    if rows is not None:
+        rows = np.array(rows, float)
+        rows[..., 3] -= rows[..., :3] @ org
+    T, nzA = build_T(M, end_stop)
+    nz = dim * nzA
+    Q2 = 2 * w_c * q_base(dt)
+    # fixed part
+    cfix = np.zeros((dim, P))
+    for k in range(dim):
+        c0 = hdr["p0"][k]
+        c1 = c0 + hdr["v0"][k] * dt / 5
+        c2 = hdr["a0"][k] * dt * dt / 20 + 2 * c1 - c0
+        cfix[k, 0:3] = (c0, c1, c2)
+    # x-space Hessian per axis and linear term
+    Hx = np.zeros((P, P))
+    for m in range(M):
+        Hx[6 * m:6 * m + 6, 6 * m:6 * m + 6] += Q2
+    fx = np.zeros((dim, P))
+    Hx_t = Hx.copy()
+    for m in range(M - ts, M):
+        Hx_t[6 * m + 5, 6 * m + 5] += 2 * w_t
+        for k in range(dim):
+            fx[k, 6 * m + 5] += -2 * w_t * hdr["goal"][k]
+    K0 = T.T @ Hx_t @ T  # same for every axis
+    g0 = np.stack([T.T @ (Hx_t @ cfix[k] + fx[k]) for k in range(dim)])  # (dim, nzA)
+
+    # ---- rows -------------------------------------------------------------------------------------
+    # two-sided per-axis rows: list of (coef vector over P, lo, hi)
+    rowsA = []  # per axis: (Gc (nr x P), lo, hi)
+    rho_pair = 0.5 * comm_range - hdr["radius"]
+    rho_wp = 0.5 * comm_range - 1e-5
+    for k in range(dim):
+        Gc, lo, hi = [], [], []
+        for m in range(M):
+            for i in range(6):
+                if m == 0 and i < 3:
+                    continue
+                l, h = world_min[k], world_max[k]
+                if use_sfc:
+                    l, h = max(l, sfc[m, 0, k]), min(h, sfc[m, 1, k])
+                if comm_range > 0 and i == 5:
+                    l = max(l, hdr["p0"][k] - rho_pair, hdr["next_waypoint"][k] - rho_wp)
+                    h = min(h, hdr["p0"][k] + rho_pair, hdr["next_waypoint"][k] + rho_wp)
+                e = np.zeros(P); e[6 * m + i] = 1
+                Gc.append(e); lo.append(l); hi.append(h)
+            for i in range(5):
+                if m == 0 and i < 2:
+                    continue
+                e = np.zeros(P); e[6 * m + i + 1] = 1; e[6 * m + i] = -1
+                Gc.append(e); lo.append(-hdr["vmax"][k] * dt / 5); hi.append(hdr["vmax"][k] * dt / 5)
+            for i in range(4):
+                if m == 0 and i < 1:
+                    continue
+                e = np.zeros(P); e[6 * m + i + 2] = 1; e[6 * m + i + 1] = -2; e[6 * m + i] = 1
+                Gc.append(e); lo.append(-hdr["amax"][k] * dt * dt / 20); hi.append(hdr["amax"][k] * dt * dt / 20)
+        if comm_range > 0:
+            for mi in range(1, M):
+                for m in range(mi, M):
+                    e = np.zeros(P); e[6 * m + 5] += 1; e[6 * mi + 0] += -1
+                    Gc.append(e); lo.append(-rho_pair); hi.append(rho_pair)
+        rowsA.append((np.array(Gc), np.array(lo), np.array(hi)))
+    # one-sided dense G in z space:  G z >= h  (all rows)
+    Gz, hz = [], []
+    for k in range(dim):
+        Gc, lo, hi = rowsA[k]
+        GT = Gc @ T
+        off = Gc @ cfix[k]
+        blk = np.zeros((len(lo), nz)); blk[:, k * nzA:(k + 1) * nzA] = GT
+        Gz.append(blk); hz.append(lo - off)
+        Gz.append(-blk); hz.append(-(hi - off))
+    n_obs = rows.shape[0] if rows is not None else 0
+    for oi in range(n_obs):
+        for m in range(M):
+            for i in range(6):
+                if m == 0 and i < 3:
+                    continue
+                nx, ny, nzc, b = rows[oi, m, i]
+                nv3 = (nx, ny, nzc)
+                if np.sqrt(nx * nx + ny * ny + nzc * nzc) < 1e-5:
+                    continue
+                g = np.zeros(nz); off = 0.0
+                for k in range(dim):
+                    g[k * nzA:(k + 1) * nzA] = nv3[k] * T[6 * m + i]
+                    off += nv3[k] * cfix[k, 6 * m + i]
+                Gz.append(g[None, :]); hz.append(np.array([b - off]))
+    Gz = np.concatenate(Gz); hz = np.concatenate(hz)
+    mrows = len(hz)
+    Kfull = np.zeros((nz, nz)); gfull = np.zeros(nz)
+    for k in range(dim):
+        Kfull[k * nzA:(k + 1) * nzA, k * nzA:(k + 1) * nzA] = K0
+        gfull[k * nzA:(k + 1) * nzA] = g0[k]
+    if np.any(np.concatenate([r[2] - r[1] for r in rowsA]) < 0):
+        return None, np.nan, 1, 0
+
+    # ---- PDIP ("G z - h = s >= 0") ----------------------------------------------------------------
+    z = np.zeros(nz)
+    for k in range(dim):  # start: every free control point at c2 of the first segment
+        z[k * nzA:(k + 1) * nzA] = cfix[k, 2]
+    s = np.maximum(Gz @ z - hz, 0.0)
+    s = np.maximum(s, 1e-2)
+    lam = np.ones(mrows)
+    gscale = max(1.0, np.abs(gfull).max())
+    objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
+        hdr["goal"][k] ** 2 for k in range(dim))
+    status, it = 2, 0
+    for it in range(max_iter):
+        rp = Gz @ z - hz - s
+        grad = Kfull @ z + gfull
+        rd = grad - Gz.T @ lam
+        mu = s @ lam / mrows
+        objz = 0.5 * z @ Kfull @ z + gfull @ z
+        if verbose:
+            print(it, "rp %.2e rd %.2e mu %.2e" % (np.abs(rp).max(), np.abs(rd).max() / gscale, mu))
+        pinf = lam @ np.abs(rp)
+        gls = max(gscale, np.abs(grad).max())
+        if np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 10 * tol * gls and mu * mrows + pinf <= tol * (1 + abs(objz + objc)):
+            status = 0
+            break
+        w = lam / s
+        K = Kfull + Gz.T @ (w[:, None] * Gz)
+        try:
+            L = np.linalg.cholesky(K)
+        except np.linalg.LinAlgError:
+            status = 3
+            break
+        def lin(q):
+            rhs = -grad + Gz.T @ q
+            return np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+        # predictor
+        dza = lin(-w * rp)
+        dsa = Gz @ dza + rp
+        dla = -lam - w * dsa
+        aa = 1.0
+        neg = dsa < 0
+        if neg.any(): aa = min(aa, (-s[neg] / dsa[neg]).min())
+        neg = dla < 0
+        if neg.any(): aa = min(aa, (-lam[neg] / dla[neg]).min())
+        mu_aff = (s + aa * dsa) @ (lam + aa * dla) / mrows
+        sigma = (mu_aff / mu) ** 3
+        q = (sigma * mu - dsa * dla) / s - w * rp
+        dz = lin(q)
+        ds = Gz @ dz + rp
+        dl = (sigma * mu - dsa * dla) / s - lam - w * ds
+        a = 1e300
+        neg = ds < 0
+        if neg.any(): a = min(a, (-s[neg] / ds[neg]).min())
+        neg = dl < 0
+        if neg.any(): a = min(a, (-lam[neg] / dl[neg]).min())
+        a = min(1.0, 0.995 * a)
+        z = z + a * dz; s = s + a * ds; lam = lam + a * dl
+    x = np.concatenate([cfix[k] + T @ z[k * nzA:(k + 1) * nzA] for k in range(dim)])
+    # objective: the same polynomial integral as x'(w_c Q)x, evaluated through third differences (stable)
+    D3 = np.array([[-1, 3, -3, 1, 0, 0], [0, -1, 3, -3, 1, 0], [0, 0, -1, 3, -3, 1]], dtype=float)
+    MB = np.array([[1 / 5, 1 / 10, 1 / 30], [1 / 10, 2 / 15, 1 / 10], [1 / 30, 1 / 10, 1 / 5]])
+    obj = 0.0
+    for k in range(dim):
+        c = x[k * P:(k + 1) * P]
+        for m in range(M):
+            j3 = D3 @ c[6 * m:6 * m + 6]
+            obj += w_c * 3600 * dt ** -5 * (j3 @ MB @ j3)
+        for m in range(M - ts, M):
+            obj += w_t * (c[6 * m + 5] - hdr["goal"][k]) ** 2
+    x = x + np.repeat(org[:dim], P)
+    return x, obj, status, it
