@@ -103,7 +103,7 @@ typedef struct lscqp_header {
     int32_t terminal_segments;/* getTerminalSegments_old(agent) (:530-538) computed by the caller with the
                                  reference's float32 semantics; <= 0: the solver computes it in fp64 */
     uint32_t reserved[2];
-    double pad[6];
+    double pad[7];
 } lscqp_header;
 
 /* One packed LSC half-space: the constraint  nx*cx + ny*cy + nz*cz >= b  on one control point.
@@ -165,14 +165,16 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
                       int32_t* status_out, lscqp_info* info_out);
 
 /* Same, DEVICE pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
- * Inputs must already be resident in HBM; nothing is copied. */
-int lscqp_solve_batch_device(lscqp_handle h, int64_t n, const lscqp_header* d_hdr, const lscqp_row* d_rows,
-                             const uint64_t* d_row_offsets, const lscqp_box* d_sfc, double* d_x_out,
-                             double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, void* stream);
+ * Inputs must already be resident in HBM; nothing is copied and nothing is synchronised.
+ * n_obs_max: upper bound of d_hdr[q].n_obs over the batch (sizes the per-wavefront LDS staging area; instances
+ * with more obstacles are truncated to it, so pass the true maximum). */
+int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                             const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                             double* d_x_out, double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out,
+                             void* stream);
 
-/* Optional: multipliers of the last-mentioned formulation are exported in the REFERENCE row order so KKT
- * residuals can be evaluated on the reference's own row-for-row model.  d_lambda_out must hold
- * lscqp_num_inequalities(h, n_obs_max) doubles per instance (stride returned by that call). */
+/* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
+ * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);
 
 /* Algorithmic HBM bytes of one instance: rows + boxes + header in, x/obj/status out. */

@@ -1,0 +1,195 @@
+"""ctypes binding of the C ABI (include/lscqp.h -> liblscqp.so).  Plumbing for tests and bench.py only.
+
+The product is the shared library (HIP kernels + C ABI) and the C++ shim in lsc_dr_planner_amd/shim/.  This module
+only moves bytes: numpy structured arrays for host calls, torch CUDA tensors (raw device pointers) for resident
+calls.  It never computes anything and has NO CPU fallback: if liblscqp.so is missing, importing fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblscqp.so")
+
+STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC = 0, 1, 2, 3
+PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC = 0, 1, 2
+OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
+
+HEADER_DTYPE = np.dtype([
+    ("p0", "f8", 3), ("v0", "f8", 3), ("a0", "f8", 3), ("goal", "f8", 3), ("next_waypoint", "f8", 3),
+    ("vmax", "f8", 3), ("amax", "f8", 3), ("radius", "f8"), ("nominal_velocity", "f8"),
+    ("n_obs", "i4"), ("terminal_segments", "i4"), ("reserved", "u4", 2), ("pad", "f8", 7),
+])
+ROW_DTYPE = np.dtype([("nx", "f8"), ("ny", "f8"), ("nz", "f8"), ("b", "f8")])
+BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)])
+INFO_DTYPE = np.dtype([("iterations", "i4"), ("reserved", "i4"), ("res_primal", "f8"), ("res_dual", "f8"),
+                       ("gap", "f8")])
+assert HEADER_DTYPE.itemsize == 256 and ROW_DTYPE.itemsize == 32 and BOX_DTYPE.itemsize == 48
+assert INFO_DTYPE.itemsize == 32
+
+
+class ClassDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("n", C.c_int32), ("phi", C.c_int32), ("phi_n", C.c_int32), ("dim", C.c_int32),
+        ("planner_mode", C.c_int32), ("use_sfc", C.c_int32), ("reserved0", C.c_int32),
+        ("dt", C.c_double), ("control_input_weight", C.c_double), ("terminal_weight", C.c_double),
+        ("communication_range", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
+        ("max_iter", C.c_int32), ("reserved1", C.c_int32), ("tol", C.c_double),
+    ]
+
+
+class LscqpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lscqp error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load liblscqp.so.  Raises if it has not been built (python -m lsc_dr_planner_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("liblscqp.so not built: run `python lsc_dr_planner_amd/build.py` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.lscqp_create.restype = C.c_int
+        L.lscqp_create.argtypes = [C.POINTER(ClassDesc), C.POINTER(vp)]
+        L.lscqp_update.restype = C.c_int
+        L.lscqp_update.argtypes = [vp, C.POINTER(ClassDesc)]
+        L.lscqp_destroy.restype = C.c_int
+        L.lscqp_destroy.argtypes = [vp]
+        L.lscqp_num_variables.restype = C.c_int
+        L.lscqp_num_variables.argtypes = [vp]
+        L.lscqp_num_inequalities.restype = C.c_int
+        L.lscqp_num_inequalities.argtypes = [vp, C.c_int32]
+        L.lscqp_algorithmic_bytes.restype = C.c_int64
+        L.lscqp_algorithmic_bytes.argtypes = [vp, C.c_int32]
+        L.lscqp_solve_batch.restype = C.c_int
+        L.lscqp_solve_batch.argtypes = [vp, C.c_int64] + [vp] * 8
+        L.lscqp_solve_batch_device.restype = C.c_int
+        L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9
+        L.lscqp_last_error.restype = C.c_char_p
+        L.lscqp_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_last_error",
+                    "lscqp_version"]
+
+
+def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
+              world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0):
+    d = ClassDesc()
+    d.M, d.n, d.phi, d.phi_n, d.dim = M, n, phi, phi_n, dim
+    d.planner_mode, d.use_sfc = planner_mode, int(use_sfc)
+    d.dt, d.control_input_weight, d.terminal_weight, d.communication_range = dt, w_c, w_t, comm_range
+    for k in range(3):
+        d.world_min[k] = float(world_min[k])
+        d.world_max[k] = float(world_max[k])
+    d.max_iter, d.tol = max_iter, tol
+    return d
+
+
+def pack_rows(lsc):
+    """Reference LSC records (p, nrm, d) -> packed rows (nx, ny, nz, b = d + nrm.p); include/lscqp.h lscqp_row."""
+    out = np.zeros(lsc.shape, ROW_DTYPE)
+    out["nx"], out["ny"], out["nz"] = lsc["nrm"][..., 0], lsc["nrm"][..., 1], lsc["nrm"][..., 2]
+    out["b"] = lsc["d"] + (lsc["nrm"] * lsc["p"]).sum(-1)
+    return out
+
+
+class Solver:
+    def __init__(self, desc):
+        self.desc = desc
+        self._h = C.c_void_p()
+        rc = lib().lscqp_create(C.byref(desc), C.byref(self._h))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        self.nv = lib().lscqp_num_variables(self._h)
+        self.M, self.dim, self.P = desc.M, desc.dim, desc.M * 6
+
+    def close(self):
+        if self._h:
+            lib().lscqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, desc):
+        rc = lib().lscqp_update(self._h, C.byref(desc))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        self.desc = desc
+
+    def algorithmic_bytes(self, n_obs):
+        return lib().lscqp_algorithmic_bytes(self._h, n_obs)
+
+    def num_inequalities(self, n_obs):
+        return lib().lscqp_num_inequalities(self._h, n_obs)
+
+    # ---- host-pointer call (numpy) --------------------------------------------------------------------
+    def solve_host(self, hdr, rows=None, row_offsets=None, sfc=None, want_info=True):
+        n = len(hdr)
+        hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE)
+        x = np.zeros((n, self.nv))
+        obj = np.zeros(n)
+        status = np.full(n, -1, dtype=np.int32)
+        info = np.zeros(n, INFO_DTYPE) if want_info else None
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE).reshape(-1)
+            row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+            assert len(row_offsets) == n + 1
+        if sfc is not None:
+            sfc = np.ascontiguousarray(sfc, dtype=BOX_DTYPE).reshape(-1)
+
+        def p(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+        rc = lib().lscqp_solve_batch(self._h, n, p(hdr), p(rows), p(row_offsets), p(sfc), p(x), p(obj), p(status), p(info))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        return dict(x=x, obj=obj, status=status, info=info)
+
+    # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
+    def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None):
+        """All arguments are torch CUDA tensors (any dtype; only data_ptr() is used) or None.
+        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        rc = lib().lscqp_solve_batch_device(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x),
+                                            p(d_obj), p(d_status), p(d_info), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+
+def batch_from_swarm(build, n_obs, M, vmax=1.0, amax=2.0, radius=0.15, nominal_velocity=1.0, terminal_segments=None):
+    """Pack the output of synth.Swarm.build() into ABI arrays (hdr, rows, row_offsets, sfc)."""
+    N = len(build["p0"])
+    hdr = np.zeros(N, HEADER_DTYPE)
+    for f in ("p0", "v0", "a0", "goal", "next_waypoint"):
+        hdr[f] = build[f]
+    hdr["vmax"], hdr["amax"] = vmax, amax
+    hdr["radius"], hdr["nominal_velocity"] = radius, nominal_velocity
+    hdr["n_obs"] = n_obs
+    hdr["terminal_segments"] = 0 if terminal_segments is None else terminal_segments
+    rows = pack_rows(build["lsc"]).reshape(-1)
+    off = (np.arange(N + 1, dtype=np.uint64) * np.uint64(n_obs * M * 6))
+    sfc = np.zeros((N, M), BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = build["sfc"]["bmin"], build["sfc"]["bmax"]
+    return hdr, rows, off, sfc

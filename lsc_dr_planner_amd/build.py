@@ -1,0 +1,68 @@
+"""Build liblscqp.so (the C-ABI library of include/lscqp.h) for gfx950 with hipcc, in-tree.
+
+One translation unit per kernel instance, compiled in parallel; hipcc cross-compiles without a GPU.
+"""
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "liblscqp.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable"]
+
+
+def instances():
+    txt = open(os.path.join(CSRC, "lscqp_launch.hpp")).read()
+    body = txt[txt.index("#define LSCQP_INSTANCES"):]
+    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+)\)", body)]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return r.stderr
+
+
+def build(force=False, verbose=False, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in ("lscqp_kernel.hpp", "lscqp_launch.hpp")] + [
+        os.path.join(HERE, "..", "include", "lscqp.h")]
+    tasks = []
+    objs = []
+    for (M, D, E) in instances():
+        o = os.path.join(OBJ, "inst_%d_%d_%d.o" % (M, D, E))
+        objs.append(o)
+        src = os.path.join(CSRC, "lscqp_inst.hip")
+        if force or _newer(o, hdrs + [src]):
+            tasks.append([HIPCC] + FLAGS + ["-DLSCQP_M=%d" % M, "-DLSCQP_DIM=%d" % D, "-DLSCQP_ES=%d" % E, "-c", src, "-o", o])
+    api_o = os.path.join(OBJ, "api.o")
+    objs.append(api_o)
+    api_src = os.path.join(CSRC, "lscqp_api.hip")
+    if force or _newer(api_o, hdrs + [api_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
+    if tasks:
+        with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
+            for msg in ex.map(_run, tasks):
+                if verbose and msg:
+                    sys.stderr.write(msg)
+    if tasks or not os.path.exists(LIB):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,240 @@
+// lscqp_api.hip — C ABI of the batched trajectory-QP solver (include/lscqp.h).  Host side, HIP runtime only.
+// There is NO CPU fallback: without a HIP device every solve call fails loudly with LSCQP_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lscqp_kernel.hpp"
+#include "lscqp_launch.hpp"
+
+#define LSCQP_DECL(M, D, E)                                                                                             \
+    extern "C" hipError_t lscqp_launch_##M##_##D##_##E(const lscqp::DevClass*, int64_t, const lscqp_header*,            \
+                                                       const lscqp_row*, const uint64_t*, const lscqp_box*, double*,    \
+                                                       double*, int32_t*, lscqp_info*, hipStream_t);
+LSCQP_INSTANCES(LSCQP_DECL)
+#undef LSCQP_DECL
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+struct Inst {
+    int M, dim, es;
+    lscqp::launch_fn fn;
+};
+const Inst kInst[] = {
+#define LSCQP_ROW(M, D, E) {M, D, E, lscqp_launch_##M##_##D##_##E},
+    LSCQP_INSTANCES(LSCQP_ROW)
+#undef LSCQP_ROW
+};
+
+lscqp::launch_fn find_instance(int M, int dim, int es) {
+    for (const Inst& i : kInst)
+        if (i.M == M && i.dim == dim && i.es == es) return i.fn;
+    return nullptr;
+}
+
+// Closed form of Q_base for n = 5, phi = 3, phi_n = 1 (reference src/traj_optimizer.cpp:163-178:
+// B Z B^T is this integer matrix, scaled by dt^(-5)).
+const double kQInt[36] = {720, -1800, 1200, 0,     0,     -120, -1800, 4800, -3600, 0,     600,   0,
+                          1200, -3600, 3600, -1200, 0,     0,    0,     0,    -1200, 3600,  -3600, 1200,
+                          0,    600,   0,    -3600, 4800,  -1800, -120, 0,    0,     1200,  -1800, 720};
+
+}  // namespace
+
+struct lscqp_solver {
+    lscqp_class_desc desc;
+    lscqp::DevClass dev;
+    lscqp::launch_fn fn;
+    int nv, P, es;
+    // staging buffers of the host-pointer entry point
+    void* d_buf = nullptr;
+    size_t d_cap = 0;
+};
+
+static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
+    // same argument checks as the reference: (n, phi) must be (5, 3) (src/traj_optimizer.cpp:198-201),
+    // dim <= 3 (:249); M >= 2 is assumed by the continuity rows (:341-352)
+    if (d->n != 5 || d->phi != 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "[TrajOptimizer] Currently, only n=5, phi=3 is available");
+    if (d->phi_n != 1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "phi_n must be 1");
+    if (d->dim < 2 || d->dim > 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "[TrajOptimizer] Invalid output dimension, output_dim > 3");
+    if (d->M < 2) return fail(LSCQP_ERR_INVALID_ARGUMENT, "M must be >= 2");
+    if (!(d->dt > 0)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "dt must be positive");
+    const int es = (d->planner_mode == LSCQP_PLANNER_LSC) ? 1 : 0;
+    lscqp::launch_fn fn = find_instance(d->M, d->dim, es);
+    if (!fn) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "no compiled kernel instance for M=%d dim=%d end_stop=%d (needs dim*(3M-2) <= 64)", d->M, d->dim, es);
+        return fail(LSCQP_ERR_UNSUPPORTED, buf);
+    }
+    s->desc = *d;
+    s->fn = fn;
+    s->es = es;
+    s->P = d->M * 6;
+    s->nv = d->dim * s->P;
+    lscqp::DevClass& c = s->dev;
+    memset(&c, 0, sizeof c);
+    c.dt = d->dt;
+    c.w_c = d->control_input_weight;
+    c.w_t = d->terminal_weight;
+    c.comm_range = d->communication_range;
+    const double sc = std::pow(d->dt, -5.0);
+    for (int i = 0; i < 36; i++) c.Q2[i] = 2.0 * d->control_input_weight * kQInt[i] * sc;
+    for (int k = 0; k < 3; k++) {
+        c.world_min[k] = d->world_min[k];
+        c.world_max[k] = d->world_max[k];
+    }
+    c.tol = d->tol > 0 ? d->tol : 1e-10;
+    c.max_iter = d->max_iter > 0 ? d->max_iter : 60;
+    c.use_sfc = d->use_sfc;
+    c.n_obs_max = 0;
+    return LSCQP_OK;
+}
+
+extern "C" {
+
+int lscqp_create(const lscqp_class_desc* desc, lscqp_handle* out) {
+    if (!desc || !out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    lscqp_solver* s = new lscqp_solver();
+    int rc = derive(s, desc);
+    if (rc != LSCQP_OK) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return LSCQP_OK;
+}
+
+int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
+    if (!h || !desc) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    lscqp_solver tmp = *h;
+    int rc = derive(&tmp, desc);
+    if (rc != LSCQP_OK) return rc;
+    tmp.d_buf = h->d_buf;
+    tmp.d_cap = h->d_cap;
+    *h = tmp;
+    return LSCQP_OK;
+}
+
+int lscqp_destroy(lscqp_handle h) {
+    if (!h) return LSCQP_OK;
+    if (h->d_buf) (void)hipFree(h->d_buf);
+    delete h;
+    return LSCQP_OK;
+}
+
+int lscqp_num_variables(lscqp_handle h) { return h ? h->nv : -1; }
+
+int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs) {
+    if (!h) return -1;
+    const int M = h->desc.M, dim = h->desc.dim, P = h->P;
+    int m = n_obs * (P - 3) + 2 * dim * (5 * M - 2) + 2 * dim * (4 * M - 1);
+    if (h->desc.use_sfc) m += 2 * dim * (P - 3);
+    if (h->desc.communication_range > 0) m += 2 * dim * (M * (M + 1) / 2 + M);
+    return m;
+}
+
+int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs) {
+    if (!h) return -1;
+    // rows (32 B each, all n_obs*P of them) + SFC boxes (48 B/segment) + header (256 B) in;
+    // control points (8 B each) + objective + status (16 B) out.
+    return (int64_t)32 * n_obs * h->P + 48 * h->desc.M + 256 + 8 * h->nv + 16;
+}
+
+int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                             const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                             double* d_x_out, double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out,
+                             void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return LSCQP_OK;
+    if (!d_hdr || !d_x_out || !d_obj_out || !d_status_out || (n_obs_max > 0 && (!d_rows || !d_row_offsets)) ||
+        (h->desc.use_sfc && !d_sfc))
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    lscqp::DevClass cls = h->dev;
+    cls.n_obs_max = n_obs_max;
+    hipError_t e = h->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_out, d_obj_out, d_status_out, d_info_out,
+                         (hipStream_t)stream);
+    if (e == hipErrorInvalidValue)
+        return fail(LSCQP_ERR_UNSUPPORTED, "instance does not fit the 160 KiB LDS of one CU (too many obstacles per agent)");
+    if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
+    return LSCQP_OK;
+}
+
+int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                      const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
+                      int32_t* status_out, lscqp_info* info_out) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return LSCQP_OK;
+    if (!hdr || !x_out || !obj_out || !status_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    int n_obs_max = 0;
+    for (int64_t q = 0; q < n; q++) {
+        if (hdr[q].n_obs < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative n_obs");
+        if (hdr[q].n_obs > n_obs_max) n_obs_max = hdr[q].n_obs;
+    }
+    if (n_obs_max > 0 && (!rows || !row_offsets)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null row buffer");
+    if (h->desc.use_sfc && !sfc) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null sfc buffer");
+    const size_t n_rows = n_obs_max > 0 ? (size_t)row_offsets[n] : 0;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(sizeof(lscqp_row) * n_rows),
+                 b_off = al(sizeof(uint64_t) * (n + 1)), b_sfc = al(sizeof(lscqp_box) * n * h->desc.M),
+                 b_x = al(sizeof(double) * n * h->nv), b_obj = al(sizeof(double) * n), b_st = al(sizeof(int32_t) * n),
+                 b_info = al(sizeof(lscqp_info) * n);
+    const size_t total = b_hdr + b_rows + b_off + b_sfc + b_x + b_obj + b_st + b_info;
+    if (total > h->d_cap) {
+        if (h->d_buf) (void)hipFree(h->d_buf);
+        h->d_buf = nullptr;
+        h->d_cap = 0;
+        if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
+        h->d_cap = total;
+    }
+    char* p = (char*)h->d_buf;
+    lscqp_header* d_hdr = (lscqp_header*)p; p += b_hdr;
+    lscqp_row* d_rows = (lscqp_row*)p; p += b_rows;
+    uint64_t* d_off = (uint64_t*)p; p += b_off;
+    lscqp_box* d_sfc = (lscqp_box*)p; p += b_sfc;
+    double* d_x = (double*)p; p += b_x;
+    double* d_obj = (double*)p; p += b_obj;
+    int32_t* d_st = (int32_t*)p; p += b_st;
+    lscqp_info* d_info = (lscqp_info*)p;
+#define LSCQP_CK(call)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(LSCQP_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
+    } while (0)
+    LSCQP_CK(hipMemcpy(d_hdr, hdr, sizeof(lscqp_header) * n, hipMemcpyHostToDevice));
+    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, sizeof(lscqp_row) * n_rows, hipMemcpyHostToDevice));
+    if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
+    else LSCQP_CK(hipMemset(d_off, 0, sizeof(uint64_t) * (n + 1)));
+    if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
+    int rc = lscqp_solve_batch_device(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, nullptr);
+    if (rc != LSCQP_OK) return rc;
+    LSCQP_CK(hipDeviceSynchronize());
+    LSCQP_CK(hipMemcpy(x_out, d_x, sizeof(double) * n * h->nv, hipMemcpyDeviceToHost));
+    LSCQP_CK(hipMemcpy(obj_out, d_obj, sizeof(double) * n, hipMemcpyDeviceToHost));
+    LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (info_out) LSCQP_CK(hipMemcpy(info_out, d_info, sizeof(lscqp_info) * n, hipMemcpyDeviceToHost));
+#undef LSCQP_CK
+    return LSCQP_OK;
+}
+
+const char* lscqp_last_error(void) { return g_err.c_str(); }
+
+const char* lscqp_version(void) { return "lscqp 0.1 (gfx950, fp64 PDIP, one wavefront per QP)"; }
+
+}  // extern "C"
