@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py — QP solves/sec of the batched trajectory-QP hot path on N MI355X GPUs of one node.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+  * A "step" is one pass of the hot path (lscqp_solve_batch_device: the HIP PDIP kernel) over one batch of synthetic
+    agents, inputs already resident in HBM.  The workload at every N is BASELINE.json configs[1] PER GPU:
+    64 agents, M = 5 segments, 20 LSC neighbours per agent (~20 half-spaces per segment and control point), dim 3,
+    fp64 — produced by a synthetic swarm after 3 warm-up replans.  Weak scaling: every rank owns its
+    own 64-agent swarm, no data-path collective (the QPs of one replan step are independent,
+    reference src/multi_sync_simulator.cpp:354-362).  `--allgather` adds the RCCL all-gather of the solved control
+    points after every step (the device analogue of broadcastMsgs, :305-352) for those who want it in the number.
+  * roofline: algorithmic bytes (20 432 B per QP at this shape) x QPs per launch / the kernel's average
+    launch duration, measured with HIP events on the launch stream over the timed region, against 8.0 TB/s.
+  * cpu_baseline: the CPU oracle (oracle/, a port: CPLEX cannot exist here) on the same batch, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed, style, warm_steps):
+    """Swarm after `warm_steps` replans (carried forward by the HIP solver itself); returns ABI arrays."""
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
+    sol = solver_factory(sw)
+    for _ in range(warm_steps):
+        b = sw.build()
+        hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+        r = sol.solve_host(hdr, rows, off, sfc, want_info=False)
+        if (r["status"] != 0).any():
+            raise RuntimeError("warm-up replan produced non-optimal instances: %s" % np.bincount(r["status"]))
+        sw.advance(r["x"])
+    b = sw.build()
+    return sw, sol, b, api.batch_from_swarm(b, sw.n_obs, M)
+
+
+def to_dev(torch, a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--agents", type=int, default=64, help="agents per GPU per step (BASELINE configs[1]: 64)")
+    ap.add_argument("--segments", type=int, default=5)
+    ap.add_argument("--obs", type=int, default=20)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--style", default="forest")
+    ap.add_argument("--allgather", action="store_true", help="all-gather solved trajectories over RCCL every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from lsc_dr_planner_amd import api, synth
+
+    M, dim, n_obs, N = args.segments, args.dim, args.obs, args.agents
+
+    def solver_factory(sw):
+        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+
+    sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed=1000 + rank,
+                                                       style=args.style, warm_steps=3)
+    n_obs_eff = sw.n_obs
+    nv = sol.nv
+    d_hdr, d_rows, d_off, d_sfc = (to_dev(torch, a, dev) for a in (hdr, rows, off, sfc))
+    d_x = torch.zeros(N * nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
+    d_all = torch.zeros(world * N * nv, dtype=torch.float64, device=dev) if (args.allgather and world > 1) else None
+
+    def step():
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+        if d_all is not None:
+            dist.all_gather_into_tensor(d_all, d_x)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the launch stream
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    status = d_st.cpu().numpy()
+    iters = d_info.cpu().numpy().view(api.INFO_DTYPE)["iterations"]
+    n_bad = int((status != 0).sum())
+    if dist is not None:
+        tb = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb)
+        n_bad = int(tb[0])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- single-launch latency distribution (enqueue -> results readable), device-resident inputs ----------
+    lat = []
+    for _ in range(300):
+        a = time.perf_counter()
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - a)
+    lat = np.array(lat[50:]) * 1e3
+    # batch-of-1 latency (the unchanged sequential simulator loop, src/multi_sync_simulator.cpp:357-362)
+    lat1 = []
+    for _ in range(200):
+        a = time.perf_counter()
+        sol.solve_device(1, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+        torch.cuda.synchronize()
+        lat1.append(time.perf_counter() - a)
+    lat1 = np.array(lat1[50:]) * 1e3
+    sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+    torch.cuda.synchronize()
+
+    bytes_per_qp = sol.algorithmic_bytes(n_obs_eff)
+    achieved = bytes_per_qp * N / (kernel_ms * 1e-3)
+    out = {
+        "metric": "qp_solves_per_sec",
+        "value": world * N * args.steps / elapsed,
+        "unit": "QP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
+                        "fp64 batched PDIP, one wavefront per QP" % (N, M, n_obs_eff, dim, args.style),
+            "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
+            "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None),
+            "parallelism": "agents sharded over %d GPU(s), no data-path collective" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": None,
+            "kernel": "lscqp_pdip_kernel<%d,%d,true>" % (M, dim), "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N,
+        },
+        "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
+                       "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99))},
+        "solver": {"non_optimal": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
+    }
+
+    # ---- CPU baseline: the oracle port on the same batch, all host cores --------------------------------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+
+        cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+        ag = np.zeros(N, O.AGENT_DTYPE)
+        for f in ("p0", "v0", "a0", "goal", "next_waypoint"):
+            ag[f] = build[f]
+        ag["vmax"], ag["amax"], ag["radius"], ag["nominal_velocity"], ag["n_obs"] = 1.0, 2.0, 0.15, 1.0, n_obs_eff
+        lsc = np.ascontiguousarray(build["lsc"]).reshape(-1)
+        loff = np.arange(N) * n_obs_eff * M * 6
+        sfc_o = np.ascontiguousarray(build["sfc"]).reshape(-1)
+        cores = os.cpu_count() or 1
+        O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)  # warm
+        reps, tcpu, R = 0, 0.0, None
+        a = time.perf_counter()
+        while tcpu < 3.0 and reps < 50:
+            R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)
+            reps += 1
+            tcpu = time.perf_counter() - a
+        a1 = time.perf_counter()
+        R1 = O.solve_batch(cls, ag[:16], lsc, loff[:16], sfc_o, threads=1)
+        t1c = time.perf_counter() - a1
+        xg = d_x.cpu().numpy().reshape(N, nv)
+        og = d_obj.cpu().numpy()
+        ok = (R["status"] == 0) & (status == 0)
+        out["cpu_baseline"] = {
+            "value": N * reps / tcpu, "unit": "QP/s", "cores": cores, "kind": "port",
+            "sample": "the same %d-QP batch solved %d times by oracle/lscqp_oracle.c (dense fp64 PDIP, OpenMP over "
+                      "agents, %.1f s); single core: %.1f QP/s" % (N, reps, tcpu, 16 / t1c),
+            "single_core_value": 16 / t1c,
+            "reference_published": "CPLEX 20.1, 6 threads: 4.58-6.64 ms/QP (151-218 QP/s) at M=10 dim=2 <=9 neighbours "
+                                   "(reference log/summary_LSC_10agents.csv)",
+        }
+        out["parity"] = {
+            "max_abs_dx": float(np.abs(xg - R["x"])[ok].max()),
+            "max_rel_dobj": float((np.abs(og - R["obj"]) / np.maximum(1.0, np.abs(R["obj"])))[ok].max()),
+            "compared": int(ok.sum()),
+        }
+
+    # ---- informational: throughput vs batch size on this GPU (not the headline) -------------------------------
+    if world == 1 and not args.no_extra:
+        extra = []
+        for nb in (512, 4096):
+            try:
+                sw2, sol2, _, (h2, r2, o2, s2) = make_batch(api, synth, solver_factory, nb, M, dim, n_obs, seed=2000 + nb,
+                                                            style=args.style, warm_steps=3)
+                dh, dr, do, ds = (to_dev(torch, a, dev) for a in (h2, r2, o2, s2))
+                dx = torch.zeros(nb * nv, dtype=torch.float64, device=dev)
+                dob = torch.zeros(nb, dtype=torch.float64, device=dev)
+                dst = torch.zeros(nb, dtype=torch.int32, device=dev)
+                for _ in range(3):
+                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reps = 20
+                for _ in range(reps):
+                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                bq = sol2.algorithmic_bytes(sw2.n_obs)
+                extra.append({"agents": nb, "kernel_ms": ms, "qp_per_s": nb / (ms * 1e-3),
+                              "hbm_frac": bq * nb / (ms * 1e-3) / HBM_PEAK, "non_optimal": int((dst.cpu().numpy() != 0).sum())})
+            except Exception as ex:  # informational only
+                extra.append({"agents": nb, "error": str(ex)[:200]})
+        out["extra_batch_sweep"] = extra
+
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

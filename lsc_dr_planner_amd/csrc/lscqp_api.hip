@@ -87,7 +87,18 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.w_t = d->terminal_weight;
     c.comm_range = d->communication_range;
     const double sc = std::pow(d->dt, -5.0);
-    for (int i = 0; i < 36; i++) c.Q2[i] = 2.0 * d->control_input_weight * kQInt[i] * sc;
+    const long double scl = 1.0L / ((long double)d->dt * d->dt * d->dt * d->dt * d->dt);
+    for (int i = 0; i < 36; i++) {
+        const double q_ref = kQInt[i] * sc;  // what Eigen computes: exact integer times the rounded pow(dt,-5)
+        c.Q2[i] = 2.0 * d->control_input_weight * q_ref;
+        // the reference's objective coefficient is fl(w_c * fl(int * pow(dt,-5))) (src/traj_optimizer.cpp:294);
+        // dQ holds its deviation from the exact product, per unit w_c, so that obj = exact + w_c * c' dQ c
+        const double p_ref = d->control_input_weight * q_ref;
+        c.dQ[i] = d->control_input_weight != 0
+                      ? (double)(((long double)p_ref - (long double)d->control_input_weight * kQInt[i] * scl) /
+                                 (long double)d->control_input_weight)
+                      : 0.0;
+    }
     for (int k = 0; k < 3; k++) {
         c.world_min[k] = d->world_min[k];
         c.world_max[k] = d->world_max[k];

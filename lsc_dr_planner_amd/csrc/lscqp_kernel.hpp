@@ -28,6 +28,9 @@ struct DevClass {
     double dt, w_c, w_t, comm_range;
     double world_min[3], world_max[3];
     double Q2[36];  // 2 * w_c * Q_base (closed form of src/traj_optimizer.cpp:163-178)
+    double dQ[36];  // Q_base as the reference rounds it (integer matrix * pow(dt,-5), per entry, in double)
+                    // minus the exact product: restores the reference model's tiny non-translation-invariance
+                    // in the reported objective
     double tol;
     int max_iter;
     int use_sfc;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     // objective exactly as cplex.getObjValue() reports it (src/traj_optimizer.cpp:100): jerk cost
     //   x'(w_c Q)x == w_c * 3600 dt^-5 * sum_seg (D3 c)' MB (D3 c)   (third differences: no cancellation)
     // plus the terminal cost including its constant goal^2 term (:301-316).  Translation invariant.
-    auto objective = [&]() -> double {
+    auto objective = [&](bool ref_rounding) -> double {
         double part = 0;
         if (lane < DIM * M) {
             const int k = lane / M, m = lane % M;
@@ -348,6 +351,17 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
             const double dt2 = dt * dt;
             part = cls.w_c * 3600.0 / (dt2 * dt2 * dt) * quad;
+            if (ref_rounding) {  // world-frame correction, O(1e-9): negligible rounding of its own
+                double corr = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    double r = 0;
+#pragma unroll
+                    for (int ip = 0; ip < 6; ip++) r += cls.dQ[i * 6 + ip] * (cc[ip] + org[k]);
+                    corr += r * (cc[i] + org[k]);
+                }
+                part += cls.w_c * corr;
+            }
             if (m >= M - ts) {
                 const double dgoal = cc[5] - goal[k];
                 part += cls.w_t * dgoal * dgoal;
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             const double gls = fmax(1.0, wave_max(fmax(fabs(gcost), fabs(gl))));
             res_p = max_rp;
             res_d = rdn / gls;
-            const double objcur = objective();
+            const double objcur = objective(false);
             res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objcur));
             // stop: primal residual (metres), scaled stationarity, and duality gap + multiplier-weighted primal
             // residual in objective units (the latter is what bounds the objective error to first order)
@@ -810,7 +824,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     if (status == LSCQP_STATUS_NUMERIC && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
 
     // ---- epilogue: objective, control points back in the world frame ---------------------------------------
-    const double obj = objective();
+    const double obj = objective(true);
     for (int e = lane; e < NX; e += 64) x_out[q * NX + e] = c_[e] + org[e / P];
     if (lane == 0) {
         obj_out[q] = obj;

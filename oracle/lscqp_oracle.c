@@ -453,7 +453,7 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         s[i] = si > 1.0 ? si : 1.0;
         lam[i] = 1.0;
     }
-    int stall = 0;
+    int stall = 0, near_opt = 0;
     for (it = 0; it < max_iter; it++) {
         /* residuals */
         double mu = 0, rpn = 0, rdn = 0, pinf = 0;
@@ -484,6 +484,9 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
             status = 0;
             break;
         }
+        /* "converged to working precision": every criterion within 100x of its target.  Remembered so that a later
+         * factorisation failure or a stalled step (W = lam/s spans > 1e20 by then) still reports the optimum. */
+        near_opt = (rpn <= 100 * tol * hscale && rdn <= 1000 * tol * gls && mu * m + pinf <= 100 * tol * (1.0 + fabs(objv)));
         /* K = H + G' W G */
         memcpy(K, H, sizeof(double) * nz * nz);
         for (int i = 0; i < m; i++) {
@@ -499,7 +502,7 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         for (int a = 0; a < nz; a++)
             for (int b = a + 1; b < nz; b++) K[a * nz + b] = K[b * nz + a];
         if (chol_factor(nz, K) != 0) {
-            status = 3;
+            status = near_opt ? 0 : 3;
             break;
         }
         /* affine: rc = s*lam */
@@ -550,12 +553,13 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         }
         if (alpha < 1e-10) {
             if (++stall >= 3) {
-                status = (rpn > 1e-6 * hscale) ? 1 : 3;
+                status = near_opt ? 0 : (rpn > 1e-6 * hscale) ? 1 : 3;
                 break;
             }
         } else
             stall = 0;
     }
+    if (status == 2 && near_opt) status = 0;
     if (status == 2) {
         /* iteration limit: classify as infeasible when the primal residual never closed */
         double rpn = 0;
@@ -594,6 +598,8 @@ int orc_solve(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const 
     /* Solve in coordinates translated by p0 (x = x' + t): the same problem, but every quantity is O(1 m),
      * which keeps the rounding floor of the stationarity residual low.  Undone before returning. */
     double* tsh = (double*)malloc(sizeof(double) * nv);
+    double* q_orig = (double*)malloc(sizeof(double) * nv); /* untranslated linear term, for the reported objective */
+    memcpy(q_orig, q, sizeof(double) * nv);
     {
         int Pn = c->M * (c->n + 1);
         for (int i = 0; i < nv; i++) tsh[i] = a->p0[i / Pn];
@@ -718,13 +724,10 @@ int orc_solve(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const 
      * and would add ~1e-9 of pure rounding noise to the value the parity tests compare against. */
     long double ov = r;
     for (int i = 0; i < nv; i++) {
-        long double s = 0, s2 = 0;
+        long double s = 0;
         for (int l = 0; l < nv; l++)
-            if (P[i * nv + l] != 0) {
-                s += (long double)P[i * nv + l] * x[l];
-                s2 += 2 * (long double)P[i * nv + l] * tsh[l];
-            }
-        ov += (long double)x[i] * (s + ((long double)q[i] - s2));
+            if (P[i * nv + l] != 0) s += (long double)P[i * nv + l] * x[l];
+        ov += (long double)x[i] * (s + (long double)q_orig[i]);
     }
     if (obj) *obj = (double)ov;
     if (lam) memcpy(lam, lall, sizeof(double) * mi);
@@ -761,7 +764,7 @@ int orc_solve(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const 
 #undef NMAT
     free(P); free(q); free(Aeq); free(beq); free(G); free(h); free(lb); free(ub);
     free(Q); free(R); free(u); free(xp); free(PN); free(Hz); free(gx); free(gz);
-    free(Gz); free(hz); free(bvar); free(bsgn); free(z0); free(z); free(lall); free(tsh);
+    free(Gz); free(hz); free(bvar); free(bsgn); free(z0); free(z); free(lall); free(tsh); free(q_orig);
     return status;
 }
 

@@ -1,0 +1,100 @@
+"""Shared helpers of the parity tests: fixture/ swarm -> oracle inputs and -> C-ABI inputs (same numbers)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return json.load(open(os.path.join(GOLDEN, name + ".json")))
+
+
+def oracle_class(O, p, use_sfc=None):
+    return O.make_class(M=p["M"], dim=p["dim"], dt=p["dt"], w_c=p["w_c"], w_t=p["w_t"], comm_range=p["comm_range"],
+                        planner_lsc=(p.get("planner_mode", "LSC") == "LSC"),
+                        use_sfc=p.get("use_sfc", True) if use_sfc is None else use_sfc,
+                        world_min=p["world_min"], world_max=p["world_max"])
+
+
+def abi_desc(A, p, use_sfc=None, **kw):
+    return A.make_desc(M=p["M"], dim=p["dim"], dt=p["dt"], w_c=p["w_c"], w_t=p["w_t"], comm_range=p["comm_range"],
+                       planner_mode=A.PLANNER_LSC if p.get("planner_mode", "LSC") == "LSC" else A.PLANNER_DLSC,
+                       use_sfc=p.get("use_sfc", True) if use_sfc is None else use_sfc,
+                       world_min=p["world_min"], world_max=p["world_max"], **kw)
+
+
+def golden_case_arrays(O, p, c):
+    """One scipy_* case -> (oracle agent, lsc LSC_DTYPE[n_obs,M,6], sfc BOX_DTYPE[M])."""
+    M = p["M"]
+    lsc = np.zeros((p["n_obs"], M, 6), O.LSC_DTYPE)
+    lsc["p"], lsc["nrm"], lsc["d"] = np.array(c["lsc_p"]), np.array(c["lsc_nrm"]), np.array(c["lsc_d"])
+    sfc = np.zeros(M, O.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = np.array(c["sfc_min"]), np.array(c["sfc_max"])
+    ag = O.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal"], next_waypoint=c["next_waypoint"],
+                      vmax=p["vmax"], amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"],
+                      n_obs=p["n_obs"])
+    return ag, lsc, sfc
+
+
+def abi_batch(A, O, cls, agents, lsc_list, sfc_list, M):
+    """Lists of per-agent oracle inputs -> ABI arrays. lsc_list[q]: LSC_DTYPE[n_obs_q, M, 6] or None."""
+    n = len(agents)
+    hdr = np.zeros(n, A.HEADER_DTYPE)
+    rows, off = [], [0]
+    for q, ag in enumerate(agents):
+        for f in ("p0", "v0", "a0", "goal", "next_waypoint", "vmax", "amax", "radius", "nominal_velocity"):
+            hdr[f][q] = ag[f]
+        nob = 0 if lsc_list[q] is None else lsc_list[q].shape[0]
+        hdr["n_obs"][q] = nob
+        hdr["terminal_segments"][q] = O.terminal_segments(cls, ag)
+        if nob:
+            rows.append(A.pack_rows(lsc_list[q]).reshape(-1))
+        off.append(off[-1] + nob * M * 6)
+    rows = np.concatenate(rows) if rows else np.zeros(1, A.ROW_DTYPE)
+    sfc = None
+    if sfc_list is not None:
+        sfc = np.zeros((n, M), A.BOX_DTYPE)
+        for q in range(n):
+            sfc["bmin"][q], sfc["bmax"][q] = sfc_list[q]["bmin"], sfc_list[q]["bmax"]
+    return hdr, rows, np.array(off, dtype=np.uint64), sfc
+
+
+def swarm_oracle_inputs(O, sw, b):
+    N = sw.N
+    ag = np.zeros(N, O.AGENT_DTYPE)
+    for f in ("p0", "v0", "a0", "goal", "next_waypoint"):
+        ag[f] = b[f]
+    ag["vmax"], ag["amax"], ag["radius"], ag["nominal_velocity"], ag["n_obs"] = sw.vmax, sw.amax, sw.radius, sw.nominal_velocity, sw.n_obs
+    lsc = np.ascontiguousarray(b["lsc"]).reshape(-1)
+    off = np.arange(N) * sw.n_obs * sw.M * 6
+    sfc = np.ascontiguousarray(b["sfc"]).reshape(-1)
+    return ag, lsc, off, sfc
+
+
+def kkt_from_primal(O, cls, ag, lsc, sfc, x, act_tol=1e-7):
+    """KKT residuals of a primal point on the reference's row-for-row model: multipliers by non-negative least
+    squares on the rows active at x (stationarity 2Px+q + Aeq'y + Ga'lam = 0, lam >= 0).
+    Returns (stationarity scaled by 1+|grad f|_inf, eq violation, ineq violation)."""
+    from scipy.optimize import nnls
+
+    A = O.assemble(cls, ag, lsc, sfc)
+    P, q, Aeq, beq, G, h, lb, ub = [A[k] for k in ("P", "q", "Aeq", "beq", "G", "h", "lb", "ub")]
+    nv = len(q)
+    g = 2 * P @ x + q
+    rows = [G[i] for i in np.where(G @ x - h > -act_tol)[0]]
+    for l in range(nv):
+        if np.isfinite(lb[l]) and x[l] - lb[l] < act_tol:
+            e = np.zeros(nv); e[l] = -1; rows.append(e)
+        if np.isfinite(ub[l]) and ub[l] - x[l] < act_tol:
+            e = np.zeros(nv); e[l] = 1; rows.append(e)
+    Ga = np.array(rows).reshape(-1, nv)
+    # unknowns: y+ , y- (free equality multipliers split), lam >= 0
+    B = np.concatenate([Aeq.T, -Aeq.T, Ga.T], axis=1)
+    sc = 1.0 + np.abs(g).max()
+    sol, rn = nnls(B / sc, -g / sc, maxiter=20 * B.shape[1])
+    stat = np.abs(B @ sol + g).max() / sc
+    eqv = np.abs(Aeq @ x - beq).max()
+    iqv = max((G @ x - h).max() if len(h) else 0.0, (lb - x).max(), (x - ub).max(), 0.0)
+    return stat, eqv, iqv

@@ -1,0 +1,62 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU path: contiguous agent blocks + all-gather of solved trajectories.
+The per-rank solver is stubbed by the CPU oracle here; on GPUs it is lscqp_solve_batch_device (bench.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, N, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lsc_dr_planner_amd import sharding, synth
+    from oracle import oracle as O
+    from tests import helpers as H
+
+    M, dim = 5, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=4, seed=5)      # every rank builds the same swarm, solves its block
+    cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    b = sw.build()
+    ag, lsc, off, sfc = H.swarm_oracle_inputs(O, sw, b)
+    lo, hi = sharding.shard_range(N, world, rank)
+    R = O.solve_batch(cls, ag[lo:hi], lsc, off[lo:hi], sfc[lo * M:], threads=1)
+    x_all = sharding.allgather_trajectories(torch.from_numpy(R["x"]), N)
+    np.save(os.path.join(out_dir, "x_%d.npy" % rank), x_all.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges():
+    from lsc_dr_planner_amd import sharding
+
+    for N in (1, 7, 8, 10, 64, 4096):
+        for G in (1, 2, 4, 8):
+            blocks = [sharding.shard_range(N, G, r) for r in range(G)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == N
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(G - 1))
+            assert max(h - l for l, h in blocks) == -(-N // G)
+
+
+def test_two_rank_gloo_allgather(tmp_path, oracle):
+    N = 7  # ragged: blocks of 4 and 3
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, N, str(tmp_path)), nprocs=2, join=True)
+    x0, x1 = np.load(tmp_path / "x_0.npy"), np.load(tmp_path / "x_1.npy")
+    assert x0.shape == (N, 90) and np.array_equal(x0, x1)
+    # equals the single-process solve of the whole batch
+    sys.path.insert(0, ROOT)
+    from lsc_dr_planner_amd import synth
+    from tests import helpers as H
+
+    sw = synth.Swarm(N, M=5, dim=3, n_obs=4, seed=5)
+    cls = oracle.make_class(M=5, dim=3, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, sw.build())
+    R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=2)
+    assert np.array_equal(R["x"], x0)

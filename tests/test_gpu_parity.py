@@ -1,0 +1,283 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same inputs,
+against the committed golden fixtures, and - at BASELINE.json's full sizes - through size-independent properties.
+
+Tolerances (fp64, stated by north_star as <= 1e-8):
+  objective     |obj_gpu - obj_oracle| <= 1e-8 * max(1, |obj|)
+  KKT           scaled stationarity, equality and inequality violation of the GPU point on the reference's own
+                row-for-row model <= 1e-8
+  control points (the optimum is unique)  max |dx| <= 1e-6 m   (float32 output precision of the reference is ~1e-7 m)
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+OBJ_TOL = 1e-8
+KKT_TOL = 1e-8
+X_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _check_against_oracle(O, cls, G, R, sel=None):
+    ok = (R["status"] == 0)
+    assert ok.all(), "oracle failed on %s" % np.where(~ok)[0]
+    assert (G["status"] == 0).all(), "gpu status %s" % np.bincount(G["status"], minlength=4)
+    dx = np.abs(G["x"] - R["x"]).max()
+    do = (np.abs(G["obj"] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))).max()
+    assert dx <= X_TOL, dx
+    assert do <= OBJ_TOL, do
+    return dx, do
+
+
+@pytest.mark.parametrize("N,M,dim,n_obs,style,seed,steps", [
+    (64, 5, 3, 20, "forest", 1, 3),    # BASELINE configs[1]
+    (10, 10, 2, 9, "forest", 2, 3),    # forest10 replica (reference launch files: M=10, dim=2)
+    (10, 5, 2, 9, "forest", 5, 2),     # forest10 with the M=5 default of src/param.cpp:71
+    (48, 6, 3, 20, "maze", 3, 3),      # dense-maze set, M=6 (configs[2] shape, fewer agents)
+    (24, 3, 3, 10, "forest", 4, 2),
+    (20, 7, 3, 12, "maze", 6, 2),      # largest dim-3 horizon of the lane-per-row kernel (nz = 57)
+])
+def test_swarm_parity(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed, steps):
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    for step in range(steps + 1):
+        b = sw.build()
+        ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, b)
+        R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=8)
+        hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+        hdr["terminal_segments"] = [oracle.terminal_segments(cls, ag[q:q + 1]) for q in range(N)]
+        G = sol.solve_host(hdr, rows, roff, sfcp)
+        _check_against_oracle(oracle, cls, G, R)
+        # KKT residuals of the GPU point on the reference's row-for-row model (a few agents per step)
+        for q in range(0, N, max(1, N // 4)):
+            lq = np.ascontiguousarray(b["lsc"][q]); sq = np.ascontiguousarray(b["sfc"][q])
+            stat, eqv, iqv = H.kkt_from_primal(oracle, cls, ag[q:q + 1], lq, sq, G["x"][q])
+            assert stat <= KKT_TOL and eqv <= KKT_TOL and iqv <= KKT_TOL, (step, q, stat, eqv, iqv)
+        assert G["info"]["res_primal"].max() <= 1e-9 and G["info"]["res_dual"].max() <= 1e-8
+        sw.advance(G["x"])  # the swarm is carried forward by the GPU solution
+
+
+@pytest.mark.parametrize("name", ["scipy_m5d3", "scipy_m10d2", "scipy_m6d3_maze"])
+def test_golden_fixtures(api, oracle, torch_cuda, name):
+    g = H.load_golden(name)
+    p = g["params"]
+    cls = H.oracle_class(oracle, p)
+    sol = api.Solver(H.abi_desc(api, p))
+    ags, lscs, sfcs = zip(*[H.golden_case_arrays(oracle, p, c) for c in g["cases"]])
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, lscs, sfcs, p["M"])
+    G = sol.solve_host(hdr, rows, off, sfc)
+    assert (G["status"] == 0).all()
+    for q, c in enumerate(g["cases"]):
+        assert np.abs(G["x"][q] - np.array(c["x"])).max() < 1e-7       # 80-bit polished optimum
+        assert np.abs(G["x"][q] - np.array(c["scipy_x"])).max() < 1e-5  # raw scipy trust-constr iterate
+        assert abs(G["obj"][q] - c["obj"]) <= OBJ_TOL * max(1.0, abs(c["obj"]))
+
+
+def test_reference_log_known_answers(api, oracle, torch_cuda):
+    """First replan of forest10_10 from the reference's own result log, solved on the GPU."""
+    g = H.load_golden("kat_log")
+    p = g["params"]
+    for case in g["cases"]:
+        use_sfc = case["sfc"] is not None
+        cls = H.oracle_class(oracle, p, use_sfc=use_sfc)
+        sol = api.Solver(H.abi_desc(api, p, use_sfc=use_sfc))
+        ag = oracle.make_agent(p0=case["p0"], goal=case["goal"], next_waypoint=case["next_waypoint"], vmax=p["vmax"],
+                               amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"])
+        sfcs = None
+        if use_sfc:
+            s = np.zeros(p["M"], oracle.BOX_DTYPE)
+            s["bmin"], s["bmax"] = case["sfc"]["bmin"], case["sfc"]["bmax"]
+            sfcs = [s]
+        hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, [ag], [None], sfcs, p["M"])
+        G = sol.solve_host(hdr, None, None, sfc)
+        assert G["status"][0] == 0
+        for st in g["agents"][case["agent"]]["states"][1:]:
+            pos, vel, acc = oracle.state_at(cls, G["x"][0], st["t"])
+            assert np.allclose(pos, st["p"][:2], rtol=0, atol=2e-5)
+            assert np.allclose(vel, st["v"][:2], rtol=1e-4, atol=2e-6)
+            assert np.allclose(acc, st["a"][:2], rtol=3e-4, atol=2e-5)
+
+
+def test_edge_cases(api, oracle, torch_cuda):
+    """No obstacles, ragged obstacle counts, zero normals, DLSC mode (no end stop), no SFC, no comm range."""
+    from lsc_dr_planner_amd import synth
+
+    M, dim, N = 5, 3, 12
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=8, seed=9)
+    b = sw.build()
+    x0 = None
+    for variant in ("ragged", "zero_normals", "dlsc", "no_sfc", "no_comm"):
+        planner_lsc = variant != "dlsc"
+        use_sfc = variant != "no_sfc"
+        comm = 0.0 if variant == "no_comm" else 3.0
+        cls = oracle.make_class(M=M, dim=dim, use_sfc=use_sfc, planner_lsc=planner_lsc, comm_range=comm,
+                                world_min=sw.world_min, world_max=sw.world_max)
+        sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=use_sfc, comm_range=comm,
+                                       planner_mode=api.PLANNER_LSC if planner_lsc else api.PLANNER_DLSC,
+                                       world_min=sw.world_min, world_max=sw.world_max))
+        ags, lscs, sfcs = [], [], []
+        for q in range(N):
+            nob = (q % 9) if variant == "ragged" else 8      # includes n_obs == 0
+            lq = np.ascontiguousarray(b["lsc"][q][:nob]).copy() if nob else None
+            if variant == "zero_normals" and lq is not None:
+                lq["nrm"][q % nob, :, :] = 0.0                # dropped by the ||n|| < 1e-5 rule
+                lq["nrm"][(q + 1) % nob, 2, 3] = (3e-6, 0, 0)
+            ags.append(oracle.make_agent(p0=b["p0"][q], v0=b["v0"][q], a0=b["a0"][q], goal=b["goal"][q],
+                                         next_waypoint=b["next_waypoint"][q], n_obs=nob))
+            lscs.append(lq)
+            sfcs.append(np.ascontiguousarray(b["sfc"][q]))
+        hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, lscs, sfcs if use_sfc else None, M)
+        G = sol.solve_host(hdr, rows, off, sfc)
+        assert (G["status"] == 0).all(), (variant, G["status"])
+        for q in range(N):
+            r = oracle.solve(cls, ags[q], lscs[q], sfcs[q] if use_sfc else None)
+            assert r["status"] == 0
+            assert np.abs(G["x"][q] - r["x"]).max() <= X_TOL, (variant, q)
+            assert abs(G["obj"][q] - r["obj"]) <= OBJ_TOL * max(1, abs(r["obj"])), (variant, q)
+
+
+def test_infeasible_instances_are_reported(api, oracle, torch_cuda):
+    """Status per instance; the shim turns != OPTIMAL into `throw PlanningReport::QPFAILED`
+    (src/traj_optimizer.cpp:143) and the caller falls back to initial_traj (src/traj_planner.cpp:767-797)."""
+    from lsc_dr_planner_amd import synth
+
+    M, dim, N = 5, 3, 16
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=6, seed=21)
+    b = sw.build()
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    ags, lscs, sfcs = [], [], []
+    bad = {3: "lsc", 7: "box", 11: "lsc_pair"}
+    for q in range(N):
+        lq = np.ascontiguousarray(b["lsc"][q]).copy()
+        sq = np.ascontiguousarray(b["sfc"][q]).copy()
+        if bad.get(q) == "lsc":
+            lq["d"][0] += 100.0                                 # half-space far outside the world box
+        if bad.get(q) == "box":
+            sq["bmin"][2] = sq["bmax"][2] + 0.5                  # empty SFC box on one segment
+        if bad.get(q) == "lsc_pair":
+            lq["nrm"][1] = -lq["nrm"][0]; lq["p"][1] = lq["p"][0]; lq["d"][1] = 0.2; lq["d"][0] = 0.2  # opposing slabs
+        ags.append(oracle.make_agent(p0=b["p0"][q], goal=b["goal"][q], next_waypoint=b["next_waypoint"][q], n_obs=6))
+        lscs.append(lq); sfcs.append(sq)
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, lscs, sfcs, M)
+    G = sol.solve_host(hdr, rows, off, sfc)
+    for q in range(N):
+        if q in bad:
+            assert G["status"][q] != 0, (q, bad[q], G["info"][q])
+            assert oracle.solve(cls, ags[q], lscs[q], sfcs[q], max_iter=100)["status"] != 0
+        else:
+            assert G["status"][q] == 0, (q, G["info"][q])
+
+
+def test_device_resident_path_and_batch_of_one(api, oracle, torch_cuda):
+    torch = torch_cuda
+    from lsc_dr_planner_amd import synth
+
+    M, dim, N = 5, 3, 32
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=12, seed=33)
+    b = sw.build()
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+    ref = sol.solve_host(hdr, rows, off, sfc)
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (hdr, rows, off, sfc)]
+    d_x = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        sol.solve_device(N, sw.n_obs, t[0], t[1], t[2], t[3], d_x, d_obj, d_st, None)
+    stream.synchronize()
+    assert (d_st.cpu().numpy() == 0).all()
+    # deterministic: bitwise equal to the host-pointer path (same kernel, same inputs)
+    assert np.array_equal(d_x.cpu().numpy().reshape(N, -1), ref["x"])
+    assert np.array_equal(d_obj.cpu().numpy(), ref["obj"])
+    # batch of one == the sequential loop of the unchanged simulator (src/multi_sync_simulator.cpp:357-362)
+    for q in (0, 5, N - 1):
+        lo, hi = int(off[q]), int(off[q + 1])
+        one = sol.solve_host(hdr[q:q + 1], rows[lo:hi], np.array([0, hi - lo], dtype=np.uint64), sfc[q:q + 1])
+        assert np.array_equal(one["x"][0], ref["x"][q])
+
+
+@pytest.mark.parametrize("N,M,dim,n_obs,style", [(512, 6, 3, 20, "maze"), (4096, 5, 3, 20, "forest")])
+def test_full_size_properties(api, oracle, torch_cuda, N, M, dim, n_obs, style):
+    """BASELINE configs[2] / configs[4] shapes (per GPU): properties that do not need the oracle on every instance."""
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=100 + N, style=style)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    for step in range(2):
+        b = sw.build()
+        hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+        G = sol.solve_host(hdr, rows, off, sfc)
+        assert (G["status"] == 0).all(), np.bincount(G["status"], minlength=4)
+        assert G["info"]["res_primal"].max() <= 1e-9 and G["info"]["res_dual"].max() <= 1e-8 and G["info"]["gap"].max() <= 1e-9
+        x = G["x"].reshape(N, dim, M, 6)
+        # 1. eliminated equalities hold: initial state, C0/C1/C2 joins, end stop (src/traj_optimizer.cpp:318-368,502-511)
+        assert np.abs(x[:, :, 0, 0] - b["p0"][:, :dim]).max() < 1e-12
+        assert np.abs((x[:, :, 0, 1] - x[:, :, 0, 0]) * 25 - b["v0"][:, :dim]).max() < 1e-9
+        assert np.abs(x[:, :, 1:, 0] - x[:, :, :-1, 5]).max() < 1e-12
+        assert np.abs((x[:, :, 1:, 1] - x[:, :, 1:, 0]) - (x[:, :, :-1, 5] - x[:, :, :-1, 4])).max() < 1e-12
+        assert np.abs(x[:, :, -1, 5] - x[:, :, -1, 3]).max() < 1e-12
+        # 2. every inequality of the reference model holds (vectorised restatement of the row families)
+        v = np.abs(np.diff(x, axis=3)) * 25
+        assert (v[:, :, 1:] <= 1 + 1e-8).all() and (v[:, :, 0, 2:] <= 1 + 1e-8).all()
+        a = np.abs(np.diff(x, 2, axis=3)) * 500
+        assert (a[:, :, 1:] <= 2 + 1e-7).all() and (a[:, :, 0, 1:] <= 2 + 1e-7).all()
+        cp = x.transpose(0, 2, 3, 1)                                            # (N, M, 6, dim)
+        lsc = b["lsc"]
+        marg = ((cp[:, None, :, :, :] - lsc["p"][..., :dim]) * lsc["nrm"][..., :dim]).sum(-1) - lsc["d"]
+        marg[:, :, 0, :3] = 1.0
+        assert marg.min() >= -1e-8
+        assert (cp >= b["sfc"]["bmin"][:, :, None, :dim] - 1e-8).all() and (cp <= b["sfc"]["bmax"][:, :, None, :dim] + 1e-8).all()
+        # 3. determinism and permutation equivariance of the batch
+        perm = np.random.default_rng(step).permutation(N)
+        rows2 = rows.reshape(N, -1)[perm].reshape(-1)
+        G2 = sol.solve_host(hdr[perm], rows2, off, sfc[perm])
+        assert np.array_equal(G2["x"], G["x"][perm]) and np.array_equal(G2["obj"], G["obj"][perm])
+        # 4. spot parity against the oracle on a bounded sample
+        ag, lsco, loff, sfco = H.swarm_oracle_inputs(oracle, sw, b)
+        for q in range(0, N, N // 16):
+            r = oracle.solve(cls, ag[q:q + 1], np.ascontiguousarray(b["lsc"][q]), np.ascontiguousarray(b["sfc"][q]))
+            assert r["status"] == 0
+            assert np.abs(G["x"][q] - r["x"]).max() <= X_TOL
+            assert abs(G["obj"][q] - r["obj"]) <= OBJ_TOL * max(1, abs(r["obj"]))
+        sw.advance(G["x"])
+
+
+def test_translation_invariance(api, oracle, torch_cuda):
+    """Shifting the whole world shifts the solution and leaves the objective unchanged (to the reference model's
+    own ~1e-9 |x|^2 rounding of Q_base)."""
+    from lsc_dr_planner_amd import synth
+
+    M, dim, N = 5, 3, 16
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=8, seed=77)
+    b = sw.build()
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    G = sol.solve_host(hdr, rows, off, sfc)
+    shift = np.array([3.0, -2.0, 1.0])   # exactly representable
+    hdr2 = hdr.copy()
+    for f in ("p0", "goal", "next_waypoint"):
+        hdr2[f] += shift
+    rows2 = rows.copy()
+    rows2["b"] += rows["nx"] * shift[0] + rows["ny"] * shift[1] + rows["nz"] * shift[2]
+    sfc2 = sfc.copy(); sfc2["bmin"] += shift; sfc2["bmax"] += shift
+    sol2 = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min + shift, world_max=sw.world_max + shift))
+    G2 = sol2.solve_host(hdr2, rows2, off, sfc2)
+    assert (G["status"] == 0).all() and (G2["status"] == 0).all()
+    assert np.abs(G2["x"] - (G["x"] + np.repeat(shift, M * 6))).max() < 1e-9
+    assert np.abs(G2["obj"] - G["obj"]).max() < 1e-7

@@ -1,0 +1,157 @@
+"""CPU tests: the oracle (oracle/lscqp_oracle.c) against the reference's own artefacts and independent solutions.
+
+The reference has no tests for the trajectory QP, so the pins are:
+  * structural known answers taken from the reference source (Q_base closed form, A_0/A_T stencils, Bernstein matrix,
+    terminal-segment formula, the row-count table of SURVEY.md §8),
+  * the reference-authored result log (tests/golden/kat_log.json, made by tools/make_golden.py from
+    log/simulation_1663743693.650981_LSC_10agents.csv),
+  * scipy trust-constr + 80-bit active-set solutions of the row-for-row assembled models (tests/golden/scipy_*.json).
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+def test_q_base_closed_form(oracle):
+    # src/traj_optimizer.cpp:163-178 for n=5, phi=3, phi_n=1
+    Q = oracle.q_base(5, 3, 1, 0.2) * 0.2 ** 5
+    ref = np.array([[720, -1800, 1200, 0, 0, -120], [-1800, 4800, -3600, 0, 600, 0], [1200, -3600, 3600, -1200, 0, 0],
+                    [0, 0, -1200, 3600, -3600, 1200], [0, 600, 0, -3600, 4800, -1800], [-120, 0, 0, 1200, -1800, 720]], float)
+    assert np.abs(Q - ref).max() < 1e-8
+    w = np.linalg.eigvalsh(ref)
+    assert (np.abs(w[:3]) < 1e-6).all() and (w[3:] > 1e3).all()  # PSD, rank 3
+
+
+def test_bernstein_matrix(oracle):
+    # include/polynomial.hpp:281-294: B maps Bernstein control points to monomial coefficients
+    B = oracle.bernstein(5)
+    assert B[0].tolist() == [1, -5, 10, -10, 5, -1]
+    assert B[5].tolist() == [0, 0, 0, 0, 0, 1]
+    t = 0.37
+    mono = np.array([t ** j for j in range(6)])
+    from math import comb
+    bern = np.array([comb(5, i) * t ** i * (1 - t) ** (5 - i) for i in range(6)])
+    assert np.allclose(B @ mono, bern)
+
+
+def test_aeq_base(oracle):
+    rc, A = oracle.aeq_base(4, 5, 3, 0.2)
+    assert rc == 0 and A.shape == (6, 24)
+    # C0 row between segments 1 and 2: +x[1][5] - x[2][0]      (src/traj_optimizer.cpp:204-213)
+    r = np.zeros(24); r[11] = 1; r[12] = -1
+    assert np.allclose(A[0], r)
+    # C1 row: n/dt (x[1][5]-x[1][4]) - n/dt (x[2][1]-x[2][0])
+    r = np.zeros(24); r[11] = 25; r[10] = -25; r[13] = -25; r[12] = 25
+    assert np.allclose(A[1], r)
+    rc, _ = oracle.aeq_base(4, 4, 3, 0.2)  # only n=5, phi=3 (std::invalid_argument in the reference)
+    assert rc == -1
+
+
+@pytest.mark.parametrize("M,dim,n_obs,exp", [
+    # SURVEY.md §8 size table: (nv, n_eq, LSC rows, SFC rows, vel, acc, comm)
+    (10, 2, 9, (120, 64, 513, 228, 192, 156, 260)),
+    (5, 3, 20, (90, 51, 540, 162, 138, 114, 120)),
+    (6, 3, 20, (108, 60, 660, 198, 168, 138, 162)),
+    (10, 3, 40, (180, 96, 2280, 342, 288, 234, 390)),
+])
+def test_row_counts(oracle, M, dim, n_obs, exp):
+    cls = oracle.make_class(M=M, dim=dim)
+    ag = oracle.make_agent(p0=(0, 0, 1), goal=(1, 0, 1), n_obs=n_obs)
+    lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+    lsc["nrm"][..., 0] = 1.0
+    s = oracle.count(cls, ag, lsc)
+    assert (s.nv, s.neq, s.n_lsc, s.n_sfc, s.n_vel, s.n_acc, s.n_comm) == exp
+    lsc["nrm"][0, 1, 2] = 0.0  # a zero normal is skipped (src/traj_optimizer.cpp:409-411)
+    s2 = oracle.count(cls, ag, lsc)
+    assert s2.n_lsc == exp[2] - 1 and s2.n_lsc_skipped == 1
+
+
+def test_terminal_segments(oracle):
+    # src/traj_optimizer.cpp:530-538: max(int((M dt - |goal-p|/v_nom + 1e-9)/dt), 1)
+    cls = oracle.make_class(M=10, dim=2)
+    assert oracle.terminal_segments(cls, oracle.make_agent(p0=(4, 0, 0.6), goal=(3.5, 0, 0.6))) == 7
+    assert oracle.terminal_segments(cls, oracle.make_agent(p0=(4, 0, 0.6), goal=(-4, 0, 0.6))) == 1
+    assert oracle.terminal_segments(cls, oracle.make_agent(p0=(4, 0, 0.6), goal=(4, 0, 0.6))) == 10
+    # point3d is float32: |goal-p| = 0.4f = 0.40000000596 > 0.4, so (2.0 - 0.4f + 1e-9)/0.2 = 7.99999997 -> 7,
+    # where exact arithmetic would give 8.  The shim passes this integer to the solver for exactly this reason.
+    assert oracle.terminal_segments(cls, oracle.make_agent(p0=(0, 0, 0), goal=(0.4, 0, 0))) == 7
+    assert oracle.terminal_segments(cls, oracle.make_agent(p0=(0, 0, 0), goal=(0.375, 0, 0))) == 8
+
+
+def test_log_known_answers(oracle):
+    """First replan of forest10_10 as the reference logged it (float32 output, 6 printed digits)."""
+    g = H.load_golden("kat_log")
+    p = g["params"]
+    for case in g["cases"]:
+        cls = H.oracle_class(oracle, p, use_sfc=case["sfc"] is not None)
+        ag = oracle.make_agent(p0=case["p0"], goal=case["goal"], next_waypoint=case["next_waypoint"], vmax=p["vmax"],
+                               amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"])
+        sfc = None
+        if case["sfc"]:
+            sfc = np.zeros(p["M"], oracle.BOX_DTYPE)
+            sfc["bmin"], sfc["bmax"] = case["sfc"]["bmin"], case["sfc"]["bmax"]
+        r = oracle.solve(cls, ag, None, sfc)
+        assert r["status"] == 0
+        log = g["agents"][case["agent"]]["states"]
+        for st in log[1:]:
+            pos, vel, acc = oracle.state_at(cls, r["x"], st["t"])
+            assert np.allclose(pos, st["p"][:2], rtol=0, atol=2e-5), (case["name"], st["t"], pos, st["p"])
+            assert np.allclose(vel, st["v"][:2], rtol=1e-4, atol=2e-6), (case["name"], st["t"], vel, st["v"])
+            assert np.allclose(acc, st["a"][:2], rtol=3e-4, atol=2e-5), (case["name"], st["t"], acc, st["a"])
+        k = oracle.kkt(cls, ag, None, sfc, r["x"], r["y"], r["lam"], r["mu_lb"], r["mu_ub"])
+        assert k["stationarity"] < 1e-9 and k["eq"] < 1e-9 and k["ineq"] < 1e-9 and k["neg_mult"] == 0
+    # symmetric agents share the answer up to sign / axis: agent 5 mirrors agent 0
+    a0, a5 = g["agents"][0]["states"][1], g["agents"][5]["states"][1]
+    assert a0["v"][0] == -a5["v"][0]
+
+
+def test_kat2_needs_the_active_face(oracle):
+    """Without the SFC rows the answer differs by 0.17 % - the KAT exercises an active inequality."""
+    g = H.load_golden("kat_log")
+    p, case = g["params"], g["cases"][1]
+    cls = H.oracle_class(oracle, p, use_sfc=False)
+    ag = oracle.make_agent(p0=case["p0"], goal=case["goal"], next_waypoint=case["next_waypoint"])
+    r = oracle.solve(cls, ag, None, None)
+    _, vel, _ = oracle.state_at(cls, r["x"], 0.1)
+    logged = g["agents"][1]["states"][1]["v"][0]
+    assert abs(vel[0] - logged) / abs(logged) > 1e-3
+
+
+@pytest.mark.parametrize("name", ["scipy_m5d3", "scipy_m10d2", "scipy_m6d3_maze"])
+def test_oracle_vs_scipy_golden(oracle, name):
+    g = H.load_golden(name)
+    p = g["params"]
+    cls = H.oracle_class(oracle, p)
+    for c in g["cases"]:
+        ag, lsc, sfc = H.golden_case_arrays(oracle, p, c)
+        r = oracle.solve(cls, ag, lsc, sfc)
+        assert r["status"] == 0
+        assert np.abs(r["x"] - np.array(c["x"])).max() < 1e-7          # 80-bit polished active-set solution
+        assert np.abs(r["x"] - np.array(c["scipy_x"])).max() < 1e-5    # raw trust-constr iterate
+        assert abs(r["obj"] - c["obj"]) <= 1e-9 * max(1.0, abs(c["obj"]))
+        k = oracle.kkt(cls, ag, lsc, sfc, r["x"], r["y"], r["lam"], r["mu_lb"], r["mu_ub"])
+        assert k["stationarity"] < 1e-9 and k["eq"] < 1e-9 and k["ineq"] < 1e-10 and k["comp"] < 1e-6
+
+
+def test_oracle_detects_infeasible(oracle):
+    cls = oracle.make_class(M=5, dim=3)
+    ag = oracle.make_agent(p0=(0, 0, 1), goal=(0.5, 0, 1), n_obs=1)
+    lsc = np.zeros((1, 5, 6), oracle.LSC_DTYPE)
+    lsc["nrm"][..., 0] = 1.0
+    lsc["d"] = 50.0  # x >= 50 for every control point: outside the world box
+    sfc = np.zeros(5, oracle.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = (-5, -5, 0), (5, 5, 2.5)
+    r = oracle.solve(cls, ag, lsc, sfc, max_iter=100)
+    assert r["status"] != 0
+
+
+def test_objective_includes_constant_terminal_term(oracle):
+    # cost += w_t (x - goal)^2 keeps goal^2 (src/traj_optimizer.cpp:301-316): hovering at the goal costs 0
+    cls = oracle.make_class(M=5, dim=3, use_sfc=False)
+    ag = oracle.make_agent(p0=(1, 2, 1), goal=(1, 2, 1))
+    r = oracle.solve(cls, ag)
+    # not exactly 0: Q_base = integer matrix * pow(dt,-5) rounded per entry, as in the reference, is not exactly
+    # translation invariant (row sums ~1e-9), which leaves ~1e-9 * |x|^2 in the objective
+    assert r["status"] == 0 and abs(r["obj"]) < 1e-8
+    assert np.abs(r["x"].reshape(3, 30) - np.array([1, 2, 1])[:, None]).max() < 1e-6
