@@ -1,0 +1,211 @@
+// Test driver of the C++ shim: exercises the reference's class surface (TrajOptimizer / CollisionConstraints /
+// Trajectory) end to end and prints one JSON object per scenario for tests/test_shim.py.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <traj_optimizer.hpp>
+
+using namespace DynamicPlanning;
+
+static Agent make_agent(point3d p, point3d goal, point3d wp) {
+    Agent a;
+    a.id = 0;
+    a.cid = 1;
+    a.current_state.position = p;
+    a.current_state.velocity = point3d(0, 0, 0);
+    a.current_state.acceleration = point3d(0, 0, 0);
+    a.start_point = p;
+    a.desired_goal_point = goal;
+    a.current_goal_point = goal;
+    a.next_waypoint = wp;
+    a.max_vel = {1.0, 1.0, 1.0};
+    a.max_acc = {2.0, 2.0, 2.0};
+    a.radius = 0.15;
+    a.downwash = 2.0;
+    a.nominal_velocity = 1.0;
+    a.collision_alert = false;
+    return a;
+}
+
+static void print_state(const char* key, const State& s, bool comma) {
+    printf("\"%s\": {\"p\": [%.9g, %.9g, %.9g], \"v\": [%.9g, %.9g, %.9g], \"a\": [%.9g, %.9g, %.9g]}%s", key, s.position.x(),
+           s.position.y(), s.position.z(), s.velocity.x(), s.velocity.y(), s.velocity.z(), s.acceleration.x(),
+           s.acceleration.y(), s.acceleration.z(), comma ? ", " : "");
+}
+
+// forest10_10 first replan, launch/simulation.launch parameters (dim 2, M 10): KAT1 (agent 0) and KAT2 (agent 1)
+static int scenario_kat(bool gpu) {
+    Param param;
+    param.world_dimension = 2;
+    param.M = 10;
+    param.world_z_2d = 0.6;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    for (int kat = 1; kat <= 2; kat++) {
+        param.world_use_octomap = (kat == 2);
+        TrajOptimizer opt(param, mission, B);
+        CollisionConstraints cons(param, mission);
+        cons.initializeLSC(0);
+        Agent a = kat == 1 ? make_agent(point3d(4, 0, 0.6f), point3d(3.5f, 0, 0.6f), point3d(3.5f, 0, 0.6f))
+                           : make_agent(point3d(3, 2.5f, 0.6f), point3d(2.55f, 2.5f, 0.6f), point3d(2.5f, 2.5f, 0.6f));
+        if (kat == 2)
+            for (int m = 0; m < param.M; m++) cons.setSFC(m, Box(point3d(2.55f, -5, 0), point3d(5, 5, 2.5f)));
+        traj_t init(param.M, param.n, param.dt);
+        init.planConstVelTraj(a.current_state.position, point3d(0, 0, 0));
+        if (!gpu) {
+            printf("{\"scenario\": \"kat%d\", \"constructed\": true}\n", kat);
+            continue;
+        }
+        TrajOptResult r = opt.solve(a, cons, init, true);
+        printf("{\"scenario\": \"kat%d\", \"cost\": %.12g, \"iters\": %d, ", kat, r.total_qp_cost, opt.lastIterations());
+        print_state("t0.1", r.desired_traj.getStateAt(0.1), true);
+        print_state("t0.2", r.desired_traj.getStateAt(0.2), true);
+        printf("\"z\": %.9g, \"cp_last\": [%.9g, %.9g]}\n", r.desired_traj[3][2].z(), r.desired_traj.lastPoint().x(), r.desired_traj.lastPoint().y());
+    }
+    return 0;
+}
+
+// one neighbour ahead, dim 3, M 5: prints inputs and the raw fp64 solution so the test can feed the oracle
+static int scenario_pair() {
+    Param param;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    TrajOptimizer opt(param, mission, B);
+    CollisionConstraints cons(param, mission);
+    Agent a = make_agent(point3d(0, 0, 1), point3d(0.5f, 0.1f, 1), point3d(0.5f, 0.1f, 1));
+    a.current_state.velocity = point3d(0.3f, 0.0f, 0.05f);
+    cons.initializeLSC(2);
+    point3d obs0(0.45f, 0.05f, 1.0f), obs1(-0.2f, 0.5f, 1.2f);
+    for (int m = 0; m < param.M; m++) {
+        points_t cps(param.n + 1, obs0);
+        point3d nrm = (a.current_state.position - obs0).normalized();
+        std::vector<double> ds(param.n + 1);
+        for (int i = 0; i <= param.n; i++) ds[i] = 0.5 * (0.3 + (a.current_state.position - obs0).dot(nrm));
+        cons.setLSC(0, m, cps, nrm, ds);
+        cons.setLSC(1, m, obs1, (a.current_state.position - obs1).normalized(), 0.31);
+        cons.setSFC(m, Box(point3d(-0.55f, -0.65f, 0.45f), point3d(0.95f, 0.75f, 1.65f)));
+    }
+    traj_t init(param.M, param.n, param.dt);
+    init.planConstVelTraj(a.current_state.position, a.current_state.velocity);
+    TrajOptResult r = opt.solve(a, cons, init, true);
+    std::vector<double> raw = opt.lastRawSolution();
+    // the same item twice through the additive batch call
+    std::vector<TrajOptimizer::BatchItem> items(2, TrajOptimizer::BatchItem{&a, &cons});
+    std::vector<TrajOptResult> res;
+    std::vector<bool> ok;
+    opt.solveBatch(items, res, ok);
+    bool same = ok[0] && ok[1] && res[0].total_qp_cost == r.total_qp_cost && res[1].total_qp_cost == r.total_qp_cost;
+    printf("{\"scenario\": \"pair\", \"cost\": %.15g, \"batch_same\": %s, \"obs\": [[%.9g, %.9g, %.9g], [%.9g, %.9g, %.9g]], \"nrm\": [",
+           r.total_qp_cost, same ? "true" : "false", obs0.x(), obs0.y(), obs0.z(), obs1.x(), obs1.y(), obs1.z());
+    for (int oi = 0; oi < 2; oi++) {
+        LSC l = cons.getLSC(oi, 1, 4);
+        printf("[%.9g, %.9g, %.9g, %.17g]%s", l.normal_vector.x(), l.normal_vector.y(), l.normal_vector.z(), l.d, oi ? "" : ", ");
+    }
+    printf("], \"x\": [");
+    for (size_t i = 0; i < raw.size(); i++) printf("%.17g%s", raw[i], i + 1 < raw.size() ? ", " : "");
+    printf("], \"cp_f32\": [%.9g, %.9g, %.9g]}\n", r.desired_traj[2][3].x(), r.desired_traj[2][3].y(), r.desired_traj[2][3].z());
+    return 0;
+}
+
+static int scenario_infeasible() {
+    Param param;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    TrajOptimizer opt(param, mission, B);
+    CollisionConstraints cons(param, mission);
+    Agent a = make_agent(point3d(0, 0, 1), point3d(0.5f, 0, 1), point3d(0.5f, 0, 1));
+    cons.initializeLSC(1);
+    for (int m = 0; m < param.M; m++) {
+        cons.setLSC(0, m, point3d(0, 0, 1), point3d(1, 0, 0), 50.0);  // x >= 50: outside the world
+        cons.setSFC(m, Box(point3d(-1, -1, 0.5f), point3d(1, 1, 1.5f)));
+    }
+    traj_t init(param.M, param.n, param.dt);
+    init.planConstVelTraj(a.current_state.position, point3d(0, 0, 0));
+    try {
+        opt.solve(a, cons, init, true);
+        printf("{\"scenario\": \"infeasible\", \"thrown\": \"nothing\"}\n");
+    } catch (PlanningReport r) {
+        // the caller's fail-safe (src/traj_planner.cpp:767-797): result.desired_traj = initial_traj
+        printf("{\"scenario\": \"infeasible\", \"thrown\": \"%s\"}\n", r == PlanningReport::QPFAILED ? "QPFAILED" : "other");
+    }
+    return 0;
+}
+
+static int scenario_host() {
+    // constructor validation mirrors the reference's exceptions; no device needed
+    Param param;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    bool threw_n = false, threw_dim = false;
+    try {
+        Param p = param;
+        p.n = 4;
+        TrajOptimizer o(p, mission, B);
+    } catch (const std::invalid_argument& e) {
+        threw_n = std::string(e.what()).find("only n=5, phi=3") != std::string::npos;
+    }
+    try {
+        Param p = param;
+        p.world_dimension = 4;
+        TrajOptimizer o(p, mission, B);
+    } catch (const std::invalid_argument&) {
+        threw_dim = true;
+    }
+    TrajOptimizer opt(param, mission, B);
+    Param p2 = param;
+    p2.planner_mode = PlannerMode::DLSC;
+    opt.updateParam(p2);
+    // container semantics
+    CollisionConstraints cons(param, mission);
+    cons.initializeLSC(3);
+    cons.setLSC(2, 4, point3d(1, 2, 3), point3d(0, 0, 1), 0.25);
+    LSC l = cons.getLSC(2, 4, 5);
+    const size_t n_obs_seen = cons.getObsSize();
+    Box box(point3d(-1, -2, -3), point3d(1, 2, 3));
+    LSCs f = box.convertToLSCs(3);
+    // trajectory evaluation: a straight constant-velocity line
+    traj_t tr(param.M, param.n, param.dt);
+    tr.planConstVelTraj(point3d(1, 1, 1), point3d(0.5f, 0, -0.25f));
+    State s = tr.getStateAt(0.3);
+    std::string no_device;
+    try {
+        Agent a = make_agent(point3d(0, 0, 1), point3d(0.5f, 0, 1), point3d(0.5f, 0, 1));
+        cons.initializeLSC(0);
+        for (int m = 0; m < param.M; m++) cons.setSFC(m, box);
+        opt.solve(a, cons, tr, true);
+        no_device = "solved";
+    } catch (const std::runtime_error& e) {
+        no_device = e.what();
+    } catch (PlanningReport) {
+        no_device = "QPFAILED";
+    }
+    printf("{\"scenario\": \"host\", \"threw_n\": %s, \"threw_dim\": %s, \"obs\": %zu, \"lsc_d\": %.9g, \"lsc_pz\": %.9g, "
+           "\"faces\": %zu, \"face3_d\": %.9g, \"face3_n\": %.9g, \"B00\": %.9g, \"B01\": %.9g, ",
+           threw_n ? "true" : "false", threw_dim ? "true" : "false", n_obs_seen, l.d, l.obs_control_point.z(), f.size(),
+           f[3].d, f[3].normal_vector.y(), B(0, 0), B(0, 1));
+    print_state("lin", s, true);
+    printf("\"solve_without_gpu\": \"%s\"}\n", no_device.c_str());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    std::string s = argc > 1 ? argv[1] : "host";
+    if (s == "host") return scenario_host();
+    if (s == "kat") return scenario_kat(true);
+    if (s == "pair") return scenario_pair();
+    if (s == "infeasible") return scenario_infeasible();
+    fprintf(stderr, "usage: shim_test host|kat|pair|infeasible\n");
+    return 2;
+}

@@ -1,0 +1,92 @@
+"""The C++ shim (lsc_dr_planner_amd/shim): the reference's TrajOptimizer / CollisionConstraints / Trajectory class
+surface over the C ABI.  Host-logic checks run on CPU; solves run on the GPU (-m gpu)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim_exe(api):
+    from lsc_dr_planner_amd.shim import build as SB
+
+    return SB.build()
+
+
+def run(exe, scenario):
+    out = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return [json.loads(l) for l in out.stdout.strip().splitlines()]
+
+
+def test_host_logic(shim_exe):
+    import torch
+
+    r = run(shim_exe, "host")[0]
+    # constructor errors mirror the reference (std::invalid_argument, src/traj_optimizer.cpp:200, :249)
+    assert r["threw_n"] and r["threw_dim"]
+    # container: setLSC(oi, m, point, normal, d) fills all n+1 control points (src/collision_constraints.cpp:532-539)
+    assert r["obs"] == 3 and r["lsc_d"] == 0.25 and r["lsc_pz"] == 3
+    # Box::convertToLSCs: face 2i+1 = (-e_i, d = -box_max(i))  (src/collision_constraints.cpp:37-59)
+    assert r["faces"] == 6 and r["face3_d"] == -2 and r["face3_n"] == -1
+    assert r["B00"] == 1 and r["B01"] == -5  # include/polynomial.hpp:281-294
+    # planConstVelTraj spaces control points dt/n apart across segment borders (src/trajectory.cpp:79-91), so segment 1
+    # starts at 6*dt/5: at t = 0.3 the point is p + v*0.34, float32
+    assert abs(r["lin"]["p"][0] - (1 + 0.5 * 0.34)) < 1e-6 and abs(r["lin"]["v"][0] - 0.5) < 1e-5
+    if not torch.cuda.is_available():
+        assert "no CPU fallback" in r["solve_without_gpu"]  # loud failure, never a silent CPU path
+
+
+@pytest.mark.gpu
+def test_reference_log_through_the_shim(shim_exe):
+    """forest10_10 first replan through TrajOptimizer::solve with float32 truncation and Trajectory::getStateAt,
+    i.e. the same pipeline that wrote the reference log: matches it to the printed digits."""
+    g = H.load_golden("kat_log")
+    res = {r["scenario"]: r for r in run(shim_exe, "kat")}
+    for case in g["cases"]:
+        r = res["kat1" if case["agent"] == 0 else "kat2"]
+        log = g["agents"][case["agent"]]["states"]
+        for key, st in (("t0.1", log[1]), ("t0.2", log[2])):
+            for comp in ("p", "v", "a"):
+                for got, logged in zip(r[key][comp], st[comp]):
+                    # the log prints 6 significant digits (std::ofstream default): agree to one unit of the 6th digit
+                    ulp6 = 10.0 ** (np.floor(np.log10(abs(logged))) - 5) if logged != 0 else 1e-9
+                    assert abs(got - logged) <= 1.01 * ulp6, (key, comp, got, logged)
+        assert abs(r["z"] - 0.6) < 1e-7  # dim == 2: z := world_z_2d (src/traj_optimizer.cpp:78-80)
+    assert abs(res["kat1"]["cost"] - 0.2024006128) < 1e-8  # -85.5476 + 7 * 3.5^2
+
+
+@pytest.mark.gpu
+def test_shim_matches_oracle(shim_exe, oracle):
+    r = run(shim_exe, "pair")[0]
+    assert r["batch_same"]
+    cls = oracle.make_class(M=5, dim=3)
+    ag = oracle.make_agent(p0=(0, 0, 1), v0=np.float32([0.3, 0.0, 0.05]).astype(float), goal=np.float32([0.5, 0.1, 1]).astype(float),
+                           n_obs=2)
+    lsc = np.zeros((2, 5, 6), oracle.LSC_DTYPE)
+    for oi in range(2):
+        lsc["p"][oi] = r["obs"][oi]
+        lsc["nrm"][oi] = r["nrm"][oi][:3]
+        lsc["d"][oi] = r["nrm"][oi][3]
+    sfc = np.zeros(5, oracle.BOX_DTYPE)
+    sfc["bmin"] = np.float32([-0.55, -0.65, 0.45]).astype(float)
+    sfc["bmax"] = np.float32([0.95, 0.75, 1.65]).astype(float)
+    o = oracle.solve(cls, ag, lsc, sfc)
+    assert o["status"] == 0
+    x = np.array(r["x"])
+    assert np.abs(x - o["x"]).max() < 1e-7
+    assert abs(r["cost"] - o["obj"]) <= 1e-8 * max(1, abs(o["obj"]))
+    # float32 truncation of the returned trajectory (src/traj_optimizer.cpp:74-76)
+    xs = x.reshape(3, 5, 6)
+    assert np.array_equal(np.float32(r["cp_f32"]), np.float32(xs[:, 2, 3]))
+
+
+@pytest.mark.gpu
+def test_qpfailed_is_thrown(shim_exe):
+    assert run(shim_exe, "infeasible")[0]["thrown"] == "QPFAILED"
