@@ -11,10 +11,10 @@
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
 
-#define LSCQP_DECL(M, D, E)                                                                                             \
-    extern "C" hipError_t lscqp_launch_##M##_##D##_##E(const lscqp::DevClass*, int64_t, const lscqp_header*,            \
-                                                       const lscqp_row*, const uint64_t*, const lscqp_box*, double*,    \
-                                                       double*, int32_t*, lscqp_info*, hipStream_t);
+#define LSCQP_DECL(M, D, E, S)                                                                                       \
+    extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S(const lscqp::DevClass*, int64_t, const lscqp_header*,    \
+                                                             const lscqp_row*, const uint64_t*, const lscqp_box*,     \
+                                                             double*, double*, int32_t*, lscqp_info*, hipStream_t);
 LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
@@ -27,19 +27,27 @@ int fail(int code, const std::string& msg) {
 }
 
 struct Inst {
-    int M, dim, es;
+    int M, dim, es, max_obs;
     lscqp::launch_fn fn;
 };
+constexpr int max_obs_of(int M, int nslot) { return nslot * ((64 / (6 * M - 3)) > 0 ? (64 / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
-#define LSCQP_ROW(M, D, E) {M, D, E, lscqp_launch_##M##_##D##_##E},
+#define LSCQP_ROW(M, D, E, S) {M, D, E, max_obs_of(M, S), lscqp_launch_##M##_##D##_##E##_##S},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
 
-lscqp::launch_fn find_instance(int M, int dim, int es) {
+// smallest instance of the shape that accommodates n_obs obstacles per agent; nullptr if none
+const Inst* find_instance(int M, int dim, int es, int n_obs) {
+    const Inst* best = nullptr;
     for (const Inst& i : kInst)
-        if (i.M == M && i.dim == dim && i.es == es) return i.fn;
-    return nullptr;
+        if (i.M == M && i.dim == dim && i.es == es && i.max_obs >= n_obs && (!best || i.max_obs < best->max_obs)) best = &i;
+    return best;
+}
+bool shape_exists(int M, int dim, int es) {
+    for (const Inst& i : kInst)
+        if (i.M == M && i.dim == dim && i.es == es) return true;
+    return false;
 }
 
 // Closed form of Q_base for n = 5, phi = 3, phi_n = 1 (reference src/traj_optimizer.cpp:163-178:
@@ -53,7 +61,6 @@ const double kQInt[36] = {720, -1800, 1200, 0,     0,     -120, -1800, 4800, -36
 struct lscqp_solver {
     lscqp_class_desc desc;
     lscqp::DevClass dev;
-    lscqp::launch_fn fn;
     int nv, P, es;
     // staging buffers of the host-pointer entry point
     void* d_buf = nullptr;
@@ -69,14 +76,12 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     if (d->M < 2) return fail(LSCQP_ERR_INVALID_ARGUMENT, "M must be >= 2");
     if (!(d->dt > 0)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "dt must be positive");
     const int es = (d->planner_mode == LSCQP_PLANNER_LSC) ? 1 : 0;
-    lscqp::launch_fn fn = find_instance(d->M, d->dim, es);
-    if (!fn) {
+    if (!shape_exists(d->M, d->dim, es)) {
         char buf[160];
         snprintf(buf, sizeof buf, "no compiled kernel instance for M=%d dim=%d end_stop=%d (needs dim*(3M-2) <= 64)", d->M, d->dim, es);
         return fail(LSCQP_ERR_UNSUPPORTED, buf);
     }
     s->desc = *d;
-    s->fn = fn;
     s->es = es;
     s->P = d->M * 6;
     s->nv = d->dim * s->P;
@@ -88,11 +93,11 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.comm_range = d->communication_range;
     const double sc = std::pow(d->dt, -5.0);
     const long double scl = 1.0L / ((long double)d->dt * d->dt * d->dt * d->dt * d->dt);
+    c.q2s = 2.0 * d->control_input_weight * sc;
     for (int i = 0; i < 36; i++) {
-        const double q_ref = kQInt[i] * sc;  // what Eigen computes: exact integer times the rounded pow(dt,-5)
-        c.Q2[i] = 2.0 * d->control_input_weight * q_ref;
-        // the reference's objective coefficient is fl(w_c * fl(int * pow(dt,-5))) (src/traj_optimizer.cpp:294);
+        // the reference's objective coefficient is fl(w_c * fl(int * pow(dt,-5))) (src/traj_optimizer.cpp:174-176,294);
         // dQ holds its deviation from the exact product, per unit w_c, so that obj = exact + w_c * c' dQ c
+        const double q_ref = kQInt[i] * sc;
         const double p_ref = d->control_input_weight * q_ref;
         c.dQ[i] = d->control_input_weight != 0
                       ? (double)(((long double)p_ref - (long double)d->control_input_weight * kQInt[i] * scl) /
@@ -173,12 +178,17 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, n_obs_max);
+    if (!inst) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "no compiled kernel instance of M=%d dim=%d holds %d obstacles per agent in registers",
+                 h->desc.M, h->desc.dim, n_obs_max);
+        return fail(LSCQP_ERR_UNSUPPORTED, buf);
+    }
     lscqp::DevClass cls = h->dev;
     cls.n_obs_max = n_obs_max;
-    hipError_t e = h->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_out, d_obj_out, d_status_out, d_info_out,
-                         (hipStream_t)stream);
-    if (e == hipErrorInvalidValue)
-        return fail(LSCQP_ERR_UNSUPPORTED, "instance does not fit the 160 KiB LDS of one CU (too many obstacles per agent)");
+    hipError_t e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_out, d_obj_out, d_status_out, d_info_out,
+                            (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
     return LSCQP_OK;
 }

@@ -1,24 +1,26 @@
 // One kernel instance per translation unit so the instances compile in parallel.
-// Built with -DLSCQP_M=<M> -DLSCQP_DIM=<dim> -DLSCQP_ES=<0|1>; exports lscqp_launch_<M>_<dim>_<ES>.
+// Built with -DLSCQP_M=<M> -DLSCQP_DIM=<dim> -DLSCQP_ES=<0|1> -DLSCQP_NSLOT=<slots>;
+// exports lscqp_launch_<M>_<dim>_<ES>_<NSLOT>.
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
 
-#define LSCQP_CAT_(a, b, c, d) a##b##_##c##_##d
-#define LSCQP_CAT(a, b, c, d) LSCQP_CAT_(a, b, c, d)
-#define LSCQP_FN LSCQP_CAT(lscqp_launch_, LSCQP_M, LSCQP_DIM, LSCQP_ES)
+#define LSCQP_CAT_(a, b, c, d, e) a##b##_##c##_##d##_##e
+#define LSCQP_CAT(a, b, c, d, e) LSCQP_CAT_(a, b, c, d, e)
+#define LSCQP_FN LSCQP_CAT(lscqp_launch_, LSCQP_M, LSCQP_DIM, LSCQP_ES, LSCQP_NSLOT)
 
 extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
                                const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
                                int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
-    using C = lscqp::Cfg<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0)>;
-    auto kern = lscqp::lscqp_pdip_kernel<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0)>;
-    const size_t lds = C::lds_bytes(cls->n_obs_max);
-    if (lds > lscqp::kMaxLdsBytes) return hipErrorInvalidValue;
-    static size_t lds_set = 0;  // raise the dynamic-LDS cap once per size (160 KiB per CU on gfx950)
-    if (lds > lds_set) {
+    using C = lscqp::Cfg<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT>;
+    auto kern = lscqp::lscqp_pdip_kernel<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT>;
+    constexpr size_t lds = C::lds_bytes();
+    static_assert(lds <= lscqp::kMaxLdsBytes, "instance does not fit the LDS of one CU");
+    if (cls->n_obs_max > C::MAX_OBS) return hipErrorInvalidValue;
+    static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
+    if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_set = lds;
+        attr_set = true;
     }
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, *cls, n, hdr, rows, row_offsets, sfc, x_out, obj_out,

@@ -3,18 +3,22 @@
 // Replaces the arithmetic of TrajOptimizer::solve (reference src/traj_optimizer.cpp:18-156: CPLEX) for the
 // model TrajOptimizer::populatebyrow builds (src/traj_optimizer.cpp:216-514).  Not a translation of either:
 //
-//   * ONE WAVEFRONT (64 lanes) PER QP, one workgroup per wavefront.
-//   * The equality rows (src/traj_optimizer.cpp:318-368, 502-511) are eliminated analytically: per axis the free
-//     variables are z = (c3,c4,c5) of every segment (one scalar for the last segment under the LSC end stop);
+//   * ONE WAVEFRONT (64 lanes) PER QP, one workgroup per wavefront; the kernel is issue/latency bound on fp64 VALU,
+//     so everything is organised to minimise the instruction count of one Mehrotra iteration.
+//   * The equality rows (:318-368, 502-511) are eliminated analytically: per axis the free variables are
+//     z = (c3,c4,c5) of every segment (one scalar for the last segment under the LSC end stop);
 //     (c0,c1,c2) of segment m+1 = TB (c3,c4,c5) of segment m, TB = [[0,0,1],[0,-1,2],[1,-4,4]].
-//     nz = dim*(3M-2) <= 64, so lane r owns row r of the reduced KKT matrix.
-//   * Inequalities are never formed as a matrix.  LSC rows (n.c >= b, one control point each) live in LDS as
-//     SoA [obstacle][control point]; the per-axis structured rows (merged interval bounds from world box / SFC /
-//     communication range, velocity and acceleration differences, communication pairs) are two-sided rows held in
-//     registers, a few per lane.
-//   * Each Mehrotra iteration: rows -> per-control-point 3x3 blocks S and x-space vectors in LDS -> every lane builds
-//     its row of the reduced matrix from per-(axis,segment) 6x6 local blocks -> LDL^T entirely in registers,
-//     pivot rows broadcast with v_readlane -> two solves -> step.
+//     nz = dim*(3M-2) <= 64: lane r owns row r of the reduced KKT matrix in registers.
+//   * LSC rows (n.c >= b, one control point each): lane = (group g, control point cp); the lane's rows are the
+//     obstacles o = g, g+G, ... of that control point.  Row constants (n, b) sit in LDS as SoA [obstacle][cp]
+//     (conflict-free ds_read_b64), row STATE (s, lambda and the per-iteration residual / direction scalars) sits in
+//     registers (NSLOT slots per lane), the per-control-point 3x3 blocks and x-space vectors are accumulated in
+//     registers over the slots and flushed once per pass.
+//   * The per-axis structured rows (merged interval bounds from world box / SFC / communication range, velocity and
+//     acceleration differences, communication pairs) are two-sided rows in registers, one ROW TYPE per slot so a
+//     wave instruction never mixes types.
+//   * Reduced matrix: every lane builds its row from per-(axis,segment) 6x6 local blocks; LDL^T and the two
+//     triangular solves run entirely in registers with v_readlane broadcasts of the pivot row.
 //   * All arithmetic fp64, in coordinates translated to the agent's position.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,16 +31,27 @@ namespace lscqp {
 struct DevClass {
     double dt, w_c, w_t, comm_range;
     double world_min[3], world_max[3];
-    double Q2[36];  // 2 * w_c * Q_base (closed form of src/traj_optimizer.cpp:163-178)
-    double dQ[36];  // Q_base as the reference rounds it (integer matrix * pow(dt,-5), per entry, in double)
-                    // minus the exact product: restores the reference model's tiny non-translation-invariance
-                    // in the reported objective
+    double q2s;     // 2 * w_c * pow(dt,-5): Q2[i][j] = q2s * KQ[i][j]  (closed form of src/traj_optimizer.cpp:163-178)
+    double dQ[36];  // the reference's per-entry coefficient rounding, see lscqp_api.hip
     double tol;
     int max_iter;
     int use_sfc;
-    int n_obs_max;  // LDS is sized for this many obstacles per instance
+    int n_obs_max;  // number of obstacles the launch must accommodate (<= NSLOT * G of the instance)
     int pad;
 };
+
+// Q_base * dt^5 for n = 5, phi = 3 (integers)
+__device__ __forceinline__ constexpr double KQ(int i, int j) {
+    constexpr int q[6][6] = {{720, -1800, 1200, 0, 0, -120},  {-1800, 4800, -3600, 0, 600, 0}, {1200, -3600, 3600, -1200, 0, 0},
+                             {0, 0, -1200, 3600, -3600, 1200}, {0, 600, 0, -3600, 4800, -1800}, {-120, 0, 0, 1200, -1800, 720}};
+    return (double)q[i][j];
+}
+// TB rows: (c0,c1,c2) of the next segment in terms of (c3,c4,c5) of this one: [[0,0,1],[0,-1,2],[1,-4,4]].
+// Written with selects, not a table: it is also evaluated with lane-dependent i, and a constexpr table indexed
+// dynamically would be materialised in scratch memory.
+__device__ __forceinline__ constexpr double TBc(int i, int j) {
+    return i == 0 ? (j == 2 ? 1.0 : 0.0) : i == 1 ? (j == 0 ? 0.0 : j == 1 ? -1.0 : 2.0) : (j == 0 ? 1.0 : j == 1 ? -4.0 : 4.0);
+}
 
 __device__ __forceinline__ double bcast(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -44,14 +59,35 @@ __device__ __forceinline__ double bcast(double v, int lane) {
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
+// interleaved butterflies so the ds_bpermute latencies of independent quantities overlap
+__device__ __forceinline__ void wave_sum2_max1(double& a, double& b, double& c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64), tc = __shfl_xor(c, o, 64);
+        a += ta;
+        b += tb;
+        c = fmax(c, tc);
+    }
+}
+__device__ __forceinline__ void wave_max2(double& a, double& b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64);
+        a = fmax(a, ta);
+        b = fmax(b, tb);
+    }
+}
+__device__ __forceinline__ void wave_max1_sum1(double& a, double& b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64);
+        a = fmax(a, ta);
+        b += tb;
+    }
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
@@ -59,6 +95,7 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
 }
+// 1/d to full fp64 precision: v_rcp_f64 + two Newton steps (5 instructions instead of an IEEE division sequence)
 __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
@@ -66,90 +103,117 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
-template <int M_, int DIM_, bool ES_>
+// Development aid: per-phase cycle totals (s_memtime), compiled in only with -DLSCQP_PHASE_TIMING.
+// Cross-lane hand-off through LDS inside ONE wavefront: the LDS executes a wave's DS instructions in order, so no
+// s_barrier is needed, but the compiler must neither reorder LDS accesses across the hand-off nor keep values in
+// registers.  (__syncthreads() is not enough here: with a 64-thread workgroup hipcc elides it completely and at -O3
+// then moves the uniform-address reads above the per-lane store.)
+#define LSCQP_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// Keeps the instruction scheduler from hoisting the LDS loads of all row slots to the top of a pass (which
+// multiplies the live registers by the slot count and forces scratch spills).
+#define LSCQP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Development aid: -DLSCQP_DEBUG_STOP=k leaves the iteration loop at stage k (bisecting device faults).
+#ifndef LSCQP_DEBUG_STOP
+#define LSCQP_DEBUG_STOP 0
+#endif
+#define LSCQP_STOP(k)                  \
+    if (LSCQP_DEBUG_STOP == (k)) {     \
+        status = 100 + (k);            \
+        break;                         \
+    }
+#ifdef LSCQP_PHASE_TIMING
+__device__ unsigned long long lscqp_dbg_cycles[16];
+#define LSCQP_T(slot)                                                     \
+    do {                                                                  \
+        const unsigned long long now_ = __builtin_readcyclecounter();    \
+        if (lane == 0) atomicAdd(&lscqp_dbg_cycles[slot], now_ - tprev_); \
+        tprev_ = __builtin_readcyclecounter();                            \
+    } while (0)
+#else
+#define LSCQP_T(slot) \
+    do {              \
+    } while (0)
+#endif
+
+template <int M_, int DIM_, bool ES_, int NSLOT_>
 struct Cfg {
-    static constexpr int M = M_, DIM = DIM_;
+    static constexpr int M = M_, DIM = DIM_, NSLOT = NSLOT_;
     static constexpr bool ES = ES_;
     static constexpr int P = 6 * M;
+    static constexpr int CP = P - 3;  // control points that carry LSC rows (all but the initial state, :404-406)
     static constexpr int NZA = 3 * (M - 1) + (ES ? 1 : 3);
     static constexpr int NZ = DIM * NZA;
     static constexpr int NX = DIM * P;  // x-space size
-    // two-sided per-axis rows, uniform index space (rows that do not exist for m==0 stay infinite):
-    //   [0,P) interval of cp | [P,P+5M) vel (m,i) | [..,+4M) acc (m,i) | comm pairs (u,up<u)
-    static constexpr int OV = P, OA = P + 5 * M, OC = P + 9 * M, NRA = P + 9 * M + M * (M - 1) / 2;
-    static constexpr int NR2 = DIM * NRA;
-    static constexpr int RPL = (NR2 + 63) / 64;
-    static constexpr int G = (64 / P) > 0 ? (64 / P) : 1;  // lane groups in the LSC pass
+    static constexpr int G = (64 / CP) > 0 ? (64 / CP) : 1;  // lane groups of the LSC pass
+    static constexpr int MAX_OBS = NSLOT * G;
+    // two-sided per-axis rows, one type per register slot
+    static constexpr int NV = DIM * 5 * M, NA = DIM * 4 * M, NCP = M * (M - 1) / 2, NC = DIM * NCP;
+    static constexpr int SI = (NX + 63) / 64, SV = (NV + 63) / 64, SA = (NA + 63) / 64, SC = (NC + 63) / 64;
+    static constexpr int NS2 = SI + SV + SA + SC;
+    // weights of the two-sided rows in LDS: [interval NX][vel NV][acc NA][comm NC]
+    static constexpr int OV = NX, OA = NX + NV, OC = NX + NV + NA, NOM = NX + NV + NA + NC;
     static constexpr int LDH = NZ | 1;
     static_assert(NZ <= 64, "lane-per-row kernel needs dim*(3M-2) <= 64");
-    static_assert(P <= 64, "M <= 10");
+    static_assert(CP <= 64, "M <= 11");
     static_assert(M >= 2, "the reference assumes M >= 2 (src/traj_optimizer.cpp:341-352)");
     // LDS carve (in doubles)
     static constexpr int o_c = 0;               // control points (translated)
     static constexpr int o_dca = o_c + NX;      // affine direction, x-space
     static constexpr int o_dc = o_dca + NX;     // final direction, x-space
-    static constexpr int o_x0 = o_dc + NX;      // x-space accumulators (4)
+    static constexpr int o_x0 = o_dc + NX;      // x-space accumulators: XL, XA, XB1, XB2
     static constexpr int o_S = o_x0 + 4 * NX;   // per-cp 3x3 sym blocks [P][6]
-    static constexpr int o_om = o_S + 6 * P;    // two-sided row weights [DIM][NRA]
-    static constexpr int o_z = o_om + NR2;      // z, dz
-    static constexpr int o_H = o_z + 2 * 64;    // per-lane scratch rows of the reduced matrix [NZ][LDH]
-    static constexpr int o_rows = ((o_H + NZ * LDH + 1) / 2) * 2;  // LSC SoA: nx,ny,nz,b,s,lam each [n_obs_max*P]
-    static size_t lds_bytes(int n_obs_max) { return sizeof(double) * ((size_t)o_rows + 6 * (size_t)n_obs_max * P); }
+    static constexpr int o_om = o_S + 6 * P;    // two-sided row weights
+    static constexpr int o_z = o_om + NOM;      // z, dz
+    static constexpr int o_col = o_z + 2 * 64;  // pivot-column broadcast buffer
+    static constexpr int o_H = ((o_col + 130 + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH]
+    static constexpr int o_rows = ((o_H + (NZ + 1) * LDH + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
+    static constexpr int NROW = MAX_OBS * CP;  // + one dead row per array
+    static constexpr size_t lds_bytes() { return sizeof(double) * ((size_t)o_rows + 4 * ((size_t)NROW + 1)); }
 };
 
-// TB rows: (c0,c1,c2) of the next segment in terms of (c3,c4,c5) of this one.
-#define LSCQP_TB(i, j) ((i) == 0 ? ((j) == 2 ? 1.0 : 0.0) : (i) == 1 ? ((j) == 0 ? 0.0 : (j) == 1 ? -1.0 : 2.0) : ((j) == 0 ? 1.0 : (j) == 1 ? -4.0 : 4.0))
-
-template <int M, int DIM, bool ES>
+template <int M, int DIM, bool ES, int NSLOT>
 __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows,
                                                         const uint64_t* __restrict__ row_offsets,
                                                         const lscqp_box* __restrict__ sfc, double* __restrict__ x_out,
                                                         double* __restrict__ obj_out, int32_t* __restrict__ status_out,
                                                         lscqp_info* __restrict__ info_out) {
-    using C = Cfg<M, DIM, ES>;
-    constexpr int P = C::P, NZA = C::NZA, NZ = C::NZ, NX = C::NX, NRA = C::NRA, NR2 = C::NR2, RPL = C::RPL, G = C::G,
-                  LDH = C::LDH;
+    using C = Cfg<M, DIM, ES, NSLOT>;
+    constexpr int P = C::P, CP = C::CP, NZA = C::NZA, NZ = C::NZ, NX = C::NX, G = C::G, LDH = C::LDH;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* const c_ = smem + C::o_c;
     double* const dca_ = smem + C::o_dca;
     double* const dc_ = smem + C::o_dc;
-    double* const XL = smem + C::o_x0;           // G' lambda          (x-space)
-    double* const XA = smem + C::o_x0 + NX;      // G' q_aff  /  later G' q_corr
-    double* const XB1 = smem + C::o_x0 + 2 * NX; // G' (1/s)
-    double* const XB2 = smem + C::o_x0 + 3 * NX; // G' (-ds_a dl_a/s - w rp)
+    double* const XL = smem + C::o_x0;            // G' lambda
+    double* const XA = smem + C::o_x0 + NX;       // G' q_aff
+    double* const XB1 = smem + C::o_x0 + 2 * NX;  // G' (1/s)
+    double* const XB2 = smem + C::o_x0 + 3 * NX;  // G' (-ds_a dl_a/s - w rp)
     double* const S_ = smem + C::o_S;
     double* const om_ = smem + C::o_om;
     double* const z_ = smem + C::o_z;
     double* const dz_ = smem + C::o_z + 64;
+    double* const col_ = smem + C::o_col;
     double* const Hs = smem + C::o_H;
-    const int nrow_max = cls.n_obs_max * P;
+    constexpr int NROW = C::NROW;
     double* const Rnx = smem + C::o_rows;
-    double* const Rny = Rnx + nrow_max;
-    double* const Rnz = Rny + nrow_max;
-    double* const Rb = Rnz + nrow_max;
-    double* const Rs = Rb + nrow_max;
-    double* const Rl = Rs + nrow_max;
+    double* const Rny = Rnx + (NROW + 1);
+    double* const Rnz = Rny + (NROW + 1);
+    double* const Rb = Rnz + (NROW + 1);
 
     const int lane = threadIdx.x;
     const int64_t q = blockIdx.x;
     if (q >= n) return;
     const lscqp_header* H = hdr + q;
-    const int n_obs = H->n_obs < cls.n_obs_max ? H->n_obs : cls.n_obs_max;
-    const int nrow = n_obs * P;
+    const int n_obs = H->n_obs < C::MAX_OBS ? H->n_obs : C::MAX_OBS;
     const double dt = cls.dt;
 
     // ---- per-QP scalars (uniform) ------------------------------------------------------------------------
-    double org[3], goal[3], wp[3], vlim[3], alim[3], cf1[3], cf2[3];
+    double org[3], goal[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         org[k] = H->p0[k];
         goal[k] = H->goal[k] - org[k];
-        wp[k] = H->next_waypoint[k] - org[k];
-        vlim[k] = H->vmax[k] * dt * 0.2;            // |c_{i+1}-c_i| <= vmax dt/n      (src/traj_optimizer.cpp:448-453)
-        alim[k] = H->amax[k] * dt * dt * 0.05;      // |c_{i+2}-2c_{i+1}+c_i| <= amax dt^2/(n(n-1))   (:462-471)
-        cf1[k] = H->v0[k] * dt * 0.2;               // c1 - c0                         (:330-332)
-        cf2[k] = H->a0[k] * dt * dt * 0.05 + 2.0 * cf1[k];  // c2 - c0                (:335-338)
     }
     int ts = H->terminal_segments;
     if (ts <= 0) {  // src/traj_optimizer.cpp:530-538 in fp64
@@ -160,9 +224,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
         if (ts < 1) ts = 1;
     }
     if (ts > M) ts = M;
-    const double rho_pair = 0.5 * cls.comm_range - H->radius;  // :484
-    const double rho_wp = 0.5 * cls.comm_range - 1e-5;         // :495
-    const bool comm_on = cls.comm_range > 0;
+    const double q2s = cls.q2s;
+    const double wt2 = 2.0 * cls.w_t;
 
     // ---- lane roles ---------------------------------------------------------------------------------------
     // z lane: row r = lane of the reduced system, r = k*NZA + a
@@ -172,114 +235,44 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     const bool zlast = ES && (za == 3 * (M - 1));
     const int zm = zlast ? (M - 1) : za / 3;
     const int zj = zlast ? 0 : za % 3;
-    // e[j']: which of (c3,c4,c5) of segment zm this variable drives
     const double e0 = (zlast || zj == 0) ? 1.0 : 0.0, e1 = (zlast || zj == 1) ? 1.0 : 0.0, e2 = (zlast || zj == 2) ? 1.0 : 0.0;
-    // tb[i] = TB[i][zj] (zero for the end-stop variable: no next segment)
     const bool has_next = (zm + 1 < M);
     const double tb0 = has_next ? (zj == 2 ? 1.0 : 0.0) : 0.0;
     const double tb1 = has_next ? (zj == 0 ? 0.0 : zj == 1 ? -1.0 : 2.0) : 0.0;
     const double tb2 = has_next ? (zj == 0 ? 1.0 : zj == 1 ? -4.0 : 4.0) : 0.0;
     auto zidx = [](int m, int j) -> int { return (ES && m == M - 1) ? 3 * (M - 1) : 3 * m + j; };
+    // LSC lane: (group lg, control point lcp in [0,CP)); x-space index of the lane's control point per axis
+    const bool ll = lane < G * CP;
+    const int lg = ll ? lane / CP : 0;
+    const int lcp = ll ? lane % CP : 0;
+    const int lx = lcp + 3;  // index within one axis of c_
 
-    // ---- two-sided rows owned by this lane (registers) ----------------------------------------------------
-    int r_ia[RPL], r_ib[RPL], r_ic[RPL];  // LDS indices into c_ (x-space), -1 = unused
-    double r_cb[RPL];                     // middle coefficient (-2 for acc, +1/-1 otherwise handled by type)
-    int r_ty[RPL];                        // 0 interval, 1 vel, 2 acc, 3 comm, -1 none
-    double r_lo[RPL], r_hi[RPL], r_slo[RPL], r_shi[RPL], r_llo[RPL], r_lhi[RPL];
-#pragma unroll
-    for (int u = 0; u < RPL; u++) {
-        const int t2 = lane + 64 * u;
-        r_ty[u] = -1;
-        r_ia[u] = r_ib[u] = r_ic[u] = 0;
-        r_cb[u] = 0;
-        r_lo[u] = -INFINITY;
-        r_hi[u] = INFINITY;
-        if (t2 < NR2) {
-            const int k = t2 / NRA, t = t2 % NRA;
-            const int base = k * P;
-            if (t < C::OV) {  // interval on cp t
-                const int m = t / 6, i = t % 6;
-                if (!(m == 0 && i < 3)) {
-                    r_ty[u] = 0;
-                    r_ia[u] = base + t;
-                    double lo = cls.world_min[k] - org[k], hi = cls.world_max[k] - org[k];  // :252-253,260-265
-                    if (cls.use_sfc) {                                                      // :372-397
-                        lo = fmax(lo, sfc[q * M + m].bmin[k] - org[k]);
-                        hi = fmin(hi, sfc[q * M + m].bmax[k] - org[k]);
-                    }
-                    if (comm_on && i == 5) {  // pairs (m, mi=0) :482-487 and waypoint rows :494-497
-                        lo = fmax(lo, fmax(-rho_pair, wp[k] - rho_wp));
-                        hi = fmin(hi, fmin(rho_pair, wp[k] + rho_wp));
-                    }
-                    r_lo[u] = lo;
-                    r_hi[u] = hi;
-                }
-            } else if (t < C::OA) {  // velocity (m,i): c[i+1]-c[i]
-                const int v = t - C::OV, m = v / 5, i = v % 5;
-                if (!(m == 0 && i < 2)) {
-                    r_ty[u] = 1;
-                    r_ia[u] = base + 6 * m + i;
-                    r_ib[u] = base + 6 * m + i + 1;
-                    r_lo[u] = -vlim[k];
-                    r_hi[u] = vlim[k];
-                }
-            } else if (t < C::OC) {  // acceleration (m,i): c[i+2]-2c[i+1]+c[i]
-                const int a = t - C::OA, m = a / 4, i = a % 4;
-                if (!(m == 0 && i < 1)) {
-                    r_ty[u] = 2;
-                    r_ia[u] = base + 6 * m + i;
-                    r_ib[u] = base + 6 * m + i + 1;
-                    r_ic[u] = base + 6 * m + i + 2;
-                    r_lo[u] = -alim[k];
-                    r_hi[u] = alim[k];
-                }
-            } else if (comm_on) {  // pair (uu, up<uu): c[uu][5] - c[up+1][0]     (:482-487 with mi = up+1 >= 1)
-                const int cidx = t - C::OC;
-                int uu = 1;
-                while (uu * (uu + 1) / 2 <= cidx) uu++;
-                const int up = cidx - uu * (uu - 1) / 2;
-                r_ty[u] = 3;
-                r_ia[u] = base + 6 * (up + 1) + 0;
-                r_ib[u] = base + 6 * uu + 5;
-                r_lo[u] = -rho_pair;
-                r_hi[u] = rho_pair;
-            }
-        }
+    // ---- control points: fixed part from (p0, v0, a0) (:321-338), free part = "stay at c2" ----------------
+    for (int e = lane; e < NX; e += 64) {
+        const int k = e / P, cp = e % P;
+        const double cf1 = H->v0[k] * dt * 0.2;                    // c1 - c0
+        const double cf2 = H->a0[k] * dt * dt * 0.05 + 2.0 * cf1;  // c2 - c0
+        c_[e] = (cp == 0) ? 0.0 : (cp == 1) ? cf1 : cf2;
+        dca_[e] = 0.0;
+        dc_[e] = 0.0;
     }
-    // row value y = g.c  for the rows of this lane
-    auto row_val = [&](const double* v, int u) -> double {
-        const int ty = r_ty[u];
-        double y = 0;
-        if (ty == 0) y = v[r_ia[u]];
-        else if (ty == 1 || ty == 3) y = v[r_ib[u]] - v[r_ia[u]];
-        else if (ty == 2) y = v[r_ic[u]] - 2.0 * v[r_ib[u]] + v[r_ia[u]];
-        return y;
-    };
-    // scatter val * g into an x-space accumulator (LDS atomics; few per lane)
-    auto row_scatter = [&](double* X, int u, double val) {
-        const int ty = r_ty[u];
-        if (ty == 0) atomicAdd(&X[r_ia[u]], val);
-        else if (ty == 1 || ty == 3) {
-            atomicAdd(&X[r_ib[u]], val);
-            atomicAdd(&X[r_ia[u]], -val);
-        } else if (ty == 2) {
-            atomicAdd(&X[r_ic[u]], val);
-            atomicAdd(&X[r_ib[u]], -2.0 * val);
-            atomicAdd(&X[r_ia[u]], val);
-        }
-    };
-
-    // ---- stage LSC rows: HBM (AoS 32 B, [oi][m][i]) -> LDS SoA, translated to the agent's origin -----------
+    if (zl) {
+        const double cf1 = H->v0[zk] * dt * 0.2;
+        z_[lane] = H->a0[zk] * dt * dt * 0.05 + 2.0 * cf1;
+        double* hrow0 = &Hs[lane * LDH];
+#pragma unroll
+        for (int cidx = 0; cidx < NZ; cidx++) hrow0[cidx] = 0.0;  // entries outside the lane's pattern stay zero
+    }
+    // ---- stage LSC row constants: HBM (AoS 32 B, [oi][m][i]) -> LDS SoA [oi][cp], translated to the agent origin --
     {
         const lscqp_row* R = rows + row_offsets[q];
-        for (int e = lane; e < nrow; e += 64) {
-            const double4 v = *reinterpret_cast<const double4*>(&R[e]);
-            const int cp = e % P;
+        const int nact = n_obs * CP;
+        for (int e = lane; e < nact; e += 64) {
+            const int o = e / CP, cp = e % CP;
+            const double4 v = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
             double nx = v.x, ny = v.y, nz = (DIM == 3) ? v.z : 0.0;
             double b = v.w - (v.x * org[0] + v.y * org[1] + (DIM == 3 ? v.z * org[2] : 0.0));
-            // rows of the initial state (:404-406) and rows with ||normal|| < 1e-5 (:409-411) are dropped
-            const bool dead = (cp < 3) || (sqrt(v.x * v.x + v.y * v.y + v.z * v.z) < 1e-5);
-            if (dead) {
+            if (sqrt(v.x * v.x + v.y * v.y + v.z * v.z) < 1e-5) {  // dropped like the reference does (:409-411)
                 nx = ny = nz = 0.0;
                 b = -1.0;
             }
@@ -288,86 +281,220 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             Rnz[e] = nz;
             Rb[e] = b;
         }
+        if (lane == 0) {  // the dead row
+            Rnx[NROW] = Rny[NROW] = Rnz[NROW] = 0.0;
+            Rb[NROW] = -1.0;
+        }
     }
-    // ---- initial point: every free control point at c2 of the first segment -------------------------------
-    for (int e = lane; e < NX; e += 64) {
-        const int k = e / P, cp = e % P;
-        c_[e] = (cp == 0) ? 0.0 : (cp == 1) ? cf1[k] : cf2[k];
-    }
-    if (zl) z_[lane] = cf2[zk];
     __syncthreads();
 
+    // ---- two-sided rows, one type per slot (registers) ----------------------------------------------------
+    // slot layout: [0,SI) interval | [SI,SI+SV) velocity | [..,+SA) acceleration | [..,+SC) communication pair
+    constexpr int NS2 = C::NS2;
+    int t_ix[NS2];                                      // x-space index of the row's first control point (-1: no row)
+    int t_i2[NS2];                                      // second index (comm pairs only)
+    double t_lo[NS2], t_hi[NS2];                        // bounds
+    double t_sl[NS2], t_sh[NS2], t_ll[NS2], t_lh[NS2];  // slack / multiplier of the lo and hi side
+    // Only (s, lambda) persist across the factorisation; residuals and directions of a row are recomputed in every
+    // pass from the x-space vectors (a handful of FMAs) instead of being kept live next to the matrix row A[].
+    {
+        const double rho_pair = 0.5 * cls.comm_range - H->radius;  // :484
+        const double rho_wp = 0.5 * cls.comm_range - 1e-5;         // :495
+        const bool comm_on = cls.comm_range > 0;
+#pragma unroll
+        for (int u = 0; u < NS2; u++) {
+            t_ix[u] = -1;
+            t_i2[u] = 0;
+            t_lo[u] = -1.0;
+            t_hi[u] = 1.0;
+            if (u < C::SI) {  // interval on one control point
+                const int e = lane + 64 * u;
+                if (e < NX) {
+                    const int k = e / P, cp = e % P, m = cp / 6;
+                    if (cp >= 3) {
+                        t_ix[u] = e;
+                        double lo = cls.world_min[k] - org[k], hi = cls.world_max[k] - org[k];  // :252-253,260-265
+                        if (cls.use_sfc) {                                                      // :372-397
+                            lo = fmax(lo, sfc[q * M + m].bmin[k] - org[k]);
+                            hi = fmin(hi, sfc[q * M + m].bmax[k] - org[k]);
+                        }
+                        if (comm_on && cp % 6 == 5) {  // pairs (m, mi=0) :482-487 and waypoint rows :494-497
+                            const double wpk = H->next_waypoint[k] - org[k];
+                            lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
+                            hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
+                        }
+                        t_lo[u] = lo;
+                        t_hi[u] = hi;
+                    }
+                }
+            } else if (u < C::SI + C::SV) {  // velocity (m,i): c[i+1]-c[i], |.| <= vmax dt/n   (:448-453)
+                const int v = lane + 64 * (u - C::SI);
+                if (v < C::NV) {
+                    const int k = v / (5 * M), r = v % (5 * M), m = r / 5, i = r % 5;
+                    if (!(m == 0 && i < 2)) {
+                        t_ix[u] = k * P + 6 * m + i;
+                        t_hi[u] = H->vmax[k] * dt * 0.2;
+                        t_lo[u] = -t_hi[u];
+                    }
+                }
+            } else if (u < C::SI + C::SV + C::SA) {  // acceleration (m,i): c[i+2]-2c[i+1]+c[i]   (:462-471)
+                const int a = lane + 64 * (u - C::SI - C::SV);
+                if (a < C::NA) {
+                    const int k = a / (4 * M), r = a % (4 * M), m = r / 4, i = r % 4;
+                    if (!(m == 0 && i < 1)) {
+                        t_ix[u] = k * P + 6 * m + i;
+                        t_hi[u] = H->amax[k] * dt * dt * 0.05;
+                        t_lo[u] = -t_hi[u];
+                    }
+                }
+            } else {  // pair (uu, up<uu): c[uu][5] - c[up+1][0]   (:482-487 with mi = up+1 >= 1)
+                const int cc = lane + 64 * (u - C::SI - C::SV - C::SA);
+                if (cc < C::NC && comm_on) {
+                    const int k = cc / C::NCP, ci = cc % C::NCP;
+                    int uu = 1;
+                    while (uu * (uu + 1) / 2 <= ci) uu++;
+                    const int up = ci - uu * (uu - 1) / 2;
+                    t_ix[u] = k * P + 6 * (up + 1);
+                    t_i2[u] = k * P + 6 * uu + 5;
+                    t_hi[u] = rho_pair;
+                    t_lo[u] = -rho_pair;
+                }
+            }
+        }
+    }
+    // value of the row's stencil on an x-space vector (slot type is compile-time)
+    auto row_val = [&](const double* v, int u) -> double {
+        const int ix = t_ix[u] < 0 ? 0 : t_ix[u];
+        if (u < C::SI) return v[ix];
+        if (u < C::SI + C::SV) return v[ix + 1] - v[ix];
+        if (u < C::SI + C::SV + C::SA) return v[ix + 2] - 2.0 * v[ix + 1] + v[ix];
+        return v[t_i2[u]] - v[ix];
+    };
+    auto row_scatter = [&](double* X, int u, double val) {
+        const int ix = t_ix[u];
+        if (u < C::SI) {
+            atomicAdd(&X[ix], val);
+        } else if (u < C::SI + C::SV) {
+            atomicAdd(&X[ix + 1], val);
+            atomicAdd(&X[ix], -val);
+        } else if (u < C::SI + C::SV + C::SA) {
+            atomicAdd(&X[ix + 2], val);
+            atomicAdd(&X[ix + 1], -2.0 * val);
+            atomicAdd(&X[ix], val);
+        } else {
+            atomicAdd(&X[t_i2[u]], val);
+            atomicAdd(&X[ix], -val);
+        }
+    };
+    auto om_index = [&](int u) -> int {  // where this slot's weight lives in om_
+        if (u < C::SI) return lane + 64 * u;
+        if (u < C::SI + C::SV) return C::OV + lane + 64 * (u - C::SI);
+        if (u < C::SI + C::SV + C::SA) return C::OA + lane + 64 * (u - C::SI - C::SV);
+        return C::OC + lane + 64 * (u - C::SI - C::SV - C::SA);
+    };
+    auto om_limit = [&](int u) -> int {
+        if (u < C::SI) return C::OV;
+        if (u < C::SI + C::SV) return C::OA;
+        if (u < C::SI + C::SV + C::SA) return C::OC;
+        return C::NOM;
+    };
+
+    // ---- initial slacks / multipliers ----------------------------------------------------------------------
     int status = LSCQP_STATUS_ITER_LIMIT;
     double m_tot = 0;
+    double r_s[NSLOT], r_l[NSLOT];    // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
     {
         double cnt = 0;
         bool bad = false;
 #pragma unroll
-        for (int u = 0; u < RPL; u++) {
-            r_slo[u] = r_shi[u] = 1.0;
-            r_llo[u] = r_lhi[u] = 0.0;
-            if (r_ty[u] >= 0) {
+        for (int u = 0; u < NS2; u++) {
+            t_sl[u] = t_sh[u] = 1.0;
+            t_ll[u] = t_lh[u] = 0.0;
+            if (t_ix[u] >= 0) {
                 const double y = row_val(c_, u);
-                if (r_lo[u] > r_hi[u]) bad = true;
-                if (r_lo[u] > -INFINITY) {
-                    r_slo[u] = fmax(y - r_lo[u], 1e-2);
-                    r_llo[u] = 1.0;
-                    cnt += 1;
-                }
-                if (r_hi[u] < INFINITY) {
-                    r_shi[u] = fmax(r_hi[u] - y, 1e-2);
-                    r_lhi[u] = 1.0;
-                    cnt += 1;
-                }
+                if (t_lo[u] > t_hi[u]) bad = true;
+                t_sl[u] = fmax(y - t_lo[u], 1e-2);
+                t_sh[u] = fmax(t_hi[u] - y, 1e-2);
+                t_ll[u] = t_lh[u] = 1.0;
+                cnt += 2.0;
             }
         }
-        for (int e = lane; e < nrow; e += 64) {
-            const int cp = e % P;
-            const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e];
-            const bool act = (nx != 0.0) || (ny != 0.0) || (nz != 0.0);
-            double r = nx * c_[cp] + ny * c_[P + cp] - Rb[e];
-            if (DIM == 3) r += nz * c_[2 * P + cp];
-            Rs[e] = act ? fmax(r, 1e-2) : 1.0;
-            Rl[e] = act ? 1.0 : 0.0;
-            cnt += act ? 1.0 : 0.0;
+        const double cx = ll ? c_[lx] : 0.0, cy = ll ? c_[P + lx] : 0.0, cz = (ll && DIM == 3) ? c_[2 * P + lx] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NSLOT; u++) {
+            r_s[u] = 1.0;
+            r_l[u] = 0.0;
+            const int o = lg + G * u;
+            if (ll && o < n_obs) {
+                const int e = o * CP + lcp;
+                const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e];
+                if ((nx != 0.0) || (ny != 0.0) || (nz != 0.0)) {
+                    r_s[u] = fmax(nx * cx + ny * cy + nz * cz - Rb[e], 1e-2);
+                    r_l[u] = 1.0;
+                    cnt += 1.0;
+                }
+            }
         }
         m_tot = wave_sum(cnt);
         if (__any(bad)) status = LSCQP_STATUS_INFEASIBLE;  // empty interval: lo > hi
     }
-    __syncthreads();
+    const double inv_m = 1.0 / m_tot;
 
     // objective exactly as cplex.getObjValue() reports it (src/traj_optimizer.cpp:100): jerk cost
     //   x'(w_c Q)x == w_c * 3600 dt^-5 * sum_seg (D3 c)' MB (D3 c)   (third differences: no cancellation)
-    // plus the terminal cost including its constant goal^2 term (:301-316).  Translation invariant.
+    // plus the terminal cost including its constant goal^2 term (:301-316).  Translation invariant; the optional
+    // world-frame correction restores the reference's own coefficient rounding (O(1e-9 |x|^2)).  Branch-free.
     auto objective = [&](bool ref_rounding) -> double {
-        double part = 0;
-        if (lane < DIM * M) {
-            const int k = lane / M, m = lane % M;
-            const double* cc = &c_[k * P + 6 * m];
-            const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
-            const double j1 = (cc[4] - cc[1]) - 3.0 * (cc[3] - cc[2]);
-            const double j2 = (cc[5] - cc[2]) - 3.0 * (cc[4] - cc[3]);
-            const double quad =
-                0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
-            const double dt2 = dt * dt;
-            part = cls.w_c * 3600.0 / (dt2 * dt2 * dt) * quad;
-            if (ref_rounding) {  // world-frame correction, O(1e-9): negligible rounding of its own
-                double corr = 0;
+        const bool on = lane < DIM * M;
+        const int k = on ? lane / M : 0, m = on ? lane % M : 0;
+        const double* cc = &c_[k * P + 6 * m];
+        const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
+        const double j1 = (cc[4] - cc[1]) - 3.0 * (cc[3] - cc[2]);
+        const double j2 = (cc[5] - cc[2]) - 3.0 * (cc[4] - cc[3]);
+        const double quad =
+            0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
+        double part = 0.5 * q2s * 3600.0 * quad;
+        if (ref_rounding) {  // compile-time constant at both call sites
+            const double ok_ = (k == 0) ? org[0] : (k == 1) ? org[1] : org[2];
+            double corr = 0;
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    double r = 0;
+            for (int i = 0; i < 6; i++) {
+                double r = 0;
 #pragma unroll
-                    for (int ip = 0; ip < 6; ip++) r += cls.dQ[i * 6 + ip] * (cc[ip] + org[k]);
-                    corr += r * (cc[i] + org[k]);
-                }
-                part += cls.w_c * corr;
+                for (int ip = 0; ip < 6; ip++) r += cls.dQ[i * 6 + ip] * (cc[ip] + ok_);
+                corr += r * (cc[i] + ok_);
             }
-            if (m >= M - ts) {
-                const double dgoal = cc[5] - goal[k];
-                part += cls.w_t * dgoal * dgoal;
-            }
+            part += cls.w_c * corr;
         }
-        return wave_sum(part);
+        const double gk = (k == 0) ? goal[0] : (k == 1) ? goal[1] : goal[2];
+        const double dgoal = cc[5] - gk;
+        part += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
+        return wave_sum(on ? part : 0.0);
+    };
+    // gather an x-space vector into the own z component: (T' v)_r.  Lanes without a next segment read the clamped
+    // segment with zero weights; non-z lanes compute a value that is never used.
+    const int gbase = zk * P + 6 * zm;
+    const int gnext = zk * P + 6 * (has_next ? zm + 1 : zm);
+    auto gatherT = [&](const double* X) -> double {
+        const double* xs = &X[gbase];
+        const double* xn = &X[gnext];
+        return e0 * xs[3] + e1 * xs[4] + e2 * xs[5] + tb0 * xn[0] + tb1 * xn[1] + tb2 * xn[2];
+    };
+    // x-space vector = T * (z-space vector in LDS), all NX entries, branch-free
+    auto expandT = [&](const double* zsrc, double* out, bool keep_fixed) {
+#pragma unroll
+        for (int t = 0; t < (NX + 63) / 64; t++) {
+            const int e0_ = lane + 64 * t;
+            const bool on = e0_ < NX;
+            const int e = on ? e0_ : 0;
+            const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
+            const double vhi = zsrc[k * NZA + zidx(m, i >= 3 ? i - 3 : 0)];
+            const double* zz = &zsrc[k * NZA + 3 * (m >= 1 ? m - 1 : 0)];
+            const double vlo = TBc(i < 3 ? i : 0, 0) * zz[0] + TBc(i < 3 ? i : 0, 1) * zz[1] + TBc(i < 3 ? i : 0, 2) * zz[2];
+            const double v = (i >= 3) ? vhi : ((m >= 1) ? vlo : 0.0);
+            const bool wr = on && !(keep_fixed && cp < 3);  // the initial state (p0,v0,a0) is never touched
+            if (wr) out[e] = v;
+        }
     };
 
     double A[NZ];  // row `lane` of the reduced KKT matrix, then its LDL^T factors
@@ -375,133 +502,153 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     double res_p = 0, res_d = 0, res_gap = 0;
     int it = 0;
     const double tol = cls.tol;
+    const bool comm_on_k = cls.comm_range > 0;
+    // row of the scratch matrix this lane assembles into: non-z lanes share one dummy row that is never read
+    double* const hrow = &Hs[(zl ? lane : NZ) * LDH];
+#ifdef LSCQP_PHASE_TIMING
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
 
+    // THE LOOP BODY IS WRITTEN WITHOUT DIVERGENT REGIONS.  Every lane owns persistent state in registers (matrix row,
+    // row slacks/multipliers); hipcc spills such state around large divergent regions with exec-masked stores, so the
+    // lanes that are inactive inside the region (z lanes that own no LSC control point, LSC lanes that are no z lane,
+    // ...) would get garbage back.  Inactive rows are therefore masked arithmetically (dead LDS row, zero weights,
+    // selects) and only single LDS stores / atomics are predicated.
     if (status != LSCQP_STATUS_INFEASIBLE)
         for (it = 0; it < cls.max_iter; it++) {
+            LSCQP_T(0);
+            LSCQP_STOP(1)
             // ============ pass 1: residuals, weights, per-cp blocks =========================================
-            for (int e = lane; e < 4 * NX + 6 * P; e += 64) smem[C::o_x0 + e] = 0.0;  // XL,XA,XB1,XB2,S
-            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < (4 * NX + 6 * P + 63) / 64; t++) {
+                const int e = lane + 64 * t;
+                if (e < 4 * NX + 6 * P) smem[C::o_x0 + e] = 0.0;  // XL,XA,XB1,XB2,S
+            }
+            LSCQP_WAVE_LDS_SYNC();
             double sum_sl = 0, sum_pinf = 0, max_rp = 0;
 #pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                if (r_ty[u] >= 0) {
-                    const double y = row_val(c_, u);
-                    const double rplo = (y - r_lo[u]) - r_slo[u], rphi = (r_hi[u] - y) - r_shi[u];
-                    const bool flo = r_lo[u] > -INFINITY, fhi = r_hi[u] < INFINITY;
-                    const double wlo = flo ? r_llo[u] / r_slo[u] : 0.0, whi = fhi ? r_lhi[u] / r_shi[u] : 0.0;
-                    if (flo) {
-                        sum_sl += r_slo[u] * r_llo[u];
-                        sum_pinf += r_llo[u] * fabs(rplo);
-                        max_rp = fmax(max_rp, fabs(rplo));
-                    }
-                    if (fhi) {
-                        sum_sl += r_shi[u] * r_lhi[u];
-                        sum_pinf += r_lhi[u] * fabs(rphi);
-                        max_rp = fmax(max_rp, fabs(rphi));
-                    }
-                    om_[lane + 64 * u] = wlo + whi;
-                    row_scatter(XL, u, r_llo[u] - r_lhi[u]);
-                    row_scatter(XA, u, -(flo ? wlo * rplo : 0.0) + (fhi ? whi * rphi : 0.0));
-                } else if (lane + 64 * u < NR2) {
-                    om_[lane + 64 * u] = 0.0;
-                }
+            for (int u = 0; u < NS2; u++) {
+                const bool on = t_ix[u] >= 0;  // rows that do not exist carry s = 1, lambda = 0, lo = -1, hi = 1
+                const double y = row_val(c_, u);
+                const double rpl = on ? (y - t_lo[u]) - t_sl[u] : 0.0, rph = on ? (t_hi[u] - y) - t_sh[u] : 0.0;
+                const double isl = fast_rcp(t_sl[u]), ish = fast_rcp(t_sh[u]);
+                const double wl = t_ll[u] * isl, wh = t_lh[u] * ish;
+                sum_sl += t_sl[u] * t_ll[u] + t_sh[u] * t_lh[u];
+                sum_pinf += t_ll[u] * fabs(rpl) + t_lh[u] * fabs(rph);
+                max_rp = fmax(max_rp, fmax(fabs(rpl), fabs(rph)));
+                if (on) row_scatter(XL, u, t_ll[u] - t_lh[u]);
+                if (on) row_scatter(XA, u, wh * rph - wl * rpl);
+                if (om_index(u) < om_limit(u)) om_[om_index(u)] = wl + wh;
             }
-            if (lane < G * P) {  // LSC rows: lane = g*P + cp, obstacles o = g, g+G, ...
-                const int g = lane / P, cp = lane % P;
+            {
                 double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0, l0 = 0, l1 = 0, l2 = 0, a0 = 0, a1 = 0, a2 = 0;
-                const double cx = c_[cp], cy = c_[P + cp], cz = (DIM == 3) ? c_[2 * P + cp] : 0.0;
-                for (int o = g; o < n_obs; o += G) {
-                    const int e = o * P + cp;
-                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = Rs[e], lam = Rl[e];
+                const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+#pragma unroll
+                for (int u = 0; u < NSLOT; u++) {
+                    const int o = lg + G * u;
+                    // slots without a row read the dead row kept at index NROW (n = 0, b = -1; their s = 1, l = 0),
+                    // which contributes exact zeros everywhere
+                    const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
+                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u], lam = r_l[u];
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
-                    const double w = lam / s;
+                    const double is = fast_rcp(s);
+                    const double w = lam * is;
                     sum_sl += s * lam;
                     sum_pinf += lam * fabs(rp);
-                    max_rp = fmax(max_rp, lam > 0.0 ? fabs(rp) : 0.0);
-                    s00 += w * nx * nx; s01 += w * nx * ny; s02 += w * nx * nz;
-                    s11 += w * ny * ny; s12 += w * ny * nz; s22 += w * nz * nz;
-                    l0 += lam * nx; l1 += lam * ny; l2 += lam * nz;
+                    max_rp = fmax(max_rp, fabs(rp));
+                    const double wx = w * nx, wy = w * ny, wz = w * nz;
+                    s00 += wx * nx; s01 += wx * ny; s11 += wy * ny;
+                    l0 += lam * nx; l1 += lam * ny;
                     const double qa = -w * rp;
-                    a0 += qa * nx; a1 += qa * ny; a2 += qa * nz;
-                }
-                atomicAdd(&S_[cp * 6 + 0], s00); atomicAdd(&S_[cp * 6 + 1], s01); atomicAdd(&S_[cp * 6 + 3], s11);
-                atomicAdd(&XL[cp], l0); atomicAdd(&XL[P + cp], l1);
-                atomicAdd(&XA[cp], a0); atomicAdd(&XA[P + cp], a1);
-                if (DIM == 3) {
-                    atomicAdd(&S_[cp * 6 + 2], s02); atomicAdd(&S_[cp * 6 + 4], s12); atomicAdd(&S_[cp * 6 + 5], s22);
-                    atomicAdd(&XL[2 * P + cp], l2);
-                    atomicAdd(&XA[2 * P + cp], a2);
+                    a0 += qa * nx; a1 += qa * ny;
+                    if (DIM == 3) {
+                        s02 += wx * nz; s12 += wy * nz; s22 += wz * nz;
+                        l2 += lam * nz;
+                        a2 += qa * nz;
+                    }
+                    }
+                const int cp6 = lx * 6;
+                if (ll) {
+                    atomicAdd(&S_[cp6 + 0], s00); atomicAdd(&S_[cp6 + 1], s01); atomicAdd(&S_[cp6 + 3], s11);
+                    atomicAdd(&XL[lx], l0); atomicAdd(&XL[P + lx], l1);
+                    atomicAdd(&XA[lx], a0); atomicAdd(&XA[P + lx], a1);
+                    if (DIM == 3) {
+                        atomicAdd(&S_[cp6 + 2], s02); atomicAdd(&S_[cp6 + 4], s12); atomicAdd(&S_[cp6 + 5], s22);
+                        atomicAdd(&XL[2 * P + lx], l2);
+                        atomicAdd(&XA[2 * P + lx], a2);
+                    }
                 }
             }
-            sum_sl = wave_sum(sum_sl);
-            sum_pinf = wave_sum(sum_pinf);
-            max_rp = wave_max(max_rp);
-            const double mu = sum_sl / m_tot;
-            __syncthreads();
+            wave_sum2_max1(sum_sl, sum_pinf, max_rp);
+            const double mu = sum_sl * inv_m;
+            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_T(1);
+            LSCQP_STOP(2)
 
-            // ============ cost gradient in x-space, z-space residual ========================================
+            // ============ cost gradient gathered into z-space, residual norms, convergence ====================
             // gx[k][cp] = sum_i' Q2[i][i'] c[m][i'] + 2 w_t (c[m][5] - goal) [terminal segments]  (:285-316)
-            auto cost_grad = [&](int k, int cp) -> double {
-                const int m = cp / 6, i = cp % 6;
-                const double* cc = &c_[k * P + 6 * m];
-                double g = 0;
+            double gcost, gl, ga;
+            {
+                const double gk = (zk == 0) ? goal[0] : (zk == 1) ? goal[1] : goal[2];
+                const double* cs = &c_[gbase];
+                const double* cn = &c_[gnext];
+                double g3 = 0, g4 = 0, g5 = 0, h0 = 0, h1 = 0, h2 = 0;
 #pragma unroll
-                for (int ip = 0; ip < 6; ip++) g += cls.Q2[i * 6 + ip] * cc[ip];
-                if (i == 5 && m >= M - ts) g += 2.0 * cls.w_t * (cc[5] - goal[k]);
-                return g;
-            };
-            // gather x-space vector -> own z component:  (T' v)_r
-            auto gatherT = [&](auto&& xs) -> double {
-                const int b0 = zk * P + 6 * zm;
-                double v = e0 * xs(zk, 6 * zm + 3) + e1 * xs(zk, 6 * zm + 4) + e2 * xs(zk, 6 * zm + 5);
-                (void)b0;
-                if (has_next) v += tb0 * xs(zk, 6 * (zm + 1) + 0) + tb1 * xs(zk, 6 * (zm + 1) + 1) + tb2 * xs(zk, 6 * (zm + 1) + 2);
-                return v;
-            };
-            double gcost = 0, gl = 0, ga = 0;
-            if (zl) {
-                gcost = gatherT([&](int k, int cp) { return cost_grad(k, cp); });
-                gl = gatherT([&](int k, int cp) { return XL[k * P + cp]; });
-                ga = gatherT([&](int k, int cp) { return XA[k * P + cp]; });
+                for (int ip = 0; ip < 6; ip++) {
+                    g3 += KQ(3, ip) * cs[ip]; g4 += KQ(4, ip) * cs[ip]; g5 += KQ(5, ip) * cs[ip];
+                    h0 += KQ(0, ip) * cn[ip]; h1 += KQ(1, ip) * cn[ip]; h2 += KQ(2, ip) * cn[ip];
+                }
+                g5 = q2s * g5 + ((zm >= M - ts) ? wt2 * (cs[5] - gk) : 0.0);
+                gcost = e0 * (q2s * g3) + e1 * (q2s * g4) + e2 * g5 + q2s * (tb0 * h0 + tb1 * h1 + tb2 * h2);
+                gl = gatherT(XL);
+                ga = gatherT(XA);
+                gcost = zl ? gcost : 0.0;
+                gl = zl ? gl : 0.0;
+                ga = zl ? ga : 0.0;
             }
-            const double rd_own = zl ? (gcost - gl) : 0.0;
-            const double rdn = wave_max(fabs(rd_own));
-            const double gls = fmax(1.0, wave_max(fmax(fabs(gcost), fabs(gl))));
+            double rdn = fabs(gcost - gl);
+            double gls = fmax(fabs(gcost), fabs(gl));
+            wave_max2(rdn, gls);
+            gls = fmax(1.0, gls);
             res_p = max_rp;
             res_d = rdn / gls;
-            const double objcur = objective(false);
-            res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objcur));
             // stop: primal residual (metres), scaled stationarity, and duality gap + multiplier-weighted primal
             // residual in objective units (the latter is what bounds the objective error to first order)
-            if (max_rp <= 1e-9 && rdn <= 10.0 * tol * gls && res_gap <= tol) {
-                status = LSCQP_STATUS_OPTIMAL;
-                break;
-            }
+            if (max_rp <= 1e-9 && rdn <= 10.0 * tol * gls) {  // wave-uniform
+                res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false)));
+                if (res_gap <= tol) {
+                    status = LSCQP_STATUS_OPTIMAL;
+                    break;
+                }
+            } else
+                res_gap = sum_sl + sum_pinf;
+            LSCQP_T(2);
+            LSCQP_STOP(3)
 
-            // ============ assemble own row of Hred = T'(H + G'WG)T into the LDS scratch row ==================
-            if (zl) {
-                double* hrow = &Hs[lane * LDH];
-#pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = 0.0;
-                // local 6x6 block (upper triangle) of (axis zk, segment m)
+            // ============ assemble own row of Hred = T'(H + G'WG)T ==========================================
+            {
+                const int sd = (zk == 0) ? 0 : (zk == 1) ? 3 : 5;  // S diagonal entry of axis zk
+                // local 6x6 block (upper triangle) of (axis zk, segment m): 2 w_c Q + terminal + interval/vel/acc
+                // weights + the LSC same-axis diagonal
                 auto local_block = [&](int m, double (&B)[6][6]) {
 #pragma unroll
                     for (int i = 0; i < 6; i++)
 #pragma unroll
-                        for (int ip = i; ip < 6; ip++) B[i][ip] = cls.Q2[i * 6 + ip];
-                    if (m >= M - ts) B[5][5] += 2.0 * cls.w_t;
-                    const double* omk = &om_[zk * NRA];
-                    const int sd = (zk == 0) ? 0 : (zk == 1) ? 3 : 5;  // S diagonal entry of axis zk
+                        for (int ip = i; ip < 6; ip++) B[i][ip] = q2s * KQ(i, ip);
+                    B[5][5] += (m >= M - ts) ? wt2 : 0.0;
+                    const double* omi = &om_[zk * P + 6 * m];
+                    const double* omv = &om_[C::OV + zk * 5 * M + 5 * m];
+                    const double* oma = &om_[C::OA + zk * 4 * M + 4 * m];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) B[i][i] += omk[6 * m + i] + S_[(6 * m + i) * 6 + sd];
+                    for (int i = 0; i < 6; i++) B[i][i] += omi[i] + S_[(6 * m + i) * 6 + sd];
 #pragma unroll
                     for (int i = 0; i < 5; i++) {
-                        const double w = omk[C::OV + 5 * m + i];
+                        const double w = omv[i];
                         B[i][i] += w; B[i + 1][i + 1] += w; B[i][i + 1] -= w;
                     }
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const double w = omk[C::OA + 4 * m + i];
+                        const double w = oma[i];
                         B[i][i] += w; B[i][i + 1] -= 2.0 * w; B[i][i + 2] += w;
                         B[i + 1][i + 1] += 4.0 * w; B[i + 1][i + 2] -= 2.0 * w; B[i + 2][i + 2] += w;
                     }
@@ -509,101 +656,109 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 auto sym = [](const double (&B)[6][6], int i, int ip) -> double { return i <= ip ? B[i][ip] : B[ip][i]; };
                 const double ej[3] = {e0, e1, e2};
                 const double tbj[3] = {tb0, tb1, tb2};
-                double Bm[6][6];
-                local_block(zm, Bm);
-                // own segment columns (zm, j')
+                const int mn = has_next ? zm + 1 : zm;  // clamped: its weights tb* are zero when there is no next
+                double own[3], prv[3], nxt[3];
+                {
+                    double Bm[6][6];
+                    local_block(zm, Bm);
+                    double bi[3];
 #pragma unroll
-                for (int jp = 0; jp < 3; jp++) {
-                    double v = 0;
-#pragma unroll
-                    for (int j = 0; j < 3; j++) v += ej[j] * sym(Bm, 3 + j, 3 + jp);
-                    hrow[zk * NZA + zidx(zm, jp)] += v;
-                }
-                // previous segment columns (zm-1, j'): c[zm][i] = sum_j' TB[i][j'] z(zm-1, j')
-                if (zm >= 1) {
+                    for (int i = 0; i < 3; i++) bi[i] = ej[0] * sym(Bm, i, 3) + ej[1] * sym(Bm, i, 4) + ej[2] * sym(Bm, i, 5);
 #pragma unroll
                     for (int jp = 0; jp < 3; jp++) {
-                        double v = 0;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) {
-                            double bi = 0;
-#pragma unroll
-                            for (int j = 0; j < 3; j++) bi += ej[j] * sym(Bm, i, 3 + j);
-                            v += LSCQP_TB(i, jp) * bi;
-                        }
-                        hrow[zk * NZA + zidx(zm - 1, jp)] += v;
+                        own[jp] = ej[0] * sym(Bm, 3, 3 + jp) + ej[1] * sym(Bm, 4, 3 + jp) + ej[2] * sym(Bm, 5, 3 + jp);
+                        prv[jp] = TBc(0, jp) * bi[0] + TBc(1, jp) * bi[1] + TBc(2, jp) * bi[2];
                     }
                 }
-                if (has_next) {
+                {
                     double Bn[6][6];
-                    local_block(zm + 1, Bn);
-                    double ta[3];  // ta[i'] = sum_i tbj[i] Bn[i][i']
+                    local_block(mn, Bn);
+                    double ta[3];
 #pragma unroll
-                    for (int ip = 0; ip < 3; ip++) {
-                        ta[ip] = 0;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) ta[ip] += tbj[i] * sym(Bn, i, ip);
-                    }
+                    for (int ip = 0; ip < 3; ip++) ta[ip] = tbj[0] * sym(Bn, 0, ip) + tbj[1] * sym(Bn, 1, ip) + tbj[2] * sym(Bn, 2, ip);
 #pragma unroll
                     for (int jp = 0; jp < 3; jp++) {
-                        double v = 0;
-#pragma unroll
-                        for (int ip = 0; ip < 3; ip++) v += ta[ip] * LSCQP_TB(ip, jp);
-                        hrow[zk * NZA + zidx(zm, jp)] += v;
-                        double v2 = 0;
-#pragma unroll
-                        for (int i = 0; i < 3; i++) v2 += tbj[i] * sym(Bn, i, 3 + jp);
-                        hrow[zk * NZA + zidx(zm + 1, jp)] += v2;
+                        own[jp] += ta[0] * TBc(0, jp) + ta[1] * TBc(1, jp) + ta[2] * TBc(2, jp);
+                        nxt[jp] = tbj[0] * sym(Bn, 0, 3 + jp) + tbj[1] * sym(Bn, 1, 3 + jp) + tbj[2] * sym(Bn, 2, 3 + jp);
                     }
                 }
+                // stores: every iteration overwrites exactly the same pattern entries, the rest of the row stays 0.
+                // Merged columns (the single end-stop variable) receive the sum.
+                double* hk = &hrow[zk * NZA];
+                const bool nlast = ES && has_next && (zm + 1 == M - 1);  // the next block is the end-stop variable
+                const double osum = own[0] + own[1] + own[2], nsum = nxt[0] + nxt[1] + nxt[2];
+                const int ob = zlast ? 3 * (M - 1) : 3 * zm;
+                hk[ob] = zlast ? osum : own[0];
+                if (!zlast) hk[ob + 1] = own[1];
+                if (!zlast) hk[ob + 2] = own[2];
+                const int pb = 3 * (zm >= 1 ? zm - 1 : 0);
+                if (zm >= 1) hk[pb + 0] = prv[0];
+                if (zm >= 1) hk[pb + 1] = prv[1];
+                if (zm >= 1) hk[pb + 2] = prv[2];
+                const int nb = nlast ? 3 * (M - 1) : 3 * mn;
+                if (has_next) hk[nb] = nlast ? nsum : nxt[0];
+                if (has_next && !nlast) hk[nb + 1] = nxt[1];
+                if (has_next && !nlast) hk[nb + 2] = nxt[2];
                 // cross-axis blocks come only from the LSC rows, block-diagonal in the segment index
 #pragma unroll
                 for (int l = 0; l < DIM; l++) {
-                    if (l == zk) continue;
                     const int a_ = zk < l ? zk : l, b_ = zk < l ? l : zk;
-                    const int so = (a_ == 0) ? b_ : 4;  // (0,1)->1 (0,2)->2 (1,2)->4
+                    const int so = (a_ == 0) ? (b_ == 0 ? 0 : b_) : (b_ == 1 ? 3 : 4);  // (0,1)->1 (0,2)->2 (1,2)->4
+                    double cr[3];
 #pragma unroll
-                    for (int jp = 0; jp < 3; jp++) {
-                        double v = ej[jp] * S_[(6 * zm + 3 + jp) * 6 + so];
-                        if (has_next) {
-#pragma unroll
-                            for (int i = 0; i < 3; i++) v += tbj[i] * LSCQP_TB(i, jp) * S_[(6 * (zm + 1) + i) * 6 + so];
-                        }
-                        hrow[l * NZA + zidx(zm, jp)] += v;
-                    }
+                    for (int jp = 0; jp < 3; jp++)
+                        cr[jp] = ej[jp] * S_[(6 * zm + 3 + jp) * 6 + so] + tbj[0] * TBc(0, jp) * S_[(6 * mn + 0) * 6 + so] +
+                                 tbj[1] * TBc(1, jp) * S_[(6 * mn + 1) * 6 + so] + tbj[2] * TBc(2, jp) * S_[(6 * mn + 2) * 6 + so];
+                    double* hl = &hrow[l * NZA];
+                    const bool wr = (l != zk);
+                    if (wr) hl[ob] = zlast ? (cr[0] + cr[1] + cr[2]) : cr[0];
+                    if (wr && !zlast) hl[ob + 1] = cr[1];
+                    if (wr && !zlast) hl[ob + 2] = cr[2];
                 }
-                // communication pairs couple the c5 variables of one axis
-                if (zlast || zj == 2) {
-                    const double* omc = &om_[zk * NRA + C::OC];
+                // communication pairs couple the c5 variables of one axis: adjacent ones land on band entries
+                // (read-modify-write after the stores above, LDS is in order), far ones are plain stores
+                {
+                    const bool c5 = (zlast || zj == 2) && comm_on_k;
+                    const double* omc = &om_[C::OC + zk * C::NCP];
+                    double dsum = 0;
+#pragma unroll
                     for (int up = 0; up < M; up++) {
-                        if (up == zm) continue;
+                        const bool use = c5 && (up != zm);
                         const int hi_ = zm > up ? zm : up, lo_ = zm > up ? up : zm;
-                        const double w = omc[hi_ * (hi_ - 1) / 2 + lo_];
-                        hrow[lane] += w;
-                        hrow[zk * NZA + zidx(up, 2)] -= w;
+                        const double w = use ? omc[hi_ * (hi_ - 1) / 2 + (use ? lo_ : 0)] : 0.0;
+                        dsum += w;
+                        double* t = &hk[zidx(up, 2)];
+                        const bool near = (up == zm - 1) || (up == zm + 1);
+                        const double old = *t;
+                        if (use) *t = near ? (old - w) : -w;
                     }
+                    hrow[zl ? lane : 0] += dsum;  // dsum == 0 for lanes that are not c5 variables
                 }
+                LSCQP_WAVE_LDS_SYNC();
 #pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) A[cidx] = hrow[cidx];
-            } else {
-#pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) A[cidx] = 0.0;
+                for (int cidx = 0; cidx < NZ; cidx++) {
+                    const double v = hrow[cidx];
+                    A[cidx] = zl ? v : 0.0;
+                }
             }
+            LSCQP_T(3);
+            LSCQP_STOP(4)
 
-            // ============ LDL^T in registers: lane i holds row i; pivot row broadcast by v_readlane ==========
+            // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
 #pragma unroll
             for (int j = 0; j < NZ; j++) {
+                // pivot row of lane j broadcast with v_readlane (2 per fp64 value)
                 const double d = bcast(A[j], j);
-                if (!(d > 1e-300)) pivot_bad = true;
+                pivot_bad = pivot_bad || !(d > 1e-300);
                 const double invd = fast_rcp(d);
-                if (lane == j) dinv_own = invd;
+                dinv_own = (lane == j) ? invd : dinv_own;
                 const double li = (lane > j) ? A[j] * invd : 0.0;
 #pragma unroll
                 for (int kk = j + 1; kk < NZ; kk++) A[kk] = fma(-li, bcast(A[kk], j), A[kk]);
-                if (lane > j) A[j] = li;
+                A[j] = (lane > j) ? li : A[j];
             }
-            if (pivot_bad) {
+            if (pivot_bad) {  // wave-uniform
                 status = LSCQP_STATUS_NUMERIC;
                 break;
             }
@@ -611,215 +766,195 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 #pragma unroll
                 for (int j = 0; j < NZ; j++) {  // L w = b (unit lower)
                     const double wj = bcast(b, j);
-                    if (lane > j) b = fma(-A[j], wj, b);
+                    b = fma(-((lane > j) ? A[j] : 0.0), wj, b);
                 }
                 double x = 0;
 #pragma unroll
                 for (int j = NZ - 1; j >= 0; j--) {  // (D L') x = w : row i of the upper factor is A[j>i] of lane i
                     const double xj = bcast(b * dinv_own, j);
-                    if (lane == j) x = xj;
-                    if (lane < j) b = fma(-A[j], xj, b);
+                    x = (lane == j) ? xj : x;
+                    b = fma(-((lane < j) ? A[j] : 0.0), xj, b);
                 }
                 return x;
             };
+            LSCQP_T(4);
+            LSCQP_STOP(5)
 
             // ============ predictor ========================================================================
-            const double dza = solve(zl ? (-gcost + ga) : 0.0);
+            const double dza = solve(-gcost + ga);
             if (zl) dz_[lane] = dza;
-            __syncthreads();
-            // x-space direction  dc = T dz
-            auto expandT = [&](double* out) {
-                for (int e = lane; e < NX; e += 64) {
-                    const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
-                    double v = 0;
-                    if (i >= 3) v = dz_[k * NZA + zidx(m, i - 3)];
-                    else if (m >= 1) {
-                        const double* zz = &dz_[k * NZA + 3 * (m - 1)];
-                        v = LSCQP_TB(i, 0) * zz[0] + LSCQP_TB(i, 1) * zz[1] + LSCQP_TB(i, 2) * zz[2];
-                    }
-                    out[e] = v;
-                }
-            };
-            expandT(dca_);
-            __syncthreads();
-            // ============ pass 2: affine step length, mu_aff, corrector right-hand side ======================
-            double amin = 1e300, sA = 0, sB = 0;  // sum(s dl + l ds), sum(ds dl)
+            // park the factor in the lane's scratch-matrix row while pass 2 runs: A[] is then dead across the pass,
+            // which removes most register spills of the pass
 #pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                if (r_ty[u] >= 0) {
-                    const double y = row_val(c_, u), dy = row_val(dca_, u);
-                    double t1 = 0, t2 = 0;
-                    if (r_lo[u] > -INFINITY) {
-                        const double s = r_slo[u], l = r_llo[u], rp = (y - r_lo[u]) - s, w = l / s;
-                        const double ds = dy + rp, dl = -l - w * ds;
-                        if (ds < 0) amin = fmin(amin, -s / ds);
-                        if (dl < 0) amin = fmin(amin, -l / dl);
-                        sA += s * dl + l * ds;
-                        sB += ds * dl;
-                        const double is = 1.0 / s;
-                        t1 += is;
-                        t2 += -ds * dl * is - w * rp;
-                    }
-                    if (r_hi[u] < INFINITY) {
-                        const double s = r_shi[u], l = r_lhi[u], rp = (r_hi[u] - y) - s, w = l / s;
-                        const double ds = -dy + rp, dl = -l - w * ds;
-                        if (ds < 0) amin = fmin(amin, -s / ds);
-                        if (dl < 0) amin = fmin(amin, -l / dl);
-                        sA += s * dl + l * ds;
-                        sB += ds * dl;
-                        const double is = 1.0 / s;
-                        t1 -= is;
-                        t2 -= -ds * dl * is - w * rp;
-                    }
-                    row_scatter(XB1, u, t1);
-                    row_scatter(XB2, u, t2);
-                }
+            for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
+            LSCQP_WAVE_LDS_SYNC();
+            expandT(dz_, dca_, false);
+            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_T(5);
+            LSCQP_STOP(6)
+            // ============ pass 2: affine step length, mu_aff, corrector right-hand side ======================
+            // with w = lam/s, ds = G dc + rp, dl = -lam - w ds:   -ds/s = -t,  -dl/lam = 1 + t,  t = ds/s
+            double rmax = 1.0, sB = 0;  // rmax = 1/alpha_aff (>= 1 caps alpha at 1)
+#pragma unroll
+            for (int u = 0; u < NS2; u++) {
+                const bool on = t_ix[u] >= 0;
+                const double y = row_val(c_, u), dy = row_val(dca_, u);
+                const double rpl = (y - t_lo[u]) - t_sl[u], rph = (t_hi[u] - y) - t_sh[u];
+                const double isl = fast_rcp(t_sl[u]), ish = fast_rcp(t_sh[u]);
+                const double tl = (dy + rpl) * isl, th = (rph - dy) * ish;
+                const double rr = fmax(fmax(-tl, 1.0 + tl), fmax(-th, 1.0 + th));
+                rmax = fmax(rmax, on ? rr : 1.0);
+                const double pl = -(dy + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dy) * t_lh[u] * (1.0 + th);
+                sB += on ? (pl + ph) : 0.0;
+                const double v1 = isl - ish;
+                const double v2 = (-pl - t_ll[u] * rpl) * isl - (-ph - t_lh[u] * rph) * ish;
+                if (on) row_scatter(XB1, u, v1);
+                if (on) row_scatter(XB2, u, v2);
             }
-            if (lane < G * P) {
-                const int g = lane / P, cp = lane % P;
+            {
                 double b10 = 0, b11 = 0, b12 = 0, b20 = 0, b21 = 0, b22 = 0;
-                const double cx = c_[cp], cy = c_[P + cp], cz = (DIM == 3) ? c_[2 * P + cp] : 0.0;
-                const double dx = dca_[cp], dy = dca_[P + cp], dzz = (DIM == 3) ? dca_[2 * P + cp] : 0.0;
-                for (int o = g; o < n_obs; o += G) {
-                    const int e = o * P + cp;
-                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = Rs[e], l = Rl[e];
-                    if (l > 0.0) {
-                        const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s, w = l / s;
-                        const double ds = (nx * dx + ny * dy + nz * dzz) + rp, dl = -l - w * ds;
-                        if (ds < 0) amin = fmin(amin, -s / ds);
-                        if (dl < 0) amin = fmin(amin, -l / dl);
-                        sA += s * dl + l * ds;
-                        sB += ds * dl;
-                        const double is = 1.0 / s, t2 = -ds * dl * is - w * rp;
-                        b10 += is * nx; b11 += is * ny; b12 += is * nz;
-                        b20 += t2 * nx; b21 += t2 * ny; b22 += t2 * nz;
+                const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+                const double dx = dca_[lx], dy = dca_[P + lx], dzz = (DIM == 3) ? dca_[2 * P + lx] : 0.0;
+#pragma unroll
+                for (int u = 0; u < NSLOT; u++) {
+                    const int o = lg + G * u;
+                    const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
+                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u], l = r_l[u];
+                    const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
+                    const double is = fast_rcp(s);
+                    const double ds = (nx * dx + ny * dy + nz * dzz) + rp;
+                    const double t = ds * is;
+                    rmax = fmax(rmax, (l > 0.0) ? fmax(-t, 1.0 + t) : 1.0);
+                    const double pa = -ds * l * (1.0 + t);  // ds_a * dl_a
+                    sB += pa;
+                    const double t2 = (-pa - l * rp) * is;  // -ds dl/s - w rp
+                    b10 += is * nx; b11 += is * ny;
+                    b20 += t2 * nx; b21 += t2 * ny;
+                    if (DIM == 3) {
+                        b12 += is * nz;
+                        b22 += t2 * nz;
+                    }
+                    }
+                if (ll) {
+                    atomicAdd(&XB1[lx], b10); atomicAdd(&XB1[P + lx], b11);
+                    atomicAdd(&XB2[lx], b20); atomicAdd(&XB2[P + lx], b21);
+                    if (DIM == 3) {
+                        atomicAdd(&XB1[2 * P + lx], b12);
+                        atomicAdd(&XB2[2 * P + lx], b22);
                     }
                 }
-                atomicAdd(&XB1[cp], b10); atomicAdd(&XB1[P + cp], b11);
-                atomicAdd(&XB2[cp], b20); atomicAdd(&XB2[P + cp], b21);
-                if (DIM == 3) {
-                    atomicAdd(&XB1[2 * P + cp], b12);
-                    atomicAdd(&XB2[2 * P + cp], b22);
-                }
             }
-            amin = wave_min(amin);
-            sA = wave_sum(sA);
-            sB = wave_sum(sB);
-            const double a_aff = fmin(1.0, amin);
-            const double mu_aff = (sum_sl + a_aff * sA + a_aff * a_aff * sB) / m_tot;
+            wave_max1_sum1(rmax, sB);
+            const double a_aff = fast_rcp(rmax);
+            // sum(s dl_a + lam ds_a) == -sum(s lam) by construction of the affine direction
+            const double mu_aff = ((1.0 - a_aff) * sum_sl + a_aff * a_aff * sB) * inv_m;
             double sigma = fmax(mu_aff, 0.0) / mu;
             sigma = sigma * sigma * sigma;
             const double smu = sigma * mu;
-            __syncthreads();
+            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_T(6);
+            LSCQP_STOP(7)
             // ============ corrector solve ==================================================================
-            double gb = 0;
-            if (zl) gb = gatherT([&](int k, int cp) { return smu * XB1[k * P + cp] + XB2[k * P + cp]; });
-            const double dzc = solve(zl ? (-gcost + gb) : 0.0);
-            __syncthreads();  // everyone is done reading dz_ (expandT above) before it is overwritten
-            if (zl) dz_[lane] = dzc;
-            __syncthreads();
-            expandT(dc_);
-            __syncthreads();
-            // ============ pass 3: step length ==============================================================
-            amin = 1e300;
-            // corrector direction of one row; returns ds, dl
-            auto row_dir = [&](double s, double l, double rp, double dya, double dyc, double& ds, double& dl) {
-                const double w = l / s;
-                const double dsa = dya + rp, dla = -l - w * dsa;
-                ds = dyc + rp;
-                dl = (smu - dsa * dla) / s - l - w * ds;
-            };
+            double gb;
+            {
+                const double* x1 = &XB1[gbase];
+                const double* x2 = &XB2[gbase];
+                const double* y1 = &XB1[gnext];
+                const double* y2 = &XB2[gnext];
+                gb = e0 * (smu * x1[3] + x2[3]) + e1 * (smu * x1[4] + x2[4]) + e2 * (smu * x1[5] + x2[5]) +
+                     tb0 * (smu * y1[0] + y2[0]) + tb1 * (smu * y1[1] + y2[1]) + tb2 * (smu * y1[2] + y2[2]);
+                gb = zl ? gb : 0.0;
+            }
 #pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                if (r_ty[u] >= 0) {
-                    const double y = row_val(c_, u), dya = row_val(dca_, u), dyc = row_val(dc_, u);
-                    double ds, dl;
-                    if (r_lo[u] > -INFINITY) {
-                        row_dir(r_slo[u], r_llo[u], (y - r_lo[u]) - r_slo[u], dya, dyc, ds, dl);
-                        if (ds < 0) amin = fmin(amin, -r_slo[u] / ds);
-                        if (dl < 0) amin = fmin(amin, -r_llo[u] / dl);
-                    }
-                    if (r_hi[u] < INFINITY) {
-                        row_dir(r_shi[u], r_lhi[u], (r_hi[u] - y) - r_shi[u], -dya, -dyc, ds, dl);
-                        if (ds < 0) amin = fmin(amin, -r_shi[u] / ds);
-                        if (dl < 0) amin = fmin(amin, -r_lhi[u] / dl);
-                    }
-                }
+            for (int cidx = 0; cidx < NZ; cidx++) {
+                const double v = hrow[cidx];
+                A[cidx] = zl ? v : 0.0;
             }
-            for (int e = lane; e < nrow; e += 64) {
-                const int cp = e % P;
-                const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = Rs[e], l = Rl[e];
-                if (l > 0.0) {
-                    double r = nx * c_[cp] + ny * c_[P + cp], da = nx * dca_[cp] + ny * dca_[P + cp],
-                           dcv = nx * dc_[cp] + ny * dc_[P + cp];
-                    if (DIM == 3) {
-                        r += nz * c_[2 * P + cp];
-                        da += nz * dca_[2 * P + cp];
-                        dcv += nz * dc_[2 * P + cp];
-                    }
-                    double ds, dl;
-                    row_dir(s, l, (r - Rb[e]) - s, da, dcv, ds, dl);
-                    if (ds < 0) amin = fmin(amin, -s / ds);
-                    if (dl < 0) amin = fmin(amin, -l / dl);
-                }
+            const double dzc = solve(-gcost + gb);
+            // the scratch row must be all-zero outside the assembly pattern again
+#pragma unroll
+            for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = 0.0;
+            if (zl) dz_[lane] = dzc;  // expandT(dca_) finished reading dz_ before
+            LSCQP_WAVE_LDS_SYNC();
+            expandT(dz_, dc_, false);
+            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_T(7);
+            LSCQP_STOP(8)
+            // ============ pass 3: step length ==============================================================
+            // ds = G dc + rp,  dl = (sigma mu - ds_a dl_a)/s - lam - w ds;  ratios -ds/s and -dl/lam
+            rmax = 0.0;
+            double t_ds[2 * NS2], t_dl[2 * NS2], r_ds[NSLOT], r_dl[NSLOT];  // live only until the update below
+#pragma unroll
+            for (int u = 0; u < NS2; u++) {
+                const bool on = t_ix[u] >= 0;
+                const double y = row_val(c_, u), dya = row_val(dca_, u), dyc = row_val(dc_, u);
+                const double rpl = (y - t_lo[u]) - t_sl[u], rph = (t_hi[u] - y) - t_sh[u];
+                const double isl = fast_rcp(t_sl[u]), ish = fast_rcp(t_sh[u]);
+                const double tl = (dya + rpl) * isl, th = (rph - dya) * ish;
+                const double pl = -(dya + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dya) * t_lh[u] * (1.0 + th);
+                const double dsl = dyc + rpl, dsh = rph - dyc;
+                const double dll = (smu - pl) * isl - t_ll[u] - t_ll[u] * isl * dsl;
+                const double dlh = (smu - ph) * ish - t_lh[u] - t_lh[u] * ish * dsh;
+                // rows that do not exist have lambda == 0: give them a harmless divisor
+                const double ill = fast_rcp(on ? t_ll[u] : 1.0), ilh = fast_rcp(on ? t_lh[u] : 1.0);
+                const double rr = fmax(fmax(-dsl * isl, -dsh * ish), fmax(-dll * ill, -dlh * ilh));
+                rmax = fmax(rmax, on ? rr : 0.0);
+                t_ds[2 * u] = on ? dsl : 0.0; t_ds[2 * u + 1] = on ? dsh : 0.0;
+                t_dl[2 * u] = on ? dll : 0.0; t_dl[2 * u + 1] = on ? dlh : 0.0;
             }
-            amin = wave_min(amin);
-            const double alpha = fmin(1.0, 0.995 * amin);
+            {
+                const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+                const double ax = dca_[lx], ay = dca_[P + lx], az = (DIM == 3) ? dca_[2 * P + lx] : 0.0;
+                const double dx = dc_[lx], dy = dc_[P + lx], dzz = (DIM == 3) ? dc_[2 * P + lx] : 0.0;
+#pragma unroll
+                for (int u = 0; u < NSLOT; u++) {
+                    const int o = lg + G * u;
+                    const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
+                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u], l = r_l[u];
+                    const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
+                    const double is = fast_rcp(s);
+                    const double dsa = (nx * ax + ny * ay + nz * az) + rp;
+                    const double pa = -dsa * l * (1.0 + dsa * is);
+                    const double ds = (nx * dx + ny * dy + nz * dzz) + rp;
+                    const bool act = l > 0.0;
+                    const double dl = act ? ((smu - pa) * is - l - l * is * ds) : 0.0;
+                    const double il = fast_rcp(act ? l : 1.0);
+                    rmax = fmax(rmax, fmax(-ds * is, -dl * il));
+                    r_ds[u] = act ? ds : 0.0;
+                    r_dl[u] = dl;
+                    }
+            }
+            rmax = wave_max(rmax);
+            // alpha = min(1, 0.995 / rmax)
+            const double alpha = (rmax > 0.995) ? 0.995 * fast_rcp(rmax) : 1.0;
+            LSCQP_T(8);
+            LSCQP_STOP(9)
             // ============ update ===========================================================================
 #pragma unroll
-            for (int u = 0; u < RPL; u++) {
-                if (r_ty[u] >= 0) {
-                    const double y = row_val(c_, u), dya = row_val(dca_, u), dyc = row_val(dc_, u);
-                    double ds, dl;
-                    if (r_lo[u] > -INFINITY) {
-                        row_dir(r_slo[u], r_llo[u], (y - r_lo[u]) - r_slo[u], dya, dyc, ds, dl);
-                        r_slo[u] += alpha * ds;
-                        r_llo[u] += alpha * dl;
-                    }
-                    if (r_hi[u] < INFINITY) {
-                        row_dir(r_shi[u], r_lhi[u], (r_hi[u] - y) - r_shi[u], -dya, -dyc, ds, dl);
-                        r_shi[u] += alpha * ds;
-                        r_lhi[u] += alpha * dl;
-                    }
-                }
+            for (int u = 0; u < NS2; u++) {
+                t_sl[u] = fma(alpha, t_ds[2 * u], t_sl[u]);
+                t_sh[u] = fma(alpha, t_ds[2 * u + 1], t_sh[u]);
+                t_ll[u] = fma(alpha, t_dl[2 * u], t_ll[u]);
+                t_lh[u] = fma(alpha, t_dl[2 * u + 1], t_lh[u]);
             }
-            for (int e = lane; e < nrow; e += 64) {
-                const int cp = e % P;
-                const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = Rs[e], l = Rl[e];
-                if (l > 0.0) {
-                    double r = nx * c_[cp] + ny * c_[P + cp], da = nx * dca_[cp] + ny * dca_[P + cp],
-                           dcv = nx * dc_[cp] + ny * dc_[P + cp];
-                    if (DIM == 3) {
-                        r += nz * c_[2 * P + cp];
-                        da += nz * dca_[2 * P + cp];
-                        dcv += nz * dc_[2 * P + cp];
-                    }
-                    double ds, dl;
-                    row_dir(s, l, (r - Rb[e]) - s, da, dcv, ds, dl);
-                    Rs[e] = s + alpha * ds;
-                    Rl[e] = l + alpha * dl;
-                }
+#pragma unroll
+            for (int u = 0; u < NSLOT; u++) {
+                r_s[u] = fma(alpha, r_ds[u], r_s[u]);
+                r_l[u] = fma(alpha, r_dl[u], r_l[u]);
             }
-            __syncthreads();  // all rows have read c_, dca_, dc_
             if (zl) z_[lane] += alpha * dzc;
-            __syncthreads();
+            LSCQP_WAVE_LDS_SYNC();
             // c = c_fixed + T z, recomputed from z so the eliminated equalities hold to rounding every iteration
-            for (int e = lane; e < NX; e += 64) {
-                const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
-                double v;
-                if (i >= 3) v = z_[k * NZA + zidx(m, i - 3)];
-                else if (m >= 1) {
-                    const double* zz = &z_[k * NZA + 3 * (m - 1)];
-                    v = LSCQP_TB(i, 0) * zz[0] + LSCQP_TB(i, 1) * zz[1] + LSCQP_TB(i, 2) * zz[2];
-                } else v = (cp == 0) ? 0.0 : (cp == 1) ? cf1[k] : cf2[k];
-                c_[e] = v;
-            }
-            __syncthreads();
-            if (!(alpha > 1e-12) || !(mu == mu)) {  // stalled or NaN
+            expandT(z_, c_, true);
+            LSCQP_WAVE_LDS_SYNC();
+            if (!(alpha > 1e-12) || !(mu == mu)) {  // stalled or NaN (wave-uniform)
                 status = LSCQP_STATUS_NUMERIC;
                 break;
             }
+            LSCQP_T(9);
+            LSCQP_STOP(10)
         }
+    LSCQP_T(10);
     if (status == LSCQP_STATUS_ITER_LIMIT && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
     if (status == LSCQP_STATUS_NUMERIC && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
 
