@@ -204,11 +204,22 @@ def main():
         lsc = np.ascontiguousarray(build["lsc"]).reshape(-1)
         loff = np.arange(N) * n_obs_eff * M * 6
         sfc_o = np.ascontiguousarray(build["sfc"]).reshape(-1)
-        cores = os.cpu_count() or 1
-        O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)  # warm
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # the box may expose many logical CPUs behind a smaller quota: time a few thread counts, keep the fastest
+        best = None
+        for th in sorted({1, 4, 8, 16, 32, min(64, avail), min(N, avail)}):
+            if th > avail:
+                continue
+            O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=th)  # warm
+            a = time.perf_counter()
+            O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=th)
+            dtm = time.perf_counter() - a
+            if best is None or dtm < best[1]:
+                best = (th, dtm)
+        cores = best[0]
         reps, tcpu, R = 0, 0.0, None
         a = time.perf_counter()
-        while tcpu < 3.0 and reps < 50:
+        while tcpu < 3.0 and reps < 200:
             R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)
             reps += 1
             tcpu = time.perf_counter() - a
@@ -221,7 +232,8 @@ def main():
         out["cpu_baseline"] = {
             "value": N * reps / tcpu, "unit": "QP/s", "cores": cores, "kind": "port",
             "sample": "the same %d-QP batch solved %d times by oracle/lscqp_oracle.c (dense fp64 PDIP, OpenMP over "
-                      "agents, %.1f s); single core: %.1f QP/s" % (N, reps, tcpu, 16 / t1c),
+                      "agents, best of several thread counts = %d threads of %d visible CPUs, %.1f s); single core: "
+                      "%.1f QP/s" % (N, reps, cores, avail, tcpu, 16 / t1c),
             "single_core_value": 16 / t1c,
             "reference_published": "CPLEX 20.1, 6 threads: 4.58-6.64 ms/QP (151-218 QP/s) at M=10 dim=2 <=9 neighbours "
                                    "(reference log/summary_LSC_10agents.csv)",

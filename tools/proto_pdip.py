@@ -146,7 +146,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         z[k * nzA:(k + 1) * nzA] = cfix[k, 2]
     s = np.maximum(Gz @ z - hz, 0.0)
     s = np.maximum(s, 1e-2)
-    lam = np.ones(mrows)
+    lam = np.full(mrows, 0.03)
     gscale = max(1.0, np.abs(gfull).max())
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
@@ -194,7 +194,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         if neg.any(): a = min(a, (-s[neg] / ds[neg]).min())
         neg = dl < 0
         if neg.any(): a = min(a, (-lam[neg] / dl[neg]).min())
-        a = min(1.0, 0.995 * a)
+        a = min(1.0, 0.9995 * a)
         z = z + a * dz; s = s + a * ds; lam = lam + a * dl
     x = np.concatenate([cfix[k] + T @ z[k * nzA:(k + 1) * nzA] for k in range(dim)])
     # objective: the same polynomial integral as x'(w_c Q)x, evaluated through third differences (stable)
