@@ -751,6 +751,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             bool pivot_bad = false;
 #pragma unroll
             for (int j = 0; j < NZ; j++) {
+#ifndef LSCQP_FACT_LDS_COLUMN
                 // pivot row of lane j broadcast with v_readlane (2 per fp64 value)
                 const double d = bcast(A[j], j);
                 pivot_bad = pivot_bad || !(d > 1e-300);
@@ -760,6 +761,24 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 #pragma unroll
                 for (int kk = j + 1; kk < NZ; kk++) A[kk] = fma(-li, bcast(A[kk], j), A[kk]);
                 A[j] = (lane > j) ? li : A[j];
+#else
+                // Measured alternative (-DLSCQP_FACT_LDS_COLUMN), correct but SLOWER on MI355X (28.7k vs 19.2k cycles
+                // per factorisation at nz = 39): by symmetry the pivot row of step j equals the pivot column A[.][j],
+                // one entry per lane; one ds_write_b64 per lane publishes it and uniform-address ds_reads broadcast
+                // it back.  Half the instructions of the v_readlane form, but every column pays an LDS write->read
+                // round trip on the critical path of a single wavefront.
+                double* const cb = col_ + (j & 1) * 64;
+                cb[lane] = A[j];
+                LSCQP_WAVE_LDS_SYNC();
+                const double d = cb[j];
+                pivot_bad = pivot_bad || !(d > 1e-300);
+                const double invd = fast_rcp(d);
+                dinv_own = (lane == j) ? invd : dinv_own;
+                const double li = (lane > j) ? A[j] * invd : 0.0;
+#pragma unroll
+                for (int kk = j + 1; kk < NZ; kk++) A[kk] = fma(-li, cb[kk], A[kk]);
+                A[j] = (lane > j) ? li : A[j];
+#endif
             }
             if (pivot_bad) {  // wave-uniform
                 status = LSCQP_STATUS_NUMERIC;
