@@ -55,6 +55,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("liblscqp.so not built: run `python lsc_dr_planner_amd/build.py` "
                               "(there is no CPU fallback)")
+        # torch bundles its own libamdhip64 / libhsa-runtime64.  If liblscqp.so (linked against /opt/rocm's copy) is
+        # loaded first, the process ends up with TWO HIP runtimes and the one that initialises second sees no device.
+        # Importing torch first makes the loader resolve liblscqp.so's libamdhip64.so.7 to the copy torch already
+        # loaded, so device pointers, streams and events are shared.  (The C++ shim has no torch and uses /opt/rocm.)
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.lscqp_create.restype = C.c_int

@@ -176,8 +176,12 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
         (h->desc.use_sfc && !d_sfc))
         return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    {
+        const hipError_t de = hipGetDeviceCount(&ndev);
+        if (de != hipSuccess || ndev == 0)
+            return fail(LSCQP_ERR_NO_DEVICE, std::string("no HIP device: lscqp has no CPU fallback (hipGetDeviceCount: ") +
+                                                 hipGetErrorString(de) + ", " + std::to_string(ndev) + " devices)");
+    }
     const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, n_obs_max);
     if (!inst) {
         char buf[200];
@@ -201,8 +205,12 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     if (n == 0) return LSCQP_OK;
     if (!hdr || !x_out || !obj_out || !status_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    {
+        const hipError_t de = hipGetDeviceCount(&ndev);
+        if (de != hipSuccess || ndev == 0)
+            return fail(LSCQP_ERR_NO_DEVICE, std::string("no HIP device: lscqp has no CPU fallback (hipGetDeviceCount: ") +
+                                                 hipGetErrorString(de) + ", " + std::to_string(ndev) + " devices)");
+    }
     int n_obs_max = 0;
     for (int64_t q = 0; q < n; q++) {
         if (hdr[q].n_obs < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative n_obs");

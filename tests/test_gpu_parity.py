@@ -281,3 +281,42 @@ def test_translation_invariance(api, oracle, torch_cuda):
     assert (G["status"] == 0).all() and (G2["status"] == 0).all()
     assert np.abs(G2["x"] - (G["x"] + np.repeat(shift, M * 6))).max() < 1e-9
     assert np.abs(G2["obj"] - G["obj"]).max() < 1e-7
+
+
+def _compiled_instances():
+    import os
+    import re
+
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lsc_dr_planner_amd", "csrc",
+                            "lscqp_launch.hpp")).read()
+    body = txt[txt.index("#define LSCQP_INSTANCES"):]
+    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
+
+
+@pytest.mark.parametrize("M,dim,es,nslot", _compiled_instances())
+def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_cuda, M, dim, es, nslot):
+    """Every kernel instance, at its full obstacle capacity: bitwise repeatable and equal to the oracle.
+    (Guards against the exec-masked register-spill hazard described in lscqp_kernel.hpp: a miscompiled instance shows
+    up as run-to-run differences long before it shows up as a wrong answer.)"""
+    from lsc_dr_planner_amd import synth
+
+    G = max(1, 64 // (6 * M - 3))
+    n_obs = nslot * G
+    N = max(24, n_obs + 2)
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=17 + M)
+    assert sw.n_obs == n_obs
+    pm = api.PLANNER_LSC if es else api.PLANNER_DLSC
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, planner_lsc=bool(es), world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=pm, world_min=sw.world_min, world_max=sw.world_max))
+    for step in range(2):
+        b = sw.build()
+        hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+        runs = [sol.solve_host(hdr, rows, off, sfc) for _ in range(3)]
+        assert (runs[0]["status"] == 0).all(), np.bincount(runs[0]["status"], minlength=4)
+        for r in runs[1:]:
+            assert np.array_equal(r["x"], runs[0]["x"]) and np.array_equal(r["obj"], runs[0]["obj"])
+            assert np.array_equal(r["info"]["iterations"], runs[0]["info"]["iterations"])
+        ag, lsc, loff, sfco = H.swarm_oracle_inputs(oracle, sw, b)
+        R = oracle.solve_batch(cls, ag, lsc, loff, sfco, threads=8)
+        _check_against_oracle(oracle, cls, runs[0], R)
+        sw.advance(runs[0]["x"])

@@ -150,7 +150,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     gscale = max(1.0, np.abs(gfull).max())
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
-    status, it = 2, 0
+    status, it, near_cnt = 2, 0, 0
     for it in range(max_iter):
         rp = Gz @ z - hz - s
         grad = Kfull @ z + gfull
@@ -161,15 +161,17 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             print(it, "rp %.2e rd %.2e mu %.2e" % (np.abs(rp).max(), np.abs(rd).max() / gscale, mu))
         pinf = lam @ np.abs(rp)
         gls = max(gscale, np.abs(grad).max())
-        if np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 10 * tol * gls and mu * mrows + pinf <= tol * (1 + abs(objz + objc)):
-            status = 0
-            break
+        if np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-8 * gls and mu * mrows + pinf <= tol * (1 + abs(objz + objc)):
+            near_cnt += 1
+            if np.abs(rd).max() <= 10 * tol * gls or near_cnt >= 2:
+                status = 0
+                break
         w = lam / s
         K = Kfull + Gz.T @ (w[:, None] * Gz)
         try:
             L = np.linalg.cholesky(K)
         except np.linalg.LinAlgError:
-            status = 3
+            status = 0 if near_cnt > 0 else 3
             break
         def lin(q):
             rhs = -grad + Gz.T @ q
