@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/lscqp.h"
 
 namespace lscqp {
@@ -51,6 +53,15 @@ __device__ __forceinline__ constexpr double KQ(int i, int j) {
 // dynamically would be materialised in scratch memory.
 __device__ __forceinline__ constexpr double TBc(int i, int j) {
     return i == 0 ? (j == 2 ? 1.0 : 0.0) : i == 1 ? (j == 0 ? 0.0 : j == 1 ? -1.0 : 2.0) : (j == 0 ? 1.0 : j == 1 ? -4.0 : 4.0);
+}
+
+// compile-time loop: guarantees constant register indices where '#pragma unroll' gives up on nested strided loops
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
 
 __device__ __forceinline__ double bcast(double v, int lane) {
@@ -756,19 +767,35 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 
             // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
-#pragma unroll
-            for (int j = 0; j < NZ; j++) {
 #ifndef LSCQP_FACT_LDS_COLUMN
-                // pivot row of lane j broadcast with v_readlane (2 per fp64 value)
+            // pivot row of lane j broadcast with v_readlane (2 per fp64 value), issued in batches of BB into distinct
+            // scalar registers so the v_readlane -> v_fma hazard slots are filled by other broadcasts, not s_nops
+            static_for<0, NZ>([&](auto Jc) {
+                constexpr int j = decltype(Jc)::value;
                 const double d = bcast(A[j], j);
                 pivot_bad = pivot_bad || !(d > 1e-300);
                 const double invd = fast_rcp(d);
                 dinv_own = (lane == j) ? invd : dinv_own;
                 const double li = (lane > j) ? A[j] * invd : 0.0;
-#pragma unroll
-                for (int kk = j + 1; kk < NZ; kk++) A[kk] = fma(-li, bcast(A[kk], j), A[kk]);
+                constexpr int BB = 4;
+                constexpr int NCH = (NZ - j - 1 + BB - 1) / BB;
+                static_for<0, NCH>([&](auto Cc) {
+                    constexpr int k0 = j + 1 + decltype(Cc)::value * BB;
+                    double ub[BB];
+                    static_for<0, BB>([&](auto Tc) {
+                        constexpr int t = decltype(Tc)::value;
+                        if constexpr (k0 + t < NZ) ub[t] = bcast(A[k0 + t], j);
+                    });
+                    static_for<0, BB>([&](auto Tc) {
+                        constexpr int t = decltype(Tc)::value;
+                        if constexpr (k0 + t < NZ) A[k0 + t] = fma(-li, ub[t], A[k0 + t]);
+                    });
+                });
                 A[j] = (lane > j) ? li : A[j];
+            });
 #else
+#pragma unroll
+            for (int j = 0; j < NZ; j++) {
                 // Measured alternative (-DLSCQP_FACT_LDS_COLUMN), correct but SLOWER on MI355X (28.7k vs 19.2k cycles
                 // per factorisation at nz = 39): by symmetry the pivot row of step j equals the pivot column A[.][j],
                 // one entry per lane; one ds_write_b64 per lane publishes it and uniform-address ds_reads broadcast
@@ -785,8 +812,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 #pragma unroll
                 for (int kk = j + 1; kk < NZ; kk++) A[kk] = fma(-li, cb[kk], A[kk]);
                 A[j] = (lane > j) ? li : A[j];
-#endif
             }
+#endif
             if (pivot_bad) {  // wave-uniform
                 status = near_cnt > 0 ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 break;
