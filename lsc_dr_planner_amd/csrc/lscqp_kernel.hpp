@@ -777,7 +777,11 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 const double invd = fast_rcp(d);
                 dinv_own = (lane == j) ? invd : dinv_own;
                 const double li = (lane > j) ? A[j] * invd : 0.0;
-                constexpr int BB = 4;
+#ifdef LSCQP_FACT_BB
+                constexpr int BB = LSCQP_FACT_BB;
+#else
+                constexpr int BB = 8;  // measured on MI355X: 1 -> 0.231 ms, 4 -> 0.214 ms, 8 -> 0.210 ms per 64-QP batch
+#endif
                 constexpr int NCH = (NZ - j - 1 + BB - 1) / BB;
                 static_for<0, NCH>([&](auto Cc) {
                     constexpr int k0 = j + 1 + decltype(Cc)::value * BB;
