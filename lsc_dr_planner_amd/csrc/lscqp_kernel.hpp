@@ -246,11 +246,18 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     const bool zlast = ES && (za == 3 * (M - 1));
     const int zm = zlast ? (M - 1) : za / 3;
     const int zj = zlast ? 0 : za % 3;
-    const double e0 = (zlast || zj == 0) ? 1.0 : 0.0, e1 = (zlast || zj == 1) ? 1.0 : 0.0, e2 = (zlast || zj == 2) ? 1.0 : 0.0;
     const bool has_next = (zm + 1 < M);
-    const double tb0 = has_next ? (zj == 2 ? 1.0 : 0.0) : 0.0;
-    const double tb1 = has_next ? (zj == 0 ? 0.0 : zj == 1 ? -1.0 : 2.0) : 0.0;
-    const double tb2 = has_next ? (zj == 0 ? 1.0 : zj == 1 ? -4.0 : 4.0) : 0.0;
+    // Selector weights of the z variable (which of c3,c4,c5 it drives, and the TB column towards the next segment).
+    // They are REMATERIALISED from (zj, zlast, has_next) at every use through an opaque copy of zj: kept as six
+    // long-lived doubles they are the first thing the register allocator spills to scratch.
+#define LSCQP_LANE_WEIGHTS()                                                                                         \
+    int zj_ = zj;                                                                                                    \
+    asm volatile("" : "+v"(zj_));                                                                                    \
+    const double e0 = (zlast || zj_ == 0) ? 1.0 : 0.0, e1 = (zlast || zj_ == 1) ? 1.0 : 0.0,                         \
+                 e2 = (zlast || zj_ == 2) ? 1.0 : 0.0;                                                               \
+    const double tb0 = has_next ? (zj_ == 2 ? 1.0 : 0.0) : 0.0;                                                      \
+    const double tb1 = has_next ? (zj_ == 0 ? 0.0 : zj_ == 1 ? -1.0 : 2.0) : 0.0;                                    \
+    const double tb2 = has_next ? (zj_ == 0 ? 1.0 : zj_ == 1 ? -4.0 : 4.0) : 0.0
     auto zidx = [](int m, int j) -> int { return (ES && m == M - 1) ? 3 * (M - 1) : 3 * m + j; };
     // LSC lane: (group lg, control point lcp in [0,CP)); x-space index of the lane's control point per axis
     const bool ll = lane < G * CP;
@@ -490,6 +497,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     const int gbase = zk * P + 6 * zm;
     const int gnext = zk * P + 6 * (has_next ? zm + 1 : zm);
     auto gatherT = [&](const double* X) -> double {
+        LSCQP_LANE_WEIGHTS();
         const double* xs = &X[gbase];
         const double* xn = &X[gnext];
         return e0 * xs[3] + e1 * xs[4] + e2 * xs[5] + tb0 * xn[0] + tb1 * xn[1] + tb2 * xn[2];
@@ -613,6 +621,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     h0 += KQ(0, ip) * cn[ip]; h1 += KQ(1, ip) * cn[ip]; h2 += KQ(2, ip) * cn[ip];
                 }
                 g5 = q2s * g5 + ((zm >= M - ts) ? wt2 * (cs[5] - gk) : 0.0);
+                LSCQP_LANE_WEIGHTS();
                 gcost = e0 * (q2s * g3) + e1 * (q2s * g4) + e2 * g5 + q2s * (tb0 * h0 + tb1 * h1 + tb2 * h2);
                 gl = gatherT(XL);
                 ga = gatherT(XA);
@@ -675,6 +684,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     }
                 };
                 auto sym = [](const double (&B)[6][6], int i, int ip) -> double { return i <= ip ? B[i][ip] : B[ip][i]; };
+                LSCQP_LANE_WEIGHTS();
                 const double ej[3] = {e0, e1, e2};
                 const double tbj[3] = {tb0, tb1, tb2};
                 const int mn = has_next ? zm + 1 : zm;  // clamped: its weights tb* are zero when there is no next
@@ -921,6 +931,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 const double* x2 = &XB2[gbase];
                 const double* y1 = &XB1[gnext];
                 const double* y2 = &XB2[gnext];
+                LSCQP_LANE_WEIGHTS();
                 gb = e0 * (smu * x1[3] + x2[3]) + e1 * (smu * x1[4] + x2[4]) + e2 * (smu * x1[5] + x2[5]) +
                      tb0 * (smu * y1[0] + y2[0]) + tb1 * (smu * y1[1] + y2[1]) + tb2 * (smu * y1[2] + y2[2]);
                 gb = zl ? gb : 0.0;
