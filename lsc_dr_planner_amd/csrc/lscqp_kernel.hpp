@@ -114,7 +114,9 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
-// Development aid: per-phase cycle totals (s_memtime), compiled in only with -DLSCQP_PHASE_TIMING.
+// Development aid: per-phase cycle totals (s_memtime), compiled in only with -DLSCQP_PHASE_TIMING.  The markers
+// are scheduling barriers and drain the memory counters, so phases do not overlap in the instrumented build (it
+// runs ~30 % slower than the product build, whose scheduler interleaves neighbouring phases).
 // Cross-lane hand-off through LDS inside ONE wavefront: the LDS executes a wave's DS instructions in order, so no
 // s_barrier is needed, but the compiler must neither reorder LDS accesses across the hand-off nor keep values in
 // registers.  (__syncthreads() is not enough here: with a 64-thread workgroup hipcc elides it completely and at -O3
@@ -137,9 +139,13 @@ __device__ __forceinline__ double fast_rcp(double d) {
 __device__ unsigned long long lscqp_dbg_cycles[16];
 #define LSCQP_T(slot)                                                     \
     do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
         const unsigned long long now_ = __builtin_readcyclecounter();    \
         if (lane == 0) atomicAdd(&lscqp_dbg_cycles[slot], now_ - tprev_); \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       \
         tprev_ = __builtin_readcyclecounter();                            \
+        __builtin_amdgcn_sched_barrier(0);                                \
     } while (0)
 #else
 #define LSCQP_T(slot) \
@@ -808,24 +814,39 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 A[j] = (lane > j) ? li : A[j];
             });
 #else
-#pragma unroll
-            for (int j = 0; j < NZ; j++) {
-                // Measured alternative (-DLSCQP_FACT_LDS_COLUMN), correct but SLOWER on MI355X (28.7k vs 19.2k cycles
-                // per factorisation at nz = 39): by symmetry the pivot row of step j equals the pivot column A[.][j],
-                // one entry per lane; one ds_write_b64 per lane publishes it and uniform-address ds_reads broadcast
-                // it back.  Half the instructions of the v_readlane form, but every column pays an LDS write->read
-                // round trip on the critical path of a single wavefront.
-                double* const cb = col_ + (j & 1) * 64;
-                cb[lane] = A[j];
+            // Measured alternative (-DLSCQP_FACT_LDS_COLUMN): LDS-column form with look-ahead.  By symmetry of the
+            // trailing matrix the pivot row of step j equals the pivot COLUMN, of which every lane holds one entry (its
+            // A[j]): one ds_write_b64 per lane publishes it and uniform-address ds_reads broadcast it back: 1 LDS read
+            // + 1 FMA per entry instead of 2 v_readlane + 1 FMA (+ the SGPR hazard nops) -- 2.1 k instead of 3.8 k
+            // instructions, 14.4 k instead of 20.5 k cycles for the factorisation alone.  Column j+1 is completed,
+            // published and its pivot inverted FIRST inside step j, so the LDS round trip and the reciprocal chain
+            // overlap the remaining FMAs of step j.  End to end it is SLOWER on MI355X (0.233 vs 0.201 ms per 64-QP
+            // batch): the extra VGPRs of the broadcast values push the neighbouring passes into more scratch spills.
+            {
+                col_[lane] = A[0];
+                double d = bcast(A[0], 0);
+                double invd = fast_rcp(d);
                 LSCQP_WAVE_LDS_SYNC();
-                const double d = cb[j];
-                pivot_bad = pivot_bad || !(d > 1e-300);
-                const double invd = fast_rcp(d);
-                dinv_own = (lane == j) ? invd : dinv_own;
-                const double li = (lane > j) ? A[j] * invd : 0.0;
-#pragma unroll
-                for (int kk = j + 1; kk < NZ; kk++) A[kk] = fma(-li, cb[kk], A[kk]);
-                A[j] = (lane > j) ? li : A[j];
+                static_for<0, NZ>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    const double* const cb = col_ + (j & 1) * 64;
+                    double* const cbn = col_ + ((j + 1) & 1) * 64;
+                    pivot_bad = pivot_bad || !(d > 1e-300);
+                    dinv_own = (lane == j) ? invd : dinv_own;
+                    const double li = (lane > j) ? A[j] * invd : 0.0;
+                    if constexpr (j + 1 < NZ) {
+                        A[j + 1] = fma(-li, cb[j + 1], A[j + 1]);
+                        cbn[lane] = A[j + 1];
+                        d = bcast(A[j + 1], j + 1);
+                        invd = fast_rcp(d);
+                    }
+                    static_for<j + 2, NZ>([&](auto Kc) {
+                        constexpr int k = decltype(Kc)::value;
+                        A[k] = fma(-li, cb[k], A[k]);
+                    });
+                    A[j] = (lane > j) ? li : A[j];
+                    LSCQP_WAVE_LDS_SYNC();
+                });
             }
 #endif
             if (pivot_bad) {  // wave-uniform

@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SRC = os.path.join(ROOT, "lsc_dr_planner_amd", "csrc")
 OUT = "/tmp/liblscqp_prof.so"
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("-")]
+xflags = [a for a in sys.argv[1:] if a.startswith("-D")]
 M, D, N, NOBS, NSLOT = [int(v) for v in (args + ["5", "3", "64", "20", "10"][len(args):])]
 drv = r'''
 #include "lscqp_kernel.hpp"
@@ -21,7 +22,7 @@ if not os.path.exists(OUT) or "--rebuild" in sys.argv or True:
     tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT) + drv
     open(os.path.join("/tmp", "prof_tu.hip"), "w").write(tu)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-                           "-DLSCQP_PHASE_TIMING", "-I", SRC, "/tmp/prof_tu.hip", "-o", OUT])
+                           "-DLSCQP_PHASE_TIMING", "-I", SRC, "/tmp/prof_tu.hip", "-o", OUT] + xflags, stderr=subprocess.DEVNULL)
 if "--build-only" in sys.argv:
     sys.exit(0)
 import torch
