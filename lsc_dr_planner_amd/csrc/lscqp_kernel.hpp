@@ -182,7 +182,8 @@ struct Cfg {
     static constexpr int o_S = o_x0 + 4 * NX;   // per-cp 3x3 sym blocks [P][6]
     static constexpr int o_om = o_S + 6 * P;    // two-sided row weights
     static constexpr int o_z = o_om + NOM;      // z, dz
-    static constexpr int o_col = o_z + 2 * 64;  // pivot-column broadcast buffer
+    static constexpr int o_goal = o_z + 2 * 64;  // goal - p0 (4 doubles)
+    static constexpr int o_col = o_goal + 4;     // pivot-column broadcast buffer
     static constexpr int o_H = ((o_col + 130 + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH]
     static constexpr int o_rows = ((o_H + (NZ + 1) * LDH + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
     static constexpr int NROW = MAX_OBS * CP;  // + one dead row per array
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     double* const om_ = smem + C::o_om;
     double* const z_ = smem + C::o_z;
     double* const dz_ = smem + C::o_z + 64;
+    double* const goal_ = smem + C::o_goal;
     double* const col_ = smem + C::o_col;
     double* const Hs = smem + C::o_H;
     constexpr int NROW = C::NROW;
@@ -226,17 +228,15 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     const double dt = cls.dt;
 
     // ---- per-QP scalars (uniform) ------------------------------------------------------------------------
-    double org[3], goal[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        org[k] = H->p0[k];
-        goal[k] = H->goal[k] - org[k];
-    }
+    // The origin is only needed by the prologue (and re-read from the header by the epilogue); the translated goal is
+    // read per axis in every iteration and sits in LDS: as per-lane scalars these uniform values would be twelve
+    // long-lived VGPRs, as a register array hipcc selects between the elements through scratch memory.
+    const double org0 = H->p0[0], org1 = H->p0[1], org2 = H->p0[2];
+    const double goal0 = H->goal[0] - org0, goal1 = H->goal[1] - org1, goal2 = H->goal[2] - org2;
+    if (lane < 3) goal_[lane] = H->goal[lane] - H->p0[lane];
     int ts = H->terminal_segments;
     if (ts <= 0) {  // src/traj_optimizer.cpp:530-538 in fp64
-        double d2 = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) d2 += goal[k] * goal[k];
+        const double d2 = goal0 * goal0 + goal1 * goal1 + goal2 * goal2;
         ts = (int)((M * dt - sqrt(d2) / H->nominal_velocity + 1e-9) / dt);
         if (ts < 1) ts = 1;
     }
@@ -253,17 +253,64 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     const int zm = zlast ? (M - 1) : za / 3;
     const int zj = zlast ? 0 : za % 3;
     const bool has_next = (zm + 1 < M);
-    // Selector weights of the z variable (which of c3,c4,c5 it drives, and the TB column towards the next segment).
-    // They are REMATERIALISED from (zj, zlast, has_next) at every use through an opaque copy of zj: kept as six
-    // long-lived doubles they are the first thing the register allocator spills to scratch.
-#define LSCQP_LANE_WEIGHTS()                                                                                         \
-    int zj_ = zj;                                                                                                    \
-    asm volatile("" : "+v"(zj_));                                                                                    \
-    const double e0 = (zlast || zj_ == 0) ? 1.0 : 0.0, e1 = (zlast || zj_ == 1) ? 1.0 : 0.0,                         \
-                 e2 = (zlast || zj_ == 2) ? 1.0 : 0.0;                                                               \
-    const double tb0 = has_next ? (zj_ == 2 ? 1.0 : 0.0) : 0.0;                                                      \
-    const double tb1 = has_next ? (zj_ == 0 ? 0.0 : zj_ == 1 ? -1.0 : 2.0) : 0.0;                                    \
-    const double tb2 = has_next ? (zj_ == 0 ? 1.0 : zj_ == 1 ? -4.0 : 4.0) : 0.0
+    // LOOP-INVARIANT LANE ROLES ARE RECOMPUTED IN EVERY PHASE OF THE ITERATION from an opaque copy of the lane id
+    // (LSCQP_PHASE_LANE).  Derived from `lane` directly, hipcc hoists every role, LDS address, selector weight and
+    // lane-vs-column compare mask out of the iteration loop (~150 VGPRs + ~240 SGPRs worth), spills them to scratch
+    // memory / VGPR lanes and reloads them in the middle of dependent LDS chains (~150 cycles per scratch reload,
+    // tools/ubench.hip).  A handful of integer instructions per phase is far cheaper.
+#define LSCQP_PHASE_LANE(name) \
+    int name = lane;           \
+    asm volatile("" : "+v"(name))
+    struct ZRole {  // row `lv` of the reduced system, lv = k*NZA + a
+        bool zl, zlast, has_next;
+        int zk, zm, zj, gbase, gnext;
+    };
+    auto zrole = [](int lv) -> ZRole {
+        ZRole R;
+        R.zl = lv < NZ;
+        R.zk = R.zl ? lv / NZA : 0;
+        const int za_ = R.zl ? lv % NZA : 0;
+        R.zlast = ES && (za_ == 3 * (M - 1));
+        R.zm = R.zlast ? (M - 1) : za_ / 3;
+        R.zj = R.zlast ? 0 : za_ % 3;
+        R.has_next = (R.zm + 1 < M);
+        R.gbase = R.zk * P + 6 * R.zm;
+        R.gnext = R.zk * P + 6 * (R.has_next ? R.zm + 1 : R.zm);
+        return R;
+    };
+    struct LRole {  // LSC lane: (group lg, control point lcp in [0,CP))
+        bool ll;
+        int lg, lcp, lx;
+    };
+    auto lrole = [](int lv) -> LRole {
+        LRole R;
+        R.ll = lv < G * CP;
+        R.lg = R.ll ? lv / CP : 0;
+        R.lcp = R.ll ? lv % CP : 0;
+        R.lx = R.lcp + 3;
+        return R;
+    };
+    // Selector weights of the z variable (which of c3,c4,c5 it drives, and the TB column towards the next segment)
+#define LSCQP_LANE_WEIGHTS(R)                                                                                        \
+    const double e0 = (R.zlast || R.zj == 0) ? 1.0 : 0.0, e1 = (R.zlast || R.zj == 1) ? 1.0 : 0.0,                   \
+                 e2 = (R.zlast || R.zj == 2) ? 1.0 : 0.0;                                                            \
+    const double tb0 = R.has_next ? (R.zj == 2 ? 1.0 : 0.0) : 0.0;                                                   \
+    const double tb1 = R.has_next ? (R.zj == 0 ? 0.0 : R.zj == 1 ? -1.0 : 2.0) : 0.0;                                \
+    const double tb2 = R.has_next ? (R.zj == 0 ? 1.0 : R.zj == 1 ? -4.0 : 4.0) : 0.0
+    // phase-local copies under the names the prologue uses (they shadow the prologue's, which stay loop invariant)
+#define LSCQP_Z_ROLES()                                                                                  \
+    LSCQP_PHASE_LANE(lvz_);                                                                              \
+    const ZRole ZR = zrole(lvz_);                                                                        \
+    const bool zl = ZR.zl, zlast = ZR.zlast, has_next = ZR.has_next;                                     \
+    const int zk = ZR.zk, zm = ZR.zm, zj = ZR.zj, gbase = ZR.gbase, gnext = ZR.gnext;                    \
+    double* const hrow = &Hs[(zl ? lvz_ : NZ) * LDH];                                                    \
+    (void)zlast, (void)has_next, (void)zk, (void)zm, (void)zj, (void)gbase, (void)gnext, (void)hrow
+#define LSCQP_L_ROLES()                                                                                  \
+    LSCQP_PHASE_LANE(lvl_);                                                                              \
+    const LRole LR = lrole(lvl_);                                                                        \
+    const bool ll = LR.ll;                                                                               \
+    const int lg = LR.lg, lcp = LR.lcp, lx = LR.lx;                                                      \
+    (void)lcp
     auto zidx = [](int m, int j) -> int { return (ES && m == M - 1) ? 3 * (M - 1) : 3 * m + j; };
     // LSC lane: (group lg, control point lcp in [0,CP)); x-space index of the lane's control point per axis
     const bool ll = lane < G * CP;
@@ -295,7 +342,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             const int o = e / CP, cp = e % CP;
             const double4 v = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
             double nx = v.x, ny = v.y, nz = (DIM == 3) ? v.z : 0.0;
-            double b = v.w - (v.x * org[0] + v.y * org[1] + (DIM == 3 ? v.z * org[2] : 0.0));
+            double b = v.w - (v.x * org0 + v.y * org1 + (DIM == 3 ? v.z * org2 : 0.0));
             if (sqrt(v.x * v.x + v.y * v.y + v.z * v.z) < 1e-5) {  // dropped like the reference does (:409-411)
                 nx = ny = nz = 0.0;
                 b = -1.0;
@@ -337,13 +384,15 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     const int k = e / P, cp = e % P, m = cp / 6;
                     if (cp >= 3) {
                         t_ix[u] = e;
-                        double lo = cls.world_min[k] - org[k], hi = cls.world_max[k] - org[k];  // :252-253,260-265
-                        if (cls.use_sfc) {                                                      // :372-397
-                            lo = fmax(lo, sfc[q * M + m].bmin[k] - org[k]);
-                            hi = fmin(hi, sfc[q * M + m].bmax[k] - org[k]);
+                        // (org[] is only ever indexed with constants: a dynamic index would put it in scratch memory)
+                        const double ok_ = (k == 0) ? org0 : (k == 1) ? org1 : org2;
+                        double lo = cls.world_min[k] - ok_, hi = cls.world_max[k] - ok_;  // :252-253,260-265
+                        if (cls.use_sfc) {                                                // :372-397
+                            lo = fmax(lo, sfc[q * M + m].bmin[k] - ok_);
+                            hi = fmin(hi, sfc[q * M + m].bmax[k] - ok_);
                         }
                         if (comm_on && cp % 6 == 5) {  // pairs (m, mi=0) :482-487 and waypoint rows :494-497
-                            const double wpk = H->next_waypoint[k] - org[k];
+                            const double wpk = H->next_waypoint[k] - ok_;
                             lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
                             hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
                         }
@@ -471,9 +520,9 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     //   x'(w_c Q)x == w_c * 3600 dt^-5 * sum_seg (D3 c)' MB (D3 c)   (third differences: no cancellation)
     // plus the terminal cost including its constant goal^2 term (:301-316).  Translation invariant; the optional
     // world-frame correction restores the reference's own coefficient rounding (O(1e-9 |x|^2)).  Branch-free.
-    auto objective = [&](bool ref_rounding) -> double {
-        const bool on = lane < DIM * M;
-        const int k = on ? lane / M : 0, m = on ? lane % M : 0;
+    auto objective = [&](bool ref_rounding, int lv) -> double {
+        const bool on = lv < DIM * M;
+        const int k = on ? lv / M : 0, m = on ? lv % M : 0;
         const double* cc = &c_[k * P + 6 * m];
         const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
         const double j1 = (cc[4] - cc[1]) - 3.0 * (cc[3] - cc[2]);
@@ -482,7 +531,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
         double part = 0.5 * q2s * 3600.0 * quad;
         if (ref_rounding) {  // compile-time constant at both call sites
-            const double ok_ = (k == 0) ? org[0] : (k == 1) ? org[1] : org[2];
+            const double ok_ = H->p0[k];
             double corr = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -493,26 +542,24 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             }
             part += cls.w_c * corr;
         }
-        const double gk = (k == 0) ? goal[0] : (k == 1) ? goal[1] : goal[2];
-        const double dgoal = cc[5] - gk;
+        const double dgoal = cc[5] - goal_[k];
         part += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
         return wave_sum(on ? part : 0.0);
     };
     // gather an x-space vector into the own z component: (T' v)_r.  Lanes without a next segment read the clamped
     // segment with zero weights; non-z lanes compute a value that is never used.
-    const int gbase = zk * P + 6 * zm;
-    const int gnext = zk * P + 6 * (has_next ? zm + 1 : zm);
-    auto gatherT = [&](const double* X) -> double {
-        LSCQP_LANE_WEIGHTS();
-        const double* xs = &X[gbase];
-        const double* xn = &X[gnext];
+    auto gatherT = [&](const double* X, const ZRole& R) -> double {
+        LSCQP_LANE_WEIGHTS(R);
+        const double* xs = &X[R.gbase];
+        const double* xn = &X[R.gnext];
         return e0 * xs[3] + e1 * xs[4] + e2 * xs[5] + tb0 * xn[0] + tb1 * xn[1] + tb2 * xn[2];
     };
     // x-space vector = T * (z-space vector in LDS), all NX entries, branch-free
     auto expandT = [&](const double* zsrc, double* out, bool keep_fixed) {
+        LSCQP_PHASE_LANE(lve_);
 #pragma unroll
         for (int t = 0; t < (NX + 63) / 64; t++) {
-            const int e0_ = lane + 64 * t;
+            const int e0_ = lve_ + 64 * t;
             const bool on = e0_ < NX;
             const int e = on ? e0_ : 0;
             const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
@@ -531,8 +578,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     int it = 0, near_cnt = 0;
     const double tol = cls.tol;
     const bool comm_on_k = cls.comm_range > 0;
-    // row of the scratch matrix this lane assembles into: non-z lanes share one dummy row that is never read
-    double* const hrow = &Hs[(zl ? lane : NZ) * LDH];
+    // (row of the scratch matrix a lane assembles into: non-z lanes share one dummy row, index NZ, that is never read)
 #ifdef LSCQP_PHASE_TIMING
     unsigned long long tprev_ = __builtin_readcyclecounter();
 #endif
@@ -569,6 +615,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 if (om_index(u) < om_limit(u)) om_[om_index(u)] = wl + wh;
             }
             {
+                LSCQP_L_ROLES();
                 double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0, l0 = 0, l1 = 0, l2 = 0, a0 = 0, a1 = 0, a2 = 0;
                 const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
 #pragma unroll
@@ -617,7 +664,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             // gx[k][cp] = sum_i' Q2[i][i'] c[m][i'] + 2 w_t (c[m][5] - goal) [terminal segments]  (:285-316)
             double gcost, gl, ga;
             {
-                const double gk = (zk == 0) ? goal[0] : (zk == 1) ? goal[1] : goal[2];
+                LSCQP_Z_ROLES();
+                const double gk = goal_[zk];
                 const double* cs = &c_[gbase];
                 const double* cn = &c_[gnext];
                 double g3 = 0, g4 = 0, g5 = 0, h0 = 0, h1 = 0, h2 = 0;
@@ -627,10 +675,10 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     h0 += KQ(0, ip) * cn[ip]; h1 += KQ(1, ip) * cn[ip]; h2 += KQ(2, ip) * cn[ip];
                 }
                 g5 = q2s * g5 + ((zm >= M - ts) ? wt2 * (cs[5] - gk) : 0.0);
-                LSCQP_LANE_WEIGHTS();
+                LSCQP_LANE_WEIGHTS(ZR);
                 gcost = e0 * (q2s * g3) + e1 * (q2s * g4) + e2 * g5 + q2s * (tb0 * h0 + tb1 * h1 + tb2 * h2);
-                gl = gatherT(XL);
-                ga = gatherT(XA);
+                gl = gatherT(XL, ZR);
+                ga = gatherT(XA, ZR);
                 gcost = zl ? gcost : 0.0;
                 gl = zl ? gl : 0.0;
                 ga = zl ? ga : 0.0;
@@ -648,7 +696,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             // whose stationarity has been below 1e-8 (the stated KKT tolerance) for two iterations is accepted too,
             // and so is such a point when the next factorisation breaks down (W = lambda/s spans > 1e20 by then).
             if (max_rp <= 1e-9 && rdn <= 1e-8 * gls) {  // wave-uniform
-                res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false)));
+                LSCQP_PHASE_LANE(lvo_);
+                res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false, lvo_)));
                 if (res_gap <= tol) {
                     near_cnt++;
                     if (rdn <= 10.0 * tol * gls || near_cnt >= 2) {
@@ -663,6 +712,9 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 
             // ============ assemble own row of Hred = T'(H + G'WG)T ==========================================
             {
+                LSCQP_Z_ROLES();
+                double q2 = q2s;  // opaque as well: q2*KQ(i,j) would otherwise be hoisted as 21 VGPR pairs
+                asm volatile("" : "+v"(q2));
                 const int sd = (zk == 0) ? 0 : (zk == 1) ? 3 : 5;  // S diagonal entry of axis zk
                 // local 6x6 block (upper triangle) of (axis zk, segment m): 2 w_c Q + terminal + interval/vel/acc
                 // weights + the LSC same-axis diagonal
@@ -670,7 +722,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 #pragma unroll
                     for (int i = 0; i < 6; i++)
 #pragma unroll
-                        for (int ip = i; ip < 6; ip++) B[i][ip] = q2s * KQ(i, ip);
+                        for (int ip = i; ip < 6; ip++) B[i][ip] = q2 * KQ(i, ip);
                     B[5][5] += (m >= M - ts) ? wt2 : 0.0;
                     const double* omi = &om_[zk * P + 6 * m];
                     const double* omv = &om_[C::OV + zk * 5 * M + 5 * m];
@@ -690,7 +742,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     }
                 };
                 auto sym = [](const double (&B)[6][6], int i, int ip) -> double { return i <= ip ? B[i][ip] : B[ip][i]; };
-                LSCQP_LANE_WEIGHTS();
+                LSCQP_LANE_WEIGHTS(ZR);
                 const double ej[3] = {e0, e1, e2};
                 const double tbj[3] = {tb0, tb1, tb2};
                 const int mn = has_next ? zm + 1 : zm;  // clamped: its weights tb* are zero when there is no next
@@ -769,7 +821,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                         const double old = *t;
                         if (use) *t = near ? (old - w) : -w;
                     }
-                    hrow[zl ? lane : 0] += dsum;  // dsum == 0 for lanes that are not c5 variables
+                    hrow[zl ? lvz_ : 0] += dsum;  // dsum == 0 for lanes that are not c5 variables
                 }
                 LSCQP_WAVE_LDS_SYNC();
 #pragma unroll
@@ -786,13 +838,19 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 #ifndef LSCQP_FACT_LDS_COLUMN
             // pivot row of lane j broadcast with v_readlane (2 per fp64 value), issued in batches of BB into distinct
             // scalar registers so the v_readlane -> v_fma hazard slots are filled by other broadcasts, not s_nops
+            // The lane-vs-column comparisons below are loop invariant; compared against `lane` itself hipcc hoists all
+            // 3*nz of them out of the iteration loop, which needs 2 SGPRs each, spills those into VGPR lanes
+            // (v_writelane) and pays a v_readlane + hazard nops per use.  An opaque copy of the lane id per phase keeps
+            // them where they are used: one v_cmp each.
+            int lf = lane;
+            asm volatile("" : "+v"(lf));
             static_for<0, NZ>([&](auto Jc) {
                 constexpr int j = decltype(Jc)::value;
                 const double d = bcast(A[j], j);
                 pivot_bad = pivot_bad || !(d > 1e-300);
                 const double invd = fast_rcp(d);
-                dinv_own = (lane == j) ? invd : dinv_own;
-                const double li = (lane > j) ? A[j] * invd : 0.0;
+                dinv_own = (lf == j) ? invd : dinv_own;
+                const double li = (lf > j) ? A[j] * invd : 0.0;
 #ifdef LSCQP_FACT_BB
                 constexpr int BB = LSCQP_FACT_BB;
 #else
@@ -811,7 +869,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                         if constexpr (k0 + t < NZ) A[k0 + t] = fma(-li, ub[t], A[k0 + t]);
                     });
                 });
-                A[j] = (lane > j) ? li : A[j];
+                A[j] = (lf > j) ? li : A[j];
             });
 #else
             // Measured alternative (-DLSCQP_FACT_LDS_COLUMN): LDS-column form with look-ahead.  By symmetry of the
@@ -823,6 +881,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             // overlap the remaining FMAs of step j.  End to end it is SLOWER on MI355X (0.233 vs 0.201 ms per 64-QP
             // batch): the extra VGPRs of the broadcast values push the neighbouring passes into more scratch spills.
             {
+                int lf = lane;
+                asm volatile("" : "+v"(lf));
                 col_[lane] = A[0];
                 double d = bcast(A[0], 0);
                 double invd = fast_rcp(d);
@@ -832,8 +892,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     const double* const cb = col_ + (j & 1) * 64;
                     double* const cbn = col_ + ((j + 1) & 1) * 64;
                     pivot_bad = pivot_bad || !(d > 1e-300);
-                    dinv_own = (lane == j) ? invd : dinv_own;
-                    const double li = (lane > j) ? A[j] * invd : 0.0;
+                    dinv_own = (lf == j) ? invd : dinv_own;
+                    const double li = (lf > j) ? A[j] * invd : 0.0;
                     if constexpr (j + 1 < NZ) {
                         A[j + 1] = fma(-li, cb[j + 1], A[j + 1]);
                         cbn[lane] = A[j + 1];
@@ -844,7 +904,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                         constexpr int k = decltype(Kc)::value;
                         A[k] = fma(-li, cb[k], A[k]);
                     });
-                    A[j] = (lane > j) ? li : A[j];
+                    A[j] = (lf > j) ? li : A[j];
                     LSCQP_WAVE_LDS_SYNC();
                 });
             }
@@ -854,17 +914,20 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 break;
             }
             auto solve = [&](double b) -> double {
+                int ls = lane;  // opaque per call, see the factorisation
+                asm volatile("" : "+v"(ls));
 #pragma unroll
                 for (int j = 0; j < NZ; j++) {  // L w = b (unit lower)
                     const double wj = bcast(b, j);
-                    b = fma(-((lane > j) ? A[j] : 0.0), wj, b);
+                    b = fma(-((ls > j) ? A[j] : 0.0), wj, b);
                 }
+                asm volatile("" : "+v"(ls));
                 double x = 0;
 #pragma unroll
                 for (int j = NZ - 1; j >= 0; j--) {  // (D L') x = w : row i of the upper factor is A[j>i] of lane i
                     const double xj = bcast(b * dinv_own, j);
-                    x = (lane == j) ? xj : x;
-                    b = fma(-((lane < j) ? A[j] : 0.0), xj, b);
+                    x = (ls == j) ? xj : x;
+                    b = fma(-((ls < j) ? A[j] : 0.0), xj, b);
                 }
                 return x;
             };
@@ -876,8 +939,12 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             if (zl) dz_[lane] = dza;
             // park the factor in the lane's scratch-matrix row while pass 2 runs: A[] is then dead across the pass,
             // which removes most register spills of the pass
+            {
+                LSCQP_PHASE_LANE(lvp_);
+                double* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
 #pragma unroll
-            for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
+                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
+            }
             LSCQP_WAVE_LDS_SYNC();
             expandT(dz_, dca_, false);
             LSCQP_WAVE_LDS_SYNC();
@@ -903,6 +970,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 if (on) row_scatter(XB2, u, v2);
             }
             {
+                LSCQP_L_ROLES();
                 double b10 = 0, b11 = 0, b12 = 0, b20 = 0, b21 = 0, b22 = 0;
                 const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
                 const double dx = dca_[lx], dy = dca_[P + lx], dzz = (DIM == 3) ? dca_[2 * P + lx] : 0.0;
@@ -948,24 +1016,28 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             // ============ corrector solve ==================================================================
             double gb;
             {
+                LSCQP_Z_ROLES();
                 const double* x1 = &XB1[gbase];
                 const double* x2 = &XB2[gbase];
                 const double* y1 = &XB1[gnext];
                 const double* y2 = &XB2[gnext];
-                LSCQP_LANE_WEIGHTS();
+                LSCQP_LANE_WEIGHTS(ZR);
                 gb = e0 * (smu * x1[3] + x2[3]) + e1 * (smu * x1[4] + x2[4]) + e2 * (smu * x1[5] + x2[5]) +
                      tb0 * (smu * y1[0] + y2[0]) + tb1 * (smu * y1[1] + y2[1]) + tb2 * (smu * y1[2] + y2[2]);
                 gb = zl ? gb : 0.0;
-            }
 #pragma unroll
-            for (int cidx = 0; cidx < NZ; cidx++) {
-                const double v = hrow[cidx];
-                A[cidx] = zl ? v : 0.0;
+                for (int cidx = 0; cidx < NZ; cidx++) {
+                    const double v = hrow[cidx];
+                    A[cidx] = zl ? v : 0.0;
+                }
             }
             const double dzc = solve(-gcost + gb);
-            // the scratch row must be all-zero outside the assembly pattern again
+            {  // the scratch row must be all-zero outside the assembly pattern again
+                LSCQP_PHASE_LANE(lvp_);
+                double* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
 #pragma unroll
-            for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = 0.0;
+                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = 0.0;
+            }
             if (zl) dz_[lane] = dzc;  // expandT(dca_) finished reading dz_ before
             LSCQP_WAVE_LDS_SYNC();
             expandT(dz_, dc_, false);
@@ -995,6 +1067,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 t_dl[2 * u] = on ? dll : 0.0; t_dl[2 * u + 1] = on ? dlh : 0.0;
             }
             {
+                LSCQP_L_ROLES();
                 const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
                 const double ax = dca_[lx], ay = dca_[P + lx], az = (DIM == 3) ? dca_[2 * P + lx] : 0.0;
                 const double dx = dc_[lx], dy = dc_[P + lx], dzz = (DIM == 3) ? dc_[2 * P + lx] : 0.0;
@@ -1052,8 +1125,11 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     if (status == LSCQP_STATUS_NUMERIC && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
 
     // ---- epilogue: objective, control points back in the world frame ---------------------------------------
-    const double obj = objective(true);
-    for (int e = lane; e < NX; e += 64) x_out[q * NX + e] = c_[e] + org[e / P];
+    const double obj = objective(true, lane);
+    for (int e = lane; e < NX; e += 64) {
+        const int k = e / P;
+        x_out[q * NX + e] = c_[e] + H->p0[k];
+    }
     if (lane == 0) {
         obj_out[q] = obj;
         status_out[q] = status;

@@ -17,7 +17,7 @@ M, D, NSLOT = [int(v) for v in (nums + ["5", "3", "10"][len(nums):])]
 os.makedirs("/tmp/asm", exist_ok=True)
 open("/tmp/asm/tu.hip", "w").write(
     '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT))
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-DLSCQP_PHASE_TIMING",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector", "-DLSCQP_PHASE_TIMING",
                        "-I", SRC, "-S", "--cuda-device-only", "/tmp/asm/tu.hip", "-o", "/tmp/asm/tu_t.s"] + flags, stderr=subprocess.DEVNULL)
 lines = open("/tmp/asm/tu_t.s").read().split("\n")
 start = [i for i, l in enumerate(lines) if l.startswith("_ZN5lscqp17lscqp_pdip_kernel") and ":" in l][0]

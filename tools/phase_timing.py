@@ -21,7 +21,7 @@ if not os.path.exists(OUT) or "--rebuild" in sys.argv or True:
     # single TU so that the __device__ symbol is shared: include the instance + api sources
     tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT) + drv
     open(os.path.join("/tmp", "prof_tu.hip"), "w").write(tu)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector",
                            "-DLSCQP_PHASE_TIMING", "-I", SRC, "/tmp/prof_tu.hip", "-o", OUT] + xflags, stderr=subprocess.DEVNULL)
 if "--build-only" in sys.argv:
     sys.exit(0)
