@@ -11,10 +11,10 @@
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
 
-#define LSCQP_DECL(M, D, E, S)                                                                                       \
-    extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S(const lscqp::DevClass*, int64_t, const lscqp_header*,    \
-                                                             const lscqp_row*, const uint64_t*, const lscqp_box*,     \
-                                                             double*, double*, int32_t*, lscqp_info*, hipStream_t);
+#define LSCQP_DECL(M, D, E, S, W)                                                                                      \
+    extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S##_##W(const lscqp::DevClass*, int64_t, const lscqp_header*, \
+                                                                  const lscqp_row*, const uint64_t*, const lscqp_box*,  \
+                                                                  double*, double*, int32_t*, lscqp_info*, hipStream_t);
 LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
@@ -30,9 +30,9 @@ struct Inst {
     int M, dim, es, max_obs;
     lscqp::launch_fn fn;
 };
-constexpr int max_obs_of(int M, int nslot) { return nslot * ((64 / (6 * M - 3)) > 0 ? (64 / (6 * M - 3)) : 1); }
+constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
-#define LSCQP_ROW(M, D, E, S) {M, D, E, max_obs_of(M, S), lscqp_launch_##M##_##D##_##E##_##S},
+#define LSCQP_ROW(M, D, E, S, W) {M, D, E, max_obs_of(M, S, W), lscqp_launch_##M##_##D##_##E##_##S##_##W},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
@@ -78,7 +78,7 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     const int es = (d->planner_mode == LSCQP_PLANNER_LSC) ? 1 : 0;
     if (!shape_exists(d->M, d->dim, es)) {
         char buf[160];
-        snprintf(buf, sizeof buf, "no compiled kernel instance for M=%d dim=%d end_stop=%d (needs dim*(3M-2) <= 64)", d->M, d->dim, es);
+        snprintf(buf, sizeof buf, "no compiled kernel instance for M=%d dim=%d end_stop=%d (compiled shapes: csrc/lscqp_launch.hpp; needs dim*(3M-2) <= 128)", d->M, d->dim, es);
         return fail(LSCQP_ERR_UNSUPPORTED, buf);
     }
     s->desc = *d;

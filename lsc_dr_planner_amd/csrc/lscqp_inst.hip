@@ -1,18 +1,21 @@
 // One kernel instance per translation unit so the instances compile in parallel.
-// Built with -DLSCQP_M=<M> -DLSCQP_DIM=<dim> -DLSCQP_ES=<0|1> -DLSCQP_NSLOT=<slots>;
-// exports lscqp_launch_<M>_<dim>_<ES>_<NSLOT>.
+// Built with -DLSCQP_M=<M> -DLSCQP_DIM=<dim> -DLSCQP_ES=<0|1> -DLSCQP_NSLOT=<slots> -DLSCQP_W=<wavefronts per QP>;
+// exports lscqp_launch_<M>_<dim>_<ES>_<NSLOT>_<W>.
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
 
-#define LSCQP_CAT_(a, b, c, d, e) a##b##_##c##_##d##_##e
-#define LSCQP_CAT(a, b, c, d, e) LSCQP_CAT_(a, b, c, d, e)
-#define LSCQP_FN LSCQP_CAT(lscqp_launch_, LSCQP_M, LSCQP_DIM, LSCQP_ES, LSCQP_NSLOT)
+#ifndef LSCQP_W
+#define LSCQP_W 1
+#endif
+#define LSCQP_CAT_(a, b, c, d, e, f) a##b##_##c##_##d##_##e##_##f
+#define LSCQP_CAT(a, b, c, d, e, f) LSCQP_CAT_(a, b, c, d, e, f)
+#define LSCQP_FN LSCQP_CAT(lscqp_launch_, LSCQP_M, LSCQP_DIM, LSCQP_ES, LSCQP_NSLOT, LSCQP_W)
 
 extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
                                const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
                                int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
-    using C = lscqp::Cfg<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT>;
-    auto kern = lscqp::lscqp_pdip_kernel<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT>;
+    using C = lscqp::Cfg<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT, LSCQP_W>;
+    auto kern = lscqp::lscqp_pdip_kernel<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT, LSCQP_W>;
     constexpr size_t lds = C::lds_bytes();
     static_assert(lds <= lscqp::kMaxLdsBytes, "instance does not fit the LDS of one CU");
     if (cls->n_obs_max > C::MAX_OBS) return hipErrorInvalidValue;
@@ -23,7 +26,7 @@ extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscq
         attr_set = true;
     }
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, stream, *cls, n, hdr, rows, row_offsets, sfc, x_out, obj_out,
+    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(C::T), lds, stream, *cls, n, hdr, rows, row_offsets, sfc, x_out, obj_out,
                        status_out, info_out);
     return hipGetLastError();
 }

@@ -4,7 +4,9 @@
 // model TrajOptimizer::populatebyrow builds (src/traj_optimizer.cpp:216-514).  Not a translation of either:
 //
 //   * ONE WAVEFRONT (64 lanes) PER QP, one workgroup per wavefront; the kernel is issue/latency bound on fp64 VALU,
-//     so everything is organised to minimise the instruction count of one Mehrotra iteration.
+//     so everything is organised to minimise the instruction count of one Mehrotra iteration.  Classes whose reduced
+//     system has more than 64 rows (M = 10 in 3-D: nz = 84) run the same code with W = 2 wavefronts per QP: lane ->
+//     thread of the workgroup, wave reductions -> wave + LDS, v_readlane broadcasts -> LDS columns + s_barrier.
 //   * The equality rows (:318-368, 502-511) are eliminated analytically: per axis the free variables are
 //     z = (c3,c4,c5) of every segment (one scalar for the last segment under the LSC end stop);
 //     (c0,c1,c2) of segment m+1 = TB (c3,c4,c5) of segment m, TB = [[0,0,1],[0,-1,2],[1,-4,4]].
@@ -127,6 +129,9 @@ __device__ __forceinline__ double fast_rcp(double d) {
 #define LSCQP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Development aid: -DLSCQP_DEBUG_STOP=k leaves the iteration loop at stage k (bisecting device faults).
+#ifndef LSCQP_CENTRALITY_GAMMA
+#define LSCQP_CENTRALITY_GAMMA 1e-4
+#endif
 #ifndef LSCQP_DEBUG_STOP
 #define LSCQP_DEBUG_STOP 0
 #endif
@@ -153,26 +158,28 @@ __device__ unsigned long long lscqp_dbg_cycles[16];
     } while (0)
 #endif
 
-template <int M_, int DIM_, bool ES_, int NSLOT_>
+template <int M_, int DIM_, bool ES_, int NSLOT_, int W_ = 1>
 struct Cfg {
-    static constexpr int M = M_, DIM = DIM_, NSLOT = NSLOT_;
+    static constexpr int M = M_, DIM = DIM_, NSLOT = NSLOT_, W = W_;
+    static constexpr int T = 64 * W;  // threads per QP
     static constexpr bool ES = ES_;
     static constexpr int P = 6 * M;
     static constexpr int CP = P - 3;  // control points that carry LSC rows (all but the initial state, :404-406)
     static constexpr int NZA = 3 * (M - 1) + (ES ? 1 : 3);
     static constexpr int NZ = DIM * NZA;
     static constexpr int NX = DIM * P;  // x-space size
-    static constexpr int G = (64 / CP) > 0 ? (64 / CP) : 1;  // lane groups of the LSC pass
+    static constexpr int G = (T / CP) > 0 ? (T / CP) : 1;  // lane groups of the LSC pass
     static constexpr int MAX_OBS = NSLOT * G;
     // two-sided per-axis rows, one type per register slot
     static constexpr int NV = DIM * 5 * M, NA = DIM * 4 * M, NCP = M * (M - 1) / 2, NC = DIM * NCP;
-    static constexpr int SI = (NX + 63) / 64, SV = (NV + 63) / 64, SA = (NA + 63) / 64, SC = (NC + 63) / 64;
+    static constexpr int SI = (NX + T - 1) / T, SV = (NV + T - 1) / T, SA = (NA + T - 1) / T, SC = (NC + T - 1) / T;
     static constexpr int NS2 = SI + SV + SA + SC;
     // weights of the two-sided rows in LDS: [interval NX][vel NV][acc NA][comm NC]
     static constexpr int OV = NX, OA = NX + NV, OC = NX + NV + NA, NOM = NX + NV + NA + NC;
     static constexpr int LDH = NZ | 1;
-    static_assert(NZ <= 64, "lane-per-row kernel needs dim*(3M-2) <= 64");
-    static_assert(CP <= 64, "M <= 11");
+    static_assert(NZ <= T, "lane-per-row kernel needs dim*(3M-2) <= 64*W");
+    static_assert(CP <= T, "6M-3 <= 64*W");
+    static_assert(W == 1 || W == 2, "one or two wavefronts per QP");
     static_assert(M >= 2, "the reference assumes M >= 2 (src/traj_optimizer.cpp:341-352)");
     // LDS carve (in doubles)
     static constexpr int o_c = 0;               // control points (translated)
@@ -182,23 +189,24 @@ struct Cfg {
     static constexpr int o_S = o_x0 + 4 * NX;   // per-cp 3x3 sym blocks [P][6]
     static constexpr int o_om = o_S + 6 * P;    // two-sided row weights
     static constexpr int o_z = o_om + NOM;      // z, dz
-    static constexpr int o_goal = o_z + 2 * 64;  // goal - p0 (4 doubles)
-    static constexpr int o_col = o_goal + 4;     // pivot-column broadcast buffer
-    static constexpr int o_H = ((o_col + 130 + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH]
+    static constexpr int o_goal = o_z + 2 * T;  // goal - p0 (4 doubles)
+    static constexpr int o_red = o_goal + 4;    // cross-wave reduction scratch (W > 1): 2 buffers x W waves x 4
+    static constexpr int o_col = o_red + (W > 1 ? 8 * W : 0);  // pivot-column / solve broadcast buffer, 2 x T
+    static constexpr int o_H = ((o_col + 2 * T + 2 + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH]
     static constexpr int o_rows = ((o_H + (NZ + 1) * LDH + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
     static constexpr int NROW = MAX_OBS * CP;  // + one dead row per array
     static constexpr size_t lds_bytes() { return sizeof(double) * ((size_t)o_rows + 4 * ((size_t)NROW + 1)); }
 };
 
-template <int M, int DIM, bool ES, int NSLOT>
-__global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
+template <int M, int DIM, bool ES, int NSLOT, int W = 1>
+__global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows,
                                                         const uint64_t* __restrict__ row_offsets,
                                                         const lscqp_box* __restrict__ sfc, double* __restrict__ x_out,
                                                         double* __restrict__ obj_out, int32_t* __restrict__ status_out,
                                                         lscqp_info* __restrict__ info_out) {
-    using C = Cfg<M, DIM, ES, NSLOT>;
-    constexpr int P = C::P, CP = C::CP, NZA = C::NZA, NZ = C::NZ, NX = C::NX, G = C::G, LDH = C::LDH;
+    using C = Cfg<M, DIM, ES, NSLOT, W>;
+    constexpr int P = C::P, CP = C::CP, NZA = C::NZA, NZ = C::NZ, NX = C::NX, G = C::G, LDH = C::LDH, T = C::T;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* const c_ = smem + C::o_c;
     double* const dca_ = smem + C::o_dca;
@@ -210,9 +218,11 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     double* const S_ = smem + C::o_S;
     double* const om_ = smem + C::o_om;
     double* const z_ = smem + C::o_z;
-    double* const dz_ = smem + C::o_z + 64;
+    double* const dz_ = smem + C::o_z + T;
     double* const goal_ = smem + C::o_goal;
+    double* const red_ = smem + C::o_red;
     double* const col_ = smem + C::o_col;
+    (void)red_;
     double* const Hs = smem + C::o_H;
     constexpr int NROW = C::NROW;
     double* const Rnx = smem + C::o_rows;
@@ -220,7 +230,70 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     double* const Rnz = Rny + (NROW + 1);
     double* const Rb = Rnz + (NROW + 1);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;  // thread of the QP's workgroup, 0 .. 64*W-1 ("lane" throughout)
+    // Hand-off through LDS between the lanes of the QP: see LSCQP_WAVE_LDS_SYNC for W = 1; a real barrier for W = 2.
+    // Every branch around a BLOCK_SYNC is workgroup-uniform (conditions come out of block reductions / LDS broadcasts).
+#define LSCQP_BLOCK_SYNC()                       \
+    do {                                         \
+        if constexpr (W == 1) {                  \
+            LSCQP_WAVE_LDS_SYNC();               \
+        } else {                                 \
+            __syncthreads();                     \
+        }                                        \
+    } while (0)
+    // cross-wave stage of the block reductions (W = 2): wave results meet in LDS, alternating between two buffers so
+    // that one barrier per reduction suffices
+    int red_flip = 0;
+    auto cross3 = [&](double& a, double& b, double& c, auto opa, auto opb, auto opc) {
+        if constexpr (W > 1) {
+            double* const buf = red_ + red_flip * 4 * W;
+            red_flip ^= 1;
+            if ((lane & 63) == 0) {
+                double* const mine = buf + 4 * (lane >> 6);
+                mine[0] = a;
+                mine[1] = b;
+                mine[2] = c;
+            }
+            __syncthreads();
+            a = buf[0];
+            b = buf[1];
+            c = buf[2];
+#pragma unroll
+            for (int w = 1; w < W; w++) {
+                a = opa(a, buf[4 * w + 0]);
+                b = opb(b, buf[4 * w + 1]);
+                c = opc(c, buf[4 * w + 2]);
+            }
+        }
+    };
+    auto op_sum = [](double x, double y) { return x + y; };
+    auto op_max = [](double x, double y) { return fmax(x, y); };
+    auto block_sum2_max1 = [&](double& a, double& b, double& c) {
+        wave_sum2_max1(a, b, c);
+        cross3(a, b, c, op_sum, op_sum, op_max);
+    };
+    auto block_max2 = [&](double& a, double& b) {
+        wave_max2(a, b);
+        double c = 0;
+        cross3(a, b, c, op_max, op_max, op_max);
+    };
+    auto block_max1_sum1 = [&](double& a, double& b) {
+        wave_max1_sum1(a, b);
+        double c = 0;
+        cross3(a, b, c, op_max, op_sum, op_max);
+    };
+    auto block_sum = [&](double v) -> double {
+        v = wave_sum(v);
+        double b = 0, c = 0;
+        cross3(v, b, c, op_sum, op_sum, op_sum);
+        return v;
+    };
+    auto block_max = [&](double v) -> double {
+        v = wave_max(v);
+        double b = 0, c = 0;
+        cross3(v, b, c, op_max, op_max, op_max);
+        return v;
+    };
     const int64_t q = blockIdx.x;
     if (q >= n) return;
     const lscqp_header* H = hdr + q;
@@ -319,7 +392,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     const int lx = lcp + 3;  // index within one axis of c_
 
     // ---- control points: fixed part from (p0, v0, a0) (:321-338), free part = "stay at c2" ----------------
-    for (int e = lane; e < NX; e += 64) {
+    for (int e = lane; e < NX; e += T) {
         const int k = e / P, cp = e % P;
         const double cf1 = H->v0[k] * dt * 0.2;                    // c1 - c0
         const double cf2 = H->a0[k] * dt * dt * 0.05 + 2.0 * cf1;  // c2 - c0
@@ -338,7 +411,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     {
         const lscqp_row* R = rows + row_offsets[q];
         const int nact = n_obs * CP;
-        for (int e = lane; e < nact; e += 64) {
+        for (int e = lane; e < nact; e += T) {
             const int o = e / CP, cp = e % CP;
             const double4 v = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
             double nx = v.x, ny = v.y, nz = (DIM == 3) ? v.z : 0.0;
@@ -379,7 +452,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             t_lo[u] = -1.0;
             t_hi[u] = 1.0;
             if (u < C::SI) {  // interval on one control point
-                const int e = lane + 64 * u;
+                const int e = lane + T * u;
                 if (e < NX) {
                     const int k = e / P, cp = e % P, m = cp / 6;
                     if (cp >= 3) {
@@ -401,7 +474,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     }
                 }
             } else if (u < C::SI + C::SV) {  // velocity (m,i): c[i+1]-c[i], |.| <= vmax dt/n   (:448-453)
-                const int v = lane + 64 * (u - C::SI);
+                const int v = lane + T * (u - C::SI);
                 if (v < C::NV) {
                     const int k = v / (5 * M), r = v % (5 * M), m = r / 5, i = r % 5;
                     if (!(m == 0 && i < 2)) {
@@ -411,7 +484,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     }
                 }
             } else if (u < C::SI + C::SV + C::SA) {  // acceleration (m,i): c[i+2]-2c[i+1]+c[i]   (:462-471)
-                const int a = lane + 64 * (u - C::SI - C::SV);
+                const int a = lane + T * (u - C::SI - C::SV);
                 if (a < C::NA) {
                     const int k = a / (4 * M), r = a % (4 * M), m = r / 4, i = r % 4;
                     if (!(m == 0 && i < 1)) {
@@ -421,7 +494,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     }
                 }
             } else {  // pair (uu, up<uu): c[uu][5] - c[up+1][0]   (:482-487 with mi = up+1 >= 1)
-                const int cc = lane + 64 * (u - C::SI - C::SV - C::SA);
+                const int cc = lane + T * (u - C::SI - C::SV - C::SA);
                 if (cc < C::NC && comm_on) {
                     const int k = cc / C::NCP, ci = cc % C::NCP;
                     int uu = 1;
@@ -443,27 +516,41 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
         if (u < C::SI + C::SV + C::SA) return v[ix + 2] - 2.0 * v[ix + 1] + v[ix];
         return v[t_i2[u]] - v[ix];
     };
-    auto row_scatter = [&](double* X, int u, double val) {
+    auto row_scatter = [&](double* X, int u, double val, bool pred) {
         const int ix = t_ix[u];
         if (u < C::SI) {
-            atomicAdd(&X[ix], val);
+            if (pred) atomicAdd(&X[ix], val);
         } else if (u < C::SI + C::SV) {
-            atomicAdd(&X[ix + 1], val);
-            atomicAdd(&X[ix], -val);
+            if (pred) atomicAdd(&X[ix + 1], val);
+            if (pred) atomicAdd(&X[ix], -val);
         } else if (u < C::SI + C::SV + C::SA) {
-            atomicAdd(&X[ix + 2], val);
-            atomicAdd(&X[ix + 1], -2.0 * val);
-            atomicAdd(&X[ix], val);
+            if (pred) atomicAdd(&X[ix + 2], val);
+            if (pred) atomicAdd(&X[ix + 1], -2.0 * val);
+            if (pred) atomicAdd(&X[ix], val);
         } else {
-            atomicAdd(&X[t_i2[u]], val);
-            atomicAdd(&X[ix], -val);
+            if (pred) atomicAdd(&X[t_i2[u]], val);
+            if (pred) atomicAdd(&X[ix], -val);
+        }
+    };
+    // LDS accumulation in a fixed order: with two wavefronts per QP the ds_add_f64 of the waves would interleave
+    // differently from run to run (floating-point sums are order dependent); the waves take turns instead, so results
+    // stay bitwise reproducible.  f(turn) issues its atomics predicated on `turn`.
+    auto wave_ordered = [&](auto&& f) {
+        if constexpr (W == 1) {
+            f(true);
+        } else {
+#pragma unroll
+            for (int w_ = 0; w_ < W; w_++) {
+                f((lane >> 6) == w_);
+                if (w_ + 1 < W) __syncthreads();
+            }
         }
     };
     auto om_index = [&](int u) -> int {  // where this slot's weight lives in om_
-        if (u < C::SI) return lane + 64 * u;
-        if (u < C::SI + C::SV) return C::OV + lane + 64 * (u - C::SI);
-        if (u < C::SI + C::SV + C::SA) return C::OA + lane + 64 * (u - C::SI - C::SV);
-        return C::OC + lane + 64 * (u - C::SI - C::SV - C::SA);
+        if (u < C::SI) return lane + T * u;
+        if (u < C::SI + C::SV) return C::OV + lane + T * (u - C::SI);
+        if (u < C::SI + C::SV + C::SA) return C::OA + lane + T * (u - C::SI - C::SV);
+        return C::OC + lane + T * (u - C::SI - C::SV - C::SA);
     };
     auto om_limit = [&](int u) -> int {
         if (u < C::SI) return C::OV;
@@ -511,8 +598,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 }
             }
         }
-        m_tot = wave_sum(cnt);
-        if (__any(bad)) status = LSCQP_STATUS_INFEASIBLE;  // empty interval: lo > hi
+        m_tot = block_sum(cnt);
+        if (block_max(bad ? 1.0 : 0.0) > 0.0) status = LSCQP_STATUS_INFEASIBLE;  // empty interval: lo > hi
     }
     const double inv_m = 1.0 / m_tot;
 
@@ -544,7 +631,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
         }
         const double dgoal = cc[5] - goal_[k];
         part += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
-        return wave_sum(on ? part : 0.0);
+        return block_sum(on ? part : 0.0);
     };
     // gather an x-space vector into the own z component: (T' v)_r.  Lanes without a next segment read the clamped
     // segment with zero weights; non-z lanes compute a value that is never used.
@@ -558,8 +645,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     auto expandT = [&](const double* zsrc, double* out, bool keep_fixed) {
         LSCQP_PHASE_LANE(lve_);
 #pragma unroll
-        for (int t = 0; t < (NX + 63) / 64; t++) {
-            const int e0_ = lve_ + 64 * t;
+        for (int t = 0; t < (NX + T - 1) / T; t++) {
+            const int e0_ = lve_ + T * t;
             const bool on = e0_ < NX;
             const int e = on ? e0_ : 0;
             const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
@@ -575,7 +662,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
     double A[NZ];  // row `lane` of the reduced KKT matrix, then its LDL^T factors
     double dinv_own = 0.0;
     double res_p = 0, res_d = 0, res_gap = 0;
-    int it = 0, near_cnt = 0;
+    int it = 0, near_cnt = 0, floor_cnt = 0;
     const double tol = cls.tol;
     const bool comm_on_k = cls.comm_range > 0;
     // (row of the scratch matrix a lane assembles into: non-z lanes share one dummy row, index NZ, that is never read)
@@ -594,12 +681,13 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             LSCQP_STOP(1)
             // ============ pass 1: residuals, weights, per-cp blocks =========================================
 #pragma unroll
-            for (int t = 0; t < (4 * NX + 6 * P + 63) / 64; t++) {
-                const int e = lane + 64 * t;
+            for (int t = 0; t < (4 * NX + 6 * P + T - 1) / T; t++) {
+                const int e = lane + T * t;
                 if (e < 4 * NX + 6 * P) smem[C::o_x0 + e] = 0.0;  // XL,XA,XB1,XB2,S
             }
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             double sum_sl = 0, sum_pinf = 0, max_rp = 0;
+            double sc1[NS2], sc2[NS2];  // W > 1: scatter values of the two-sided rows, flushed in wave order below
 #pragma unroll
             for (int u = 0; u < NS2; u++) {
                 const bool on = t_ix[u] >= 0;  // rows that do not exist carry s = 1, lambda = 0, lo = -1, hi = 1
@@ -610,8 +698,13 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 sum_sl += t_sl[u] * t_ll[u] + t_sh[u] * t_lh[u];
                 sum_pinf += t_ll[u] * fabs(rpl) + t_lh[u] * fabs(rph);
                 max_rp = fmax(max_rp, fmax(fabs(rpl), fabs(rph)));
-                if (on) row_scatter(XL, u, t_ll[u] - t_lh[u]);
-                if (on) row_scatter(XA, u, wh * rph - wl * rpl);
+                if constexpr (W == 1) {
+                    row_scatter(XL, u, t_ll[u] - t_lh[u], on);
+                    row_scatter(XA, u, wh * rph - wl * rpl, on);
+                } else {
+                    sc1[u] = t_ll[u] - t_lh[u];
+                    sc2[u] = wh * rph - wl * rpl;
+                }
                 if (om_index(u) < om_limit(u)) om_[om_index(u)] = wl + wh;
             }
             {
@@ -643,20 +736,29 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     }
                     }
                 const int cp6 = lx * 6;
-                if (ll) {
-                    atomicAdd(&S_[cp6 + 0], s00); atomicAdd(&S_[cp6 + 1], s01); atomicAdd(&S_[cp6 + 3], s11);
-                    atomicAdd(&XL[lx], l0); atomicAdd(&XL[P + lx], l1);
-                    atomicAdd(&XA[lx], a0); atomicAdd(&XA[P + lx], a1);
-                    if (DIM == 3) {
-                        atomicAdd(&S_[cp6 + 2], s02); atomicAdd(&S_[cp6 + 4], s12); atomicAdd(&S_[cp6 + 5], s22);
-                        atomicAdd(&XL[2 * P + lx], l2);
-                        atomicAdd(&XA[2 * P + lx], a2);
+                wave_ordered([&](bool turn) {
+                    if constexpr (W > 1) {
+#pragma unroll
+                        for (int u = 0; u < NS2; u++) {
+                            row_scatter(XL, u, sc1[u], turn && t_ix[u] >= 0);
+                            row_scatter(XA, u, sc2[u], turn && t_ix[u] >= 0);
+                        }
                     }
-                }
+                    if (ll && turn) {
+                        atomicAdd(&S_[cp6 + 0], s00); atomicAdd(&S_[cp6 + 1], s01); atomicAdd(&S_[cp6 + 3], s11);
+                        atomicAdd(&XL[lx], l0); atomicAdd(&XL[P + lx], l1);
+                        atomicAdd(&XA[lx], a0); atomicAdd(&XA[P + lx], a1);
+                        if (DIM == 3) {
+                            atomicAdd(&S_[cp6 + 2], s02); atomicAdd(&S_[cp6 + 4], s12); atomicAdd(&S_[cp6 + 5], s22);
+                            atomicAdd(&XL[2 * P + lx], l2);
+                            atomicAdd(&XA[2 * P + lx], a2);
+                        }
+                    }
+                });
             }
-            wave_sum2_max1(sum_sl, sum_pinf, max_rp);
+            block_sum2_max1(sum_sl, sum_pinf, max_rp);
             const double mu = sum_sl * inv_m;
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             LSCQP_T(1);
             LSCQP_STOP(2)
 
@@ -685,7 +787,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             }
             double rdn = fabs(gcost - gl);
             double gls = fmax(fabs(gcost), fabs(gl));
-            wave_max2(rdn, gls);
+            block_max2(rdn, gls);
             gls = fmax(1.0, gls);
             res_p = max_rp;
             res_d = rdn / gls;
@@ -695,14 +797,20 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
             // which can sit between the strict target and 1e-8: a point that satisfies the primal and gap tests and
             // whose stationarity has been below 1e-8 (the stated KKT tolerance) for two iterations is accepted too,
             // and so is such a point when the next factorisation breaks down (W = lambda/s spans > 1e20 by then).
-            if (max_rp <= 1e-9 && rdn <= 1e-8 * gls) {  // wave-uniform
+            // A point that meets the primal and gap tests while its stationarity is still above 1e-8 (cond(Hred) ~ 1e7 at
+            // M = 10 in 3-D leaves a rounding floor of ~2e-8) is remembered as well (floor_cnt): if the iteration later
+            // stalls or breaks down numerically, the result is accepted rather than reported as a failure.
+            if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {  // uniform over the QP's lanes
                 LSCQP_PHASE_LANE(lvo_);
                 res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false, lvo_)));
                 if (res_gap <= tol) {
-                    near_cnt++;
-                    if (rdn <= 10.0 * tol * gls || near_cnt >= 2) {
-                        status = LSCQP_STATUS_OPTIMAL;
-                        break;
+                    floor_cnt++;
+                    if (rdn <= 1e-8 * gls) {
+                        near_cnt++;
+                        if (rdn <= 10.0 * tol * gls || near_cnt >= 2) {
+                            status = LSCQP_STATUS_OPTIMAL;
+                            break;
+                        }
                     }
                 }
             } else
@@ -835,6 +943,7 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 
             // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
+            if constexpr (W == 1) {
 #ifndef LSCQP_FACT_LDS_COLUMN
             // pivot row of lane j broadcast with v_readlane (2 per fp64 value), issued in batches of BB into distinct
             // scalar registers so the v_readlane -> v_fma hazard slots are filled by other broadcasts, not s_nops
@@ -909,23 +1018,57 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 });
             }
 #endif
-            if (pivot_bad) {  // wave-uniform
-                status = near_cnt > 0 ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+            } else {
+                // W = 2: the rows live in the registers of two wavefronts.  By symmetry of the trailing matrix the pivot
+                // row of step j equals the pivot COLUMN, of which every lane holds one entry (its A[j]): published to
+                // LDS (double buffered), one s_barrier per column, read back with uniform-address ds_reads.
+                int lf = lane;
+                asm volatile("" : "+v"(lf));
+                static_for<0, NZ>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    double* const cb = col_ + (j & 1) * T;
+                    cb[lane] = A[j];
+                    __syncthreads();
+                    const double d = cb[j];
+                    pivot_bad = pivot_bad || !(d > 1e-300);
+                    const double invd = fast_rcp(d);
+                    dinv_own = (lf == j) ? invd : dinv_own;
+                    const double li = (lf > j) ? A[j] * invd : 0.0;
+                    static_for<j + 1, NZ>([&](auto Kc) {
+                        constexpr int k = decltype(Kc)::value;
+                        A[k] = fma(-li, cb[k], A[k]);
+                    });
+                    A[j] = (lf > j) ? li : A[j];
+                });
+            }
+            if (pivot_bad) {  // uniform over the QP's lanes
+                status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 break;
             }
+            // broadcast of lane j's value to all lanes of the QP: v_readlane (W = 1) or an LDS slot + barrier (W = 2; one
+            // slot per column and direction, so no slot is rewritten while a slower wavefront may still read it)
+            auto bcast_q = [&](double v, int j, int ls, double* slots) -> double {
+                if constexpr (W == 1) {
+                    return bcast(v, j);
+                } else {
+                    if (ls == j) slots[j] = v;
+                    __syncthreads();
+                    return slots[j];
+                }
+            };
             auto solve = [&](double b) -> double {
                 int ls = lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
 #pragma unroll
                 for (int j = 0; j < NZ; j++) {  // L w = b (unit lower)
-                    const double wj = bcast(b, j);
+                    const double wj = bcast_q(b, j, ls, col_);
                     b = fma(-((ls > j) ? A[j] : 0.0), wj, b);
                 }
                 asm volatile("" : "+v"(ls));
                 double x = 0;
 #pragma unroll
                 for (int j = NZ - 1; j >= 0; j--) {  // (D L') x = w : row i of the upper factor is A[j>i] of lane i
-                    const double xj = bcast(b * dinv_own, j);
+                    const double xj = bcast_q(b * dinv_own, j, ls, col_ + T);
                     x = (ls == j) ? xj : x;
                     b = fma(-((ls < j) ? A[j] : 0.0), xj, b);
                 }
@@ -945,9 +1088,9 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
             }
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             expandT(dz_, dca_, false);
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             LSCQP_T(5);
             LSCQP_STOP(6)
             // ============ pass 2: affine step length, mu_aff, corrector right-hand side ======================
@@ -966,8 +1109,13 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 sB += on ? (pl + ph) : 0.0;
                 const double v1 = isl - ish;
                 const double v2 = (-pl - t_ll[u] * rpl) * isl - (-ph - t_lh[u] * rph) * ish;
-                if (on) row_scatter(XB1, u, v1);
-                if (on) row_scatter(XB2, u, v2);
+                if constexpr (W == 1) {
+                    row_scatter(XB1, u, v1, on);
+                    row_scatter(XB2, u, v2, on);
+                } else {
+                    sc1[u] = v1;
+                    sc2[u] = v2;
+                }
             }
             {
                 LSCQP_L_ROLES();
@@ -994,23 +1142,32 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                         b22 += t2 * nz;
                     }
                     }
-                if (ll) {
-                    atomicAdd(&XB1[lx], b10); atomicAdd(&XB1[P + lx], b11);
-                    atomicAdd(&XB2[lx], b20); atomicAdd(&XB2[P + lx], b21);
-                    if (DIM == 3) {
-                        atomicAdd(&XB1[2 * P + lx], b12);
-                        atomicAdd(&XB2[2 * P + lx], b22);
+                wave_ordered([&](bool turn) {
+                    if constexpr (W > 1) {
+#pragma unroll
+                        for (int u = 0; u < NS2; u++) {
+                            row_scatter(XB1, u, sc1[u], turn && t_ix[u] >= 0);
+                            row_scatter(XB2, u, sc2[u], turn && t_ix[u] >= 0);
+                        }
                     }
-                }
+                    if (ll && turn) {
+                        atomicAdd(&XB1[lx], b10); atomicAdd(&XB1[P + lx], b11);
+                        atomicAdd(&XB2[lx], b20); atomicAdd(&XB2[P + lx], b21);
+                        if (DIM == 3) {
+                            atomicAdd(&XB1[2 * P + lx], b12);
+                            atomicAdd(&XB2[2 * P + lx], b22);
+                        }
+                    }
+                });
             }
-            wave_max1_sum1(rmax, sB);
+            block_max1_sum1(rmax, sB);
             const double a_aff = fast_rcp(rmax);
             // sum(s dl_a + lam ds_a) == -sum(s lam) by construction of the affine direction
             const double mu_aff = ((1.0 - a_aff) * sum_sl + a_aff * a_aff * sB) * inv_m;
             double sigma = fmax(mu_aff, 0.0) / mu;
             sigma = sigma * sigma * sigma;
             const double smu = sigma * mu;
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             LSCQP_T(6);
             LSCQP_STOP(7)
             // ============ corrector solve ==================================================================
@@ -1039,14 +1196,15 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = 0.0;
             }
             if (zl) dz_[lane] = dzc;  // expandT(dca_) finished reading dz_ before
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             expandT(dz_, dc_, false);
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             LSCQP_T(7);
             LSCQP_STOP(8)
             // ============ pass 3: step length ==============================================================
             // ds = G dc + rp,  dl = (sigma mu - ds_a dl_a)/s - lam - w ds;  ratios -ds/s and -dl/lam
             rmax = 0.0;
+            double sdl = 0, sdd = 0;  // sum(s dl + lam ds), sum(ds dl): mu along the step is a quadratic in alpha
             double t_ds[2 * NS2], t_dl[2 * NS2], r_ds[NSLOT], r_dl[NSLOT];  // live only until the update below
 #pragma unroll
             for (int u = 0; u < NS2; u++) {
@@ -1065,6 +1223,8 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 rmax = fmax(rmax, on ? rr : 0.0);
                 t_ds[2 * u] = on ? dsl : 0.0; t_ds[2 * u + 1] = on ? dsh : 0.0;
                 t_dl[2 * u] = on ? dll : 0.0; t_dl[2 * u + 1] = on ? dlh : 0.0;
+                sdl += t_sl[u] * t_dl[2 * u] + t_ll[u] * t_ds[2 * u] + t_sh[u] * t_dl[2 * u + 1] + t_lh[u] * t_ds[2 * u + 1];
+                sdd += t_ds[2 * u] * t_dl[2 * u] + t_ds[2 * u + 1] * t_dl[2 * u + 1];
             }
             {
                 LSCQP_L_ROLES();
@@ -1087,11 +1247,36 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                     rmax = fmax(rmax, fmax(-ds * is, -dl * il));
                     r_ds[u] = act ? ds : 0.0;
                     r_dl[u] = dl;
+                    sdl += s * r_dl[u] + l * r_ds[u];
+                    sdd += r_ds[u] * r_dl[u];
                     }
             }
-            rmax = wave_max(rmax);
+            block_sum2_max1(sdl, sdd, rmax);
             // alpha = min(1, tau / rmax), fraction to the boundary tau = 0.9995
-            const double alpha = (rmax > 0.9995) ? 0.9995 * fast_rcp(rmax) : 1.0;
+            double alpha = (rmax > 0.9995) ? 0.9995 * fast_rcp(rmax) : 1.0;
+            // Centrality safeguard: no complementarity product may fall below GAMMA * mu(alpha).  Without it Mehrotra's
+            // heuristic occasionally drives single products to ~1e-4 mu; the next directions are then blocked at
+            // alpha ~ 0.07 and mu cycles around 1e-9 forever (seen at M = 10, dim 3, 40 neighbours; tools/proto_pdip.py).
+            // Costs one extra block reduction per iteration; the loop is uniform over the QP's lanes.
+            for (int bt = 0; bt < 10; bt++) {
+                const double mu_a = (sum_sl + alpha * (sdl + alpha * sdd)) * inv_m;
+                double pmin = 1e300;
+#pragma unroll
+                for (int u = 0; u < NS2; u++) {
+                    const bool on = t_ix[u] >= 0;
+                    const double pl = fma(alpha, t_ds[2 * u], t_sl[u]) * fma(alpha, t_dl[2 * u], t_ll[u]);
+                    const double ph = fma(alpha, t_ds[2 * u + 1], t_sh[u]) * fma(alpha, t_dl[2 * u + 1], t_lh[u]);
+                    pmin = fmin(pmin, on ? fmin(pl, ph) : 1e300);
+                }
+#pragma unroll
+                for (int u = 0; u < NSLOT; u++) {
+                    const double pr = fma(alpha, r_ds[u], r_s[u]) * fma(alpha, r_dl[u], r_l[u]);
+                    pmin = fmin(pmin, (r_l[u] > 0.0) ? pr : 1e300);
+                }
+                pmin = -block_max(-pmin);
+                if (pmin >= LSCQP_CENTRALITY_GAMMA * mu_a) break;
+                alpha *= 0.7;
+            }
             LSCQP_T(8);
             LSCQP_STOP(9)
             // ============ update ===========================================================================
@@ -1108,25 +1293,25 @@ __global__ __launch_bounds__(64) void lscqp_pdip_kernel(DevClass cls, int64_t n,
                 r_l[u] = fma(alpha, r_dl[u], r_l[u]);
             }
             if (zl) z_[lane] += alpha * dzc;
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             // c = c_fixed + T z, recomputed from z so the eliminated equalities hold to rounding every iteration
             expandT(z_, c_, true);
-            LSCQP_WAVE_LDS_SYNC();
+            LSCQP_BLOCK_SYNC();
             if (!(alpha > 1e-12) || !(mu == mu)) {  // stalled or NaN (wave-uniform)
-                status = (near_cnt > 0 && mu == mu) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+                status = ((near_cnt > 0 || floor_cnt > 0) && mu == mu) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 break;
             }
             LSCQP_T(9);
             LSCQP_STOP(10)
         }
     LSCQP_T(10);
-    if (status == LSCQP_STATUS_ITER_LIMIT && near_cnt > 0) status = LSCQP_STATUS_OPTIMAL;
+    if (status == LSCQP_STATUS_ITER_LIMIT && (near_cnt > 0 || floor_cnt > 0)) status = LSCQP_STATUS_OPTIMAL;
     if (status == LSCQP_STATUS_ITER_LIMIT && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
     if (status == LSCQP_STATUS_NUMERIC && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
 
     // ---- epilogue: objective, control points back in the world frame ---------------------------------------
     const double obj = objective(true, lane);
-    for (int e = lane; e < NX; e += 64) {
+    for (int e = lane; e < NX; e += T) {
         const int k = e / P;
         x_out[q * NX + e] = c_[e] + H->p0[k];
     }

@@ -453,7 +453,7 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         s[i] = si > 1.0 ? si : 1.0;
         lam[i] = 1.0;
     }
-    int stall = 0, near_opt = 0;
+    int stall = 0, near_opt = 0, floor_seen = 0;
     for (it = 0; it < max_iter; it++) {
         /* residuals */
         double mu = 0, rpn = 0, rdn = 0, pinf = 0;
@@ -487,6 +487,10 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         /* "converged to working precision": every criterion within 100x of its target.  Remembered so that a later
          * factorisation failure or a stalled step (W = lam/s spans > 1e20 by then) still reports the optimum. */
         near_opt = (rpn <= 100 * tol * hscale && rdn <= 1000 * tol * gls && mu * m + pinf <= 100 * tol * (1.0 + fabs(objv)));
+        /* The stationarity residual has a rounding floor of ~eps * cond(K) * |grad|; at M = 10 in 3-D (nz = 84, cond ~ 1e7)
+         * it can sit above 1000 tol.  A point that meets the primal and gap targets with the stationarity below 1e-6 is
+         * remembered too and accepted if the iteration later breaks down (sticky, unlike near_opt). */
+        if (rpn <= 100 * tol * hscale && rdn <= 1e-6 * gls && mu * m + pinf <= 100 * tol * (1.0 + fabs(objv))) floor_seen = 1;
         /* K = H + G' W G */
         memcpy(K, H, sizeof(double) * nz * nz);
         for (int i = 0; i < m; i++) {
@@ -502,7 +506,7 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         for (int a = 0; a < nz; a++)
             for (int b = a + 1; b < nz; b++) K[a * nz + b] = K[b * nz + a];
         if (chol_factor(nz, K) != 0) {
-            status = near_opt ? 0 : 3;
+            status = (near_opt || floor_seen) ? 0 : 3;
             break;
         }
         /* affine: rc = s*lam */
@@ -546,6 +550,18 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
             if (dl[i] < 0) amax = fmin(amax, -lam[i] / dl[i]);
         }
         alpha = fmin(1.0, 0.995 * amax);
+        /* centrality safeguard: no complementarity product below 1e-4 mu along the step (without it Mehrotra's heuristic
+         * can cycle with mu ~ 1e-9 at M = 10 in 3-D, see tools/proto_pdip.py) */
+        for (int bt = 0; bt < 10; bt++) {
+            double mua = 0, pmin = 1e300;
+            for (int i = 0; i < m; i++) {
+                const double pr = (s[i] + alpha * ds[i]) * (lam[i] + alpha * dl[i]);
+                mua += pr;
+                pmin = fmin(pmin, pr);
+            }
+            if (m == 0 || pmin >= 1e-4 * mua / m) break;
+            alpha *= 0.7;
+        }
         for (int j = 0; j < nz; j++) z[j] += alpha * dz[j];
         for (int i = 0; i < m; i++) {
             s[i] += alpha * ds[i];
@@ -553,13 +569,13 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         }
         if (alpha < 1e-10) {
             if (++stall >= 3) {
-                status = near_opt ? 0 : (rpn > 1e-6 * hscale) ? 1 : 3;
+                status = (near_opt || floor_seen) ? 0 : (rpn > 1e-6 * hscale) ? 1 : 3;
                 break;
             }
         } else
             stall = 0;
     }
-    if (status == 2 && near_opt) status = 0;
+    if (status == 2 && (near_opt || floor_seen)) status = 0;
     if (status == 2) {
         /* iteration limit: classify as infeasible when the primal residual never closed */
         double rpn = 0;

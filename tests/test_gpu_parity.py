@@ -44,7 +44,8 @@ def _check_against_oracle(O, cls, G, R, sel=None):
     (10, 5, 2, 9, "forest", 5, 2),     # forest10 with the M=5 default of src/param.cpp:71
     (48, 6, 3, 20, "maze", 3, 3),      # dense-maze set, M=6 (configs[2] shape, fewer agents)
     (24, 3, 3, 10, "forest", 4, 2),
-    (20, 7, 3, 12, "maze", 6, 2),      # largest dim-3 horizon of the lane-per-row kernel (nz = 57)
+    (20, 7, 3, 12, "maze", 6, 2),      # largest dim-3 horizon of the one-wavefront kernel (nz = 57)
+    (24, 10, 3, 40, "forest", 8, 2),   # configs[3] shape: M=10, dim 3, 40 neighbours + SFC (nz = 84: two wavefronts per QP)
 ])
 def test_swarm_parity(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed, steps):
     from lsc_dr_planner_amd import synth
@@ -65,7 +66,11 @@ def test_swarm_parity(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed, st
             lq = np.ascontiguousarray(b["lsc"][q]); sq = np.ascontiguousarray(b["sfc"][q])
             stat, eqv, iqv = H.kkt_from_primal(oracle, cls, ag[q:q + 1], lq, sq, G["x"][q])
             assert stat <= KKT_TOL and eqv <= KKT_TOL and iqv <= KKT_TOL, (step, q, stat, eqv, iqv)
-        assert G["info"]["res_primal"].max() <= 1e-9 and G["info"]["res_dual"].max() <= 1e-8
+        # the solver's own scaled stationarity residual: <= 1e-8, except that at nz = 84 (cond(Hred) ~ 1e7) single
+        # QPs stop at its rounding floor (<= 1e-6, documented in lscqp_kernel.hpp); the KKT residuals on the reference's
+        # model, checked above with the 1e-8 bar, are not affected
+        rd_bar = 1e-8 if dim * (3 * M - 2) <= 64 else 1e-6
+        assert G["info"]["res_primal"].max() <= 1e-9 and G["info"]["res_dual"].max() <= rd_bar
         sw.advance(G["x"])  # the swarm is carried forward by the GPU solution
 
 
@@ -290,17 +295,17 @@ def _compiled_instances():
     txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lsc_dr_planner_amd", "csrc",
                             "lscqp_launch.hpp")).read()
     body = txt[txt.index("#define LSCQP_INSTANCES"):]
-    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
+    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
 
 
-@pytest.mark.parametrize("M,dim,es,nslot", _compiled_instances())
-def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_cuda, M, dim, es, nslot):
+@pytest.mark.parametrize("M,dim,es,nslot,waves", _compiled_instances())
+def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_cuda, M, dim, es, nslot, waves):
     """Every kernel instance, at its full obstacle capacity: bitwise repeatable and equal to the oracle.
     (Guards against the exec-masked register-spill hazard described in lscqp_kernel.hpp: a miscompiled instance shows
     up as run-to-run differences long before it shows up as a wrong answer.)"""
     from lsc_dr_planner_amd import synth
 
-    G = max(1, 64 // (6 * M - 3))
+    G = max(1, 64 * waves // (6 * M - 3))
     n_obs = nslot * G
     N = max(24, n_obs + 2)
     sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=17 + M)

@@ -48,7 +48,7 @@ cls = DevClass(); cls.dt = 0.2; cls.w_c = 0.01; cls.w_t = 1.0; cls.comm_range = 
 for k in range(3): cls.world_min[k] = sw.world_min[k]; cls.world_max[k] = sw.world_max[k]
 cls.q2s = 2 * 0.01 * 0.2 ** -5
 cls.tol = 1e-10; cls.max_iter = 60; cls.use_sfc = 1; cls.n_obs_max = sw.n_obs
-fn = getattr(L, "lscqp_launch_%d_%d_1_%d" % (M, D, NSLOT))
+fn = getattr(L, "lscqp_launch_%d_%d_1_%d_1" % (M, D, NSLOT))
 fn.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
 def launch():
     rc = fn(C.byref(cls), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), dx.data_ptr(), dob.data_ptr(), dst.data_ptr(), dinfo.data_ptr(), None)
