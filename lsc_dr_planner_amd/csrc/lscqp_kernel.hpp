@@ -72,42 +72,68 @@ __device__ __forceinline__ double bcast(double v, int lane) {
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
-// interleaved butterflies so the ds_bpermute latencies of independent quantities overlap
-__device__ __forceinline__ void wave_sum2_max1(double& a, double& b, double& c) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64), tc = __shfl_xor(c, o, 64);
-        a += ta;
-        b += tb;
-        c = fmax(c, tc);
-    }
+// Wave reductions with DPP moves instead of ds_bpermute butterflies (tools/ubench.hip: a 6-step bpermute butterfly
+// costs ~460 cycles per value on a lone wavefront, the DPP form ~150): four row_shr steps build an inclusive scan
+// inside each row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across, lane 63 ends up with the
+// result and two v_readlane make it uniform.  Lanes without a source keep the identity in `old`.
+struct OpSum {
+    static __device__ __forceinline__ double id() { return 0.0; }
+    static __device__ __forceinline__ double ap(double a, double b) { return a + b; }
+};
+struct OpMax {  // all reduced maxima are over non-negative quantities or use -1e300 as "nothing"
+    static __device__ __forceinline__ double id() { return -1e300; }
+    static __device__ __forceinline__ double ap(double a, double b) { return fmax(a, b); }
+};
+template <class Op, int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_step(double v) {
+    const double idn = Op::id();
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(idn), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(idn), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return Op::ap(v, __hiloint2double(hi, lo));
 }
+__device__ __forceinline__ double bcast63(double v) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// three independent reductions advanced together so their DPP latencies overlap
+template <class OpA, class OpB, class OpC>
+__device__ __forceinline__ void wave_reduce3(double& a, double& b, double& c) {
+#define LSCQP_DPP3(CTRL, MASK)        \
+    a = dpp_step<OpA, CTRL, MASK>(a); \
+    b = dpp_step<OpB, CTRL, MASK>(b); \
+    c = dpp_step<OpC, CTRL, MASK>(c)
+    LSCQP_DPP3(0x111, 0xf);  // row_shr:1
+    LSCQP_DPP3(0x112, 0xf);  // row_shr:2
+    LSCQP_DPP3(0x114, 0xf);  // row_shr:4
+    LSCQP_DPP3(0x118, 0xf);  // row_shr:8
+    LSCQP_DPP3(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    LSCQP_DPP3(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef LSCQP_DPP3
+    a = bcast63(a);
+    b = bcast63(b);
+    c = bcast63(c);
+}
+template <class Op>
+__device__ __forceinline__ double wave_reduce1(double v) {
+    v = dpp_step<Op, 0x111, 0xf>(v);
+    v = dpp_step<Op, 0x112, 0xf>(v);
+    v = dpp_step<Op, 0x114, 0xf>(v);
+    v = dpp_step<Op, 0x118, 0xf>(v);
+    v = dpp_step<Op, 0x142, 0xa>(v);
+    v = dpp_step<Op, 0x143, 0xc>(v);
+    return bcast63(v);
+}
+__device__ __forceinline__ void wave_sum2_max1(double& a, double& b, double& c) { wave_reduce3<OpSum, OpSum, OpMax>(a, b, c); }
 __device__ __forceinline__ void wave_max2(double& a, double& b) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64);
-        a = fmax(a, ta);
-        b = fmax(b, tb);
-    }
+    double c = 0;
+    wave_reduce3<OpMax, OpMax, OpMax>(a, b, c);
 }
 __device__ __forceinline__ void wave_max1_sum1(double& a, double& b) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ta = __shfl_xor(a, o, 64), tb = __shfl_xor(b, o, 64);
-        a = fmax(a, ta);
-        b += tb;
-    }
+    double c = 0;
+    wave_reduce3<OpMax, OpSum, OpSum>(a, b, c);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce1<OpSum>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce1<OpMax>(v); }
 // 1/d to full fp64 precision: v_rcp_f64 + two Newton steps (5 instructions instead of an IEEE division sequence)
 __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
