@@ -134,6 +134,24 @@ __device__ __forceinline__ void wave_max1_sum1(double& a, double& b) {
 }
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce1<OpSum>(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce1<OpMax>(v); }
+// A double pinned to two accumulation registers (AGPRs).  The row state (slack, multiplier of every row slot) lives
+// across the whole iteration loop; left to the register allocator it is assigned to AGPRs anyway (the 256 VGPRs are
+// needed by the matrix row and the pass temporaries) but shuttled in and out ~3x per use.  With the residence made
+// explicit every access is exactly one v_accvgpr_read/write per dword, and the allocator never considers these values
+// for VGPRs.
+struct AD {
+    int lo, hi;
+    __device__ __forceinline__ double get() const {
+        int l, h;
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+        asm("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+        return __hiloint2double(h, l);
+    }
+    __device__ __forceinline__ void set(double v) {
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
+        asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
+    }
+};
 // 1/d to full fp64 precision: v_rcp_f64 + two Newton steps (5 instructions instead of an IEEE division sequence)
 __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -463,8 +481,18 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     constexpr int NS2 = C::NS2;
     int t_ix[NS2];                                      // x-space index of the row's first control point (-1: no row)
     int t_i2[NS2];                                      // second index (comm pairs only)
-    double t_lo[NS2], t_hi[NS2];                        // bounds
-    double t_sl[NS2], t_sh[NS2], t_ll[NS2], t_lh[NS2];  // slack / multiplier of the lo and hi side
+#ifdef LSCQP_STATE_IN_VGPR
+    struct VD {  // same interface as AD, plain register (measured alternative)
+        double v;
+        __device__ __forceinline__ double get() const { return v; }
+        __device__ __forceinline__ void set(double x) { v = x; }
+    };
+    using SD = VD;
+#else
+    using SD = AD;
+#endif
+    SD t_lo[NS2], t_hi[NS2];                        // bounds
+    SD t_sl[NS2], t_sh[NS2], t_ll[NS2], t_lh[NS2];  // slack / multiplier of the lo and hi side
     // Only (s, lambda) persist across the factorisation; residuals and directions of a row are recomputed in every
     // pass from the x-space vectors (a handful of FMAs) instead of being kept live next to the matrix row A[].
     {
@@ -475,8 +503,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         for (int u = 0; u < NS2; u++) {
             t_ix[u] = -1;
             t_i2[u] = 0;
-            t_lo[u] = -1.0;
-            t_hi[u] = 1.0;
+            double lo_u = -1.0, hi_u = 1.0;
             if (u < C::SI) {  // interval on one control point
                 const int e = lane + T * u;
                 if (e < NX) {
@@ -495,8 +522,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                             lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
                             hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
                         }
-                        t_lo[u] = lo;
-                        t_hi[u] = hi;
+                        lo_u = lo;
+                        hi_u = hi;
                     }
                 }
             } else if (u < C::SI + C::SV) {  // velocity (m,i): c[i+1]-c[i], |.| <= vmax dt/n   (:448-453)
@@ -505,8 +532,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     const int k = v / (5 * M), r = v % (5 * M), m = r / 5, i = r % 5;
                     if (!(m == 0 && i < 2)) {
                         t_ix[u] = k * P + 6 * m + i;
-                        t_hi[u] = H->vmax[k] * dt * 0.2;
-                        t_lo[u] = -t_hi[u];
+                        hi_u = H->vmax[k] * dt * 0.2;
+                        lo_u = -hi_u;
                     }
                 }
             } else if (u < C::SI + C::SV + C::SA) {  // acceleration (m,i): c[i+2]-2c[i+1]+c[i]   (:462-471)
@@ -515,8 +542,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     const int k = a / (4 * M), r = a % (4 * M), m = r / 4, i = r % 4;
                     if (!(m == 0 && i < 1)) {
                         t_ix[u] = k * P + 6 * m + i;
-                        t_hi[u] = H->amax[k] * dt * dt * 0.05;
-                        t_lo[u] = -t_hi[u];
+                        hi_u = H->amax[k] * dt * dt * 0.05;
+                        lo_u = -hi_u;
                     }
                 }
             } else {  // pair (uu, up<uu): c[uu][5] - c[up+1][0]   (:482-487 with mi = up+1 >= 1)
@@ -528,10 +555,12 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     const int up = ci - uu * (uu - 1) / 2;
                     t_ix[u] = k * P + 6 * (up + 1);
                     t_i2[u] = k * P + 6 * uu + 5;
-                    t_hi[u] = rho_pair;
-                    t_lo[u] = -rho_pair;
+                    hi_u = rho_pair;
+                    lo_u = -rho_pair;
                 }
             }
+            t_lo[u].set(lo_u);
+            t_hi[u].set(hi_u);
         }
     }
     // value of the row's stencil on an x-space vector (slot type is compile-time)
@@ -591,38 +620,43 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     constexpr double LAM0 = 0.03;
     int status = LSCQP_STATUS_ITER_LIMIT;
     double m_tot = 0;
-    double r_s[NSLOT], r_l[NSLOT];    // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
+    SD r_s[NSLOT], r_l[NSLOT];  // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
     {
         double cnt = 0;
         bool bad = false;
 #pragma unroll
         for (int u = 0; u < NS2; u++) {
-            t_sl[u] = t_sh[u] = 1.0;
-            t_ll[u] = t_lh[u] = 0.0;
+            double sl0 = 1.0, sh0 = 1.0, l0_ = 0.0;
             if (t_ix[u] >= 0) {
                 const double y = row_val(c_, u);
-                if (t_lo[u] > t_hi[u]) bad = true;
-                t_sl[u] = fmax(y - t_lo[u], 1e-2);
-                t_sh[u] = fmax(t_hi[u] - y, 1e-2);
-                t_ll[u] = t_lh[u] = LAM0;
+                const double lo = t_lo[u].get(), hi = t_hi[u].get();
+                if (lo > hi) bad = true;
+                sl0 = fmax(y - lo, 1e-2);
+                sh0 = fmax(hi - y, 1e-2);
+                l0_ = LAM0;
                 cnt += 2.0;
             }
+            t_sl[u].set(sl0);
+            t_sh[u].set(sh0);
+            t_ll[u].set(l0_);
+            t_lh[u].set(l0_);
         }
         const double cx = ll ? c_[lx] : 0.0, cy = ll ? c_[P + lx] : 0.0, cz = (ll && DIM == 3) ? c_[2 * P + lx] : 0.0;
 #pragma unroll
         for (int u = 0; u < NSLOT; u++) {
-            r_s[u] = 1.0;
-            r_l[u] = 0.0;
+            double s_init = 1.0, l_init = 0.0;
             const int o = lg + G * u;
             if (ll && o < n_obs) {
                 const int e = o * CP + lcp;
                 const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e];
                 if ((nx != 0.0) || (ny != 0.0) || (nz != 0.0)) {
-                    r_s[u] = fmax(nx * cx + ny * cy + nz * cz - Rb[e], 1e-2);
-                    r_l[u] = LAM0;
+                    s_init = fmax(nx * cx + ny * cy + nz * cz - Rb[e], 1e-2);
+                    l_init = LAM0;
                     cnt += 1.0;
                 }
             }
+            r_s[u].set(s_init);
+            r_l[u].set(l_init);
         }
         m_tot = block_sum(cnt);
         if (block_max(bad ? 1.0 : 0.0) > 0.0) status = LSCQP_STATUS_INFEASIBLE;  // empty interval: lo > hi
@@ -717,18 +751,20 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #pragma unroll
             for (int u = 0; u < NS2; u++) {
                 const bool on = t_ix[u] >= 0;  // rows that do not exist carry s = 1, lambda = 0, lo = -1, hi = 1
+                const double tsl = t_sl[u].get(), tsh = t_sh[u].get(), tll = t_ll[u].get(), tlh = t_lh[u].get();
+                const double tlo = t_lo[u].get(), thi = t_hi[u].get();
                 const double y = row_val(c_, u);
-                const double rpl = on ? (y - t_lo[u]) - t_sl[u] : 0.0, rph = on ? (t_hi[u] - y) - t_sh[u] : 0.0;
-                const double isl = fast_rcp(t_sl[u]), ish = fast_rcp(t_sh[u]);
-                const double wl = t_ll[u] * isl, wh = t_lh[u] * ish;
-                sum_sl += t_sl[u] * t_ll[u] + t_sh[u] * t_lh[u];
-                sum_pinf += t_ll[u] * fabs(rpl) + t_lh[u] * fabs(rph);
+                const double rpl = on ? (y - tlo) - tsl : 0.0, rph = on ? (thi - y) - tsh : 0.0;
+                const double isl = fast_rcp(tsl), ish = fast_rcp(tsh);
+                const double wl = tll * isl, wh = tlh * ish;
+                sum_sl += tsl * tll + tsh * tlh;
+                sum_pinf += tll * fabs(rpl) + tlh * fabs(rph);
                 max_rp = fmax(max_rp, fmax(fabs(rpl), fabs(rph)));
                 if constexpr (W == 1) {
-                    row_scatter(XL, u, t_ll[u] - t_lh[u], on);
+                    row_scatter(XL, u, tll - tlh, on);
                     row_scatter(XA, u, wh * rph - wl * rpl, on);
                 } else {
-                    sc1[u] = t_ll[u] - t_lh[u];
+                    sc1[u] = tll - tlh;
                     sc2[u] = wh * rph - wl * rpl;
                 }
                 if (om_index(u) < om_limit(u)) om_[om_index(u)] = wl + wh;
@@ -743,7 +779,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     // slots without a row read the dead row kept at index NROW (n = 0, b = -1; their s = 1, l = 0),
                     // which contributes exact zeros everywhere
                     const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
-                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u], lam = r_l[u];
+                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u].get(), lam = r_l[u].get();
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
                     const double is = fast_rcp(s);
                     const double w = lam * is;
@@ -1082,13 +1118,29 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     return slots[j];
                 }
             };
+#ifdef LSCQP_SOLVE_FROM_LDS
+            // the factor is parked in the lane's scratch-matrix row right after the factorisation and both solves read
+            // it from there (lane-private row, conflict-free ds_read_b64, independent of the solve's dependency chain)
+            {
+                LSCQP_PHASE_LANE(lvp_);
+                double* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
+#pragma unroll
+                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
+                LSCQP_WAVE_LDS_SYNC();
+            }
+#define LSCQP_FACTOR_ENTRY(j) hr[j]
+#else
+#define LSCQP_FACTOR_ENTRY(j) A[j]
+#endif
             auto solve = [&](double b) -> double {
                 int ls = lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
+                const double* const hr = &Hs[(ls < NZ ? ls : NZ) * LDH];
+                (void)hr;
 #pragma unroll
                 for (int j = 0; j < NZ; j++) {  // L w = b (unit lower)
                     const double wj = bcast_q(b, j, ls, col_);
-                    b = fma(-((ls > j) ? A[j] : 0.0), wj, b);
+                    b = fma(-((ls > j) ? LSCQP_FACTOR_ENTRY(j) : 0.0), wj, b);
                 }
                 asm volatile("" : "+v"(ls));
                 double x = 0;
@@ -1096,7 +1148,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 for (int j = NZ - 1; j >= 0; j--) {  // (D L') x = w : row i of the upper factor is A[j>i] of lane i
                     const double xj = bcast_q(b * dinv_own, j, ls, col_ + T);
                     x = (ls == j) ? xj : x;
-                    b = fma(-((ls < j) ? A[j] : 0.0), xj, b);
+                    b = fma(-((ls < j) ? LSCQP_FACTOR_ENTRY(j) : 0.0), xj, b);
                 }
                 return x;
             };
@@ -1106,6 +1158,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // ============ predictor ========================================================================
             const double dza = solve(-gcost + ga);
             if (zl) dz_[lane] = dza;
+#ifndef LSCQP_SOLVE_FROM_LDS
             // park the factor in the lane's scratch-matrix row while pass 2 runs: A[] is then dead across the pass,
             // which removes most register spills of the pass
             {
@@ -1114,6 +1167,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
             }
+#endif
             LSCQP_BLOCK_SYNC();
             expandT(dz_, dca_, false);
             LSCQP_BLOCK_SYNC();
@@ -1125,16 +1179,18 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #pragma unroll
             for (int u = 0; u < NS2; u++) {
                 const bool on = t_ix[u] >= 0;
+                const double tsl = t_sl[u].get(), tsh = t_sh[u].get(), tll = t_ll[u].get(), tlh = t_lh[u].get();
+                const double tlo = t_lo[u].get(), thi = t_hi[u].get();
                 const double y = row_val(c_, u), dy = row_val(dca_, u);
-                const double rpl = (y - t_lo[u]) - t_sl[u], rph = (t_hi[u] - y) - t_sh[u];
-                const double isl = fast_rcp(t_sl[u]), ish = fast_rcp(t_sh[u]);
+                const double rpl = (y - tlo) - tsl, rph = (thi - y) - tsh;
+                const double isl = fast_rcp(tsl), ish = fast_rcp(tsh);
                 const double tl = (dy + rpl) * isl, th = (rph - dy) * ish;
                 const double rr = fmax(fmax(-tl, 1.0 + tl), fmax(-th, 1.0 + th));
                 rmax = fmax(rmax, on ? rr : 1.0);
-                const double pl = -(dy + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dy) * t_lh[u] * (1.0 + th);
+                const double pl = -(dy + rpl) * tll * (1.0 + tl), ph = -(rph - dy) * tlh * (1.0 + th);
                 sB += on ? (pl + ph) : 0.0;
                 const double v1 = isl - ish;
-                const double v2 = (-pl - t_ll[u] * rpl) * isl - (-ph - t_lh[u] * rph) * ish;
+                const double v2 = (-pl - tll * rpl) * isl - (-ph - tlh * rph) * ish;
                 if constexpr (W == 1) {
                     row_scatter(XB1, u, v1, on);
                     row_scatter(XB2, u, v2, on);
@@ -1152,7 +1208,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 for (int u = 0; u < NSLOT; u++) {
                     const int o = lg + G * u;
                     const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
-                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u], l = r_l[u];
+                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u].get(), l = r_l[u].get();
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
                     const double is = fast_rcp(s);
                     const double ds = (nx * dx + ny * dy + nz * dzz) + rp;
@@ -1208,11 +1264,13 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 gb = e0 * (smu * x1[3] + x2[3]) + e1 * (smu * x1[4] + x2[4]) + e2 * (smu * x1[5] + x2[5]) +
                      tb0 * (smu * y1[0] + y2[0]) + tb1 * (smu * y1[1] + y2[1]) + tb2 * (smu * y1[2] + y2[2]);
                 gb = zl ? gb : 0.0;
+#ifndef LSCQP_SOLVE_FROM_LDS
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) {
                     const double v = hrow[cidx];
                     A[cidx] = zl ? v : 0.0;
                 }
+#endif
             }
             const double dzc = solve(-gcost + gb);
             {  // the scratch row must be all-zero outside the assembly pattern again
@@ -1235,21 +1293,23 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #pragma unroll
             for (int u = 0; u < NS2; u++) {
                 const bool on = t_ix[u] >= 0;
+                const double tsl = t_sl[u].get(), tsh = t_sh[u].get(), tll = t_ll[u].get(), tlh = t_lh[u].get();
+                const double tlo = t_lo[u].get(), thi = t_hi[u].get();
                 const double y = row_val(c_, u), dya = row_val(dca_, u), dyc = row_val(dc_, u);
-                const double rpl = (y - t_lo[u]) - t_sl[u], rph = (t_hi[u] - y) - t_sh[u];
-                const double isl = fast_rcp(t_sl[u]), ish = fast_rcp(t_sh[u]);
+                const double rpl = (y - tlo) - tsl, rph = (thi - y) - tsh;
+                const double isl = fast_rcp(tsl), ish = fast_rcp(tsh);
                 const double tl = (dya + rpl) * isl, th = (rph - dya) * ish;
-                const double pl = -(dya + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dya) * t_lh[u] * (1.0 + th);
+                const double pl = -(dya + rpl) * tll * (1.0 + tl), ph = -(rph - dya) * tlh * (1.0 + th);
                 const double dsl = dyc + rpl, dsh = rph - dyc;
-                const double dll = (smu - pl) * isl - t_ll[u] - t_ll[u] * isl * dsl;
-                const double dlh = (smu - ph) * ish - t_lh[u] - t_lh[u] * ish * dsh;
+                const double dll = (smu - pl) * isl - tll - tll * isl * dsl;
+                const double dlh = (smu - ph) * ish - tlh - tlh * ish * dsh;
                 // rows that do not exist have lambda == 0: give them a harmless divisor
-                const double ill = fast_rcp(on ? t_ll[u] : 1.0), ilh = fast_rcp(on ? t_lh[u] : 1.0);
+                const double ill = fast_rcp(on ? tll : 1.0), ilh = fast_rcp(on ? tlh : 1.0);
                 const double rr = fmax(fmax(-dsl * isl, -dsh * ish), fmax(-dll * ill, -dlh * ilh));
                 rmax = fmax(rmax, on ? rr : 0.0);
                 t_ds[2 * u] = on ? dsl : 0.0; t_ds[2 * u + 1] = on ? dsh : 0.0;
                 t_dl[2 * u] = on ? dll : 0.0; t_dl[2 * u + 1] = on ? dlh : 0.0;
-                sdl += t_sl[u] * t_dl[2 * u] + t_ll[u] * t_ds[2 * u] + t_sh[u] * t_dl[2 * u + 1] + t_lh[u] * t_ds[2 * u + 1];
+                sdl += tsl * t_dl[2 * u] + tll * t_ds[2 * u] + tsh * t_dl[2 * u + 1] + tlh * t_ds[2 * u + 1];
                 sdd += t_ds[2 * u] * t_dl[2 * u] + t_ds[2 * u + 1] * t_dl[2 * u + 1];
             }
             {
@@ -1261,7 +1321,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 for (int u = 0; u < NSLOT; u++) {
                     const int o = lg + G * u;
                     const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
-                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u], l = r_l[u];
+                    const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u].get(), l = r_l[u].get();
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
                     const double is = fast_rcp(s);
                     const double dsa = (nx * ax + ny * ay + nz * az) + rp;
@@ -1290,14 +1350,15 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #pragma unroll
                 for (int u = 0; u < NS2; u++) {
                     const bool on = t_ix[u] >= 0;
-                    const double pl = fma(alpha, t_ds[2 * u], t_sl[u]) * fma(alpha, t_dl[2 * u], t_ll[u]);
-                    const double ph = fma(alpha, t_ds[2 * u + 1], t_sh[u]) * fma(alpha, t_dl[2 * u + 1], t_lh[u]);
+                    const double pl = fma(alpha, t_ds[2 * u], t_sl[u].get()) * fma(alpha, t_dl[2 * u], t_ll[u].get());
+                    const double ph = fma(alpha, t_ds[2 * u + 1], t_sh[u].get()) * fma(alpha, t_dl[2 * u + 1], t_lh[u].get());
                     pmin = fmin(pmin, on ? fmin(pl, ph) : 1e300);
                 }
 #pragma unroll
                 for (int u = 0; u < NSLOT; u++) {
-                    const double pr = fma(alpha, r_ds[u], r_s[u]) * fma(alpha, r_dl[u], r_l[u]);
-                    pmin = fmin(pmin, (r_l[u] > 0.0) ? pr : 1e300);
+                    const double lu = r_l[u].get();
+                    const double pr = fma(alpha, r_ds[u], r_s[u].get()) * fma(alpha, r_dl[u], lu);
+                    pmin = fmin(pmin, (lu > 0.0) ? pr : 1e300);
                 }
                 pmin = -block_max(-pmin);
                 if (pmin >= LSCQP_CENTRALITY_GAMMA * mu_a) break;
@@ -1308,15 +1369,15 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // ============ update ===========================================================================
 #pragma unroll
             for (int u = 0; u < NS2; u++) {
-                t_sl[u] = fma(alpha, t_ds[2 * u], t_sl[u]);
-                t_sh[u] = fma(alpha, t_ds[2 * u + 1], t_sh[u]);
-                t_ll[u] = fma(alpha, t_dl[2 * u], t_ll[u]);
-                t_lh[u] = fma(alpha, t_dl[2 * u + 1], t_lh[u]);
+                t_sl[u].set(fma(alpha, t_ds[2 * u], t_sl[u].get()));
+                t_sh[u].set(fma(alpha, t_ds[2 * u + 1], t_sh[u].get()));
+                t_ll[u].set(fma(alpha, t_dl[2 * u], t_ll[u].get()));
+                t_lh[u].set(fma(alpha, t_dl[2 * u + 1], t_lh[u].get()));
             }
 #pragma unroll
             for (int u = 0; u < NSLOT; u++) {
-                r_s[u] = fma(alpha, r_ds[u], r_s[u]);
-                r_l[u] = fma(alpha, r_dl[u], r_l[u]);
+                r_s[u].set(fma(alpha, r_ds[u], r_s[u].get()));
+                r_l[u].set(fma(alpha, r_dl[u], r_l[u].get()));
             }
             if (zl) z_[lane] += alpha * dzc;
             LSCQP_BLOCK_SYNC();
