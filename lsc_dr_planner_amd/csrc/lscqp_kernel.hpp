@@ -173,6 +173,9 @@ __device__ __forceinline__ double fast_rcp(double d) {
 #define LSCQP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Development aid: -DLSCQP_DEBUG_STOP=k leaves the iteration loop at stage k (bisecting device faults).
+#ifndef LSCQP_FACT_HYBRID
+#define LSCQP_FACT_HYBRID 5  // percent of a pivot row (beyond the first 4 entries) broadcast with v_readlane
+#endif
 #ifndef LSCQP_CENTRALITY_GAMMA
 #define LSCQP_CENTRALITY_GAMMA 1e-4
 #endif
@@ -1006,8 +1009,63 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
             if constexpr (W == 1) {
-#ifndef LSCQP_FACT_LDS_COLUMN
-            // pivot row of lane j broadcast with v_readlane (2 per fp64 value), issued in batches of BB into distinct
+#ifndef LSCQP_FACT_READLANE
+            // Pivot-row broadcast over BOTH pipes.  A v_readlane costs ~8 cycles of VALU issue (16 per fp64 value, next
+            // to 4.6 for the FMA it feeds); a uniform-address ds_read_b64 costs ~11 cycles of the LDS pipe and none of
+            // the VALU's (tools/ubench.hip).  By symmetry of the trailing matrix the pivot row of step j equals the
+            // pivot COLUMN, of which every lane holds one entry (its A[j]); each step publishes column j+1 to LDS as
+            // soon as it is final, the first ~1/4 of the next row is broadcast with v_readlane (no LDS dependency, hides
+            // the LDS latency) and the rest is read back from LDS while the VALU works.  The pivot reciprocal of step
+            // j+1 is started inside step j as well.
+            {
+                int lf = lane;
+                asm volatile("" : "+v"(lf));
+                col_[lane] = A[0];
+                double d = bcast(A[0], 0);
+                double invd = fast_rcp(d);
+                static_for<0, NZ>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    constexpr int n = NZ - j - 1;  // trailing entries k = j+1 .. NZ-1
+                    constexpr int r0 = (n * LSCQP_FACT_HYBRID + 50) / 100;
+                    constexpr int nr = n <= 4 ? n : (r0 < 3 ? 4 : r0 + 1);  // via v_readlane (k = j+1 always)
+                    constexpr int nl = n - (nr < n ? nr : n);              // via LDS
+                    constexpr int NR = n - nl;
+                    const double* const cb = col_ + (j & 1) * 64;
+                    double* const cbn = col_ + ((j + 1) & 1) * 64;
+                    pivot_bad = pivot_bad || !(d > 1e-300);
+                    dinv_own = (lf == j) ? invd : dinv_own;
+                    const double li = (lf > j) ? A[j] * invd : 0.0;
+                    double ul[nl > 0 ? nl : 1];
+                    static_for<0, nl>([&](auto Tc) {
+                        constexpr int t = decltype(Tc)::value;
+                        ul[t] = cb[j + 1 + NR + t];
+                    });
+                    if constexpr (NR > 0) {
+                        double ur[NR];
+                        static_for<0, NR>([&](auto Tc) {
+                            constexpr int t = decltype(Tc)::value;
+                            ur[t] = bcast(A[j + 1 + t], j);
+                        });
+                        A[j + 1] = fma(-li, ur[0], A[j + 1]);
+                        cbn[lane] = A[j + 1];
+                        d = bcast(A[j + 1], j + 1);
+                        invd = fast_rcp(d);
+                        static_for<1, NR>([&](auto Tc) {
+                            constexpr int t = decltype(Tc)::value;
+                            A[j + 1 + t] = fma(-li, ur[t], A[j + 1 + t]);
+                        });
+                    }
+                    static_for<0, nl>([&](auto Tc) {
+                        constexpr int t = decltype(Tc)::value;
+                        A[j + 1 + NR + t] = fma(-li, ul[t], A[j + 1 + NR + t]);
+                    });
+                    A[j] = (lf > j) ? li : A[j];
+                    asm volatile("" ::: "memory");  // LDS program order between the steps (no wait: the LDS runs in order)
+                });
+            }
+#else
+            // Measured alternative (-DLSCQP_FACT_READLANE, 0.153 vs 0.148 ms per 64-QP batch): the whole pivot row of
+            // lane j broadcast with v_readlane (2 per fp64 value), issued in batches of BB into distinct
             // scalar registers so the v_readlane -> v_fma hazard slots are filled by other broadcasts, not s_nops
             // The lane-vs-column comparisons below are loop invariant; compared against `lane` itself hipcc hoists all
             // 3*nz of them out of the iteration loop, which needs 2 SGPRs each, spills those into VGPR lanes
@@ -1042,43 +1100,6 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 });
                 A[j] = (lf > j) ? li : A[j];
             });
-#else
-            // Measured alternative (-DLSCQP_FACT_LDS_COLUMN): LDS-column form with look-ahead.  By symmetry of the
-            // trailing matrix the pivot row of step j equals the pivot COLUMN, of which every lane holds one entry (its
-            // A[j]): one ds_write_b64 per lane publishes it and uniform-address ds_reads broadcast it back: 1 LDS read
-            // + 1 FMA per entry instead of 2 v_readlane + 1 FMA (+ the SGPR hazard nops) -- 2.1 k instead of 3.8 k
-            // instructions, 14.4 k instead of 20.5 k cycles for the factorisation alone.  Column j+1 is completed,
-            // published and its pivot inverted FIRST inside step j, so the LDS round trip and the reciprocal chain
-            // overlap the remaining FMAs of step j.  End to end it is SLOWER on MI355X (0.233 vs 0.201 ms per 64-QP
-            // batch): the extra VGPRs of the broadcast values push the neighbouring passes into more scratch spills.
-            {
-                int lf = lane;
-                asm volatile("" : "+v"(lf));
-                col_[lane] = A[0];
-                double d = bcast(A[0], 0);
-                double invd = fast_rcp(d);
-                LSCQP_WAVE_LDS_SYNC();
-                static_for<0, NZ>([&](auto Jc) {
-                    constexpr int j = decltype(Jc)::value;
-                    const double* const cb = col_ + (j & 1) * 64;
-                    double* const cbn = col_ + ((j + 1) & 1) * 64;
-                    pivot_bad = pivot_bad || !(d > 1e-300);
-                    dinv_own = (lf == j) ? invd : dinv_own;
-                    const double li = (lf > j) ? A[j] * invd : 0.0;
-                    if constexpr (j + 1 < NZ) {
-                        A[j + 1] = fma(-li, cb[j + 1], A[j + 1]);
-                        cbn[lane] = A[j + 1];
-                        d = bcast(A[j + 1], j + 1);
-                        invd = fast_rcp(d);
-                    }
-                    static_for<j + 2, NZ>([&](auto Kc) {
-                        constexpr int k = decltype(Kc)::value;
-                        A[k] = fma(-li, cb[k], A[k]);
-                    });
-                    A[j] = (lf > j) ? li : A[j];
-                    LSCQP_WAVE_LDS_SYNC();
-                });
-            }
 #endif
             } else {
                 // W = 2: the rows live in the registers of two wavefronts.  By symmetry of the trailing matrix the pivot
