@@ -162,14 +162,18 @@ def main():
     bytes_per_qp = sol.algorithmic_bytes(n_obs_eff)
     achieved = bytes_per_qp * N / (kernel_ms * 1e-3)
     # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the value comes from the
-    # committed rocprofv3 --pmc passes of THIS command (profiles/r01_pmc_traffic.json) and is only reported when the
+    # committed rocprofv3 --pmc passes of THIS command (profiles/*_pmc_traffic.json, tools/profile_round.py) and is only reported when the
     # kernel instance and batch size match; otherwise null.
     traffic, traffic_src = None, None
     try:
-        pm = json.load(open(os.path.join(HERE, "profiles", "r01_pmc_traffic.json")))
-        if pm.get("qps_per_launch") == N and pm.get("kernel", "").startswith("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) \
-                and n_obs_eff == 20:
-            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+        import glob
+
+        pf = sorted(glob.glob(os.path.join(HERE, "profiles", "*_pmc_traffic.json")))[-1]  # newest tag of the round
+        pm = json.load(open(pf))
+        kname = (pm.get("kernel") or "").replace(" ", "")
+        if pm.get("qps_per_launch") == N and ("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) in kname and n_obs_eff == 20:
+            traffic = pm["traffic_bytes_per_launch"]
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" % os.path.basename(pf)
     except Exception:
         pass
     out = {
@@ -195,7 +199,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT>" % (M, dim), "kernel_ms": kernel_ms,
+            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W>" % (M, dim), "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N,
         },
         "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),

@@ -84,7 +84,7 @@ typedef struct lscqp_class_desc {
     /* solver controls (0 selects the default) */
     int32_t max_iter; /* default 60 */
     int32_t reserved1;
-    double tol;       /* scaled KKT tolerance, default 1e-9 */
+    double tol;       /* relative duality-gap tolerance, 0 = default 1e-10 */
 } lscqp_class_desc;
 
 /* Per-QP header: the fields of Agent (include/sp_const.hpp:146-160) that populatebyrow reads.
