@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,22 +28,48 @@ int fail(int code, const std::string& msg) {
 }
 
 struct Inst {
-    int M, dim, es, max_obs;
+    int M, dim, es, max_obs, waves;
     lscqp::launch_fn fn;
 };
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
-#define LSCQP_ROW(M, D, E, S, W) {M, D, E, max_obs_of(M, S, W), lscqp_launch_##M##_##D##_##E##_##S##_##W},
+#define LSCQP_ROW(M, D, E, S, W) {M, D, E, max_obs_of(M, S, W), W, lscqp_launch_##M##_##D##_##E##_##S##_##W},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
 
-// smallest instance of the shape that accommodates n_obs obstacles per agent; nullptr if none
-const Inst* find_instance(int M, int dim, int es, int n_obs) {
+// Instance of the shape that accommodates n_obs obstacles per agent; nullptr if none.
+// Launch policy: a batch small enough to leave SIMDs idle (n <= 2 x CUs: at most two QPs per CU) takes a
+// two-wavefront instance when the shape has one -- the row passes of a QP then run on two SIMDs; larger batches
+// take one wavefront per QP, which is what fills the chip (4 QPs per CU).  Within a wave count: smallest capacity.
+const Inst* find_instance(int M, int dim, int es, int n_obs, int64_t n, int n_cu) {
     const Inst* best = nullptr;
-    for (const Inst& i : kInst)
-        if (i.M == M && i.dim == dim && i.es == es && i.max_obs >= n_obs && (!best || i.max_obs < best->max_obs)) best = &i;
+    const bool small = n <= 2 * (int64_t)n_cu;
+    // testing knob: LSCQP_WAVES=1|2 pins the wavefront count (every compiled instance has to be reachable by the tests)
+    const char* pin = getenv("LSCQP_WAVES");
+    const int pin_w = (pin && (pin[0] == '1' || pin[0] == '2') && pin[1] == 0) ? pin[0] - '0' : 0;
+    for (const Inst& i : kInst) {
+        if (!(i.M == M && i.dim == dim && i.es == es && i.max_obs >= n_obs)) continue;
+        if (pin_w && i.waves != pin_w) continue;
+        bool better = !best;
+        if (best) {
+            if (i.waves != best->waves)
+                better = small ? (i.waves > best->waves) : (i.waves < best->waves);
+            else
+                better = i.max_obs < best->max_obs;
+        }
+        if (better) best = &i;
+    }
     return best;
+}
+int cu_count() {
+    static int n_cu = -1;
+    if (n_cu < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
+    return n_cu;
 }
 bool shape_exists(int M, int dim, int es) {
     for (const Inst& i : kInst)
@@ -182,7 +209,7 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
             return fail(LSCQP_ERR_NO_DEVICE, std::string("no HIP device: lscqp has no CPU fallback (hipGetDeviceCount: ") +
                                                  hipGetErrorString(de) + ", " + std::to_string(ndev) + " devices)");
     }
-    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, n_obs_max);
+    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, n_obs_max, n, cu_count());
     if (!inst) {
         char buf[200];
         snprintf(buf, sizeof buf, "no compiled kernel instance of M=%d dim=%d holds %d obstacles per agent in registers",

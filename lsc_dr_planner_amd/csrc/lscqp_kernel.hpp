@@ -226,7 +226,7 @@ struct Cfg {
     static constexpr int LDH = NZ | 1;
     static_assert(NZ <= T, "lane-per-row kernel needs dim*(3M-2) <= 64*W");
     static_assert(CP <= T, "6M-3 <= 64*W");
-    static_assert(W == 1 || W == 2, "one or two wavefronts per QP");
+    static_assert(W == 1 || W == 2, "one or two wavefronts per QP (four measured slower than two: 0.167 vs 0.158 ms per 64-QP batch)");
     static_assert(M >= 2, "the reference assumes M >= 2 (src/traj_optimizer.cpp:341-352)");
     // LDS carve (in doubles)
     static constexpr int o_c = 0;               // control points (translated)
@@ -997,10 +997,13 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     hrow[zl ? lvz_ : 0] += dsum;  // dsum == 0 for lanes that are not c5 variables
                 }
                 LSCQP_WAVE_LDS_SYNC();
+                // (W = 2 with nz <= 64: the system lives in wavefront 0; the other wavefront runs the same factorisation
+                // code on an identity matrix, so that it neither divides by zero nor leaves the uniform control flow)
+                const int own_col = (W > 1 && NZ <= 64 && lvz_ >= 64) ? (lvz_ & 63) : -1;
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) {
                     const double v = hrow[cidx];
-                    A[cidx] = zl ? v : 0.0;
+                    A[cidx] = zl ? v : (cidx == own_col ? 1.0 : 0.0);
                 }
             }
             LSCQP_T(3);
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 
             // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
-            if constexpr (W == 1) {
+            if constexpr (W == 1 || NZ <= 64) {
 #ifndef LSCQP_FACT_READLANE
             // Pivot-row broadcast over BOTH pipes.  A v_readlane costs ~8 cycles of VALU issue (16 per fp64 value, next
             // to 4.6 for the FMA it feeds); a uniform-address ds_read_b64 costs ~11 cycles of the LDS pipe and none of
@@ -1018,9 +1021,10 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // the LDS latency) and the rest is read back from LDS while the VALU works.  The pivot reciprocal of step
             // j+1 is started inside step j as well.
             {
-                int lf = lane;
+                int lf = lane & 63;  // (lane of the wavefront: see the identity rows of a second wavefront)
                 asm volatile("" : "+v"(lf));
-                col_[lane] = A[0];
+                double* const colw = col_ + (W > 1 ? 2 * 64 * (lane >> 6) : 0);  // each wavefront its own column buffer
+                colw[lf] = A[0];
                 double d = bcast(A[0], 0);
                 double invd = fast_rcp(d);
                 static_for<0, NZ>([&](auto Jc) {
@@ -1030,8 +1034,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     constexpr int nr = n <= 4 ? n : (r0 < 3 ? 4 : r0 + 1);  // via v_readlane (k = j+1 always)
                     constexpr int nl = n - (nr < n ? nr : n);              // via LDS
                     constexpr int NR = n - nl;
-                    const double* const cb = col_ + (j & 1) * 64;
-                    double* const cbn = col_ + ((j + 1) & 1) * 64;
+                    const double* const cb = colw + (j & 1) * 64;
+                    double* const cbn = colw + ((j + 1) & 1) * 64;
                     pivot_bad = pivot_bad || !(d > 1e-300);
                     dinv_own = (lf == j) ? invd : dinv_own;
                     const double li = (lf > j) ? A[j] * invd : 0.0;
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                             ur[t] = bcast(A[j + 1 + t], j);
                         });
                         A[j + 1] = fma(-li, ur[0], A[j + 1]);
-                        cbn[lane] = A[j + 1];
+                        cbn[lf] = A[j + 1];
                         d = bcast(A[j + 1], j + 1);
                         invd = fast_rcp(d);
                         static_for<1, NR>([&](auto Tc) {
@@ -1071,7 +1075,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // 3*nz of them out of the iteration loop, which needs 2 SGPRs each, spills those into VGPR lanes
             // (v_writelane) and pays a v_readlane + hazard nops per use.  An opaque copy of the lane id per phase keeps
             // them where they are used: one v_cmp each.
-            int lf = lane;
+            int lf = lane & 63;
             asm volatile("" : "+v"(lf));
             static_for<0, NZ>([&](auto Jc) {
                 constexpr int j = decltype(Jc)::value;
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // broadcast of lane j's value to all lanes of the QP: v_readlane (W = 1) or an LDS slot + barrier (W = 2; one
             // slot per column and direction, so no slot is rewritten while a slower wavefront may still read it)
             auto bcast_q = [&](double v, int j, int ls, double* slots) -> double {
-                if constexpr (W == 1) {
+                if constexpr (W == 1 || NZ <= 64) {
                     return bcast(v, j);
                 } else {
                     if (ls == j) slots[j] = v;
@@ -1154,7 +1158,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #define LSCQP_FACTOR_ENTRY(j) A[j]
 #endif
             auto solve = [&](double b) -> double {
-                int ls = lane;  // opaque per call, see the factorisation
+                int ls = (NZ <= 64) ? (lane & 63) : lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
                 const double* const hr = &Hs[(ls < NZ ? ls : NZ) * LDH];
                 (void)hr;

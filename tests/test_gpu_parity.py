@@ -299,12 +299,16 @@ def _compiled_instances():
 
 
 @pytest.mark.parametrize("M,dim,es,nslot,waves", _compiled_instances())
-def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_cuda, M, dim, es, nslot, waves):
+def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_cuda, request, M, dim, es, nslot, waves):
     """Every kernel instance, at its full obstacle capacity: bitwise repeatable and equal to the oracle.
     (Guards against the exec-masked register-spill hazard described in lscqp_kernel.hpp: a miscompiled instance shows
     up as run-to-run differences long before it shows up as a wrong answer.)"""
     from lsc_dr_planner_amd import synth
 
+    import os
+
+    os.environ["LSCQP_WAVES"] = str(waves)  # pin the launch policy to the instance under test
+    request.addfinalizer(lambda: os.environ.pop("LSCQP_WAVES", None))
     G = max(1, 64 * waves // (6 * M - 3))
     n_obs = nslot * G
     N = max(24, n_obs + 2)
