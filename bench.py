@@ -191,7 +191,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
-                        "fp64 batched PDIP, one wavefront per QP" % (N, M, n_obs_eff, dim, args.style),
+                        "fp64 batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (N, M, n_obs_eff, dim, args.style),
             "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
             "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None),
             "parallelism": "agents sharded over %d GPU(s), no data-path collective" % world,
