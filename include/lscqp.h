@@ -173,6 +173,39 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
                              double* d_x_out, double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out,
                              void* stream);
 
+/* ---- next row of the path: the producer of the LSC rows --------------------------------
+ *
+ * Replaces TrajPlanner::generateLSC for agent-type obstacles (reference src/traj_planner.cpp:611-657), i.e.
+ * normalVectorBetweenPolys (:1179-1205), the closest point of closestPointsBetweenPointAndConvexHull
+ * (include/geometry.hpp:266-296; openGJK in the reference), downwashBetween (:1229-1240),
+ * Trajectory::coordinateTransform (src/trajectory.cpp:207-219) and CollisionConstraints::setLSC
+ * (src/collision_constraints.cpp:514-521) -- and writes the result directly in the packed row layout that
+ * lscqp_solve_batch_device consumes (rows of local agent a at offset a * n_obs * M * (n+1), order [oi][m][i]).
+ * DEVICE pointers, asynchronous on `stream`.
+ *   d_traj        [n_total][M][n+1][3]  control points of ALL agents: the planning agent's initial trajectory and a
+ *                 neighbour's predicted trajectory are both shifted previous plans (:273-310, 399-411); values as the
+ *                 reference holds them (float32-representable; lscqp_shift_traj_device produces exactly this)
+ *   d_neighbours  [n_agents][n_obs]     global agent ids of each local agent's obstacles; < 0 = none -> all-zero rows
+ *                 (the solver drops them like any normal shorter than 1e-5, src/traj_optimizer.cpp:409-411)
+ *   d_radius, d_downwash [n_total]      Agent::radius, Agent::downwash
+ *   d_goal        [n_agents][3]         current_goal_point: fallback normal when the hull contains the origin (:624-633)
+ *   first_agent   global id of local agent 0 (the local shard is [first_agent, first_agent + n_agents))
+ *   d_rows_out    [n_agents * n_obs * M * (n+1)] rows
+ * Dynamic obstacles / BVC / collision-predicted obstacles (the other branches of generateLSC) are not handled. */
+int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
+                              const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
+                              const double* d_goal, lscqp_row* d_rows_out, void* stream);
+
+/* Replaces TrajPlanner::initialTrajPlanningPrevSol (src/traj_planner.cpp:399-411) on the solver's output: segment m of
+ * the new initial trajectory := segment m+1 of the previous plan, the last segment := its last point; control points
+ * truncated to float32 like TrajOptResult::desired_traj (src/traj_optimizer.cpp:71-83); dim == 2 -> z := z_2d.
+ *   d_x_prev [n][dim*M*(n+1)] (x_out of lscqp_solve_batch_device)  ->  d_traj [n][M][n+1][3] */
+int lscqp_shift_traj_device(lscqp_handle h, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream);
+
+/* Algorithmic HBM bytes of one lscqp_generate_lsc_device call: rows written + every agent's control points,
+ * neighbour list, radius, downwash and goal read once. */
+int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t n_total);
+
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);

@@ -79,6 +79,12 @@ def lib():
         L.lscqp_solve_batch.argtypes = [vp, C.c_int64] + [vp] * 8
         L.lscqp_solve_batch_device.restype = C.c_int
         L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9
+        L.lscqp_generate_lsc_device.restype = C.c_int
+        L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
+        L.lscqp_shift_traj_device.restype = C.c_int
+        L.lscqp_shift_traj_device.argtypes = [vp, C.c_int64, C.c_double, vp, vp, vp]
+        L.lscqp_generate_lsc_bytes.restype = C.c_int64
+        L.lscqp_generate_lsc_bytes.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64]
         L.lscqp_last_error.restype = C.c_char_p
         L.lscqp_version.restype = C.c_char_p
         _lib = L
@@ -86,8 +92,8 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_last_error",
-                    "lscqp_version"]
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device",
+                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_last_error", "lscqp_version"]
 
 
 def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
@@ -182,6 +188,34 @@ class Solver:
                                             p(d_obj), p(d_status), p(d_info), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+
+    # ---- the producer of the rows, device pointers -----------------------------------
+    def generate_lsc_device(self, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal, d_rows,
+                            stream=None):
+        """TrajPlanner::generateLSC for agent obstacles, rows written in the layout solve_device consumes."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_generate_lsc_device(self._h, n_agents, n_obs, first_agent, C.c_void_p(d_traj.data_ptr()),
+                                             C.c_void_p(d_neighbours.data_ptr()), C.c_void_p(d_radius.data_ptr()),
+                                             C.c_void_p(d_downwash.data_ptr()), C.c_void_p(d_goal.data_ptr()),
+                                             C.c_void_p(d_rows.data_ptr()), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def shift_traj_device(self, n, d_x_prev, d_traj, z_2d=1.0, stream=None):
+        """initialTrajPlanningPrevSol: solver output [n][dim*M*6] -> initial trajectories [n][M][6][3] (float32 values)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_shift_traj_device(self._h, n, float(z_2d), C.c_void_p(d_x_prev.data_ptr()), C.c_void_p(d_traj.data_ptr()),
+                                           C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def generate_lsc_bytes(self, n_agents, n_obs, n_total):
+        return lib().lscqp_generate_lsc_bytes(self._h, n_agents, n_obs, n_total)
 
 
 def batch_from_swarm(build, n_obs, M, vmax=1.0, amax=2.0, radius=0.15, nominal_velocity=1.0, terminal_segments=None):

@@ -58,6 +58,11 @@ def build(force=False, verbose=False, jobs=None):
     api_src = os.path.join(CSRC, "lscqp_api.hip")
     if force or _newer(api_o, hdrs + [api_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
+    gen_o = os.path.join(OBJ, "lscgen.o")
+    objs.append(gen_o)
+    gen_src = os.path.join(CSRC, "lscgen.hip")
+    if force or _newer(gen_o, hdrs + [gen_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", gen_src, "-o", gen_o])
     if tasks:
         with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
             for msg in ex.map(_run, tasks):

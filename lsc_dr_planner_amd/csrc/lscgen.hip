@@ -1,0 +1,230 @@
+// lscgen.hip — LSC generation on the device, gfx950 only: the producer of the rows the trajectory QP
+// consumes, plus the shift of the previous plan that feeds it.  C ABI in include/lscqp.h.
+//
+// Replaces, for agent-type obstacles, TrajPlanner::generateLSC (reference src/traj_planner.cpp:611-657) with
+// normalVectorBetweenPolys (:1179-1205), the closest point of closestPointsBetweenPointAndConvexHull
+// (include/geometry.hpp:266-296: openGJK in the reference), downwashBetween (:1229-1240),
+// Trajectory::coordinateTransform (src/trajectory.cpp:207-219) and CollisionConstraints::setLSC
+// (src/collision_constraints.cpp:514-521).  Not a translation: the reference runs GJK per (neighbour, segment) on the CPU
+// and stores 56-byte LSC records in nested vectors; here one lane owns one (agent, neighbour, segment) unit, finds the
+// closest point of the 6-point hull by enumerating its candidate faces (the closest point of a convex hull is unique,
+// so this agrees with GJK; branch-light, no iteration count) and writes the six packed 32-byte rows
+// (nx, ny, nz, b = d + n.p_obs) the QP kernel stages, straight into HBM.
+//
+// The kernel is HBM-side work: per unit 192 B written + 144 B (neighbour's control points) read, ~2 kflop fp64.
+// Rows of one wavefront are staged through LDS so that every global store instruction writes 64 x 16 contiguous bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/lscqp.h"
+
+namespace lscgen {
+
+constexpr int kThreads = 256;
+
+struct P3 {
+    double x, y, z;
+};
+__device__ __forceinline__ P3 sub(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ double dot(P3 a, P3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ P3 cross(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ P3 axpy(P3 a, double t, P3 b) { return {a.x + t * b.x, a.y + t * b.y, a.z + t * b.z}; }
+
+// closest point to the origin on conv{p[0..5]}: 6 vertices, 15 edges, 20 triangles, and the 15 tetrahedra that decide
+// whether the origin is inside (distance 0)
+__device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
+    double best = 1e300;
+    P3 bp = {0, 0, 0};
+    auto consider = [&](P3 q, bool ok) {
+        const double d2 = dot(q, q);
+        const bool take = ok && d2 < best;
+        best = take ? d2 : best;
+        bp.x = take ? q.x : bp.x;
+        bp.y = take ? q.y : bp.y;
+        bp.z = take ? q.z : bp.z;
+    };
+#pragma unroll
+    for (int i = 0; i < 6; i++) consider(p[i], true);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) {
+            const P3 ab = sub(p[j], p[i]);
+            const double den = dot(ab, ab);
+            const bool ok = den > 1e-18;
+            const double t = -dot(p[i], ab) / (ok ? den : 1.0);
+            consider(axpy(p[i], t, ab), ok && t >= 0.0 && t <= 1.0);
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i + 1; j < 6; j++)
+#pragma unroll
+            for (int l = j + 1; l < 6; l++) {
+                const P3 e1 = sub(p[j], p[i]), e2 = sub(p[l], p[i]);
+                const double g11 = dot(e1, e1), g12 = dot(e1, e2), g22 = dot(e2, e2);
+                const double r1 = -dot(p[i], e1), r2 = -dot(p[i], e2);
+                const double det = g11 * g22 - g12 * g12;
+                const bool ok = det > 1e-14 * fmax(g11 * g22, 1e-300);  // degenerate triangle: its edges cover it
+                const double idet = 1.0 / (ok ? det : 1.0);
+                const double u = (r1 * g22 - r2 * g12) * idet, v = (r2 * g11 - r1 * g12) * idet;
+                consider(axpy(axpy(p[i], u, e1), v, e2), ok && u >= 0.0 && v >= 0.0 && u + v <= 1.0);
+            }
+    bool inside = false;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i + 1; j < 6; j++)
+#pragma unroll
+            for (int l = j + 1; l < 6; l++)
+#pragma unroll
+                for (int q = l + 1; q < 6; q++) {
+                    const P3 u = sub(p[j], p[i]), v = sub(p[l], p[i]), w = sub(p[q], p[i]);
+                    const P3 vw = cross(v, w);
+                    const double det = dot(u, vw);
+                    const double scale = sqrt(dot(u, u) * dot(v, v) * dot(w, w));
+                    const bool ok = fabs(det) > 1e-12 * scale && scale != 0.0;  // flat tetrahedron: skipped
+                    const P3 r = {-p[i].x, -p[i].y, -p[i].z};
+                    const double idet = 1.0 / (ok ? det : 1.0);
+                    const double l1 = dot(r, vw) * idet, l2 = dot(u, cross(r, w)) * idet, l3 = dot(u, cross(v, r)) * idet;
+                    inside = inside || (ok && l1 >= 0.0 && l2 >= 0.0 && l3 >= 0.0 && l1 + l2 + l3 <= 1.0);
+                }
+    if (inside) bp = {0, 0, 0};
+    return bp;
+}
+
+// one lane per (agent a, obstacle slot o, segment m); unit index t = (a*n_obs + o)*M + m, rows of unit t = out[6t .. 6t+6)
+__global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, int64_t n_units, int32_t n_obs, int64_t first_agent,
+                                                                const double* __restrict__ traj,
+                                                                const int32_t* __restrict__ neighbours,
+                                                                const double* __restrict__ radius,
+                                                                const double* __restrict__ downwash,
+                                                                const double* __restrict__ goal, lscqp_row* __restrict__ out) {
+    __shared__ double4 stage[kThreads * 6];  // the block's rows in output order: [lane][row], 32 B each (48 KiB)
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool live = t < n_units;
+    const int64_t tt = live ? t : 0;
+    const int m = (int)(tt % M);
+    const int64_t ao = tt / M;
+    const int o = (int)(ao % n_obs);
+    const int64_t a = ao / n_obs;
+    const int64_t ga = first_agent + a;
+    const int32_t gb_raw = neighbours[a * n_obs + o];
+    const bool has = live && gb_raw >= 0;
+    const int64_t gb = has ? gb_raw : ga;
+
+    const double r_own = radius[ga], r_obs = radius[gb];
+    // downwashBetween, both agents (:1229-1240); 2-D missions plan in the plane
+    const double dw = (dim == 3) ? (downwash[ga] * r_own + downwash[gb] * r_obs) / (r_own + r_obs) : 1.0;
+    const float dwf = (float)dw;
+    const double* own = traj + (ga * M + m) * 18;
+    const double* obs = traj + (gb * M + m) * 18;
+    P3 pobs[6];
+    float relf[6][3];
+    P3 rel[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double ax = own[3 * i], ay = own[3 * i + 1], az = own[3 * i + 2];
+        const double bx = obs[3 * i], by = obs[3 * i + 1], bz = obs[3 * i + 2];
+        pobs[i] = {(double)(float)bx, (double)(float)by, (double)(float)bz};
+        // point3d arithmetic of the reference: float control points, z /= (float)downwash (src/trajectory.cpp:214),
+        // float difference (:1186)
+        float azf = (float)az, bzf = (float)bz;
+        if (dim == 3) {
+            azf = azf / dwf;
+            bzf = bzf / dwf;
+        }
+        relf[i][0] = (float)ax - (float)bx;
+        relf[i][1] = (float)ay - (float)by;
+        relf[i][2] = (dim == 3) ? azf - bzf : 0.0f;
+        rel[i] = {(double)relf[i][0], (double)relf[i][1], (double)relf[i][2]};
+    }
+    const P3 cp = hull_closest_point(rel);
+    // closest_point2 is a point3d (float), normalized() in float (:1195); hull around the origin -> fallback (:624-633)
+    float nx = (float)cp.x, ny = (float)cp.y, nz = (float)cp.z;
+    float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (len < 1e-5f) {
+        const double* g = goal + 3 * a;
+        nx = (float)(g[0] - obs[0]);
+        ny = (float)(g[1] - obs[1]);
+        nz = (dim == 3) ? (float)(g[2] - obs[2]) / dwf : 0.0f;
+        len = sqrtf(nx * nx + ny * ny + nz * nz);
+    }
+    if (len > 0.0f) {
+        nx /= len;
+        ny /= len;
+        nz /= len;
+    }
+    const double collision_dist = r_obs + r_own;  // :641
+    const double onx = (double)nx, ony = (double)ny;
+    const double onz = (dim == 3) ? (double)(float)((double)nz / dw) : 0.0;  // :653
+    double4* mine = stage + (size_t)threadIdx.x * 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float dotf = relf[i][0] * nx + relf[i][1] * ny + relf[i][2] * nz;  // float dot of :642-643
+        const double d = 0.5 * (collision_dist + (double)dotf);
+        const double b = d + (onx * pobs[i].x + ony * pobs[i].y + onz * pobs[i].z);  // packed row: n.c >= b = d + n.p_obs
+        // rows of a missing neighbour are all-zero: the solver drops normals shorter than 1e-5 (:409-411)
+        mine[i] = has ? double4{onx, ony, onz, b} : double4{0, 0, 0, 0};
+    }
+    __syncthreads();
+    // cooperative store: the block's rows are contiguous in `out` in exactly the staging order, so every global store
+    // instruction of a wavefront writes 64 x 32 contiguous bytes
+    const int64_t base_row = (int64_t)blockIdx.x * kThreads * 6;
+    const int64_t n_rows = n_units * 6;
+    double4* o4 = reinterpret_cast<double4*>(out);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int rix = k * kThreads + threadIdx.x;  // row index within the block
+        if (base_row + rix < n_rows) o4[base_row + rix] = stage[rix];
+    }
+}
+
+// initialTrajPlanningPrevSol (reference src/traj_planner.cpp:399-411) on the solver's output layout:
+// x_prev [n][dim][M][6] fp64 (reference variable order) -> traj [n][M][6][3], segment m := previous segment m+1, last
+// segment := the previous plan's last point; values rounded to float32 like desired_traj (src/traj_optimizer.cpp:71-83);
+// dim == 2: z := z_2d (world_z_2d)
+__global__ __launch_bounds__(kThreads) void shift_traj_kernel(int M, int dim, int64_t n, double z_2d, const double* __restrict__ x_prev,
+                                                              double* __restrict__ traj) {
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n * M * 6) return;
+    const int i = (int)(t % 6);
+    const int m = (int)((t / 6) % M);
+    const int64_t a = t / (6 * M);
+    const int ms = (m + 1 < M) ? m + 1 : M - 1, is = (m + 1 < M) ? i : 5;
+    const double* x = x_prev + a * dim * M * 6;
+    double* o = traj + ((a * M + m) * 6 + i) * 3;
+    o[0] = (double)(float)x[(0 * M + ms) * 6 + is];
+    o[1] = (double)(float)x[(1 * M + ms) * 6 + is];
+    o[2] = (dim == 3) ? (double)(float)x[(2 * M + ms) * 6 + is] : (double)(float)z_2d;
+}
+
+}  // namespace lscgen
+
+extern "C" int lscqp_set_error_(int code, const char* msg);  // lscqp_api.hip
+
+extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
+                                       const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
+                                       const double* d_goal, lscqp_row* d_rows_out, void* stream) {
+    const int64_t n_units = n_agents * (int64_t)n_obs * M;
+    if (n_units == 0) return LSCQP_OK;
+    const unsigned blocks = (unsigned)((n_units + lscgen::kThreads - 1) / lscgen::kThreads);
+    hipLaunchKernelGGL(lscgen::generate_lsc_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n_units, n_obs,
+                       first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal, d_rows_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
+
+extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream) {
+    const int64_t total = n * M * 6;
+    if (total == 0) return LSCQP_OK;
+    const unsigned blocks = (unsigned)((total + lscgen::kThreads - 1) / lscgen::kThreads);
+    hipLaunchKernelGGL(lscgen::shift_traj_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n, z_2d, d_x_prev,
+                       d_traj);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}

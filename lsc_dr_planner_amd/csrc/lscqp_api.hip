@@ -19,6 +19,11 @@
 LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
+extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
+                                       const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
+                                       const double* d_goal, lscqp_row* d_rows_out, void* stream);
+extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream);
+
 namespace {
 
 thread_local std::string g_err;
@@ -26,6 +31,10 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+
+}  // namespace
+extern "C" int lscqp_set_error_(int code, const char* msg) { return fail(code, msg); }
+namespace {
 
 struct Inst {
     int M, dim, es, max_obs, waves;
@@ -175,6 +184,40 @@ int lscqp_destroy(lscqp_handle h) {
 }
 
 int lscqp_num_variables(lscqp_handle h) { return h ? h->nv : -1; }
+
+int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
+                              const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
+                              const double* d_goal, lscqp_row* d_rows_out, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_agents < 0 || n_obs < 0 || first_agent < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n_agents == 0 || n_obs == 0) return LSCQP_OK;
+    if (!d_traj || !d_neighbours || !d_radius || !d_downwash || !d_goal || !d_rows_out)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_generate_lsc_raw_(h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash,
+                                   d_goal, d_rows_out, stream);
+}
+
+int lscqp_shift_traj_device(lscqp_handle h, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return LSCQP_OK;
+    if (!d_x_prev || !d_traj) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_shift_traj_raw_(h->desc.M, h->desc.dim, n, z_2d, d_x_prev, d_traj, stream);
+}
+
+int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t n_total) {
+    if (!h) return -1;
+    const int64_t P = h->P;
+    return n_agents * (int64_t)n_obs * P * 32      /* rows written */
+           + n_total * (P * 24 + 16)               /* control points, radius, downwash */
+           + n_agents * ((int64_t)n_obs * 4 + 24); /* neighbour ids, goal */
+}
 
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs) {
     if (!h) return -1;

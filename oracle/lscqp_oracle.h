@@ -111,6 +111,13 @@ int orc_solve_batch(const orc_class* c, int n, const orc_agent* agents, const or
                     const long long* lsc_off, const orc_box* sfc, double tol, int max_iter, int threads,
                     double* x, double* obj, int* status, int* iters);
 
+/* ---- LSC generation (oracle/lscgen_oracle.c; reference src/traj_planner.cpp:611-657) ---- */
+double orc_hull_closest_point(const double* pts, int k, double* out);
+void orc_generate_lsc_pair(int M, int dim, const double* own, const double* obs, double r_own, double r_obs, double dw_own,
+                           double dw_obs, const double* fallback, orc_lsc* out);
+void orc_generate_lsc(int M, int dim, int n_agents, int n_obs, int first_agent, const double* traj, const int* neighbours,
+                      const double* radius, const double* downwash, const double* goal, orc_lsc* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-"""ctypes binding of the CPU oracle (oracle/lscqp_oracle.c).
+"""ctypes binding of the CPU oracle (oracle/lscqp_oracle.c, oracle/lscgen_oracle.c) and of oracle/_ref.
 
 TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and the cpu_baseline leg of
 bench.py may import this module.  The product package never does.
@@ -47,15 +47,49 @@ assert AGENT_DTYPE.itemsize == C.sizeof(OrcAgent)
 _lib = None
 
 
+_REF_GJK_PATH = os.path.join(_HERE, "_ref", "libref_gjk.so")
+_REFERENCE = "/root/reference"
+
+
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    src = os.path.join(_HERE, "lscqp_oracle.c")
-    hdr = os.path.join(_HERE, "lscqp_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscqp_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liblscqp_oracle.so"])
     return _LIB_PATH
+
+
+def build_ref():
+    """oracle/_ref/libref_gjk.so: the reference's own openGJK compiled from the reference checkout (build container
+    only; the GPU box uses the prebuilt file that travelled with the snapshot, or the committed golden vectors).
+    Returns the path, or None when neither the checkout nor a prebuilt library is there."""
+    if os.path.exists(os.path.join(_REFERENCE, "src", "openGJK", "openGJK.cpp")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return _REF_GJK_PATH if os.path.exists(_REF_GJK_PATH) else None
+
+
+_ref_gjk = None
+
+
+def ref_gjk(hull, point=(0.0, 0.0, 0.0)):
+    """The reference's openGJK on (hull (k,3), point): returns (distance, closest point of the hull relative to
+    `point`), exactly what closestPointsBetweenPointAndConvexHull gets (reference include/geometry.hpp:266-296).
+    None if oracle/_ref is not built."""
+    global _ref_gjk
+    if _ref_gjk is None:
+        if not os.path.exists(_REF_GJK_PATH):
+            return None
+        _ref_gjk = C.CDLL(_REF_GJK_PATH)
+        dp = C.POINTER(C.c_double)
+        _ref_gjk.ref_gjk_point_hull.restype = C.c_double
+        _ref_gjk.ref_gjk_point_hull.argtypes = [dp, C.c_int, dp, dp]
+    h = np.ascontiguousarray(hull, dtype=np.float64)
+    pt = np.ascontiguousarray(point, dtype=np.float64)
+    v = np.zeros(3)
+    d = _ref_gjk.ref_gjk_point_hull(_dp(h), h.shape[0], _dp(pt), _dp(v))
+    return d, v
 
 
 def lib():
@@ -78,6 +112,9 @@ def lib():
         _lib.orc_aeq_base.restype = C.c_int
         _lib.orc_aeq_base.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, dp]
         _lib.orc_bernstein.argtypes = [C.c_int, dp]
+        _lib.orc_hull_closest_point.restype = C.c_double
+        _lib.orc_hull_closest_point.argtypes = [dp, C.c_int, dp]
+        _lib.orc_generate_lsc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_void_p]
         _lib.orc_solve_batch.restype = C.c_int
         _lib.orc_solve_batch.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
@@ -195,3 +232,28 @@ def solve_batch(cls, agents, lsc=None, lsc_off=None, sfc=None, tol=1e-11, max_it
                                 threads, _dp(x), _dp(obj), status.ctypes.data_as(C.POINTER(C.c_int)),
                                 iters.ctypes.data_as(C.POINTER(C.c_int)))
     return dict(x=x, obj=obj, status=status, iters=iters, bad=bad)
+
+
+def hull_closest_point(pts):
+    """Closest point to the origin on conv(pts), pts (k,3), k <= 8: (distance, point).  oracle/lscgen_oracle.c."""
+    p = np.ascontiguousarray(pts, dtype=np.float64)
+    out = np.zeros(3)
+    d = lib().orc_hull_closest_point(_dp(p), p.shape[0], _dp(out))
+    return d, out
+
+
+def generate_lsc(traj, neighbours, radius, downwash, goal, dim=3, first_agent=0):
+    """Restatement of TrajPlanner::generateLSC for agent obstacles (reference src/traj_planner.cpp:611-657).
+    traj (n_total, M, 6, 3) initial / predicted control points, neighbours (n_agents, n_obs) global ids (< 0: none),
+    radius, downwash (n_total,), goal (n_agents, 3).  Returns LSC_DTYPE[n_agents, n_obs, M, 6]."""
+    traj = np.ascontiguousarray(traj, dtype=np.float64)
+    nb = np.ascontiguousarray(neighbours, dtype=np.int32)
+    n_total, M = traj.shape[0], traj.shape[1]
+    n_agents, n_obs = nb.shape
+    r = np.ascontiguousarray(np.broadcast_to(radius, (n_total,)), dtype=np.float64)
+    dw = np.ascontiguousarray(np.broadcast_to(downwash, (n_total,)), dtype=np.float64)
+    g = np.ascontiguousarray(goal, dtype=np.float64).reshape(n_agents, 3)
+    out = np.zeros((n_agents, n_obs, M, 6), LSC_DTYPE)
+    lib().orc_generate_lsc(M, dim, n_agents, n_obs, first_agent, _dp(traj), nb.ctypes.data_as(C.POINTER(C.c_int)), _dp(r),
+                           _dp(dw), _dp(g), out.ctypes.data_as(C.c_void_p))
+    return out
