@@ -32,8 +32,8 @@ __device__ __forceinline__ double dot(P3 a, P3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ P3 cross(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ P3 axpy(P3 a, double t, P3 b) { return {a.x + t * b.x, a.y + t * b.y, a.z + t * b.z}; }
 
-// closest point to the origin on conv{p[0..5]}: 6 vertices, 15 edges, 20 triangles, and the 15 tetrahedra that decide
-// whether the origin is inside (distance 0)
+// closest point to the origin on conv{p[0..5]}: 6 vertices, 15 edges, 20 triangles, then a supporting-plane test that
+// decides whether the origin is inside (distance 0)
 __device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
     double best = 1e300;
     P3 bp = {0, 0, 0};
@@ -72,25 +72,12 @@ __device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
                 const double u = (r1 * g22 - r2 * g12) * idet, v = (r2 * g11 - r1 * g12) * idet;
                 consider(axpy(axpy(p[i], u, e1), v, e2), ok && u >= 0.0 && v >= 0.0 && u + v <= 1.0);
             }
+    // Hull around the origin -> distance 0 (what openGJK reports once its simplex has 4 vertices).  If bp were the closest
+    // point of a hull that does not contain the origin, every vertex would lie beyond the supporting plane through bp
+    // (p_i . bp >= |bp|^2); a hull around the origin has a vertex with p_i . bp < 0.  The threshold sits halfway.
     bool inside = false;
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i + 1; j < 6; j++)
-#pragma unroll
-            for (int l = j + 1; l < 6; l++)
-#pragma unroll
-                for (int q = l + 1; q < 6; q++) {
-                    const P3 u = sub(p[j], p[i]), v = sub(p[l], p[i]), w = sub(p[q], p[i]);
-                    const P3 vw = cross(v, w);
-                    const double det = dot(u, vw);
-                    const double scale = sqrt(dot(u, u) * dot(v, v) * dot(w, w));
-                    const bool ok = fabs(det) > 1e-12 * scale && scale != 0.0;  // flat tetrahedron: skipped
-                    const P3 r = {-p[i].x, -p[i].y, -p[i].z};
-                    const double idet = 1.0 / (ok ? det : 1.0);
-                    const double l1 = dot(r, vw) * idet, l2 = dot(u, cross(r, w)) * idet, l3 = dot(u, cross(v, r)) * idet;
-                    inside = inside || (ok && l1 >= 0.0 && l2 >= 0.0 && l3 >= 0.0 && l1 + l2 + l3 <= 1.0);
-                }
+    for (int i = 0; i < 6; i++) inside = inside || (dot(p[i], bp) < 0.5 * best);
     if (inside) bp = {0, 0, 0};
     return bp;
 }

@@ -15,7 +15,8 @@
  *
  * The closest point itself is computed by the reference with openGJK (src/openGJK/openGJK.cpp, vendored in the
  * reference tree).  The closest point of a convex hull to the origin is unique, so any exact method must agree with
- * it; here it is found by enumeration of the hull's candidate faces (6 vertices, 15 edges, 20 triangles).
+ * it; here it is found by enumeration of the hull's candidate faces (6 vertices, 15 edges, 20 triangles) plus a
+ * supporting-plane test for a hull that contains the origin.
  * PARITY PINNING: tests/test_lscgen.py checks this routine against the REFERENCE's openGJK — compiled from the
  * reference's own source into oracle/_ref/libref_gjk.so (oracle/Makefile, target ref) when /root/reference is
  * present, and through the committed outputs of that library (tests/golden/gjk_hulls.json, tools/make_golden_gjk.py)
@@ -75,33 +76,20 @@ double orc_hull_closest_point(const double* pts, int k, double* out) {
                     memcpy(bp, p, sizeof bp);
                 }
             }
-    /* origin inside the hull (Caratheodory: inside some tetrahedron of the vertex set) -> distance 0, as openGJK
-     * reports when its simplex reaches 4 vertices */
-    for (int i = 0; i < k && best > 0; i++)
-        for (int j = i + 1; j < k && best > 0; j++)
-            for (int l = j + 1; l < k && best > 0; l++)
-                for (int q = l + 1; q < k; q++) {
-                    const double *a = &pts[3 * i], *b = &pts[3 * j], *c = &pts[3 * l], *e = &pts[3 * q];
-                    double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, v[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]},
-                           w[3] = {e[0] - a[0], e[1] - a[1], e[2] - a[2]};
-                    double vw[3] = {v[1] * w[2] - v[2] * w[1], v[2] * w[0] - v[0] * w[2], v[0] * w[1] - v[1] * w[0]};
-                    double det = u[0] * vw[0] + u[1] * vw[1] + u[2] * vw[2];
-                    double scale = sqrt((u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) *
-                                        (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]));
-                    if (!(fabs(det) > 1e-12 * scale) || scale == 0) continue; /* flat tetrahedron */
-                    double r[3] = {-a[0], -a[1], -a[2]};
-                    /* Cramer: r = l1 u + l2 v + l3 w */
-                    double rw[3] = {r[1] * w[2] - r[2] * w[1], r[2] * w[0] - r[0] * w[2], r[0] * w[1] - r[1] * w[0]};
-                    double vr[3] = {v[1] * r[2] - v[2] * r[1], v[2] * r[0] - v[0] * r[2], v[0] * r[1] - v[1] * r[0]};
-                    double l1 = (r[0] * vw[0] + r[1] * vw[1] + r[2] * vw[2]) / det;
-                    double l2 = (u[0] * rw[0] + u[1] * rw[1] + u[2] * rw[2]) / det;
-                    double l3 = (u[0] * vr[0] + u[1] * vr[1] + u[2] * vr[2]) / det;
-                    if (l1 >= 0 && l2 >= 0 && l3 >= 0 && l1 + l2 + l3 <= 1) {
-                        best = 0;
-                        bp[0] = bp[1] = bp[2] = 0;
-                        break;
-                    }
-                }
+    /* Origin inside the hull -> distance 0 (openGJK reports 0 once its simplex reaches 4 vertices).  If bp were the
+     * closest point of a hull that does not contain the origin, every vertex would lie beyond the supporting plane
+     * through bp (p_i . bp >= |bp|^2); a hull around the origin has vertices on the far side of any direction. */
+    if (best > 0) {
+        const double bb = bp[0] * bp[0] + bp[1] * bp[1] + bp[2] * bp[2];
+        for (int i = 0; i < k; i++) {
+            const double* a = &pts[3 * i];
+            if (a[0] * bp[0] + a[1] * bp[1] + a[2] * bp[2] < 0.5 * bb) { /* outside: all >= bb; inside: some < 0 */
+                best = 0;
+                bp[0] = bp[1] = bp[2] = 0;
+                break;
+            }
+        }
+    }
     memcpy(out, bp, sizeof bp);
     return best;
 }
