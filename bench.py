@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--style", default="forest")
     ap.add_argument("--allgather", action="store_true", help="all-gather solved trajectories over RCCL every step")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="step = all-gather of the plans (N > 1) -> LSC generation on the device -> QP solve (SURVEY 8f-1); "
+                         "the default step is the QP solve of BASELINE's metric alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
     args = ap.parse_args()
@@ -95,11 +98,30 @@ def main():
     d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
     d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
     d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
-    d_all = torch.zeros(world * N * nv, dtype=torch.float64, device=dev) if (args.allgather and world > 1) else None
+    d_all = torch.zeros(world * N * nv, dtype=torch.float64, device=dev) if ((args.allgather or args.pipeline) and world > 1) else None
+    if args.pipeline:
+        # every rank's swarm is independent (weak scaling); global agent id = rank * N + local id.  The rows are
+        # regenerated every step from the CURRENT plans of all agents (replanning from the same state: the previous
+        # plans satisfy the new rows by the supporting-hyperplane argument of SURVEY 8d), so the exchange is load bearing.
+        n_total = world * N
+        d_traj = torch.zeros(n_total * M * 6 * 3, dtype=torch.float64, device=dev)
+        d_nbr = torch.from_numpy((build["nbr"] + rank * N).astype(np.int32)).to(dev)
+        d_rad = torch.full((n_total,), sw.radius, dtype=torch.float64, device=dev)
+        d_dw = torch.full((n_total,), sw.downwash, dtype=torch.float64, device=dev)
+        d_goal = torch.from_numpy(np.ascontiguousarray(build["goal"], dtype=np.float64)).to(dev)
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)  # plans to start from
+        torch.cuda.synchronize()
 
     def step():
+        if args.pipeline:
+            src = d_x
+            if d_all is not None:
+                dist.all_gather_into_tensor(d_all, d_x)
+                src = d_all
+            sol.shift_traj_device(world * N, src, d_traj, z_2d=float(build["p0"][0][2]), shift=0)
+            sol.generate_lsc_device(N, n_obs_eff, rank * N, d_traj, d_nbr, d_rad, d_dw, d_goal, d_rows)
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
-        if d_all is not None:
+        if d_all is not None and not args.pipeline:
             dist.all_gather_into_tensor(d_all, d_x)
 
     def barrier():
@@ -193,7 +215,7 @@ def main():
             "workload": "%d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
                         "fp64 batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (N, M, n_obs_eff, dim, args.style),
             "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
-            "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None),
+            "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline),
             "parallelism": "agents sharded over %d GPU(s), no data-path collective" % world,
         },
         "roofline": {

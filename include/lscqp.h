@@ -199,8 +199,10 @@ int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, i
 /* Replaces TrajPlanner::initialTrajPlanningPrevSol (src/traj_planner.cpp:399-411) on the solver's output: segment m of
  * the new initial trajectory := segment m+1 of the previous plan, the last segment := its last point; control points
  * truncated to float32 like TrajOptResult::desired_traj (src/traj_optimizer.cpp:71-83); dim == 2 -> z := z_2d.
- *   d_x_prev [n][dim*M*(n+1)] (x_out of lscqp_solve_batch_device)  ->  d_traj [n][M][n+1][3] */
-int lscqp_shift_traj_device(lscqp_handle h, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream);
+ *   d_x_prev [n][dim*M*(n+1)] (x_out of lscqp_solve_batch_device)  ->  d_traj [n][M][n+1][3]
+ *   shift_segments: 1 = the reference's shift; 0 = layout change and truncation only (replanning from the same state) */
+int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, double z_2d, const double* d_x_prev,
+                            double* d_traj, void* stream);
 
 /* Algorithmic HBM bytes of one lscqp_generate_lsc_device call: rows written + every agent's control points,
  * neighbour list, radius, downwash and goal read once. */

@@ -82,7 +82,7 @@ def lib():
         L.lscqp_generate_lsc_device.restype = C.c_int
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_shift_traj_device.restype = C.c_int
-        L.lscqp_shift_traj_device.argtypes = [vp, C.c_int64, C.c_double, vp, vp, vp]
+        L.lscqp_shift_traj_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_double, vp, vp, vp]
         L.lscqp_generate_lsc_bytes.restype = C.c_int64
         L.lscqp_generate_lsc_bytes.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64]
         L.lscqp_last_error.restype = C.c_char_p
@@ -204,12 +204,12 @@ class Solver:
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
-    def shift_traj_device(self, n, d_x_prev, d_traj, z_2d=1.0, stream=None):
+    def shift_traj_device(self, n, d_x_prev, d_traj, z_2d=1.0, shift=1, stream=None):
         """initialTrajPlanningPrevSol: solver output [n][dim*M*6] -> initial trajectories [n][M][6][3] (float32 values)."""
         import torch
 
         s = stream if stream is not None else torch.cuda.current_stream()
-        rc = lib().lscqp_shift_traj_device(self._h, n, float(z_2d), C.c_void_p(d_x_prev.data_ptr()), C.c_void_p(d_traj.data_ptr()),
+        rc = lib().lscqp_shift_traj_device(self._h, n, int(shift), float(z_2d), C.c_void_p(d_x_prev.data_ptr()), C.c_void_p(d_traj.data_ptr()),
                                            C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())

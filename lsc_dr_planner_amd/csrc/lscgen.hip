@@ -173,14 +173,15 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
 // x_prev [n][dim][M][6] fp64 (reference variable order) -> traj [n][M][6][3], segment m := previous segment m+1, last
 // segment := the previous plan's last point; values rounded to float32 like desired_traj (src/traj_optimizer.cpp:71-83);
 // dim == 2: z := z_2d (world_z_2d)
-__global__ __launch_bounds__(kThreads) void shift_traj_kernel(int M, int dim, int64_t n, double z_2d, const double* __restrict__ x_prev,
-                                                              double* __restrict__ traj) {
+__global__ __launch_bounds__(kThreads) void shift_traj_kernel(int M, int dim, int64_t n, int shift, double z_2d,
+                                                              const double* __restrict__ x_prev, double* __restrict__ traj) {
     const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (t >= n * M * 6) return;
     const int i = (int)(t % 6);
     const int m = (int)((t / 6) % M);
     const int64_t a = t / (6 * M);
-    const int ms = (m + 1 < M) ? m + 1 : M - 1, is = (m + 1 < M) ? i : 5;
+    // shift == 0: layout change + float32 truncation only (replanning from the same state)
+    const int ms = (m + shift < M) ? m + shift : M - 1, is = (m + shift < M) ? i : 5;
     const double* x = x_prev + a * dim * M * 6;
     double* o = traj + ((a * M + m) * 6 + i) * 3;
     o[0] = (double)(float)x[(0 * M + ms) * 6 + is];
@@ -205,12 +206,13 @@ extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t
     return LSCQP_OK;
 }
 
-extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream) {
+extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, int shift, double z_2d, const double* d_x_prev, double* d_traj,
+                                     void* stream) {
     const int64_t total = n * M * 6;
     if (total == 0) return LSCQP_OK;
     const unsigned blocks = (unsigned)((total + lscgen::kThreads - 1) / lscgen::kThreads);
-    hipLaunchKernelGGL(lscgen::shift_traj_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n, z_2d, d_x_prev,
-                       d_traj);
+    hipLaunchKernelGGL(lscgen::shift_traj_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n, shift, z_2d,
+                       d_x_prev, d_traj);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;

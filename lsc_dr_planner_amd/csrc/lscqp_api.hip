@@ -22,7 +22,8 @@ LSCQP_INSTANCES(LSCQP_DECL)
 extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
                                        const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
                                        const double* d_goal, lscqp_row* d_rows_out, void* stream);
-extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream);
+extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, int shift, double z_2d, const double* d_x_prev, double* d_traj,
+                                     void* stream);
 
 namespace {
 
@@ -200,15 +201,17 @@ int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, i
                                    d_goal, d_rows_out, stream);
 }
 
-int lscqp_shift_traj_device(lscqp_handle h, int64_t n, double z_2d, const double* d_x_prev, double* d_traj, void* stream) {
+int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, double z_2d, const double* d_x_prev, double* d_traj,
+                            void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (shift_segments < 0 || shift_segments > 1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "shift_segments must be 0 or 1");
     if (n == 0) return LSCQP_OK;
     if (!d_x_prev || !d_traj) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_shift_traj_raw_(h->desc.M, h->desc.dim, n, z_2d, d_x_prev, d_traj, stream);
+    return lscqp_shift_traj_raw_(h->desc.M, h->desc.dim, n, shift_segments, z_2d, d_x_prev, d_traj, stream);
 }
 
 int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t n_total) {
