@@ -73,14 +73,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (LSCQP_BENCH_BACKEND=gloo lets a 1-GPU box exercise the multi-rank code path: the ranks then
+    # share the device and the collectives go through gloo; never used for reported numbers.)
+    backend = os.environ.get("LSCQP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from lsc_dr_planner_amd import api, synth
 
@@ -216,7 +223,8 @@ def main():
                         "fp64 batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (N, M, n_obs_eff, dim, args.style),
             "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
             "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline),
-            "parallelism": "agents sharded over %d GPU(s), no data-path collective" % world,
+            "parallelism": ("agents sharded over %d GPU(s), " % world) +
+                           ("one RCCL all-gather of the plans per step" if d_all is not None else "no data-path collective"),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
