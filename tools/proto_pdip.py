@@ -196,12 +196,14 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         if neg.any(): a = min(a, (-s[neg] / ds[neg]).min())
         neg = dl < 0
         if neg.any(): a = min(a, (-lam[neg] / dl[neg]).min())
-        a = min(1.0, 0.9995 * a)
+        tau = max(0.9995, 1.0 - mu) if sigma < 1e-4 else 0.9995  # adaptive fraction to the boundary (kernel: same rule)
+        a_std = min(1.0, 0.9995 * a)
+        a = min(1.0, tau * a)
         for _bt in range(10):  # centrality safeguard: every product stays >= 1e-4 mu(a)  (kernel: same rule)
             sn = s + a * ds; ln = lam + a * dl
             if (sn * ln).min() >= 1e-4 * (sn @ ln) / mrows:
                 break
-            a *= 0.7
+            a = a_std if (_bt == 0 and a_std < a) else 0.7 * a
         z = z + a * dz; s = s + a * ds; lam = lam + a * dl
     x = np.concatenate([cfix[k] + T @ z[k * nzA:(k + 1) * nzA] for k in range(dim)])
     # objective: the same polynomial integral as x'(w_c Q)x, evaluated through third differences (stable)
