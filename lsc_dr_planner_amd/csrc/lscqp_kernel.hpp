@@ -618,9 +618,12 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     };
 
     // ---- initial slacks / multipliers ----------------------------------------------------------------------
-    // s = max(residual, 1e-2), lambda = 0.03: most rows are far from active at the optimum, and starting their
-    // multipliers small saves ~2 of ~7 iterations on the reference-like workloads (tools/proto_pdip.py sweep)
-    constexpr double LAM0 = 0.03;
+    // Centred start: s = max(residual, 0.1), lambda = mu0 / s with mu0 = 3e-3, i.e. every complementarity product starts
+    // at mu0.  Most rows are far from active at the optimum and get a small multiplier, rows close to their bound get a
+    // large one.  Swept in tools/proto_pdip.py together with the step rule: uniform lambda0 = 1 needed ~7 iterations on
+    // the forest workload, uniform 0.03 ~5 (4.1 with the adaptive step rule), the centred start 3.4 with the same or a
+    // shorter tail (maximum over a 64-QP batch 5-6; smaller mu0 lowers the mean further but lengthens the tail).
+    constexpr double MU0 = 3e-3, S0MIN = 0.1;
     int status = LSCQP_STATUS_ITER_LIMIT;
     double m_tot = 0;
     SD r_s[NSLOT], r_l[NSLOT];  // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
@@ -634,15 +637,15 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double y = row_val(c_, u);
                 const double lo = t_lo[u].get(), hi = t_hi[u].get();
                 if (lo > hi) bad = true;
-                sl0 = fmax(y - lo, 1e-2);
-                sh0 = fmax(hi - y, 1e-2);
-                l0_ = LAM0;
+                sl0 = fmax(y - lo, S0MIN);
+                sh0 = fmax(hi - y, S0MIN);
+                l0_ = 1.0;  // marks an existing row; the multipliers are set below
                 cnt += 2.0;
             }
             t_sl[u].set(sl0);
             t_sh[u].set(sh0);
-            t_ll[u].set(l0_);
-            t_lh[u].set(l0_);
+            t_ll[u].set(l0_ * MU0 / sl0);
+            t_lh[u].set(l0_ * MU0 / sh0);
         }
         const double cx = ll ? c_[lx] : 0.0, cy = ll ? c_[P + lx] : 0.0, cz = (ll && DIM == 3) ? c_[2 * P + lx] : 0.0;
 #pragma unroll
@@ -653,8 +656,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const int e = o * CP + lcp;
                 const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e];
                 if ((nx != 0.0) || (ny != 0.0) || (nz != 0.0)) {
-                    s_init = fmax(nx * cx + ny * cy + nz * cz - Rb[e], 1e-2);
-                    l_init = LAM0;
+                    s_init = fmax(nx * cx + ny * cy + nz * cz - Rb[e], S0MIN);
+                    l_init = MU0 / s_init;
                     cnt += 1.0;
                 }
             }

@@ -73,11 +73,13 @@ def swarm_oracle_inputs(O, sw, b):
     return ag, lsc, off, sfc
 
 
-def kkt_from_primal(O, cls, ag, lsc, sfc, x, act_tols=(1e-7, 1e-6, 1e-5)):
+def kkt_from_primal(O, cls, ag, lsc, sfc, x, act_tols=(1e-7, 1e-6, 1e-5, 1e-4, 1e-3)):
     """KKT residuals of a primal point on the reference's row-for-row model: multipliers by non-negative least
     squares on the rows within act_tol of being active at x (stationarity 2Px+q + Aeq'y + Ga'lam = 0, lam >= 0).
-    Weakly active rows (slack 1e-7 .. 1e-5 with a small multiplier) occur at M = 10 in 3-D, so the active set is tried
-    at several thresholds and the complementarity products lam_i * slack_i of the rows taken in are charged to the
+    An interior-point solution leaves rows with slack s and multiplier lam with s*lam ~ 1e-10 each: a row with slack 3e-5
+    still carries lam ~ 3e-6, which is a stationarity error of that size if the row is left out.  The active set is
+    therefore tried at several thresholds, the least-squares problem carries the complementarity products lam_i * slack_i as extra
+    residuals (so that a row is not handed a multiplier its slack cannot support), and the products are charged to the
     result: returns (max(stationarity, complementarity) scaled by 1+|grad f|_inf, eq violation, ineq violation)."""
     from scipy.optimize import nnls
 
@@ -97,12 +99,15 @@ def kkt_from_primal(O, cls, ag, lsc, sfc, x, act_tols=(1e-7, 1e-6, 1e-5)):
             if np.isfinite(ub[l]) and ub[l] - x[l] < act_tol:
                 e = np.zeros(nv); e[l] = 1; rows.append(e); slack.append(max(ub[l] - x[l], 0.0))
         Ga = np.array(rows).reshape(-1, nv)
+        slack = np.array(slack)
+        ne2 = 2 * Aeq.shape[0]
         # unknowns: y+ , y- (free equality multipliers split), lam >= 0
         B = np.concatenate([Aeq.T, -Aeq.T, Ga.T], axis=1)
-        sol, rn = nnls(B / sc, -g / sc, maxiter=20 * B.shape[1])
+        Caug = np.concatenate([np.zeros((len(slack), ne2)), np.diag(slack)], axis=1)  # lam_i * slack_i -> 0
+        sol, rn = nnls(np.concatenate([B, Caug]) / sc, np.concatenate([-g, np.zeros(len(slack))]) / sc,
+                       maxiter=20 * B.shape[1])
         stat = np.abs(B @ sol + g).max() / sc
-        lam = sol[2 * Aeq.shape[0]:]
-        comp = (lam * np.array(slack)).max() / sc if len(slack) else 0.0
+        comp = (sol[ne2:] * slack).max() / sc if len(slack) else 0.0
         best = min(best, max(stat, comp))
     stat = best
     eqv = np.abs(Aeq @ x - beq).max()

@@ -145,8 +145,8 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     for k in range(dim):  # start: every free control point at c2 of the first segment
         z[k * nzA:(k + 1) * nzA] = cfix[k, 2]
     s = np.maximum(Gz @ z - hz, 0.0)
-    s = np.maximum(s, 1e-2)
-    lam = np.full(mrows, 0.03)
+    s = np.maximum(s, 1e-1)
+    lam = 3e-3 / s  # centred start: every product s*lam = mu0
     gscale = max(1.0, np.abs(gfull).max())
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
