@@ -208,6 +208,21 @@ int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, d
  * neighbour list, radius, downwash and goal read once. */
 int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t n_total);
 
+/* ---- next row of the path: the planner's other CPLEX call -------------------------------
+ *
+ * Replaces GoalOptimizer::solve (reference src/goal_optimizer.cpp:7-70; model :72-147): the one-variable LP
+ *     min t in [0, 1 + 1e-5]   s.t.   n_r . ((g - w) t + w - p_r) - d_r >= 0
+ * over the SFC faces of the last segment (if use_sfc) and the LSC rows (oi, M-1, n) of every obstacle, solved in
+ * closed form on the device.  On entry hdr[q].goal = current_goal_point g and hdr[q].next_waypoint = w; on return
+ * hdr[q].goal = (g - w) t* + w (:55), ready for lscqp_solve_batch*.  rows / row_offsets / sfc exactly as for the solve.
+ * status_out[q] = LSCQP_STATUS_OPTIMAL, or LSCQP_STATUS_INFEASIBLE where the reference throws QPFAILED (goal unchanged).
+ * |g - w| < 1e-5 returns w like the reference (:12-14). */
+int lscqp_optimize_goal_device(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                               const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status_out, void* stream);
+/* Same, HOST pointers, synchronous (hdr is updated in place). */
+int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
+                        const lscqp_box* sfc, int32_t* status_out);
+
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);

@@ -85,6 +85,10 @@ def lib():
         L.lscqp_shift_traj_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_double, vp, vp, vp]
         L.lscqp_generate_lsc_bytes.restype = C.c_int64
         L.lscqp_generate_lsc_bytes.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64]
+        L.lscqp_optimize_goal_device.restype = C.c_int
+        L.lscqp_optimize_goal_device.argtypes = [vp, C.c_int64] + [vp] * 6
+        L.lscqp_optimize_goal.restype = C.c_int
+        L.lscqp_optimize_goal.argtypes = [vp, C.c_int64] + [vp] * 5
         L.lscqp_last_error.restype = C.c_char_p
         L.lscqp_version.restype = C.c_char_p
         _lib = L
@@ -93,7 +97,8 @@ def lib():
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device",
-                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_last_error", "lscqp_version"]
+                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal",
+                    "lscqp_last_error", "lscqp_version"]
 
 
 def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
@@ -189,6 +194,38 @@ class Solver:
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
+
+    # ---- GoalOptimizer::solve in closed form ----------------------------------------
+    def optimize_goal_host(self, hdr, rows=None, row_offsets=None, sfc=None):
+        """hdr["goal"] = current_goal_point on entry; returns (hdr with the optimised goal, status)."""
+        n = len(hdr)
+        hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE).copy()
+        status = np.full(n, -1, dtype=np.int32)
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE).reshape(-1)
+            row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+        if sfc is not None:
+            sfc = np.ascontiguousarray(sfc, dtype=BOX_DTYPE).reshape(-1)
+
+        def p(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+        rc = lib().lscqp_optimize_goal(self._h, n, p(hdr), p(rows), p(row_offsets), p(sfc), p(status))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        return hdr, status
+
+    def optimize_goal_device(self, n, d_hdr, d_rows, d_off, d_sfc, d_status, stream=None):
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        rc = lib().lscqp_optimize_goal_device(self._h, n, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_status), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     # ---- the producer of the rows (SURVEY.md section 8f-1), device pointers -----------------------------------
     def generate_lsc_device(self, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal, d_rows,

@@ -58,6 +58,11 @@ def build(force=False, verbose=False, jobs=None):
     api_src = os.path.join(CSRC, "lscqp_api.hip")
     if force or _newer(api_o, hdrs + [api_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
+    goal_o = os.path.join(OBJ, "lscgoal.o")
+    objs.append(goal_o)
+    goal_src = os.path.join(CSRC, "lscgoal.hip")
+    if force or _newer(goal_o, hdrs + [goal_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", goal_src, "-o", goal_o])
     gen_o = os.path.join(OBJ, "lscgen.o")
     objs.append(gen_o)
     gen_src = os.path.join(CSRC, "lscgen.hip")

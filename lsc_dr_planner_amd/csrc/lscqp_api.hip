@@ -22,6 +22,8 @@ LSCQP_INSTANCES(LSCQP_DECL)
 extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
                                        const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
                                        const double* d_goal, lscqp_row* d_rows_out, void* stream);
+extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                               const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
 extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, int shift, double z_2d, const double* d_x_prev, double* d_traj,
                                      void* stream);
 
@@ -220,6 +222,70 @@ int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs
     return n_agents * (int64_t)n_obs * P * 32      /* rows written */
            + n_total * (P * 24 + 16)               /* control points, radius, downwash */
            + n_agents * ((int64_t)n_obs * 4 + 24); /* neighbour ids, goal */
+}
+
+int lscqp_optimize_goal_device(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                               const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status_out, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return LSCQP_OK;
+    if (!d_hdr || !d_status_out || (h->desc.use_sfc && !d_sfc)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_goal_raw_(h->desc.M, h->desc.dim, h->desc.use_sfc, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status_out, stream);
+}
+
+int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
+                        const lscqp_box* sfc, int32_t* status_out) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return LSCQP_OK;
+    if (!hdr || !status_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    int n_obs_max = 0;
+    for (int64_t q = 0; q < n; q++) {
+        if (hdr[q].n_obs < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative n_obs");
+        if (hdr[q].n_obs > n_obs_max) n_obs_max = hdr[q].n_obs;
+    }
+    if (n_obs_max > 0 && (!rows || !row_offsets)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null row buffer");
+    if (h->desc.use_sfc && !sfc) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null sfc buffer");
+    const size_t n_rows = n_obs_max > 0 ? (size_t)row_offsets[n] : 0;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(sizeof(lscqp_row) * n_rows), b_off = al(sizeof(uint64_t) * (n + 1)),
+                 b_sfc = al(sizeof(lscqp_box) * n * h->desc.M), b_st = al(sizeof(int32_t) * n);
+    const size_t total = b_hdr + b_rows + b_off + b_sfc + b_st;
+    if (total > h->d_cap) {
+        if (h->d_buf) (void)hipFree(h->d_buf);
+        h->d_buf = nullptr;
+        h->d_cap = 0;
+        if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
+        h->d_cap = total;
+    }
+    char* p = (char*)h->d_buf;
+    lscqp_header* d_hdr = (lscqp_header*)p; p += b_hdr;
+    lscqp_row* d_rows = (lscqp_row*)p; p += b_rows;
+    uint64_t* d_off = (uint64_t*)p; p += b_off;
+    lscqp_box* d_sfc = (lscqp_box*)p; p += b_sfc;
+    int32_t* d_st = (int32_t*)p;
+#define LSCQP_CK(call)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(LSCQP_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
+    } while (0)
+    LSCQP_CK(hipMemcpy(d_hdr, hdr, sizeof(lscqp_header) * n, hipMemcpyHostToDevice));
+    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, sizeof(lscqp_row) * n_rows, hipMemcpyHostToDevice));
+    if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
+    if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
+    int rc = lscqp_optimize_goal_device(h, n, d_hdr, d_rows, d_off, d_sfc, d_st, nullptr);
+    if (rc != LSCQP_OK) return rc;
+    LSCQP_CK(hipDeviceSynchronize());
+    LSCQP_CK(hipMemcpy(hdr, d_hdr, sizeof(lscqp_header) * n, hipMemcpyDeviceToHost));
+    LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+#undef LSCQP_CK
+    return LSCQP_OK;
 }
 
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs) {

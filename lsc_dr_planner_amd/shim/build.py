@@ -8,7 +8,8 @@ EXE = os.path.join(HERE, "shim_test")
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, "src", "traj_optimizer.cpp"), os.path.join(HERE, "test", "shim_test.cpp")]
+    srcs = [os.path.join(HERE, "src", "traj_optimizer.cpp"), os.path.join(HERE, "src", "goal_optimizer.cpp"),
+            os.path.join(HERE, "test", "shim_test.cpp")]
     deps = srcs + [os.path.join(HERE, "include", f) for f in os.listdir(os.path.join(HERE, "include"))] + [
         os.path.join(ROOT, "include", "lscqp.h")]
     lib = os.path.join(os.path.dirname(HERE), "liblscqp.so")

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <goal_optimizer.hpp>
 #include <traj_optimizer.hpp>
 
 using namespace DynamicPlanning;
@@ -200,12 +201,49 @@ static int scenario_host() {
     return 0;
 }
 
+// GoalOptimizer of forest10_10's agent 1: waypoint x = 2.5, current goal x = 3.0, the SFC's -x face
+// at 2.55 -> goal x = 2.55; then an LSC row that cuts the whole segment off -> QPFAILED like the reference
+static int scenario_goal() {
+    Param param;
+    param.world_dimension = 2;
+    param.M = 10;
+    param.world_z_2d = 0.6;
+    param.world_use_octomap = true;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    GoalOptimizer gopt(param, mission);
+    CollisionConstraints cons(param, mission);
+    cons.initializeLSC(1);
+    for (int m = 0; m < param.M; m++) cons.setSFC(m, Box(point3d(2.55f, -5, 0), point3d(5, 5, 2.5f)));
+    Agent a = make_agent(point3d(3, 2.5f, 0.6f), point3d(3.0f, 2.5f, 0.6f), point3d(2.5f, 2.5f, 0.6f));
+    // obstacle far behind: its row n = (+1,0,0), p = (0,2.5), d = 1 holds on the whole segment -> the SFC face decides
+    std::vector<double> d(param.n + 1, 1.0);
+    points_t obs(param.n + 1, point3d(0, 2.5f, 0.6f));
+    for (int m = 0; m < param.M; m++) cons.setLSC(0, m, obs, point3d(1, 0, 0), d);
+    point3d g = gopt.solve(a, cons, point3d(3.0f, 2.5f, 0.6f), point3d(2.5f, 2.5f, 0.6f));
+    point3d same = gopt.solve(a, cons, point3d(2.5f, 2.5f, 0.6f), point3d(2.5f, 2.5f, 0.6f));
+    // now the obstacle row demands x >= 3.5: infeasible on [2.5, 3.0]
+    std::vector<double> d2(param.n + 1, 3.5);
+    for (int m = 0; m < param.M; m++) cons.setLSC(0, m, obs, point3d(1, 0, 0), d2);
+    const char* thrown = "nothing";
+    try {
+        gopt.solve(a, cons, point3d(3.0f, 2.5f, 0.6f), point3d(2.5f, 2.5f, 0.6f));
+    } catch (PlanningReport r) {
+        thrown = r == PlanningReport::QPFAILED ? "QPFAILED" : "other";
+    }
+    printf("{\"scenario\": \"goal\", \"goal\": [%.9g, %.9g, %.9g], \"same\": [%.9g, %.9g, %.9g], \"thrown\": \"%s\"}\n", g.x(), g.y(),
+           g.z(), same.x(), same.y(), same.z(), thrown);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string s = argc > 1 ? argv[1] : "host";
     if (s == "host") return scenario_host();
     if (s == "kat") return scenario_kat(true);
     if (s == "pair") return scenario_pair();
     if (s == "infeasible") return scenario_infeasible();
-    fprintf(stderr, "usage: shim_test host|kat|pair|infeasible\n");
+    if (s == "goal") return scenario_goal();
+    fprintf(stderr, "usage: shim_test host|kat|pair|infeasible|goal\n");
     return 2;
 }

@@ -118,6 +118,12 @@ void orc_generate_lsc_pair(int M, int dim, const double* own, const double* obs,
 void orc_generate_lsc(int M, int dim, int n_agents, int n_obs, int first_agent, const double* traj, const int* neighbours,
                       const double* radius, const double* downwash, const double* goal, orc_lsc* out);
 
+/* ---- goal LP (oracle/lscgoal_oracle.c; reference src/goal_optimizer.cpp:72-147) ---- */
+int orc_goal_rows(const orc_class* cls, const double* g, const double* w, int n_obs, const orc_lsc* lsc, const orc_box* sfc_last,
+                  double* a, double* c);
+int orc_goal_opt(const orc_class* cls, const double* g, const double* w, int n_obs, const orc_lsc* lsc, const orc_box* sfc_last,
+                 double* goal_out, double* t_out);
+
 #ifdef __cplusplus
 }
 #endif

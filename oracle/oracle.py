@@ -53,7 +53,7 @@ _REFERENCE = "/root/reference"
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscqp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscqp_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
@@ -115,6 +115,10 @@ def lib():
         _lib.orc_hull_closest_point.restype = C.c_double
         _lib.orc_hull_closest_point.argtypes = [dp, C.c_int, dp]
         _lib.orc_generate_lsc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_void_p]
+        _lib.orc_goal_rows.restype = C.c_int
+        _lib.orc_goal_rows.argtypes = [C.POINTER(OrcClass), dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, dp]
+        _lib.orc_goal_opt.restype = C.c_int
+        _lib.orc_goal_opt.argtypes = [C.POINTER(OrcClass), dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_double)]
         _lib.orc_solve_batch.restype = C.c_int
         _lib.orc_solve_batch.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
@@ -257,3 +261,29 @@ def generate_lsc(traj, neighbours, radius, downwash, goal, dim=3, first_agent=0)
     lib().orc_generate_lsc(M, dim, n_agents, n_obs, first_agent, _dp(traj), nb.ctypes.data_as(C.POINTER(C.c_int)), _dp(r),
                            _dp(dw), _dp(g), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def goal_rows(cls, goal, next_waypoint, lsc=None, sfc_last=None):
+    """Rows a t + c >= 0 of GoalOptimizer::populatebyrow (reference src/goal_optimizer.cpp:118-155), in its order."""
+    g = np.ascontiguousarray(goal, dtype=np.float64)
+    w = np.ascontiguousarray(next_waypoint, dtype=np.float64)
+    n_obs = 0 if lsc is None else lsc.shape[0]
+    lscc = None if lsc is None else np.ascontiguousarray(lsc, dtype=LSC_DTYPE)
+    box = None if sfc_last is None else np.ascontiguousarray(sfc_last, dtype=BOX_DTYPE).reshape(1)
+    a = np.zeros(2 * cls.dim + n_obs + 2)
+    c = np.zeros_like(a)
+    nr = lib().orc_goal_rows(C.byref(cls), _dp(g), _dp(w), n_obs, _vp(lscc), _vp(box), _dp(a), _dp(c))
+    return a[:nr], c[:nr]
+
+
+def goal_opt(cls, goal, next_waypoint, lsc=None, sfc_last=None):
+    """GoalOptimizer::solve restated: returns (status 0/1, optimised goal (3,), t)."""
+    g = np.ascontiguousarray(goal, dtype=np.float64)
+    w = np.ascontiguousarray(next_waypoint, dtype=np.float64)
+    n_obs = 0 if lsc is None else lsc.shape[0]
+    lscc = None if lsc is None else np.ascontiguousarray(lsc, dtype=LSC_DTYPE)
+    box = None if sfc_last is None else np.ascontiguousarray(sfc_last, dtype=BOX_DTYPE).reshape(1)
+    out = np.zeros(3)
+    t = C.c_double(0)
+    st = lib().orc_goal_opt(C.byref(cls), _dp(g), _dp(w), n_obs, _vp(lscc), _vp(box), _dp(out), C.byref(t))
+    return st, out, t.value

@@ -90,3 +90,14 @@ def test_shim_matches_oracle(shim_exe, oracle):
 @pytest.mark.gpu
 def test_qpfailed_is_thrown(shim_exe):
     assert run(shim_exe, "infeasible")[0]["thrown"] == "QPFAILED"
+
+
+@pytest.mark.gpu
+def test_goal_optimizer_through_the_shim(shim_exe):
+    """GoalOptimizer (reference include/goal_optimizer.hpp surface) over lscqp_optimize_goal: the forest10_10 agent-1 case of
+    the reference log (goal x = 2.55 from the SFC face), goal == waypoint, and QPFAILED when the
+    rows cut the whole segment off (reference src/goal_optimizer.cpp:57-69)."""
+    r = run(shim_exe, "goal")[0]
+    assert np.allclose(r["goal"], [np.float32(2.55), 2.5, np.float32(0.6)], rtol=0, atol=1e-6)
+    assert np.allclose(r["same"], [2.5, 2.5, np.float32(0.6)], rtol=0, atol=1e-7)
+    assert r["thrown"] == "QPFAILED"
