@@ -223,6 +223,19 @@ int lscqp_optimize_goal_device(lscqp_handle h, int64_t n, lscqp_header* d_hdr, c
 int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
                         const lscqp_box* sfc, int32_t* status_out);
 
+/* ---- next row of the path: what the planner does with a solved trajectory ----------------
+ *
+ * Replaces, for a batch, TrajPlanner::isSolValid (reference src/traj_planner.cpp:990-1045: SFC containment of the control
+ * points, velocity / acceleration within 1 % of the limits at the simulation step), Trajectory::getStateAt
+ * (src/trajectory.cpp:156-170) and AgentManager::doStep (src/agent_manager.cpp:29-50: the agent's next state is the
+ * trajectory's state at time_step).  Control points are first truncated to float32 like TrajOptResult::desired_traj
+ * (src/traj_optimizer.cpp:71-83); dim == 2: z := z_2d.  DEVICE pointers, asynchronous on `stream`.
+ *   d_x [n][dim*M*(n+1)]   x_out of the solve        d_hdr [n]  (max_vel / max_acc are read from it)      d_sfc [n*M] or NULL
+ *   d_valid_out [n]  1 = isSolValid would return true        d_state_out [n][9]  position, velocity, acceleration */
+int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, double z_2d, const double* d_x,
+                               const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid_out, double* d_state_out,
+                               void* stream);
+
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);

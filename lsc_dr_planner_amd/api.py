@@ -89,6 +89,8 @@ def lib():
         L.lscqp_optimize_goal_device.argtypes = [vp, C.c_int64] + [vp] * 6
         L.lscqp_optimize_goal.restype = C.c_int
         L.lscqp_optimize_goal.argtypes = [vp, C.c_int64] + [vp] * 5
+        L.lscqp_validate_step_device.restype = C.c_int
+        L.lscqp_validate_step_device.argtypes = [vp, C.c_int64, C.c_double, C.c_double] + [vp] * 6
         L.lscqp_last_error.restype = C.c_char_p
         L.lscqp_version.restype = C.c_char_p
         _lib = L
@@ -97,7 +99,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device",
-                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal",
+                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device",
                     "lscqp_last_error", "lscqp_version"]
 
 
@@ -224,6 +226,20 @@ class Solver:
             return None if t is None else C.c_void_p(t.data_ptr())
 
         rc = lib().lscqp_optimize_goal_device(self._h, n, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_status), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    # ---- isSolValid + getStateAt + doStep -------------------------------------------
+    def validate_step_device(self, n, time_step, d_x, d_hdr, d_sfc, d_valid, d_state, z_2d=1.0, stream=None):
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        rc = lib().lscqp_validate_step_device(self._h, n, float(time_step), float(z_2d), p(d_x), p(d_hdr), p(d_sfc), p(d_valid),
+                                              p(d_state), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

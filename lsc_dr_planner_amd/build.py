@@ -58,6 +58,11 @@ def build(force=False, verbose=False, jobs=None):
     api_src = os.path.join(CSRC, "lscqp_api.hip")
     if force or _newer(api_o, hdrs + [api_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
+    post_o = os.path.join(OBJ, "lscpost.o")
+    objs.append(post_o)
+    post_src = os.path.join(CSRC, "lscpost.hip")
+    if force or _newer(post_o, hdrs + [post_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", post_src, "-o", post_o])
     goal_o = os.path.join(OBJ, "lscgoal.o")
     objs.append(goal_o)
     goal_src = os.path.join(CSRC, "lscgoal.hip")

@@ -24,6 +24,9 @@ extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t
                                        const double* d_goal, lscqp_row* d_rows_out, void* stream);
 extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
+extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const double* d_x,
+                                        const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid, double* d_state,
+                                        void* stream);
 extern "C" int lscqp_shift_traj_raw_(int M, int dim, int64_t n, int shift, double z_2d, const double* d_x_prev, double* d_traj,
                                      void* stream);
 
@@ -286,6 +289,20 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
     LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
 #undef LSCQP_CK
     return LSCQP_OK;
+}
+
+int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, double z_2d, const double* d_x,
+                               const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid_out, double* d_state_out,
+                               void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !(time_step >= 0)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size or time");
+    if (n == 0) return LSCQP_OK;
+    if (!d_x || !d_hdr || !d_valid_out || !d_state_out || (h->desc.use_sfc && !d_sfc)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_validate_step_raw_(h->desc.M, h->desc.dim, h->desc.use_sfc, h->desc.dt, n, time_step, z_2d, d_x, d_hdr, d_sfc, d_valid_out,
+                                    d_state_out, stream);
 }
 
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs) {

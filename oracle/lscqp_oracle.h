@@ -124,6 +124,10 @@ int orc_goal_rows(const orc_class* cls, const double* g, const double* w, int n_
 int orc_goal_opt(const orc_class* cls, const double* g, const double* w, int n_obs, const orc_lsc* lsc, const orc_box* sfc_last,
                  double* goal_out, double* t_out);
 
+/* ---- post-solve checks (oracle/lscpost_oracle.c; reference src/traj_planner.cpp:990-1045, src/agent_manager.cpp:29-50) ---- */
+int orc_validate_step(const orc_class* c, const orc_agent* ag, const orc_box* sfc, const double* x, double time_step, double z_2d,
+                      double* state9);
+
 #ifdef __cplusplus
 }
 #endif

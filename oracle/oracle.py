@@ -53,7 +53,7 @@ _REFERENCE = "/root/reference"
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscqp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscqp_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
@@ -119,6 +119,8 @@ def lib():
         _lib.orc_goal_rows.argtypes = [C.POINTER(OrcClass), dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, dp]
         _lib.orc_goal_opt.restype = C.c_int
         _lib.orc_goal_opt.argtypes = [C.POINTER(OrcClass), dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_double)]
+        _lib.orc_validate_step.restype = C.c_int
+        _lib.orc_validate_step.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, dp, C.c_double, C.c_double, dp]
         _lib.orc_solve_batch.restype = C.c_int
         _lib.orc_solve_batch.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
@@ -287,3 +289,14 @@ def goal_opt(cls, goal, next_waypoint, lsc=None, sfc_last=None):
     t = C.c_double(0)
     st = lib().orc_goal_opt(C.byref(cls), _dp(g), _dp(w), n_obs, _vp(lscc), _vp(box), _dp(out), C.byref(t))
     return st, out, t.value
+
+
+def validate_step(cls, agent, sfc, x, time_step, z_2d=1.0):
+    """isSolValid + doStep restated (reference src/traj_planner.cpp:990-1045, src/agent_manager.cpp:29-50):
+    returns (valid 0/1, state (9,) = position, velocity, acceleration at time_step)."""
+    ag = np.ascontiguousarray(agent, dtype=AGENT_DTYPE).reshape(1)
+    box = None if sfc is None else np.ascontiguousarray(sfc, dtype=BOX_DTYPE).reshape(-1)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    st = np.zeros(9)
+    ok = lib().orc_validate_step(C.byref(cls), _vp(ag), _vp(box), _dp(xx), float(time_step), float(z_2d), _dp(st))
+    return ok, st
