@@ -278,6 +278,9 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     double* const Rb = Rnz + (NROW + 1);
 
     const int lane = threadIdx.x;  // thread of the QP's workgroup, 0 .. 64*W-1 ("lane" throughout)
+#ifdef LSCQP_PHASE_TIMING
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
     // Hand-off through LDS between the lanes of the QP: see LSCQP_WAVE_LDS_SYNC for W = 1; a real barrier for W = 2.
     // Every branch around a BLOCK_SYNC is workgroup-uniform (conditions come out of block reductions / LDS broadcasts).
 #define LSCQP_BLOCK_SYNC()                       \
@@ -454,6 +457,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #pragma unroll
         for (int cidx = 0; cidx < NZ; cidx++) hrow0[cidx] = 0.0;  // entries outside the lane's pattern stay zero
     }
+    LSCQP_T(11);  // prologue a: header, control points, scratch rows
     // ---- stage LSC row constants: HBM (AoS 32 B, [oi][m][i]) -> LDS SoA [oi][cp], translated to the agent origin --
     {
         const lscqp_row* R = rows + row_offsets[q];
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         }
     }
     __syncthreads();
+    LSCQP_T(12);  // prologue b: row staging
 
     // ---- two-sided rows, one type per slot (registers) ----------------------------------------------------
     // slot layout: [0,SI) interval | [SI,SI+SV) velocity | [..,+SA) acceleration | [..,+SC) communication pair
@@ -617,6 +622,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         return C::NOM;
     };
 
+    LSCQP_T(13);  // prologue c: two-sided row setup
     // ---- initial slacks / multipliers ----------------------------------------------------------------------
     // Centred start: s = max(residual, 0.1), lambda = mu0 / s with mu0 = 3e-3, i.e. every complementarity product starts
     // at mu0.  Most rows are far from active at the optimum and get a small multiplier, rows close to their bound get a
@@ -644,8 +650,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             }
             t_sl[u].set(sl0);
             t_sh[u].set(sh0);
-            t_ll[u].set(l0_ * MU0 / sl0);
-            t_lh[u].set(l0_ * MU0 / sh0);
+            t_ll[u].set(l0_ * MU0 * fast_rcp(sl0));  // (an IEEE fp64 division is ~30 instructions; 22 of them per lane here)
+            t_lh[u].set(l0_ * MU0 * fast_rcp(sh0));
         }
         const double cx = ll ? c_[lx] : 0.0, cy = ll ? c_[P + lx] : 0.0, cz = (ll && DIM == 3) ? c_[2 * P + lx] : 0.0;
 #pragma unroll
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e];
                 if ((nx != 0.0) || (ny != 0.0) || (nz != 0.0)) {
                     s_init = fmax(nx * cx + ny * cy + nz * cz - Rb[e], S0MIN);
-                    l_init = MU0 / s_init;
+                    l_init = MU0 * fast_rcp(s_init);
                     cnt += 1.0;
                 }
             }
@@ -732,9 +738,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     const double tol = cls.tol;
     const bool comm_on_k = cls.comm_range > 0;
     // (row of the scratch matrix a lane assembles into: non-z lanes share one dummy row, index NZ, that is never read)
-#ifdef LSCQP_PHASE_TIMING
-    unsigned long long tprev_ = __builtin_readcyclecounter();
-#endif
+    LSCQP_T(15);  // prologue d: start point, objective lambdas
 
     // THE LOOP BODY IS WRITTEN WITHOUT DIVERGENT REGIONS.  Every lane owns persistent state in registers (matrix row,
     // row slacks/multipliers); hipcc spills such state around large divergent regions with exec-masked stores, so the
