@@ -216,9 +216,10 @@ def test_device_resident_path_and_batch_of_one(api, oracle, torch_cuda):
         assert np.array_equal(one["x"][0], ref["x"][q])
 
 
-@pytest.mark.parametrize("N,M,dim,n_obs,style", [(512, 6, 3, 20, "maze"), (4096, 5, 3, 20, "forest")])
+@pytest.mark.parametrize("N,M,dim,n_obs,style", [(512, 6, 3, 20, "maze"), (4096, 5, 3, 20, "forest"), (128, 10, 3, 40, "forest")])
 def test_full_size_properties(api, oracle, torch_cuda, N, M, dim, n_obs, style):
-    """BASELINE configs[2] / configs[4] shapes (per GPU): properties that do not need the oracle on every instance."""
+    """BASELINE configs[2] / configs[4] / configs[3] shapes (per GPU: 512, 4096 and 1024/8 agents): properties that do not
+    need the oracle on every instance."""
     from lsc_dr_planner_amd import synth
 
     sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=100 + N, style=style)
@@ -229,7 +230,8 @@ def test_full_size_properties(api, oracle, torch_cuda, N, M, dim, n_obs, style):
         hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
         G = sol.solve_host(hdr, rows, off, sfc)
         assert (G["status"] == 0).all(), np.bincount(G["status"], minlength=4)
-        assert G["info"]["res_primal"].max() <= 1e-9 and G["info"]["res_dual"].max() <= 1e-8 and G["info"]["gap"].max() <= 1e-9
+        rd_bar = 1e-8 if dim * (3 * M - 2) <= 64 else 1e-6  # rounding floor of the nz = 84 class, see test_swarm_parity
+        assert G["info"]["res_primal"].max() <= 1e-9 and G["info"]["res_dual"].max() <= rd_bar and G["info"]["gap"].max() <= 1e-9
         x = G["x"].reshape(N, dim, M, 6)
         # 1. eliminated equalities hold: initial state, C0/C1/C2 joins, end stop (src/traj_optimizer.cpp:318-368,502-511)
         assert np.abs(x[:, :, 0, 0] - b["p0"][:, :dim]).max() < 1e-12
