@@ -1164,7 +1164,66 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
 #else
 #define LSCQP_FACTOR_ENTRY(j) A[j]
 #endif
-            auto solve = [&](double b) -> double {
+            // nz > 64 (two wavefronts hold the rows): blocked triangular solves.  Rows 0..63 live in wavefront 0, the rest
+            // in wavefront 1; inside a wavefront the column-oriented substitution broadcasts with v_readlane as in the
+            // one-wavefront case, and the coupling between the two row blocks is ONE hand-off through LDS per
+            // direction (2 barriers per solve instead of one per column: 168 -> 2).  The branches on the wavefront id
+            // are uniform (scalar), so no lane-masked region is created.
+            auto solve_blocked = [&](double b) __attribute__((always_inline)) -> double {  // (called twice: must not become a real call)
+                const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
+                int ll_ = lane & 63;
+                asm volatile("" : "+v"(ll_));
+                constexpr int N1 = NZ - 64;  // rows of the second block
+                // ---- forward: L w = b (unit lower) ----
+                if (wv == 0) {
+                    static_for<0, 64>([&](auto Jc) {
+                        constexpr int j = decltype(Jc)::value;
+                        const double wj = bcast(b, j);
+                        b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
+                    });
+                    col_[ll_] = b;  // w_0 .. w_63
+                }
+                __syncthreads();
+                if (wv == 1) {
+                    static_for<0, 64>([&](auto Jc) {  // L21 w_1 (rows >= 64: every entry is below the diagonal)
+                        constexpr int j = decltype(Jc)::value;
+                        b = fma(-A[j], col_[j], b);
+                    });
+                    static_for<0, N1>([&](auto Jc) {
+                        constexpr int jj = decltype(Jc)::value;
+                        const double wj = bcast(b, jj);
+                        b = fma(-((ll_ > jj) ? A[64 + jj] : 0.0), wj, b);
+                    });
+                }
+                // ---- backward: (D L') x = w; row i of the upper factor is A[j > i] of lane i ----
+                asm volatile("" : "+v"(ll_));
+                double x = 0;
+                if (wv == 1) {
+                    static_for<0, N1>([&](auto Jc) {
+                        constexpr int jj = N1 - 1 - decltype(Jc)::value;
+                        const double xj = bcast(b * dinv_own, jj);
+                        x = (ll_ == jj) ? xj : x;
+                        b = fma(-((ll_ < jj) ? A[64 + jj] : 0.0), xj, b);
+                    });
+                    col_[64 + ll_] = x;  // x_64 .. (lanes beyond the system carry zeros)
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    static_for<0, N1>([&](auto Jc) {  // U12 x_2 (rows < 64 <= column)
+                        constexpr int jj = decltype(Jc)::value;
+                        b = fma(-A[64 + jj], col_[64 + jj], b);
+                    });
+                    static_for<0, 64>([&](auto Jc) {
+                        constexpr int j = 63 - decltype(Jc)::value;
+                        const double xj = bcast(b * dinv_own, j);
+                        x = (ll_ == j) ? xj : x;
+                        b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);
+                    });
+                }
+                return x;
+            };
+            auto solve = [&](double b) __attribute__((always_inline)) -> double {
+                if constexpr (W > 1 && NZ > 64) return solve_blocked(b);
                 int ls = (NZ <= 64) ? (lane & 63) : lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
                 const double* const hr = &Hs[(ls < NZ ? ls : NZ) * LDH];

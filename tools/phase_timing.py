@@ -7,7 +7,7 @@ SRC = os.path.join(ROOT, "lsc_dr_planner_amd", "csrc")
 OUT = "/tmp/liblscqp_prof.so"
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 xflags = [a for a in sys.argv[1:] if a.startswith("-D")]
-M, D, N, NOBS, NSLOT = [int(v) for v in (args + ["5", "3", "64", "20", "10"][len(args):])]
+M, D, N, NOBS, NSLOT, W = [int(v) for v in (args + ["5", "3", "64", "20", "10", "1"][len(args):])]
 drv = r'''
 #include "lscqp_kernel.hpp"
 extern "C" int lscqp_dbg_read(unsigned long long* out, int reset) {
@@ -19,7 +19,7 @@ extern "C" int lscqp_dbg_read(unsigned long long* out, int reset) {
 if not os.path.exists(OUT) or "--rebuild" in sys.argv or True:
     open("/tmp/prof_drv.hip", "w").write(drv)
     # single TU so that the __device__ symbol is shared: include the instance + api sources
-    tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT) + drv
+    tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#define LSCQP_W %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT, W) + drv
     open(os.path.join("/tmp", "prof_tu.hip"), "w").write(tu)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector",
                            "-DLSCQP_PHASE_TIMING", "-I", SRC, "/tmp/prof_tu.hip", "-o", OUT] + xflags, stderr=subprocess.DEVNULL)
@@ -48,7 +48,7 @@ cls = DevClass(); cls.dt = 0.2; cls.w_c = 0.01; cls.w_t = 1.0; cls.comm_range = 
 for k in range(3): cls.world_min[k] = sw.world_min[k]; cls.world_max[k] = sw.world_max[k]
 cls.q2s = 2 * 0.01 * 0.2 ** -5
 cls.tol = 1e-10; cls.max_iter = 60; cls.use_sfc = 1; cls.n_obs_max = sw.n_obs
-fn = getattr(L, "lscqp_launch_%d_%d_1_%d_1" % (M, D, NSLOT))
+fn = getattr(L, "lscqp_launch_%d_%d_1_%d_%d" % (M, D, NSLOT, W))
 fn.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
 def launch():
     rc = fn(C.byref(cls), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), dx.data_ptr(), dob.data_ptr(), dst.data_ptr(), dinfo.data_ptr(), None)
