@@ -44,32 +44,37 @@ namespace {
 
 struct Inst {
     int M, dim, es, max_obs, waves;
+    size_t lds;  // bytes of LDS per workgroup
     lscqp::launch_fn fn;
 };
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
-#define LSCQP_ROW(M, D, E, S, W) {M, D, E, max_obs_of(M, S, W), W, lscqp_launch_##M##_##D##_##E##_##S##_##W},
+#define LSCQP_ROW(M, D, E, S, W) \
+    {M, D, E, max_obs_of(M, S, W), W, lscqp::Cfg<M, D, (E != 0), S, W>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
 
 // Instance of the shape that accommodates n_obs obstacles per agent; nullptr if none.
-// Launch policy: a batch small enough to leave SIMDs idle (n <= 2 x CUs: at most two QPs per CU) takes a
-// two-wavefront instance when the shape has one -- the row passes of a QP then run on two SIMDs; larger batches
-// take one wavefront per QP, which is what fills the chip (4 QPs per CU).  Within a wave count: smallest capacity.
+// Launch policy: a batch small enough to leave SIMDs idle (n <= 2 x CUs: at most two QPs per CU) takes the instance
+// with the most wavefronts per QP the shape has -- the row passes of a QP then run on several SIMDs; larger batches take
+// the fewest wavefronts per QP, which is what fills the chip (4 QPs per CU) -- unless the instance's LDS footprint admits
+// only one workgroup per CU anyway (the nz = 84 class): then more wavefronts are free.  Within a wave count: smallest
+// capacity.
 const Inst* find_instance(int M, int dim, int es, int n_obs, int64_t n, int n_cu) {
     const Inst* best = nullptr;
     const bool small = n <= 2 * (int64_t)n_cu;
     // testing knob: LSCQP_WAVES=1|2 pins the wavefront count (every compiled instance has to be reachable by the tests)
     const char* pin = getenv("LSCQP_WAVES");
-    const int pin_w = (pin && (pin[0] == '1' || pin[0] == '2') && pin[1] == 0) ? pin[0] - '0' : 0;
+    const int pin_w = (pin && (pin[0] == '1' || pin[0] == '2' || pin[0] == '4') && pin[1] == 0) ? pin[0] - '0' : 0;
     for (const Inst& i : kInst) {
         if (!(i.M == M && i.dim == dim && i.es == es && i.max_obs >= n_obs)) continue;
         if (pin_w && i.waves != pin_w) continue;
         bool better = !best;
         if (best) {
+            const bool one_wg_per_cu = i.lds > lscqp::kMaxLdsBytes / 2 && best->lds > lscqp::kMaxLdsBytes / 2;
             if (i.waves != best->waves)
-                better = small ? (i.waves > best->waves) : (i.waves < best->waves);
+                better = (small || one_wg_per_cu) ? (i.waves > best->waves) : (i.waves < best->waves);
             else
                 better = i.max_obs < best->max_obs;
         }

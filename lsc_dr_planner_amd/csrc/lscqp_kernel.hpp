@@ -226,7 +226,7 @@ struct Cfg {
     static constexpr int LDH = NZ | 1;
     static_assert(NZ <= T, "lane-per-row kernel needs dim*(3M-2) <= 64*W");
     static_assert(CP <= T, "6M-3 <= 64*W");
-    static_assert(W == 1 || W == 2, "one or two wavefronts per QP (four measured slower than two: 0.167 vs 0.158 ms per 64-QP batch)");
+    static_assert(W == 1 || W == 2 || W == 4, "1, 2 or 4 wavefronts per QP");
     static_assert(M >= 2, "the reference assumes M >= 2 (src/traj_optimizer.cpp:341-352)");
     // LDS carve (in doubles)
     static constexpr int o_c = 0;               // control points (translated)
