@@ -32,30 +32,50 @@ __device__ __forceinline__ double dot(P3 a, P3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ P3 cross(P3 a, P3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 __device__ __forceinline__ P3 axpy(P3 a, double t, P3 b) { return {a.x + t * b.x, a.y + t * b.y, a.z + t * b.z}; }
 
-// closest point to the origin on conv{p[0..5]}: 6 vertices, 15 edges, 20 triangles, then a supporting-plane test that
-// decides whether the origin is inside (distance 0)
+// 1/d to full fp64 precision: v_rcp_f64 + two Newton steps (5 instructions instead of an IEEE division sequence)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// Closest point to the origin on conv{p[0..5]}: 6 vertices, 15 edges, 20 triangles, then a supporting-plane test that
+// decides whether the origin is inside (distance 0).  Everything is evaluated on the Gram matrix G_ij = p_i . p_j (21
+// dot products, computed once): an edge or triangle candidate then costs a dozen scalar operations instead of vector
+// arithmetic, and only the winner's barycentric weights are turned back into a point.
 __device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
-    double best = 1e300;
-    P3 bp = {0, 0, 0};
-    auto consider = [&](P3 q, bool ok) {
-        const double d2 = dot(q, q);
+    double G[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+            G[i][j] = dot(p[i], p[j]);
+            G[j][i] = G[i][j];
+        }
+    double best = 1e300;  // squared distance of the best candidate a + u (b - a) + v (c - a)
+    int bi = 0, bj = 0, bl = 0;
+    double bu = 0, bv = 0;
+    auto consider = [&](double d2, bool ok, int i, int j, int l, double u, double v) {
         const bool take = ok && d2 < best;
         best = take ? d2 : best;
-        bp.x = take ? q.x : bp.x;
-        bp.y = take ? q.y : bp.y;
-        bp.z = take ? q.z : bp.z;
+        bi = take ? i : bi;
+        bj = take ? j : bj;
+        bl = take ? l : bl;
+        bu = take ? u : bu;
+        bv = take ? v : bv;
     };
 #pragma unroll
-    for (int i = 0; i < 6; i++) consider(p[i], true);
+    for (int i = 0; i < 6; i++) consider(G[i][i], true, i, i, i, 0.0, 0.0);
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = i + 1; j < 6; j++) {
-            const P3 ab = sub(p[j], p[i]);
-            const double den = dot(ab, ab);
+            const double den = G[i][i] - 2.0 * G[i][j] + G[j][j];  // |b - a|^2
+            const double r1 = G[i][i] - G[i][j];                   // -a . (b - a)
             const bool ok = den > 1e-18;
-            const double t = -dot(p[i], ab) / (ok ? den : 1.0);
-            consider(axpy(p[i], t, ab), ok && t >= 0.0 && t <= 1.0);
+            const double t = r1 * fast_rcp(ok ? den : 1.0);
+            consider(G[i][i] - t * r1, ok && t >= 0.0 && t <= 1.0, i, j, i, t, 0.0);
         }
 #pragma unroll
     for (int i = 0; i < 6; i++)
@@ -63,21 +83,34 @@ __device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
         for (int j = i + 1; j < 6; j++)
 #pragma unroll
             for (int l = j + 1; l < 6; l++) {
-                const P3 e1 = sub(p[j], p[i]), e2 = sub(p[l], p[i]);
-                const double g11 = dot(e1, e1), g12 = dot(e1, e2), g22 = dot(e2, e2);
-                const double r1 = -dot(p[i], e1), r2 = -dot(p[i], e2);
+                const double g11 = G[j][j] - 2.0 * G[i][j] + G[i][i], g22 = G[l][l] - 2.0 * G[i][l] + G[i][i];
+                const double g12 = G[j][l] - G[i][j] - G[i][l] + G[i][i];
+                const double r1 = G[i][i] - G[i][j], r2 = G[i][i] - G[i][l];
                 const double det = g11 * g22 - g12 * g12;
                 const bool ok = det > 1e-14 * fmax(g11 * g22, 1e-300);  // degenerate triangle: its edges cover it
-                const double idet = 1.0 / (ok ? det : 1.0);
+                const double idet = fast_rcp(ok ? det : 1.0);
                 const double u = (r1 * g22 - r2 * g12) * idet, v = (r2 * g11 - r1 * g12) * idet;
-                consider(axpy(axpy(p[i], u, e1), v, e2), ok && u >= 0.0 && v >= 0.0 && u + v <= 1.0);
+                consider(G[i][i] - u * r1 - v * r2, ok && u >= 0.0 && v >= 0.0 && u + v <= 1.0, i, j, l, u, v);
             }
+    auto pick = [&](int k) -> P3 {
+        P3 r = p[0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) {
+            r.x = (k == i) ? p[i].x : r.x;
+            r.y = (k == i) ? p[i].y : r.y;
+            r.z = (k == i) ? p[i].z : r.z;
+        }
+        return r;
+    };
+    const P3 a = pick(bi), b = pick(bj), c = pick(bl);
+    P3 bp = axpy(axpy(a, bu, sub(b, a)), bv, sub(c, a));
+    const double bb = dot(bp, bp);
     // Hull around the origin -> distance 0 (what openGJK reports once its simplex has 4 vertices).  If bp were the closest
     // point of a hull that does not contain the origin, every vertex would lie beyond the supporting plane through bp
     // (p_i . bp >= |bp|^2); a hull around the origin has a vertex with p_i . bp < 0.  The threshold sits halfway.
     bool inside = false;
 #pragma unroll
-    for (int i = 0; i < 6; i++) inside = inside || (dot(p[i], bp) < 0.5 * best);
+    for (int i = 0; i < 6; i++) inside = inside || (dot(p[i], bp) < 0.5 * bb);
     if (inside) bp = {0, 0, 0};
     return bp;
 }
