@@ -26,6 +26,8 @@ BENCH_SHORT = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", 
 
 
 def run(cmd, log):
+    if os.environ.get("REPARSE") == "1":  # only re-read the files of an earlier run
+        return 0
     with open(os.path.join(OUT, log), "w") as f:
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT)
     return r.returncode
@@ -64,8 +66,9 @@ def pmc(counters, name):
         for r in csv.DictReader(open(f)):
             if "lscqp_pdip_kernel" not in r["Kernel_Name"]:
                 continue
-            # only the timed workload: grid = qps_per_launch * threads (other launches belong to the parity / latency legs)
-            if int(r["Grid_Size"]) != 64 * 64:
+            # only the timed workload: 64 workgroups (one per QP; 64 or 128 threads each, by the launch policy); other
+            # launches belong to the parity / latency legs
+            if int(r["Grid_Size"]) != 64 * int(r["Workgroup_Size"]):
                 continue
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             disp = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Kernel_Name") if k in r}
@@ -78,7 +81,7 @@ sq, ns, _ = pmc(["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU"
                  "SQ_WAIT_INST_ANY"], "sq")
 res = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) -- python bench.py --steps 50 "
-              "--warmup 5 --no-cpu-baseline --no-extra; dispatches of the PDIP kernel with grid 4096 (= 64 QPs x 64 lanes) only",
+              "--warmup 5 --no-cpu-baseline --no-extra; dispatches of the PDIP kernel with 64 workgroups (= the 64-QP batch) only",
     "kernel": disp.get("Kernel_Name"),
     "qps_per_launch": 64,
     "launches_averaged": nf.get("FETCH_SIZE"),
