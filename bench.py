@@ -268,9 +268,11 @@ def main():
             R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)
             reps += 1
             tcpu = time.perf_counter() - a
-        a1 = time.perf_counter()
-        R1 = O.solve_batch(cls, ag[:16], lsc, loff[:16], sfc_o, threads=1)
-        t1c = time.perf_counter() - a1
+        t1c = 1e30  # single core: the first 16 QPs, best of 5 (a lone 30 ms sample is at the mercy of the host's clock ramp)
+        for _ in range(5):
+            a1 = time.perf_counter()
+            O.solve_batch(cls, ag[:16], lsc, loff[:16], sfc_o, threads=1)
+            t1c = min(t1c, time.perf_counter() - a1)
         xg = d_x.cpu().numpy().reshape(N, nv)
         og = d_obj.cpu().numpy()
         ok = (R["status"] == 0) & (status == 0)
