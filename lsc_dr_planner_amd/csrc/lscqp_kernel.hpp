@@ -1113,9 +1113,9 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             });
 #endif
             } else {
-                // W = 2: the rows live in the registers of two wavefronts.  By symmetry of the trailing matrix the pivot
-                // row of step j equals the pivot COLUMN, of which every lane holds one entry (its A[j]): published to
-                // LDS (double buffered), one s_barrier per column, read back with uniform-address ds_reads.
+#ifdef LSCQP_FACT_LOCKSTEP
+                // Measured alternative (-DLSCQP_FACT_LOCKSTEP): both row blocks eliminate column j together; the pivot
+                // column goes through LDS (double buffered) with one s_barrier per column: 125 k cycles at nz = 84.
                 int lf = lane;
                 asm volatile("" : "+v"(lf));
                 static_for<0, NZ>([&](auto Jc) {
@@ -1134,6 +1134,118 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     });
                     A[j] = (lf > j) ? li : A[j];
                 });
+#else
+                // nz > 64: BLOCKED LDL^T over the two row blocks (rows 0..63 in wavefront 0, the rest in wavefront 1).
+                //   1. wavefront 0 eliminates columns 0..63 of its own rows without any barrier: inside the block the
+                //      pivot row goes over both pipes as in the one-wavefront case, the entries of columns >= 64 (the
+                //      unscaled upper block U12) are broadcast with v_readlane;
+                //   2. U12 and 1/d go to LDS (the scratch matrix is free at this point), ONE barrier;
+                //   3. wavefront 1 forms its rows of L21 = U12' D^-1, the Schur complement A22 -= L21 U12 (uniform LDS
+                //      reads) and factorises the remaining (nz-64)^2 block with v_readlane.
+                // 3 barriers instead of 84; the branches on the wavefront id are scalar.
+                constexpr int N1 = NZ - 64;
+                const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
+                int lf = lane & 63;
+                asm volatile("" : "+v"(lf));
+                double* const U12s = Hs;                  // [64][N1]
+                double* const dinvs = Hs + 64 * N1;       // [64]
+                double* const flag = Hs + 64 * N1 + 64;   // [2] pivot failures of the two blocks
+                if (wv == 0) {
+                    col_[lf] = A[0];
+                    double d = bcast(A[0], 0);
+                    double invd = fast_rcp(d);
+                    static_for<0, 64>([&](auto Jc) {
+                        constexpr int j = decltype(Jc)::value;
+                        constexpr int n = 63 - j;  // trailing entries inside the block, k = j+1 .. 63
+                        constexpr int r0 = (n * LSCQP_FACT_HYBRID + 50) / 100;
+                        constexpr int nr = n <= 4 ? n : (r0 < 3 ? 4 : r0 + 1);
+                        constexpr int nl = n - (nr < n ? nr : n);
+                        constexpr int NR = n - nl;
+                        const double* const cb = col_ + (j & 1) * 64;
+                        double* const cbn = col_ + ((j + 1) & 1) * 64;
+                        pivot_bad = pivot_bad || !(d > 1e-300);
+                        dinv_own = (lf == j) ? invd : dinv_own;
+                        const double li = (lf > j) ? A[j] * invd : 0.0;
+                        double ul[nl > 0 ? nl : 1];
+                        static_for<0, nl>([&](auto Tc) {
+                            constexpr int t = decltype(Tc)::value;
+                            ul[t] = cb[j + 1 + NR + t];
+                        });
+                        if constexpr (NR > 0) {
+                            double ur[NR];
+                            static_for<0, NR>([&](auto Tc) {
+                                constexpr int t = decltype(Tc)::value;
+                                ur[t] = bcast(A[j + 1 + t], j);
+                            });
+                            A[j + 1] = fma(-li, ur[0], A[j + 1]);
+                            cbn[lf] = A[j + 1];
+                            d = bcast(A[j + 1], j + 1);
+                            invd = fast_rcp(d);
+                            static_for<1, NR>([&](auto Tc) {
+                                constexpr int t = decltype(Tc)::value;
+                                A[j + 1 + t] = fma(-li, ur[t], A[j + 1 + t]);
+                            });
+                        }
+                        static_for<0, nl>([&](auto Tc) {
+                            constexpr int t = decltype(Tc)::value;
+                            A[j + 1 + NR + t] = fma(-li, ul[t], A[j + 1 + NR + t]);
+                        });
+                        // the upper block: columns 64 .. nz-1 of the pivot row, v_readlane in batches of 8
+                        static_for<0, (N1 + 7) / 8>([&](auto Cc) {
+                            constexpr int k0 = 64 + decltype(Cc)::value * 8;
+                            double ub[8];
+                            static_for<0, 8>([&](auto Tc) {
+                                constexpr int t = decltype(Tc)::value;
+                                if constexpr (k0 + t < NZ) ub[t] = bcast(A[k0 + t], j);
+                            });
+                            static_for<0, 8>([&](auto Tc) {
+                                constexpr int t = decltype(Tc)::value;
+                                if constexpr (k0 + t < NZ) A[k0 + t] = fma(-li, ub[t], A[k0 + t]);
+                            });
+                        });
+                        A[j] = (lf > j) ? li : A[j];
+                        asm volatile("" ::: "memory");
+                    });
+                    static_for<0, N1>([&](auto Cc) {
+                        constexpr int c = decltype(Cc)::value;
+                        U12s[lf * N1 + c] = A[64 + c];
+                    });
+                    dinvs[lf] = dinv_own;
+                    if (lf == 0) flag[0] = pivot_bad ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                if (wv == 1) {
+                    const bool row = lf < N1;  // the other lanes of this wavefront hold no row of the system
+                    static_for<0, 64>([&](auto Jc) {
+                        constexpr int j = decltype(Jc)::value;
+                        const double l = U12s[j * N1 + (row ? lf : 0)] * dinvs[j];  // L21[row][j]
+                        const double lj = row ? l : 0.0;
+                        // Schur complement with the UNSCALED upper entries: A22[row][c] -= L21[row][j] U12[j][c]
+                        static_for<0, N1>([&](auto Cc) {
+                            constexpr int c = decltype(Cc)::value;
+                            A[64 + c] = fma(-lj, U12s[j * N1 + c], A[64 + c]);
+                        });
+                        A[j] = lj;
+                    });
+                    static_for<0, N1>([&](auto Jc) {  // the remaining block, pivot row by v_readlane
+                        constexpr int jj = decltype(Jc)::value;
+                        const double d = bcast(A[64 + jj], jj);
+                        pivot_bad = pivot_bad || !(d > 1e-300);
+                        const double invd = fast_rcp(d);
+                        dinv_own = (lf == jj) ? invd : dinv_own;
+                        const double li = (lf > jj && row) ? A[64 + jj] * invd : 0.0;
+                        static_for<jj + 1, N1>([&](auto Kc) {
+                            constexpr int kk = decltype(Kc)::value;
+                            A[64 + kk] = fma(-li, bcast(A[64 + kk], jj), A[64 + kk]);
+                        });
+                        A[64 + jj] = (lf > jj && row) ? li : A[64 + jj];
+                    });
+                    if (lf == 0) flag[1] = pivot_bad ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                pivot_bad = (flag[0] != 0.0) || (flag[1] != 0.0);
+                __syncthreads();  // the flags sit in the scratch matrix, which the next phase overwrites
+#endif
             }
             if (pivot_bad) {  // uniform over the QP's lanes
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
@@ -1169,7 +1281,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // one-wavefront case, and the coupling between the two row blocks is ONE hand-off through LDS per
             // direction (2 barriers per solve instead of one per column: 168 -> 2).  The branches on the wavefront id
             // are uniform (scalar), so no lane-masked region is created.
-            auto solve_blocked = [&](double b) __attribute__((always_inline)) -> double {  // (called twice: must not become a real call)
+            // (generic lambda: instantiated only for the nz > 64 instances; called twice: must not become a real call)
+            auto solve_blocked = [&](double b, auto) __attribute__((always_inline)) -> double {
                 const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
                 int ll_ = lane & 63;
                 asm volatile("" : "+v"(ll_));
@@ -1223,7 +1336,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 return x;
             };
             auto solve = [&](double b) __attribute__((always_inline)) -> double {
-                if constexpr (W > 1 && NZ > 64) return solve_blocked(b);
+                if constexpr (W > 1 && NZ > 64) return solve_blocked(b, 0);
                 int ls = (NZ <= 64) ? (lane & 63) : lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
                 const double* const hr = &Hs[(ls < NZ ? ls : NZ) * LDH];
