@@ -1,0 +1,32 @@
+"""bench.py contract: one JSON line with the fields the driver reads (GPU only: there is no CPU path to bench)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3", "--no-extra"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["steps"] == 20 and b["warmup"] == 3 and b["higher_is_better"] is True and b["scaling"] == "weak"
+    assert b["dtype"] == "f64" and b["data"] == "synthetic" and b["vs_baseline"] is None and "workload" in b["config"]
+    r = b["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0
+    c = b["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "QP/s" and c["sample"]
+    assert b["solver"]["non_optimal"] == 0
+    assert b["parity"]["max_rel_dobj"] <= 1e-8 and b["parity"]["max_abs_dx"] <= 1e-6
+    # value is whole-job throughput of the timed steps
+    assert abs(b["value"] - 64 * 1e3 / b["ms_per_step"]) <= 1e-6 * b["value"]
