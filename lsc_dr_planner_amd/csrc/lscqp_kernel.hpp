@@ -134,6 +134,19 @@ __device__ __forceinline__ void wave_max1_sum1(double& a, double& b) {
 }
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce1<OpSum>(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce1<OpMax>(v); }
+// Reciprocals of the row passes (1/s, 1/lambda: weights and step ratios): v_rcp_f64 + ONE Newton step.  The weights only
+// steer the direction (residuals and the objective are computed exactly), so the last bits do not matter: against two
+// steps the solutions differ by 1e-12 m / 3e-15 relative in the objective, and ~90 reciprocals per lane and iteration get
+// two instructions shorter (-2 % kernel time).  The pivots of the factorisation keep fast_rcp's two steps.
+#ifndef LSCQP_ROW_RCP_STEPS
+#define LSCQP_ROW_RCP_STEPS 1
+#endif
+__device__ __forceinline__ double row_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    if (LSCQP_ROW_RCP_STEPS > 1) r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
 // A double pinned to two accumulation registers (AGPRs).  The row state (slack, multiplier of every row slot) lives
 // across the whole iteration loop; left to the register allocator it is assigned to AGPRs anyway (the 256 VGPRs are
 // needed by the matrix row and the pass temporaries) but shuttled in and out ~3x per use.  With the residence made
@@ -765,7 +778,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double tlo = t_lo[u].get(), thi = t_hi[u].get();
                 const double y = row_val(c_, u);
                 const double rpl = on ? (y - tlo) - tsl : 0.0, rph = on ? (thi - y) - tsh : 0.0;
-                const double isl = fast_rcp(tsl), ish = fast_rcp(tsh);
+                const double isl = row_rcp(tsl), ish = row_rcp(tsh);
                 const double wl = tll * isl, wh = tlh * ish;
                 sum_sl += tsl * tll + tsh * tlh;
                 sum_pinf += tll * fabs(rpl) + tlh * fabs(rph);
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
                     const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u].get(), lam = r_l[u].get();
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
-                    const double is = fast_rcp(s);
+                    const double is = row_rcp(s);
                     const double w = lam * is;
                     sum_sl += s * lam;
                     sum_pinf += lam * fabs(rp);
@@ -1387,7 +1400,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double tlo = t_lo[u].get(), thi = t_hi[u].get();
                 const double y = row_val(c_, u), dy = row_val(dca_, u);
                 const double rpl = (y - tlo) - tsl, rph = (thi - y) - tsh;
-                const double isl = fast_rcp(tsl), ish = fast_rcp(tsh);
+                const double isl = row_rcp(tsl), ish = row_rcp(tsh);
                 const double tl = (dy + rpl) * isl, th = (rph - dy) * ish;
                 const double rr = fmax(fmax(-tl, 1.0 + tl), fmax(-th, 1.0 + th));
                 rmax = fmax(rmax, on ? rr : 1.0);
@@ -1414,7 +1427,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
                     const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u].get(), l = r_l[u].get();
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
-                    const double is = fast_rcp(s);
+                    const double is = row_rcp(s);
                     const double ds = (nx * dx + ny * dy + nz * dzz) + rp;
                     const double t = ds * is;
                     rmax = fmax(rmax, (l > 0.0) ? fmax(-t, 1.0 + t) : 1.0);
@@ -1469,10 +1482,12 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                      tb0 * (smu * y1[0] + y2[0]) + tb1 * (smu * y1[1] + y2[1]) + tb2 * (smu * y1[2] + y2[2]);
                 gb = zl ? gb : 0.0;
 #ifndef LSCQP_SOLVE_FROM_LDS
+                // (W = 1: lanes without a row parked zeros in the shared dummy row, nothing to mask; with more wavefronts the
+                // dummy row holds whatever the last lane parked)
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) {
                     const double v = hrow[cidx];
-                    A[cidx] = zl ? v : 0.0;
+                    A[cidx] = (W == 1 || zl) ? v : 0.0;
                 }
 #endif
             }
@@ -1501,14 +1516,14 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double tlo = t_lo[u].get(), thi = t_hi[u].get();
                 const double y = row_val(c_, u), dya = row_val(dca_, u), dyc = row_val(dc_, u);
                 const double rpl = (y - tlo) - tsl, rph = (thi - y) - tsh;
-                const double isl = fast_rcp(tsl), ish = fast_rcp(tsh);
+                const double isl = row_rcp(tsl), ish = row_rcp(tsh);
                 const double tl = (dya + rpl) * isl, th = (rph - dya) * ish;
                 const double pl = -(dya + rpl) * tll * (1.0 + tl), ph = -(rph - dya) * tlh * (1.0 + th);
                 const double dsl = dyc + rpl, dsh = rph - dyc;
                 const double dll = (smu - pl) * isl - tll - tll * isl * dsl;
                 const double dlh = (smu - ph) * ish - tlh - tlh * ish * dsh;
                 // rows that do not exist have lambda == 0: give them a harmless divisor
-                const double ill = fast_rcp(on ? tll : 1.0), ilh = fast_rcp(on ? tlh : 1.0);
+                const double ill = row_rcp(on ? tll : 1.0), ilh = row_rcp(on ? tlh : 1.0);
                 const double rr = fmax(fmax(-dsl * isl, -dsh * ish), fmax(-dll * ill, -dlh * ilh));
                 rmax = fmax(rmax, on ? rr : 0.0);
                 t_ds[2 * u] = on ? dsl : 0.0; t_ds[2 * u + 1] = on ? dsh : 0.0;
@@ -1527,13 +1542,13 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     const int e = (ll && o < n_obs) ? (o * CP + lcp) : NROW;
                     const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e], s = r_s[u].get(), l = r_l[u].get();
                     const double rp = (nx * cx + ny * cy + nz * cz - Rb[e]) - s;
-                    const double is = fast_rcp(s);
+                    const double is = row_rcp(s);
                     const double dsa = (nx * ax + ny * ay + nz * az) + rp;
                     const double pa = -dsa * l * (1.0 + dsa * is);
                     const double ds = (nx * dx + ny * dy + nz * dzz) + rp;
                     const bool act = l > 0.0;
                     const double dl = act ? ((smu - pa) * is - l - l * is * ds) : 0.0;
-                    const double il = fast_rcp(act ? l : 1.0);
+                    const double il = row_rcp(act ? l : 1.0);
                     rmax = fmax(rmax, fmax(-ds * is, -dl * il));
                     r_ds[u] = act ? ds : 0.0;
                     r_dl[u] = dl;
