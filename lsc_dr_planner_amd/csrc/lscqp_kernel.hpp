@@ -1569,43 +1569,42 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // heuristic occasionally drives single products to ~1e-4 mu; the next directions are then blocked at
             // alpha ~ 0.07 and mu cycles around 1e-9 forever (seen at M = 10, dim 3, 40 neighbours; tools/proto_pdip.py).
             // Costs one extra block reduction per iteration; the loop is uniform over the QP's lanes.
-            for (int bt = 0; bt < 10; bt++) {
+            // The step is applied to the row state inside the same loop (trial 0 writes s + alpha ds; a rejected trial is
+            // corrected by the difference of the step lengths), so the state is read and written once per iteration
+            // instead of once for the test and once more for the update.
+            double applied = 0.0;
+            for (int bt = 0;; bt++) {
                 const double mu_a = (sum_sl + alpha * (sdl + alpha * sdd)) * inv_m;
+                const double delta = alpha - applied;
+                applied = alpha;
                 double pmin = 1e300;
 #pragma unroll
                 for (int u = 0; u < NS2; u++) {
                     const bool on = t_ix[u] >= 0;
-                    const double pl = fma(alpha, t_ds[2 * u], t_sl[u].get()) * fma(alpha, t_dl[2 * u], t_ll[u].get());
-                    const double ph = fma(alpha, t_ds[2 * u + 1], t_sh[u].get()) * fma(alpha, t_dl[2 * u + 1], t_lh[u].get());
-                    pmin = fmin(pmin, on ? fmin(pl, ph) : 1e300);
+                    const double nsl = fma(delta, t_ds[2 * u], t_sl[u].get()), nll = fma(delta, t_dl[2 * u], t_ll[u].get());
+                    const double nsh = fma(delta, t_ds[2 * u + 1], t_sh[u].get()), nlh = fma(delta, t_dl[2 * u + 1], t_lh[u].get());
+                    t_sl[u].set(nsl);
+                    t_ll[u].set(nll);
+                    t_sh[u].set(nsh);
+                    t_lh[u].set(nlh);
+                    pmin = fmin(pmin, on ? fmin(nsl * nll, nsh * nlh) : 1e300);
                 }
 #pragma unroll
                 for (int u = 0; u < NSLOT; u++) {
-                    const double lu = r_l[u].get();
-                    const double pr = fma(alpha, r_ds[u], r_s[u].get()) * fma(alpha, r_dl[u], lu);
-                    pmin = fmin(pmin, (lu > 0.0) ? pr : 1e300);
+                    const double ns = fma(delta, r_ds[u], r_s[u].get()), nl = fma(delta, r_dl[u], r_l[u].get());
+                    r_s[u].set(ns);
+                    r_l[u].set(nl);
+                    pmin = fmin(pmin, (nl > 0.0) ? ns * nl : 1e300);
                 }
                 pmin = -block_max(-pmin);
-                if (pmin >= LSCQP_CENTRALITY_GAMMA * mu_a) break;
+                if (pmin >= LSCQP_CENTRALITY_GAMMA * mu_a || bt == 9) break;
                 // a blocked step taken to within mu of the boundary leaves the blocking product at ~mu^2: first retreat
                 // to the standard fraction, then shorten
                 alpha = (bt == 0 && alpha_std < alpha) ? alpha_std : 0.7 * alpha;
             }
             LSCQP_T(8);
             LSCQP_STOP(9)
-            // ============ update ===========================================================================
-#pragma unroll
-            for (int u = 0; u < NS2; u++) {
-                t_sl[u].set(fma(alpha, t_ds[2 * u], t_sl[u].get()));
-                t_sh[u].set(fma(alpha, t_ds[2 * u + 1], t_sh[u].get()));
-                t_ll[u].set(fma(alpha, t_dl[2 * u], t_ll[u].get()));
-                t_lh[u].set(fma(alpha, t_dl[2 * u + 1], t_lh[u].get()));
-            }
-#pragma unroll
-            for (int u = 0; u < NSLOT; u++) {
-                r_s[u].set(fma(alpha, r_ds[u], r_s[u].get()));
-                r_l[u].set(fma(alpha, r_dl[u], r_l[u].get()));
-            }
+            // ============ update of z and the control points =================================================
             if (zl) z_[lane] += alpha * dzc;
             LSCQP_BLOCK_SYNC();
             // c = c_fixed + T z, recomputed from z so the eliminated equalities hold to rounding every iteration
