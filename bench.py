@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="step = all-gather of the plans (N > 1) -> LSC generation on the device -> QP solve (SURVEY 8f-1); "
                          "the default step is the QP solve of BASELINE's metric alone")
+    ap.add_argument("--cold-start", action="store_true", help="do not hand the initial trajectories to the solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
     args = ap.parse_args()
@@ -101,6 +102,8 @@ def main():
     n_obs_eff = sw.n_obs
     nv = sol.nv
     d_hdr, d_rows, d_off, d_sfc = (to_dev(torch, a, dev) for a in (hdr, rows, off, sfc))
+    # TrajOptimizer::solve's initial_traj (the shifted previous plan): the solver's primal start
+    d_xinit = None if args.cold_start else torch.from_numpy(api.x_init_from_swarm(build, dim)).to(dev)
     d_x = torch.zeros(N * nv, dtype=torch.float64, device=dev)
     d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
     d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
@@ -116,7 +119,7 @@ def main():
         d_rad = torch.full((n_total,), sw.radius, dtype=torch.float64, device=dev)
         d_dw = torch.full((n_total,), sw.downwash, dtype=torch.float64, device=dev)
         d_goal = torch.from_numpy(np.ascontiguousarray(build["goal"], dtype=np.float64)).to(dev)
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)  # plans to start from
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)  # plans to start from
         torch.cuda.synchronize()
 
     def step():
@@ -127,7 +130,7 @@ def main():
                 src = d_all
             sol.shift_traj_device(world * N, src, d_traj, z_2d=float(build["p0"][0][2]), shift=0)
             sol.generate_lsc_device(N, n_obs_eff, rank * N, d_traj, d_nbr, d_rad, d_dw, d_goal, d_rows)
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         if d_all is not None and not args.pipeline:
             dist.all_gather_into_tensor(d_all, d_x)
 
@@ -173,7 +176,7 @@ def main():
     lat = []
     for _ in range(300):
         a = time.perf_counter()
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - a)
     lat = np.array(lat[50:]) * 1e3
@@ -181,11 +184,11 @@ def main():
     lat1 = []
     for _ in range(200):
         a = time.perf_counter()
-        sol.solve_device(1, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+        sol.solve_device(1, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
         lat1.append(time.perf_counter() - a)
     lat1 = np.array(lat1[50:]) * 1e3
-    sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info)
+    sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
     torch.cuda.synchronize()
 
     bytes_per_qp = sol.algorithmic_bytes(n_obs_eff)
@@ -223,6 +226,7 @@ def main():
                         "fp64 batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (N, M, n_obs_eff, dim, args.style),
             "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
             "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline),
+            "warm_start": "initial_traj (shifted previous plan) as primal start" if d_xinit is not None else "none",
             "parallelism": ("agents sharded over %d GPU(s), " % world) +
                            ("one RCCL all-gather of the plans per step" if d_all is not None else "no data-path collective"),
         },
@@ -296,20 +300,21 @@ def main():
         extra = []
         for nb in (512, 4096):
             try:
-                sw2, sol2, _, (h2, r2, o2, s2) = make_batch(api, synth, solver_factory, nb, M, dim, n_obs, seed=2000 + nb,
-                                                            style=args.style, warm_steps=3)
+                sw2, sol2, b2, (h2, r2, o2, s2) = make_batch(api, synth, solver_factory, nb, M, dim, n_obs, seed=2000 + nb,
+                                                             style=args.style, warm_steps=3)
                 dh, dr, do, ds = (to_dev(torch, a, dev) for a in (h2, r2, o2, s2))
+                dxi = None if args.cold_start else torch.from_numpy(api.x_init_from_swarm(b2, dim)).to(dev)
                 dx = torch.zeros(nb * nv, dtype=torch.float64, device=dev)
                 dob = torch.zeros(nb, dtype=torch.float64, device=dev)
                 dst = torch.zeros(nb, dtype=torch.int32, device=dev)
                 for _ in range(3):
-                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None)
+                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None, d_x_init=dxi)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 reps = 20
                 for _ in range(reps):
-                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None)
+                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None, d_x_init=dxi)
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps

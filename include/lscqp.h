@@ -155,14 +155,18 @@ int lscqp_num_variables(lscqp_handle h);
  *                (the m==0,i<3 entries are present and ignored, :404-406)
  *   row_offsets  [n+1] in units of rows (uint64)
  *   sfc          [n*M] boxes, or NULL when !use_sfc
+ *   x_init       [n*nv] or NULL: the `initial_traj` argument of TrajOptimizer::solve (the shifted previous plan,
+ *                src/traj_planner.cpp:399-411) as control points in the reference variable order.  CPLEX ignores it
+ *                (src/traj_optimizer.cpp:516-528 is dead code); here it is the primal start of the interior-point
+ *                iteration (same optimum, about one iteration fewer in steady state).  NULL: start from hover.
  *   x_out        [n*nv]  raw fp64 control points, reference variable order (no float32 truncation)
  *   obj_out      [n]     objective INCLUDING the constant terminal term, == cplex.getObjValue() (:100)
  *   status_out   [n]     LSCQP_STATUS_*
  *   info_out     [n] or NULL
  */
 int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
-                      const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
-                      int32_t* status_out, lscqp_info* info_out);
+                      const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
+                      double* obj_out, int32_t* status_out, lscqp_info* info_out);
 
 /* Same, DEVICE pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
  * Inputs must already be resident in HBM; nothing is copied and nothing is synchronised.
@@ -170,8 +174,8 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
  * with more obstacles are truncated to it, so pass the true maximum). */
 int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                              const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
-                             double* d_x_out, double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out,
-                             void* stream);
+                             const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                             lscqp_info* d_info_out, void* stream);
 
 /* ---- next row of the path: the producer of the LSC rows --------------------------------
  *

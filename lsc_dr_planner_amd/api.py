@@ -76,9 +76,9 @@ def lib():
         L.lscqp_algorithmic_bytes.restype = C.c_int64
         L.lscqp_algorithmic_bytes.argtypes = [vp, C.c_int32]
         L.lscqp_solve_batch.restype = C.c_int
-        L.lscqp_solve_batch.argtypes = [vp, C.c_int64] + [vp] * 8
+        L.lscqp_solve_batch.argtypes = [vp, C.c_int64] + [vp] * 9
         L.lscqp_solve_batch_device.restype = C.c_int
-        L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9
+        L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 10
         L.lscqp_generate_lsc_device.restype = C.c_int
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_shift_traj_device.restype = C.c_int
@@ -158,7 +158,8 @@ class Solver:
         return lib().lscqp_num_inequalities(self._h, n_obs)
 
     # ---- host-pointer call (numpy) --------------------------------------------------------------------
-    def solve_host(self, hdr, rows=None, row_offsets=None, sfc=None, want_info=True):
+    def solve_host(self, hdr, rows=None, row_offsets=None, sfc=None, want_info=True, x_init=None):
+        """x_init: (n, nv) initial trajectories (TrajOptimizer::solve's initial_traj) as the primal start, or None."""
         n = len(hdr)
         hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE)
         x = np.zeros((n, self.nv))
@@ -175,13 +176,16 @@ class Solver:
         def p(a):
             return None if a is None else a.ctypes.data_as(C.c_void_p)
 
-        rc = lib().lscqp_solve_batch(self._h, n, p(hdr), p(rows), p(row_offsets), p(sfc), p(x), p(obj), p(status), p(info))
+        if x_init is not None:
+            x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(n, self.nv)
+        rc = lib().lscqp_solve_batch(self._h, n, p(hdr), p(rows), p(row_offsets), p(sfc), p(x_init), p(x), p(obj), p(status), p(info))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
         return dict(x=x, obj=obj, status=status, info=info)
 
     # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
-    def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None):
+    def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None,
+                     d_x_init=None):
         """All arguments are torch CUDA tensors (any dtype; only data_ptr() is used) or None.
         Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream."""
         import torch
@@ -191,7 +195,7 @@ class Solver:
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
 
-        rc = lib().lscqp_solve_batch_device(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x),
+        rc = lib().lscqp_solve_batch_device(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
                                             p(d_obj), p(d_status), p(d_info), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
@@ -269,6 +273,13 @@ class Solver:
 
     def generate_lsc_bytes(self, n_agents, n_obs, n_total):
         return lib().lscqp_generate_lsc_bytes(self._h, n_agents, n_obs, n_total)
+
+
+def x_init_from_swarm(build, dim):
+    """synth.Swarm.build()["init"] (N, M, 6, 3) -> (N, dim*M*6) in the reference variable order (axis, segment, point)."""
+    init = np.asarray(build["init"], dtype=np.float64)
+    N = init.shape[0]
+    return np.ascontiguousarray(init.transpose(0, 3, 1, 2)[:, :dim]).reshape(N, -1)
 
 
 def batch_from_swarm(build, n_obs, M, vmax=1.0, amax=2.0, radius=0.15, nominal_velocity=1.0, terminal_segments=None):

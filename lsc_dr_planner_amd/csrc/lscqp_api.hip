@@ -15,7 +15,8 @@
 #define LSCQP_DECL(M, D, E, S, W)                                                                                      \
     extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S##_##W(const lscqp::DevClass*, int64_t, const lscqp_header*, \
                                                                   const lscqp_row*, const uint64_t*, const lscqp_box*,  \
-                                                                  double*, double*, int32_t*, lscqp_info*, hipStream_t);
+                                                                  const double*, double*, double*, int32_t*, lscqp_info*, \
+                                                                  hipStream_t);
 LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
@@ -328,8 +329,8 @@ int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs) {
 
 int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                              const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
-                             double* d_x_out, double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out,
-                             void* stream) {
+                             const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                             lscqp_info* d_info_out, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -352,15 +353,15 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
     }
     lscqp::DevClass cls = h->dev;
     cls.n_obs_max = n_obs_max;
-    hipError_t e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_out, d_obj_out, d_status_out, d_info_out,
+    hipError_t e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out,
                             (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
     return LSCQP_OK;
 }
 
 int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
-                      const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
-                      int32_t* status_out, lscqp_info* info_out) {
+                      const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
+                      double* obj_out, int32_t* status_out, lscqp_info* info_out) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -384,8 +385,8 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(sizeof(lscqp_row) * n_rows),
                  b_off = al(sizeof(uint64_t) * (n + 1)), b_sfc = al(sizeof(lscqp_box) * n * h->desc.M),
                  b_x = al(sizeof(double) * n * h->nv), b_obj = al(sizeof(double) * n), b_st = al(sizeof(int32_t) * n),
-                 b_info = al(sizeof(lscqp_info) * n);
-    const size_t total = b_hdr + b_rows + b_off + b_sfc + b_x + b_obj + b_st + b_info;
+                 b_info = al(sizeof(lscqp_info) * n), b_xi = x_init ? b_x : 0;
+    const size_t total = b_hdr + b_rows + b_off + b_sfc + b_x + b_obj + b_st + b_info + b_xi;
     if (total > h->d_cap) {
         if (h->d_buf) (void)hipFree(h->d_buf);
         h->d_buf = nullptr;
@@ -401,7 +402,8 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     double* d_x = (double*)p; p += b_x;
     double* d_obj = (double*)p; p += b_obj;
     int32_t* d_st = (int32_t*)p; p += b_st;
-    lscqp_info* d_info = (lscqp_info*)p;
+    lscqp_info* d_info = (lscqp_info*)p; p += b_info;
+    double* d_xi = x_init ? (double*)p : nullptr;
 #define LSCQP_CK(call)                                                                           \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
@@ -412,7 +414,8 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
     else LSCQP_CK(hipMemset(d_off, 0, sizeof(uint64_t) * (n + 1)));
     if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
-    int rc = lscqp_solve_batch_device(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, nullptr);
+    if (d_xi) LSCQP_CK(hipMemcpy(d_xi, x_init, sizeof(double) * n * h->nv, hipMemcpyHostToDevice));
+    int rc = lscqp_solve_batch_device(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, nullptr);
     if (rc != LSCQP_OK) return rc;
     LSCQP_CK(hipDeviceSynchronize());
     LSCQP_CK(hipMemcpy(x_out, d_x, sizeof(double) * n * h->nv, hipMemcpyDeviceToHost));

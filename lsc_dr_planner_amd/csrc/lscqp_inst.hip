@@ -12,8 +12,8 @@
 #define LSCQP_FN LSCQP_CAT(lscqp_launch_, LSCQP_M, LSCQP_DIM, LSCQP_ES, LSCQP_NSLOT, LSCQP_W)
 
 extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
-                               const uint64_t* row_offsets, const lscqp_box* sfc, double* x_out, double* obj_out,
-                               int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
+                               const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
+                               double* obj_out, int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
     using C = lscqp::Cfg<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT, LSCQP_W>;
     auto kern = lscqp::lscqp_pdip_kernel<LSCQP_M, LSCQP_DIM, (LSCQP_ES != 0), LSCQP_NSLOT, LSCQP_W>;
     constexpr size_t lds = C::lds_bytes();
@@ -26,7 +26,7 @@ extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscq
         attr_set = true;
     }
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(C::T), lds, stream, *cls, n, hdr, rows, row_offsets, sfc, x_out, obj_out,
-                       status_out, info_out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(C::T), lds, stream, *cls, n, hdr, rows, row_offsets, sfc, x_init, x_out,
+                       obj_out, status_out, info_out);
     return hipGetLastError();
 }

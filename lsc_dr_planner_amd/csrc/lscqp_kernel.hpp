@@ -262,7 +262,8 @@ template <int M, int DIM, bool ES, int NSLOT, int W = 1>
 __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows,
                                                         const uint64_t* __restrict__ row_offsets,
-                                                        const lscqp_box* __restrict__ sfc, double* __restrict__ x_out,
+                                                        const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init,
+                                                        double* __restrict__ x_out,
                                                         double* __restrict__ obj_out, int32_t* __restrict__ status_out,
                                                         lscqp_info* __restrict__ info_out) {
     using C = Cfg<M, DIM, ES, NSLOT, W>;
@@ -469,6 +470,24 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         double* hrow0 = &Hs[lane * LDH];
 #pragma unroll
         for (int cidx = 0; cidx < NZ; cidx++) hrow0[cidx] = 0.0;  // entries outside the lane's pattern stay zero
+        // Primal start from the caller's initial trajectory (TrajOptimizer::solve's `initial_traj`: the shifted previous
+        // plan): the free control points c3..c5 of every segment (c5 alone under the end stop), translated.  The
+        // equalities are re-imposed by c = c_fixed + T z below, so float32 rounding of the plan does no harm.
+        if (x_init) {
+            const double o_k = (zk == 0) ? org0 : (zk == 1) ? org1 : org2;
+            z_[lane] = x_init[q * NX + zk * P + 6 * zm + (zlast ? 5 : 3 + zj)] - o_k;
+        }
+    }
+    if (x_init) {  // uniform over the grid
+        __syncthreads();
+        for (int e = lane; e < NX; e += T) {
+            const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
+            const double vhi = z_[k * NZA + ((ES && m == M - 1) ? 3 * (M - 1) : 3 * m + (i >= 3 ? i - 3 : 0))];
+            const double* zz = &z_[k * NZA + 3 * (m >= 1 ? m - 1 : 0)];
+            const int ii = i < 3 ? i : 0;
+            const double vlo = TBc(ii, 0) * zz[0] + TBc(ii, 1) * zz[1] + TBc(ii, 2) * zz[2];
+            if (cp >= 3) c_[e] = (i >= 3) ? vhi : vlo;
+        }
     }
     LSCQP_T(11);  // prologue a: header, control points, scratch rows
     // ---- stage LSC row constants: HBM (AoS 32 B, [oi][m][i]) -> LDS SoA [oi][cp], translated to the agent origin --

@@ -10,7 +10,7 @@ struct DevClass;
 constexpr size_t kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
 
 using launch_fn = hipError_t (*)(const DevClass*, int64_t, const lscqp_header*, const lscqp_row*, const uint64_t*,
-                                 const lscqp_box*, double*, double*, int32_t*, lscqp_info*, hipStream_t);
+                                 const lscqp_box*, const double*, double*, double*, int32_t*, lscqp_info*, hipStream_t);
 }  // namespace lscqp
 
 // The compiled kernel instances, X(M, DIM, ES, NSLOT, W):

@@ -41,6 +41,7 @@ public:
     struct BatchItem {
         const Agent* agent;
         const CollisionConstraints* constraints;
+        const traj_t* initial_traj = nullptr;  // optional: primal start of the interior-point iteration
     };
     // Solves every item in one launch.  results[i] is filled for every item; ok[i] == false where the reference
     // would have thrown PlanningReport::QPFAILED (the caller substitutes initial_traj, src/traj_planner.cpp:767-797).

@@ -138,13 +138,24 @@ void TrajOptimizer::solveBatch(const std::vector<BatchItem>& items, std::vector<
         off[q + 1] = rows.size();
     }
     const int nv = dim * M * (n + 1);
+    // initial_traj (src/traj_planner.cpp:399-411) as the primal start, if every item carries one of the right shape
+    std::vector<double> x_init;
+    bool warm = nq > 0;
+    for (size_t q = 0; q < nq && warm; q++) warm = items[q].initial_traj && items[q].initial_traj->size() == M;
+    if (warm) {
+        x_init.resize(nq * nv);
+        for (size_t q = 0; q < nq; q++)
+            for (int k = 0; k < dim; k++)
+                for (int m = 0; m < M; m++)
+                    for (int i = 0; i < n + 1; i++) x_init[q * nv + (k * M + m) * (n + 1) + i] = (*items[q].initial_traj)[m][i](k);
+    }
     raw_x.assign(nq * nv, 0.0);
     std::vector<double> obj(nq);
     std::vector<int32_t> status(nq);
     std::vector<lscqp_info> info(nq);
     if (rows.empty()) rows.resize(1);
     int rc = lscqp_solve_batch(handle, (int64_t)nq, hdr.data(), rows.data(), off.data(), boxes.empty() ? nullptr : boxes.data(),
-                               raw_x.data(), obj.data(), status.data(), info.data());
+                               warm ? x_init.data() : nullptr, raw_x.data(), obj.data(), status.data(), info.data());
     if (rc != LSCQP_OK) throw std::runtime_error(std::string("[TrajOptimizer] ") + lscqp_last_error());
     results.resize(nq);
     ok.assign(nq, false);
@@ -155,13 +166,14 @@ void TrajOptimizer::solveBatch(const std::vector<BatchItem>& items, std::vector<
     }
 }
 
-TrajOptResult TrajOptimizer::solve(const Agent& agent, const CollisionConstraints& constraints, const traj_t& /*initial_traj*/,
+TrajOptResult TrajOptimizer::solve(const Agent& agent, const CollisionConstraints& constraints, const traj_t& initial_traj,
                                    bool /*use_primal_algorithm*/) {
-    // initial_traj is unused by the reference's solve as well (only dead code reads it, :516-528);
-    // use_primal_algorithm selected CPLEX's primal simplex (:36-39) and has no meaning for an interior-point method.
+    // initial_traj is unused by the reference's solve (only dead code reads it, :516-528); here it is the primal start of the
+    // interior-point iteration.  use_primal_algorithm selected CPLEX's primal simplex (:36-39) and has no meaning here.
     std::vector<BatchItem> one(1);
     one[0].agent = &agent;
     one[0].constraints = &constraints;
+    one[0].initial_traj = &initial_traj;
     std::vector<TrajOptResult> res;
     std::vector<bool> ok;
     solveBatch(one, res, ok);

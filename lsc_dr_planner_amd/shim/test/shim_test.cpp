@@ -97,7 +97,7 @@ static int scenario_pair() {
     TrajOptResult r = opt.solve(a, cons, init, true);
     std::vector<double> raw = opt.lastRawSolution();
     // the same item twice through the additive batch call
-    std::vector<TrajOptimizer::BatchItem> items(2, TrajOptimizer::BatchItem{&a, &cons});
+    std::vector<TrajOptimizer::BatchItem> items(2, TrajOptimizer::BatchItem{&a, &cons, &init});
     std::vector<TrajOptResult> res;
     std::vector<bool> ok;
     opt.solveBatch(items, res, ok);

@@ -48,10 +48,12 @@ cls = DevClass(); cls.dt = 0.2; cls.w_c = 0.01; cls.w_t = 1.0; cls.comm_range = 
 for k in range(3): cls.world_min[k] = sw.world_min[k]; cls.world_max[k] = sw.world_max[k]
 cls.q2s = 2 * 0.01 * 0.2 ** -5
 cls.tol = 1e-10; cls.max_iter = 60; cls.use_sfc = 1; cls.n_obs_max = sw.n_obs
+d_xi = torch.from_numpy(api.x_init_from_swarm(b, D)).to(dev) if os.environ.get("WARM", "1") != "0" else None
+XINIT = d_xi.data_ptr() if d_xi is not None else None
 fn = getattr(L, "lscqp_launch_%d_%d_1_%d_%d" % (M, D, NSLOT, W))
-fn.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 9
+fn.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
 def launch():
-    rc = fn(C.byref(cls), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), dx.data_ptr(), dob.data_ptr(), dst.data_ptr(), dinfo.data_ptr(), None)
+    rc = fn(C.byref(cls), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), XINIT, dx.data_ptr(), dob.data_ptr(), dst.data_ptr(), dinfo.data_ptr(), None)
     assert rc == 0, rc
 launch(); torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)(); L.lscqp_dbg_read(buf, 1)
