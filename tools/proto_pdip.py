@@ -144,9 +144,18 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     z = np.zeros(nz)
     for k in range(dim):  # start: every free control point at c2 of the first segment
         z[k * nzA:(k + 1) * nzA] = cfix[k, 2]
+    warm = hdr.get("init") is not None  # the caller's initial trajectory (M,6,3): shifted previous plan (kernel: x_init)
+    if warm:
+        init = np.asarray(hdr["init"], float) - org[None, None, :]
+        for k in range(dim):
+            for m in range(M):
+                last = (m == M - 1) and end_stop
+                for j in range(3):
+                    z[k * nzA + 3 * m + (0 if last else j)] = init[m, 5 if last else 3 + j, k]
+    mu0, s0 = (1e-3, 0.03) if warm else (3e-3, 0.1)
     s = np.maximum(Gz @ z - hz, 0.0)
-    s = np.maximum(s, 1e-1)
-    lam = 3e-3 / s  # centred start: every product s*lam = mu0
+    s = np.maximum(s, s0)
+    lam = mu0 / s  # centred start: every product s*lam = mu0
     gscale = max(1.0, np.abs(gfull).max())
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
