@@ -15,7 +15,8 @@ import helpers as H  # noqa: E402
 from lsc_dr_planner_amd import api, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
+WARM = "--warm" in sys.argv  # hand the initial trajectory (shifted previous plan) to the solver as primal start
 shapes = [(48, 5, 3, 20, "forest"), (32, 6, 3, 20, "maze"), (16, 10, 2, 9, "forest"), (24, 7, 3, 12, "maze"), (32, 4, 3, 12, "forest"),
           (24, 10, 3, 40, "forest"), (40, 5, 2, 12, "forest"), (24, 8, 2, 12, "maze")]
 bad_total = 0
@@ -30,7 +31,7 @@ for (N, M, dim, n_obs, style) in shapes:
         for step in range(3):
             b = sw.build()
             hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
-            G = sol.solve_host(hdr, rows, off, sfc)
+            G = sol.solve_host(hdr, rows, off, sfc, x_init=api.x_init_from_swarm(b, dim) if WARM else None)
             ag, lsc, loff, sfco = H.swarm_oracle_inputs(O, sw, b)
             R = O.solve_batch(cls, ag, lsc, loff, sfco, threads=16)
             both = (G["status"] == 0) & (R["status"] == 0)
