@@ -1344,15 +1344,13 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 }
                 // ---- backward: (D L') x = w; row i of the upper factor is A[j > i] of lane i ----
                 asm volatile("" : "+v"(ll_));
-                double x = 0;
                 if (wv == 1) {
                     static_for<0, N1>([&](auto Jc) {
                         constexpr int jj = N1 - 1 - decltype(Jc)::value;
                         const double xj = bcast(b * dinv_own, jj);
-                        x = (ll_ == jj) ? xj : x;
                         b = fma(-((ll_ < jj) ? A[64 + jj] : 0.0), xj, b);
                     });
-                    col_[64 + ll_] = x;  // x_64 .. (lanes beyond the system carry zeros)
+                    col_[64 + ll_] = b * dinv_own;  // x_64 .. (lanes beyond the system carry zeros: dinv_own = 0 there)
                 }
                 __syncthreads();
                 if (wv == 0) {
@@ -1363,10 +1361,10 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     static_for<0, 64>([&](auto Jc) {
                         constexpr int j = 63 - decltype(Jc)::value;
                         const double xj = bcast(b * dinv_own, j);
-                        x = (ll_ == j) ? xj : x;
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);
                     });
                 }
+                const double x = b * dinv_own;  // (final once the lane's own column has been broadcast)
                 return x;
             };
             auto solve = [&](double b) __attribute__((always_inline)) -> double {
@@ -1381,14 +1379,14 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     b = fma(-((ls > j) ? LSCQP_FACTOR_ENTRY(j) : 0.0), wj, b);
                 }
                 asm volatile("" : "+v"(ls));
-                double x = 0;
 #pragma unroll
                 for (int j = NZ - 1; j >= 0; j--) {  // (D L') x = w : row i of the upper factor is A[j>i] of lane i
                     const double xj = bcast_q(b * dinv_own, j, ls, col_ + T);
-                    x = (ls == j) ? xj : x;
                     b = fma(-((ls < j) ? LSCQP_FACTOR_ENTRY(j) : 0.0), xj, b);
                 }
-                return x;
+                // lane i's b is final once column i has been broadcast (later columns j < i leave it alone), so its own
+                // component needs no per-step select
+                return b * dinv_own;
             };
             LSCQP_T(4);
             LSCQP_STOP(5)
