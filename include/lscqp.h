@@ -195,10 +195,30 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
  *   d_goal        [n_agents][3]         current_goal_point: fallback normal when the hull contains the origin (:624-633)
  *   first_agent   global id of local agent 0 (the local shard is [first_agent, first_agent + n_agents))
  *   d_rows_out    [n_agents * n_obs * M * (n+1)] rows
- * Dynamic obstacles / BVC / collision-predicted obstacles (the other branches of generateLSC) are not handled. */
+ * Dynamic (non-agent) obstacles and collision-predicted obstacles (the other branches of generateLSC) are not handled;
+ * generateCLSC and generateBVC are served by lscqp_generate_constraints_device below. */
 int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
                               const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
                               const double* d_goal, lscqp_row* d_rows_out, void* stream);
+
+/* The planner's other constraint generators for agent-type obstacles, same inputs / output layout / launch as
+ * lscqp_generate_lsc_device, selected by `mode`:
+ *   LSCQP_GEN_LSC   generateLSC  (src/traj_planner.cpp:611-657)  -- identical to lscqp_generate_lsc_device
+ *   LSCQP_GEN_CLSC  generateCLSC (:659-706): what constructLSC() runs for the reference's default launch (mode/planner = lsc
+ *                   with mode/goal = grid_based_planner, :551-553).  Segments m < M-1 as generateLSC without the fallback
+ *                   normal (a hull around the origin leaves zero rows); the last segment separates the line segments
+ *                   (last control point -> goal point) of the neighbour and of the agent with
+ *                   closestPointsBetweenLineSegments (include/geometry.hpp:174-263) and carries one obstacle point and one
+ *                   margin for all control points (CollisionConstraints::setLSC, src/collision_constraints.cpp:532-539)
+ *   LSCQP_GEN_BVC   generateBVC  (:708-734): buffered Voronoi cell from the two start points
+ *   d_goal_all [n_total][3]: current goal point of EVERY agent (the planning agent's own, agent.current_goal_point, and the
+ *   neighbours', obstacles[oi].goal_point as broadcast), indexed by global id. */
+#define LSCQP_GEN_LSC 0
+#define LSCQP_GEN_CLSC 1
+#define LSCQP_GEN_BVC 2
+int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                      const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                      const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, void* stream);
 
 /* Replaces TrajPlanner::initialTrajPlanningPrevSol (src/traj_planner.cpp:399-411) on the solver's output: segment m of
  * the new initial trajectory := segment m+1 of the previous plan, the last segment := its last point; control points

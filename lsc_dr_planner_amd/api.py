@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblscqp.so")
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC = 0, 1, 2, 3
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC = 0, 1, 2
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
+GEN_LSC, GEN_CLSC, GEN_BVC = 0, 1, 2  # lscqp_generate_constraints_device modes (include/lscqp.h)
 
 HEADER_DTYPE = np.dtype([
     ("p0", "f8", 3), ("v0", "f8", 3), ("a0", "f8", 3), ("goal", "f8", 3), ("next_waypoint", "f8", 3),
@@ -81,6 +82,8 @@ def lib():
         L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 10
         L.lscqp_generate_lsc_device.restype = C.c_int
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
+        L.lscqp_generate_constraints_device.restype = C.c_int
+        L.lscqp_generate_constraints_device.argtypes = [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_shift_traj_device.restype = C.c_int
         L.lscqp_shift_traj_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_double, vp, vp, vp]
         L.lscqp_generate_lsc_bytes.restype = C.c_int64
@@ -98,7 +101,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device",
                     "lscqp_last_error", "lscqp_version"]
 
@@ -258,6 +261,20 @@ class Solver:
                                              C.c_void_p(d_neighbours.data_ptr()), C.c_void_p(d_radius.data_ptr()),
                                              C.c_void_p(d_downwash.data_ptr()), C.c_void_p(d_goal.data_ptr()),
                                              C.c_void_p(d_rows.data_ptr()), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def generate_constraints_device(self, mode, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal_all,
+                                    d_rows, stream=None):
+        """generateLSC / generateCLSC / generateBVC (mode GEN_LSC / GEN_CLSC / GEN_BVC) on the device; d_goal_all holds the
+        current goal point of every agent, indexed by global id (see include/lscqp.h)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_generate_constraints_device(self._h, int(mode), n_agents, n_obs, first_agent, C.c_void_p(d_traj.data_ptr()),
+                                                     C.c_void_p(d_neighbours.data_ptr()), C.c_void_p(d_radius.data_ptr()),
+                                                     C.c_void_p(d_downwash.data_ptr()), C.c_void_p(d_goal_all.data_ptr()),
+                                                     C.c_void_p(d_rows.data_ptr()), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

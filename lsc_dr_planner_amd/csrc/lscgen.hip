@@ -115,13 +115,177 @@ __device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
     return bp;
 }
 
+// ---- octomap::point3d arithmetic (3 x float) of the reference's geometry helpers, used by the CLSC / BVC generators.
+// Semantics of octomath::Vector3: component arithmetic and cross() in float, dot() / norm_sq() float expressions widened
+// to double, norm() = sqrt of that, distance() = sqrt of the double sum of squared float differences, normalize()
+// divides by (float)norm().  No FMA contraction in these routines: the reference's x86-64 build has none, and the CPU
+// oracle restates them the same way, so both sides round identically.
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 fsub(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return {a.x - b.x, a.y - b.y, a.z - b.z};
+}
+__device__ __forceinline__ F3 fadd(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return {a.x + b.x, a.y + b.y, a.z + b.z};
+}
+__device__ __forceinline__ F3 fscale(F3 a, float s) {
+#pragma clang fp contract(off)
+    return {a.x * s, a.y * s, a.z * s};
+}
+__device__ __forceinline__ F3 fcross(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double fdot(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    return (double)(a.x * b.x + a.y * b.y + a.z * b.z);
+}
+__device__ __forceinline__ double fnorm(F3 a) {
+#pragma clang fp contract(off)
+    return sqrt((double)(a.x * a.x + a.y * a.y + a.z * a.z));
+}
+__device__ __forceinline__ double fdist(F3 a, F3 b) {
+#pragma clang fp contract(off)
+    const double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+__device__ __forceinline__ F3 fnormalized(F3 a) {
+#pragma clang fp contract(off)
+    const double len = fnorm(a);
+    if (len > 0) {
+        const float f = (float)len;
+        a.x /= f;
+        a.y /= f;
+        a.z /= f;
+    }
+    return a;
+}
+
+// closestPointsBetweenPointAndLineSegment (reference include/geometry.hpp:67-102): cp2 = closest point of [s, e] to `point`
+__device__ __forceinline__ double point_segment(F3 point, F3 s, F3 e, F3& cp2) {
+#pragma clang fp contract(off)
+    const F3 a = fsub(s, point), b = fsub(e, point);
+    double dist_min = fnorm(a);
+    F3 rel = a;
+    if (!(a.x == b.x && a.y == b.y && a.z == b.z)) {
+        double dist = fnorm(b);
+        if (dist_min > dist) {
+            dist_min = dist;
+            rel = b;
+        }
+        const F3 n_line = fnormalized(fsub(b, a));
+        const F3 c = fsub(a, fscale(n_line, (float)fdot(a, n_line)));
+        dist = fnorm(c);
+        if (fdot(fsub(c, a), fsub(c, b)) < 0 && dist_min > dist) {
+            dist_min = dist;
+            rel = c;
+        }
+    }
+    cp2 = fadd(rel, point);
+    return dist_min;
+}
+
+// closestPointsBetweenLineSegments (reference include/geometry.hpp:174-263, with closestPointsBetweenLines :129-172 and
+// its Eigen Matrix3f inverse written out as cofactors / determinant)
+__device__ __forceinline__ double segseg_closest(F3 s1, F3 e1, F3 s2, F3 e2, F3& cp1, F3& cp2) {
+#pragma clang fp contract(off)
+    if (fdist(s1, e1) < 1e-5) {
+        cp1 = s1;
+        return point_segment(s1, s2, e2, cp2);
+    }
+    if (fdist(s2, e2) < 1e-5) {
+        cp2 = s2;
+        return point_segment(s2, s1, e1, cp1);
+    }
+    const F3 v1 = fsub(e1, s1), v2 = fsub(e2, s2);
+    const double l1 = fnorm(v1), l2 = fnorm(v2);
+    const F3 n1 = fscale(v1, (float)(1 / l1)), n2 = fscale(v2, (float)(1 / l2));
+    if (fnorm(fcross(n1, n2)) < 1e-5) {  // parallel segments, :192-219
+        double bound_min = fdot(fsub(s2, s1), n1), bound_max = fdot(fsub(e2, s1), n1);
+        F3 p2_min = s2, p2_max = e2;
+        if (bound_max < bound_min) {
+            const double t = bound_min;
+            bound_min = bound_max;
+            bound_max = t;
+            const F3 tp = p2_min;
+            p2_min = p2_max;
+            p2_max = tp;
+        }
+        F3 delta = fsub(s2, s1);
+        delta = fsub(delta, fscale(n1, (float)fdot(delta, n1)));
+        if (l1 < bound_min) {
+            cp1 = e1;
+            cp2 = p2_min;
+        } else if (bound_max < 0) {
+            cp1 = s1;
+            cp2 = p2_max;
+        } else if (bound_min < 0) {
+            cp1 = s1;
+            cp2 = fadd(s1, delta);
+        } else {
+            cp1 = fsub(p2_min, delta);
+            cp2 = p2_min;
+        }
+        return fdist(cp1, cp2);
+    }
+    {  // closestPointsBetweenLines :129-172
+        const F3 m1 = fnormalized(v1), m2 = fnormalized(v2);
+        const F3 delta = fsub(s2, s1);
+        const F3 neg2 = {-m2.x, -m2.y, -m2.z};
+        if (fdist(m1, m2) < 1e-5 || fdist(m1, neg2) < 1e-5) {
+            const F3 dl = fsub(delta, fscale(m1, (float)fdot(delta, m1)));
+            cp1 = s1;
+            cp2 = fadd(s1, dl);
+        } else {
+            const F3 m3 = fnormalized(fcross(m2, m1));
+            // A = [m1 | -m2 | m3] (columns); x = inverse(A) * delta, inverse = cofactors^T / det, float
+            const float a00 = m1.x, a01 = -m2.x, a02 = m3.x, a10 = m1.y, a11 = -m2.y, a12 = m3.y, a20 = m1.z, a21 = -m2.z, a22 = m3.z;
+            const float c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+            const float c10 = a12 * a20 - a10 * a22, c11 = a00 * a22 - a02 * a20, c12 = a02 * a10 - a00 * a12;
+            const float det = a00 * c00 + a10 * c01 + a20 * c02;
+            const float invdet = 1.0f / det;
+            const float al0 = (c00 * invdet) * delta.x + (c01 * invdet) * delta.y + (c02 * invdet) * delta.z;
+            const float al1 = (c10 * invdet) * delta.x + (c11 * invdet) * delta.y + (c12 * invdet) * delta.z;
+            cp1 = fadd(s1, fscale(m1, al0));
+            cp2 = fadd(s2, fscale(m2, al1));
+        }
+    }
+    const double alpha1 = fdot(fsub(cp1, s1), n1) / l1, alpha2 = fdot(fsub(cp2, s2), n2) / l2;
+    if (alpha1 < 0)
+        cp1 = s1;
+    else if (alpha1 > 1)
+        cp1 = e1;
+    if (alpha2 < 0)
+        cp2 = s2;
+    else if (alpha2 > 1)
+        cp2 = e2;
+    if (alpha1 < 0 || alpha1 > 1) {
+        double dt = fdot(n2, fsub(cp1, s2));
+        dt = dt < 0 ? 0 : (dt > l2 ? l2 : dt);
+        cp2 = fadd(s2, fscale(n2, (float)dt));
+    }
+    if (alpha2 < 0 || alpha2 > 1) {
+        double dt = fdot(n1, fsub(cp2, s1));
+        dt = dt < 0 ? 0 : (dt > l1 ? l1 : dt);
+        cp1 = fadd(s1, fscale(n1, (float)dt));
+    }
+    return fdist(cp1, cp2);
+}
+
 // one lane per (agent a, obstacle slot o, segment m); unit index t = (a*n_obs + o)*M + m, rows of unit t = out[6t .. 6t+6)
+// MODE: LSCQP_GEN_LSC = generateLSC (:611-657), LSCQP_GEN_CLSC = generateCLSC (:659-706), LSCQP_GEN_BVC = generateBVC (:708-734)
+// goal: current goal point of local agent a at goal[3a]; goal_all: of global agent g at goal_all[3g] (CLSC only)
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, int64_t n_units, int32_t n_obs, int64_t first_agent,
                                                                 const double* __restrict__ traj,
                                                                 const int32_t* __restrict__ neighbours,
                                                                 const double* __restrict__ radius,
                                                                 const double* __restrict__ downwash,
-                                                                const double* __restrict__ goal, lscqp_row* __restrict__ out) {
+                                                                const double* __restrict__ goal,
+                                                                const double* __restrict__ goal_all, lscqp_row* __restrict__ out) {
     __shared__ double4 stage[kThreads * 6];  // the block's rows in output order: [lane][row], 32 B each (48 KiB)
     const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool live = t < n_units;
@@ -136,6 +300,69 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
     const int64_t gb = has ? gb_raw : ga;
 
     const double r_own = radius[ga], r_obs = radius[gb];
+    double4* mine = stage + (size_t)threadIdx.x * 6;
+    if constexpr (MODE != LSCQP_GEN_LSC) {
+        // generateCLSC / generateBVC: float point3d arithmetic throughout, downwash never gated by the dimension (a 2-D
+        // mission has equal z everywhere, so the transform cancels); generateCLSC skips the transform in 2-D (:666-672)
+        const double dw = (downwash[ga] * r_own + downwash[gb] * r_obs) / (r_own + r_obs);
+        const float dwf = (float)dw;
+        const bool tr = (MODE == LSCQP_GEN_BVC) || dim != 2;
+        const double collision_dist = r_obs + r_own;
+        auto cpt = [&](int64_t g, int mm, int i) -> F3 {
+            const double* p = traj + ((g * M + mm) * 6 + i) * 3;
+            return F3{(float)p[0], (float)p[1], (float)p[2]};
+        };
+        auto trf = [&](F3 p) -> F3 {
+            if (tr) p.z = p.z / dwf;
+            return p;
+        };
+        F3 nrm = {0, 0, 0};
+        double d[6];
+        F3 pob[6];
+        if (MODE == LSCQP_GEN_BVC) {
+            const F3 diff = fsub(trf(cpt(ga, 0, 0)), trf(cpt(gb, 0, 0)));
+            nrm = fnormalized(diff);
+            const double dd = 0.5 * (collision_dist + fdot(diff, nrm));
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                d[i] = dd;
+                pob[i] = cpt(gb, m, i);
+            }
+        } else if (m < M - 1) {
+            F3 relf[6];
+            P3 rel[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                pob[i] = cpt(gb, m, i);
+                relf[i] = fsub(trf(cpt(ga, m, i)), trf(pob[i]));
+                rel[i] = {(double)relf[i].x, (double)relf[i].y, (double)relf[i].z};
+            }
+            const P3 cp = hull_closest_point(rel);
+            nrm = fnormalized(F3{(float)cp.x, (float)cp.y, (float)cp.z});  // no fallback normal in generateCLSC: zero rows drop out
+#pragma unroll
+            for (int i = 0; i < 6; i++) d[i] = 0.5 * (collision_dist + fdot(relf[i], nrm));
+        } else {
+            // :691-703: separate the segments (last point -> goal point) of the neighbour and of the agent; the goal
+            // points are used untransformed, and one obstacle point / one margin serve all control points (:532-539)
+            const double* go = goal_all + 3 * gb;
+            const double* gw = goal + 3 * a;
+            F3 cp1, cp2;
+            const double dist = segseg_closest(trf(cpt(gb, M - 1, 5)), F3{(float)go[0], (float)go[1], (float)go[2]},
+                                               trf(cpt(ga, M - 1, 5)), F3{(float)gw[0], (float)gw[1], (float)gw[2]}, cp1, cp2);
+            nrm = fnormalized(fsub(cp2, cp1));
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                d[i] = 0.5 * (collision_dist + dist);
+                pob[i] = cp1;
+            }
+        }
+        const double onx = (double)nrm.x, ony = (double)nrm.y, onz = (double)(float)((double)nrm.z / dw);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double b = d[i] + (onx * (double)pob[i].x + ony * (double)pob[i].y + onz * (double)pob[i].z);
+            mine[i] = has ? double4{onx, ony, onz, b} : double4{0, 0, 0, 0};
+        }
+    } else {
     // downwashBetween, both agents (:1229-1240); 2-D missions plan in the plane
     const double dw = (dim == 3) ? (downwash[ga] * r_own + downwash[gb] * r_obs) / (r_own + r_obs) : 1.0;
     const float dwf = (float)dw;
@@ -180,7 +407,6 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
     const double collision_dist = r_obs + r_own;  // :641
     const double onx = (double)nx, ony = (double)ny;
     const double onz = (dim == 3) ? (double)(float)((double)nz / dw) : 0.0;  // :653
-    double4* mine = stage + (size_t)threadIdx.x * 6;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const float dotf = relf[i][0] * nx + relf[i][1] * ny + relf[i][2] * nz;  // float dot of :642-643
@@ -189,6 +415,7 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
         // rows of a missing neighbour are all-zero: the solver drops normals shorter than 1e-5 (:409-411)
         mine[i] = has ? double4{onx, ony, onz, b} : double4{0, 0, 0, 0};
     }
+    }  // MODE == LSCQP_GEN_LSC
     __syncthreads();
     // cooperative store: the block's rows are contiguous in `out` in exactly the staging order, so every global store
     // instruction of a wavefront writes 64 x 32 contiguous bytes
@@ -226,14 +453,18 @@ __global__ __launch_bounds__(kThreads) void shift_traj_kernel(int M, int dim, in
 
 extern "C" int lscqp_set_error_(int code, const char* msg);  // lscqp_api.hip
 
-extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
-                                       const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
-                                       const double* d_goal, lscqp_row* d_rows_out, void* stream) {
+extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                       const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                       const double* d_downwash, const double* d_goal, const double* d_goal_all, lscqp_row* d_rows_out,
+                                       void* stream) {
     const int64_t n_units = n_agents * (int64_t)n_obs * M;
     if (n_units == 0) return LSCQP_OK;
     const unsigned blocks = (unsigned)((n_units + lscgen::kThreads - 1) / lscgen::kThreads);
-    hipLaunchKernelGGL(lscgen::generate_lsc_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n_units, n_obs,
-                       first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal, d_rows_out);
+    auto* kern = mode == LSCQP_GEN_CLSC  ? lscgen::generate_lsc_kernel<LSCQP_GEN_CLSC>
+                 : mode == LSCQP_GEN_BVC ? lscgen::generate_lsc_kernel<LSCQP_GEN_BVC>
+                                         : lscgen::generate_lsc_kernel<LSCQP_GEN_LSC>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n_units, n_obs, first_agent, d_traj,
+                       d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, d_rows_out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;

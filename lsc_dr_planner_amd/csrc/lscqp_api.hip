@@ -20,9 +20,10 @@
 LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
-extern "C" int lscqp_generate_lsc_raw_(int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
-                                       const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
-                                       const double* d_goal, lscqp_row* d_rows_out, void* stream);
+extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                       const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                       const double* d_downwash, const double* d_goal, const double* d_goal_all, lscqp_row* d_rows_out,
+                                       void* stream);
 extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
 extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const double* d_x,
@@ -208,8 +209,25 @@ int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, i
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_generate_lsc_raw_(h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash,
-                                   d_goal, d_rows_out, stream);
+    return lscqp_generate_lsc_raw_(LSCQP_GEN_LSC, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
+                                   d_downwash, d_goal, nullptr, d_rows_out, stream);
+}
+
+int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                      const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                      const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (mode != LSCQP_GEN_LSC && mode != LSCQP_GEN_CLSC && mode != LSCQP_GEN_BVC)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "mode must be LSCQP_GEN_LSC, LSCQP_GEN_CLSC or LSCQP_GEN_BVC");
+    if (n_agents < 0 || n_obs < 0 || first_agent < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n_agents == 0 || n_obs == 0) return LSCQP_OK;
+    if (!d_traj || !d_neighbours || !d_radius || !d_downwash || !d_goal_all || !d_rows_out)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_generate_lsc_raw_(mode, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
+                                   d_downwash, d_goal_all + 3 * first_agent, d_goal_all, d_rows_out, stream);
 }
 
 int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, double z_2d, const double* d_x_prev, double* d_traj,

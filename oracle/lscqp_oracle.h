@@ -118,6 +118,15 @@ void orc_generate_lsc_pair(int M, int dim, const double* own, const double* obs,
 void orc_generate_lsc(int M, int dim, int n_agents, int n_obs, int first_agent, const double* traj, const int* neighbours,
                       const double* radius, const double* downwash, const double* goal, orc_lsc* out);
 
+/* ---- the other constraint generators (oracle/lscmode_oracle.c): mode 1 = generateCLSC (src/traj_planner.cpp:659-706),
+ * mode 2 = generateBVC (:708-734) ---- */
+double orc_segseg_closest(const double* l1s, const double* l1e, const double* l2s, const double* l2e, double* cp1_out,
+                          double* cp2_out);
+void orc_generate_mode_pair(int mode, int M, int dim, const double* own, const double* obs, double r_own, double r_obs,
+                            double dw_own, double dw_obs, const double* goal_own, const double* goal_obs, orc_lsc* out);
+void orc_generate_mode(int mode, int M, int dim, int n_agents, int n_obs, int first_agent, const double* traj,
+                       const int* neighbours, const double* radius, const double* downwash, const double* goal_all, orc_lsc* out);
+
 /* ---- goal LP (oracle/lscgoal_oracle.c; reference src/goal_optimizer.cpp:72-147) ---- */
 int orc_goal_rows(const orc_class* cls, const double* g, const double* w, int n_obs, const orc_lsc* lsc, const orc_box* sfc_last,
                   double* a, double* c);

@@ -53,7 +53,7 @@ _REFERENCE = "/root/reference"
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscqp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscmode_oracle.c", "Makefile", "lscqp_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
@@ -115,6 +115,9 @@ def lib():
         _lib.orc_hull_closest_point.restype = C.c_double
         _lib.orc_hull_closest_point.argtypes = [dp, C.c_int, dp]
         _lib.orc_generate_lsc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_void_p]
+        _lib.orc_generate_mode.argtypes = [C.c_int] * 6 + [dp, ip, dp, dp, dp, C.c_void_p]
+        _lib.orc_segseg_closest.restype = C.c_double
+        _lib.orc_segseg_closest.argtypes = [dp] * 6
         _lib.orc_goal_rows.restype = C.c_int
         _lib.orc_goal_rows.argtypes = [C.POINTER(OrcClass), dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, dp]
         _lib.orc_goal_opt.restype = C.c_int
@@ -263,6 +266,37 @@ def generate_lsc(traj, neighbours, radius, downwash, goal, dim=3, first_agent=0)
     lib().orc_generate_lsc(M, dim, n_agents, n_obs, first_agent, _dp(traj), nb.ctypes.data_as(C.POINTER(C.c_int)), _dp(r),
                            _dp(dw), _dp(g), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+MODE_LSC, MODE_CLSC, MODE_BVC = 0, 1, 2
+
+
+def generate_constraints(mode, traj, neighbours, radius, downwash, goal_all, dim=3, first_agent=0):
+    """Restatement of the planner's linear-constraint generators for agent obstacles: mode 0 = generateLSC
+    (reference src/traj_planner.cpp:611-657), 1 = generateCLSC (:659-706, the default launch), 2 = generateBVC (:708-734).
+    goal_all (n_total, 3): every agent's current goal point.  Returns LSC_DTYPE[n_agents, n_obs, M, 6]."""
+    traj = np.ascontiguousarray(traj, dtype=np.float64)
+    nb = np.ascontiguousarray(neighbours, dtype=np.int32)
+    n_total, M = traj.shape[0], traj.shape[1]
+    n_agents, n_obs = nb.shape
+    g = np.ascontiguousarray(goal_all, dtype=np.float64).reshape(n_total, 3)
+    if mode == MODE_LSC:
+        return generate_lsc(traj, nb, radius, downwash, g[first_agent:first_agent + n_agents], dim=dim, first_agent=first_agent)
+    r = np.ascontiguousarray(np.broadcast_to(radius, (n_total,)), dtype=np.float64)
+    dw = np.ascontiguousarray(np.broadcast_to(downwash, (n_total,)), dtype=np.float64)
+    out = np.zeros((n_agents, n_obs, M, 6), LSC_DTYPE)
+    lib().orc_generate_mode(mode, M, dim, n_agents, n_obs, first_agent, _dp(traj), nb.ctypes.data_as(C.POINTER(C.c_int)), _dp(r),
+                            _dp(dw), _dp(g), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def segseg_closest(l1s, l1e, l2s, l2e):
+    """closestPointsBetweenLineSegments (reference include/geometry.hpp:174-263) in its float32 arithmetic:
+    returns (dist, closest_point1 on line1, closest_point2 on line2)."""
+    a = [np.ascontiguousarray(np.float32(v), dtype=np.float64) for v in (l1s, l1e, l2s, l2e)]
+    c1, c2 = np.zeros(3), np.zeros(3)
+    d = lib().orc_segseg_closest(_dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), _dp(c1), _dp(c2))
+    return d, c1, c2
 
 
 def goal_rows(cls, goal, next_waypoint, lsc=None, sfc_last=None):

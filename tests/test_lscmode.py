@@ -1,0 +1,145 @@
+"""The planner's other constraint generators (generateLSC / generateCLSC; plus generateBVC):
+the oracle restatement (oracle/lscmode_oracle.c) against independent solutions and the reference's invariants, and the
+HIP kernel against the oracle.  generateCLSC is what the reference's default launch runs (mode/planner = lsc with
+mode/goal = grid_based_planner, reference src/traj_planner.cpp:551-553)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+CLSC, BVC = 1, 2
+
+
+def test_segment_segment_closest_points_against_exact_golden(oracle):
+    """closestPointsBetweenLineSegments restated in the reference's float32 arithmetic vs the exact fp64 closest pair
+    (tools/make_golden_segseg.py, 240 cases: generic, planar, parallel, degenerate, crossing)."""
+    g = H.load_golden("segseg")
+    worst_d = worst_p = 0.0
+    for c in g["cases"]:
+        d, c1, c2 = oracle.segseg_closest(c["l1s"], c["l1e"], c["l2s"], c["l2e"])
+        worst_d = max(worst_d, abs(d - c["dist"]))
+        if c["kind"] in ("generic", "planar", "degenerate1", "degenerate2"):  # unique closest pair
+            worst_p = max(worst_p, np.abs(c1 - c["cp1"]).max(), np.abs(c2 - c["cp2"]).max())
+        else:  # parallel / crossing: the pair is not unique (or ill conditioned); it must still be a closest pair
+            assert abs(np.linalg.norm(c1 - c2) - c["dist"]) <= 2e-5
+    # float32 procedure (points up to 3 m, a 3x3 float inverse) against an fp64 solution
+    assert worst_d <= 2e-5 and worst_p <= 2e-4, (worst_d, worst_p)
+
+
+def _swarm(N, M, dim, n_obs, seed):
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed)
+    b = sw.build()
+    return sw, b
+
+
+@pytest.mark.parametrize("N,M,dim,n_obs,seed", [(24, 5, 3, 8, 1), (12, 10, 2, 5, 2)])
+def test_clsc_restatement_invariants(oracle, N, M, dim, n_obs, seed):
+    sw, b = _swarm(N, M, dim, n_obs, seed)
+    goal_all = np.ascontiguousarray(b["goal"], dtype=np.float64)
+    init, nbr = b["init"], b["nbr"].astype(np.int32)
+    L1 = oracle.generate_constraints(CLSC, init, nbr, sw.radius, sw.downwash, goal_all, dim=dim)
+    L0 = oracle.generate_constraints(0, init, nbr, sw.radius, sw.downwash, goal_all, dim=dim)
+    # segments m < M-1: generateCLSC = generateLSC whenever the hull does not contain the origin (:677-690 vs :618-657)
+    for f in ("nrm", "d", "p"):
+        assert np.array_equal(L1[f][:, :, :M - 1], L0[f][:, :, :M - 1]), f
+    # last segment (:691-703): one point, one margin, one normal for the 6 control points; the agent's own last point and
+    # its goal lie on the agent's side with slack (dist - (r_i + r_j)) / 2 by the closest-point property
+    last = L1[:, :, M - 1]
+    assert (last["d"] == last["d"][..., :1]).all() and (last["nrm"] == last["nrm"][..., :1, :]).all()
+    dw = sw.downwash if dim == 3 else 1.0
+    for a in range(N):
+        for o in range(n_obs):
+            r = last[a, o, 0]
+            n_t = r["nrm"] * np.array([1, 1, dw])  # back in the transformed frame the normal is a unit vector
+            if np.linalg.norm(r["nrm"]) < 1e-5:
+                continue
+            assert abs(np.linalg.norm(n_t) - 1) <= 1e-6
+            dist = 2 * r["d"] - 2 * sw.radius
+            for pt in (init[a, M - 1, 5] / np.array([1, 1, dw]), goal_all[a]):
+                assert n_t @ (pt - r["p"]) >= dist - 2e-5, (a, o)
+    # a pair sees mirrored last-segment constraints: n_ab = -n_ba, same margin
+    for a in range(N):
+        for o in range(n_obs):
+            bb = nbr[a, o]
+            where = np.nonzero(nbr[bb] == a)[0]
+            if len(where):
+                other = L1[bb, where[0], M - 1, 0]
+                assert np.abs(other["nrm"] + last[a, o, 0]["nrm"]).max() <= 2e-6 and abs(other["d"] - last[a, o, 0]["d"]) <= 2e-6
+
+
+def test_bvc_restatement_closed_form(oracle):
+    sw, b = _swarm(16, 5, 3, 6, 3)
+    goal_all = np.ascontiguousarray(b["goal"], dtype=np.float64)
+    init, nbr = b["init"], b["nbr"].astype(np.int32)
+    L = oracle.generate_constraints(BVC, init, nbr, sw.radius, sw.downwash, goal_all, dim=3)
+    dw = sw.downwash
+    for a in range(16):
+        for o in range(6):
+            diff = (init[a, 0, 0] - init[nbr[a, o], 0, 0]) / np.array([1, 1, dw])  # :716-718
+            n = diff / np.linalg.norm(diff)
+            want_d = 0.5 * (2 * sw.radius + np.linalg.norm(diff))  # :722-727
+            want_n = n / np.array([1, 1, dw])  # :730
+            assert np.abs(L[a, o]["nrm"] - want_n).max() <= 2e-7 and np.abs(L[a, o]["d"] - want_d).max() <= 2e-6
+            assert np.array_equal(L[a, o]["p"], init[nbr[a, o]])  # :732-733: the neighbour's control points
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [CLSC, BVC, 0])
+@pytest.mark.parametrize("N,M,dim,n_obs,seed", [(64, 5, 3, 20, 1), (10, 10, 2, 9, 2), (44, 10, 3, 40, 8)])
+def test_gpu_generate_constraints_matches_oracle(api, oracle, mode, N, M, dim, n_obs, seed):
+    import torch
+
+    assert torch.cuda.is_available()
+    sw, b = _swarm(N, M, dim, n_obs, seed)
+    nbr = b["nbr"].astype(np.int32).copy()
+    nbr[0, -1] = -1  # a missing neighbour -> zero rows
+    init = b["init"].copy()
+    init[1] = init[nbr[1, 0]]  # agent 1 sits exactly on its first neighbour: zero normals (CLSC) / fallback (LSC)
+    goal_all = np.ascontiguousarray(b["goal"], dtype=np.float64).copy()
+    goal_all[2] = init[2, M - 1, 5]  # agent 2 has arrived: degenerate (point) segment in the CLSC last-segment rows
+    rad = np.full(N, sw.radius)
+    dwv = np.full(N, sw.downwash)
+    rad[3], dwv[3] = 0.2, 1.5  # heterogeneous pair: radius-weighted downwash (:1229-1240)
+    L = oracle.generate_constraints(mode, init, nbr, rad, dwv, goal_all, dim=dim)
+    want = api.pack_rows(L).reshape(N, n_obs, M, 6)
+    dev = torch.device("cuda", 0)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d_rows = torch.full((N * n_obs * M * 6 * 4,), float("nan"), dtype=torch.float64, device=dev)
+    sol.generate_constraints_device(mode, N, n_obs, 0, up(init), up(nbr), up(rad), up(dwv), up(goal_all), d_rows)
+    torch.cuda.synchronize()
+    got = d_rows.cpu().numpy().view(api.ROW_DTYPE).reshape(N, n_obs, M, 6)
+    assert np.isfinite(d_rows.cpu().numpy()).all()
+    assert (got["nx"][0, -1] == 0).all() and (got["b"][0, -1] == 0).all()
+    # same float32 stages on both sides; the fp64 hull enumeration differs in operation order only (one float32 ulp on
+    # the normal, 2e-6 on b = d + n.p); the float32 segment-segment procedure is restated without contraction on both
+    # sides and agrees to the last bit except through sqrt/division rounding of the device (<= 1 ulp)
+    for f, tol in (("nx", 2e-7), ("ny", 2e-7), ("nz", 2e-7), ("b", 2e-6)):
+        assert np.abs(got[f] - want[f]).max() <= tol, (f, np.abs(got[f] - want[f]).max())
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_constraints_use_global_goal_ids(api, oracle):
+    """first_agent > 0: the local shard indexes trajectories, radii and goal points by global id."""
+    import torch
+
+    N, M, dim, n_obs = 40, 5, 3, 8
+    sw, b = _swarm(N, M, dim, n_obs, 4)
+    nbr = b["nbr"].astype(np.int32)
+    goal_all = np.ascontiguousarray(b["goal"], dtype=np.float64)
+    first, n_loc = 24, 16
+    L = oracle.generate_constraints(CLSC, b["init"], nbr[first:], sw.radius, sw.downwash, goal_all, dim=dim, first_agent=first)
+    want = api.pack_rows(L).reshape(n_loc, n_obs, M, 6)
+    dev = torch.device("cuda", 0)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d_rows = torch.zeros(n_loc * n_obs * M * 6 * 4, dtype=torch.float64, device=dev)
+    sol.generate_constraints_device(CLSC, n_loc, n_obs, first, up(b["init"]), up(nbr[first:]), up(np.full(N, sw.radius)),
+                                    up(np.full(N, sw.downwash)), up(goal_all), d_rows)
+    torch.cuda.synchronize()
+    got = d_rows.cpu().numpy().view(api.ROW_DTYPE).reshape(n_loc, n_obs, M, 6)
+    for f, tol in (("nx", 2e-7), ("ny", 2e-7), ("nz", 2e-7), ("b", 2e-6)):
+        assert np.abs(got[f] - want[f]).max() <= tol, f
