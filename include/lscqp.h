@@ -260,6 +260,27 @@ int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, doub
                                const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid_out, double* d_state_out,
                                void* stream);
 
+/* Safety metrics of one planned step, the figures MultiSyncSimulator::update accumulates for the reference's summary CSV
+ * (src/multi_sync_simulator.cpp:486-577; log/summary_*.csv columns safety_ratio_agent, vel/acc excess): for each local
+ * agent and each sample time s * record_time_step, s < n_samples (the reference samples while future_time <
+ * multisim_time_step - 1e-5, :489), the smallest ellipsoidal distance to any other agent over the sum of the radii
+ * (ellipsoidalDistance, include/util.hpp:155-159, radius-weighted downwash :505-507) and the positive parts of
+ * (v_k - max_vel_k) / max_vel_k, (a_k - max_acc_k) / max_acc_k (:560-572).  States are Trajectory::getStateAt of the
+ * float32 control points.  The mission-wide figures are the min / max of these per-agent records (over ranks: one
+ * MIN / MAX all-reduce).  Obstacle safety ratios (:530-557) need the obstacle models, which are out of scope.
+ *   d_x_all [n_total][dim*M*(n+1)]  every agent's current plan (x_out of the solve, all-gathered)
+ *   d_radius, d_downwash [n_total]   d_hdr [n_agents] (max_vel / max_acc)   d_out [n_agents] */
+typedef struct lscqp_safety {
+    double safety_ratio;        /* min over samples and other agents; +inf if there is no other agent */
+    int32_t closest_agent;      /* global id attaining it (first sample, then smallest id, like the reference's strict <) */
+    int32_t sample;             /* sample index attaining it */
+    double vel_excess_ratio[3]; /* max over samples, 0 where the limit is kept */
+    double acc_excess_ratio[3];
+} lscqp_safety;
+int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_samples,
+                                double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
+                                const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream);
+
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);

@@ -24,6 +24,8 @@ HEADER_DTYPE = np.dtype([
 ])
 ROW_DTYPE = np.dtype([("nx", "f8"), ("ny", "f8"), ("nz", "f8"), ("b", "f8")])
 BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)])
+SAFETY_DTYPE = np.dtype([("safety_ratio", "f8"), ("closest_agent", "i4"), ("sample", "i4"), ("vel_excess_ratio", "f8", 3),
+                         ("acc_excess_ratio", "f8", 3)])
 INFO_DTYPE = np.dtype([("iterations", "i4"), ("reserved", "i4"), ("res_primal", "f8"), ("res_dual", "f8"),
                        ("gap", "f8")])
 assert HEADER_DTYPE.itemsize == 256 and ROW_DTYPE.itemsize == 32 and BOX_DTYPE.itemsize == 48
@@ -92,6 +94,8 @@ def lib():
         L.lscqp_optimize_goal_device.argtypes = [vp, C.c_int64] + [vp] * 6
         L.lscqp_optimize_goal.restype = C.c_int
         L.lscqp_optimize_goal.argtypes = [vp, C.c_int64] + [vp] * 5
+        L.lscqp_safety_metrics_device.restype = C.c_int
+        L.lscqp_safety_metrics_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double] + [vp] * 6
         L.lscqp_validate_step_device.restype = C.c_int
         L.lscqp_validate_step_device.argtypes = [vp, C.c_int64, C.c_double, C.c_double] + [vp] * 6
         L.lscqp_last_error.restype = C.c_char_p
@@ -102,7 +106,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_generate_constraints_device",
-                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device",
+                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
 
 
@@ -237,6 +241,18 @@ class Solver:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     # ---- isSolValid + getStateAt + doStep -------------------------------------------
+    def safety_metrics_device(self, n_agents, first_agent, n_total, n_samples, record_time_step, d_x_all, d_radius, d_downwash, d_hdr,
+                              d_out, z_2d=1.0, stream=None):
+        """MultiSyncSimulator::update's safety ratio / excess ratios per local agent (SAFETY_DTYPE records in d_out)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = lib().lscqp_safety_metrics_device(self._h, n_agents, first_agent, n_total, int(n_samples), float(record_time_step), float(z_2d),
+                                               p(d_x_all), p(d_radius), p(d_downwash), p(d_hdr), p(d_out), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
     def validate_step_device(self, n, time_step, d_x, d_hdr, d_sfc, d_valid, d_state, z_2d=1.0, stream=None):
         import torch
 

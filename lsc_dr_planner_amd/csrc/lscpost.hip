@@ -6,6 +6,8 @@
 //                                    simulation step; its LSC check is commented out in the reference and stays out)
 //   Trajectory::getStateAt           src/trajectory.cpp:156-170 (getPointAt :111-153, derivative :180-199)
 //   AgentManager::doStep             src/agent_manager.cpp:29-50  (the agent's next state = ideal future state)
+//   MultiSyncSimulator::update       src/multi_sync_simulator.cpp:486-577 (safety ratio between agents, velocity /
+//                                    acceleration excess ratios: the numbers of the reference's summary CSV)
 // Control points are first truncated to float32 exactly as TrajOptResult::desired_traj holds them
 // (src/traj_optimizer.cpp:71-83); in 2-D missions z := world_z_2d.  One lane per agent.
 #include <hip/hip_runtime.h>
@@ -93,9 +95,155 @@ __global__ __launch_bounds__(kThreads) void validate_step_kernel(int M, int dim,
     valid[q] = ok ? 1 : 0;
 }
 
+// ---- safety metrics of MultiSyncSimulator::update (reference src/multi_sync_simulator.cpp:486-577) --------------------
+// For every sample time t_s = s * record_time_step of the step just planned and every local agent i:
+//   safety ratio  min_j |E (p_i - p_j)| / (r_i + r_j),  E = diag(1, 1, 1/downwash_ij)   (ellipsoidalDistance, include/util.hpp:155-159)
+//   excess ratios (v_k - vmax_k) / vmax_k and (a_k - amax_k) / amax_k where positive       (:560-572; signed, like the reference)
+// An all-pairs pass: 32 local agents x 8 slices of the j range per block; the block evaluates a tile of 256 trajectories
+// at t_s into LDS (about 2 flop per pair of redundant work, no scratch buffer in HBM) and every lane scans its slice of it.
+constexpr int kSafI = 32, kSafS = 8, kSafT = kSafI * kSafS;
+
+// position (float32, as State holds it) of the trajectory xq at time t
+__device__ __forceinline__ void position_at(int M, int dim, double dt, double t, double z_2d, const double* xq, float (&pos)[3]) {
+    const int P = 6 * M;
+    int ms = -1;
+    double tn = 0, end = 0;
+    for (int idx = 0; idx < M; idx++) {  // getPointAt's segment search (src/trajectory.cpp:121-136)
+        end += dt;
+        if (t < end) {
+            ms = idx;
+            tn = 1 - (end - t) / dt;
+            break;
+        }
+    }
+    if (ms < 0) {
+        ms = M - 1;
+        tn = 1.0;
+    }
+    for (int k = 0; k < 3; k++) {
+        double c[6];
+        for (int i = 0; i < 6; i++) c[i] = (k < dim) ? (double)(float)xq[k * P + 6 * ms + i] : (double)(float)z_2d;
+        pos[k] = (float)bern<5>(c, tn);
+    }
+}
+
+__global__ __launch_bounds__(kSafT) void safety_metrics_kernel(int M, int dim, double dt, int64_t n_agents, int64_t first_agent,
+                                                               int64_t n_total, int n_samples, double record_time_step, double z_2d,
+                                                               const double* __restrict__ x_all, const double* __restrict__ radius,
+                                                               const double* __restrict__ downwash,
+                                                               const lscqp_header* __restrict__ hdr, lscqp_safety* __restrict__ out) {
+    __shared__ float tp[kSafT][3];
+    __shared__ double tr[kSafT], tdr[kSafT];  // r_j, downwash_j * r_j
+    __shared__ double red_v[kSafT];
+    __shared__ int64_t red_k[kSafT];
+    const int li = threadIdx.x % kSafI, slice = threadIdx.x / kSafI;
+    const int64_t a = (int64_t)blockIdx.x * kSafI + li;
+    const bool live = a < n_agents;
+    const int64_t gi = first_agent + (live ? a : 0);
+    const int nv = dim * 6 * M;
+    const double ri = radius[gi], dri = downwash[gi] * ri;
+    double best = 1e300;
+    int64_t best_key = INT64_MAX;  // (sample, j): the reference keeps the first strict minimum in this order
+    double vex[3] = {0, 0, 0}, aex[3] = {0, 0, 0};
+    for (int s = 0; s < n_samples; s++) {
+        const double t = s * record_time_step;
+        float pi[3];
+        position_at(M, dim, dt, t, z_2d, x_all + gi * nv, pi);
+        if (slice == 0 && live) {  // velocity / acceleration excess at t (:560-572)
+            const double* xq = x_all + gi * nv;
+            const int P = 6 * M;
+            int ms = M - 1;
+            double tn = 1.0, end = 0;
+            for (int idx = 0; idx < M; idx++) {
+                end += dt;
+                if (t < end) {
+                    ms = idx;
+                    tn = 1 - (end - t) / dt;
+                    break;
+                }
+            }
+            for (int k = 0; k < dim; k++) {
+                double c[6], d1[6] = {0, 0, 0, 0, 0, 0}, d2[6] = {0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < 6; i++) c[i] = (double)(float)xq[k * P + 6 * ms + i];
+                for (int i = 0; i < 5; i++) d1[i] = (c[i + 1] - c[i]) * (5.0 / dt);
+                for (int i = 0; i < 4; i++) d2[i] = (d1[i + 1] - d1[i]) * (4.0 / dt);
+                const double vel = (double)(float)bern<4>(d1, tn), acc = (double)(float)bern<3>(d2, tn);
+                const double ve = (vel - hdr[a].vmax[k]) / hdr[a].vmax[k], ae = (acc - hdr[a].amax[k]) / hdr[a].amax[k];
+                vex[k] = (ve > 0 && ve > vex[k]) ? ve : vex[k];
+                aex[k] = (ae > 0 && ae > aex[k]) ? ae : aex[k];
+            }
+        }
+        for (int64_t tile = 0; tile < n_total; tile += kSafT) {
+            __syncthreads();
+            const int64_t gj = tile + threadIdx.x;
+            if (gj < n_total) {
+                float pj[3];
+                position_at(M, dim, dt, t, z_2d, x_all + gj * nv, pj);
+                tp[threadIdx.x][0] = pj[0], tp[threadIdx.x][1] = pj[1], tp[threadIdx.x][2] = pj[2];
+                tr[threadIdx.x] = radius[gj];
+                tdr[threadIdx.x] = downwash[gj] * tr[threadIdx.x];
+            }
+            __syncthreads();
+            const int cnt = (int)((n_total - tile < kSafT) ? n_total - tile : kSafT);
+            for (int jj = slice; jj < cnt; jj += kSafS) {
+                const int64_t j = tile + jj;
+                const double rsum = ri + tr[jj];
+                const double dwn = (dri + tdr[jj]) / rsum;  // :505-507
+                // point3d delta = p_i - p_j (float); delta.z /= downwash; norm() = sqrt of the float sum of squares
+                const float dx = pi[0] - tp[jj][0], dy = pi[1] - tp[jj][1];
+                const float dz = (float)((double)(pi[2] - tp[jj][2]) / dwn);
+                float nsq;
+                {
+#pragma clang fp contract(off)
+                    nsq = dx * dx + dy * dy + dz * dz;
+                }
+                const double ratio = sqrt((double)nsq) / rsum;
+                const int64_t key = (int64_t)s * n_total + j;
+                const bool take = (j != gi) && (ratio < best || (ratio == best && key < best_key));
+                best = take ? ratio : best;
+                best_key = take ? key : best_key;
+            }
+        }
+    }
+    red_v[threadIdx.x] = best;
+    red_k[threadIdx.x] = best_key;
+    __syncthreads();
+    if (slice == 0 && live) {
+        for (int q = 1; q < kSafS; q++) {
+            const double v = red_v[q * kSafI + li];
+            const int64_t k = red_k[q * kSafI + li];
+            const bool take = v < best || (v == best && k < best_key);
+            best = take ? v : best;
+            best_key = take ? k : best_key;
+        }
+        lscqp_safety R;
+        const bool any = best_key != INT64_MAX;
+        R.safety_ratio = any ? best : INFINITY;  // SP_INFINITY when there is no other agent
+        R.closest_agent = any ? (int32_t)(best_key % n_total) : -1;
+        R.sample = any ? (int32_t)(best_key / n_total) : -1;
+        for (int k = 0; k < 3; k++) {
+            R.vel_excess_ratio[k] = vex[k];
+            R.acc_excess_ratio[k] = aex[k];
+        }
+        out[a] = R;
+    }
+}
+
 }  // namespace lscpost
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
+
+extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
+                                         double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
+                                         const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream) {
+    if (n_agents == 0) return LSCQP_OK;
+    const unsigned blocks = (unsigned)((n_agents + lscpost::kSafI - 1) / lscpost::kSafI);
+    hipLaunchKernelGGL(lscpost::safety_metrics_kernel, dim3(blocks), dim3(lscpost::kSafT), 0, (hipStream_t)stream, M, dim, dt, n_agents,
+                       first_agent, n_total, n_samples, record_time_step, z_2d, d_x_all, d_radius, d_downwash, d_hdr, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
 
 extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const double* d_x,
                                         const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid, double* d_state,

@@ -26,6 +26,9 @@ extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agent
                                        void* stream);
 extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
+extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
+                                         double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
+                                         const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream);
 extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const double* d_x,
                                         const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid, double* d_state,
                                         void* stream);
@@ -313,6 +316,21 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
     LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
 #undef LSCQP_CK
     return LSCQP_OK;
+}
+
+int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_samples,
+                                double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
+                                const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_agents < 0 || first_agent < 0 || n_samples < 0 || n_total < first_agent + n_agents)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes");
+    if (n_agents == 0) return LSCQP_OK;
+    if (!d_x_all || !d_radius || !d_downwash || !d_hdr || !d_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_safety_metrics_raw_(h->desc.M, h->desc.dim, h->desc.dt, n_agents, first_agent, n_total, n_samples, record_time_step, z_2d,
+                                     d_x_all, d_radius, d_downwash, d_hdr, d_out, stream);
 }
 
 int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, double z_2d, const double* d_x,

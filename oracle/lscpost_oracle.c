@@ -10,6 +10,7 @@
  * against the reference's result log (tests/golden/kat_log.json: states at t = 0.1 s and 0.2 s).
  */
 #include <math.h>
+#include <stddef.h>
 
 #include "lscqp_oracle.h"
 
@@ -41,4 +42,52 @@ int orc_validate_step(const orc_class* c, const orc_agent* ag, const orc_box* sf
         }
     }
     return ok;
+}
+
+/*
+ * MultiSyncSimulator::update's safety metrics (reference src/multi_sync_simulator.cpp:486-577) for agents
+ * [first, first + n_agents) of n_total: per agent the minimum over samples t_s = s * step and over the other agents of
+ * ellipsoidalDistance (include/util.hpp:155-159) / (r_i + r_j), the first (sample, j) attaining it, and the positive parts
+ * of the signed velocity / acceleration excess ratios (:560-572).  out: [n_agents][9] = ratio, j, sample, vex[3], aex[3].
+ */
+void orc_safety_metrics(const orc_class* c, int n_agents, int first, int n_total, int n_samples, double step, double z_2d,
+                        const double* x_all, const double* radius, const double* downwash, const orc_agent* ag, double* out) {
+    const int nv = c->dim * c->M * 6;
+    for (int a = 0; a < n_agents; a++) {
+        const int gi = first + a;
+        double best = INFINITY, bj = -1, bs = -1, vex[3] = {0, 0, 0}, aex[3] = {0, 0, 0};
+        for (int s = 0; s < n_samples; s++) {
+            const double t = s * step;
+            double xf[3 * 6 * 16], pi[3] = {0, 0, 0}, vi[3] = {0, 0, 0}, ai[3] = {0, 0, 0};
+            for (int i = 0; i < nv; i++) xf[i] = (double)(float)x_all[(size_t)gi * nv + i];
+            orc_state_at(c, xf, t, pi, vi, ai);
+            if (c->dim == 2) pi[2] = z_2d;
+            for (int k = 0; k < c->dim; k++) {
+                const double ve = ((double)(float)vi[k] - ag[a].vmax[k]) / ag[a].vmax[k];
+                const double ae = ((double)(float)ai[k] - ag[a].amax[k]) / ag[a].amax[k];
+                if (ve > 0 && ve > vex[k]) vex[k] = ve;
+                if (ae > 0 && ae > aex[k]) aex[k] = ae;
+            }
+            for (int j = 0; j < n_total; j++) {
+                if (j == gi) continue;
+                double pj[3] = {0, 0, 0}, vj[3], aj[3];
+                for (int i = 0; i < nv; i++) xf[i] = (double)(float)x_all[(size_t)j * nv + i];
+                orc_state_at(c, xf, t, pj, vj, aj);
+                if (c->dim == 2) pj[2] = z_2d;
+                const double dwn = (downwash[gi] * radius[gi] + downwash[j] * radius[j]) / (radius[gi] + radius[j]);
+                const float dx = (float)pi[0] - (float)pj[0], dy = (float)pi[1] - (float)pj[1];
+                const float dz = (float)((double)((float)pi[2] - (float)pj[2]) / dwn);
+                const float nsq = dx * dx + dy * dy + dz * dz;
+                const double ratio = sqrt((double)nsq) / (radius[gi] + radius[j]);
+                if (ratio < best) {
+                    best = ratio;
+                    bj = j;
+                    bs = s;
+                }
+            }
+        }
+        double* o = &out[(size_t)a * 9];
+        o[0] = best, o[1] = bj, o[2] = bs;
+        for (int k = 0; k < 3; k++) o[3 + k] = vex[k], o[6 + k] = aex[k];
+    }
 }

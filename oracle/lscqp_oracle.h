@@ -136,6 +136,8 @@ int orc_goal_opt(const orc_class* cls, const double* g, const double* w, int n_o
 /* ---- post-solve checks (oracle/lscpost_oracle.c; reference src/traj_planner.cpp:990-1045, src/agent_manager.cpp:29-50) ---- */
 int orc_validate_step(const orc_class* c, const orc_agent* ag, const orc_box* sfc, const double* x, double time_step, double z_2d,
                       double* state9);
+void orc_safety_metrics(const orc_class* c, int n_agents, int first, int n_total, int n_samples, double step, double z_2d,
+                        const double* x_all, const double* radius, const double* downwash, const orc_agent* ag, double* out);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,8 @@ def lib():
         _lib.orc_goal_opt.argtypes = [C.POINTER(OrcClass), dp, dp, C.c_int, C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_double)]
         _lib.orc_validate_step.restype = C.c_int
         _lib.orc_validate_step.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, dp, C.c_double, C.c_double, dp]
+        _lib.orc_safety_metrics.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp,
+                                            C.c_void_p, dp]
         _lib.orc_solve_batch.restype = C.c_int
         _lib.orc_solve_batch.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
@@ -334,3 +336,18 @@ def validate_step(cls, agent, sfc, x, time_step, z_2d=1.0):
     st = np.zeros(9)
     ok = lib().orc_validate_step(C.byref(cls), _vp(ag), _vp(box), _dp(xx), float(time_step), float(z_2d), _dp(st))
     return ok, st
+
+
+def safety_metrics(cls, agents, x_all, radius, downwash, n_samples, step, first=0, z_2d=1.0):
+    """MultiSyncSimulator::update's safety ratio / excess ratios (reference src/multi_sync_simulator.cpp:486-577) for the
+    local agents `agents` (AGENT_DTYPE, ids first..) among x_all (n_total, nv).  Returns (n_agents, 9):
+    ratio, closest j, sample, vel_excess[3], acc_excess[3]."""
+    ag = np.ascontiguousarray(agents, dtype=AGENT_DTYPE)
+    xx = np.ascontiguousarray(x_all, dtype=np.float64)
+    n_total = xx.shape[0]
+    r = np.ascontiguousarray(np.broadcast_to(radius, (n_total,)), dtype=np.float64)
+    dw = np.ascontiguousarray(np.broadcast_to(downwash, (n_total,)), dtype=np.float64)
+    out = np.zeros((ag.shape[0], 9))
+    lib().orc_safety_metrics(C.byref(cls), ag.shape[0], first, n_total, int(n_samples), float(step), float(z_2d), _dp(xx), _dp(r), _dp(dw),
+                             _vp(ag), _dp(out))
+    return out

@@ -68,3 +68,106 @@ def test_gpu_validate_step_matches_oracle(api, oracle, N, M, dim, n_obs, seed):
             # same float32 control points, fp64 Bernstein evaluation on both sides, float32 result: at most one ulp
             assert np.allclose(got_s[q], st, rtol=2e-7, atol=1e-7), (q, got_s[q], st)
         assert got_v.sum() < N and got_v.sum() >= N - (N + 2) // 3
+
+
+# ---- safety metrics (reference src/multi_sync_simulator.cpp:486-577) -----------------------------------------------
+def _const_plans(pos, M, dim):
+    """Plans whose control points all equal `pos` (n, 3): getStateAt(0) returns exactly that position."""
+    n = pos.shape[0]
+    x = np.zeros((n, dim, M, 6))
+    for k in range(dim):
+        x[:, k] = pos[:, k, None, None]
+    return x.reshape(n, -1)
+
+
+def test_safety_ratio_oracle_reproduces_reference_summary(oracle):
+    """The reference's own run: positions of its 10 agents at every logged time (log/simulation_*_LSC_10agents.csv) must
+    give the safety_ratio_agent of its summary CSV (1.02089) and zero velocity / acceleration excess."""
+    g = H.load_golden("sim_log_states")
+    M, dim = 10, 2
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=False, world_min=[-5, -5, 0], world_max=[5, 5, 2.5])
+    ag = np.zeros(10, oracle.AGENT_DTYPE)
+    ag["vmax"], ag["amax"] = g["vmax"], g["amax"]
+    best = np.inf
+    for p in g["pos"]:
+        p = np.array(p)
+        out = oracle.safety_metrics(cls, ag, _const_plans(p, M, dim), g["radius"], g["downwash"], 1, 0.1, z_2d=p[0, 2])
+        best = min(best, out[:, 0].min())
+    # the log prints 6 significant digits -> positions to 5e-6 m -> ratio to ~3e-5
+    assert abs(best - g["summary"]["safety_ratio_agent"]) <= 5e-5, best
+    v, a = np.array(g["vel"]), np.array(g["acc"])
+    assert max(0.0, ((v - g["vmax"]) / g["vmax"]).max()) == g["summary"]["vel_excess_ratio"] == 0.0
+    assert max(0.0, ((a - g["amax"]) / g["amax"]).max()) == g["summary"]["acc_excess_ratio"] == 0.0
+
+
+def test_safety_metrics_oracle_against_numpy(oracle):
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim = 14, 5, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=6, seed=5)
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    b = sw.build()
+    ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, b)
+    R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=4)
+    ag["vmax"][:, 0] = 0.002  # for the metrics only: a limit the plans exceed in +x (the reference's ratio is signed)
+    rad = np.full(N, sw.radius)
+    dwv = np.full(N, sw.downwash)
+    rad[2], dwv[2] = 0.25, 1.2
+    out = oracle.safety_metrics(cls, ag, R["x"], rad, dwv, 3, 0.05)
+    xf = np.float32(R["x"]).astype(np.float64)
+    for a in range(N):
+        best, bkey, vex = np.inf, None, 0.0
+        for s in range(3):
+            pa, va, _ = oracle.state_at(cls, xf[a], s * 0.05)
+            vex = max(vex, (np.float32(va[0]) - 0.002) / 0.002)
+            for j in range(N):
+                if j == a:
+                    continue
+                pj, _, _ = oracle.state_at(cls, xf[j], s * 0.05)
+                dwn = (dwv[a] * rad[a] + dwv[j] * rad[j]) / (rad[a] + rad[j])
+                d = np.float32(pa) - np.float32(pj)
+                d[2] = np.float32(d[2] / dwn)
+                r = np.sqrt(float(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))) / (rad[a] + rad[j])
+                if r < best:
+                    best, bkey = r, (j, s)
+        assert abs(out[a, 0] - best) <= 1e-7 * best and (out[a, 1], out[a, 2]) == bkey
+        assert abs(out[a, 3] - max(vex, 0.0)) <= 1e-6
+    assert out[:, 3].max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,dim,n_obs,first,n_loc,seed", [(64, 5, 3, 12, 0, 64, 3), (300, 5, 3, 8, 100, 77, 4), (10, 10, 2, 9, 0, 10, 2)])
+def test_gpu_safety_metrics_match_oracle(api, oracle, N, M, dim, n_obs, first, n_loc, seed):
+    import torch
+
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed)
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    b = sw.build()
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+    r = sol.solve_host(hdr, rows, off, sfc)
+    x = r["x"]
+    hdr["vmax"][:, 0] = 0.002  # for the metrics only: a limit the plans exceed in +x (the reference's ratio is signed)
+    rad = np.full(N, sw.radius)
+    dwv = np.full(N, sw.downwash)
+    rad[1], dwv[1] = 0.25, 1.2
+    z2d = float(b["p0"][0][2])
+    ag = np.zeros(n_loc, oracle.AGENT_DTYPE)
+    ag["vmax"], ag["amax"] = hdr["vmax"][first:first + n_loc], hdr["amax"][first:first + n_loc]
+    want = oracle.safety_metrics(cls, ag, x, rad, dwv, 2, 0.05, first=first, z_2d=z2d)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_out = torch.zeros(n_loc * api.SAFETY_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    sol.safety_metrics_device(n_loc, first, N, 2, 0.05, torch.from_numpy(x.copy()).to(dev), torch.from_numpy(rad).to(dev),
+                              torch.from_numpy(dwv).to(dev), up(hdr[first:first + n_loc]), d_out, z_2d=z2d)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(api.SAFETY_DTYPE)
+    # same float32 states and float32 distance arithmetic on both sides: the Bernstein evaluation may differ in the last
+    # fp64 bit before the float32 rounding of a position (one float32 ulp of a 10 m coordinate = 1e-6 m)
+    assert np.abs(got["safety_ratio"] - want[:, 0]).max() <= 1e-5
+    same = got["closest_agent"] == want[:, 1].astype(np.int32)
+    assert same.mean() >= 0.98 and (got["sample"][same] == want[same, 2].astype(np.int32)).all()  # exact ties may swap
+    assert np.abs(got["vel_excess_ratio"] - want[:, 3:6]).max() <= 1e-5 and np.abs(got["acc_excess_ratio"] - want[:, 6:9]).max() <= 1e-5
+    assert got["vel_excess_ratio"][:, 0].max() > 0  # the tightened limit is really exceeded somewhere
