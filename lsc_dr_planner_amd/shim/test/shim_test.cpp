@@ -5,6 +5,9 @@
 #include <string>
 #include <goal_optimizer.hpp>
 #include <traj_optimizer.hpp>
+#include <result_csv.hpp>
+#include <iostream>
+#include <vector>
 
 using namespace DynamicPlanning;
 
@@ -237,6 +240,43 @@ static int scenario_goal() {
     return 0;
 }
 
+// result log writer: states from a text file (qn, rows, then rows x qn x (t, p, v, a, planning_time)) -> CSV on stdout,
+// followed by two rows written through writeStep from constant-velocity trajectories
+static int scenario_csv(const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return 2;
+    int qn = 0, rows = 0;
+    if (fscanf(f, "%d %d", &qn, &rows) != 2) return 2;
+    SimulationResultCsv w(std::cout, (size_t)qn);
+    w.writeHeader();
+    for (int r = 0; r < rows; r++) {
+        std::vector<State> st((size_t)qn);
+        std::vector<double> pt((size_t)qn);
+        double t = 0;
+        for (int q = 0; q < qn; q++) {
+            double v[11];
+            for (double& x : v)
+                if (fscanf(f, "%lf", &x) != 1) return 2;
+            t = v[0];
+            st[q].position = point3d((float)v[1], (float)v[2], (float)v[3]);
+            st[q].velocity = point3d((float)v[4], (float)v[5], (float)v[6]);
+            st[q].acceleration = point3d((float)v[7], (float)v[8], (float)v[9]);
+            pt[q] = v[10];
+        }
+        w.writeRow(t, st, pt);
+    }
+    fclose(f);
+    std::vector<traj_t> trajs;
+    for (int q = 0; q < 2; q++) {
+        traj_t tr(5, 5, 0.2);
+        tr.planConstVelTraj(point3d(1.0f + q, 2.0f, 0.5f), point3d(0.5f, 0.0f, -0.25f));
+        trajs.push_back(tr);
+    }
+    SimulationResultCsv w2(std::cout, 2);
+    w2.writeStep(1.0, 0.2, 0.1, trajs, {0.001, 0.002});
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string s = argc > 1 ? argv[1] : "host";
     if (s == "host") return scenario_host();
@@ -244,6 +284,7 @@ int main(int argc, char** argv) {
     if (s == "pair") return scenario_pair();
     if (s == "infeasible") return scenario_infeasible();
     if (s == "goal") return scenario_goal();
+    if (s == "csv" && argc > 2) return scenario_csv(argv[2]);
     fprintf(stderr, "usage: shim_test host|kat|pair|infeasible|goal\n");
     return 2;
 }

@@ -101,3 +101,27 @@ def test_goal_optimizer_through_the_shim(shim_exe):
     assert np.allclose(r["goal"], [np.float32(2.55), 2.5, np.float32(0.6)], rtol=0, atol=1e-6)
     assert np.allclose(r["same"], [2.5, 2.5, np.float32(0.6)], rtol=0, atol=1e-7)
     assert r["thrown"] == "QPFAILED"
+
+
+def test_result_csv_writer_reproduces_reference_log_lines(shim_exe, tmp_path):
+    """SimulationResultCsv (shim/include/result_csv.hpp) against the reference's own result log: the states of its first
+    three logged rows, fed back through the writer, give the log's header and rows character for character
+    (MultiSyncSimulator::saveSimulationResultAsCSV, reference src/multi_sync_simulator.cpp:586-656)."""
+    g = H.load_golden("sim_log_states")
+    p = tmp_path / "states.txt"
+    with open(p, "w") as f:
+        f.write("10 3\n")
+        for r in range(3):
+            for q in range(10):
+                vals = [g["t"][r]] + g["pos"][r][q] + g["vel"][r][q] + g["acc"][r][q] + [g["planning_time"][r][q]]
+                f.write(" ".join(repr(float(v)) for v in vals) + "\n")
+    out = subprocess.run([shim_exe, "csv", str(p)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[:4] == g["raw_lines"]
+    # writeStep: header, then samples at future_time = 0 and 0.1 (< time_step 0.2) of constant-velocity plans, t advancing
+    f4 = [float(v) for v in lines[4].split(",")]
+    want4 = [0, 1, 1, 2, 0.5, 0.5, 0, -0.25, 0, 0, 0, 0.001, 1, 1, 2, 2, 0.5, 0.5, 0, -0.25, 0, 0, 0, 0.002]
+    assert np.abs(np.array(f4) - want4).max() < 1e-4  # float32 second differences leave 1e-5 m/s^2 of rounding noise
+    f5 = lines[5].split(",")
+    assert f5[1] == "1.1" and abs(float(f5[2]) - 1.05) < 1e-6 and abs(float(f5[4]) - 0.475) < 1e-6 and len(lines) == 6
