@@ -281,6 +281,49 @@ int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_
                                 double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
                                 const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream);
 
+/* ---- next row of the path: the producer of the SFC boxes -----------------------------------
+ *
+ * A build-owned voxel map replaces the reference's octomap + DynamicEDTOctomap (both third-party, absent here):
+ *   lscqp_map_create           MapManager::updateOctreeFromCSV (src/map_manager.cpp:262-305): the rows of the world CSV --
+ *                              boxes [n_boxes][6] = centre x,y,z, size x,y,z -- are rasterised exactly as the reference
+ *                              does, over the bounding box world_min .. world_max (DynamicEDTOctomap's, :13-14,74-76),
+ *                              and every voxel gets its nearest occupied cell within max_dist (the reference passes 1.0 m):
+ *                              exact Euclidean distance between cell centres.  Ties between equally near cells, which
+ *                              dynamicEDT3D resolves by propagation order, go to the smallest (dz, dy), then the nearer
+ *                              side with -x first.  HOST pointers; the map lives in HBM.
+ *   lscqp_map_create_from_csv  the same from a world CSV file (the reference's CSVRange loop)
+ *   lscqp_map_info / lscqp_map_download   grid size, first octomap key, and the two fields (for inspection and tests):
+ *                              occ [dims[2]][dims[1]][dims[0]] bytes; nearest, same shape, int32:
+ *                              (dx+128) | (dy+128)<<8 | (dz+128)<<16 | 1<<24, or 0 = none within max_dist
+ * and the corridor of each agent is updated on the device, one wavefront per agent:
+ *   lscqp_construct_sfc_device, mode
+ *     LSCQP_SFC_INIT        CollisionConstraints::initializeSFC (src/collision_constraints.cpp:366-384): all M boxes :=
+ *                           expandSFC of the grid cell around the position; status 0 where the reference throws
+ *     LSCQP_SFC_FROM_HULL   constructSFCFromConvexHull (:414-436; the default launch, goal mode grid_based_planner): boxes
+ *                           shift down by one segment, the last one := expandSFCFromConvexHull of {last point, goal point,
+ *                           next waypoint} (:692-722), else of {last point, goal point} inside the previous box (:724-775),
+ *                           else the previous box (status 0)
+ *     LSCQP_SFC_FROM_POINT  constructSFCFromPoint (:396-412): the last box := expandSFCFromPoint(last point) with the
+ *                           goal-ordered axis candidates (setAxisCand :1134-1170), else the previous box (status 0)
+ *   with isObstacleInSFC (:777-808), isSFCInBoundary (:810-817) and expandSFC (:819-946) in the reference's float32 /
+ *   double arithmetic.  One deviation: where the reference's distance-map query finds no cell within max_dist it measures
+ *   against a phantom cell at the world origin (the default-constructed closest_point, :796-800); here that is "no obstacle".
+ *   d_points [n][3][3]  per agent: position (INIT) or last point of the initial trajectory, current goal point, next waypoint
+ *   d_radius [n]        Agent::radius (the margin)       d_sfc [n][M] boxes, updated in place       d_status_out [n] */
+typedef struct lscqp_map_s* lscqp_map;
+#define LSCQP_SFC_INIT 0
+#define LSCQP_SFC_FROM_HULL 1
+#define LSCQP_SFC_FROM_POINT 2
+int lscqp_map_create(const double* boxes, int64_t n_boxes, const double* world_min, const double* world_max, double resolution,
+                     double max_dist, lscqp_map* out);
+int lscqp_map_create_from_csv(const char* path, const double* world_min, const double* world_max, double resolution,
+                              double max_dist, lscqp_map* out);
+void lscqp_map_destroy(lscqp_map map);
+int lscqp_map_info(lscqp_map map, int32_t* dims, int32_t* key0);
+int lscqp_map_download(lscqp_map map, uint8_t* occ, int32_t* nearest);
+int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map map, int32_t mode, int64_t n, const double* d_points,
+                               const double* d_radius, lscqp_box* d_sfc, int32_t* d_status_out, void* stream);
+
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */
 int lscqp_num_inequalities(lscqp_handle h, int32_t n_obs);

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblscqp.so")
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC = 0, 1, 2, 3
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC = 0, 1, 2
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
+SFC_INIT, SFC_FROM_HULL, SFC_FROM_POINT = 0, 1, 2  # lscqp_construct_sfc_device modes
 GEN_LSC, GEN_CLSC, GEN_BVC = 0, 1, 2  # lscqp_generate_constraints_device modes (include/lscqp.h)
 
 HEADER_DTYPE = np.dtype([
@@ -96,6 +97,18 @@ def lib():
         L.lscqp_optimize_goal.argtypes = [vp, C.c_int64] + [vp] * 5
         L.lscqp_safety_metrics_device.restype = C.c_int
         L.lscqp_safety_metrics_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double] + [vp] * 6
+        L.lscqp_map_create.restype = C.c_int
+        L.lscqp_map_create.argtypes = [vp, C.c_int64, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+        L.lscqp_map_create_from_csv.restype = C.c_int
+        L.lscqp_map_create_from_csv.argtypes = [C.c_char_p, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+        L.lscqp_map_destroy.restype = None
+        L.lscqp_map_destroy.argtypes = [vp]
+        L.lscqp_map_info.restype = C.c_int
+        L.lscqp_map_info.argtypes = [vp, vp, vp]
+        L.lscqp_map_download.restype = C.c_int
+        L.lscqp_map_download.argtypes = [vp, vp, vp]
+        L.lscqp_construct_sfc_device.restype = C.c_int
+        L.lscqp_construct_sfc_device.argtypes = [vp, vp, C.c_int32, C.c_int64] + [vp] * 5
         L.lscqp_validate_step_device.restype = C.c_int
         L.lscqp_validate_step_device.argtypes = [vp, C.c_int64, C.c_double, C.c_double] + [vp] * 6
         L.lscqp_last_error.restype = C.c_char_p
@@ -106,7 +119,8 @@ def lib():
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_generate_constraints_device",
-                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_safety_metrics_device",
+                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
+                    "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
 
 
@@ -129,6 +143,49 @@ def pack_rows(lsc):
     out["nx"], out["ny"], out["nz"] = lsc["nrm"][..., 0], lsc["nrm"][..., 1], lsc["nrm"][..., 2]
     out["b"] = lsc["d"] + (lsc["nrm"] * lsc["p"]).sum(-1)
     return out
+
+
+class WorldMap:
+    """The voxel map of the corridor construction (lscqp_map): world boxes (n, 6) = centre xyz, size xyz -- the rows of the
+    reference's world CSV -- or the CSV file itself; lives in HBM."""
+
+    def __init__(self, boxes=None, world_min=(-5, -5, 0), world_max=(5, 5, 2.5), resolution=0.1, max_dist=1.0, csv_path=None):
+        wmin = np.ascontiguousarray(world_min, dtype=np.float64)
+        wmax = np.ascontiguousarray(world_max, dtype=np.float64)
+        h = C.c_void_p()
+        if csv_path is not None:
+            rc = lib().lscqp_map_create_from_csv(os.fsencode(csv_path), wmin.ctypes.data_as(C.c_void_p), wmax.ctypes.data_as(C.c_void_p),
+                                                 float(resolution), float(max_dist), C.byref(h))
+        else:
+            b = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+            rc = lib().lscqp_map_create(b.ctypes.data_as(C.c_void_p), b.shape[0], wmin.ctypes.data_as(C.c_void_p),
+                                        wmax.ctypes.data_as(C.c_void_p), float(resolution), float(max_dist), C.byref(h))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        self._h = h
+        dims, key0 = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        lib().lscqp_map_info(self._h, dims.ctypes.data_as(C.c_void_p), key0.ctypes.data_as(C.c_void_p))
+        self.dims, self.key0 = dims, key0
+
+    def download(self):
+        """(occ uint8, nearest int32), both shaped (dims[2], dims[1], dims[0])."""
+        shape = (int(self.dims[2]), int(self.dims[1]), int(self.dims[0]))
+        occ, near = np.zeros(shape, np.uint8), np.zeros(shape, np.int32)
+        rc = lib().lscqp_map_download(self._h, occ.ctypes.data_as(C.c_void_p), near.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        return occ, near
+
+    def close(self):
+        if self._h:
+            lib().lscqp_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Solver:
@@ -250,6 +307,17 @@ class Solver:
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         rc = lib().lscqp_safety_metrics_device(self._h, n_agents, first_agent, n_total, int(n_samples), float(record_time_step), float(z_2d),
                                                p(d_x_all), p(d_radius), p(d_downwash), p(d_hdr), p(d_out), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def construct_sfc_device(self, world_map, mode, n, d_points, d_radius, d_sfc, d_status, stream=None):
+        """Corridor update of n agents on the device (SFC_INIT / SFC_FROM_HULL / SFC_FROM_POINT, see include/lscqp.h)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        rc = lib().lscqp_construct_sfc_device(self._h, world_map._h, int(mode), n, p(d_points), p(d_radius), p(d_sfc), p(d_status),
+                                              C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

@@ -68,6 +68,11 @@ def build(force=False, verbose=False, jobs=None):
     goal_src = os.path.join(CSRC, "lscgoal.hip")
     if force or _newer(goal_o, hdrs + [goal_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", goal_src, "-o", goal_o])
+    sfc_o = os.path.join(OBJ, "lscsfc.o")
+    objs.append(sfc_o)
+    sfc_src = os.path.join(CSRC, "lscsfc.hip")
+    if force or _newer(sfc_o, hdrs + [sfc_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", sfc_src, "-o", sfc_o])
     gen_o = os.path.join(OBJ, "lscgen.o")
     objs.append(gen_o)
     gen_src = os.path.join(CSRC, "lscgen.hip")

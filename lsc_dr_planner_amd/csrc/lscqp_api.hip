@@ -29,6 +29,8 @@ extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_hea
 extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
                                          double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
                                          const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream);
+extern "C" int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius,
+                                        lscqp_box* d_sfc, int32_t* d_status_out, void* stream);
 extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const double* d_x,
                                         const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid, double* d_state,
                                         void* stream);
@@ -331,6 +333,21 @@ int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     return lscqp_safety_metrics_raw_(h->desc.M, h->desc.dim, h->desc.dt, n_agents, first_agent, n_total, n_samples, record_time_step, z_2d,
                                      d_x_all, d_radius, d_downwash, d_hdr, d_out, stream);
+}
+
+int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map mp, int32_t mode, int64_t n, const double* d_points, const double* d_radius,
+                               lscqp_box* d_sfc, int32_t* d_status_out, void* stream) {
+    if (!h || !mp) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (mode != LSCQP_SFC_INIT && mode != LSCQP_SFC_FROM_HULL && mode != LSCQP_SFC_FROM_POINT)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "mode must be LSCQP_SFC_INIT, LSCQP_SFC_FROM_HULL or LSCQP_SFC_FROM_POINT");
+    if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (n == 0) return LSCQP_OK;
+    if (!d_points || !d_radius || !d_sfc || !d_status_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    if (h->desc.M > 21) return fail(LSCQP_ERR_UNSUPPORTED, "corridor shift supports M <= 21");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_construct_sfc_raw_(mp, mode, h->desc.M, n, d_points, d_radius, d_sfc, d_status_out, stream);
 }
 
 int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, double z_2d, const double* d_x,

@@ -1,0 +1,535 @@
+// lscsfc.hip — safe-flight-corridor construction on the device, gfx950 only: the producer of the boxes
+// (lscqp_box) the trajectory QP and the goal LP consume.  C ABI in include/lscqp.h.
+//
+// Replaces, on a build-owned voxel map (no octomap, no dynamicEDT3D),
+//   MapManager::updateOctreeFromCSV                reference src/map_manager.cpp:262-305 (world CSV boxes -> occupied cells)
+//   DynamicEDTOctomap (maxdist 1.0 m, :13-14,74-76)  the nearest occupied cell of every voxel
+//   CollisionConstraints::isObstacleInSFC / isSFCInBoundary / expandSFC (both orders) / setAxisCand
+//                                                  src/collision_constraints.cpp:777-946, 1134-1170
+//   expandSFCFromPoint / expandSFCFromConvexHull   :666-775
+//   initializeSFC / constructSFCFromPoint / constructSFCFromConvexHull   :366-436
+// Not a translation: the reference grows one box per agent on the CPU, asking an octree-backed distance map point by
+// point.  Here the map is a dense voxel grid in HBM (1 B occupancy + 4 B nearest-cell code per voxel; 288 GB holds
+// kilometre-scale worlds at 0.1 m), its nearest-cell field is built by three separable passes (exact Euclidean, 3 x (2R+1)
+// reads per voxel instead of (2R+1)^3), and one wavefront owns one agent's corridor: the box state is wave-uniform, the
+// lanes test the sample points of a slab in parallel and vote (ballot), so a slab test costs ceil(points / 64) steps.
+//
+// Arithmetic: boxes and points are octomap::point3d (float) in the reference; every statement below keeps float where
+// the reference stores a point3d component and double where it computes in double, and the file is compiled without
+// FMA contraction, so box coordinates come out bit-identical to the CPU restatement (oracle/lscsfc_oracle.c).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lscqp.h"
+
+#pragma clang fp contract(off)
+
+extern "C" int lscqp_set_error_(int code, const char* msg);  // lscqp_api.hip
+
+struct lscqp_map_s {
+    double res;
+    float world_min[3], world_max[3];
+    int key0[3], dims[3];
+    int radius_cells;
+    uint8_t* d_occ;
+    int32_t* d_nearest;
+};
+
+namespace lscsfc {
+
+struct MapView {
+    double res;
+    float world_min[3], world_max[3];
+    int key0[3], dims[3];
+    const int32_t* nearest;
+};
+
+__host__ __device__ inline int key_of(double coord, double res) { return (int)floor((1.0 / res) * coord); }  // coordToKey
+
+// ---- map construction ----------------------------------------------------------------------------------------------
+// one block per world box: its cells [round((c - s/2)/res), round((c + s/2)/res)) per axis (updateOctreeFromCSV)
+__global__ void rasterise_kernel(const double* __restrict__ boxes, double res, int kx0, int ky0, int kz0, int nx, int ny, int nz,
+                                 uint8_t* __restrict__ occ) {
+    const double* b = boxes + 6 * (int64_t)blockIdx.x;
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        const float com = (float)b[k], size = (float)b[3 + k];
+        lo[k] = (int)round((com - 0.5 * size) / res);
+        hi[k] = (int)round((com + 0.5 * size) / res);
+    }
+    const int ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    if (ex <= 0 || ey <= 0 || ez <= 0) return;
+    const int64_t total = (int64_t)ex * ey * ez;
+    for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
+        const int x = lo[0] + (int)(t % ex) - kx0, y = lo[1] + (int)((t / ex) % ey) - ky0, z = lo[2] + (int)(t / ((int64_t)ex * ey)) - kz0;
+        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+        occ[((int64_t)z * ny + y) * nx + x] = 1;
+    }
+}
+
+constexpr int kNone = 127;  // "no occupied cell within R in this row / plane"
+
+// pass X: nearest occupied cell of the voxel's own row, |dx| <= R, the negative side first on ties
+__global__ void nearest_x_kernel(int nx, int64_t nvox, int R, const uint8_t* __restrict__ occ, int8_t* __restrict__ dxo) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int x = (int)(v % nx);
+    const uint8_t* row = occ + (v - x);
+    int best = kNone;
+    for (int ad = 0; ad <= R; ad++) {
+        if (x - ad >= 0 && row[x - ad]) {
+            best = -ad;
+            break;
+        }
+        if (ad > 0 && x + ad < nx && row[x + ad]) {
+            best = ad;
+            break;
+        }
+    }
+    dxo[v] = (int8_t)best;
+}
+
+// pass Y: over the rows y + dy of the voxel's plane, ascending dy, strict improvement
+__global__ void nearest_y_kernel(int nx, int ny, int64_t nvox, int R, const int8_t* __restrict__ dxi, int8_t* __restrict__ dxo,
+                                 int8_t* __restrict__ dyo) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int y = (int)((v / nx) % ny);
+    int best = R * R + 1, bx = kNone, by = 0;
+    for (int dy = -R; dy <= R; dy++) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= ny) continue;
+        const int dx = dxi[v + (int64_t)dy * nx];
+        if (dx == kNone) continue;
+        const int d2 = dx * dx + dy * dy;
+        if (d2 < best) {
+            best = d2;
+            bx = dx;
+            by = dy;
+        }
+    }
+    dxo[v] = (int8_t)bx;
+    dyo[v] = (int8_t)by;
+}
+
+// pass Z: over the planes z + dz, ascending dz, strict improvement; writes the packed code
+__global__ void nearest_z_kernel(int nx, int ny, int nz, int64_t nvox, int R, const int8_t* __restrict__ dxi,
+                                 const int8_t* __restrict__ dyi, int32_t* __restrict__ out) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvox) return;
+    const int64_t plane = (int64_t)nx * ny;
+    const int z = (int)(v / plane);
+    int best = R * R + 1, bx = 0, by = 0, bz = 0, found = 0;
+    for (int dz = -R; dz <= R; dz++) {
+        const int zz = z + dz;
+        if (zz < 0 || zz >= nz) continue;
+        const int dx = dxi[v + dz * plane];
+        if (dx == kNone) continue;
+        const int dy = dyi[v + dz * plane];
+        const int d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < best) {
+            best = d2;
+            bx = dx, by = dy, bz = dz;
+            found = 1;
+        }
+    }
+    out[v] = found ? (((bx + 128) & 255) | (((by + 128) & 255) << 8) | (((bz + 128) & 255) << 16) | (1 << 24)) : 0;
+}
+
+// ---- corridor construction: one wavefront per agent -------------------------------------------------------------------
+struct BoxF {
+    float lo[3], hi[3];
+};
+
+// isObstacleInSFC (:777-808): lanes take the sample points of the box in turn and vote
+__device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
+    const double res = mp.res;
+    const float delta = (float)(0.5 * res);
+    int n[3];
+    for (int k = 0; k < 3; k++) n[k] = (int)floor(((double)(b.hi[k] - b.lo[k]) + 1e-5) / res) + 1;
+    // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
+    const int64_t total = (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) ? 0 : (int64_t)n[0] * n[1] * n[2];
+    const int lane = threadIdx.x;
+    for (int64_t base = 0; base < total; base += 64) {
+        const int64_t idx = base + lane;
+        bool hit = false;
+        if (idx < total) {
+            const int it[3] = {(int)(idx / ((int64_t)n[1] * n[2])), (int)((idx / n[2]) % n[1]), (int)(idx % n[2])};
+            float p[3];
+            int v[3];
+            bool inside = true;
+            for (int k = 0; k < 3; k++) {
+                p[k] = (float)((double)b.lo[k] + (double)it[k] * res);  // search_point(i) = box_min(i) + iter * res
+                v[k] = key_of((double)p[k], res) - mp.key0[k];          // worldToMap
+                inside = inside && v[k] >= 0 && v[k] < mp.dims[k];
+            }
+            if (inside) {
+                const int code = mp.nearest[((int64_t)v[2] * mp.dims[1] + v[1]) * mp.dims[0] + v[0]];
+                if (code >> 24) {
+                    const int off[3] = {(code & 255) - 128, ((code >> 8) & 255) - 128, ((code >> 16) & 255) - 128};
+                    double dist = 0;
+                    for (int k = 0; k < 3; k++) {
+                        // keyToCoord: cell centre (key + 0.5) res as float; closest point of the cell box; L-infinity distance
+                        const float c = (float)(((double)(v[k] + off[k] + mp.key0[k]) + 0.5) * res);
+                        const float cmin = c - delta, cmax = c + delta;
+                        const float q = p[k] < cmin ? cmin : (p[k] > cmax ? cmax : p[k]);
+                        const double dk = fabs((double)(q - p[k]));
+                        dist = dist < dk ? dk : dist;
+                    }
+                    hit = dist < margin + 1e-5;
+                }
+            }
+        }
+        if (__ballot(hit) != 0ull) return true;
+    }
+    return false;
+}
+
+__device__ bool in_boundary(const MapView& mp, const BoxF& b, double margin) {  // :810-817
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+        ok = ok && ((double)b.lo[k] > (double)mp.world_min[k] + margin - 1e-5);
+        ok = ok && ((double)b.hi[k] < (double)mp.world_max[k] - margin + 1e-5);
+    }
+    return ok;
+}
+
+__device__ void axis_order(const BoxF& b, const float* goal, int* cand) {  // setAxisCand :1134-1170
+    int offsets[3], order[3], cnt = 0;
+    double values[3];
+    for (int k = 0; k < 3; k++) {
+        const float mid = (b.lo[k] + b.hi[k]) * 0.5f;
+        const float d = goal[k] - mid;
+        offsets[k] = d > 0 ? 3 : 0;
+        values[k] = fabs((double)d);
+    }
+    double max_value = -1, min_value = 1e9;
+    for (int i = 0; i < 3; i++) {
+        int pos;
+        if (values[i] > max_value) {
+            pos = 0;
+            max_value = values[i];
+        } else if (values[i] < min_value) {
+            pos = cnt;
+            min_value = values[i];
+        } else {
+            pos = 1;
+        }
+        for (int j = cnt; j > pos; j--) order[j] = order[j - 1];
+        order[pos] = i;
+        cnt++;
+    }
+    for (int i = 0; i < 3; i++) {
+        cand[i] = order[i] + offsets[order[i]];
+        cand[5 - i] = order[i] + (3 - offsets[order[i]]);
+    }
+}
+
+// expandSFC (:819-881 without goal, :883-946 with it)
+__device__ bool expand_sfc(const MapView& mp, const BoxF& initial, const float* goal, double margin, BoxF& out) {
+    if (obstacle_in(mp, initial, margin)) return false;
+    int cand[6] = {0, 1, 2, 3, 4, 5}, ncand = 6;
+    if (goal) axis_order(initial, goal, cand);
+    const double res = mp.res;
+    BoxF sfc = initial, sfc_cand, sfc_update;
+    int i = -1;
+    while (ncand > 0) {
+        sfc_cand = sfc;
+        sfc_update = sfc;
+        while (in_boundary(mp, sfc_update, 0) && !obstacle_in(mp, sfc_update, margin)) {
+            i++;
+            if (i >= ncand) i = 0;
+            const int axis = cand[i];
+            sfc = sfc_cand;
+            sfc_update = sfc_cand;
+            for (int k = 0; k < 3; k++) {  // indexed by a loop so the boxes stay in registers
+                if (axis == k) {
+                    sfc_update.hi[k] = sfc_cand.lo[k];
+                    sfc_cand.lo[k] = (float)((double)sfc_cand.lo[k] - res);
+                    sfc_update.lo[k] = sfc_cand.lo[k];
+                }
+                if (axis == k + 3) {
+                    sfc_update.lo[k] = sfc_cand.hi[k];
+                    sfc_cand.hi[k] = (float)((double)sfc_cand.hi[k] + res);
+                    sfc_update.hi[k] = sfc_cand.hi[k];
+                }
+            }
+        }
+        if (i < 0) return false;  // initial box outside the world: the reference erases begin() - 1 here (undefined)
+        for (int j = 0; j < 5; j++) cand[j] = (j >= i) ? cand[j + 1] : cand[j];
+        ncand--;
+        i = (i > 0) ? i - 1 : ncand - 1;
+    }
+    const double delta = margin - ((int)(margin / res) * res);  // margin compensation, :868-877
+    for (int k = 0; k < 3; k++) {
+        if ((double)sfc.lo[k] > (double)mp.world_min[k] + 1e-5) sfc.lo[k] = (float)((double)sfc.lo[k] - delta);
+        if ((double)sfc.hi[k] < (double)mp.world_max[k] - 1e-5) sfc.hi[k] = (float)((double)sfc.hi[k] + delta);
+    }
+    out = sfc;
+    return true;
+}
+
+__device__ bool point_in(const BoxF& b, const float* p) {  // Box::isPointInBox :81-88
+    bool ok = true;
+    for (int k = 0; k < 3; k++) ok = ok && ((double)p[k] > (double)b.lo[k] - 1e-5) && ((double)p[k] < (double)b.hi[k] + 1e-5);
+    return ok;
+}
+
+__device__ void clip_to_prev(const BoxF& prev, BoxF& ini, double res) {  // :677-685, :762-770
+    if (!(point_in(prev, ini.lo) && point_in(prev, ini.hi))) {
+        for (int k = 0; k < 3; k++) {
+            const float lo = prev.lo[k] > ini.lo[k] ? prev.lo[k] : ini.lo[k];
+            const float hi = prev.hi[k] < ini.hi[k] ? prev.hi[k] : ini.hi[k];
+            ini.lo[k] = (float)(ceil(((double)lo - 1e-5) / res) * res);
+            ini.hi[k] = (float)(floor(((double)hi + 1e-5) / res) * res);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void construct_sfc_kernel(MapView mp, int mode, int M, int64_t n, const double* __restrict__ pts,
+                                                           const double* __restrict__ radius, lscqp_box* __restrict__ sfc,
+                                                           int32_t* __restrict__ status) {
+    const int64_t a = blockIdx.x;
+    if (a >= n) return;
+    const double res = mp.res;
+    const double margin = radius[a];
+    float P[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) P[i][k] = (float)pts[9 * a + 3 * i + k];
+    lscqp_box* S = sfc + a * M;
+    BoxF ini, out, prev;
+    bool ok;
+    if (mode == LSCQP_SFC_INIT) {  // initializeSFC :366-384
+        for (int k = 0; k < 3; k++) {
+            ini.lo[k] = (float)(floor((double)P[0][k] / res) * res);
+            ini.hi[k] = (float)(ceil((double)P[0][k] / res) * res);
+        }
+        ok = expand_sfc(mp, ini, nullptr, margin, out);
+        if (ok)
+            for (int t = threadIdx.x; t < M * 6; t += 64) {
+                const int m = t / 6, c = t % 6;
+                double val = 0;
+                for (int k = 0; k < 3; k++) {
+                    val = (c == k) ? (double)out.lo[k] : val;
+                    val = (c == k + 3) ? (double)out.hi[k] : val;
+                }
+                (c < 3 ? S[m].bmin[c] : S[m].bmax[c - 3]) = val;
+            }
+        if (threadIdx.x == 0) status[a] = ok ? 1 : 0;
+        return;
+    }
+    for (int k = 0; k < 3; k++) prev.lo[k] = (float)S[M - 1].bmin[k], prev.hi[k] = (float)S[M - 1].bmax[k];
+    if (mode == LSCQP_SFC_FROM_HULL) {  // constructSFCFromConvexHull :414-436
+        for (int k = 0; k < 3; k++) {   // hull + next waypoint, aligned by round() (:692-722)
+            float mn = P[0][k], mx = P[0][k];
+            for (int i = 1; i < 3; i++) {
+                mn = P[i][k] < mn ? P[i][k] : mn;
+                mx = P[i][k] > mx ? P[i][k] : mx;
+            }
+            ini.lo[k] = (float)(round((double)mn / res) * res);
+            ini.hi[k] = (float)(round((double)mx / res) * res);
+        }
+        ok = expand_sfc(mp, ini, nullptr, margin, out);
+        if (ok) {  // isSuperSetOfConvexHull :135-150
+            for (int k = 0; k < 3; k++) {
+                float mn = P[0][k], mx = P[0][k];
+                for (int i = 1; i < 3; i++) {
+                    mn = P[i][k] < mn ? P[i][k] : mn;
+                    mx = P[i][k] > mx ? P[i][k] : mx;
+                }
+                ok = ok && !((double)mn < (double)out.lo[k] - 1e-5 || (double)mx > (double)out.hi[k] + 1e-5);
+            }
+        }
+        if (!ok) {  // the hull alone, inside the previous box, aligned outwards (:724-775)
+            for (int k = 0; k < 3; k++) {
+                const float mn = P[0][k] < P[1][k] ? P[0][k] : P[1][k], mx = P[0][k] > P[1][k] ? P[0][k] : P[1][k];
+                ini.lo[k] = (float)(floor((double)mn / res) * res);
+                ini.hi[k] = (float)(ceil((double)mx / res) * res);
+            }
+            clip_to_prev(prev, ini, res);
+            ok = expand_sfc(mp, ini, nullptr, margin, out);
+        }
+    } else {  // constructSFCFromPoint :396-412, expandSFCFromPoint :666-690
+        for (int k = 0; k < 3; k++) {
+            ini.lo[k] = (float)(floor((double)P[0][k] / res) * res);
+            ini.hi[k] = (float)(ceil((double)P[0][k] / res) * res);
+        }
+        clip_to_prev(prev, ini, res);
+        ok = expand_sfc(mp, ini, P[1], margin, out);
+    }
+    // sfcs[m] = sfcs[m + 1] for m < M - 1, then the new (or the kept) last box.  Every lane moves whole elements; the
+    // values were all read before any is overwritten only if the shift is staged, so stage it in registers.
+    double stage[2];
+    int cnt = 0;
+    for (int t = threadIdx.x; t < (M - 1) * 6; t += 64, cnt++) {
+        const int m = t / 6, c = t % 6;
+        stage[cnt] = c < 3 ? S[m + 1].bmin[c] : S[m + 1].bmax[c - 3];
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int t = threadIdx.x; t < (M - 1) * 6; t += 64, cnt++) {
+        const int m = t / 6, c = t % 6;
+        (c < 3 ? S[m].bmin[c] : S[m].bmax[c - 3]) = stage[cnt];
+    }
+    if (ok && threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        double val = 0;
+        for (int k = 0; k < 3; k++) {
+            val = (c == k) ? (double)out.lo[k] : val;
+            val = (c == k + 3) ? (double)out.hi[k] : val;
+        }
+        (c < 3 ? S[M - 1].bmin[c] : S[M - 1].bmax[c - 3]) = val;
+    }
+    if (threadIdx.x == 0) status[a] = ok ? 1 : 0;
+}
+
+}  // namespace lscsfc
+
+#define LSCSFC_HIP(call)                                                                                              \
+    do {                                                                                                              \
+        const hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string(#call ": ") + hipGetErrorString(e_)).c_str()); \
+    } while (0)
+
+extern "C" {
+
+int lscqp_map_create(const double* boxes, int64_t n_boxes, const double* world_min, const double* world_max, double resolution,
+                     double max_dist, lscqp_map* out) {
+    if (!out || !world_min || !world_max || (n_boxes > 0 && !boxes) || n_boxes < 0)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(resolution > 0) || !(max_dist >= 0)) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "resolution must be > 0, max_dist >= 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    lscqp_map_s* mp = new lscqp_map_s();
+    mp->res = resolution;
+    int64_t nvox = 1;
+    for (int k = 0; k < 3; k++) {
+        mp->world_min[k] = (float)world_min[k];
+        mp->world_max[k] = (float)world_max[k];
+        mp->key0[k] = lscsfc::key_of((double)mp->world_min[k], resolution);  // DynamicEDTOctomap bounding box keys
+        mp->dims[k] = lscsfc::key_of((double)mp->world_max[k], resolution) - mp->key0[k] + 1;
+        if (mp->dims[k] <= 0) {
+            delete mp;
+            return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "world_max must not be below world_min");
+        }
+        nvox *= mp->dims[k];
+    }
+    const int R = (int)floor(max_dist / resolution + 1e-9);
+    if (R > 120) {
+        delete mp;
+        return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "max_dist / resolution must be <= 120 cells");
+    }
+    mp->radius_cells = R;
+    mp->d_occ = nullptr;
+    mp->d_nearest = nullptr;
+    double* d_boxes = nullptr;
+    int8_t *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+    auto cleanup = [&]() {
+        if (d_boxes) (void)hipFree(d_boxes);
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        if (d_c) (void)hipFree(d_c);
+    };
+    auto fail = [&](hipError_t e, const char* what) {
+        cleanup();
+        if (mp->d_occ) (void)hipFree(mp->d_occ);
+        if (mp->d_nearest) (void)hipFree(mp->d_nearest);
+        delete mp;
+        return lscqp_set_error_(LSCQP_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&mp->d_occ, nvox)) != hipSuccess) return fail(e, "hipMalloc(occupancy)");
+    if ((e = hipMalloc(&mp->d_nearest, nvox * sizeof(int32_t))) != hipSuccess) return fail(e, "hipMalloc(nearest)");
+    if ((e = hipMalloc(&d_a, nvox)) != hipSuccess || (e = hipMalloc(&d_b, nvox)) != hipSuccess || (e = hipMalloc(&d_c, nvox)) != hipSuccess)
+        return fail(e, "hipMalloc(scratch)");
+    if ((e = hipMemset(mp->d_occ, 0, nvox)) != hipSuccess) return fail(e, "hipMemset");
+    if (n_boxes > 0) {
+        if ((e = hipMalloc(&d_boxes, n_boxes * 6 * sizeof(double))) != hipSuccess) return fail(e, "hipMalloc(boxes)");
+        if ((e = hipMemcpy(d_boxes, boxes, n_boxes * 6 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(boxes)");
+        hipLaunchKernelGGL(lscsfc::rasterise_kernel, dim3((unsigned)n_boxes), dim3(256), 0, 0, d_boxes, resolution, mp->key0[0], mp->key0[1],
+                           mp->key0[2], mp->dims[0], mp->dims[1], mp->dims[2], mp->d_occ);
+    }
+    const unsigned blocks = (unsigned)((nvox + 255) / 256);
+    hipLaunchKernelGGL(lscsfc::nearest_x_kernel, dim3(blocks), dim3(256), 0, 0, mp->dims[0], nvox, R, mp->d_occ, d_a);
+    hipLaunchKernelGGL(lscsfc::nearest_y_kernel, dim3(blocks), dim3(256), 0, 0, mp->dims[0], mp->dims[1], nvox, R, d_a, d_b, d_c);
+    hipLaunchKernelGGL(lscsfc::nearest_z_kernel, dim3(blocks), dim3(256), 0, 0, mp->dims[0], mp->dims[1], mp->dims[2], nvox, R, d_b, d_c,
+                       mp->d_nearest);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "map kernels");
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "map kernels");
+    cleanup();
+    *out = mp;
+    return LSCQP_OK;
+}
+
+int lscqp_map_create_from_csv(const char* path, const double* world_min, const double* world_max, double resolution, double max_dist,
+                              lscqp_map* out) {
+    if (!path) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null path");
+    FILE* f = fopen(path, "r");
+    if (!f) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, (std::string("cannot open world file ") + path).c_str());
+    std::vector<double> boxes;
+    char line[4096];
+    while (fgets(line, sizeof line, f)) {  // rows: centre x,y,z, size x,y,z; a row with fewer than two fields ends the list (:267-269)
+        double v[6];
+        int cnt = 0;
+        char* s = line;
+        while (cnt < 6) {
+            char* end = nullptr;
+            const double x = strtod(s, &end);
+            if (end == s) break;
+            v[cnt++] = x;
+            s = end;
+            while (*s == ',' || *s == ' ' || *s == '\t') s++;
+        }
+        if (cnt < 2) break;
+        if (cnt < 6) {
+            fclose(f);
+            return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "world CSV row with fewer than 6 fields");
+        }
+        boxes.insert(boxes.end(), v, v + 6);
+    }
+    fclose(f);
+    return lscqp_map_create(boxes.data(), (int64_t)(boxes.size() / 6), world_min, world_max, resolution, max_dist, out);
+}
+
+void lscqp_map_destroy(lscqp_map mp) {
+    if (!mp) return;
+    if (mp->d_occ) (void)hipFree(mp->d_occ);
+    if (mp->d_nearest) (void)hipFree(mp->d_nearest);
+    delete mp;
+}
+
+int lscqp_map_info(lscqp_map mp, int32_t* dims, int32_t* key0) {
+    if (!mp || !dims || !key0) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    for (int k = 0; k < 3; k++) dims[k] = mp->dims[k], key0[k] = mp->key0[k];
+    return LSCQP_OK;
+}
+
+int lscqp_map_download(lscqp_map mp, uint8_t* occ, int32_t* nearest) {
+    if (!mp) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null map");
+    const int64_t nvox = (int64_t)mp->dims[0] * mp->dims[1] * mp->dims[2];
+    if (occ) LSCSFC_HIP(hipMemcpy(occ, mp->d_occ, nvox, hipMemcpyDeviceToHost));
+    if (nearest) LSCSFC_HIP(hipMemcpy(nearest, mp->d_nearest, nvox * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return LSCQP_OK;
+}
+
+int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius, lscqp_box* d_sfc,
+                             int32_t* d_status_out, void* stream) {
+    lscsfc::MapView v;
+    v.res = mp->res;
+    for (int k = 0; k < 3; k++) v.world_min[k] = mp->world_min[k], v.world_max[k] = mp->world_max[k], v.key0[k] = mp->key0[k], v.dims[k] = mp->dims[k];
+    v.nearest = mp->d_nearest;
+    hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, v, mode, M, n, d_points, d_radius,
+                       d_sfc, d_status_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
+
+}  // extern "C"

@@ -127,6 +127,25 @@ void orc_generate_mode_pair(int mode, int M, int dim, const double* own, const d
 void orc_generate_mode(int mode, int M, int dim, int n_agents, int n_obs, int first_agent, const double* traj,
                        const int* neighbours, const double* radius, const double* downwash, const double* goal_all, orc_lsc* out);
 
+/* ---- safe flight corridor construction (oracle/lscsfc_oracle.c; reference src/collision_constraints.cpp:366-436, 666-946) ---- */
+typedef struct orc_map {
+    double res;
+    float world_min[3], world_max[3];
+    int key0[3], dims[3]; /* voxel (x, y, z) <-> octomap key - key0; x fastest */
+    int radius_cells;
+    unsigned char* occ;
+    int* nearest; /* per voxel: (dx+128) | (dy+128)<<8 | (dz+128)<<16 | valid<<24 of the nearest occupied cell */
+} orc_map;
+orc_map* orc_map_create(const double* boxes, int n_boxes, const double* world_min, const double* world_max, double res,
+                        double max_dist);
+void orc_map_destroy(orc_map* mp);
+void orc_map_info(const orc_map* mp, int* dims, int* key0);
+const unsigned char* orc_map_occ(const orc_map* mp);
+const int* orc_map_nearest(const orc_map* mp);
+int orc_construct_sfc(const orc_map* mp, int mode, int M, const double* pts, double radius, orc_box* sfc);
+void orc_construct_sfc_batch(const orc_map* mp, int mode, int M, int n, const double* pts, const double* radius, orc_box* sfc,
+                             int* status);
+
 /* ---- goal LP (oracle/lscgoal_oracle.c; reference src/goal_optimizer.cpp:72-147) ---- */
 int orc_goal_rows(const orc_class* cls, const double* g, const double* w, int n_obs, const orc_lsc* lsc, const orc_box* sfc_last,
                   double* a, double* c);

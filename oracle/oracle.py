@@ -53,7 +53,7 @@ _REFERENCE = "/root/reference"
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscmode_oracle.c", "Makefile", "lscqp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscmode_oracle.c", "lscsfc_oracle.c", "Makefile", "lscqp_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
@@ -126,6 +126,15 @@ def lib():
         _lib.orc_validate_step.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, dp, C.c_double, C.c_double, dp]
         _lib.orc_safety_metrics.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp,
                                             C.c_void_p, dp]
+        _lib.orc_map_create.restype = C.c_void_p
+        _lib.orc_map_create.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double]
+        _lib.orc_map_destroy.argtypes = [C.c_void_p]
+        _lib.orc_map_info.argtypes = [C.c_void_p, ip, ip]
+        _lib.orc_map_occ.restype = C.POINTER(C.c_ubyte)
+        _lib.orc_map_occ.argtypes = [C.c_void_p]
+        _lib.orc_map_nearest.restype = ip
+        _lib.orc_map_nearest.argtypes = [C.c_void_p]
+        _lib.orc_construct_sfc_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp, C.c_void_p, ip]
         _lib.orc_solve_batch.restype = C.c_int
         _lib.orc_solve_batch.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
@@ -351,3 +360,46 @@ def safety_metrics(cls, agents, x_all, radius, downwash, n_samples, step, first=
     lib().orc_safety_metrics(C.byref(cls), ag.shape[0], first, n_total, int(n_samples), float(step), float(z_2d), _dp(xx), _dp(r), _dp(dw),
                              _vp(ag), _dp(out))
     return out
+
+
+SFC_INIT, SFC_FROM_HULL, SFC_FROM_POINT = 0, 1, 2
+
+
+class Map:
+    """The occupancy grid + nearest-occupied-cell field of the corridor construction (oracle/lscsfc_oracle.c):
+    boxes (n, 6) = centre xyz, size xyz, the rows of the reference's world CSV (src/map_manager.cpp:262-305)."""
+
+    def __init__(self, boxes, world_min, world_max, res=0.1, max_dist=1.0):
+        b = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        wmin = np.ascontiguousarray(world_min, dtype=np.float64)
+        wmax = np.ascontiguousarray(world_max, dtype=np.float64)
+        self._h = lib().orc_map_create(_dp(b), b.shape[0], _dp(wmin), _dp(wmax), float(res), float(max_dist))
+        dims, key0 = np.zeros(3, np.int32), np.zeros(3, np.int32)
+        lib().orc_map_info(self._h, dims.ctypes.data_as(C.POINTER(C.c_int)), key0.ctypes.data_as(C.POINTER(C.c_int)))
+        self.dims, self.key0, self.res = dims, key0, res
+
+    def occ(self):
+        n = int(np.prod(self.dims))
+        return np.ctypeslib.as_array(lib().orc_map_occ(self._h), shape=(n,)).reshape(self.dims[2], self.dims[1], self.dims[0]).copy()
+
+    def nearest(self):
+        n = int(np.prod(self.dims))
+        return np.ctypeslib.as_array(lib().orc_map_nearest(self._h), shape=(n,)).reshape(self.dims[2], self.dims[1], self.dims[0]).copy()
+
+    def construct_sfc(self, mode, pts, radius, sfc):
+        """Corridor update of n agents: pts (n, 3, 3) = (position | last point, goal point, next waypoint), sfc BOX_DTYPE
+        (n, M) updated in place (mode SFC_INIT fills it).  Returns status (n,): 1 = new box, 0 = previous kept / failure."""
+        P = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 9)
+        n = P.shape[0]
+        assert sfc.dtype == BOX_DTYPE and sfc.flags.c_contiguous and sfc.shape[0] == n
+        r = np.ascontiguousarray(np.broadcast_to(radius, (n,)), dtype=np.float64)
+        st = np.zeros(n, np.int32)
+        lib().orc_construct_sfc_batch(self._h, int(mode), sfc.shape[1], n, _dp(P), _dp(r), sfc.ctypes.data_as(C.c_void_p),
+                                      st.ctypes.data_as(C.POINTER(C.c_int)))
+        return st
+
+    def __del__(self):
+        try:
+            lib().orc_map_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,257 @@
+"""Safe-flight-corridor construction: the oracle restatement (oracle/lscsfc_oracle.c) against the
+face the reference's result log pins and against geometric invariants; the HIP map + construction kernels against the
+oracle, bit for bit; and the chain map -> corridor -> goal LP -> QP against the reference log on the GPU."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+def _forest(oracle):
+    g = H.load_golden("forest10_world")
+    mp = oracle.Map(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
+    return g, mp
+
+
+def _pts(first, second=None, third=None):
+    n = len(first)
+    P = np.zeros((n, 3, 3))
+    P[:, 0] = first
+    P[:, 1] = first if second is None else second
+    P[:, 2] = first if third is None else third
+    return P
+
+
+def _clear_of_obstacles(occ, key0, res, lo, hi, reach):
+    """True if no occupied cell intersects the open box (lo - reach, hi + reach) -- geometry only, no distance map."""
+    nz, ny, nx = occ.shape
+    idx = []
+    for k, n in zip(range(3), (nx, ny, nz)):
+        a = int(np.floor((lo[k] - reach) / res + 1e-6)) - key0[k]       # first cell whose interior reaches above lo - reach
+        b = int(np.ceil((hi[k] + reach) / res - 1e-6)) - key0[k]        # one past the last cell below hi + reach
+        idx.append((max(a, 0), min(b, n)))
+    sub = occ[idx[2][0]:idx[2][1], idx[1][0]:idx[1][1], idx[0][0]:idx[0][1]]
+    return not sub.any()
+
+
+def test_forest10_corridors_pin_and_invariants(oracle):
+    g, mp = _forest(oracle)
+    starts = np.array(g["starts"])
+    n, M = len(starts), 10
+    sfc = np.zeros((n, M), oracle.BOX_DTYPE)
+    st = mp.construct_sfc(oracle.SFC_INIT, _pts(starts), g["radius"], sfc)
+    assert (st == 1).all()
+    # the face the reference's own run pins (agent 1, -x): rasterised obstacle edge 2.4 + margin 0.15
+    a = g["pinned"]["agent"]
+    assert abs(sfc[a, 0]["bmin"][0] - g["pinned"]["value"]) <= 1e-6
+    occ = mp.occ()
+    wmin, wmax = np.array(g["world_min"]), np.array(g["world_max"])
+    for q in range(n):
+        lo, hi = sfc[q, 0]["bmin"], sfc[q, 0]["bmax"]
+        assert (sfc[q]["bmin"] == lo).all() and (sfc[q]["bmax"] == hi).all()  # initializeSFC: all M boxes equal (:381-383)
+        assert (starts[q] > lo - 1e-5).all() and (starts[q] < hi + 1e-5).all()
+        assert (lo >= wmin - 1e-5).all() and (hi <= wmax + 1e-5).all()
+        # an agent (L-infinity radius) whose centre is anywhere in the corridor touches no occupied cell
+        assert _clear_of_obstacles(occ, mp.key0, g["resolution"], lo, hi, g["radius"] - 1e-4), q
+        # maximal: one more cell in any direction that is not the world boundary runs into an obstacle
+        for k in range(3):
+            for side in (0, 1):
+                if (side == 0 and lo[k] <= wmin[k] + 1e-5) or (side == 1 and hi[k] >= wmax[k] - 1e-5):
+                    continue
+                lo2, hi2 = lo.copy(), hi.copy()
+                if side == 0:
+                    lo2[k] -= g["resolution"]
+                else:
+                    hi2[k] += g["resolution"]
+                assert not _clear_of_obstacles(occ, mp.key0, g["resolution"], lo2, hi2, g["radius"] - 1e-4), (q, k, side)
+
+
+def test_map_rasterisation_and_nearest_field(oracle):
+    g, mp = _forest(oracle)
+    occ, near = mp.occ(), mp.nearest()
+    assert tuple(mp.dims) == (101, 101, 26) and tuple(mp.key0) == (-50, -50, 0)
+    # updateOctreeFromCSV: cells round((c - s/2)/res) .. round((c + s/2)/res) - 1 per axis
+    want = np.zeros_like(occ)
+    for b in np.float32(g["boxes"]).astype(np.float64):
+        lo = [int(np.floor((b[k] - 0.5 * b[3 + k]) / 0.1 + 0.5)) for k in range(3)]
+        hi = [int(np.floor((b[k] + 0.5 * b[3 + k]) / 0.1 + 0.5)) for k in range(3)]
+        x0, x1 = max(lo[0] + 50, 0), min(hi[0] + 50, 101)
+        y0, y1 = max(lo[1] + 50, 0), min(hi[1] + 50, 101)
+        want[max(lo[2], 0):min(hi[2], 26), y0:y1, x0:x1] = 1
+    assert np.array_equal(occ, want)
+    # nearest field against scipy's exact Euclidean distance transform (distances; the argmin may differ at ties)
+    from scipy import ndimage
+
+    dist, ind = ndimage.distance_transform_edt(occ == 0, return_indices=True)
+    valid = (near >> 24) & 1
+    off = np.stack([((near >> s) & 255) - 128 for s in (16, 8, 0)], axis=0)  # dz, dy, dx
+    d_mine = np.sqrt((off.astype(np.float64) ** 2).sum(axis=0))
+    assert np.array_equal(valid == 1, dist <= 10.0 + 1e-9)
+    assert np.abs(d_mine[valid == 1] - dist[valid == 1]).max() <= 1e-9
+    zz, yy, xx = np.nonzero(valid)
+    assert occ[zz + off[0][zz, yy, xx], yy + off[1][zz, yy, xx], xx + off[2][zz, yy, xx]].all()  # the code points at an occupied cell
+
+
+def test_corridor_updates_shift_and_contain(oracle):
+    g, mp = _forest(oracle)
+    starts, goals = np.array(g["starts"]), np.array(g["goals"])
+    n, M = len(starts), 5
+    sfc = np.zeros((n, M), oracle.BOX_DTYPE)
+    mp.construct_sfc(oracle.SFC_INIT, _pts(starts), g["radius"], sfc)
+    step = (goals - starts) / np.linalg.norm(goals - starts, axis=1, keepdims=True)
+    for mode in (oracle.SFC_FROM_HULL, oracle.SFC_FROM_POINT):
+        cur = sfc.copy()
+        # make the boxes of a corridor distinguishable, then update with points 0.3 m / 0.5 m ahead
+        for m in range(M):
+            cur["bmax"][:, m, 2] -= 0.1 * m
+        before = cur.copy()
+        last, goal, wp = starts + 0.3 * step, starts + 0.5 * step, starts + 0.5 * step
+        last, goal, wp = (np.float32(v).astype(np.float64) for v in (last, goal, wp))
+        st = mp.construct_sfc(mode, _pts(last, goal, wp), g["radius"], cur)
+        assert np.array_equal(cur[:, :M - 1], before[:, 1:])  # sfcs[m] = sfcs[m + 1] (:400-402, :418-420)
+        for q in range(n):
+            lo, hi = cur[q, M - 1]["bmin"], cur[q, M - 1]["bmax"]
+            if st[q] == 0:
+                assert cur[q, M - 1] == before[q, M - 1]  # "use previous one" (:406-409, :430-433)
+                continue
+            pts = [last[q]] if mode == oracle.SFC_FROM_POINT else [last[q], goal[q]]
+            for p in pts:
+                assert (p > lo - 1e-5).all() and (p < hi + 1e-5).all(), (mode, q)
+        assert st.sum() >= n - 2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _random_world(seed, n_boxes=120):
+    rng = np.random.default_rng(seed)
+    wmin, wmax = np.array([-6.0, -6.0, 0.0]), np.array([6.0, 6.0, 4.0])
+    c = rng.uniform(wmin, wmax, (n_boxes, 3))
+    s = rng.choice([0.3, 0.5, 0.8, 1.2], (n_boxes, 3))
+    return np.concatenate([c, s], axis=1), wmin, wmax
+
+
+@pytest.mark.gpu
+def test_gpu_map_matches_oracle(api, oracle, tmp_path):
+    g = H.load_golden("forest10_world")
+    worlds = [(np.array(g["boxes"]), g["world_min"], g["world_max"])] + [_random_world(3)]
+    for boxes, wmin, wmax in worlds:
+        want = oracle.Map(boxes, wmin, wmax, 0.1, 1.0)
+        got = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+        assert np.array_equal(got.dims, want.dims) and np.array_equal(got.key0, want.key0)
+        occ, near = got.download()
+        assert np.array_equal(occ, want.occ())
+        assert np.array_equal(near, want.nearest())  # separable passes == brute force, including the tie rule
+        # the CSV loader reads what the reference's world files hold
+        p = tmp_path / "world.csv"
+        np.savetxt(p, boxes, delimiter=",", fmt="%.17g")
+        from_csv = api.WorldMap(csv_path=str(p), world_min=wmin, world_max=wmax)
+        assert np.array_equal(from_csv.download()[0], occ)
+        got.close()
+        from_csv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", ["forest10", "random3d"])
+def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world):
+    import torch
+
+    rng = np.random.default_rng(11)
+    if world == "forest10":
+        g = H.load_golden("forest10_world")
+        boxes, wmin, wmax = np.array(g["boxes"]), np.array(g["world_min"]), np.array(g["world_max"])
+        starts = np.concatenate([np.array(g["starts"]), np.c_[rng.uniform(-4.8, 4.8, (150, 2)), np.full(150, 0.6)]])
+        M, dim = 10, 2
+    else:
+        boxes, wmin, wmax = _random_world(5)
+        starts = rng.uniform(wmin + 0.2, wmax - 0.2, (300, 3))
+        M, dim = 5, 3
+    starts = np.float32(starts).astype(np.float64)
+    n = len(starts)
+    radius = np.where(np.arange(n) % 7 == 0, 0.25, 0.15)
+    omap = oracle.Map(boxes, wmin, wmax, 0.1, 1.0)
+    gmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=wmin, world_max=wmax))
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+
+    def gpu(mode, pts, sfc):
+        d_sfc = torch.from_numpy(sfc.view(np.float64).reshape(-1).copy()).to(dev)
+        d_st = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        sol.construct_sfc_device(gmap, mode, n, up(pts.reshape(-1)), up(radius), d_sfc, d_st)
+        torch.cuda.synchronize()
+        return d_sfc.cpu().numpy().view(api.BOX_DTYPE).reshape(n, M), d_st.cpu().numpy()
+
+    want = np.zeros((n, M), oracle.BOX_DTYPE)
+    st_w = omap.construct_sfc(oracle.SFC_INIT, _pts(starts), radius, want)
+    got, st_g = gpu(api.SFC_INIT, _pts(starts), np.zeros((n, M), api.BOX_DTYPE))
+    assert np.array_equal(st_g, st_w) and 0 < st_w.sum()
+    ok = st_w == 1
+    assert np.array_equal(got["bmin"][ok], want["bmin"][ok]) and np.array_equal(got["bmax"][ok], want["bmax"][ok])
+    assert (got["bmin"][~ok] == 0).all()  # failures (start inside an inflated obstacle) leave the boxes untouched
+    # replan updates from the valid corridors, both generators
+    idx = np.nonzero(ok)[0]
+    base = want.copy()
+    base[~ok] = base[idx[0]]
+    direction = rng.normal(size=(n, 3))
+    if dim == 2:
+        direction[:, 2] = 0
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    last = np.float32(starts + 0.25 * direction).astype(np.float64)
+    goal = np.float32(starts + 0.6 * direction).astype(np.float64)
+    wp = np.float32(starts + 0.5 * direction).astype(np.float64)
+    for mode_o, mode_g in ((oracle.SFC_FROM_HULL, api.SFC_FROM_HULL), (oracle.SFC_FROM_POINT, api.SFC_FROM_POINT)):
+        w = base.copy()
+        st_w = omap.construct_sfc(mode_o, _pts(last, goal, wp), radius, w)
+        got, st_g = gpu(mode_g, _pts(last, goal, wp), base.copy())
+        assert np.array_equal(st_g, st_w) and 0 < st_w.sum() < n + 1
+        assert np.array_equal(got["bmin"], w["bmin"]) and np.array_equal(got["bmax"], w["bmax"]), mode_o
+    gmap.close()
+
+
+@pytest.mark.gpu
+def test_gpu_chain_world_to_trajectory_reproduces_reference_log(api, oracle):
+    """forest10, agent 1, first replan, everything on the device: world boxes -> voxel map -> initializeSFC -> goal LP ->
+    trajectory QP.  The reference's own result log (tests/golden/kat_log.json) is the expected output."""
+    import torch
+
+    g = H.load_golden("forest10_world")
+    kat = H.load_golden("kat_log")
+    p = kat["params"]
+    case = [c for c in kat["cases"] if c["agent"] == 1][0]
+    M = p["M"]
+    dev = torch.device("cuda", 0)
+    gmap = api.WorldMap(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
+    sol = api.Solver(H.abi_desc(api, p, use_sfc=True))
+    cls = H.oracle_class(oracle, p, use_sfc=True)
+    start = np.array(g["starts"][1])
+    d_sfc = torch.zeros(M * 6, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    sol.construct_sfc_device(gmap, api.SFC_INIT, 1, torch.from_numpy(_pts(start[None]).reshape(-1)).to(dev),
+                             torch.tensor([g["radius"]], dtype=torch.float64, device=dev), d_sfc, d_st)
+    torch.cuda.synchronize()
+    assert d_st.item() == 1
+    hdr = np.zeros(1, api.HEADER_DTYPE)
+    hdr["p0"][0] = case["p0"]
+    hdr["goal"][0] = [3.0, 2.5, 0.6]            # current goal point before the goal LP (one grid cell behind the waypoint)
+    hdr["next_waypoint"][0] = case["next_waypoint"]
+    hdr["vmax"][0], hdr["amax"][0] = p["vmax"], p["amax"]
+    hdr["radius"][0], hdr["nominal_velocity"][0] = p["radius"], p["nominal_velocity"]
+    d_hdr = torch.from_numpy(hdr.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_rows = torch.zeros(4, dtype=torch.float64, device=dev)
+    d_gst = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    sol.optimize_goal_device(1, d_hdr, d_rows, d_off, d_sfc, d_gst)
+    d_x = torch.zeros(sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_qst = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    sol.solve_device(1, 0, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_qst)
+    torch.cuda.synchronize()
+    assert d_gst.item() == 0 and d_qst.item() == 0
+    goal = d_hdr.cpu().numpy().view(api.HEADER_DTYPE)["goal"][0]
+    assert abs(goal[0] - 2.55) <= 1e-6  # the SFC face bounds the goal LP
+    x = d_x.cpu().numpy()
+    for st in kat["agents"][1]["states"][1:]:
+        pos, vel, acc = oracle.state_at(cls, x, st["t"])
+        assert np.allclose(pos, st["p"][:2], rtol=0, atol=2e-5)
+        assert np.allclose(vel, st["v"][:2], rtol=1e-4, atol=2e-6)
+        assert np.allclose(acc, st["a"][:2], rtol=3e-4, atol=2e-5)
+    gmap.close()
