@@ -16,7 +16,7 @@
 //
 // Arithmetic: boxes and points are octomap::point3d (float) in the reference; every statement below keeps float where
 // the reference stores a point3d component and double where it computes in double, and the file is compiled without
-// FMA contraction, so box coordinates come out bit-identical to the CPU restatement (oracle/lscsfc_oracle.c).
+// FMA contraction, so box coordinates are reproducible bit for bit on any IEEE machine.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
