@@ -295,7 +295,7 @@ int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_
  *   lscqp_map_info / lscqp_map_download   grid size, first octomap key, and the two fields (for inspection and tests):
  *                              occ [dims[2]][dims[1]][dims[0]] bytes; nearest, same shape, int32:
  *                              (dx+128) | (dy+128)<<8 | (dz+128)<<16 | 1<<24, or 0 = none within max_dist
- * and the corridor of each agent is updated on the device, one wavefront per agent:
+ * and the corridor of each agent is updated on the device, one workgroup (4 wavefronts) per agent:
  *   lscqp_construct_sfc_device, mode
  *     LSCQP_SFC_INIT        CollisionConstraints::initializeSFC (src/collision_constraints.cpp:366-384): all M boxes :=
  *                           expandSFC of the grid cell around the position; status 0 where the reference throws

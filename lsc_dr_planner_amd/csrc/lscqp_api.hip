@@ -481,6 +481,6 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
 
 const char* lscqp_last_error(void) { return g_err.c_str(); }
 
-const char* lscqp_version(void) { return "lscqp 0.2 (gfx950, fp64 PDIP, 1-4 wavefronts per QP; LSC generation, goal LP, post-solve step)"; }
+const char* lscqp_version(void) { return "lscqp 0.3 (gfx950, fp64 PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics)"; }
 
 }  // extern "C"

@@ -11,8 +11,8 @@
 // Not a translation: the reference grows one box per agent on the CPU, asking an octree-backed distance map point by
 // point.  Here the map is a dense voxel grid in HBM (1 B occupancy + 4 B nearest-cell code per voxel; 288 GB holds
 // kilometre-scale worlds at 0.1 m), its nearest-cell field is built by three separable passes (exact Euclidean, 3 x (2R+1)
-// reads per voxel instead of (2R+1)^3), and one wavefront owns one agent's corridor: the box state is wave-uniform, the
-// lanes test the sample points of a slab in parallel and vote (ballot), so a slab test costs ceil(points / 64) steps.
+// reads per voxel instead of (2R+1)^3), and one workgroup owns one agent's corridor: the box state is uniform across the
+// group, its 256 lanes test the sample points of a slab in parallel and vote, so a slab test costs ceil(points / 512) steps.
 //
 // Arithmetic: boxes and points are octomap::point3d (float) in the reference; every statement below keeps float where
 // the reference stores a point3d component and double where it computes in double, and the file is compiled without
@@ -142,12 +142,14 @@ __global__ void nearest_z_kernel(int nx, int ny, int nz, int64_t nvox, int R, co
     out[v] = found ? (((bx + 128) & 255) | (((by + 128) & 255) << 8) | (((bz + 128) & 255) << 16) | (1 << 24)) : 0;
 }
 
-// ---- corridor construction: one wavefront per agent -------------------------------------------------------------------
+// ---- corridor construction: one workgroup per agent -------------------------------------------------------------------
+constexpr int kSfcThreads = 256;  // one workgroup (4 wavefronts) per agent: a 50 x 50-cell slab is 5 000 sample points
+
 struct BoxF {
     float lo[3], hi[3];
 };
 
-// isObstacleInSFC (:777-808): lanes take the sample points of the box in turn and vote
+// isObstacleInSFC (:777-808): the block's lanes take the sample points of the box in turn and vote
 __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
     const double res = mp.res;
     const float delta = (float)(0.5 * res);
@@ -156,37 +158,44 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
     // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
     const int64_t total = (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) ? 0 : (int64_t)n[0] * n[1] * n[2];
     const int lane = threadIdx.x;
-    for (int64_t base = 0; base < total; base += 64) {
-        const int64_t idx = base + lane;
-        bool hit = false;
-        if (idx < total) {
-            const int it[3] = {(int)(idx / ((int64_t)n[1] * n[2])), (int)((idx / n[2]) % n[1]), (int)(idx % n[2])};
-            float p[3];
-            int v[3];
-            bool inside = true;
+    // kU chunks of 64 points per vote: the kU nearest-cell loads of a lane are independent and in flight together, which is
+    // what bounds a large slab (the loop is a chain of dependent HBM / L2 reads otherwise)
+    constexpr int kU = 2;
+    const int64_t n12 = (int64_t)n[1] * n[2];
+    for (int64_t base = 0; base < total; base += kSfcThreads * kU) {
+        float p[kU][3];
+        int v[kU][3], code[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int64_t idx = base + u * kSfcThreads + lane;
+            bool inside = idx < total;
+            const int64_t ii = inside ? idx : 0;
+            const int it[3] = {(int)(ii / n12), (int)((ii / n[2]) % n[1]), (int)(ii % n[2])};
             for (int k = 0; k < 3; k++) {
-                p[k] = (float)((double)b.lo[k] + (double)it[k] * res);  // search_point(i) = box_min(i) + iter * res
-                v[k] = key_of((double)p[k], res) - mp.key0[k];          // worldToMap
-                inside = inside && v[k] >= 0 && v[k] < mp.dims[k];
+                p[u][k] = (float)((double)b.lo[k] + (double)it[k] * res);  // search_point(i) = box_min(i) + iter * res
+                v[u][k] = key_of((double)p[u][k], res) - mp.key0[k];       // worldToMap
+                inside = inside && v[u][k] >= 0 && v[u][k] < mp.dims[k];
             }
-            if (inside) {
-                const int code = mp.nearest[((int64_t)v[2] * mp.dims[1] + v[1]) * mp.dims[0] + v[0]];
-                if (code >> 24) {
-                    const int off[3] = {(code & 255) - 128, ((code >> 8) & 255) - 128, ((code >> 16) & 255) - 128};
-                    double dist = 0;
-                    for (int k = 0; k < 3; k++) {
-                        // keyToCoord: cell centre (key + 0.5) res as float; closest point of the cell box; L-infinity distance
-                        const float c = (float)(((double)(v[k] + off[k] + mp.key0[k]) + 0.5) * res);
-                        const float cmin = c - delta, cmax = c + delta;
-                        const float q = p[k] < cmin ? cmin : (p[k] > cmax ? cmax : p[k]);
-                        const double dk = fabs((double)(q - p[k]));
-                        dist = dist < dk ? dk : dist;
-                    }
-                    hit = dist < margin + 1e-5;
+            code[u] = inside ? mp.nearest[((int64_t)v[u][2] * mp.dims[1] + v[u][1]) * mp.dims[0] + v[u][0]] : 0;
+        }
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            if (code[u] >> 24) {
+                const int off[3] = {(code[u] & 255) - 128, ((code[u] >> 8) & 255) - 128, ((code[u] >> 16) & 255) - 128};
+                double dist = 0;
+                for (int k = 0; k < 3; k++) {
+                    // keyToCoord: cell centre (key + 0.5) res as float; closest point of the cell box; L-infinity distance
+                    const float c = (float)(((double)(v[u][k] + off[k] + mp.key0[k]) + 0.5) * res);
+                    const float cmin = c - delta, cmax = c + delta;
+                    const float q = p[u][k] < cmin ? cmin : (p[u][k] > cmax ? cmax : p[u][k]);
+                    const double dk = fabs((double)(q - p[u][k]));
+                    dist = dist < dk ? dk : dist;
                 }
+                hit = hit || (dist < margin + 1e-5);
             }
         }
-        if (__ballot(hit) != 0ull) return true;
+        if (__syncthreads_or(hit)) return true;  // block-uniform: every wavefront holds the same box state
     }
     return false;
 }
@@ -292,7 +301,7 @@ __device__ void clip_to_prev(const BoxF& prev, BoxF& ini, double res) {  // :677
     }
 }
 
-__global__ __launch_bounds__(64) void construct_sfc_kernel(MapView mp, int mode, int M, int64_t n, const double* __restrict__ pts,
+__global__ __launch_bounds__(kSfcThreads) void construct_sfc_kernel(MapView mp, int mode, int M, int64_t n, const double* __restrict__ pts,
                                                            const double* __restrict__ radius, lscqp_box* __restrict__ sfc,
                                                            int32_t* __restrict__ status) {
     const int64_t a = blockIdx.x;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(64) void construct_sfc_kernel(MapView mp, int mode,
         }
         ok = expand_sfc(mp, ini, nullptr, margin, out);
         if (ok)
-            for (int t = threadIdx.x; t < M * 6; t += 64) {
+            for (int t = threadIdx.x; t < M * 6; t += kSfcThreads) {
                 const int m = t / 6, c = t % 6;
                 double val = 0;
                 for (int k = 0; k < 3; k++) {
@@ -365,18 +374,11 @@ __global__ __launch_bounds__(64) void construct_sfc_kernel(MapView mp, int mode,
     }
     // sfcs[m] = sfcs[m + 1] for m < M - 1, then the new (or the kept) last box.  Every lane moves whole elements; the
     // values were all read before any is overwritten only if the shift is staged, so stage it in registers.
-    double stage[2];
-    int cnt = 0;
-    for (int t = threadIdx.x; t < (M - 1) * 6; t += 64, cnt++) {
-        const int m = t / 6, c = t % 6;
-        stage[cnt] = c < 3 ? S[m + 1].bmin[c] : S[m + 1].bmax[c - 3];
-    }
+    double stage = 0;  // (M - 1) * 6 <= kSfcThreads: one element per lane
+    const int ts = threadIdx.x;
+    if (ts < (M - 1) * 6) stage = (ts % 6) < 3 ? S[ts / 6 + 1].bmin[ts % 6] : S[ts / 6 + 1].bmax[ts % 6 - 3];
     __syncthreads();
-    cnt = 0;
-    for (int t = threadIdx.x; t < (M - 1) * 6; t += 64, cnt++) {
-        const int m = t / 6, c = t % 6;
-        (c < 3 ? S[m].bmin[c] : S[m].bmax[c - 3]) = stage[cnt];
-    }
+    if (ts < (M - 1) * 6) ((ts % 6) < 3 ? S[ts / 6].bmin[ts % 6] : S[ts / 6].bmax[ts % 6 - 3]) = stage;
     if (ok && threadIdx.x < 6) {
         const int c = threadIdx.x;
         double val = 0;
@@ -525,7 +527,7 @@ int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const dou
     v.res = mp->res;
     for (int k = 0; k < 3; k++) v.world_min[k] = mp->world_min[k], v.world_max[k] = mp->world_max[k], v.key0[k] = mp->key0[k], v.dims[k] = mp->dims[k];
     v.nearest = mp->d_nearest;
-    hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, v, mode, M, n, d_points, d_radius,
+    hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(lscsfc::kSfcThreads), 0, (hipStream_t)stream, v, mode, M, n, d_points, d_radius,
                        d_sfc, d_status_out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());

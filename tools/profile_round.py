@@ -137,4 +137,18 @@ gen["note"] = ("rows written = 409600 units x 192 B = 78.6 MB; inputs (control p
                "from L2 by the 20 agents that share a neighbour; FETCH_SIZE raw (KB) as reported, x2 if read as contiguous 16 B/lane "
                "streaming per MI355X_MICROARCH.md; WRITE_SIZE as reported")
 json.dump(gen, open(os.path.join(OUT, tag + "_lscgen.json"), "w"), indent=1)
+# 5. the other kernels either side of the QP (CLSC / BVC generation, safety metrics, voxel map, corridors)
+NEXT = [sys.executable, os.path.join(ROOT, "tools", "bench_next_rows.py"), "4096"]
+dn = os.path.join(OUT, "trace_next_rows")
+run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", dn, "--"] + NEXT, tag + "_next_rows_trace.log")
+lines = [l for l in open(os.path.join(OUT, tag + "_next_rows_trace.log")).read().splitlines() if l.startswith("{")]
+with open(os.path.join(OUT, tag + "_next_rows.jsonl"), "w") as f:
+    f.write("\n".join(lines) + "\n")
+for f in glob.glob(os.path.join(dn, "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.reader(open(f)))
+    keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ("generate_lsc_kernel", "safety_metrics", "construct_sfc", "nearest_",
+                                                                        "rasterise"))]
+    with open(os.path.join(OUT, tag + "_next_rows_kernel_stats.csv"), "w", newline="") as g:
+        csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
+
 print(json.dumps({"bench": b and {k: b[k] for k in ("value", "ms_per_step")}, "pmc": {k: res.get(k) for k in ("FETCH_SIZE_KB_raw", "WRITE_SIZE_KB_raw", "traffic_bytes_per_launch")}}))
