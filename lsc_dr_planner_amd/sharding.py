@@ -31,3 +31,20 @@ def allgather_trajectories(x_local, n_agents, group=None):
     out = torch.empty((world * per, nv), dtype=x_local.dtype, device=x_local.device)
     dist.all_gather_into_tensor(out, send.contiguous(), group=group)
     return out[:n_agents]
+
+
+def reduce_safety_metrics(safety_ratio_local, vel_excess_local, acc_excess_local, group=None):
+    """Mission-wide safety figures from the per-agent records of lscqp_safety_metrics_device on every rank
+    (reference src/multi_sync_simulator.cpp:512-514, 560-572: running min of the safety ratio, running max of the excess
+    ratios): tensors (n_local,), (n_local, 3), (n_local, 3) -> (safety_ratio_agent, vel_excess_ratio[3], acc_excess_ratio[3])
+    on every rank.  One MIN and one MAX all-reduce of 1 + 6 doubles; an empty shard contributes +inf / 0."""
+    dev, dt = safety_ratio_local.device, safety_ratio_local.dtype
+    mn = safety_ratio_local.min().reshape(1) if safety_ratio_local.numel() else torch.full((1,), float("inf"), dtype=dt, device=dev)
+    if vel_excess_local.numel():
+        mx = torch.cat([vel_excess_local.max(dim=0).values, acc_excess_local.max(dim=0).values])
+    else:
+        mx = torch.zeros(6, dtype=dt, device=dev)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    return mn[0], mx[:3], mx[3:]

@@ -29,6 +29,13 @@ def _worker(rank, world, port, N, out_dir):
     R = O.solve_batch(cls, ag[lo:hi], lsc, off[lo:hi], sfc[lo * M:], threads=1)
     x_all = sharding.allgather_trajectories(torch.from_numpy(R["x"]), N)
     np.save(os.path.join(out_dir, "x_%d.npy" % rank), x_all.numpy())
+    # safety figures of the step: per-agent records of the local block (oracle here, lscqp_safety_metrics_device on GPUs),
+    # then one MIN / MAX all-reduce
+    agl = ag[lo:hi].copy()
+    agl["vmax"][:, 0] = 0.002
+    S = O.safety_metrics(cls, agl, x_all.numpy(), sw.radius, sw.downwash, 2, 0.05, first=lo)
+    red = sharding.reduce_safety_metrics(torch.from_numpy(S[:, 0].copy()), torch.from_numpy(S[:, 3:6].copy()), torch.from_numpy(S[:, 6:9].copy()))
+    np.save(os.path.join(out_dir, "s_%d.npy" % rank), np.concatenate([red[0].reshape(1).numpy(), red[1].numpy(), red[2].numpy()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,3 +67,9 @@ def test_two_rank_gloo_allgather(tmp_path, oracle):
     ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, sw.build())
     R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=2)
     assert np.array_equal(R["x"], x0)
+    # the reduced safety figures equal the single-process figures over all agents, on both ranks
+    s0, s1 = np.load(tmp_path / "s_0.npy"), np.load(tmp_path / "s_1.npy")
+    ag["vmax"][:, 0] = 0.002
+    S = oracle.safety_metrics(cls, ag, R["x"], sw.radius, sw.downwash, 2, 0.05)
+    want = np.concatenate([[S[:, 0].min()], S[:, 3:6].max(axis=0), S[:, 6:9].max(axis=0)])
+    assert np.array_equal(s0, s1) and np.array_equal(s0, want) and want[1] > 0
