@@ -323,6 +323,9 @@ int lscqp_map_info(lscqp_map map, int32_t* dims, int32_t* key0);
 int lscqp_map_download(lscqp_map map, uint8_t* occ, int32_t* nearest);
 int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map map, int32_t mode, int64_t n, const double* d_points,
                                const double* d_radius, lscqp_box* d_sfc, int32_t* d_status_out, void* stream);
+/* Same, HOST pointers, synchronous; M boxes per agent (sfc is read and updated in place). */
+int lscqp_construct_sfc(lscqp_map map, int32_t mode, int32_t M, int64_t n, const double* points, const double* radius,
+                        lscqp_box* sfc, int32_t* status_out);
 
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */

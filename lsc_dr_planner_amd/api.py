@@ -107,6 +107,8 @@ def lib():
         L.lscqp_map_info.argtypes = [vp, vp, vp]
         L.lscqp_map_download.restype = C.c_int
         L.lscqp_map_download.argtypes = [vp, vp, vp]
+        L.lscqp_construct_sfc.restype = C.c_int
+        L.lscqp_construct_sfc.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, vp]
         L.lscqp_construct_sfc_device.restype = C.c_int
         L.lscqp_construct_sfc_device.argtypes = [vp, vp, C.c_int32, C.c_int64] + [vp] * 5
         L.lscqp_validate_step_device.restype = C.c_int
@@ -120,7 +122,7 @@ def lib():
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
-                    "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_safety_metrics_device",
+                    "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
 
 

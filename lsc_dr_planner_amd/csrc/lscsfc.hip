@@ -161,6 +161,9 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
     // kU chunks of 64 points per vote: the kU nearest-cell loads of a lane are independent and in flight together, which is
     // what bounds a large slab (the loop is a chain of dependent HBM / L2 reads otherwise)
     constexpr int kU = 2;
+    // 32-bit index arithmetic (a slab of a kilometre-scale world still has < 2^31 sample points; beyond that: 64-bit)
+    const bool small = total <= 0x7fffffffLL;
+    const uint32_t n2u = (uint32_t)n[2], n1u = (uint32_t)n[1];
     const int64_t n12 = (int64_t)n[1] * n[2];
     for (int64_t base = 0; base < total; base += kSfcThreads * kU) {
         float p[kU][3];
@@ -170,7 +173,15 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
             const int64_t idx = base + u * kSfcThreads + lane;
             bool inside = idx < total;
             const int64_t ii = inside ? idx : 0;
-            const int it[3] = {(int)(ii / n12), (int)((ii / n[2]) % n[1]), (int)(ii % n[2])};
+            int it[3];
+            if (small) {
+                const uint32_t iu = (uint32_t)ii, r = iu / n2u;
+                it[2] = (int)(iu - r * n2u);
+                it[0] = (int)(r / n1u);
+                it[1] = (int)(r - (uint32_t)it[0] * n1u);
+            } else {
+                it[0] = (int)(ii / n12), it[1] = (int)((ii / n[2]) % n[1]), it[2] = (int)(ii % n[2]);
+            }
             for (int k = 0; k < 3; k++) {
                 p[u][k] = (float)((double)b.lo[k] + (double)it[k] * res);  // search_point(i) = box_min(i) + iter * res
                 v[u][k] = key_of((double)p[u][k], res) - mp.key0[k];       // worldToMap
@@ -532,6 +543,47 @@ int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const dou
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;
+}
+
+// HOST pointers, synchronous: the batch-of-1 form the unchanged planner loop uses (TrajPlanner::generateSFC, one agent at a time)
+int lscqp_construct_sfc(lscqp_map mp, int32_t mode, int32_t M, int64_t n, const double* points, const double* radius, lscqp_box* sfc,
+                        int32_t* status_out) {
+    if (!mp) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null map");
+    if (mode != LSCQP_SFC_INIT && mode != LSCQP_SFC_FROM_HULL && mode != LSCQP_SFC_FROM_POINT)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "mode must be LSCQP_SFC_INIT, LSCQP_SFC_FROM_HULL or LSCQP_SFC_FROM_POINT");
+    if (n < 0 || M < 1 || M > 21) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "n >= 0 and 1 <= M <= 21 required");
+    if (n == 0) return LSCQP_OK;
+    if (!points || !radius || !sfc || !status_out) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    double *d_p = nullptr, *d_r = nullptr;
+    lscqp_box* d_s = nullptr;
+    int32_t* d_st = nullptr;
+    auto done = [&](int rc) {
+        if (d_p) (void)hipFree(d_p);
+        if (d_r) (void)hipFree(d_r);
+        if (d_s) (void)hipFree(d_s);
+        if (d_st) (void)hipFree(d_st);
+        return rc;
+    };
+    auto bad = [&](hipError_t e, const char* what) {
+        return done(lscqp_set_error_(LSCQP_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str()));
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&d_p, n * 9 * sizeof(double))) != hipSuccess || (e = hipMalloc(&d_r, n * sizeof(double))) != hipSuccess ||
+        (e = hipMalloc(&d_s, n * M * sizeof(lscqp_box))) != hipSuccess || (e = hipMalloc(&d_st, n * sizeof(int32_t))) != hipSuccess)
+        return bad(e, "hipMalloc");
+    if ((e = hipMemcpy(d_p, points, n * 9 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_r, radius, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_s, sfc, n * M * sizeof(lscqp_box), hipMemcpyHostToDevice)) != hipSuccess)
+        return bad(e, "hipMemcpy (in)");
+    const int rc = lscqp_construct_sfc_raw_(mp, mode, M, n, d_p, d_r, d_s, d_st, nullptr);
+    if (rc != LSCQP_OK) return done(rc);
+    if ((e = hipMemcpy(sfc, d_s, n * M * sizeof(lscqp_box), hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(status_out, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess)
+        return bad(e, "hipMemcpy (out)");
+    return done(LSCQP_OK);
 }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 #include <traj_optimizer.hpp>
 #include <result_csv.hpp>
 #include <iostream>
+#include <memory>
 #include <vector>
 
 using namespace DynamicPlanning;
@@ -277,6 +278,43 @@ static int scenario_csv(const char* path) {
     return 0;
 }
 
+// corridors through the reference's CollisionConstraints surface: world CSV -> DistanceMap -> initializeSFC ->
+// constructSFCFromConvexHull -> constructSFCFromPoint, boxes printed for tests/test_shim.py
+static int scenario_sfc(const char* world_csv) {
+    Param param;
+    param.M = 10;
+    param.world_dimension = 2;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    CollisionConstraints cc(param, mission);
+    auto dm = std::make_shared<DistanceMap>(std::string(world_csv), mission.world_min, mission.world_max, 0.1);
+    cc.setDistmap(dm);
+    auto show = [&](const char* name) {
+        printf("{\"scenario\": \"%s\", \"boxes\": [", name);
+        for (int m = 0; m < param.M; m++) {
+            const Box b = cc.getSFC(m);
+            printf("%s[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", m ? ", " : "", b.box_min.x(), b.box_min.y(), b.box_min.z(), b.box_max.x(),
+                   b.box_max.y(), b.box_max.z());
+        }
+        printf("]}\n");
+    };
+    cc.initializeSFC(point3d(3.0f, 2.5f, 0.6f), 0.15);
+    show("sfc_init");
+    cc.constructSFCFromConvexHull({point3d(2.8f, 2.5f, 0.6f), point3d(2.55f, 2.5f, 0.6f)}, point3d(2.5f, 2.5f, 0.6f), 0.15);
+    show("sfc_hull");
+    cc.constructSFCFromPoint(point3d(2.7f, 2.4f, 0.6f), point3d(-3.0f, -2.5f, 0.6f), 0.15);
+    show("sfc_point");
+    bool threw = false;
+    try {
+        cc.initializeSFC(point3d(2.2f, 2.1f, 0.6f), 0.15);  // inside the obstacle at (2.18, 2.10)
+    } catch (const std::invalid_argument&) {
+        threw = true;
+    }
+    printf("{\"scenario\": \"sfc_invalid\", \"threw\": %s}\n", threw ? "true" : "false");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string s = argc > 1 ? argv[1] : "host";
     if (s == "host") return scenario_host();
@@ -285,6 +323,7 @@ int main(int argc, char** argv) {
     if (s == "infeasible") return scenario_infeasible();
     if (s == "goal") return scenario_goal();
     if (s == "csv" && argc > 2) return scenario_csv(argv[2]);
+    if (s == "sfc" && argc > 2) return scenario_sfc(argv[2]);
     fprintf(stderr, "usage: shim_test host|kat|pair|infeasible|goal\n");
     return 2;
 }

@@ -125,3 +125,35 @@ def test_result_csv_writer_reproduces_reference_log_lines(shim_exe, tmp_path):
     assert np.abs(np.array(f4) - want4).max() < 1e-4  # float32 second differences leave 1e-5 m/s^2 of rounding noise
     f5 = lines[5].split(",")
     assert f5[1] == "1.1" and abs(float(f5[2]) - 1.05) < 1e-6 and abs(float(f5[4]) - 0.475) < 1e-6 and len(lines) == 6
+
+
+@pytest.mark.gpu
+def test_corridors_through_the_shim_match_oracle(shim_exe, oracle, tmp_path):
+    """CollisionConstraints::initializeSFC / constructSFCFromConvexHull / constructSFCFromPoint over the reference's world
+    CSV format (DistanceMap in place of DynamicEDTOctomap): the boxes equal the CPU restatement bit for bit."""
+    g = H.load_golden("forest10_world")
+    world = tmp_path / "forest10.csv"
+    np.savetxt(world, np.array(g["boxes"]), delimiter=",", fmt="%.17g")
+    out = subprocess.run([shim_exe, "sfc", str(world)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    res = {r["scenario"]: r for r in (json.loads(l) for l in out.stdout.strip().splitlines())}
+    mp = oracle.Map(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
+    f32 = lambda *v: np.float32(v).astype(np.float64)  # noqa: E731
+    sfc = np.zeros((1, 10), oracle.BOX_DTYPE)
+
+    def pts(a, b, c):
+        return np.stack([a, b, c])[None]
+
+    def same(name):
+        got = np.float32(res[name]["boxes"])  # printed with 9 significant digits: round-trips float32 exactly
+        assert np.array_equal(got[:, :3], np.float32(sfc[0]["bmin"])) and np.array_equal(got[:, 3:], np.float32(sfc[0]["bmax"])), name
+
+    p0 = f32(3.0, 2.5, 0.6)
+    assert mp.construct_sfc(oracle.SFC_INIT, pts(p0, p0, p0), 0.15, sfc)[0] == 1
+    same("sfc_init")
+    assert abs(res["sfc_init"]["boxes"][0][0] - 2.55) <= 1e-6  # the face the reference's log pins
+    mp.construct_sfc(oracle.SFC_FROM_HULL, pts(f32(2.8, 2.5, 0.6), f32(2.55, 2.5, 0.6), f32(2.5, 2.5, 0.6)), 0.15, sfc)
+    same("sfc_hull")
+    mp.construct_sfc(oracle.SFC_FROM_POINT, pts(f32(2.7, 2.4, 0.6), f32(-3.0, -2.5, 0.6), f32(-3.0, -2.5, 0.6)), 0.15, sfc)
+    same("sfc_point")
+    assert res["sfc_invalid"]["threw"] is True  # std::invalid_argument("Invalid initial SFC"), :377-379
