@@ -181,6 +181,9 @@ def test_infeasible_instances_are_reported(api, oracle, torch_cuda):
     for q in range(N):
         if q in bad:
             assert G["status"][q] != 0, (q, bad[q], G["info"][q])
+            # reported early (a stalled primal residual), not at the iteration limit of 60: a launch lasts as long as its
+            # slowest QP, and the caller falls back to the initial trajectory anyway
+            assert G["info"]["iterations"][q] <= 24, (q, bad[q], G["info"][q])
             assert oracle.solve(cls, ags[q], lscs[q], sfcs[q], max_iter=100)["status"] != 0
         else:
             assert G["status"][q] == 0, (q, G["info"][q])
