@@ -159,7 +159,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     gscale = max(1.0, np.abs(gfull).max())
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
-    status, it, near_cnt = 2, 0, 0
+    status, it, near_cnt, rp_ref = 2, 0, 0, 3.0e38
     for it in range(max_iter):
         rp = Gz @ z - hz - s
         grad = Kfull @ z + gfull
@@ -175,6 +175,12 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             if np.abs(rd).max() <= 10 * tol * gls or near_cnt >= 2:
                 status = 0
                 break
+        # infeasible instances: the primal residual stalls above 1e-3 (same test as the kernel)
+        if it % 4 == 2:
+            if it >= 10 and np.abs(rp).max() > 1e-3 and np.abs(rp).max() > 0.7 * rp_ref:
+                status = 1
+                break
+            rp_ref = float(np.float32(np.abs(rp).max()))
         w = lam / s
         K = Kfull + Gz.T @ (w[:, None] * Gz)
         try:
