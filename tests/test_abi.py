@@ -92,3 +92,42 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 bad = re.search(r"^\s*(from|import)\s+oracle|lscqp_oracle|orc_solve|oracle/", txt, flags=re.M)
                 assert not bad, "%s uses the oracle: %r" % (os.path.join(dp, f), bad.group(0))
+
+
+def test_next_row_entry_points_validate_and_accept_empty_batches(api):
+    """The entry points either side of the QP: empty batches are no-ops, bad arguments are reported (not crashed on), and on
+    a GPU-less host every one of them fails loudly instead of computing on the CPU."""
+    import torch
+
+    L = api.lib()
+    s = api.Solver(api.make_desc(M=5, dim=3))
+    h = s._h
+    one = (C.c_double * 64)()
+    p = C.cast(one, C.c_void_p)
+    # empty inputs
+    assert L.lscqp_generate_constraints_device(h, api.GEN_CLSC, 0, 8, 0, p, p, p, p, p, p, None) == api.OK
+    assert L.lscqp_generate_lsc_device(h, 0, 8, 0, p, p, p, p, p, p, None) == api.OK
+    assert L.lscqp_shift_traj_device(h, 0, 1, 1.0, p, p, None) == api.OK
+    assert L.lscqp_safety_metrics_device(h, 0, 0, 0, 1, 0.1, 1.0, p, p, p, p, p, None) == api.OK
+    assert L.lscqp_validate_step_device(h, 0, 0.2, 1.0, p, p, p, p, p, None) == api.OK
+    # bad arguments
+    assert L.lscqp_generate_constraints_device(h, 7, 4, 8, 0, p, p, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT
+    assert b"mode" in L.lscqp_last_error()
+    assert L.lscqp_generate_constraints_device(None, api.GEN_LSC, 4, 8, 0, p, p, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT
+    assert L.lscqp_generate_constraints_device(h, api.GEN_BVC, 4, 8, 0, p, None, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT
+    assert L.lscqp_safety_metrics_device(h, 4, 2, 5, 1, 0.1, 1.0, p, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT  # 2 + 4 > 5
+    assert L.lscqp_shift_traj_device(h, 4, 2, 1.0, p, p, None) == api.ERR_INVALID_ARGUMENT
+    assert L.lscqp_construct_sfc(None, api.SFC_INIT, 5, 1, p, p, p, p) == api.ERR_INVALID_ARGUMENT
+    hm = C.c_void_p()
+    assert L.lscqp_map_create(p, 1, p, p, 0.0, 1.0, C.byref(hm)) == api.ERR_INVALID_ARGUMENT  # resolution 0
+    assert L.lscqp_map_create_from_csv(b"/nonexistent/world.csv", p, p, 0.1, 1.0, C.byref(hm)) == api.ERR_INVALID_ARGUMENT
+    assert b"cannot open" in L.lscqp_last_error()
+    if not torch.cuda.is_available():
+        for rc in (L.lscqp_generate_constraints_device(h, api.GEN_CLSC, 4, 8, 0, p, p, p, p, p, p, None),
+                   L.lscqp_safety_metrics_device(h, 1, 0, 1, 1, 0.1, 1.0, p, p, p, p, p, None),
+                   L.lscqp_validate_step_device(h, 1, 0.2, 1.0, p, p, p, p, p, None),
+                   L.lscqp_shift_traj_device(h, 1, 1, 1.0, p, p, None)):
+            assert rc == api.ERR_NO_DEVICE and b"no CPU fallback" in L.lscqp_last_error()
+        wmin, wmax = (C.c_double * 3)(-1, -1, 0), (C.c_double * 3)(1, 1, 1)
+        assert L.lscqp_map_create(p, 0, wmin, wmax, 0.1, 1.0, C.byref(hm)) == api.ERR_NO_DEVICE
+    s.close()
