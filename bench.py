@@ -196,7 +196,7 @@ def main():
     # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the value comes from the
     # committed rocprofv3 --pmc passes of THIS command (profiles/*_pmc_traffic.json, tools/profile_round.py) and is only reported when the
     # kernel instance and batch size match; otherwise null.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     try:
         import glob
 
@@ -206,6 +206,14 @@ def main():
         if pm.get("qps_per_launch") == N and ("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) in kname and n_obs_eff == 20:
             traffic = pm["traffic_bytes_per_launch"]
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" % os.path.basename(pf)
+            sq = pm.get("sq") or {}
+            if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAVES"):
+                # the limit this kernel actually runs into (SURVEY.md 8d asks for it next to the HBM figure): the share of a
+                # wavefront's lifetime in which a vector-ALU instruction of it is executing, from the same PMC passes
+                valu = {"valu_active_frac_of_wave_lifetime": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
+                        "valu_instructions_per_wavefront": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"],
+                        "lds_instructions_per_wavefront": sq["SQ_INSTS_LDS"] / sq["SQ_WAVES"],
+                        "wavefronts_per_launch": sq["SQ_WAVES"], "source": "profiles/%s (rocprofv3 --pmc SQ_*)" % os.path.basename(pf)}
     except Exception:
         pass
     out = {
@@ -234,7 +242,7 @@ def main():
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
             "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W>" % (M, dim), "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N,
+            "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N, "valu": valu,
         },
         "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
                        "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99))},
