@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="step = all-gather of the plans (N > 1) -> LSC generation on the device -> QP solve (SURVEY 8f-1); "
                          "the default step is the QP solve of BASELINE's metric alone")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step (all its kernel launches) in a HIP graph and replay it: removes the launch gaps of the "
+                         "multi-kernel --pipeline step (single GPU only; no *_device entry point synchronises or allocates)")
     ap.add_argument("--cold-start", action="store_true", help="do not hand the initial trajectories to the solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
@@ -133,6 +136,22 @@ def main():
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         if d_all is not None and not args.pipeline:
             dist.all_gather_into_tensor(d_all, d_x)
+
+    if args.graph:
+        if world != 1:
+            raise SystemExit("--graph is a single-GPU option")
+        eager_step = step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm up on the capture stream, as graph capture requires
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph, stream=side):
+            eager_step()
+        step = hip_graph.replay  # noqa: F811
 
     def barrier():
         if dist is not None:
@@ -233,7 +252,7 @@ def main():
             "workload": "%d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
                         "fp64 batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (N, M, n_obs_eff, dim, args.style),
             "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
-            "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline),
+            "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline), "hip_graph": bool(args.graph),
             "warm_start": "initial_traj (shifted previous plan) as primal start" if d_xinit is not None else "none",
             "parallelism": ("agents sharded over %d GPU(s), " % world) +
                            ("one RCCL all-gather of the plans per step" if d_all is not None else "no data-path collective"),
