@@ -112,6 +112,7 @@ def main():
     d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
     d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
     d_all = torch.zeros(world * N * nv, dtype=torch.float64, device=dev) if ((args.allgather or args.pipeline) and world > 1) else None
+    d_xwarm = torch.zeros(N * nv, dtype=torch.float64, device=dev)
     if args.pipeline:
         # every rank's swarm is independent (weak scaling); global agent id = rank * N + local id.  The rows are
         # regenerated every step from the CURRENT plans of all agents (replanning from the same state: the previous
@@ -133,7 +134,10 @@ def main():
                 src = d_all
             sol.shift_traj_device(world * N, src, d_traj, z_2d=float(build["p0"][0][2]), shift=0)
             sol.generate_lsc_device(N, n_obs_eff, rank * N, d_traj, d_nbr, d_rad, d_dw, d_goal, d_rows)
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+            if d_xinit is not None:
+                d_xwarm.copy_(d_x)  # the plans the rows were generated from are the primal start of the re-solve
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info,
+                         d_x_init=(d_xwarm if (args.pipeline and d_xinit is not None) else d_xinit))
         if d_all is not None and not args.pipeline:
             dist.all_gather_into_tensor(d_all, d_x)
 
