@@ -220,6 +220,17 @@ int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_ag
                                       const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
                                       const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, void* stream);
 
+/* Who is whose obstacle: MultiSyncSimulator::broadcastMsgs (src/multi_sync_simulator.cpp:305-352) hands agent i every other
+ * agent j with LInfinityDistance(p_i, p_j) <= communication_range (include/util.hpp:122-131; all of them if the range is <= 0),
+ * in id order.  d_positions [n_total][3]: the agents' current positions (float32 values, all-gathered when sharded).
+ * d_neighbours_out [n_agents][n_obs]: the global ids in ascending order, padded with -1 -- the list
+ * lscqp_generate_*_device consumes.  The reference's list is unbounded; here the row buffers hold n_obs neighbours per
+ * agent, so when more are in range the n_obs NEAREST are kept (L-infinity distance, ties to the smaller id; still listed in
+ * id order).  d_count_out [n_agents]: how many were in range (> n_obs tells the caller that the list was cut). */
+int lscqp_select_neighbours_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_obs,
+                                   double communication_range, const double* d_positions, int32_t* d_neighbours_out,
+                                   int32_t* d_count_out, void* stream);
+
 /* Replaces TrajPlanner::initialTrajPlanningPrevSol (src/traj_planner.cpp:399-411) on the solver's output: segment m of
  * the new initial trajectory := segment m+1 of the previous plan, the last segment := its last point; control points
  * truncated to float32 like TrajOptResult::desired_traj (src/traj_optimizer.cpp:71-83); dim == 2 -> z := z_2d.

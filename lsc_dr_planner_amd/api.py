@@ -87,6 +87,8 @@ def lib():
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_generate_constraints_device.restype = C.c_int
         L.lscqp_generate_constraints_device.argtypes = [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
+        L.lscqp_select_neighbours_device.restype = C.c_int
+        L.lscqp_select_neighbours_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, vp, vp, vp, vp]
         L.lscqp_shift_traj_device.restype = C.c_int
         L.lscqp_shift_traj_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_double, vp, vp, vp]
         L.lscqp_generate_lsc_bytes.restype = C.c_int64
@@ -120,7 +122,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_generate_constraints_device",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
                     "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
@@ -361,6 +363,17 @@ class Solver:
                                                      C.c_void_p(d_neighbours.data_ptr()), C.c_void_p(d_radius.data_ptr()),
                                                      C.c_void_p(d_downwash.data_ptr()), C.c_void_p(d_goal_all.data_ptr()),
                                                      C.c_void_p(d_rows.data_ptr()), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def select_neighbours_device(self, n_agents, first_agent, n_total, n_obs, comm_range, d_positions, d_neighbours, d_count, stream=None):
+        """broadcastMsgs' range filter on the device: neighbour ids (ascending, -1 padded) and the in-range counts."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_select_neighbours_device(self._h, n_agents, first_agent, n_total, int(n_obs), float(comm_range),
+                                                  C.c_void_p(d_positions.data_ptr()), C.c_void_p(d_neighbours.data_ptr()),
+                                                  C.c_void_p(d_count.data_ptr()), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

@@ -449,9 +449,104 @@ __global__ __launch_bounds__(kThreads) void shift_traj_kernel(int M, int dim, in
     o[2] = (dim == 3) ? (double)(float)x[(2 * M + ms) * 6 + is] : (double)(float)z_2d;
 }
 
+// MultiSyncSimulator::broadcastMsgs (reference src/multi_sync_simulator.cpp:305-352): agent i receives every other agent j
+// with LInfinityDistance(p_i, p_j) <= communication_range (all of them when the range is <= 0), in id order.  One
+// wavefront per local agent: the lanes test 64 candidates at a time, and a ballot + prefix population count compacts the
+// accepted ids in order.  The row buffers have room for n_obs neighbours per agent; when more are in range the n_obs
+// nearest are kept (L-infinity distance, then id; still listed in id order) and count_out tells the caller.
+__global__ __launch_bounds__(64) void select_neighbours_kernel(int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_obs,
+                                                               double range, const double* __restrict__ pos,
+                                                               int32_t* __restrict__ nbr, int32_t* __restrict__ count) {
+    const int64_t a = blockIdx.x;
+    if (a >= n_agents) return;
+    const int lane = threadIdx.x;
+    const int64_t gi = first_agent + a;
+    // positions are point3d (float) in the reference; LInfinityDistance widens the float differences (include/util.hpp:122-131)
+    const float px = (float)pos[3 * gi], py = (float)pos[3 * gi + 1], pz = (float)pos[3 * gi + 2];
+    auto dist_of = [&](int64_t j) -> double {
+        const float dx = px - (float)pos[3 * j], dy = py - (float)pos[3 * j + 1], dz = pz - (float)pos[3 * j + 2];
+        return fmax(fmax(fabs((double)dx), fabs((double)dy)), fabs((double)dz));
+    };
+    auto in_range = [&](int64_t j, double limit) -> bool {
+        return j < n_total && j != gi && !(range > 0 && dist_of(j) > limit);
+    };
+    int total = 0;
+    for (int64_t base = 0; base < n_total; base += 64) total += __popcll(__ballot(in_range(base + lane, range)));
+    double limit = range;
+    int n_strict = 0;  // overflow: keep everything nearer than `limit`, then the smallest ids at exactly `limit`
+    bool capped = false;
+    if (total > n_obs && n_obs > 0) {
+        // the n_obs-th smallest distance, by bisection on the float-valued distances (they are exact in double)
+        double lo = 0, hi = range > 0 ? range : 3.0e38;
+        if (!(range > 0)) {
+            double mx = 0;
+            for (int64_t base = 0; base < n_total; base += 64) {
+                const int64_t j = base + lane;
+                double d = (j < n_total && j != gi) ? dist_of(j) : 0.0;
+                for (int o = 32; o > 0; o >>= 1) d = fmax(d, __shfl_xor(d, o));
+                mx = fmax(mx, d);
+            }
+            hi = mx;
+        }
+        for (int it = 0; it < 64 && lo < hi; it++) {
+            const double mid = 0.5 * (lo + hi);
+            if (mid <= lo || mid >= hi) break;
+            int c = 0;
+            for (int64_t base = 0; base < n_total; base += 64) {
+                const int64_t j = base + lane;
+                c += __popcll(__ballot(j < n_total && j != gi && dist_of(j) <= mid));
+            }
+            if (c >= n_obs)
+                hi = mid;
+            else
+                lo = mid;
+        }
+        limit = hi;  // smallest distance value with at least n_obs agents at or below it
+        for (int64_t base = 0; base < n_total; base += 64) {
+            const int64_t j = base + lane;
+            n_strict += __popcll(__ballot(j < n_total && j != gi && dist_of(j) < limit));
+        }
+        capped = true;
+    }
+    int written = 0, ties_left = capped ? n_obs - n_strict : 0;
+    for (int64_t base = 0; base < n_total && written < n_obs; base += 64) {
+        const int64_t j = base + lane;
+        bool take;
+        if (!capped) {
+            take = in_range(j, range);
+        } else {
+            const bool valid = j < n_total && j != gi;
+            const double d = valid ? dist_of(j) : 0.0;
+            const bool tie = valid && d == limit;
+            const unsigned long long tm = __ballot(tie);
+            const int tie_rank = __popcll(tm & ((1ull << lane) - 1ull));
+            take = valid && (d < limit || (tie && tie_rank < ties_left));
+            const int used = __popcll(tm);
+            ties_left -= used < ties_left ? used : ties_left;
+        }
+        const unsigned long long m = __ballot(take);
+        const int p = written + __popcll(m & ((1ull << lane) - 1ull));
+        if (take && p < n_obs) nbr[a * n_obs + p] = (int32_t)j;
+        written += __popcll(m);
+    }
+    written = written < n_obs ? written : n_obs;
+    for (int p = written + lane; p < n_obs; p += 64) nbr[a * n_obs + p] = -1;
+    if (lane == 0) count[a] = total;
+}
+
 }  // namespace lscgen
 
 extern "C" int lscqp_set_error_(int code, const char* msg);  // lscqp_api.hip
+
+extern "C" int lscqp_select_neighbours_raw_(int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_obs, double range,
+                                            const double* d_pos, int32_t* d_nbr, int32_t* d_count, void* stream) {
+    if (n_agents == 0) return LSCQP_OK;
+    hipLaunchKernelGGL(lscgen::select_neighbours_kernel, dim3((unsigned)n_agents), dim3(64), 0, (hipStream_t)stream, n_agents, first_agent,
+                       n_total, n_obs, range, d_pos, d_nbr, d_count);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
 
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const int32_t* d_neighbours, const double* d_radius,

@@ -31,6 +31,8 @@ extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_ag
                                          const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream);
 extern "C" int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius,
                                         lscqp_box* d_sfc, int32_t* d_status_out, void* stream);
+extern "C" int lscqp_select_neighbours_raw_(int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_obs, double range,
+                                            const double* d_pos, int32_t* d_nbr, int32_t* d_count, void* stream);
 extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const double* d_x,
                                         const lscqp_header* d_hdr, const lscqp_box* d_sfc, int32_t* d_valid, double* d_state,
                                         void* stream);
@@ -348,6 +350,21 @@ int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map mp, int32_t mode, int64
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     return lscqp_construct_sfc_raw_(mp, mode, h->desc.M, n, d_points, d_radius, d_sfc, d_status_out, stream);
+}
+
+int lscqp_select_neighbours_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_obs,
+                                   double communication_range, const double* d_positions, int32_t* d_neighbours_out,
+                                   int32_t* d_count_out, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_agents < 0 || first_agent < 0 || n_obs < 0 || n_total < first_agent + n_agents)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes");
+    if (n_agents == 0) return LSCQP_OK;
+    if (!d_positions || !d_count_out || (n_obs > 0 && !d_neighbours_out)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_select_neighbours_raw_(n_agents, first_agent, n_total, n_obs, communication_range, d_positions, d_neighbours_out,
+                                        d_count_out, stream);
 }
 
 int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, double z_2d, const double* d_x,

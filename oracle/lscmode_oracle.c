@@ -31,6 +31,7 @@
  * and bounds it (feasible pair on both segments, distance >= the true distance) everywhere else.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "lscqp_oracle.h"
@@ -294,5 +295,43 @@ void orc_generate_mode(int mode, int M, int dim, int n_agents, int n_obs, int fi
             orc_generate_mode_pair(mode, M, dim, &traj[(size_t)ga * M * 18], &traj[(size_t)gb * M * 18], radius[ga], radius[gb],
                                    downwash[ga], downwash[gb], &goal_all[3 * (size_t)ga], &goal_all[3 * (size_t)gb], dst);
         }
+    }
+}
+
+/*
+ * MultiSyncSimulator::broadcastMsgs' range filter (reference src/multi_sync_simulator.cpp:318-333): the obstacles of agent i
+ * are the other agents with LInfinityDistance (include/util.hpp:122-131, float differences widened) <= range (all if range <= 0),
+ * in id order.  nbr [n_agents][n_obs] (-1 padded), count [n_agents] = how many were in range.  Capacity rule of the build (the
+ * reference's list is unbounded): when more than n_obs are in range the n_obs nearest are kept, ties to the smaller id.
+ */
+void orc_select_neighbours(int n_agents, int first, int n_total, int n_obs, double range, const double* pos, int* nbr, int* count) {
+    for (int a = 0; a < n_agents; a++) {
+        const int gi = first + a;
+        double* d = (double*)malloc(sizeof(double) * (size_t)n_total);
+        int total = 0;
+        for (int j = 0; j < n_total; j++) {
+            double m = 0;
+            for (int k = 0; k < 3; k++) {
+                const float df = (float)pos[3 * gi + k] - (float)pos[3 * j + k];
+                const double ad = fabs((double)df);
+                if (m < ad) m = ad;
+            }
+            d[j] = (j == gi || (range > 0 && m > range)) ? -1.0 : m; /* -1: not a neighbour */
+            if (d[j] >= 0) total++;
+        }
+        count[a] = total;
+        if (total > n_obs) { /* drop the farthest (largest id among equals) until n_obs remain */
+            for (int drop = total - n_obs; drop > 0; drop--) {
+                int worst = -1;
+                for (int j = 0; j < n_total; j++)
+                    if (d[j] >= 0 && (worst < 0 || d[j] >= d[worst])) worst = j;
+                d[worst] = -1.0;
+            }
+        }
+        int w = 0;
+        for (int j = 0; j < n_total && w < n_obs; j++)
+            if (d[j] >= 0) nbr[(size_t)a * n_obs + w++] = j;
+        for (; w < n_obs; w++) nbr[(size_t)a * n_obs + w] = -1;
+        free(d);
     }
 }

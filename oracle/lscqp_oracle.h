@@ -146,6 +146,8 @@ int orc_construct_sfc(const orc_map* mp, int mode, int M, const double* pts, dou
 void orc_construct_sfc_batch(const orc_map* mp, int mode, int M, int n, const double* pts, const double* radius, orc_box* sfc,
                              int* status);
 
+void orc_select_neighbours(int n_agents, int first, int n_total, int n_obs, double range, const double* pos, int* nbr, int* count);
+
 /* ---- goal LP (oracle/lscgoal_oracle.c; reference src/goal_optimizer.cpp:72-147) ---- */
 int orc_goal_rows(const orc_class* cls, const double* g, const double* w, int n_obs, const orc_lsc* lsc, const orc_box* sfc_last,
                   double* a, double* c);

@@ -116,6 +116,7 @@ def lib():
         _lib.orc_hull_closest_point.argtypes = [dp, C.c_int, dp]
         _lib.orc_generate_lsc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_void_p]
         _lib.orc_generate_mode.argtypes = [C.c_int] * 6 + [dp, ip, dp, dp, dp, C.c_void_p]
+        _lib.orc_select_neighbours.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, dp, ip, ip]
         _lib.orc_segseg_closest.restype = C.c_double
         _lib.orc_segseg_closest.argtypes = [dp] * 6
         _lib.orc_goal_rows.restype = C.c_int
@@ -403,3 +404,16 @@ class Map:
             lib().orc_map_destroy(self._h)
         except Exception:
             pass
+
+
+def select_neighbours(pos, n_obs, comm_range, first=0, n_agents=None):
+    """broadcastMsgs' range filter (reference src/multi_sync_simulator.cpp:318-333): (nbr (n_agents, n_obs) int32 with -1
+    padding, count (n_agents,)).  More than n_obs in range: the n_obs nearest are kept (the build's capacity rule)."""
+    P = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+    n_total = P.shape[0]
+    n_agents = n_total - first if n_agents is None else n_agents
+    nbr = np.zeros((n_agents, n_obs), np.int32)
+    cnt = np.zeros(n_agents, np.int32)
+    ip = C.POINTER(C.c_int)
+    lib().orc_select_neighbours(n_agents, first, n_total, n_obs, float(comm_range), _dp(P), nbr.ctypes.data_as(ip), cnt.ctypes.data_as(ip))
+    return nbr, cnt

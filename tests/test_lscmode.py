@@ -143,3 +143,45 @@ def test_gpu_sharded_constraints_use_global_goal_ids(api, oracle):
     got = d_rows.cpu().numpy().view(api.ROW_DTYPE).reshape(n_loc, n_obs, M, 6)
     for f, tol in (("nx", 2e-7), ("ny", 2e-7), ("nz", 2e-7), ("b", 2e-6)):
         assert np.abs(got[f] - want[f]).max() <= tol, f
+
+
+# ---- who is whose obstacle: broadcastMsgs' range filter (reference src/multi_sync_simulator.cpp:318-333) ---------------
+def _numpy_neighbours(P, a, n_obs, rng_):
+    d = np.abs(np.float32(P[a]) - np.float32(P)).max(1).astype(np.float64)
+    ok = [j for j in range(len(P)) if j != a and not (rng_ > 0 and d[j] > rng_)]
+    keep = sorted(sorted(ok, key=lambda j: (d[j], j))[:n_obs])
+    return keep + [-1] * (n_obs - len(keep)), len(ok)
+
+
+def test_neighbour_selection_oracle_against_numpy(oracle):
+    rng = np.random.default_rng(3)
+    P = np.float32(rng.uniform(-5, 5, (60, 3))).astype(np.float64)
+    P[7] = P[3]  # coincident agents: distance 0
+    for n_obs, rng_ in ((8, 3.0), (20, 3.0), (5, 0.0), (59, -1.0), (12, 1e-3)):
+        nbr, cnt = oracle.select_neighbours(P, n_obs, rng_)
+        for a in range(60):
+            want, c = _numpy_neighbours(P, a, n_obs, rng_)
+            assert list(nbr[a]) == want and cnt[a] == c, (n_obs, rng_, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,n_obs,comm_range,first,n_loc", [(300, 20, 3.0, 0, 300), (300, 6, 3.0, 100, 77), (130, 40, 0.0, 0, 130),
+                                                            (64, 8, 1e-3, 0, 64), (4096, 20, 3.0, 1024, 512)])
+def test_gpu_neighbour_selection_matches_oracle(api, oracle, N, n_obs, comm_range, first, n_loc):
+    import torch
+
+    rng = np.random.default_rng(N + n_obs)
+    side = (N / 2.0) ** (1 / 3) * 2.5
+    P = np.float32(rng.uniform(0, side, (N, 3))).astype(np.float64)
+    P[first + 1] = P[first]  # coincident pair
+    P[first + 2, 0] = P[first, 0] + 3.0  # exactly at the range in one axis (float32-exact): the reference's test is dist > range
+    want, cnt = oracle.select_neighbours(P, n_obs, comm_range, first=first, n_agents=n_loc)
+    dev = torch.device("cuda", 0)
+    sol = api.Solver(api.make_desc(M=5, dim=3))
+    d_nbr = torch.full((n_loc * n_obs,), -7, dtype=torch.int32, device=dev)
+    d_cnt = torch.full((n_loc,), -7, dtype=torch.int32, device=dev)
+    sol.select_neighbours_device(n_loc, first, N, n_obs, comm_range, torch.from_numpy(P).to(dev), d_nbr, d_cnt)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy(), cnt)
+    assert np.array_equal(d_nbr.cpu().numpy().reshape(n_loc, n_obs), want)
+    assert (cnt > n_obs).any() or comm_range == 1e-3 or n_obs >= 20  # the capacity rule is exercised in the small-n_obs cases

@@ -1,7 +1,7 @@
 """Closed-loop replanning with every row of the path on the device, in the reference's default configuration
 (mode/planner = lsc, mode/goal = grid_based_planner: generateCLSC + constructSFCFromConvexHull + GoalOptimizer + TrajOptimizer):
 
-    world boxes -> voxel map -> [ per replan: shift previous plans -> corridors -> CLSC rows -> goal LP -> trajectory QP
+    world boxes -> voxel map -> [ per replan: shift previous plans -> neighbours in range -> corridors -> CLSC rows -> goal LP -> trajectory QP
                                   -> isSolValid / next state -> safety metrics ]
 
     python tools/closed_loop.py [--steps 40] [--world tests/golden/forest10_world.json]
@@ -101,9 +101,10 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     upb = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
 
-    # neighbours: every other agent (the reference broadcasts all agents within range; 10 agents in a 10 m world)
-    nbr = np.array([[j for j in range(N) if j != a] for a in range(N)], dtype=np.int32)
-    d_nbr = up(nbr)
+    # neighbours: chosen on the device each replan, the other agents within the communication range of the launch file (3 m)
+    d_nbr = torch.full((N * n_obs,), -1, dtype=torch.int32, device=dev)
+    d_ncount = torch.zeros(N, dtype=torch.int32, device=dev)
+    comm_range = 3.0
     d_rad = torch.full((N,), radius, dtype=torch.float64, device=dev)
     d_dw = torch.full((N,), 2.0, dtype=torch.float64, device=dev)
     d_off = up((np.arange(N + 1) * n_obs * M * 6).astype(np.uint64).view(np.int64))
@@ -155,6 +156,7 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None):
             P = np.stack([last, goal_pt, waypoint], axis=1)
             sol.construct_sfc_device(wmap, api.SFC_FROM_HULL, N, up(P.reshape(-1)), d_rad, d_sfc, d_sst)
         d_goal_all = up(goal_pt)
+        sol.select_neighbours_device(N, 0, N, n_obs, comm_range, up(state[:, :3]), d_nbr, d_ncount)  # broadcastMsgs' range filter
         sol.generate_constraints_device(api.GEN_CLSC, N, n_obs, 0, d_traj, d_nbr, d_rad, d_dw, d_goal_all, d_rows)
         hdr = np.zeros(N, api.HEADER_DTYPE)
         hdr["p0"], hdr["v0"], hdr["a0"] = state[:, 0:3], state[:, 3:6], state[:, 6:9]
