@@ -197,7 +197,7 @@ def main():
 
     # ---- single-launch latency distribution (enqueue -> results readable), device-resident inputs ----------
     lat = []
-    for _ in range(300):
+    for _ in range(1050):  # p50 / p99 over >= 1000 timed calls
         a = time.perf_counter()
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
@@ -205,12 +205,20 @@ def main():
     lat = np.array(lat[50:]) * 1e3
     # batch-of-1 latency (the unchanged sequential simulator loop, src/multi_sync_simulator.cpp:357-362)
     lat1 = []
-    for _ in range(200):
+    for _ in range(1050):
         a = time.perf_counter()
         sol.solve_device(1, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
         lat1.append(time.perf_counter() - a)
     lat1 = np.array(lat1[50:]) * 1e3
+    # the host-pointer entry (lscqp_solve_batch: H2D of the inputs, solve, D2H of the results) -- PCIe-inclusive, never `value`
+    lath = []
+    x0_host = None if d_xinit is None else d_xinit.cpu().numpy().reshape(N, nv)
+    for _ in range(250):
+        a = time.perf_counter()
+        sol.solve_host(hdr, rows, off, sfc, want_info=False, x_init=x0_host)
+        lath.append(time.perf_counter() - a)
+    lath = np.array(lath[50:]) * 1e3
     sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
     torch.cuda.synchronize()
 
@@ -268,7 +276,9 @@ def main():
             "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N, "valu": valu,
         },
         "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
-                       "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99))},
+                       "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99)),
+                       "host_pointers_batch_p50": float(np.percentile(lath, 50)), "host_pointers_batch_p99": float(np.percentile(lath, 99)),
+                       "samples": {"device_resident": int(len(lat)), "single_qp": int(len(lat1)), "host_pointers": int(len(lath))}},
         "solver": {"non_optimal": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
     }
 
