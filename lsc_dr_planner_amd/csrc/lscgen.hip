@@ -44,7 +44,10 @@ __device__ __forceinline__ double fast_rcp(double d) {
 // decides whether the origin is inside (distance 0).  Everything is evaluated on the Gram matrix G_ij = p_i . p_j (21
 // dot products, computed once): an edge or triangle candidate then costs a dozen scalar operations instead of vector
 // arithmetic, and only the winner's barycentric weights are turned back into a point.
-__device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
+// `planar`: all points share z = 0 (2-D missions).  The closest point of a planar hull to an origin in its plane lies on an
+// edge or a vertex unless the origin is inside, which the supporting-plane test at the end detects on its own: the 20
+// triangle candidates are skipped (a wave-uniform branch), the result is the same.
+__device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6], bool planar = false) {
     double G[6][6];
 #pragma unroll
     for (int i = 0; i < 6; i++)
@@ -77,6 +80,7 @@ __device__ __forceinline__ P3 hull_closest_point(const P3 (&p)[6]) {
             const double t = r1 * fast_rcp(ok ? den : 1.0);
             consider(G[i][i] - t * r1, ok && t >= 0.0 && t <= 1.0, i, j, i, t, 0.0);
         }
+    if (!planar)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -337,7 +341,10 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
                 relf[i] = fsub(trf(cpt(ga, m, i)), trf(pob[i]));
                 rel[i] = {(double)relf[i].x, (double)relf[i].y, (double)relf[i].z};
             }
-            const P3 cp = hull_closest_point(rel);
+            bool flat = dim == 2;  // generateCLSC does not transform in 2-D (:666-672): planar only if all z are equal
+#pragma unroll
+            for (int i = 0; i < 6; i++) flat = flat && relf[i].z == 0.0f;
+            const P3 cp = hull_closest_point(rel, flat);
             nrm = fnormalized(F3{(float)cp.x, (float)cp.y, (float)cp.z});  // no fallback normal in generateCLSC: zero rows drop out
 #pragma unroll
             for (int i = 0; i < 6; i++) d[i] = 0.5 * (collision_dist + fdot(relf[i], nrm));
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
         relf[i][2] = (dim == 3) ? azf - bzf : 0.0f;
         rel[i] = {(double)relf[i][0], (double)relf[i][1], (double)relf[i][2]};
     }
-    const P3 cp = hull_closest_point(rel);
+    const P3 cp = hull_closest_point(rel, dim == 2);
     // closest_point2 is a point3d (float), normalized() in float (:1195); hull around the origin -> fallback (:624-633)
     float nx = (float)cp.x, ny = (float)cp.y, nz = (float)cp.z;
     float len = sqrtf(nx * nx + ny * ny + nz * nz);

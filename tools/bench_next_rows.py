@@ -17,7 +17,7 @@ from lsc_dr_planner_amd import api, synth  # noqa: E402
 
 N = ([int(a) for a in sys.argv[1:] if a.isdigit()] or [4096])[0]
 CPU = "--cpu" in sys.argv
-M, dim, n_obs = 5, 3, 20
+M, dim, n_obs = 5, (2 if "--dim2" in sys.argv else 3), 20
 dev = torch.device("cuda", 0)
 if CPU:
     from oracle import oracle as O
