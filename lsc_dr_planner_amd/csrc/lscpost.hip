@@ -103,6 +103,25 @@ __global__ __launch_bounds__(kThreads) void validate_step_kernel(int M, int dim,
 // at t_s into LDS (about 2 flop per pair of redundant work, no scratch buffer in HBM) and every lane scans its slice of it.
 constexpr int kSafI = 32, kSafS = 8, kSafT = kSafI * kSafS;
 
+__device__ __forceinline__ double post_rcp(double d) {  // 1/d: v_rcp_f64 + two Newton steps
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double post_sqrt(double x) {  // sqrt(x), x >= 0: v_rsq_f64 + two coupled Newton steps
+    if (!(x > 0.0)) return 0.0;
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    return fma(fma(-g, g, x), h, g);  // final correction: g + (x - g^2) * h
+}
+
 // position (float32, as State holds it) of the trajectory xq at time t
 __device__ __forceinline__ void position_at(int M, int dim, double dt, double t, double z_2d, const double* xq, float (&pos)[3]) {
     const int P = 6 * M;
@@ -187,17 +206,20 @@ __global__ __launch_bounds__(kSafT) void safety_metrics_kernel(int M, int dim, d
             const int cnt = (int)((n_total - tile < kSafT) ? n_total - tile : kSafT);
             for (int jj = slice; jj < cnt; jj += kSafS) {
                 const int64_t j = tile + jj;
+                // 16.8 M pairs at 4096 agents: the two divisions and the square root per pair go through v_rcp_f64 / v_rsq_f64
+                // plus Newton steps (full fp64 accuracy to the last bit or two) instead of the IEEE sequences
                 const double rsum = ri + tr[jj];
-                const double dwn = (dri + tdr[jj]) / rsum;  // :505-507
+                const double irs = post_rcp(rsum);
+                const double dwn = (dri + tdr[jj]) * irs;  // :505-507
                 // point3d delta = p_i - p_j (float); delta.z /= downwash; norm() = sqrt of the float sum of squares
                 const float dx = pi[0] - tp[jj][0], dy = pi[1] - tp[jj][1];
-                const float dz = (float)((double)(pi[2] - tp[jj][2]) / dwn);
+                const float dz = (float)((double)(pi[2] - tp[jj][2]) * post_rcp(dwn));
                 float nsq;
                 {
 #pragma clang fp contract(off)
                     nsq = dx * dx + dy * dy + dz * dz;
                 }
-                const double ratio = sqrt((double)nsq) / rsum;
+                const double ratio = post_sqrt((double)nsq) * irs;
                 const int64_t key = (int64_t)s * n_total + j;
                 const bool take = (j != gi) && (ratio < best || (ratio == best && key < best_key));
                 best = take ? ratio : best;
