@@ -90,6 +90,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            try:  # the solve path has no collective; RCCL only carries the barrier, the timing reduction and --allgather
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:  # RCCL unusable on this node: the measurement does not depend on it, keep going over gloo
+                sys.stderr.write("bench.py: RCCL probe failed (%s); falling back to gloo for barrier / reductions\n" % e)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
