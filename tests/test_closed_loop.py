@@ -19,7 +19,9 @@ def test_forest10_closed_loop_is_safe_and_feasible():
     # every QP of 60 replans x 10 agents solves and passes isSolValid: the generated constraints are mutually consistent
     assert log["qp_failed"] == 0 and log["invalid"] == 0 and log["sfc_kept"] == 0, log
     # the LSC guarantee: agents never come closer than the sum of their radii (reference summary: safety_ratio_agent >= 1)
-    assert log["min_safety_ratio"] >= 1.0 - 1e-6, log
+    # (up to the float32 truncation of the control points, which the reference applies as well: 5e-7 m on a 5 m coordinate
+    # is 3e-6 of the 0.3 m the ratio is measured in)
+    assert log["min_safety_ratio"] >= 1.0 - 5e-6, log
     assert log["max_vel_excess"] <= 1e-5 and log["max_acc_excess"] <= 1e-5, log
     assert log["mean_progress_m"] > 1.5, log  # and they do fly towards their goals
     assert log["max_iters"] <= 30, log
