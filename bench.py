@@ -375,6 +375,24 @@ def main():
                 bq = sol2.algorithmic_bytes(sw2.n_obs)
                 extra.append({"agents": nb, "kernel_ms": ms, "qp_per_s": nb / (ms * 1e-3),
                               "hbm_frac": bq * nb / (ms * 1e-3) / HBM_PEAK, "non_optimal": int((dst.cpu().numpy() != 0).sum())})
+                if nb == 4096:
+                    # BASELINE configs[4] (4096 agents x 5 segments, 16-byte rows): the same batch with the rows stored as
+                    # float32 (LSCQP_ROWS_F32: half the bytes; the arithmetic and the result format stay fp64)
+                    sol3 = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw2.world_min, world_max=sw2.world_max, row_format=api.ROWS_F32))
+                    dr3 = to_dev(torch, sol3.rows_in_format(r2), dev)
+                    for _ in range(3):
+                        sol3.solve_device(nb, sw2.n_obs, dh, dr3, do, ds, dx, dob, dst, None, d_x_init=dxi)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(reps):
+                        sol3.solve_device(nb, sw2.n_obs, dh, dr3, do, ds, dx, dob, dst, None, d_x_init=dxi)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms3 = e0.elapsed_time(e1) / reps
+                    bq3 = sol3.algorithmic_bytes(sw2.n_obs)
+                    extra.append({"agents": nb, "rows": "f32 (16 B)", "algorithmic_bytes_per_qp": bq3, "kernel_ms": ms3,
+                                  "qp_per_s": nb / (ms3 * 1e-3), "hbm_frac": bq3 * nb / (ms3 * 1e-3) / HBM_PEAK,
+                                  "non_optimal": int((dst.cpu().numpy() != 0).sum())})
             except Exception as ex:  # informational only
                 extra.append({"agents": nb, "error": str(ex)[:200]})
         out["extra_batch_sweep"] = extra

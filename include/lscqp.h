@@ -66,6 +66,15 @@ enum {
 
 /* Problem class: everything TrajOptimizer caches from Param/Mission at construction
  * (src/traj_optimizer.cpp:4-16) plus the Param fields populatebyrow reads. */
+/* Storage format of the packed LSC rows, a property of the class (row_format below).  The reference's LSC record holds its
+ * normal and obstacle point as float32 and only d as double (include/collision_constraints.hpp:19-33); LSCQP_ROWS_F32 stores
+ * the packed row (nx, ny, nz, b = d + n.p_obs) as four floats -- half the HBM bytes of the batch, SURVEY.md section 8d's byte model
+ * for BASELINE configs[4] (10 832 B per QP at M = 5, 20 neighbours; the SFC boxes stay fp64) -- and is widened to fp64 when a kernel stages it: every
+ * entry point that reads or writes rows (solve, goal LP, constraint generation) follows the handle's format, the arithmetic
+ * stays fp64, and a solve on f32 rows equals bit for bit the solve on f64 rows holding the same float values. */
+#define LSCQP_ROWS_F64 0
+#define LSCQP_ROWS_F32 1
+
 typedef struct lscqp_class_desc {
     int32_t M;            /* param.M   — number of segments, >= 2 */
     int32_t n;            /* param.n   — must be 5 */
@@ -74,7 +83,7 @@ typedef struct lscqp_class_desc {
     int32_t dim;          /* param.world_dimension, 2 or 3 */
     int32_t planner_mode; /* LSCQP_PLANNER_* */
     int32_t use_sfc;      /* param.world_use_octomap: SFC rows present (:372) */
-    int32_t reserved0;
+    int32_t row_format;   /* LSCQP_ROWS_F64 (0, default): lscqp_row, 32 B; LSCQP_ROWS_F32: lscqp_row_f32, 16 B (see below) */
     double dt;                   /* param.dt */
     double control_input_weight; /* param.control_input_weight (:294) */
     double terminal_weight;      /* param.terminal_weight (:304) */
@@ -86,6 +95,12 @@ typedef struct lscqp_class_desc {
     int32_t reserved1;
     double tol;       /* relative duality-gap tolerance, 0 = default 1e-10 */
 } lscqp_class_desc;
+
+/* A packed row in the LSCQP_ROWS_F32 format; pointers declared `lscqp_row*` below then point at arrays of this type, and row
+ * offsets stay in units of rows. */
+typedef struct lscqp_row_f32 {
+    float nx, ny, nz, b;
+} lscqp_row_f32;
 
 /* Per-QP header: the fields of Agent (include/sp_const.hpp:146-160) that populatebyrow reads.
  * Exactly 256 bytes. */

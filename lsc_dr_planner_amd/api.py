@@ -24,6 +24,8 @@ HEADER_DTYPE = np.dtype([
     ("n_obs", "i4"), ("terminal_segments", "i4"), ("reserved", "u4", 2), ("pad", "f8", 7),
 ])
 ROW_DTYPE = np.dtype([("nx", "f8"), ("ny", "f8"), ("nz", "f8"), ("b", "f8")])
+ROW_F32_DTYPE = np.dtype([("nx", "f4"), ("ny", "f4"), ("nz", "f4"), ("b", "f4")])  # lscqp_row_f32 (row_format = ROWS_F32)
+ROWS_F64, ROWS_F32 = 0, 1
 BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)])
 SAFETY_DTYPE = np.dtype([("safety_ratio", "f8"), ("closest_agent", "i4"), ("sample", "i4"), ("vel_excess_ratio", "f8", 3),
                          ("acc_excess_ratio", "f8", 3)])
@@ -36,7 +38,7 @@ assert INFO_DTYPE.itemsize == 32
 class ClassDesc(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("n", C.c_int32), ("phi", C.c_int32), ("phi_n", C.c_int32), ("dim", C.c_int32),
-        ("planner_mode", C.c_int32), ("use_sfc", C.c_int32), ("reserved0", C.c_int32),
+        ("planner_mode", C.c_int32), ("use_sfc", C.c_int32), ("row_format", C.c_int32),
         ("dt", C.c_double), ("control_input_weight", C.c_double), ("terminal_weight", C.c_double),
         ("communication_range", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
         ("max_iter", C.c_int32), ("reserved1", C.c_int32), ("tol", C.c_double),
@@ -129,8 +131,9 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
 
 
 def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
-              world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0):
+              world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0, row_format=ROWS_F64):
     d = ClassDesc()
+    d.row_format = row_format
     d.M, d.n, d.phi, d.phi_n, d.dim = M, n, phi, phi_n, dim
     d.planner_mode, d.use_sfc = planner_mode, int(use_sfc)
     d.dt, d.control_input_weight, d.terminal_weight, d.communication_range = dt, w_c, w_t, comm_range
@@ -202,6 +205,19 @@ class Solver:
         self.nv = lib().lscqp_num_variables(self._h)
         self.M, self.dim, self.P = desc.M, desc.dim, desc.M * 6
 
+    def rows_in_format(self, rows):
+        """Packed rows (ROW_DTYPE or ROW_F32_DTYPE) in the handle's storage format; fp64 rows are rounded to float32 for
+        a ROWS_F32 handle (what a producer writing that format would store)."""
+        rows = np.asarray(rows)
+        want = ROW_F32_DTYPE if self.desc.row_format == ROWS_F32 else ROW_DTYPE
+        if rows.dtype != want:
+            src = np.ascontiguousarray(rows, dtype=ROW_DTYPE if rows.dtype.names is None else rows.dtype).reshape(-1)
+            out = np.zeros(src.shape, want)
+            for f in ("nx", "ny", "nz", "b"):
+                out[f] = src[f]
+            rows = out
+        return np.ascontiguousarray(rows).reshape(-1)
+
     def close(self):
         if self._h:
             lib().lscqp_destroy(self._h)
@@ -235,7 +251,7 @@ class Solver:
         status = np.full(n, -1, dtype=np.int32)
         info = np.zeros(n, INFO_DTYPE) if want_info else None
         if rows is not None:
-            rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE).reshape(-1)
+            rows = self.rows_in_format(rows)
             row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
             assert len(row_offsets) == n + 1
         if sfc is not None:
@@ -276,7 +292,7 @@ class Solver:
         hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE).copy()
         status = np.full(n, -1, dtype=np.int32)
         if rows is not None:
-            rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE).reshape(-1)
+            rows = self.rows_in_format(rows)
             row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
         if sfc is not None:
             sfc = np.ascontiguousarray(sfc, dtype=BOX_DTYPE).reshape(-1)

@@ -289,7 +289,8 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
                                                                 const double* __restrict__ radius,
                                                                 const double* __restrict__ downwash,
                                                                 const double* __restrict__ goal,
-                                                                const double* __restrict__ goal_all, lscqp_row* __restrict__ out) {
+                                                                const double* __restrict__ goal_all, int rows_f32,
+                                                                lscqp_row* __restrict__ out) {
     __shared__ double4 stage[kThreads * 6];  // the block's rows in output order: [lane][row], 32 B each (48 KiB)
     const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool live = t < n_units;
@@ -429,10 +430,17 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
     const int64_t base_row = (int64_t)blockIdx.x * kThreads * 6;
     const int64_t n_rows = n_units * 6;
     double4* o4 = reinterpret_cast<double4*>(out);
+    float4* o4f = reinterpret_cast<float4*>(out);  // LSCQP_ROWS_F32: the same rows rounded to float32, 16 B each
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const int rix = k * kThreads + threadIdx.x;  // row index within the block
-        if (base_row + rix < n_rows) o4[base_row + rix] = stage[rix];
+        if (base_row + rix < n_rows) {
+            const double4 v = stage[rix];
+            if (rows_f32)
+                o4f[base_row + rix] = float4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+            else
+                o4[base_row + rix] = v;
+        }
     }
 }
 
@@ -557,8 +565,8 @@ extern "C" int lscqp_select_neighbours_raw_(int64_t n_agents, int64_t first_agen
 
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
-                                       const double* d_downwash, const double* d_goal, const double* d_goal_all, lscqp_row* d_rows_out,
-                                       void* stream) {
+                                       const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
+                                       lscqp_row* d_rows_out, void* stream) {
     const int64_t n_units = n_agents * (int64_t)n_obs * M;
     if (n_units == 0) return LSCQP_OK;
     const unsigned blocks = (unsigned)((n_units + lscgen::kThreads - 1) / lscgen::kThreads);
@@ -566,7 +574,7 @@ extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agent
                  : mode == LSCQP_GEN_BVC ? lscgen::generate_lsc_kernel<LSCQP_GEN_BVC>
                                          : lscgen::generate_lsc_kernel<LSCQP_GEN_LSC>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n_units, n_obs, first_agent, d_traj,
-                       d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, d_rows_out);
+                       d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, rows_f32, d_rows_out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;

@@ -21,7 +21,7 @@ constexpr int kThreads = 64;
 constexpr double kEpsFloat = 1e-5;  // SP_EPSILON_FLOAT (reference include/sp_const.hpp)
 constexpr double kFeasTol = 1e-9;   // slack allowed on a_r = 0 rows and on L <= U (CPLEX's own LP tolerance is 1e-6)
 
-__global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_sfc, int64_t n, lscqp_header* __restrict__ hdr,
+__global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
                                                         const lscqp_box* __restrict__ sfc, int32_t* __restrict__ status) {
     const int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -58,9 +58,16 @@ __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_
         }
     }
     const int n_obs = H->n_obs;
-    const lscqp_row* R = rows + (n_obs > 0 ? row_offsets[q] : 0);
+    const uint64_t roff = n_obs > 0 ? row_offsets[q] : 0;
     for (int o = 0; o < n_obs; o++) {
-        const lscqp_row r = R[((size_t)o * M + (M - 1)) * 6 + 5];  // getLSC(oi, M-1, n)
+        const size_t ri = roff + ((size_t)o * M + (M - 1)) * 6 + 5;  // getLSC(oi, M-1, n)
+        lscqp_row r;
+        if (rows_f32) {
+            const lscqp_row_f32 f = reinterpret_cast<const lscqp_row_f32*>(rows)[ri];
+            r = lscqp_row{(double)f.nx, (double)f.ny, (double)f.nz, (double)f.b};
+        } else {
+            r = rows[ri];
+        }
         if (sqrt(r.nx * r.nx + r.ny * r.ny + r.nz * r.nz) < kEpsFloat) continue;  // :142-144
         double a = r.nx * dgw[0] + r.ny * dgw[1], c = r.nx * w[0] + r.ny * w[1];
         if (dim == 3) {
@@ -82,11 +89,11 @@ __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
 
-extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream) {
     if (n == 0) return LSCQP_OK;
     const unsigned blocks = (unsigned)((n + lscgoal::kThreads - 1) / lscgoal::kThreads);
-    hipLaunchKernelGGL(lscgoal::goal_kernel, dim3(blocks), dim3(lscgoal::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, n, d_hdr, d_rows,
+    hipLaunchKernelGGL(lscgoal::goal_kernel, dim3(blocks), dim3(lscgoal::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, rows_f32, n, d_hdr, d_rows,
                        d_row_offsets, d_sfc, d_status);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());

@@ -22,9 +22,9 @@ LSCQP_INSTANCES(LSCQP_DECL)
 
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
-                                       const double* d_downwash, const double* d_goal, const double* d_goal_all, lscqp_row* d_rows_out,
-                                       void* stream);
-extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                       const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
+                                       lscqp_row* d_rows_out, void* stream);
+extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
 extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
                                          double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
@@ -127,6 +127,8 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     // same argument checks as the reference: (n, phi) must be (5, 3) (src/traj_optimizer.cpp:198-201),
     // dim <= 3 (:249); M >= 2 is assumed by the continuity rows (:341-352)
     if (d->n != 5 || d->phi != 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "[TrajOptimizer] Currently, only n=5, phi=3 is available");
+    if (d->row_format != LSCQP_ROWS_F64 && d->row_format != LSCQP_ROWS_F32)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "row_format must be LSCQP_ROWS_F64 or LSCQP_ROWS_F32");
     if (d->phi_n != 1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "phi_n must be 1");
     if (d->dim < 2 || d->dim > 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "[TrajOptimizer] Invalid output dimension, output_dim > 3");
     if (d->M < 2) return fail(LSCQP_ERR_INVALID_ARGUMENT, "M must be >= 2");
@@ -168,8 +170,11 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.max_iter = d->max_iter > 0 ? d->max_iter : 60;
     c.use_sfc = d->use_sfc;
     c.n_obs_max = 0;
+    c.rows_f32 = d->row_format == LSCQP_ROWS_F32;
     return LSCQP_OK;
 }
+
+static inline size_t row_bytes(lscqp_handle h) { return h->dev.rows_f32 ? sizeof(lscqp_row_f32) : sizeof(lscqp_row); }
 
 extern "C" {
 
@@ -217,7 +222,7 @@ int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, i
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     return lscqp_generate_lsc_raw_(LSCQP_GEN_LSC, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
-                                   d_downwash, d_goal, nullptr, d_rows_out, stream);
+                                   d_downwash, d_goal, nullptr, h->dev.rows_f32, d_rows_out, stream);
 }
 
 int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
@@ -234,7 +239,7 @@ int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_ag
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     return lscqp_generate_lsc_raw_(mode, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
-                                   d_downwash, d_goal_all + 3 * first_agent, d_goal_all, d_rows_out, stream);
+                                   d_downwash, d_goal_all + 3 * first_agent, d_goal_all, h->dev.rows_f32, d_rows_out, stream);
 }
 
 int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, double z_2d, const double* d_x_prev, double* d_traj,
@@ -253,7 +258,7 @@ int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, d
 int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t n_total) {
     if (!h) return -1;
     const int64_t P = h->P;
-    return n_agents * (int64_t)n_obs * P * 32      /* rows written */
+    return n_agents * (int64_t)n_obs * P * (h->dev.rows_f32 ? 16 : 32) /* rows written */
            + n_total * (P * 24 + 16)               /* control points, radius, downwash */
            + n_agents * ((int64_t)n_obs * 4 + 24); /* neighbour ids, goal */
 }
@@ -267,7 +272,7 @@ int lscqp_optimize_goal_device(lscqp_handle h, int64_t n, lscqp_header* d_hdr, c
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_goal_raw_(h->desc.M, h->desc.dim, h->desc.use_sfc, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status_out, stream);
+    return lscqp_goal_raw_(h->desc.M, h->desc.dim, h->desc.use_sfc, h->dev.rows_f32, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status_out, stream);
 }
 
 int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
@@ -288,7 +293,7 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
     if (h->desc.use_sfc && !sfc) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null sfc buffer");
     const size_t n_rows = n_obs_max > 0 ? (size_t)row_offsets[n] : 0;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(sizeof(lscqp_row) * n_rows), b_off = al(sizeof(uint64_t) * (n + 1)),
+    const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(row_bytes(h) * n_rows), b_off = al(sizeof(uint64_t) * (n + 1)),
                  b_sfc = al(sizeof(lscqp_box) * n * h->desc.M), b_st = al(sizeof(int32_t) * n);
     const size_t total = b_hdr + b_rows + b_off + b_sfc + b_st;
     if (total > h->d_cap) {
@@ -310,7 +315,7 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
         if (e_ != hipSuccess) return fail(LSCQP_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
     } while (0)
     LSCQP_CK(hipMemcpy(d_hdr, hdr, sizeof(lscqp_header) * n, hipMemcpyHostToDevice));
-    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, sizeof(lscqp_row) * n_rows, hipMemcpyHostToDevice));
+    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, row_bytes(h) * n_rows, hipMemcpyHostToDevice));
     if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
     if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
     int rc = lscqp_optimize_goal_device(h, n, d_hdr, d_rows, d_off, d_sfc, d_st, nullptr);
@@ -394,7 +399,7 @@ int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs) {
     if (!h) return -1;
     // rows (32 B each, all n_obs*P of them) + SFC boxes (48 B/segment) + header (256 B) in;
     // control points (8 B each) + objective + status (16 B) out.
-    return (int64_t)32 * n_obs * h->P + 48 * h->desc.M + 256 + 8 * h->nv + 16;
+    return (int64_t)(h->dev.rows_f32 ? 16 : 32) * n_obs * h->P + 48 * h->desc.M + 256 + 8 * h->nv + 16;
 }
 
 int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
@@ -452,7 +457,7 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     if (h->desc.use_sfc && !sfc) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null sfc buffer");
     const size_t n_rows = n_obs_max > 0 ? (size_t)row_offsets[n] : 0;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(sizeof(lscqp_row) * n_rows),
+    const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(row_bytes(h) * n_rows),
                  b_off = al(sizeof(uint64_t) * (n + 1)), b_sfc = al(sizeof(lscqp_box) * n * h->desc.M),
                  b_x = al(sizeof(double) * n * h->nv), b_obj = al(sizeof(double) * n), b_st = al(sizeof(int32_t) * n),
                  b_info = al(sizeof(lscqp_info) * n), b_xi = x_init ? b_x : 0;
@@ -480,7 +485,7 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
         if (e_ != hipSuccess) return fail(LSCQP_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
     } while (0)
     LSCQP_CK(hipMemcpy(d_hdr, hdr, sizeof(lscqp_header) * n, hipMemcpyHostToDevice));
-    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, sizeof(lscqp_row) * n_rows, hipMemcpyHostToDevice));
+    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, row_bytes(h) * n_rows, hipMemcpyHostToDevice));
     if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
     else LSCQP_CK(hipMemset(d_off, 0, sizeof(uint64_t) * (n + 1)));
     if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
@@ -498,6 +503,6 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
 
 const char* lscqp_last_error(void) { return g_err.c_str(); }
 
-const char* lscqp_version(void) { return "lscqp 0.3 (gfx950, fp64 PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics)"; }
+const char* lscqp_version(void) { return "lscqp 0.4 (gfx950, fp64 PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics)"; }
 
 }  // extern "C"

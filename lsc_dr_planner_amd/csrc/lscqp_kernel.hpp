@@ -41,7 +41,7 @@ struct DevClass {
     int max_iter;
     int use_sfc;
     int n_obs_max;  // number of obstacles the launch must accommodate (<= NSLOT * G of the instance)
-    int pad;
+    int rows_f32;   // lscqp_class_desc.row_format == LSCQP_ROWS_F32
 };
 
 // Q_base * dt^5 for n = 5, phi = 3 (integers)
@@ -496,7 +496,13 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         const int nact = n_obs * CP;
         for (int e = lane; e < nact; e += T) {
             const int o = e / CP, cp = e % CP;
-            const double4 v = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
+            double4 v;
+            if (cls.rows_f32) {  // LSCQP_ROWS_F32: 16-byte rows, widened here; everything after this line is the same arithmetic
+                const float4 f = reinterpret_cast<const float4*>(rows)[row_offsets[q] + (uint64_t)(o * P + cp + 3)];
+                v = double4{(double)f.x, (double)f.y, (double)f.z, (double)f.w};
+            } else {
+                v = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
+            }
             double nx = v.x, ny = v.y, nz = (DIM == 3) ? v.z : 0.0;
             double b = v.w - (v.x * org0 + v.y * org1 + (DIM == 3 ? v.z * org2 : 0.0));
             if (sqrt(v.x * v.x + v.y * v.y + v.z * v.z) < 1e-5) {  // dropped like the reference does (:409-411)
