@@ -25,3 +25,36 @@ def test_forest10_closed_loop_is_safe_and_feasible():
     assert log["max_vel_excess"] <= 1e-5 and log["max_acc_excess"] <= 1e-5, log
     assert log["mean_progress_m"] > 1.5, log  # and they do fly towards their goals
     assert log["max_iters"] <= 30, log
+
+
+@pytest.mark.gpu
+def test_closed_loop_replan_matches_the_oracle(oracle):
+    """One replan from the middle of the run -- CLSC rows, corridors and goal all produced on the device -- re-solved by the
+    CPU oracle from the very same buffers: the parity bar of the QP (objective 1e-8, x 1e-6 m) holds on the reference's
+    default configuration too (M = 10, 2-D, 9 neighbours, agents interacting)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop
+
+    log = closed_loop.run(os.path.join(ROOT, "tests", "golden", "forest10_world.json"), steps=26, keep_step=25)
+    K = log["kept"]
+    hdr, rows, sfc = K["hdr"], K["rows"], K["sfc"]
+    N, M, n_obs = len(hdr), sfc.shape[1], K["n_obs"]
+    cls = oracle.make_class(M=M, dim=2, use_sfc=True, world_min=K["world_min"], world_max=K["world_max"])
+    R = rows.reshape(N, n_obs, M, 6)
+    active = 0
+    for q in range(N):
+        ag = oracle.make_agent(p0=hdr["p0"][q], v0=hdr["v0"][q], a0=hdr["a0"][q], goal=hdr["goal"][q], next_waypoint=hdr["next_waypoint"][q],
+                               vmax=hdr["vmax"][q], amax=hdr["amax"][q], radius=hdr["radius"][q],
+                               nominal_velocity=hdr["nominal_velocity"][q], n_obs=n_obs)
+        lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)  # packed rows n.c >= b  ==  LSC with p_obs = 0, d = b
+        lsc["nrm"][..., 0], lsc["nrm"][..., 1], lsc["nrm"][..., 2], lsc["d"] = R["nx"][q], R["ny"][q], R["nz"][q], R["b"][q]
+        box = np.zeros(M, oracle.BOX_DTYPE)
+        box["bmin"], box["bmax"] = sfc["bmin"][q], sfc["bmax"][q]
+        o = oracle.solve(cls, ag, lsc, box)
+        assert o["status"] == 0 and K["status"][q] == 0
+        assert abs(o["obj"] - K["obj"][q]) <= 1e-8 * max(1.0, abs(o["obj"])), (q, o["obj"], K["obj"][q])
+        assert np.abs(o["x"] - K["x"][q]).max() <= 1e-6, q
+        active += int((np.linalg.norm(lsc["nrm"], axis=-1) > 1e-5).any())
+    assert active >= N // 2  # the agents do see each other at that point of the run

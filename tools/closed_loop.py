@@ -84,7 +84,7 @@ class GridRouter:
         return self.wmin + self.sp * np.array(arg), self.wmin + self.sp * np.array([i, j])
 
 
-def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None):
+def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=None):
     import torch
 
     from lsc_dr_planner_amd import api
@@ -173,6 +173,10 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None):
         qst, valid = d_qst.cpu().numpy(), d_valid.cpu().numpy()
         good = (qst == 0) & (valid == 1)
         x_new = d_x.cpu().numpy().reshape(N, nv)
+        if keep_step is not None and step == keep_step:  # inputs and outputs of one replan, for the parity test
+            log["kept"] = dict(hdr=d_hdr.cpu().numpy().view(api.HEADER_DTYPE).copy(), rows=d_rows.cpu().numpy().view(api.ROW_DTYPE).copy(),
+                               sfc=d_sfc.cpu().numpy().view(api.BOX_DTYPE).reshape(N, M).copy(), x=d_x.cpu().numpy().reshape(N, nv).copy(),
+                               obj=d_obj.cpu().numpy().copy(), status=qst.copy(), n_obs=n_obs, world_min=g["world_min"], world_max=g["world_max"])
         if dump and (qst != 0).any() and not os.path.exists(dump):
             np.savez(dump, hdr=d_hdr.cpu().numpy(), rows=d_rows.cpu().numpy(), sfc=d_sfc.cpu().numpy(), qst=qst, x_init=x_init,
                      info=d_info.cpu().numpy(), step=step)
