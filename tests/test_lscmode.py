@@ -185,3 +185,47 @@ def test_gpu_neighbour_selection_matches_oracle(api, oracle, N, n_obs, comm_rang
     assert np.array_equal(d_cnt.cpu().numpy(), cnt)
     assert np.array_equal(d_nbr.cpu().numpy().reshape(n_loc, n_obs), want)
     assert (cnt > n_obs).any() or comm_range == 1e-3 or n_obs >= 20  # the capacity rule is exercised in the small-n_obs cases
+
+
+@pytest.mark.gpu
+def test_bvc_mode_end_to_end_on_the_default_shape(api, oracle):
+    """planner mode BVC on the reference's default shape (M = 10, 2-D): generateBVC rows from the device feed the QP without
+    the LSC-mode end-stop rows (src/traj_optimizer.cpp:502-511 applies them in LSC mode only); the oracle re-solves from the
+    same rows."""
+    import torch
+
+    N, M, dim, n_obs = 10, 10, 2, 9
+    sw, b = _swarm(N, M, dim, n_obs, 2)
+    dev = torch.device("cuda", 0)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=api.PLANNER_BVC, world_min=sw.world_min, world_max=sw.world_max))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, planner_lsc=False, world_min=sw.world_min, world_max=sw.world_max)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    goal_all = np.ascontiguousarray(b["goal"], dtype=np.float64)
+    nbr = b["nbr"].astype(np.int32)
+    d_rows = torch.zeros(N * n_obs * M * 6 * 4, dtype=torch.float64, device=dev)
+    sol.generate_constraints_device(api.GEN_BVC, N, n_obs, 0, up(b["init"]), up(nbr), up(np.full(N, sw.radius)),
+                                    up(np.full(N, sw.downwash)), up(goal_all), d_rows)
+    hdr, _, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+    upb = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_x = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    sol.solve_device(N, n_obs, upb(hdr), d_rows, upb(off), upb(sfc), d_x, d_obj, d_st)
+    torch.cuda.synchronize()
+    R = d_rows.cpu().numpy().view(api.ROW_DTYPE).reshape(N, n_obs, M, 6)
+    x, obj, st = d_x.cpu().numpy().reshape(N, -1), d_obj.cpu().numpy(), d_st.cpu().numpy()
+    assert (st == 0).all()
+    for q in range(N):
+        ag = oracle.make_agent(p0=hdr["p0"][q], v0=hdr["v0"][q], a0=hdr["a0"][q], goal=hdr["goal"][q], next_waypoint=hdr["next_waypoint"][q],
+                               vmax=hdr["vmax"][q], amax=hdr["amax"][q], radius=hdr["radius"][q],
+                               nominal_velocity=hdr["nominal_velocity"][q], n_obs=n_obs)
+        lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+        lsc["nrm"][..., 0], lsc["nrm"][..., 1], lsc["nrm"][..., 2], lsc["d"] = R["nx"][q], R["ny"][q], R["nz"][q], R["b"][q]
+        box = np.zeros(M, oracle.BOX_DTYPE)
+        box["bmin"], box["bmax"] = b["sfc"]["bmin"][q], b["sfc"]["bmax"][q]
+        o = oracle.solve(cls, ag, lsc, box)
+        assert o["status"] == 0
+        assert abs(o["obj"] - obj[q]) <= 1e-8 * max(1.0, abs(o["obj"])) and np.abs(o["x"] - x[q]).max() <= 1e-6, q
+    # no end stop in BVC mode: some plan still moves at the end of the horizon
+    X = x.reshape(N, dim, M, 6)
+    assert np.abs(X[:, :, M - 1, 5] - X[:, :, M - 1, 4]).max() > 1e-4
