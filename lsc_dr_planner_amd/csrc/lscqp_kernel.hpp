@@ -938,6 +938,12 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                             break;
                         }
                     }
+                } else if (res_gap <= 10.0 * tol && rdn <= 1e-8 * gls) {
+                    // duplicated active rows (generateCLSC puts one plane on all six control points of the last segment, and
+                    // the end stop makes three of them the same variable) leave the gap hovering just above the target until
+                    // the factorisation breaks down: such a point -- KKT residuals within the stated 1e-8, objective within
+                    // 1e-9 -- is kept as a fallback as well, never as a reason to stop
+                    floor_cnt++;
                 }
             } else
                 res_gap = sum_sl + sum_pinf;

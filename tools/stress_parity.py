@@ -16,14 +16,19 @@ from lsc_dr_planner_amd import api, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
+GEN = None  # --gen 0|1|2: the rows come from the device generator (generateLSC / generateCLSC / generateBVC), not from synth
+if "--gen" in sys.argv:
+    GEN = int(sys.argv[sys.argv.index("--gen") + 1])
 WARM = "--warm" in sys.argv  # hand the initial trajectory (shifted previous plan) to the solver as primal start
 shapes = [(48, 5, 3, 20, "forest"), (32, 6, 3, 20, "maze"), (16, 10, 2, 9, "forest"), (24, 7, 3, 12, "maze"), (32, 4, 3, 12, "forest"),
           (24, 10, 3, 40, "forest"), (40, 5, 2, 12, "forest"), (24, 8, 2, 12, "maze")]
+if "--shape" in sys.argv:
+    shapes = [shapes[int(sys.argv[sys.argv.index("--shape") + 1])]]
 bad_total = 0
 for (N, M, dim, n_obs, style) in shapes:
     worst_dx = worst_do = 0.0
     iters = []
-    nbad = 0
+    nbad = n_both_bad = 0
     for seed in range(100, 100 + n_seeds):
         sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
         cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
@@ -31,17 +36,31 @@ for (N, M, dim, n_obs, style) in shapes:
         for step in range(3):
             b = sw.build()
             hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
-            G = sol.solve_host(hdr, rows, off, sfc, x_init=api.x_init_from_swarm(b, dim) if WARM else None)
             ag, lsc, loff, sfco = H.swarm_oracle_inputs(O, sw, b)
+            if GEN is not None:
+                dev = torch.device("cuda", 0)
+                up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+                d_rows = torch.zeros(N * sw.n_obs * M * 6 * 4, dtype=torch.float64, device=dev)
+                sol.generate_constraints_device(GEN, N, sw.n_obs, 0, up(b["init"]), up(b["nbr"].astype(np.int32)), up(np.full(N, sw.radius)),
+                                                up(np.full(N, sw.downwash)), up(np.ascontiguousarray(b["goal"], dtype=np.float64)), d_rows)
+                torch.cuda.synchronize()
+                rows = d_rows.cpu().numpy().view(api.ROW_DTYPE).copy()
+                lsc = np.zeros(rows.shape[0], O.LSC_DTYPE)  # packed row n.c >= b  ==  LSC with p_obs = 0, d = b
+                lsc["nrm"][:, 0], lsc["nrm"][:, 1], lsc["nrm"][:, 2], lsc["d"] = rows["nx"], rows["ny"], rows["nz"], rows["b"]
+            G = sol.solve_host(hdr, rows, off, sfc, x_init=api.x_init_from_swarm(b, dim) if WARM else None)
             R = O.solve_batch(cls, ag, lsc, loff, sfco, threads=16)
             both = (G["status"] == 0) & (R["status"] == 0)
+            n_both_bad += int(((G["status"] != 0) & (R["status"] != 0)).sum())
             dx = np.abs(G["x"] - R["x"]).max(axis=1)
             do = np.abs(G["obj"] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))
             for q in range(N):
-                if G["status"][q] != R["status"][q] or (both[q] and (dx[q] > 1e-6 or do[q] > 1e-8)):
+                # a disagreement is one side optimal and the other not (the two solvers name their failures differently:
+                # INFEASIBLE here, a stalled / numeric exit in the oracle), or an optimum outside the parity tolerances
+                if (G["status"][q] == 0) != (R["status"][q] == 0) or (both[q] and (dx[q] > 1e-6 or do[q] > 1e-8)):
                     nbad += 1
-                    print("  MISMATCH %s seed %d step %d q %d: gpu status %d oracle %d dx %.2e dobj %.2e it %d" % (
-                        (N, M, dim, n_obs, style), seed, step, q, G["status"][q], R["status"][q], dx[q], do[q], G["info"]["iterations"][q]))
+                    print("  MISMATCH %s seed %d step %d q %d: gpu status %d oracle %d dx %.2e dobj %.2e it %d (res_p %.1e res_d %.1e gap %.1e)" % (
+                        (N, M, dim, n_obs, style), seed, step, q, G["status"][q], R["status"][q], dx[q], do[q], G["info"]["iterations"][q],
+                        G["info"]["res_primal"][q], G["info"]["res_dual"][q], G["info"]["gap"][q]))
             if both.any():
                 worst_dx = max(worst_dx, dx[both].max())
                 worst_do = max(worst_do, do[both].max())
@@ -49,6 +68,6 @@ for (N, M, dim, n_obs, style) in shapes:
             sw.advance(np.where((G["status"] == 0)[:, None], G["x"], R["x"]))
     it = np.concatenate(iters)
     bad_total += nbad
-    print("%-28s seeds %d: mismatches %d, max dx %.2e, max rel dobj %.2e, iterations mean %.2f max %d" % (
-        str((N, M, dim, n_obs, style)), n_seeds, nbad, worst_dx, worst_do, it.mean(), it.max()))
+    print("%-28s seeds %d: mismatches %d, max dx %.2e, max rel dobj %.2e, iterations mean %.2f max %d, non-optimal on both sides %d" % (
+        str((N, M, dim, n_obs, style)), n_seeds, nbad, worst_dx, worst_do, it.mean(), it.max(), n_both_bad))
 print("TOTAL mismatches", bad_total)
