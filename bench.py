@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cold-start", action="store_true", help="do not hand the initial trajectories to the solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the latency loops (their launches would mix into a kernel trace of the timed steps)")
     args = ap.parse_args()
 
     import torch
@@ -209,8 +211,9 @@ def main():
         return
 
     # ---- single-launch latency distribution (enqueue -> results readable), device-resident inputs ----------
+    n_lat, n_lath = (60, 60) if args.no_latency else (1050, 250)
     lat = []
-    for _ in range(1050):  # p50 / p99 over >= 1000 timed calls
+    for _ in range(n_lat):  # p50 / p99 over >= 1000 timed calls
         a = time.perf_counter()
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
@@ -218,20 +221,20 @@ def main():
     lat = np.array(lat[50:]) * 1e3
     # batch-of-1 latency (the unchanged sequential simulator loop, src/multi_sync_simulator.cpp:357-362)
     lat1 = []
-    for _ in range(1050):
+    for _ in range(n_lat if not args.no_latency else 0):
         a = time.perf_counter()
         sol.solve_device(1, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
         lat1.append(time.perf_counter() - a)
-    lat1 = np.array(lat1[50:]) * 1e3
+    lat1 = np.array(lat1[50:] or [float('nan')]) * 1e3
     # the host-pointer entry (lscqp_solve_batch: H2D of the inputs, solve, D2H of the results) -- PCIe-inclusive, never `value`
     lath = []
     x0_host = None if d_xinit is None else d_xinit.cpu().numpy().reshape(N, nv)
-    for _ in range(250):
+    for _ in range(n_lath if not args.no_latency else 0):
         a = time.perf_counter()
         sol.solve_host(hdr, rows, off, sfc, want_info=False, x_init=x0_host)
         lath.append(time.perf_counter() - a)
-    lath = np.array(lath[50:]) * 1e3
+    lath = np.array(lath[50:] or [float('nan')]) * 1e3
     sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
     torch.cuda.synchronize()
 

@@ -22,7 +22,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 os.makedirs(OUT, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-BENCH_SHORT = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-extra"]
+BENCH_SHORT = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-extra",
+               "--no-latency"]  # the default step counts; no side loops, so the trace averages the timed 64-QP launches
 
 
 def run(cmd, log):
@@ -80,8 +81,8 @@ write, nw, _ = pmc(["WRITE_SIZE"], "write")
 sq, ns, _ = pmc(["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU",
                  "SQ_WAIT_INST_ANY"], "sq")
 res = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) -- python bench.py --steps 50 "
-              "--warmup 5 --no-cpu-baseline --no-extra; dispatches of the PDIP kernel with 64 workgroups (= the 64-QP batch) only",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) -- python bench.py --steps 200 "
+              "--warmup 20 --no-cpu-baseline --no-extra --no-latency; dispatches of the PDIP kernel with 64 workgroups (= the 64-QP batch) only",
     "kernel": disp.get("Kernel_Name"),
     "qps_per_launch": 64,
     "launches_averaged": nf.get("FETCH_SIZE"),
