@@ -906,12 +906,16 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             res_d = rdn / gls;
             // Infeasible instances (opposing half-spaces, a waypoint out of communication range, limits the start state
             // violates ...) show a primal residual that stays above 1e-2 m and shrinks by less than 30 % over four
-            // iterations, for ever; feasible ones are below 1e-3 m by iteration 6 in every class measured (M = 10 with 40
+            // iterations, for ever; feasible ones are below 1e-4 m by iteration 10 in every class measured (M = 10 with 40
             // neighbours included).  Stop such an instance instead of running it to the iteration limit: the workgroup's
             // launch lasts as long as its slowest QP, and the caller falls back to the initial trajectory anyway
             // (reference src/traj_planner.cpp:767-797).  Tested every fourth iteration from the tenth on.
+            // Marginally infeasible instances creep down to ~1e-3 m before they stall while their multipliers run away
+            // (sum lambda |r_p| passes 1e6 within a few more iterations): the stall test therefore goes down to 1e-4 m, and a
+            // runaway multiplier-weighted residual ends the instance as well.
             if ((it & 3) == 2) {
-                if (it >= 10 && max_rp > 1e-3 && max_rp > 0.7 * (double)rp_ref) {  // uniform over the QP's lanes
+                if (it >= 10 && ((max_rp > 1e-4 && max_rp > 0.7 * (double)rp_ref) ||  // uniform over the QP's lanes
+                                 (max_rp > 1e-5 && sum_pinf > 1e6))) {
                     status = LSCQP_STATUS_INFEASIBLE;
                     break;
                 }

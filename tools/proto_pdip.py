@@ -175,9 +175,9 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             if np.abs(rd).max() <= 10 * tol * gls or near_cnt >= 2:
                 status = 0
                 break
-        # infeasible instances: the primal residual stalls above 1e-3 (same test as the kernel)
+        # infeasible instances: the primal residual stalls above 1e-4, or the multipliers run away (same test as the kernel)
         if it % 4 == 2:
-            if it >= 10 and np.abs(rp).max() > 1e-3 and np.abs(rp).max() > 0.7 * rp_ref:
+            if it >= 10 and ((np.abs(rp).max() > 1e-4 and np.abs(rp).max() > 0.7 * rp_ref) or (np.abs(rp).max() > 1e-5 and pinf > 1e6)):
                 status = 1
                 break
             rp_ref = float(np.float32(np.abs(rp).max()))
