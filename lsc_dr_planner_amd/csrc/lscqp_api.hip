@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -498,6 +499,51 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     if (info_out) LSCQP_CK(hipMemcpy(info_out, d_info, sizeof(lscqp_info) * n, hipMemcpyDeviceToHost));
 #undef LSCQP_CK
+    // An interior-point iteration started from the caller's trajectory can jam against the boundary (a few instances in ten
+    // thousand: residuals at machine precision, the gap stuck around 1e-6): instances that ran out of
+    // iterations or broke down numerically are solved once more from the default start, which does not depend on x_init.
+    // Infeasible instances are not retried.
+    if (x_init) {
+        std::vector<int64_t> again;
+        for (int64_t q = 0; q < n; q++)
+            if (status_out[q] == LSCQP_STATUS_ITER_LIMIT || status_out[q] == LSCQP_STATUS_NUMERIC) again.push_back(q);
+        if (!again.empty()) {
+            const int64_t m = (int64_t)again.size();
+            const size_t rb = row_bytes(h);
+            std::vector<lscqp_header> hs(m);
+            std::vector<uint64_t> os(m + 1, 0);
+            std::vector<lscqp_box> bs(h->desc.use_sfc ? (size_t)m * h->desc.M : 0);
+            std::vector<char> rs;
+            for (int64_t i = 0; i < m; i++) {
+                const int64_t q = again[i];
+                hs[i] = hdr[q];
+                const size_t nr = hdr[q].n_obs > 0 ? (size_t)hdr[q].n_obs * h->P : 0;
+                if (nr) {
+                    const char* src = reinterpret_cast<const char*>(rows) + rb * (size_t)row_offsets[q];
+                    rs.insert(rs.end(), src, src + rb * nr);
+                }
+                os[i + 1] = os[i] + nr;
+                if (h->desc.use_sfc) std::copy(sfc + q * h->desc.M, sfc + (q + 1) * h->desc.M, bs.begin() + i * h->desc.M);
+            }
+            std::vector<double> xs((size_t)m * h->nv), objs(m);
+            std::vector<int32_t> sts(m);
+            std::vector<lscqp_info> infos(m);
+            const int rc2 = lscqp_solve_batch(h, m, hs.data(), reinterpret_cast<const lscqp_row*>(rs.data()), os.data(),
+                                              bs.empty() ? nullptr : bs.data(), nullptr, xs.data(), objs.data(), sts.data(), infos.data());
+            if (rc2 != LSCQP_OK) return rc2;
+            for (int64_t i = 0; i < m; i++) {
+                if (sts[i] != LSCQP_STATUS_OPTIMAL) continue;
+                const int64_t q = again[i];
+                std::copy(xs.begin() + i * h->nv, xs.begin() + (i + 1) * h->nv, x_out + q * h->nv);
+                obj_out[q] = objs[i];
+                status_out[q] = sts[i];
+                if (info_out) {
+                    infos[i].iterations += info_out[q].iterations;  // both attempts
+                    info_out[q] = infos[i];
+                }
+            }
+        }
+    }
     return LSCQP_OK;
 }
 

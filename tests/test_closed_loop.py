@@ -58,3 +58,18 @@ def test_closed_loop_replan_matches_the_oracle(oracle):
         assert np.abs(o["x"] - K["x"][q]).max() <= 1e-6, q
         active += int((np.linalg.norm(lsc["nrm"], axis=-1) > 1e-5).any())
     assert active >= N // 2  # the agents do see each other at that point of the run
+
+
+@pytest.mark.gpu
+def test_synthetic_forest_closed_loop_with_64_agents():
+    """BASELINE configs[1]'s agent count in closed loop: 64 agents swapping sides through a synthetic forest (the reference's
+    world format), 20 neighbour slots per agent with up to ~40 agents within the 3 m communication range (the capacity rule of
+    the neighbour selection at work), M = 10 segments.  Every QP of 80 replans solves (a jammed warm start is re-launched cold),
+    nothing collides."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop
+
+    log = closed_loop.run(closed_loop.random_forest_world(64), steps=80, n_obs=20)
+    assert log["qp_failed"] == 0 and log["invalid"] == 0, log
+    assert log["min_safety_ratio"] >= 1.0 - 5e-6 and log["max_vel_excess"] <= 1e-5 and log["max_acc_excess"] <= 1e-5, log
+    assert log["max_in_range"] > 20 and log["mean_progress_m"] > 3.0, log

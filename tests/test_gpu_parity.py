@@ -364,3 +364,47 @@ def test_initial_trajectory_as_primal_start(api, oracle, torch_cuda, N, M, dim, 
             it_warm += warm["info"]["iterations"].sum()
         sw.advance(warm["x"])
     assert it_warm <= it_cold
+
+
+def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_cuda):
+    """An instance from the 64-agent closed loop (tests/golden/warm_start_jam.json) whose iteration, started from the shifted
+    previous plan, stalls with the gap near 6e-7: the host entry point solves it once more from the default start and returns
+    the optimum (the oracle's, to the parity bar); the device entry point reports the failure as it is."""
+    torch = torch_cuda
+    g = H.load_golden("warm_start_jam")
+    M, dim, n_obs = g["M"], g["dim"], g["n_obs"]
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=g["world_min"], world_max=g["world_max"]))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=g["world_min"], world_max=g["world_max"])
+    hdr = np.zeros(1, api.HEADER_DTYPE)
+    for f, v in g["hdr"].items():
+        hdr[f][0] = v
+    hdr["n_obs"][0] = n_obs
+    R = np.array(g["rows"])
+    rows = np.zeros(len(R), api.ROW_DTYPE)
+    rows["nx"], rows["ny"], rows["nz"], rows["b"] = R[:, 0], R[:, 1], R[:, 2], R[:, 3]
+    sfc = np.zeros(M, api.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = g["sfc_min"], g["sfc_max"]
+    off = np.array([0, len(R)], dtype=np.uint64)
+    x0 = np.array(g["x_init"])[None]
+    G = sol.solve_host(hdr, rows, off, sfc, x_init=x0)
+    assert G["status"][0] == 0 and G["info"]["iterations"][0] > 60  # both attempts are counted
+    ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
+    lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+    lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)
+    lsc["d"] = R[:, 3].reshape(n_obs, M, 6)
+    o = oracle.solve(cls, ag, lsc, sfc)
+    assert o["status"] == 0
+    assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= 1e-6
+    # the device entry point cannot look at the status without synchronising: it reports ITER_LIMIT, and a cold re-launch solves it
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_x = torch.zeros(sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_st = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    args = (1, n_obs, up(hdr), up(rows), up(off), up(sfc), d_x, d_obj, d_st)
+    sol.solve_device(*args, d_x_init=torch.from_numpy(x0.copy()).to(dev))
+    torch.cuda.synchronize()
+    assert d_st.item() == 2
+    sol.solve_device(*args)
+    torch.cuda.synchronize()
+    assert d_st.item() == 0 and abs(d_obj.item() - o["obj"]) <= OBJ_TOL * max(1.0, abs(o["obj"]))

@@ -84,17 +84,37 @@ class GridRouter:
         return self.wmin + self.sp * np.array(arg), self.wmin + self.sp * np.array([i, j])
 
 
-def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=None):
+def random_forest_world(n_agents=64, side=24.0, n_boxes=150, seed=0, clearance=0.8):
+    """A synthetic 2-D forest in the reference's world format (pillars 0.5 x 0.5 x 2.5 m, like world/forest/*.csv) with
+    n_agents start / goal pairs on opposite sides of a circle (the antipodal swap of the reference's missions), all on the
+    0.5 m grid and clear of the pillars."""
+    rng = np.random.default_rng(seed)
+    half = side / 2
+    ang = np.linspace(0, 2 * np.pi, n_agents, endpoint=False)
+    starts = np.round(np.c_[np.cos(ang), np.sin(ang)] * (half - 2.0) / 0.5) * 0.5
+    goals = -starts
+    boxes = []
+    while len(boxes) < n_boxes:
+        c = rng.uniform(-half + 1, half - 1, 2)
+        if np.abs(starts - c).max(axis=1).min() < clearance or np.abs(goals - c).max(axis=1).min() < clearance:
+            continue
+        boxes.append([c[0], c[1], 1.25, 0.5, 0.5, 2.5])
+    z = 0.6
+    return {"boxes": boxes, "world_min": [-half, -half, 0.0], "world_max": [half, half, 2.5], "resolution": 0.1, "max_dist": 1.0,
+            "z_2d": z, "radius": 0.15, "starts": [[p[0], p[1], z] for p in starts], "goals": [[p[0], p[1], z] for p in goals]}
+
+
+def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=None, n_obs=None):
     import torch
 
     from lsc_dr_planner_amd import api
 
-    g = json.load(open(world_json))
+    g = world_json if isinstance(world_json, dict) else json.load(open(world_json))
     dev = torch.device("cuda", 0)
     dim, z2d, radius = 2, float(g["z_2d"]), float(g["radius"])
     starts, desired = np.array(g["starts"], dtype=np.float64), np.array(g["goals"], dtype=np.float64)
     N = len(starts)
-    n_obs = N - 1
+    n_obs = N - 1 if n_obs is None else n_obs  # capacity of the row buffers per agent (the nearest n_obs if more are in range)
     sol = api.Solver(api.make_desc(M=M, dim=dim, dt=dt, world_min=g["world_min"], world_max=g["world_max"]))
     wmap = api.WorldMap(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
     nv = sol.nv
@@ -171,6 +191,23 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
         sol.validate_step_device(N, dt, d_x, d_hdr, d_sfc, d_valid, d_state, z_2d=z2d)
         torch.cuda.synchronize()
         qst, valid = d_qst.cpu().numpy(), d_valid.cpu().numpy()
+        if ((qst == 2) | (qst == 3)).any():
+            # a warm-started iteration that ran out of iterations or broke down: one cold re-launch of the batch, results taken
+            # for those agents only (what the host entry point lscqp_solve_batch does by itself)
+            d_x2, d_obj2, d_st2 = torch.zeros_like(d_x), torch.zeros_like(d_obj), torch.zeros_like(d_qst)
+            sol.solve_device(N, n_obs, d_hdr, d_rows, d_off, d_sfc, d_x2, d_obj2, d_st2)
+            torch.cuda.synchronize()
+            st2 = d_st2.cpu().numpy()
+            fix = ((qst == 2) | (qst == 3)) & (st2 == 0)
+            if fix.any():
+                sel = torch.from_numpy(np.nonzero(fix)[0]).to(dev)
+                d_x.view(N, nv)[sel] = d_x2.view(N, nv)[sel]
+                d_obj[sel] = d_obj2[sel]
+                d_qst[sel] = d_st2[sel]
+                log["cold_retries"] = log.get("cold_retries", 0) + int(fix.sum())
+                sol.validate_step_device(N, dt, d_x, d_hdr, d_sfc, d_valid, d_state, z_2d=z2d)
+                torch.cuda.synchronize()
+                qst, valid = d_qst.cpu().numpy(), d_valid.cpu().numpy()
         good = (qst == 0) & (valid == 1)
         x_new = d_x.cpu().numpy().reshape(N, nv)
         if keep_step is not None and step == keep_step:  # inputs and outputs of one replan, for the parity test
@@ -190,6 +227,7 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
         state = d_state.cpu().numpy().reshape(N, 9)
         d_xprev.copy_(d_x.view(N, nv))
         goal_pt = d_hdr.cpu().numpy().view(api.HEADER_DTYPE)["goal"].copy()  # the goal LP's result is the next current goal point
+        log["max_in_range"] = int(max(log.get("max_in_range", 0), d_ncount.cpu().numpy().max()))
         log["qp_failed"] += int((qst != 0).sum())
         log["invalid"] += int(((qst == 0) & (valid != 1)).sum())
         log["sfc_kept"] += int((d_sst.cpu().numpy() == 0).sum()) if step > 0 else 0
@@ -217,6 +255,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--world", default=os.path.join(ROOT, "tests", "golden", "forest10_world.json"))
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("--forest", type=int, default=0, help="N > 0: a synthetic forest with N agents instead of --world")
+    ap.add_argument("--obs", type=int, default=None, help="neighbour capacity per agent")
     ap.add_argument("--dump", default=None, help="npz path: inputs of the first replan with a failed QP")
     a = ap.parse_args()
-    print(json.dumps(run(a.world, steps=a.steps, verbose=a.v, dump=a.dump)))
+    world = random_forest_world(a.forest) if a.forest > 0 else a.world
+    print(json.dumps(run(world, steps=a.steps, verbose=a.v, dump=a.dump, n_obs=a.obs)))
