@@ -178,10 +178,10 @@ int lscqp_num_variables(lscqp_handle h);
  *   obj_out      [n]     objective INCLUDING the constant terminal term, == cplex.getObjValue() (:100)
  *   status_out   [n]     LSCQP_STATUS_*
  *   info_out     [n] or NULL
- * With x_init given, instances that end in ITER_LIMIT / NUMERIC are solved once more from the default start before the
- * call returns (an iteration started from the caller's trajectory can jam against the boundary in a few instances per ten
- * thousand); lscqp_info.iterations then counts both attempts.  The device variant below cannot look at the statuses without
- * synchronising: its caller re-launches those instances with d_x_init = NULL if it wants the same. */
+ * An iteration started from the caller's trajectory can jam against the boundary (a few instances per ten thousand); the
+ * kernel re-centres such an instance once.  With x_init given, instances that still end in ITER_LIMIT / NUMERIC are solved
+ * once more from the default start before this call returns (lscqp_info.iterations then counts both attempts); the device
+ * variant below cannot look at the statuses without synchronising and leaves that to its caller. */
 int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
                       const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
                       double* obj_out, int32_t* status_out, lscqp_info* info_out);

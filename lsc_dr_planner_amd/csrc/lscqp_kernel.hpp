@@ -673,9 +673,9 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     int status = LSCQP_STATUS_ITER_LIMIT;
     double m_tot = 0;
     SD r_s[NSLOT], r_l[NSLOT];  // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
-    {
-        double cnt = 0;
-        bool bad = false;
+    // centred row state at the current control points c_: s = max(residual, s_c), lambda = mu_c / s.  Used for the start and,
+    // at most once, to re-centre an iteration that has jammed against the boundary (see the loop).
+    auto centre_rows = [&](double mu_c, double s_c, double& cnt, bool& bad) {
 #pragma unroll
         for (int u = 0; u < NS2; u++) {
             double sl0 = 1.0, sh0 = 1.0, l0_ = 0.0;
@@ -683,16 +683,17 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double y = row_val(c_, u);
                 const double lo = t_lo[u].get(), hi = t_hi[u].get();
                 if (lo > hi) bad = true;
-                sl0 = fmax(y - lo, S0MIN);
-                sh0 = fmax(hi - y, S0MIN);
+                sl0 = fmax(y - lo, s_c);
+                sh0 = fmax(hi - y, s_c);
                 l0_ = 1.0;  // marks an existing row; the multipliers are set below
                 cnt += 2.0;
             }
             t_sl[u].set(sl0);
             t_sh[u].set(sh0);
-            t_ll[u].set(l0_ * MU0 * fast_rcp(sl0));  // (an IEEE fp64 division is ~30 instructions; 22 of them per lane here)
-            t_lh[u].set(l0_ * MU0 * fast_rcp(sh0));
+            t_ll[u].set(l0_ * mu_c * fast_rcp(sl0));  // (an IEEE fp64 division is ~30 instructions; 22 of them per lane here)
+            t_lh[u].set(l0_ * mu_c * fast_rcp(sh0));
         }
+        LSCQP_L_ROLES();  // phase-local lane role: the lambda also runs inside the loop
         const double cx = ll ? c_[lx] : 0.0, cy = ll ? c_[P + lx] : 0.0, cz = (ll && DIM == 3) ? c_[2 * P + lx] : 0.0;
 #pragma unroll
         for (int u = 0; u < NSLOT; u++) {
@@ -702,14 +703,19 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const int e = o * CP + lcp;
                 const double nx = Rnx[e], ny = Rny[e], nz = Rnz[e];
                 if ((nx != 0.0) || (ny != 0.0) || (nz != 0.0)) {
-                    s_init = fmax(nx * cx + ny * cy + nz * cz - Rb[e], S0MIN);
-                    l_init = MU0 * fast_rcp(s_init);
+                    s_init = fmax(nx * cx + ny * cy + nz * cz - Rb[e], s_c);
+                    l_init = mu_c * fast_rcp(s_init);
                     cnt += 1.0;
                 }
             }
             r_s[u].set(s_init);
             r_l[u].set(l_init);
         }
+    };
+    {
+        double cnt = 0;
+        bool bad = false;
+        centre_rows(MU0, S0MIN, cnt, bad);
         m_tot = block_sum(cnt);
         if (block_max(bad ? 1.0 : 0.0) > 0.0) status = LSCQP_STATUS_INFEASIBLE;  // empty interval: lo > hi
     }
@@ -776,6 +782,9 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     double res_p = 0, res_d = 0, res_gap = 0;
     int it = 0, near_cnt = 0, floor_cnt = 0;
     float rp_ref = 3.0e38f;  // primal residual four iterations ago (infeasibility test below)
+    float gap_mark = 3.0e38f;  // jam test: the gap when it last improved tenfold, iterations since, done once
+    int jam_since = 0;
+    bool recentred = false;
     const double tol = cls.tol;
     const bool comm_on_k = cls.comm_range > 0;
     // (row of the scratch matrix a lane assembles into: non-z lanes share one dummy row, index NZ, that is never read)
@@ -949,8 +958,35 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     // 1e-9 -- is kept as a fallback as well, never as a reason to stop
                     floor_cnt++;
                 }
+                // A warm-started iteration can jam: residuals at machine precision, the gap stuck near 1e-6 because some rows sit
+                // at the boundary with the wrong member of their (slack, multiplier) pair at zero -- a few instances in ten
+                // thousand, which the default start solves in a handful of iterations (tests/golden/warm_start_jam.json).  If the
+                // gap has not improved tenfold within six such iterations the row state is re-centred ONCE at the current control
+                // points (every product back to mu0) and the iteration carries on from there.
+                // (counted only for a warm-started iteration that is already close, gap <= 1e-4: a cold start is primal feasible
+                // from the first iteration on and legitimately spends many iterations bringing a large gap down)
+                if (res_gap > tol && res_gap <= 1e-4 && x_init != nullptr) {
+                    if ((float)res_gap <= 0.1f * gap_mark) {
+                        gap_mark = (float)res_gap;
+                        jam_since = 0;
+                    } else {
+                        jam_since++;
+                    }
+                }
             } else
                 res_gap = sum_sl + sum_pinf;
+            // (never once a point that meets the gap target has been seen: then the iteration is polishing its stationarity
+            // residual, not jammed, and that point is the fallback the exits below rely on)
+            if (!recentred && jam_since >= 6 && floor_cnt == 0) {  // uniform over the QP's lanes
+                double cnt_ = 0;
+                bool bad_ = false;
+                centre_rows(1e-3, 0.03, cnt_, bad_);
+                recentred = true;
+                rp_ref = 3.0e38f;
+                near_cnt = 0;
+                LSCQP_BLOCK_SYNC();
+                continue;
+            }
             LSCQP_T(2);
             LSCQP_STOP(3)
 

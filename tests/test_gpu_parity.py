@@ -368,8 +368,8 @@ def test_initial_trajectory_as_primal_start(api, oracle, torch_cuda, N, M, dim, 
 
 def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_cuda):
     """An instance from the 64-agent closed loop (tests/golden/warm_start_jam.json) whose iteration, started from the shifted
-    previous plan, stalls with the gap near 6e-7: the host entry point solves it once more from the default start and returns
-    the optimum (the oracle's, to the parity bar); the device entry point reports the failure as it is."""
+    previous plan, stalls with the gap near 6e-7 unless the row state is re-centred: both entry points return the optimum (the
+    oracle's, to the parity bar)."""
     torch = torch_cuda
     g = H.load_golden("warm_start_jam")
     M, dim, n_obs = g["M"], g["dim"], g["n_obs"]
@@ -387,7 +387,7 @@ def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_c
     off = np.array([0, len(R)], dtype=np.uint64)
     x0 = np.array(g["x_init"])[None]
     G = sol.solve_host(hdr, rows, off, sfc, x_init=x0)
-    assert G["status"][0] == 0 and G["info"]["iterations"][0] > 60  # both attempts are counted
+    assert G["status"][0] == 0
     ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
     lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
     lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)
@@ -402,9 +402,13 @@ def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_c
     d_obj = torch.zeros(1, dtype=torch.float64, device=dev)
     d_st = torch.full((1,), -1, dtype=torch.int32, device=dev)
     args = (1, n_obs, up(hdr), up(rows), up(off), up(sfc), d_x, d_obj, d_st)
-    sol.solve_device(*args, d_x_init=torch.from_numpy(x0.copy()).to(dev))
+    d_info = torch.zeros(api.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    sol.solve_device(*args, d_info=d_info, d_x_init=torch.from_numpy(x0.copy()).to(dev))
     torch.cuda.synchronize()
-    assert d_st.item() == 2
-    sol.solve_device(*args)
+    # the kernel notices the jam (no tenfold improvement of the gap within six converged-residual iterations), re-centres the
+    # row state once at the current point and finishes: far fewer than the 60 + 8 iterations of a failed attempt plus a cold one
+    assert d_st.item() == 0 and abs(d_obj.item() - o["obj"]) <= OBJ_TOL * max(1.0, abs(o["obj"]))
+    assert d_info.cpu().numpy().view(api.INFO_DTYPE)["iterations"][0] <= 40
+    sol.solve_device(*args)  # and the default start needs no help
     torch.cuda.synchronize()
     assert d_st.item() == 0 and abs(d_obj.item() - o["obj"]) <= OBJ_TOL * max(1.0, abs(o["obj"]))

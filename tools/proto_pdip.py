@@ -160,6 +160,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
     status, it, near_cnt, rp_ref = 2, 0, 0, 3.0e38
+    gap_mark, jam_since, recentred, floor_seen = 3.0e38, 0, False, False
     for it in range(max_iter):
         rp = Gz @ z - hz - s
         grad = Kfull @ z + gfull
@@ -181,6 +182,21 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
                 status = 1
                 break
             rp_ref = float(np.float32(np.abs(rp).max()))
+        # jammed warm start (same rule as the kernel): residuals converged, the gap below 1e-4 but without a tenfold improvement
+        # within six such iterations and never at its target -> the row state is re-centred once at the current point
+        if warm and not recentred and np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-6 * gls:
+            gap_rel = (mu * mrows + pinf) / (1 + abs(objz + objc))
+            if tol < gap_rel <= 1e-4:
+                if gap_rel <= 0.1 * gap_mark:
+                    gap_mark, jam_since = gap_rel, 0
+                else:
+                    jam_since += 1
+            if jam_since >= 6 and not floor_seen:
+                s = np.maximum(Gz @ z - hz, 0.03)
+                lam = 1e-3 / s
+                recentred, rp_ref, near_cnt = True, 3.0e38, 0
+                continue
+            floor_seen = floor_seen or gap_rel <= tol
         w = lam / s
         K = Kfull + Gz.T @ (w[:, None] * Gz)
         try:
