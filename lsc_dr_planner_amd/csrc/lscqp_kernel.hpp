@@ -965,6 +965,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 // points (every product back to mu0) and the iteration carries on from there.
                 // (counted only for a warm-started iteration that is already close, gap <= 1e-4: a cold start is primal feasible
                 // from the first iteration on and legitimately spends many iterations bringing a large gap down)
+#ifndef LSCQP_NO_RECENTRE  // (A/B switch; carrying the test costs ~1 % of a step, measured with tools/_bis builds)
                 if (res_gap > tol && res_gap <= 1e-4 && x_init != nullptr) {
                     if ((float)res_gap <= 0.1f * gap_mark) {
                         gap_mark = (float)res_gap;
@@ -973,10 +974,12 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                         jam_since++;
                     }
                 }
+#endif
             } else
                 res_gap = sum_sl + sum_pinf;
             // (never once a point that meets the gap target has been seen: then the iteration is polishing its stationarity
             // residual, not jammed, and that point is the fallback the exits below rely on)
+#ifndef LSCQP_NO_RECENTRE
             if (!recentred && jam_since >= 6 && floor_cnt == 0) {  // uniform over the QP's lanes
                 double cnt_ = 0;
                 bool bad_ = false;
@@ -987,6 +990,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 LSCQP_BLOCK_SYNC();
                 continue;
             }
+#endif
             LSCQP_T(2);
             LSCQP_STOP(3)
 
