@@ -485,8 +485,52 @@ __global__ __launch_bounds__(64) void select_neighbours_kernel(int64_t n_agents,
     auto in_range = [&](int64_t j, double limit) -> bool {
         return j < n_total && j != gi && !(range > 0 && dist_of(j) > limit);
     };
+    // pass 1: count the agents in range and keep them (distance, id; id order) in LDS while they fit
+    constexpr int kCap = 1024;
+    __shared__ double cand_d[kCap];
+    __shared__ int32_t cand_j[kCap];
     int total = 0;
-    for (int64_t base = 0; base < n_total; base += 64) total += __popcll(__ballot(in_range(base + lane, range)));
+    for (int64_t base = 0; base < n_total; base += 64) {
+        const int64_t j = base + lane;
+        const bool valid = j < n_total && j != gi;
+        const double d = valid ? dist_of(j) : 0.0;
+        const bool in = valid && !(range > 0 && d > range);
+        const unsigned long long m = __ballot(in);
+        const int p = total + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && p < kCap) {
+            cand_d[p] = d;
+            cand_j[p] = (int32_t)j;
+        }
+        total += __popcll(m);
+    }
+    __syncthreads();
+    if (total <= kCap) {
+        // everything in range is in LDS.  No overflow: copy the first `total`.  Overflow: an entry stays if fewer than n_obs
+        // entries precede it in (distance, id) order -- a rank count over at most kCap candidates -- and the survivors are
+        // compacted in id order (the list is in id order already)
+        const bool capped_l = total > n_obs && n_obs > 0;
+        int written = 0;
+        for (int base = 0; base < total && written < n_obs; base += 64) {
+            const int e = base + lane;
+            bool keep = e < total;
+            if (keep && capped_l) {
+                const double de = cand_d[e];
+                const int32_t je = cand_j[e];
+                int rank = 0;
+                for (int f = 0; f < total; f++) rank += (cand_d[f] < de || (cand_d[f] == de && cand_j[f] < je)) ? 1 : 0;
+                keep = rank < n_obs;
+            }
+            const unsigned long long m = __ballot(keep);
+            const int p = written + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && p < n_obs) nbr[a * n_obs + p] = cand_j[e];
+            written += __popcll(m);
+        }
+        written = written < n_obs ? written : n_obs;
+        for (int p = written + lane; p < n_obs; p += 64) nbr[a * n_obs + p] = -1;
+        if (lane == 0) count[a] = total;
+        return;
+    }
+    // more than kCap agents in range: threshold distance by bisection over all candidates (below)
     double limit = range;
     int n_strict = 0;  // overflow: keep everything nearer than `limit`, then the smallest ids at exactly `limit`
     bool capped = false;

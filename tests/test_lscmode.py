@@ -166,7 +166,8 @@ def test_neighbour_selection_oracle_against_numpy(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,n_obs,comm_range,first,n_loc", [(300, 20, 3.0, 0, 300), (300, 6, 3.0, 100, 77), (130, 40, 0.0, 0, 130),
-                                                            (64, 8, 1e-3, 0, 64), (4096, 20, 3.0, 1024, 512)])
+                                                            (64, 8, 1e-3, 0, 64), (4096, 20, 3.0, 1024, 512),
+                                                            (1500, 8, 0.0, 700, 48)])  # > 1024 agents in range: the bisection path
 def test_gpu_neighbour_selection_matches_oracle(api, oracle, N, n_obs, comm_range, first, n_loc):
     import torch
 

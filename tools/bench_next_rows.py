@@ -77,6 +77,26 @@ if CPU and N <= 4096:
     rec["cpu_oracle_ms_1core_scaled"] = (time.perf_counter() - t0) * 1e3 * N / nn
 print(json.dumps(rec))
 
+# the small per-agent kernels of a replan step: neighbour selection, shift of the previous plans, goal LP, validity / next state
+d_nb2 = torch.zeros(N * n_obs, dtype=torch.int32, device=dev)
+d_cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+d_pos = up(np.float32(sw.pos).astype(np.float64))
+ms = timed(lambda: sol.select_neighbours_device(N, 0, N, n_obs, 3.0, d_pos, d_nb2, d_cnt), reps=100)
+print(json.dumps({"kernel": "select_neighbours (broadcastMsgs range filter)", "agents": N, "kernel_ms": ms, "pairs": N * (N - 1)}))
+ms = timed(lambda: sol.shift_traj_device(N, d_x, d_traj, z_2d=1.0, shift=1), reps=100)
+print(json.dumps({"kernel": "shift_traj (initialTrajPlanningPrevSol)", "agents": N, "kernel_ms": ms}))
+d_off = up((np.arange(N + 1) * n_obs * M * 6).astype(np.int64))
+d_sfc0 = torch.zeros(N * M * 6, dtype=torch.float64, device=dev)
+d_sfc0.view(N, M, 6)[:, :, :3] = -1e3
+d_sfc0.view(N, M, 6)[:, :, 3:] = 1e3
+d_gst = torch.zeros(N, dtype=torch.int32, device=dev)
+ms = timed(lambda: sol.optimize_goal_device(N, d_hdr, d_rows, d_off, d_sfc0, d_gst), reps=100)
+print(json.dumps({"kernel": "optimize_goal (GoalOptimizer LP, closed form)", "agents": N, "kernel_ms": ms}))
+d_valid = torch.zeros(N, dtype=torch.int32, device=dev)
+d_state = torch.zeros(N * 9, dtype=torch.float64, device=dev)
+ms = timed(lambda: sol.validate_step_device(N, 0.2, d_x, d_hdr, d_sfc0, d_valid, d_state), reps=100)
+print(json.dumps({"kernel": "validate_step (isSolValid + doStep)", "agents": N, "kernel_ms": ms}))
+
 # voxel map + corridors: a random 3-D forest of pillars and blocks scaled to the swarm's world, 0.1 m cells
 rng = np.random.default_rng(2)
 wmin, wmax = np.array(sw.world_min, dtype=np.float64), np.array(sw.world_max, dtype=np.float64)

@@ -148,7 +148,7 @@ with open(os.path.join(OUT, tag + "_next_rows.jsonl"), "w") as f:
 for f in glob.glob(os.path.join(dn, "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ("generate_lsc_kernel", "safety_metrics", "construct_sfc", "nearest_",
-                                                                        "rasterise"))]
+                                                                        "rasterise", "select_neighbours", "shift_traj", "goal_kernel", "validate_step"))]
     with open(os.path.join(OUT, tag + "_next_rows_kernel_stats.csv"), "w", newline="") as g:
         csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
 
