@@ -235,6 +235,14 @@ def main():
         sol.solve_host(hdr, rows, off, sfc, want_info=False, x_init=x0_host)
         lath.append(time.perf_counter() - a)
     lath = np.array(lath[50:] or [float('nan')]) * 1e3
+    # ... and for a single QP: what one TrajOptimizer::solve call of the unchanged sequential planner loop costs end to end
+    lath1 = []
+    for _ in range(n_lath if not args.no_latency else 0):
+        a = time.perf_counter()
+        sol.solve_host(hdr[:1], rows.reshape(N, -1)[0], off[:2], sfc.reshape(N, M)[:1], want_info=False,
+                       x_init=None if x0_host is None else x0_host[:1])
+        lath1.append(time.perf_counter() - a)
+    lath1 = np.array(lath1[50:] or [float('nan')]) * 1e3
     sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
     torch.cuda.synchronize()
 
@@ -294,6 +302,7 @@ def main():
         "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
                        "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99)),
                        "host_pointers_batch_p50": float(np.percentile(lath, 50)), "host_pointers_batch_p99": float(np.percentile(lath, 99)),
+                       "host_pointers_single_qp_p50": float(np.percentile(lath1, 50)), "host_pointers_single_qp_p99": float(np.percentile(lath1, 99)),
                        "samples": {"device_resident": int(len(lat)), "single_qp": int(len(lat1)), "host_pointers": int(len(lath))}},
         "solver": {"non_optimal": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
     }

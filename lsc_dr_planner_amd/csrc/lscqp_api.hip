@@ -122,6 +122,8 @@ struct lscqp_solver {
     // staging buffers of the host-pointer entry point
     void* d_buf = nullptr;
     size_t d_cap = 0;
+    void* h_buf = nullptr;  // pinned mirror of d_buf: one H2D and one D2H per host-pointer solve instead of eight small copies
+    size_t h_cap = 0;
 };
 
 static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
@@ -198,6 +200,8 @@ int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
     if (rc != LSCQP_OK) return rc;
     tmp.d_buf = h->d_buf;
     tmp.d_cap = h->d_cap;
+    tmp.h_buf = h->h_buf;
+    tmp.h_cap = h->h_cap;
     *h = tmp;
     return LSCQP_OK;
 }
@@ -205,6 +209,7 @@ int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
 int lscqp_destroy(lscqp_handle h) {
     if (!h) return LSCQP_OK;
     if (h->d_buf) (void)hipFree(h->d_buf);
+    if (h->h_buf) (void)hipHostFree(h->h_buf);
     delete h;
     return LSCQP_OK;
 }
@@ -462,7 +467,9 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
                  b_off = al(sizeof(uint64_t) * (n + 1)), b_sfc = al(sizeof(lscqp_box) * n * h->desc.M),
                  b_x = al(sizeof(double) * n * h->nv), b_obj = al(sizeof(double) * n), b_st = al(sizeof(int32_t) * n),
                  b_info = al(sizeof(lscqp_info) * n), b_xi = x_init ? b_x : 0;
-    const size_t total = b_hdr + b_rows + b_off + b_sfc + b_x + b_obj + b_st + b_info + b_xi;
+    // layout: [hdr | rows | offsets | sfc | x_init] = one contiguous input region, [x | obj | status | info] = one output region
+    const size_t b_in = b_hdr + b_rows + b_off + b_sfc + b_xi, b_out = b_x + b_obj + b_st + b_info;
+    const size_t total = b_in + b_out;
     if (total > h->d_cap) {
         if (h->d_buf) (void)hipFree(h->d_buf);
         h->d_buf = nullptr;
@@ -470,34 +477,46 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
         if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
         h->d_cap = total;
     }
-    char* p = (char*)h->d_buf;
-    lscqp_header* d_hdr = (lscqp_header*)p; p += b_hdr;
-    lscqp_row* d_rows = (lscqp_row*)p; p += b_rows;
-    uint64_t* d_off = (uint64_t*)p; p += b_off;
-    lscqp_box* d_sfc = (lscqp_box*)p; p += b_sfc;
-    double* d_x = (double*)p; p += b_x;
-    double* d_obj = (double*)p; p += b_obj;
-    int32_t* d_st = (int32_t*)p; p += b_st;
-    lscqp_info* d_info = (lscqp_info*)p; p += b_info;
-    double* d_xi = x_init ? (double*)p : nullptr;
+    if (total > h->h_cap) {
+        if (h->h_buf) (void)hipHostFree(h->h_buf);
+        h->h_buf = nullptr;
+        h->h_cap = 0;
+        if (hipHostMalloc(&h->h_buf, total, hipHostMallocDefault) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipHostMalloc failed");
+        h->h_cap = total;
+    }
+    char* const dbase = (char*)h->d_buf;
+    char* const hbase = (char*)h->h_buf;
+    const size_t o_hdr = 0, o_rows = o_hdr + b_hdr, o_off = o_rows + b_rows, o_sfc = o_off + b_off, o_xi = o_sfc + b_sfc,
+                 o_x = b_in, o_obj = o_x + b_x, o_st = o_obj + b_obj, o_info = o_st + b_st;
+    lscqp_header* d_hdr = (lscqp_header*)(dbase + o_hdr);
+    lscqp_row* d_rows = (lscqp_row*)(dbase + o_rows);
+    uint64_t* d_off = (uint64_t*)(dbase + o_off);
+    lscqp_box* d_sfc = (lscqp_box*)(dbase + o_sfc);
+    double* d_xi = x_init ? (double*)(dbase + o_xi) : nullptr;
+    double* d_x = (double*)(dbase + o_x);
+    double* d_obj = (double*)(dbase + o_obj);
+    int32_t* d_st = (int32_t*)(dbase + o_st);
+    lscqp_info* d_info = (lscqp_info*)(dbase + o_info);
 #define LSCQP_CK(call)                                                                           \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
         if (e_ != hipSuccess) return fail(LSCQP_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
     } while (0)
-    LSCQP_CK(hipMemcpy(d_hdr, hdr, sizeof(lscqp_header) * n, hipMemcpyHostToDevice));
-    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, row_bytes(h) * n_rows, hipMemcpyHostToDevice));
-    if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
-    else LSCQP_CK(hipMemset(d_off, 0, sizeof(uint64_t) * (n + 1)));
-    if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
-    if (d_xi) LSCQP_CK(hipMemcpy(d_xi, x_init, sizeof(double) * n * h->nv, hipMemcpyHostToDevice));
+    memcpy(hbase + o_hdr, hdr, sizeof(lscqp_header) * n);
+    if (n_rows) memcpy(hbase + o_rows, rows, row_bytes(h) * n_rows);
+    if (n_obs_max > 0) memcpy(hbase + o_off, row_offsets, sizeof(uint64_t) * (n + 1));
+    else memset(hbase + o_off, 0, sizeof(uint64_t) * (n + 1));
+    if (h->desc.use_sfc) memcpy(hbase + o_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M);
+    if (d_xi) memcpy(hbase + o_xi, x_init, sizeof(double) * n * h->nv);
+    LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, nullptr));
     int rc = lscqp_solve_batch_device(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, nullptr);
     if (rc != LSCQP_OK) return rc;
-    LSCQP_CK(hipDeviceSynchronize());
-    LSCQP_CK(hipMemcpy(x_out, d_x, sizeof(double) * n * h->nv, hipMemcpyDeviceToHost));
-    LSCQP_CK(hipMemcpy(obj_out, d_obj, sizeof(double) * n, hipMemcpyDeviceToHost));
-    LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (info_out) LSCQP_CK(hipMemcpy(info_out, d_info, sizeof(lscqp_info) * n, hipMemcpyDeviceToHost));
+    LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, nullptr));
+    LSCQP_CK(hipStreamSynchronize(nullptr));
+    memcpy(x_out, hbase + o_x, sizeof(double) * n * h->nv);
+    memcpy(obj_out, hbase + o_obj, sizeof(double) * n);
+    memcpy(status_out, hbase + o_st, sizeof(int32_t) * n);
+    if (info_out) memcpy(info_out, hbase + o_info, sizeof(lscqp_info) * n);
 #undef LSCQP_CK
     // An interior-point iteration started from the caller's trajectory can jam against the boundary (a few instances in ten
     // thousand: residuals at machine precision, the gap stuck around 1e-6): instances that ran out of
