@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -39,6 +40,10 @@ struct lscqp_map_s {
     int radius_cells;
     uint8_t* d_occ;
     int32_t* d_nearest;
+    // staging of the host-pointer corridor call (one pinned buffer, one copy each way)
+    void* d_stage = nullptr;
+    void* h_stage = nullptr;
+    size_t stage_cap = 0;
 };
 
 namespace lscsfc {
@@ -515,6 +520,8 @@ void lscqp_map_destroy(lscqp_map mp) {
     if (!mp) return;
     if (mp->d_occ) (void)hipFree(mp->d_occ);
     if (mp->d_nearest) (void)hipFree(mp->d_nearest);
+    if (mp->d_stage) (void)hipFree(mp->d_stage);
+    if (mp->h_stage) (void)hipHostFree(mp->h_stage);
     delete mp;
 }
 
@@ -557,33 +564,33 @@ int lscqp_construct_sfc(lscqp_map mp, int32_t mode, int32_t M, int64_t n, const 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    double *d_p = nullptr, *d_r = nullptr;
-    lscqp_box* d_s = nullptr;
-    int32_t* d_st = nullptr;
-    auto done = [&](int rc) {
-        if (d_p) (void)hipFree(d_p);
-        if (d_r) (void)hipFree(d_r);
-        if (d_s) (void)hipFree(d_s);
-        if (d_st) (void)hipFree(d_st);
-        return rc;
-    };
-    auto bad = [&](hipError_t e, const char* what) {
-        return done(lscqp_set_error_(LSCQP_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str()));
-    };
-    hipError_t e;
-    if ((e = hipMalloc(&d_p, n * 9 * sizeof(double))) != hipSuccess || (e = hipMalloc(&d_r, n * sizeof(double))) != hipSuccess ||
-        (e = hipMalloc(&d_s, n * M * sizeof(lscqp_box))) != hipSuccess || (e = hipMalloc(&d_st, n * sizeof(int32_t))) != hipSuccess)
-        return bad(e, "hipMalloc");
-    if ((e = hipMemcpy(d_p, points, n * 9 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(d_r, radius, n * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(d_s, sfc, n * M * sizeof(lscqp_box), hipMemcpyHostToDevice)) != hipSuccess)
-        return bad(e, "hipMemcpy (in)");
-    const int rc = lscqp_construct_sfc_raw_(mp, mode, M, n, d_p, d_r, d_s, d_st, nullptr);
-    if (rc != LSCQP_OK) return done(rc);
-    if ((e = hipMemcpy(sfc, d_s, n * M * sizeof(lscqp_box), hipMemcpyDeviceToHost)) != hipSuccess ||
-        (e = hipMemcpy(status_out, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess)
-        return bad(e, "hipMemcpy (out)");
-    return done(LSCQP_OK);
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_p = al(n * 9 * sizeof(double)), b_r = al(n * sizeof(double)), b_s = al(n * M * sizeof(lscqp_box)),
+                 b_st = al(n * sizeof(int32_t));
+    const size_t total = b_p + b_r + b_s + b_st;  // [points | radius | boxes (in/out) | status (out)]
+    if (total > mp->stage_cap) {
+        if (mp->d_stage) (void)hipFree(mp->d_stage);
+        if (mp->h_stage) (void)hipHostFree(mp->h_stage);
+        mp->d_stage = mp->h_stage = nullptr;
+        mp->stage_cap = 0;
+        if (hipMalloc(&mp->d_stage, total) != hipSuccess || hipHostMalloc(&mp->h_stage, total, hipHostMallocDefault) != hipSuccess)
+            return lscqp_set_error_(LSCQP_ERR_HIP, "staging allocation failed");
+        mp->stage_cap = total;
+    }
+    char* const hb = (char*)mp->h_stage;
+    char* const db = (char*)mp->d_stage;
+    memcpy(hb, points, n * 9 * sizeof(double));
+    memcpy(hb + b_p, radius, n * sizeof(double));
+    memcpy(hb + b_p + b_r, sfc, n * M * sizeof(lscqp_box));
+    LSCSFC_HIP(hipMemcpyAsync(db, hb, b_p + b_r + b_s, hipMemcpyHostToDevice, nullptr));
+    const int rc = lscqp_construct_sfc_raw_(mp, mode, M, n, (const double*)db, (const double*)(db + b_p), (lscqp_box*)(db + b_p + b_r),
+                                            (int32_t*)(db + b_p + b_r + b_s), nullptr);
+    if (rc != LSCQP_OK) return rc;
+    LSCSFC_HIP(hipMemcpyAsync(hb + b_p + b_r, db + b_p + b_r, b_s + b_st, hipMemcpyDeviceToHost, nullptr));
+    LSCSFC_HIP(hipStreamSynchronize(nullptr));
+    memcpy(sfc, hb + b_p + b_r, n * M * sizeof(lscqp_box));
+    memcpy(status_out, hb + b_p + b_r + b_s, n * sizeof(int32_t));
+    return LSCQP_OK;
 }
 
 }  // extern "C"
