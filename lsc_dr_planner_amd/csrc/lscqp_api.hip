@@ -301,7 +301,8 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_hdr = al(sizeof(lscqp_header) * n), b_rows = al(row_bytes(h) * n_rows), b_off = al(sizeof(uint64_t) * (n + 1)),
                  b_sfc = al(sizeof(lscqp_box) * n * h->desc.M), b_st = al(sizeof(int32_t) * n);
-    const size_t total = b_hdr + b_rows + b_off + b_sfc + b_st;
+    // layout [rows | offsets | sfc | hdr | status]: one H2D of rows .. hdr, one D2H of hdr .. status (pinned staging)
+    const size_t total = b_rows + b_off + b_sfc + b_hdr + b_st;
     if (total > h->d_cap) {
         if (h->d_buf) (void)hipFree(h->d_buf);
         h->d_buf = nullptr;
@@ -309,26 +310,34 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
         if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
         h->d_cap = total;
     }
-    char* p = (char*)h->d_buf;
-    lscqp_header* d_hdr = (lscqp_header*)p; p += b_hdr;
-    lscqp_row* d_rows = (lscqp_row*)p; p += b_rows;
-    uint64_t* d_off = (uint64_t*)p; p += b_off;
-    lscqp_box* d_sfc = (lscqp_box*)p; p += b_sfc;
-    int32_t* d_st = (int32_t*)p;
+    if (total > h->h_cap) {
+        if (h->h_buf) (void)hipHostFree(h->h_buf);
+        h->h_buf = nullptr;
+        h->h_cap = 0;
+        if (hipHostMalloc(&h->h_buf, total, hipHostMallocDefault) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipHostMalloc failed");
+        h->h_cap = total;
+    }
+    char* const db = (char*)h->d_buf;
+    char* const hb = (char*)h->h_buf;
+    const size_t o_rows = 0, o_off = b_rows, o_sfc = o_off + b_off, o_hdr = o_sfc + b_sfc, o_st = o_hdr + b_hdr;
 #define LSCQP_CK(call)                                                                           \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
         if (e_ != hipSuccess) return fail(LSCQP_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); \
     } while (0)
-    LSCQP_CK(hipMemcpy(d_hdr, hdr, sizeof(lscqp_header) * n, hipMemcpyHostToDevice));
-    if (n_rows) LSCQP_CK(hipMemcpy(d_rows, rows, row_bytes(h) * n_rows, hipMemcpyHostToDevice));
-    if (n_obs_max > 0) LSCQP_CK(hipMemcpy(d_off, row_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice));
-    if (h->desc.use_sfc) LSCQP_CK(hipMemcpy(d_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M, hipMemcpyHostToDevice));
-    int rc = lscqp_optimize_goal_device(h, n, d_hdr, d_rows, d_off, d_sfc, d_st, nullptr);
+    if (n_rows) memcpy(hb + o_rows, rows, row_bytes(h) * n_rows);
+    if (n_obs_max > 0) memcpy(hb + o_off, row_offsets, sizeof(uint64_t) * (n + 1));
+    else memset(hb + o_off, 0, sizeof(uint64_t) * (n + 1));
+    if (h->desc.use_sfc) memcpy(hb + o_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M);
+    memcpy(hb + o_hdr, hdr, sizeof(lscqp_header) * n);
+    LSCQP_CK(hipMemcpyAsync(db, hb, o_st, hipMemcpyHostToDevice, nullptr));
+    int rc = lscqp_optimize_goal_device(h, n, (lscqp_header*)(db + o_hdr), (const lscqp_row*)(db + o_rows), (const uint64_t*)(db + o_off),
+                                        (const lscqp_box*)(db + o_sfc), (int32_t*)(db + o_st), nullptr);
     if (rc != LSCQP_OK) return rc;
-    LSCQP_CK(hipDeviceSynchronize());
-    LSCQP_CK(hipMemcpy(hdr, d_hdr, sizeof(lscqp_header) * n, hipMemcpyDeviceToHost));
-    LSCQP_CK(hipMemcpy(status_out, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    LSCQP_CK(hipMemcpyAsync(hb + o_hdr, db + o_hdr, b_hdr + b_st, hipMemcpyDeviceToHost, nullptr));
+    LSCQP_CK(hipStreamSynchronize(nullptr));
+    memcpy(hdr, hb + o_hdr, sizeof(lscqp_header) * n);
+    memcpy(status_out, hb + o_st, sizeof(int32_t) * n);
 #undef LSCQP_CK
     return LSCQP_OK;
 }
