@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LSCQP_VERSION_MAJOR 0
-#define LSCQP_VERSION_MINOR 2
+#define LSCQP_VERSION_MINOR 5
 
 /* ---- return codes of the API calls themselves (misuse / runtime errors) ---- */
 enum {
@@ -53,7 +53,10 @@ enum {
     LSCQP_STATUS_OPTIMAL = 0,
     LSCQP_STATUS_INFEASIBLE = 1, /* CPLEX Infeasible / InfeasibleOrUnbounded, :105-106 */
     LSCQP_STATUS_ITER_LIMIT = 2,
-    LSCQP_STATUS_NUMERIC = 3
+    LSCQP_STATUS_NUMERIC = 3,
+    LSCQP_STATUS_CAPACITY = 4    /* hdr.n_obs exceeds the row capacity of the kernel instance the launch selected (n_obs_max too
+                                    small, or no compiled instance that large): the instance is REFUSED -- LSC rows are never
+                                    dropped silently, the reference gives every obstacle its rows (:399-437) */
 };
 
 /* PlannerMode values the QP reads (include/sp_const.hpp:19-26).  Only LSC adds the
@@ -91,10 +94,26 @@ typedef struct lscqp_class_desc {
     double world_min[3];         /* mission.world_min — variable lower bounds (:252) */
     double world_max[3];         /* mission.world_max — variable upper bounds (:253) */
     /* solver controls (0 selects the default) */
-    int32_t max_iter; /* default 60 */
-    int32_t reserved1;
-    double tol;       /* relative duality-gap tolerance, 0 = default 1e-10 */
+    int32_t max_iter;  /* default 60 */
+    int32_t precision; /* LSCQP_PRECISION_* below */
+    double tol;        /* relative duality-gap tolerance, 0 = default 1e-10 */
 } lscqp_class_desc;
+
+/* Arithmetic of the interior-point iteration (lscqp_class_desc.precision).
+ *   LSCQP_PRECISION_F64    everything fp64 (default; what the reference's CPLEX call computes in, src/traj_optimizer.cpp:66-70).
+ *   LSCQP_PRECISION_MIXED  BASELINE configs[4], "fp32 PDIP with fp64 residual check": the reduced KKT matrix is rounded to
+ *                          float32 and factorised / substituted in float32 (half the registers and broadcasts of the dominant
+ *                          phase); control points, slacks, multipliers, residuals and every stopping test stay fp64, so an
+ *                          accepted point meets exactly the same KKT bar as in fp64 mode -- the float32 directions cost
+ *                          iterations (+0.4 on the forest class), never accuracy.  Instances on which the float32
+ *                          factorisation breaks down (ill-conditioned final iterations; rare on the forest class, common in
+ *                          dense mazes) are re-solved by the fp64 kernel in a second pass over the batch inside the same call
+ *                          (no host round trip; lscqp_info.flags & LSCQP_INFO_REPAIRED).  The result format (fp64 control
+ *                          points, float32 truncation by the shim as in :71-83) is unchanged.
+ *                          Available for the throughput shapes (one wavefront per QP); lscqp_create returns
+ *                          LSCQP_ERR_UNSUPPORTED for a shape without a compiled mixed instance. */
+#define LSCQP_PRECISION_F64 0
+#define LSCQP_PRECISION_MIXED 1
 
 /* A packed row in the LSCQP_ROWS_F32 format; pointers declared `lscqp_row*` below then point at arrays of this type, and row
  * offsets stay in units of rows. */
@@ -138,9 +157,15 @@ typedef struct lscqp_box {
 } lscqp_box;
 
 /* Optional per-instance solver diagnostics. 32 bytes. */
+#define LSCQP_INFO_FLOOR_ACCEPTED 1 /* OPTIMAL by the fallback rule: the iteration broke down / stalled / hit the limit after a
+                                       point had met the primal (1e-9 m) and gap tests with its stationarity residual at the
+                                       rounding floor (<= 1e-6 relative instead of 1e-8); the returned point IS that point */
+#define LSCQP_INFO_REPAIRED 2       /* solved by the second pass of the call (fp64 after a mixed-precision breakdown, or the
+                                       default start after a warm-started failure); iterations counts both passes */
+#define LSCQP_INFO_RECENTRED 4      /* a jammed warm start was re-centred once inside the kernel */
 typedef struct lscqp_info {
     int32_t iterations;
-    int32_t reserved;
+    int32_t flags;     /* LSCQP_INFO_* */
     double res_primal; /* max inequality violation, metres */
     double res_dual;   /* inf-norm of the reduced stationarity residual, scaled */
     double gap;        /* complementarity: mean s*lambda, scaled */
@@ -188,8 +213,17 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
 
 /* Same, DEVICE pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
  * Inputs must already be resident in HBM; nothing is copied and nothing is synchronised.
- * n_obs_max: upper bound of d_hdr[q].n_obs over the batch (sizes the per-wavefront LDS staging area; instances
- * with more obstacles are truncated to it, so pass the true maximum). */
+ * n_obs_max: upper bound of d_hdr[q].n_obs over the batch; it selects the kernel instance (row slots in registers, LDS
+ * staging area).  An instance whose n_obs exceeds the selected kernel's capacity is refused with LSCQP_STATUS_CAPACITY --
+ * rows are never dropped -- so pass the true maximum; LSCQP_ERR_UNSUPPORTED if no compiled instance holds n_obs_max.
+ * retry != 0: a second pass over the batch on the same stream re-solves, from the default start, the instances that the
+ * first pass did not bring to OPTIMAL (jammed / diverged warm starts; what lscqp_solve_batch does for its callers) --
+ * no host round trip, ~3 us when there is nothing to repair.  In LSCQP_PRECISION_MIXED the fp64 second pass always runs. */
+int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                                const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                                const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                                lscqp_info* d_info_out, int32_t retry, void* stream);
+/* lscqp_solve_batch_device_ex with retry = 0. */
 int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                              const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                              const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,

@@ -12,7 +12,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblscqp.so")
 
-STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC = 0, 1, 2, 3
+STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC, STATUS_CAPACITY = 0, 1, 2, 3, 4
+PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
+INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED = 1, 2, 4  # lscqp_info.flags
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC = 0, 1, 2
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
 SFC_INIT, SFC_FROM_HULL, SFC_FROM_POINT = 0, 1, 2  # lscqp_construct_sfc_device modes
@@ -29,7 +31,7 @@ ROWS_F64, ROWS_F32 = 0, 1
 BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)])
 SAFETY_DTYPE = np.dtype([("safety_ratio", "f8"), ("closest_agent", "i4"), ("sample", "i4"), ("vel_excess_ratio", "f8", 3),
                          ("acc_excess_ratio", "f8", 3)])
-INFO_DTYPE = np.dtype([("iterations", "i4"), ("reserved", "i4"), ("res_primal", "f8"), ("res_dual", "f8"),
+INFO_DTYPE = np.dtype([("iterations", "i4"), ("flags", "i4"), ("res_primal", "f8"), ("res_dual", "f8"),
                        ("gap", "f8")])
 assert HEADER_DTYPE.itemsize == 256 and ROW_DTYPE.itemsize == 32 and BOX_DTYPE.itemsize == 48
 assert INFO_DTYPE.itemsize == 32
@@ -41,7 +43,7 @@ class ClassDesc(C.Structure):
         ("planner_mode", C.c_int32), ("use_sfc", C.c_int32), ("row_format", C.c_int32),
         ("dt", C.c_double), ("control_input_weight", C.c_double), ("terminal_weight", C.c_double),
         ("communication_range", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
-        ("max_iter", C.c_int32), ("reserved1", C.c_int32), ("tol", C.c_double),
+        ("max_iter", C.c_int32), ("precision", C.c_int32), ("tol", C.c_double),
     ]
 
 
@@ -85,6 +87,8 @@ def lib():
         L.lscqp_solve_batch.argtypes = [vp, C.c_int64] + [vp] * 9
         L.lscqp_solve_batch_device.restype = C.c_int
         L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 10
+        L.lscqp_solve_batch_device_ex.restype = C.c_int
+        L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
         L.lscqp_generate_lsc_device.restype = C.c_int
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_generate_constraints_device.restype = C.c_int
@@ -124,16 +128,18 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
                     "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
 
 
 def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
-              world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0, row_format=ROWS_F64):
+              world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0, row_format=ROWS_F64,
+              precision=PRECISION_F64):
     d = ClassDesc()
     d.row_format = row_format
+    d.precision = precision
     d.M, d.n, d.phi, d.phi_n, d.dim = M, n, phi, phi_n, dim
     d.planner_mode, d.use_sfc = planner_mode, int(use_sfc)
     d.dt, d.control_input_weight, d.terminal_weight, d.communication_range = dt, w_c, w_t, comm_range
@@ -269,9 +275,9 @@ class Solver:
 
     # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
     def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None,
-                     d_x_init=None):
+                     d_x_init=None, retry=False):
         """All arguments are torch CUDA tensors (any dtype; only data_ptr() is used) or None.
-        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream."""
+        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream.  retry: lscqp_solve_batch_device_ex's second pass."""
         import torch
 
         s = stream if stream is not None else torch.cuda.current_stream()
@@ -279,8 +285,8 @@ class Solver:
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
 
-        rc = lib().lscqp_solve_batch_device(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
-                                            p(d_obj), p(d_status), p(d_info), C.c_void_p(s.cuda_stream))
+        rc = lib().lscqp_solve_batch_device_ex(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
+                                               p(d_obj), p(d_status), p(d_info), int(bool(retry)), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 def instances():
     txt = open(os.path.join(CSRC, "lscqp_launch.hpp")).read()
     body = txt[txt.index("#define LSCQP_INSTANCES"):]
-    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
+    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
 
 
 def _newer(target, deps):
@@ -47,12 +47,13 @@ def build(force=False, verbose=False, jobs=None):
         os.path.join(HERE, "..", "include", "lscqp.h"), os.path.abspath(__file__)]
     tasks = []
     objs = []
-    for (M, D, E, S, W) in instances():
-        o = os.path.join(OBJ, "inst_%d_%d_%d_%d_%d.o" % (M, D, E, S, W))
+    for (M, D, E, S, W, X) in instances():
+        o = os.path.join(OBJ, "inst_%d_%d_%d_%d_%d_%d.o" % (M, D, E, S, W, X))
         objs.append(o)
         src = os.path.join(CSRC, "lscqp_inst.hip")
         if force or _newer(o, hdrs + [src]):
-            tasks.append([HIPCC] + FLAGS + ["-DLSCQP_M=%d" % M, "-DLSCQP_DIM=%d" % D, "-DLSCQP_ES=%d" % E, "-DLSCQP_NSLOT=%d" % S, "-DLSCQP_W=%d" % W, "-c", src, "-o", o])
+            extra = os.environ.get("LSCQP_EXTRA_MIXED_FLAGS", "").split() if X else os.environ.get("LSCQP_EXTRA_F64_FLAGS", "").split()
+            tasks.append([HIPCC] + FLAGS + extra + ["-DLSCQP_M=%d" % M, "-DLSCQP_DIM=%d" % D, "-DLSCQP_ES=%d" % E, "-DLSCQP_NSLOT=%d" % S, "-DLSCQP_W=%d" % W, "-DLSCQP_MIXED=%d" % X, "-c", src, "-o", o])
     api_o = os.path.join(OBJ, "api.o")
     objs.append(api_o)
     api_src = os.path.join(CSRC, "lscqp_api.hip")

@@ -13,8 +13,8 @@
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
 
-#define LSCQP_DECL(M, D, E, S, W)                                                                                      \
-    extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S##_##W(const lscqp::DevClass*, int64_t, const lscqp_header*, \
+#define LSCQP_DECL(M, D, E, S, W, X)                                                                                      \
+    extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X(const lscqp::DevClass*, int64_t, const lscqp_header*, \
                                                                   const lscqp_row*, const uint64_t*, const lscqp_box*,  \
                                                                   const double*, double*, double*, int32_t*, lscqp_info*, \
                                                                   hipStream_t);
@@ -53,14 +53,14 @@ extern "C" int lscqp_set_error_(int code, const char* msg) { return fail(code, m
 namespace {
 
 struct Inst {
-    int M, dim, es, max_obs, waves;
+    int M, dim, es, max_obs, waves, mixed;
     size_t lds;  // bytes of LDS per workgroup
     lscqp::launch_fn fn;
 };
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
-#define LSCQP_ROW(M, D, E, S, W) \
-    {M, D, E, max_obs_of(M, S, W), W, lscqp::Cfg<M, D, (E != 0), S, W>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W},
+#define LSCQP_ROW(M, D, E, S, W, X) \
+    {M, D, E, max_obs_of(M, S, W), W, X, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
@@ -71,15 +71,15 @@ const Inst kInst[] = {
 // the fewest wavefronts per QP, which is what fills the chip (4 QPs per CU) -- unless the instance's LDS footprint admits
 // only one workgroup per CU anyway (the nz = 84 class): then more wavefronts are free.  Within a wave count: smallest
 // capacity.
-const Inst* find_instance(int M, int dim, int es, int n_obs, int64_t n, int n_cu) {
+const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t n, int n_cu) {
     const Inst* best = nullptr;
     const bool small = n <= 2 * (int64_t)n_cu;
     // testing knob: LSCQP_WAVES=1|2 pins the wavefront count (every compiled instance has to be reachable by the tests)
     const char* pin = getenv("LSCQP_WAVES");
     const int pin_w = (pin && (pin[0] == '1' || pin[0] == '2' || pin[0] == '4') && pin[1] == 0) ? pin[0] - '0' : 0;
     for (const Inst& i : kInst) {
-        if (!(i.M == M && i.dim == dim && i.es == es && i.max_obs >= n_obs)) continue;
-        if (pin_w && i.waves != pin_w) continue;
+        if (!(i.M == M && i.dim == dim && i.es == es && i.mixed == mixed && i.max_obs >= n_obs)) continue;
+        if (pin_w && i.waves != pin_w && !mixed) continue;
         bool better = !best;
         if (best) {
             const bool one_wg_per_cu = i.lds > lscqp::kMaxLdsBytes / 2 && best->lds > lscqp::kMaxLdsBytes / 2;
@@ -92,18 +92,21 @@ const Inst* find_instance(int M, int dim, int es, int n_obs, int64_t n, int n_cu
     }
     return best;
 }
-int cu_count() {
-    static int n_cu = -1;
-    if (n_cu < 0) {
-        int dev = 0;
+int cu_count() {  // of the CURRENT device (one process may drive several: lscqp_comm_*)
+    static int n_cu[64];
+    static bool known[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!known[dev]) {
         hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+        n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+        known[dev] = true;
     }
-    return n_cu;
+    return n_cu[dev];
 }
-bool shape_exists(int M, int dim, int es) {
+bool shape_exists(int M, int dim, int es, int mixed) {
     for (const Inst& i : kInst)
-        if (i.M == M && i.dim == dim && i.es == es) return true;
+        if (i.M == M && i.dim == dim && i.es == es && i.mixed == mixed) return true;
     return false;
 }
 
@@ -137,9 +140,16 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     if (d->M < 2) return fail(LSCQP_ERR_INVALID_ARGUMENT, "M must be >= 2");
     if (!(d->dt > 0)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "dt must be positive");
     const int es = (d->planner_mode == LSCQP_PLANNER_LSC) ? 1 : 0;
-    if (!shape_exists(d->M, d->dim, es)) {
+    if (d->precision != LSCQP_PRECISION_F64 && d->precision != LSCQP_PRECISION_MIXED)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "precision must be LSCQP_PRECISION_F64 or LSCQP_PRECISION_MIXED");
+    if (!shape_exists(d->M, d->dim, es, 0)) {
         char buf[160];
         snprintf(buf, sizeof buf, "no compiled kernel instance for M=%d dim=%d end_stop=%d (compiled shapes: csrc/lscqp_launch.hpp; needs dim*(3M-2) <= 128)", d->M, d->dim, es);
+        return fail(LSCQP_ERR_UNSUPPORTED, buf);
+    }
+    if (d->precision == LSCQP_PRECISION_MIXED && !shape_exists(d->M, d->dim, es, 1)) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "no compiled MIXED-precision kernel instance for M=%d dim=%d end_stop=%d (csrc/lscqp_launch.hpp lists them)", d->M, d->dim, es);
         return fail(LSCQP_ERR_UNSUPPORTED, buf);
     }
     s->desc = *d;
@@ -174,6 +184,7 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.use_sfc = d->use_sfc;
     c.n_obs_max = 0;
     c.rows_f32 = d->row_format == LSCQP_ROWS_F32;
+    c.repair = 0;
     return LSCQP_OK;
 }
 
@@ -417,10 +428,10 @@ int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs) {
     return (int64_t)(h->dev.rows_f32 ? 16 : 32) * n_obs * h->P + 48 * h->desc.M + 256 + 8 * h->nv + 16;
 }
 
-int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
-                             const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
-                             const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
-                             lscqp_info* d_info_out, void* stream) {
+int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                                const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                                const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                                lscqp_info* d_info_out, int32_t retry, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -434,11 +445,13 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
             return fail(LSCQP_ERR_NO_DEVICE, std::string("no HIP device: lscqp has no CPU fallback (hipGetDeviceCount: ") +
                                                  hipGetErrorString(de) + ", " + std::to_string(ndev) + " devices)");
     }
-    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, n_obs_max, n, cu_count());
-    if (!inst) {
+    const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
+    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, cu_count());
+    const Inst* inst64 = mixed ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : inst;
+    if (!inst || !inst64) {
         char buf[200];
-        snprintf(buf, sizeof buf, "no compiled kernel instance of M=%d dim=%d holds %d obstacles per agent in registers",
-                 h->desc.M, h->desc.dim, n_obs_max);
+        snprintf(buf, sizeof buf, "no compiled kernel instance of M=%d dim=%d%s holds %d obstacles per agent in registers",
+                 h->desc.M, h->desc.dim, mixed ? " (mixed precision)" : "", n_obs_max);
         return fail(LSCQP_ERR_UNSUPPORTED, buf);
     }
     lscqp::DevClass cls = h->dev;
@@ -446,7 +459,26 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
     hipError_t e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out,
                             (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
+    // Second pass over the batch, same stream, no host round trip: a workgroup whose instance is already OPTIMAL (or was
+    // refused for capacity) returns at once.  Mixed precision: the fp64 kernel re-solves what the float32 factorisation could
+    // not finish (same start).  retry: the fp64 kernel re-solves from the DEFAULT start what a warm start did not bring to
+    // OPTIMAL -- a jammed or diverged warm start (ITER_LIMIT / NUMERIC, or relabelled INFEASIBLE on its primal residual) says
+    // nothing about the problem, a cold start proves infeasibility independently of x_init.
+    if (mixed || (retry && d_x_init)) {
+        cls.repair = 1;
+        e = inst64->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
+                       d_info_out, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));
+    }
     return LSCQP_OK;
+}
+
+int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                             const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                             const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                             lscqp_info* d_info_out, void* stream) {
+    return lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
+                                       d_info_out, 0, stream);
 }
 
 int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
@@ -518,7 +550,9 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     if (h->desc.use_sfc) memcpy(hbase + o_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M);
     if (d_xi) memcpy(hbase + o_xi, x_init, sizeof(double) * n * h->nv);
     LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, nullptr));
-    int rc = lscqp_solve_batch_device(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, nullptr);
+    // (retry = 1: instances a warm start did not bring to OPTIMAL are solved once more from the default start by a second pass
+    // on the device, before the results are copied back)
+    int rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, 1, nullptr);
     if (rc != LSCQP_OK) return rc;
     LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, nullptr));
     LSCQP_CK(hipStreamSynchronize(nullptr));
@@ -527,56 +561,11 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     memcpy(status_out, hbase + o_st, sizeof(int32_t) * n);
     if (info_out) memcpy(info_out, hbase + o_info, sizeof(lscqp_info) * n);
 #undef LSCQP_CK
-    // An interior-point iteration started from the caller's trajectory can jam against the boundary (a few instances in ten
-    // thousand: residuals at machine precision, the gap stuck around 1e-6): instances that ran out of
-    // iterations or broke down numerically are solved once more from the default start, which does not depend on x_init.
-    // Infeasible instances are not retried.
-    if (x_init) {
-        std::vector<int64_t> again;
-        for (int64_t q = 0; q < n; q++)
-            if (status_out[q] == LSCQP_STATUS_ITER_LIMIT || status_out[q] == LSCQP_STATUS_NUMERIC) again.push_back(q);
-        if (!again.empty()) {
-            const int64_t m = (int64_t)again.size();
-            const size_t rb = row_bytes(h);
-            std::vector<lscqp_header> hs(m);
-            std::vector<uint64_t> os(m + 1, 0);
-            std::vector<lscqp_box> bs(h->desc.use_sfc ? (size_t)m * h->desc.M : 0);
-            std::vector<char> rs;
-            for (int64_t i = 0; i < m; i++) {
-                const int64_t q = again[i];
-                hs[i] = hdr[q];
-                const size_t nr = hdr[q].n_obs > 0 ? (size_t)hdr[q].n_obs * h->P : 0;
-                if (nr) {
-                    const char* src = reinterpret_cast<const char*>(rows) + rb * (size_t)row_offsets[q];
-                    rs.insert(rs.end(), src, src + rb * nr);
-                }
-                os[i + 1] = os[i] + nr;
-                if (h->desc.use_sfc) std::copy(sfc + q * h->desc.M, sfc + (q + 1) * h->desc.M, bs.begin() + i * h->desc.M);
-            }
-            std::vector<double> xs((size_t)m * h->nv), objs(m);
-            std::vector<int32_t> sts(m);
-            std::vector<lscqp_info> infos(m);
-            const int rc2 = lscqp_solve_batch(h, m, hs.data(), reinterpret_cast<const lscqp_row*>(rs.data()), os.data(),
-                                              bs.empty() ? nullptr : bs.data(), nullptr, xs.data(), objs.data(), sts.data(), infos.data());
-            if (rc2 != LSCQP_OK) return rc2;
-            for (int64_t i = 0; i < m; i++) {
-                if (sts[i] != LSCQP_STATUS_OPTIMAL) continue;
-                const int64_t q = again[i];
-                std::copy(xs.begin() + i * h->nv, xs.begin() + (i + 1) * h->nv, x_out + q * h->nv);
-                obj_out[q] = objs[i];
-                status_out[q] = sts[i];
-                if (info_out) {
-                    infos[i].iterations += info_out[q].iterations;  // both attempts
-                    info_out[q] = infos[i];
-                }
-            }
-        }
-    }
     return LSCQP_OK;
 }
 
 const char* lscqp_last_error(void) { return g_err.c_str(); }
 
-const char* lscqp_version(void) { return "lscqp 0.4 (gfx950, fp64 PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics)"; }
+const char* lscqp_version(void) { return "lscqp 0.5 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics)"; }
 
 }  // extern "C"

@@ -42,6 +42,7 @@ struct DevClass {
     int use_sfc;
     int n_obs_max;  // number of obstacles the launch must accommodate (<= NSLOT * G of the instance)
     int rows_f32;   // lscqp_class_desc.row_format == LSCQP_ROWS_F32
+    int repair;     // second pass over a batch: only instances whose status_out is neither OPTIMAL nor CAPACITY are solved
 };
 
 // Q_base * dt^5 for n = 5, phi = 3 (integers)
@@ -71,6 +72,9 @@ __device__ __forceinline__ double bcast(double v, int lane) {
     lo = __builtin_amdgcn_readlane(lo, lane);
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bcast(float v, int lane) {  // (mixed-precision instances: one v_readlane per value)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 // Wave reductions with DPP moves instead of ds_bpermute butterflies (tools/ubench.hip: a 6-step bpermute butterfly
 // costs ~460 cycles per value on a lone wavefront, the DPP form ~150): four row_shr steps build an inclusive scan
@@ -173,6 +177,15 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
+__device__ __forceinline__ float fast_rcp(float d) {  // v_rcp_f32 (1 ulp) + one Newton step
+    float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+template <class FT>
+__device__ __forceinline__ bool pivot_ok(FT d) {
+    return std::is_same<FT, double>::value ? (d > (FT)1e-300) : (d > (FT)1e-30);
+}
+
 // Development aid: per-phase cycle totals (s_memtime), compiled in only with -DLSCQP_PHASE_TIMING.  The markers
 // are scheduling barriers and drain the memory counters, so phases do not overlap in the instrumented build (it
 // runs ~30 % slower than the product build, whose scheduler interleaves neighbouring phases).
@@ -218,7 +231,10 @@ __device__ unsigned long long lscqp_dbg_cycles[16];
     } while (0)
 #endif
 
-template <int M_, int DIM_, bool ES_, int NSLOT_, int W_ = 1>
+// FB_ = bytes of the scalar the reduced matrix is held, factorised and substituted in: 8 (fp64), or 4 for the MIXED-PRECISION
+// instances (BASELINE configs[4]: float32 LDL^T / substitutions steering an iteration whose residuals, multipliers, control
+// points and stopping tests stay fp64; tools/proto_fp32.py).
+template <int M_, int DIM_, bool ES_, int NSLOT_, int W_ = 1, int FB_ = 8>
 struct Cfg {
     static constexpr int M = M_, DIM = DIM_, NSLOT = NSLOT_, W = W_;
     static constexpr int T = 64 * W;  // threads per QP
@@ -241,6 +257,7 @@ struct Cfg {
     static_assert(CP <= T, "6M-3 <= 64*W");
     static_assert(W == 1 || W == 2 || W == 4, "1, 2 or 4 wavefronts per QP");
     static_assert(M >= 2, "the reference assumes M >= 2 (src/traj_optimizer.cpp:341-352)");
+    static_assert(FB_ == 8 || (FB_ == 4 && W == 1), "mixed precision: one wavefront per QP (the throughput form)");
     // LDS carve (in doubles)
     static constexpr int o_c = 0;               // control points (translated)
     static constexpr int o_dca = o_c + NX;      // affine direction, x-space
@@ -252,21 +269,26 @@ struct Cfg {
     static constexpr int o_goal = o_z + 2 * T;  // goal - p0 (4 doubles)
     static constexpr int o_red = o_goal + 4;    // cross-wave reduction scratch (W > 1): 2 buffers x W waves x 4
     static constexpr int o_col = o_red + (W > 1 ? 8 * W : 0);  // pivot-column / solve broadcast buffer, 2 x T
-    static constexpr int o_H = ((o_col + 2 * T + 2 + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH]
-    static constexpr int o_rows = ((o_H + (NZ + 1) * LDH + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
+    static constexpr int o_zs = o_col + 2 * T + 2;  // the last point that met the acceptance tests (z), NZ
+    static constexpr int o_H = ((o_zs + NZ + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH], scalars of FB_ bytes
+    static constexpr int o_rows = ((o_H + ((NZ + 1) * LDH * FB_ + 7) / 8 + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
     static constexpr int NROW = MAX_OBS * CP;  // + one dead row per array
     static constexpr size_t lds_bytes() { return sizeof(double) * ((size_t)o_rows + 4 * ((size_t)NROW + 1)); }
 };
 
-template <int M, int DIM, bool ES, int NSLOT, int W = 1>
-__global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
+#ifndef LSCQP_KERNEL_ATTR
+#define LSCQP_KERNEL_ATTR
+#endif
+template <int M, int DIM, bool ES, int NSLOT, int W = 1, class FT = double>
+__global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows,
                                                         const uint64_t* __restrict__ row_offsets,
                                                         const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init,
                                                         double* __restrict__ x_out,
                                                         double* __restrict__ obj_out, int32_t* __restrict__ status_out,
                                                         lscqp_info* __restrict__ info_out) {
-    using C = Cfg<M, DIM, ES, NSLOT, W>;
+    using C = Cfg<M, DIM, ES, NSLOT, W, (int)sizeof(FT)>;
+    constexpr bool MIXED = !std::is_same<FT, double>::value;
     constexpr int P = C::P, CP = C::CP, NZA = C::NZA, NZ = C::NZ, NX = C::NX, G = C::G, LDH = C::LDH, T = C::T;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* const c_ = smem + C::o_c;
@@ -284,7 +306,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     double* const red_ = smem + C::o_red;
     double* const col_ = smem + C::o_col;
     (void)red_;
-    double* const Hs = smem + C::o_H;
+    double* const zs_ = smem + C::o_zs;
+    FT* const Hs = reinterpret_cast<FT*>(smem + C::o_H);
     constexpr int NROW = C::NROW;
     double* const Rnx = smem + C::o_rows;
     double* const Rny = Rnx + (NROW + 1);
@@ -361,7 +384,31 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     const int64_t q = blockIdx.x;
     if (q >= n) return;
     const lscqp_header* H = hdr + q;
-    const int n_obs = H->n_obs < C::MAX_OBS ? H->n_obs : C::MAX_OBS;
+    int flags = 0;           // lscqp_info.flags
+    int it_before = 0;       // iterations of an earlier pass over this instance
+    if (cls.repair) {        // uniform over the workgroup
+        const int st0 = status_out[q];
+        if (st0 == LSCQP_STATUS_OPTIMAL || st0 == LSCQP_STATUS_CAPACITY) return;
+        flags |= LSCQP_INFO_REPAIRED;
+        if (info_out) it_before = info_out[q].iterations;
+    }
+    // An instance with more obstacles than this kernel instance has row slots for is REFUSED, never truncated: dropping LSC
+    // rows silently would void the collision-avoidance guarantee the rows exist for (reference: every obstacle gets its rows,
+    // src/traj_optimizer.cpp:399-437).  The caller picks a larger instance through n_obs_max or splits the batch.
+    if (H->n_obs > C::MAX_OBS) {
+        for (int e = lane; e < NX; e += T) x_out[q * NX + e] = x_init ? x_init[q * NX + e] : H->p0[e / P];
+        if (lane == 0) {
+            obj_out[q] = 0.0;
+            status_out[q] = LSCQP_STATUS_CAPACITY;
+            if (info_out) {
+                info_out[q].iterations = 0;
+                info_out[q].flags = flags;
+                info_out[q].res_primal = info_out[q].res_dual = info_out[q].gap = 0.0;
+            }
+        }
+        return;
+    }
+    const int n_obs = H->n_obs;
     const double dt = cls.dt;
 
     // ---- per-QP scalars (uniform) ------------------------------------------------------------------------
@@ -440,7 +487,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     const ZRole ZR = zrole(lvz_);                                                                        \
     const bool zl = ZR.zl, zlast = ZR.zlast, has_next = ZR.has_next;                                     \
     const int zk = ZR.zk, zm = ZR.zm, zj = ZR.zj, gbase = ZR.gbase, gnext = ZR.gnext;                    \
-    double* const hrow = &Hs[(zl ? lvz_ : NZ) * LDH];                                                    \
+    FT* const hrow = &Hs[(zl ? lvz_ : NZ) * LDH];                                                        \
     (void)zlast, (void)has_next, (void)zk, (void)zm, (void)zj, (void)gbase, (void)gnext, (void)hrow
 #define LSCQP_L_ROLES()                                                                                  \
     LSCQP_PHASE_LANE(lvl_);                                                                              \
@@ -467,9 +514,9 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
     if (zl) {
         const double cf1 = H->v0[zk] * dt * 0.2;
         z_[lane] = H->a0[zk] * dt * dt * 0.05 + 2.0 * cf1;
-        double* hrow0 = &Hs[lane * LDH];
+        FT* hrow0 = &Hs[lane * LDH];
 #pragma unroll
-        for (int cidx = 0; cidx < NZ; cidx++) hrow0[cidx] = 0.0;  // entries outside the lane's pattern stay zero
+        for (int cidx = 0; cidx < NZ; cidx++) hrow0[cidx] = (FT)0;  // entries outside the lane's pattern stay zero
         // Primal start from the caller's initial trajectory (TrajOptimizer::solve's `initial_traj`: the shifted previous
         // plan): the free control points c3..c5 of every segment (c5 alone under the end stop), translated.  The
         // equalities are re-imposed by c = c_fixed + T z below, so float32 rounding of the plan does no harm.
@@ -777,9 +824,11 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         }
     };
 
-    double A[NZ];  // row `lane` of the reduced KKT matrix, then its LDL^T factors
-    double dinv_own = 0.0;
+    FT A[NZ];  // row `lane` of the reduced KKT matrix, then its LDL^T factors
+    FT dinv_own = (FT)0;
     double res_p = 0, res_d = 0, res_gap = 0;
+    double snap_p = 0, snap_d = 0, snap_gap = 0;  // residuals of the last point that met the acceptance tests (kept in zs_)
+    bool restore = false;                         // the result is that remembered point, not the current iterate
     int it = 0, near_cnt = 0, floor_cnt = 0;
     float rp_ref = 3.0e38f;  // primal residual four iterations ago (infeasibility test below)
     float gap_mark = 3.0e38f;  // jam test: the gap when it last improved tenfold, iterations since, done once
@@ -942,6 +991,15 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {  // uniform over the QP's lanes
                 LSCQP_PHASE_LANE(lvo_);
                 res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false, lvo_)));
+                if (res_gap <= tol || (res_gap <= 10.0 * tol && rdn <= 1e-8 * gls)) {
+                    // remember the point: the fallback exits return THIS iterate (tested), not whatever the iteration
+                    // moved on to afterwards
+                    LSCQP_PHASE_LANE(lvs_);
+                    if (lvs_ < NZ) zs_[lvs_] = z_[lvs_];
+                    snap_p = max_rp;
+                    snap_d = res_d;
+                    snap_gap = res_gap;
+                }
                 if (res_gap <= tol) {
                     floor_cnt++;
                     if (rdn <= 1e-8 * gls) {
@@ -1057,7 +1115,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 }
                 // stores: every iteration overwrites exactly the same pattern entries, the rest of the row stays 0.
                 // Merged columns (the single end-stop variable) receive the sum.
-                double* hk = &hrow[zk * NZA];
+                FT* hk = &hrow[zk * NZA];
                 const bool nlast = ES && has_next && (zm + 1 == M - 1);  // the next block is the end-stop variable
                 const double osum = own[0] + own[1] + own[2], nsum = nxt[0] + nxt[1] + nxt[2];
                 const int ob = zlast ? 3 * (M - 1) : 3 * zm;
@@ -1082,7 +1140,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     for (int jp = 0; jp < 3; jp++)
                         cr[jp] = ej[jp] * S_[(6 * zm + 3 + jp) * 6 + so] + tbj[0] * TBc(0, jp) * S_[(6 * mn + 0) * 6 + so] +
                                  tbj[1] * TBc(1, jp) * S_[(6 * mn + 1) * 6 + so] + tbj[2] * TBc(2, jp) * S_[(6 * mn + 2) * 6 + so];
-                    double* hl = &hrow[l * NZA];
+                    FT* hl = &hrow[l * NZA];
                     const bool wr = (l != zk);
                     if (wr) hl[ob] = zlast ? (cr[0] + cr[1] + cr[2]) : cr[0];
                     if (wr && !zlast) hl[ob + 1] = cr[1];
@@ -1100,12 +1158,12 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                         const int hi_ = zm > up ? zm : up, lo_ = zm > up ? up : zm;
                         const double w = use ? omc[hi_ * (hi_ - 1) / 2 + (use ? lo_ : 0)] : 0.0;
                         dsum += w;
-                        double* t = &hk[zidx(up, 2)];
+                        FT* t = &hk[zidx(up, 2)];
                         const bool near = (up == zm - 1) || (up == zm + 1);
-                        const double old = *t;
-                        if (use) *t = near ? (old - w) : -w;
+                        const double old = (double)*t;
+                        if (use) *t = (FT)(near ? (old - w) : -w);
                     }
-                    hrow[zl ? lvz_ : 0] += dsum;  // dsum == 0 for lanes that are not c5 variables
+                    hrow[zl ? lvz_ : 0] += (FT)dsum;  // dsum == 0 for lanes that are not c5 variables
                 }
                 LSCQP_WAVE_LDS_SYNC();
                 // (W = 2 with nz <= 64: the system lives in wavefront 0; the other wavefront runs the same factorisation
@@ -1113,8 +1171,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const int own_col = (W > 1 && NZ <= 64 && lvz_ >= 64) ? (lvz_ & 63) : -1;
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) {
-                    const double v = hrow[cidx];
-                    A[cidx] = zl ? v : (cidx == own_col ? 1.0 : 0.0);
+                    const FT v = hrow[cidx];
+                    A[cidx] = zl ? v : (cidx == own_col ? (FT)1 : (FT)0);
                 }
             }
             LSCQP_T(3);
@@ -1134,10 +1192,10 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             {
                 int lf = lane & 63;  // (lane of the wavefront: see the identity rows of a second wavefront)
                 asm volatile("" : "+v"(lf));
-                double* const colw = col_ + (W > 1 ? 2 * 64 * (lane >> 6) : 0);  // each wavefront its own column buffer
+                FT* const colw = reinterpret_cast<FT*>(col_) + (W > 1 ? 2 * 64 * (lane >> 6) : 0);  // each wavefront its own column buffer
                 colw[lf] = A[0];
-                double d = bcast(A[0], 0);
-                double invd = fast_rcp(d);
+                FT d = bcast(A[0], 0);
+                FT invd = fast_rcp(d);
                 static_for<0, NZ>([&](auto Jc) {
                     constexpr int j = decltype(Jc)::value;
                     constexpr int n = NZ - j - 1;  // trailing entries k = j+1 .. NZ-1
@@ -1145,18 +1203,18 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                     constexpr int nr = n <= 4 ? n : (r0 < 3 ? 4 : r0 + 1);  // via v_readlane (k = j+1 always)
                     constexpr int nl = n - (nr < n ? nr : n);              // via LDS
                     constexpr int NR = n - nl;
-                    const double* const cb = colw + (j & 1) * 64;
-                    double* const cbn = colw + ((j + 1) & 1) * 64;
-                    pivot_bad = pivot_bad || !(d > 1e-300);
+                    const FT* const cb = colw + (j & 1) * 64;
+                    FT* const cbn = colw + ((j + 1) & 1) * 64;
+                    pivot_bad = pivot_bad || !pivot_ok<FT>(d);
                     dinv_own = (lf == j) ? invd : dinv_own;
-                    const double li = (lf > j) ? A[j] * invd : 0.0;
-                    double ul[nl > 0 ? nl : 1];
+                    const FT li = (lf > j) ? A[j] * invd : (FT)0;
+                    FT ul[nl > 0 ? nl : 1];
                     static_for<0, nl>([&](auto Tc) {
                         constexpr int t = decltype(Tc)::value;
                         ul[t] = cb[j + 1 + NR + t];
                     });
                     if constexpr (NR > 0) {
-                        double ur[NR];
+                        FT ur[NR];
                         static_for<0, NR>([&](auto Tc) {
                             constexpr int t = decltype(Tc)::value;
                             ur[t] = bcast(A[j + 1 + t], j);
@@ -1190,11 +1248,11 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             asm volatile("" : "+v"(lf));
             static_for<0, NZ>([&](auto Jc) {
                 constexpr int j = decltype(Jc)::value;
-                const double d = bcast(A[j], j);
-                pivot_bad = pivot_bad || !(d > 1e-300);
-                const double invd = fast_rcp(d);
+                const FT d = bcast(A[j], j);
+                pivot_bad = pivot_bad || !pivot_ok<FT>(d);
+                const FT invd = fast_rcp(d);
                 dinv_own = (lf == j) ? invd : dinv_own;
-                const double li = (lf > j) ? A[j] * invd : 0.0;
+                const FT li = (lf > j) ? A[j] * invd : (FT)0;
 #ifdef LSCQP_FACT_BB
                 constexpr int BB = LSCQP_FACT_BB;
 #else
@@ -1203,7 +1261,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 constexpr int NCH = (NZ - j - 1 + BB - 1) / BB;
                 static_for<0, NCH>([&](auto Cc) {
                     constexpr int k0 = j + 1 + decltype(Cc)::value * BB;
-                    double ub[BB];
+                    FT ub[BB];
                     static_for<0, BB>([&](auto Tc) {
                         constexpr int t = decltype(Tc)::value;
                         if constexpr (k0 + t < NZ) ub[t] = bcast(A[k0 + t], j);
@@ -1353,17 +1411,18 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             }
             if (pivot_bad) {  // uniform over the QP's lanes
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+                restore = status == LSCQP_STATUS_OPTIMAL;
                 break;
             }
             // broadcast of lane j's value to all lanes of the QP: v_readlane (W = 1) or an LDS slot + barrier (W = 2; one
             // slot per column and direction, so no slot is rewritten while a slower wavefront may still read it)
-            auto bcast_q = [&](double v, int j, int ls, double* slots) -> double {
+            auto bcast_q = [&](FT v, int j, int ls, double* slots) -> FT {
                 if constexpr (W == 1 || NZ <= 64) {
                     return bcast(v, j);
                 } else {
                     if (ls == j) slots[j] = v;
                     __syncthreads();
-                    return slots[j];
+                    return (FT)slots[j];
                 }
             };
 #ifdef LSCQP_SOLVE_FROM_LDS
@@ -1371,7 +1430,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // it from there (lane-private row, conflict-free ds_read_b64, independent of the solve's dependency chain)
             {
                 LSCQP_PHASE_LANE(lvp_);
-                double* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
+                FT* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
                 LSCQP_WAVE_LDS_SYNC();
@@ -1437,26 +1496,30 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 const double x = b * dinv_own;  // (final once the lane's own column has been broadcast)
                 return x;
             };
-            auto solve = [&](double b) __attribute__((always_inline)) -> double {
-                if constexpr (W > 1 && NZ > 64) return solve_blocked(b, 0);
+            // (mixed precision: the right-hand side is rounded to float32, the direction comes back as fp64; no refinement --
+            // the residuals the NEXT iteration computes are fp64, so an inexact direction costs iterations, not accuracy:
+            // +0.4 iterations on the forest class, tools/proto_fp32.py)
+            auto solve = [&](double b64) __attribute__((always_inline)) -> double {
+                if constexpr (W > 1 && NZ > 64) return solve_blocked(b64, 0);
+                FT b = (FT)b64;
                 int ls = (NZ <= 64) ? (lane & 63) : lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
-                const double* const hr = &Hs[(ls < NZ ? ls : NZ) * LDH];
+                const FT* const hr = &Hs[(ls < NZ ? ls : NZ) * LDH];
                 (void)hr;
 #pragma unroll
                 for (int j = 0; j < NZ; j++) {  // L w = b (unit lower)
-                    const double wj = bcast_q(b, j, ls, col_);
-                    b = fma(-((ls > j) ? LSCQP_FACTOR_ENTRY(j) : 0.0), wj, b);
+                    const FT wj = bcast_q(b, j, ls, col_);
+                    b = fma(-((ls > j) ? LSCQP_FACTOR_ENTRY(j) : (FT)0), wj, b);
                 }
                 asm volatile("" : "+v"(ls));
 #pragma unroll
                 for (int j = NZ - 1; j >= 0; j--) {  // (D L') x = w : row i of the upper factor is A[j>i] of lane i
-                    const double xj = bcast_q(b * dinv_own, j, ls, col_ + T);
-                    b = fma(-((ls < j) ? LSCQP_FACTOR_ENTRY(j) : 0.0), xj, b);
+                    const FT xj = bcast_q(b * dinv_own, j, ls, col_ + T);
+                    b = fma(-((ls < j) ? LSCQP_FACTOR_ENTRY(j) : (FT)0), xj, b);
                 }
                 // lane i's b is final once column i has been broadcast (later columns j < i leave it alone), so its own
                 // component needs no per-step select
-                return b * dinv_own;
+                return (double)(b * dinv_own);
             };
             LSCQP_T(4);
             LSCQP_STOP(5)
@@ -1469,7 +1532,7 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             // which removes most register spills of the pass
             {
                 LSCQP_PHASE_LANE(lvp_);
-                double* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
+                FT* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
             }
@@ -1575,17 +1638,17 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
                 // dummy row holds whatever the last lane parked)
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) {
-                    const double v = hrow[cidx];
-                    A[cidx] = (W == 1 || zl) ? v : 0.0;
+                    const FT v = hrow[cidx];
+                    A[cidx] = (W == 1 || zl) ? v : (FT)0;
                 }
 #endif
             }
             const double dzc = solve(-gcost + gb);
             {  // the scratch row must be all-zero outside the assembly pattern again
                 LSCQP_PHASE_LANE(lvp_);
-                double* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
+                FT* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
 #pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = 0.0;
+                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = (FT)0;
             }
             if (zl) dz_[lane] = dzc;  // expandT(dca_) finished reading dz_ before
             LSCQP_BLOCK_SYNC();
@@ -1700,16 +1763,33 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
             expandT(z_, c_, true);
             LSCQP_BLOCK_SYNC();
             if (!(alpha > 1e-12) || !(mu == mu)) {  // stalled or NaN (wave-uniform)
-                status = ((near_cnt > 0 || floor_cnt > 0) && mu == mu) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+                status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+                restore = status == LSCQP_STATUS_OPTIMAL;
                 break;
             }
             LSCQP_T(9);
             LSCQP_STOP(10)
         }
     LSCQP_T(10);
-    if (status == LSCQP_STATUS_ITER_LIMIT && (near_cnt > 0 || floor_cnt > 0)) status = LSCQP_STATUS_OPTIMAL;
+    if (status == LSCQP_STATUS_ITER_LIMIT && (near_cnt > 0 || floor_cnt > 0)) {
+        status = LSCQP_STATUS_OPTIMAL;
+        restore = true;
+    }
     if (status == LSCQP_STATUS_ITER_LIMIT && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
     if (status == LSCQP_STATUS_NUMERIC && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
+    // Fallback acceptance (breakdown, stall or iteration limit after a point had met the primal and gap tests with its
+    // stationarity at the rounding floor, <= 1e-6 relative): the result IS that remembered point, and lscqp_info says so.
+    if (restore) {  // uniform over the QP's lanes
+        if (lane < NZ) z_[lane] = zs_[lane];
+        LSCQP_BLOCK_SYNC();
+        expandT(z_, c_, true);
+        LSCQP_BLOCK_SYNC();
+        res_p = snap_p;
+        res_d = snap_d;
+        res_gap = snap_gap;
+        flags |= LSCQP_INFO_FLOOR_ACCEPTED;
+    }
+    if (recentred) flags |= LSCQP_INFO_RECENTRED;
 
     // ---- epilogue: objective, control points back in the world frame ---------------------------------------
     const double obj = objective(true, lane);
@@ -1721,8 +1801,8 @@ __global__ __launch_bounds__(64 * W) void lscqp_pdip_kernel(DevClass cls, int64_
         obj_out[q] = obj;
         status_out[q] = status;
         if (info_out) {
-            info_out[q].iterations = it;
-            info_out[q].reserved = 0;
+            info_out[q].iterations = it + it_before;
+            info_out[q].flags = flags;
             info_out[q].res_primal = res_p;
             info_out[q].res_dual = res_d;
             info_out[q].gap = res_gap;

@@ -13,13 +13,15 @@ using launch_fn = hipError_t (*)(const DevClass*, int64_t, const lscqp_header*, 
                                  const lscqp_box*, const double*, double*, double*, int32_t*, lscqp_info*, hipStream_t);
 }  // namespace lscqp
 
-// The compiled kernel instances, X(M, DIM, ES, NSLOT, W):
+// The compiled kernel instances, X(M, DIM, ES, NSLOT, W, MIXED):
 //   W = wavefronts per QP; dim*(3M-2) <= 64*W is required by the lane-per-row factorisation (W = 2: M = 10 in 3-D);
 //   W = 2 instances of shapes with nz <= 64 are the low-latency variants for small batches (lscqp_api.hip policy);
 //   the nz = 84 class (one workgroup per CU by LDS anyway) also has a W = 4 instance: 2.6 -> 1.6 ms per 128-QP batch;
-//   NSLOT = LSC row slots per lane (registers); an instance serves up to NSLOT * floor(64*W/(6M-3)) obstacles per agent.
+//   NSLOT = LSC row slots per lane (registers); an instance serves up to NSLOT * floor(64*W/(6M-3)) obstacles per agent;
+//   MIXED = 1: float32 factorisation / substitutions (LSCQP_PRECISION_MIXED, BASELINE configs[4]), one wavefront per QP.
 #define LSCQP_INSTANCES(X)                                                                                              \
-    X(5, 3, 1, 10, 1) X(5, 3, 1, 24, 1) X(6, 3, 1, 20, 1) X(7, 3, 1, 12, 1) X(4, 3, 1, 12, 1) X(3, 3, 1, 8, 1) X(2, 3, 1, 8, 1) \
-    X(10, 2, 1, 10, 1) X(10, 2, 1, 24, 1) X(8, 2, 1, 12, 1) X(5, 2, 1, 12, 1)                                           \
-    X(5, 3, 0, 10, 1) X(5, 2, 0, 12, 1) X(10, 2, 0, 10, 1)                                                               \
-    X(10, 3, 1, 20, 2) X(5, 3, 1, 5, 2) X(6, 3, 1, 7, 2) X(10, 2, 1, 5, 2) X(10, 3, 1, 10, 4)
+    X(5, 3, 1, 10, 1, 0) X(5, 3, 1, 24, 1, 0) X(6, 3, 1, 20, 1, 0) X(7, 3, 1, 12, 1, 0) X(4, 3, 1, 12, 1, 0) X(3, 3, 1, 8, 1, 0) X(2, 3, 1, 8, 1, 0) \
+    X(10, 2, 1, 10, 1, 0) X(10, 2, 1, 24, 1, 0) X(8, 2, 1, 12, 1, 0) X(5, 2, 1, 12, 1, 0)                                           \
+    X(5, 3, 0, 10, 1, 0) X(5, 2, 0, 12, 1, 0) X(10, 2, 0, 10, 1, 0)                                                               \
+    X(10, 3, 1, 20, 2, 0) X(5, 3, 1, 5, 2, 0) X(6, 3, 1, 7, 2, 0) X(10, 2, 1, 5, 2, 0) X(10, 3, 1, 10, 4, 0) \
+    X(5, 3, 1, 10, 1, 1) X(5, 3, 1, 24, 1, 1) X(6, 3, 1, 20, 1, 1) X(10, 2, 1, 10, 1, 1)

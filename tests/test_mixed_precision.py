@@ -1,0 +1,222 @@
+"""GPU tests (-m gpu) of BASELINE configs[4], "fp32 PDIP with fp64 residual check" (LSCQP_PRECISION_MIXED): the reduced system
+is factorised and substituted in float32, every residual / multiplier / stopping test stays fp64, and instances the float32
+factorisation cannot finish are re-solved by the fp64 kernel inside the same call.  The bar is the SAME as for the fp64 mode:
+
+  objective     |obj_gpu - obj_oracle| <= 1e-8 * max(1, |obj|)
+  control points max |dx| <= 1e-6 m
+  solver's own fp64 residuals: primal <= 1e-9 m, scaled stationarity <= 1e-8 (1e-6 only with LSCQP_INFO_FLOOR_ACCEPTED)
+
+plus the status / flag contract of the second pass, and the capacity status that replaced the silent row truncation.
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+OBJ_TOL = 1e-8
+X_TOL = 1e-6
+
+
+def _solve_all(api, oracle, sw, M, dim, precision, steps, check_oracle=True, x_warm=True):
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, precision=precision))
+    out = []
+    for step in range(steps + 1):
+        b = sw.build()
+        hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+        ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, b)
+        hdr["terminal_segments"] = [oracle.terminal_segments(cls, ag[q:q + 1]) for q in range(sw.N)]
+        G = sol.solve_host(hdr, rows, roff, sfcp, x_init=api.x_init_from_swarm(b, dim) if x_warm else None)
+        assert (G["status"] == 0).all(), np.bincount(G["status"], minlength=5)
+        assert G["info"]["res_primal"].max() <= 1e-9
+        strict = (G["info"]["flags"] & api.INFO_FLOOR_ACCEPTED) == 0
+        assert G["info"]["res_dual"][strict].max(initial=0.0) <= 1e-8
+        assert G["info"]["res_dual"].max() <= 1e-6
+        if check_oracle:
+            R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=8)
+            assert (R["status"] == 0).all()
+            dx = np.abs(G["x"] - R["x"]).max()
+            do = (np.abs(G["obj"] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))).max()
+            assert dx <= X_TOL and do <= OBJ_TOL, (step, dx, do)
+        out.append(G)
+        sw.advance(G["x"])
+    return out
+
+
+@pytest.mark.parametrize("N,M,dim,n_obs,style,seed,steps", [
+    (64, 5, 3, 20, "forest", 1, 3),   # the configs[4] class at the configs[1] batch size
+    (48, 6, 3, 20, "maze", 3, 3),     # dense maze: float32 breakdowns happen, the fp64 second pass repairs them
+    (10, 10, 2, 9, "forest", 2, 3),   # forest10 replica
+])
+def test_mixed_precision_matches_the_oracle(api, oracle, N, M, dim, n_obs, style, seed, steps):
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
+    _solve_all(api, oracle, sw, M, dim, api.PRECISION_MIXED, steps)
+
+
+def test_configs4_full_size_4096_agents(api, oracle):
+    """BASELINE configs[4] at its own size: 4096 agents x M = 5 x 20 neighbours, float32 rows AND float32 factorisation, against
+    the fp64 mode on the same batch (every instance) and the oracle (a bounded sample)."""
+    import torch
+
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim, n_obs = 4096, 5, 3, 20
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=44)
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    s64 = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    smx = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, precision=api.PRECISION_MIXED,
+                                   row_format=api.ROWS_F32))
+    for step in range(3):
+        b = sw.build()
+        hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+        x0 = api.x_init_from_swarm(b, dim)
+        rows32 = smx.rows_in_format(rows)          # what a producer writing 16-byte rows stores
+        rows64 = np.zeros(rows32.shape, api.ROW_DTYPE)  # ... and the same values for the fp64 run
+        for f in ("nx", "ny", "nz", "b"):
+            rows64[f] = rows32[f]
+        G64 = s64.solve_host(hdr, rows64, roff, sfcp, x_init=x0)
+        GMX = smx.solve_host(hdr, rows32, roff, sfcp, x_init=x0)
+        assert (G64["status"] == 0).all() and (GMX["status"] == 0).all()
+        dx = np.abs(G64["x"] - GMX["x"]).max()
+        do = (np.abs(G64["obj"] - GMX["obj"]) / np.maximum(1.0, np.abs(G64["obj"]))).max()
+        assert dx <= X_TOL and do <= OBJ_TOL, (step, dx, do)
+        assert GMX["info"]["res_primal"].max() <= 1e-9 and GMX["info"]["res_dual"].max() <= 1e-6
+        # iterations: with cond(Hred) ~ 2e5 a float32 solve carries a relative residual of ~1e-2, i.e. the dual residual shrinks
+        # ~100x per iteration instead of quadratically: about two more iterations than fp64 on this class (measured 5.1 vs 3.1)
+        assert GMX["info"]["iterations"].mean() <= G64["info"]["iterations"].mean() + 3.0
+        if step == 2:  # oracle on a bounded sample of the very same rows
+            sel = np.arange(0, N, 64)
+            ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, b)
+            lsc_q = np.ascontiguousarray(b["lsc"])[sel].copy()
+            # the oracle takes LSC records (p, nrm, d): hand it records that pack to exactly the float32 row values
+            r64 = rows64.reshape(N, sw.n_obs, M, 6)[sel]
+            lsc_q["nrm"][..., 0], lsc_q["nrm"][..., 1], lsc_q["nrm"][..., 2] = r64["nx"], r64["ny"], r64["nz"]
+            lsc_q["p"] = 0.0
+            lsc_q["d"] = r64["b"]
+            R = oracle.solve_batch(cls, ag[sel], lsc_q.reshape(-1), np.arange(len(sel)) * sw.n_obs * M * 6,
+                                   np.ascontiguousarray(b["sfc"])[sel].reshape(-1), threads=8)
+            assert (R["status"] == 0).all()
+            assert np.abs(GMX["x"][sel] - R["x"]).max() <= X_TOL
+            assert (np.abs(GMX["obj"][sel] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))).max() <= OBJ_TOL
+        sw.advance(G64["x"])
+    del torch
+
+
+def test_second_pass_flags_and_iteration_accounting(api, oracle):
+    """Dense-maze class in mixed precision: whatever the float32 factorisation could not finish comes back OPTIMAL from the
+    fp64 second pass with LSCQP_INFO_REPAIRED set and both passes' iterations counted; untouched instances carry no flag."""
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim = 96, 6, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=20, seed=11, style="maze")
+    outs = _solve_all(api, oracle, sw, M, dim, api.PRECISION_MIXED, steps=3, check_oracle=False)
+    rep = np.concatenate([(G["info"]["flags"] & api.INFO_REPAIRED) != 0 for G in outs])
+    its = np.concatenate([G["info"]["iterations"] for G in outs])
+    assert its.min() >= 1 and its.max() <= 120
+    # (how many need the second pass is workload dependent; the contract is only that none of them fails)
+    print("mixed precision, dense maze: %d of %d instances repaired by the fp64 pass" % (rep.sum(), rep.size))
+
+
+def test_mixed_precision_needs_a_compiled_instance(api):
+    with pytest.raises(api.LscqpError) as e:
+        api.Solver(api.make_desc(M=7, dim=3, precision=api.PRECISION_MIXED))
+    assert e.value.code == api.ERR_UNSUPPORTED
+    with pytest.raises(api.LscqpError) as e:
+        api.Solver(api.make_desc(M=5, dim=3, precision=7))
+    assert e.value.code == api.ERR_INVALID_ARGUMENT
+
+
+def test_capacity_is_a_status_not_a_truncation(api, oracle):
+    """An instance with more obstacles than the launched kernel instance holds is refused (LSCQP_STATUS_CAPACITY); its
+    neighbours in the batch are solved; nothing is truncated silently (round-1 behaviour: min(n_obs, capacity))."""
+    import torch
+
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim = 8, 5, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=7, seed=3)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    b = sw.build()
+    hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+    G0 = sol.solve_host(hdr, rows, roff, sfcp)
+    assert (G0["status"] == 0).all()
+    # device call that under-declares n_obs_max = 0 would select the smallest instance, which still holds 20: declare
+    # an instance with a bogus obstacle count instead (25 > the 20 slots of the default M = 5 instance, <= 48 of the large one)
+    dev = torch.device("cuda", 0)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    hdr2 = hdr.copy()
+    hdr2["n_obs"][3] = 25  # its row block is only 7 obstacles long: the kernel must not touch it at all
+    d_x = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
+    sol.solve_device(N, 7, up(hdr2), up(rows), up(roff), up(sfcp), d_x, d_obj, d_st, d_info)
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    assert st[3] == api.STATUS_CAPACITY and (np.delete(st, 3) == 0).all(), st
+    x = d_x.cpu().numpy().reshape(N, sol.nv)
+    assert np.abs(np.delete(x, 3, 0) - np.delete(G0["x"], 3, 0)).max() == 0.0  # the others are bit-identical
+    # the host entry sizes the launch from the headers: the same batch with a TRUE 25-obstacle instance goes to the
+    # large-capacity kernel and is solved
+    sw2 = synth.Swarm(40, M=M, dim=dim, n_obs=25, seed=4)
+    sol2 = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw2.world_min, world_max=sw2.world_max))
+    b2 = sw2.build()
+    h2, r2, o2, s2 = api.batch_from_swarm(b2, sw2.n_obs, M)
+    assert (sol2.solve_host(h2, r2, o2, s2)["status"] == 0).all()
+    # ... and a count no compiled instance holds is an API error, not a truncation
+    with pytest.raises(api.LscqpError) as e:
+        sol.solve_device(N, 4000, up(hdr2), up(rows), up(roff), up(sfcp), d_x, d_obj, d_st, d_info)
+    assert e.value.code == api.ERR_UNSUPPORTED
+
+
+def test_device_retry_solves_a_jammed_warm_start(api, oracle):
+    """tests/golden/warm_start_jam.json through the DEVICE entry with retry and too few iterations for the warm start to finish
+    (max_iter = 12: it needs 21 with the in-kernel re-centring): the second pass solves it from the default start on the
+    device, no host round trip; LSCQP_INFO_REPAIRED is set and both passes' iterations are counted."""
+    import torch
+
+    g = H.load_golden("warm_start_jam")
+    M, dim, n_obs = g["M"], g["dim"], g["n_obs"]
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=g["world_min"], world_max=g["world_max"], max_iter=12))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=g["world_min"], world_max=g["world_max"])
+    hdr = np.zeros(1, api.HEADER_DTYPE)
+    for f, v in g["hdr"].items():
+        hdr[f][0] = v
+    hdr["n_obs"][0] = n_obs
+    R = np.array(g["rows"])
+    rows = np.zeros(len(R), api.ROW_DTYPE)
+    rows["nx"], rows["ny"], rows["nz"], rows["b"] = R[:, 0], R[:, 1], R[:, 2], R[:, 3]
+    sfc = np.zeros(M, api.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = g["sfc_min"], g["sfc_max"]
+    off = np.array([0, len(R)], dtype=np.uint64)
+    x0 = np.array(g["x_init"])[None]
+    dev = torch.device("cuda", 0)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    d_x = torch.zeros(sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(1, dtype=torch.float64, device=dev)
+    res = {}
+    for retry in (False, True):
+        d_st = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        d_info = torch.zeros(32, dtype=torch.uint8, device=dev)
+        sol.solve_device(1, n_obs, up(hdr), up(rows), up(off), up(sfc), d_x, d_obj, d_st, d_info, d_x_init=up(x0), retry=retry)
+        torch.cuda.synchronize()
+        res[retry] = (int(d_st.cpu()[0]), d_info.cpu().numpy().view(api.INFO_DTYPE)[0].copy(), d_x.cpu().numpy().copy())
+    assert res[False][0] != 0, "fixture no longer jams within 12 iterations: pick a smaller max_iter"
+    assert res[True][0] == 0 and (res[True][1]["flags"] & api.INFO_REPAIRED)
+    assert res[True][1]["iterations"] > res[False][1]["iterations"]
+    ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
+    lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+    lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)
+    lsc["d"] = R[:, 3].reshape(n_obs, M, 6)
+    o = oracle.solve(cls, ag, lsc, sfc)
+    assert o["status"] == 0 and np.abs(res[True][2] - o["x"]).max() <= X_TOL

@@ -31,8 +31,42 @@ def build_T(M, end_stop):
     return T, nzA
 
 
+PIVOT_FLOOR = 0.0
+JACOBI = True
+
+
+def ldl32(K):
+    """LDL^T of K in float32 arithmetic (right-looking, as the kernel does it); None on a non-positive pivot."""
+    A = K.astype(np.float32).copy()
+    n = A.shape[0]
+    d = np.zeros(n, np.float32)
+    for j in range(n):
+        d[j] = A[j, j]
+        if not d[j] > PIVOT_FLOOR * np.float32(K[j, j]):
+            if PIVOT_FLOOR == 0:
+                return None
+            d[j] = np.float32(1e30)  # modified Cholesky: a pivot lost to rounding freezes its direction for this solve
+        l = (A[j + 1:, j] / d[j]).astype(np.float32)
+        A[j + 1:, j + 1:] -= np.outer(l, A[j, j + 1:]).astype(np.float32)
+        A[j + 1:, j] = l
+    return np.tril(A, -1) + np.eye(n, dtype=np.float32), d
+
+
+def solve32(fac, b):
+    L, d = fac
+    n = len(d)
+    w = b.astype(np.float32).copy()
+    sc = np.float32(1.0)
+    for j in range(n):
+        w[j + 1:] -= (L[j + 1:, j] * w[j]).astype(np.float32)
+    w = (w / d).astype(np.float32)
+    for j in range(n - 1, -1, -1):
+        w[:j] -= (L[j, :j] * w[j]).astype(np.float32)
+    return w.astype(np.float64)
+
+
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
-          tol=1e-10, max_iter=60, verbose=False):
+          tol=1e-10, max_iter=60, verbose=False, fp32=None):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -199,14 +233,29 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             floor_seen = floor_seen or gap_rel <= tol
         w = lam / s
         K = Kfull + Gz.T @ (w[:, None] * Gz)
-        try:
-            L = np.linalg.cholesky(K)
-        except np.linalg.LinAlgError:
-            status = 0 if near_cnt > 0 else 3
-            break
-        def lin(q):
-            rhs = -grad + Gz.T @ q
-            return np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+        if fp32 is not None:
+            # mixed-precision experiment (BASELINE configs[4]): K rounded to float32, LDL^T and the substitutions in float32,
+            # `fp32` refinement sweeps on the fp64 residual of the linear system
+            jac = 1.0 / np.sqrt(np.diag(K)) if JACOBI else np.ones(len(K))  # Jacobi equilibration: unit diagonal, |entries| <= 1 (no float32 overflow)
+            fac = ldl32(K * jac[:, None] * jac[None, :])
+            if fac is None:
+                status = 0 if near_cnt > 0 else 3
+                break
+            def lin(q):
+                rhs = -grad + Gz.T @ q
+                dzv = jac * solve32(fac, jac * rhs)
+                for _r in range(fp32):
+                    dzv = dzv + jac * solve32(fac, jac * (rhs - K @ dzv))
+                return dzv
+        else:
+            try:
+                L = np.linalg.cholesky(K)
+            except np.linalg.LinAlgError:
+                status = 0 if near_cnt > 0 else 3
+                break
+            def lin(q):
+                rhs = -grad + Gz.T @ q
+                return np.linalg.solve(L.T, np.linalg.solve(L, rhs))
         # predictor
         dza = lin(-w * rp)
         dsa = Gz @ dza + rp
