@@ -185,6 +185,10 @@ int lscqp_destroy(lscqp_handle h);
 
 /* nv = dim*M*(n+1): number of doubles per instance in x_out. */
 int lscqp_num_variables(lscqp_handle h);
+/* M, whether the class carries SFC rows, and the bytes of one packed row in the handle's row_format (32 or 16). */
+int lscqp_num_segments(lscqp_handle h);
+int lscqp_uses_sfc(lscqp_handle h);
+int lscqp_row_bytes(lscqp_handle h);
 
 /* Replaces TrajOptimizer::solve (src/traj_optimizer.cpp:18-156) for a batch of n independent agents
  * (the sequential loop at src/multi_sync_simulator.cpp:354-362 issues n == 1).
@@ -211,6 +215,16 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
                       const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
                       double* obj_out, int32_t* status_out, lscqp_info* info_out);
 
+/* lscqp_solve_batch with the H2D copy, the kernels and the D2H copy issued on the CALLER's stream (a hipStream_t passed as
+ * void*; NULL = a private non-blocking stream of the call); returns after that stream has been synchronised.
+ * THREAD SAFETY of the host-pointer entry points (this one, lscqp_solve_batch, lscqp_optimize_goal, lscqp_construct_sfc): each
+ * call stages through its own (device buffer, pinned mirror, stream) slot taken from a pool inside the handle, so any number of
+ * threads may call them concurrently on the same solver / map handle -- the reference builds a fresh IloEnv per call and is
+ * re-entrant in the same sense (src/traj_optimizer.cpp:25-29).  lscqp_update / lscqp_destroy must not race with calls in flight. */
+int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                             const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
+                             double* obj_out, int32_t* status_out, lscqp_info* info_out, void* stream);
+
 /* Same, DEVICE pointers, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream).
  * Inputs must already be resident in HBM; nothing is copied and nothing is synchronised.
  * n_obs_max: upper bound of d_hdr[q].n_obs over the batch; it selects the kernel instance (row slots in registers, LDS
@@ -228,6 +242,54 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
                              const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                              const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
                              lscqp_info* d_info_out, void* stream);
+
+/* ---- multi-GPU: the agent batch over the GPUs of one node, from ONE host process ----------------
+ *
+ * The reference's host is a single process (one ROS node); within a replan step its N QPs are independent
+ * (src/multi_sync_simulator.cpp:354-362) and the only exchange is broadcastMsgs (:305-352: every agent receives the others'
+ * previous plans).  A communicator owns one private stream, one staging pool and one RCCL communicator per device
+ * (ncclCommInitAll; RCCL is bound at run time, a single-GPU host needs none).  Partitioning: contiguous blocks of
+ * ceil(N / G) agents in id order; NO collective on the solve path.
+ *   lscqp_comm_create        n_devices <= 0: all visible devices; device_ids NULL: 0 .. n_devices-1
+ *   lscqp_comm_backend       "rccl <version> (ncclCommInitAll, G devices)" or "none: single device, ..." -- what actually runs
+ *   lscqp_comm_devices_for   how many devices a batch of n agents is spread over: clamp(n / min_agents_per_device, 1, G), default
+ *                            256 agents per device -- one 64-QP block per device finishes no sooner than 512 QPs on one
+ *                            device (0.108 vs 0.136 ms at M = 5), so spreading a small batch buys nothing and only adds the
+ *                            exchange; north_star: "only when agent count justifies it".  lscqp_comm_set_min_agents_per_device
+ *                            moves the threshold (1 = always use every device).
+ *   lscqp_comm_shard         the block [first, first + count) of device g when n agents are spread over n_used devices
+ *   lscqp_solve_batch_sharded        HOST pointers for the whole batch (same arguments as lscqp_solve_batch): every block is staged
+ *                            to its device, solved there (with the retry pass) and fetched back, all devices concurrently, each
+ *                            on its own stream; results land in the caller's arrays in agent order.  *n_devices_used reports the
+ *                            spread.  This is what TrajOptimizer::solveBatch calls when it has a communicator.
+ *   lscqp_solve_batch_sharded_device DEVICE-resident blocks: arrays of G per-device pointers, n[g] agents on device g, launched on
+ *                            the communicator's streams, asynchronous (lscqp_comm_synchronize waits for all of them)
+ *   lscqp_allgather          the device analogue of broadcastMsgs: device g contributes d_send[g][count] doubles (its block of
+ *                            solved control points, x_out) and receives everybody's into d_recv[g][G * count]; one grouped
+ *                            ncclAllGather over xGMI on the communicator's streams, asynchronous.  Equal counts per device:
+ *                            pad the last block.  count * 8 B per device is 46 KB (64 agents, M = 5) to 369 KB (512 agents):
+ *                            latency-bound on xGMI, hence the spreading rule above. */
+typedef struct lscqp_comm_s* lscqp_comm;
+int lscqp_comm_create(int32_t n_devices, const int32_t* device_ids, lscqp_comm* out);
+void lscqp_comm_destroy(lscqp_comm c);
+int32_t lscqp_comm_size(lscqp_comm c);
+int32_t lscqp_comm_device(lscqp_comm c, int32_t g);
+void* lscqp_comm_stream(lscqp_comm c, int32_t g); /* hipStream_t of device g */
+const char* lscqp_comm_backend(lscqp_comm c);
+int lscqp_comm_set_min_agents_per_device(lscqp_comm c, int64_t n);
+int32_t lscqp_comm_devices_for(lscqp_comm c, int64_t n);
+int lscqp_comm_shard(lscqp_comm c, int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count);
+/* the same partition rule without a communicator (no device needed): block g of n agents over n_used devices */
+int lscqp_shard_range(int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count);
+int lscqp_comm_synchronize(lscqp_comm c);
+int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                              const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
+                              int32_t* status_out, lscqp_info* info_out, int32_t* n_devices_used);
+int lscqp_solve_batch_sharded_device(lscqp_handle h, lscqp_comm c, const int64_t* n, int32_t n_obs_max, const lscqp_header* const* d_hdr,
+                                     const lscqp_row* const* d_rows, const uint64_t* const* d_row_offsets, const lscqp_box* const* d_sfc,
+                                     const double* const* d_x_init, double* const* d_x_out, double* const* d_obj_out,
+                                     int32_t* const* d_status_out, lscqp_info* const* d_info_out, int32_t retry);
+int lscqp_allgather(lscqp_comm c, const double* const* d_send, double* const* d_recv, int64_t count);
 
 /* ---- next row of the path: the producer of the LSC rows --------------------------------
  *

@@ -89,6 +89,39 @@ def lib():
         L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 10
         L.lscqp_solve_batch_device_ex.restype = C.c_int
         L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
+        L.lscqp_solve_batch_stream.restype = C.c_int
+        L.lscqp_solve_batch_stream.argtypes = [vp, C.c_int64] + [vp] * 10
+        for f in ("lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes"):
+            getattr(L, f).restype = C.c_int
+            getattr(L, f).argtypes = [vp]
+        L.lscqp_comm_create.restype = C.c_int
+        L.lscqp_comm_create.argtypes = [C.c_int32, vp, C.POINTER(vp)]
+        L.lscqp_comm_destroy.restype = None
+        L.lscqp_comm_destroy.argtypes = [vp]
+        L.lscqp_comm_size.restype = C.c_int32
+        L.lscqp_comm_size.argtypes = [vp]
+        L.lscqp_comm_device.restype = C.c_int32
+        L.lscqp_comm_device.argtypes = [vp, C.c_int32]
+        L.lscqp_comm_stream.restype = vp
+        L.lscqp_comm_stream.argtypes = [vp, C.c_int32]
+        L.lscqp_comm_backend.restype = C.c_char_p
+        L.lscqp_comm_backend.argtypes = [vp]
+        L.lscqp_comm_set_min_agents_per_device.restype = C.c_int
+        L.lscqp_comm_set_min_agents_per_device.argtypes = [vp, C.c_int64]
+        L.lscqp_comm_devices_for.restype = C.c_int32
+        L.lscqp_comm_devices_for.argtypes = [vp, C.c_int64]
+        L.lscqp_comm_shard.restype = C.c_int
+        L.lscqp_comm_shard.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, vp, vp]
+        L.lscqp_shard_range.restype = C.c_int
+        L.lscqp_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp]
+        L.lscqp_comm_synchronize.restype = C.c_int
+        L.lscqp_comm_synchronize.argtypes = [vp]
+        L.lscqp_solve_batch_sharded.restype = C.c_int
+        L.lscqp_solve_batch_sharded.argtypes = [vp, vp, C.c_int64] + [vp] * 10
+        L.lscqp_solve_batch_sharded_device.restype = C.c_int
+        L.lscqp_solve_batch_sharded_device.argtypes = [vp, vp, vp, C.c_int32] + [vp] * 9 + [C.c_int32]
+        L.lscqp_allgather.restype = C.c_int
+        L.lscqp_allgather.argtypes = [vp, vp, vp, C.c_int64]
         L.lscqp_generate_lsc_device.restype = C.c_int
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_generate_constraints_device.restype = C.c_int
@@ -128,7 +161,11 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex",
+                    "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
+                    "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
+                    "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
+                    "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
                     "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
@@ -199,6 +236,65 @@ class WorldMap:
             self.close()
         except Exception:
             pass
+
+
+def shard_range(n, n_used, g):
+    """lscqp_shard_range: block [first, first + count) of device g when n agents are spread over n_used devices."""
+    f, c = C.c_int64(), C.c_int64()
+    rc = lib().lscqp_shard_range(n, n_used, g, C.byref(f), C.byref(c))
+    if rc != OK:
+        raise LscqpError(rc, lib().lscqp_last_error().decode())
+    return f.value, c.value
+
+
+class Comm:
+    """lscqp_comm: one host process driving the GPUs of a node (private stream + staging pool + RCCL communicator per device)."""
+
+    def __init__(self, n_devices=0, device_ids=None):
+        self._h = C.c_void_p()
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        rc = lib().lscqp_comm_create(int(n_devices), None if ids is None else ids.ctypes.data_as(C.c_void_p), C.byref(self._h))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        self.size = lib().lscqp_comm_size(self._h)
+        self.backend = lib().lscqp_comm_backend(self._h).decode()
+
+    def close(self):
+        if self._h:
+            lib().lscqp_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_min_agents_per_device(self, n):
+        rc = lib().lscqp_comm_set_min_agents_per_device(self._h, int(n))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def devices_for(self, n):
+        return lib().lscqp_comm_devices_for(self._h, int(n))
+
+    def stream(self, g):
+        return lib().lscqp_comm_stream(self._h, g)
+
+    def synchronize(self):
+        rc = lib().lscqp_comm_synchronize(self._h)
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def allgather(self, send, recv, count):
+        """send / recv: lists of torch CUDA tensors, one per device (device g contributes send[g][:count] doubles and
+        receives size * count); asynchronous on the communicator's streams."""
+        vp = C.c_void_p * self.size
+        ps = vp(*[t.data_ptr() for t in send])
+        pr = vp(*[t.data_ptr() for t in recv])
+        rc = lib().lscqp_allgather(self._h, ps, pr, int(count))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
 
 
 class Solver:
@@ -272,6 +368,32 @@ class Solver:
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
         return dict(x=x, obj=obj, status=status, info=info)
+
+    def solve_sharded(self, comm, hdr, rows=None, row_offsets=None, sfc=None, want_info=True, x_init=None):
+        """lscqp_solve_batch_sharded: the host-pointer call over the devices of `comm`; returns solve_host's dict + devices_used."""
+        n = len(hdr)
+        hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE)
+        x = np.zeros((n, self.nv))
+        obj = np.zeros(n)
+        status = np.full(n, -1, dtype=np.int32)
+        info = np.zeros(n, INFO_DTYPE) if want_info else None
+        if rows is not None:
+            rows = self.rows_in_format(rows)
+            row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+        if sfc is not None:
+            sfc = np.ascontiguousarray(sfc, dtype=BOX_DTYPE).reshape(-1)
+        if x_init is not None:
+            x_init = np.ascontiguousarray(x_init, dtype=np.float64).reshape(n, self.nv)
+
+        def p(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+        used = C.c_int32(0)
+        rc = lib().lscqp_solve_batch_sharded(self._h, comm._h, n, p(hdr), p(rows), p(row_offsets), p(sfc), p(x_init), p(x), p(obj),
+                                             p(status), p(info), C.cast(C.byref(used), C.c_void_p))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        return dict(x=x, obj=obj, status=status, info=info, devices_used=used.value)
 
     # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
     def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None,

@@ -43,7 +43,7 @@ def _run(cmd):
 
 def build(force=False, verbose=False, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in ("lscqp_kernel.hpp", "lscqp_launch.hpp")] + [
+    hdrs = [os.path.join(CSRC, f) for f in ("lscqp_kernel.hpp", "lscqp_launch.hpp", "lscqp_staging.hpp")] + [
         os.path.join(HERE, "..", "include", "lscqp.h"), os.path.abspath(__file__)]
     tasks = []
     objs = []
@@ -74,6 +74,11 @@ def build(force=False, verbose=False, jobs=None):
     sfc_src = os.path.join(CSRC, "lscsfc.hip")
     if force or _newer(sfc_o, hdrs + [sfc_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", sfc_src, "-o", sfc_o])
+    comm_o = os.path.join(OBJ, "lscqp_comm.o")
+    objs.append(comm_o)
+    comm_src = os.path.join(CSRC, "lscqp_comm.hip")
+    if force or _newer(comm_o, hdrs + [comm_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", comm_src, "-o", comm_o])
     gen_o = os.path.join(OBJ, "lscgen.o")
     objs.append(gen_o)
     gen_src = os.path.join(CSRC, "lscgen.hip")
@@ -85,7 +90,7 @@ def build(force=False, verbose=False, jobs=None):
                 if verbose and msg:
                     sys.stderr.write(msg)
     if tasks or not os.path.exists(LIB):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
     return LIB
 
 

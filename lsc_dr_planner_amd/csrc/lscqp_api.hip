@@ -12,6 +12,7 @@
 
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
+#include "lscqp_staging.hpp"
 
 #define LSCQP_DECL(M, D, E, S, W, X)                                                                                      \
     extern "C" hipError_t lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X(const lscqp::DevClass*, int64_t, const lscqp_header*, \
@@ -122,11 +123,9 @@ struct lscqp_solver {
     lscqp_class_desc desc;
     lscqp::DevClass dev;
     int nv, P, es;
-    // staging buffers of the host-pointer entry point
-    void* d_buf = nullptr;
-    size_t d_cap = 0;
-    void* h_buf = nullptr;  // pinned mirror of d_buf: one H2D and one D2H per host-pointer solve instead of eight small copies
-    size_t h_cap = 0;
+    // staging of the host-pointer entry points: device buffer + pinned mirror + private stream per concurrent call
+    // (one H2D and one D2H per host-pointer solve instead of eight small copies; lscqp_staging.hpp)
+    lscqp::StagePool* pool = nullptr;
 };
 
 static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
@@ -200,6 +199,7 @@ int lscqp_create(const lscqp_class_desc* desc, lscqp_handle* out) {
         delete s;
         return rc;
     }
+    s->pool = new lscqp::StagePool();
     *out = s;
     return LSCQP_OK;
 }
@@ -209,23 +209,21 @@ int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
     lscqp_solver tmp = *h;
     int rc = derive(&tmp, desc);
     if (rc != LSCQP_OK) return rc;
-    tmp.d_buf = h->d_buf;
-    tmp.d_cap = h->d_cap;
-    tmp.h_buf = h->h_buf;
-    tmp.h_cap = h->h_cap;
-    *h = tmp;
+    *h = tmp;  // (the staging pool pointer travels with the copy)
     return LSCQP_OK;
 }
 
 int lscqp_destroy(lscqp_handle h) {
     if (!h) return LSCQP_OK;
-    if (h->d_buf) (void)hipFree(h->d_buf);
-    if (h->h_buf) (void)hipHostFree(h->h_buf);
+    delete h->pool;
     delete h;
     return LSCQP_OK;
 }
 
 int lscqp_num_variables(lscqp_handle h) { return h ? h->nv : -1; }
+int lscqp_num_segments(lscqp_handle h) { return h ? h->desc.M : -1; }
+int lscqp_uses_sfc(lscqp_handle h) { return h ? (h->desc.use_sfc ? 1 : 0) : -1; }
+int lscqp_row_bytes(lscqp_handle h) { return h ? (int)row_bytes(h) : -1; }
 
 int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
                               const int32_t* d_neighbours, const double* d_radius, const double* d_downwash,
@@ -314,22 +312,11 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
                  b_sfc = al(sizeof(lscqp_box) * n * h->desc.M), b_st = al(sizeof(int32_t) * n);
     // layout [rows | offsets | sfc | hdr | status]: one H2D of rows .. hdr, one D2H of hdr .. status (pinned staging)
     const size_t total = b_rows + b_off + b_sfc + b_hdr + b_st;
-    if (total > h->d_cap) {
-        if (h->d_buf) (void)hipFree(h->d_buf);
-        h->d_buf = nullptr;
-        h->d_cap = 0;
-        if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
-        h->d_cap = total;
-    }
-    if (total > h->h_cap) {
-        if (h->h_buf) (void)hipHostFree(h->h_buf);
-        h->h_buf = nullptr;
-        h->h_cap = 0;
-        if (hipHostMalloc(&h->h_buf, total, hipHostMallocDefault) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipHostMalloc failed");
-        h->h_cap = total;
-    }
-    char* const db = (char*)h->d_buf;
-    char* const hb = (char*)h->h_buf;
+    lscqp::SlotGuard sg{*h->pool, h->pool->acquire(total)};
+    if (!sg.slot) return fail(LSCQP_ERR_HIP, "staging allocation failed (hipMalloc / hipHostMalloc / stream)");
+    hipStream_t st = sg.slot->stream;
+    char* const db = (char*)sg.slot->d;
+    char* const hb = (char*)sg.slot->h;
     const size_t o_rows = 0, o_off = b_rows, o_sfc = o_off + b_off, o_hdr = o_sfc + b_sfc, o_st = o_hdr + b_hdr;
 #define LSCQP_CK(call)                                                                           \
     do {                                                                                         \
@@ -341,12 +328,12 @@ int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscq
     else memset(hb + o_off, 0, sizeof(uint64_t) * (n + 1));
     if (h->desc.use_sfc) memcpy(hb + o_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M);
     memcpy(hb + o_hdr, hdr, sizeof(lscqp_header) * n);
-    LSCQP_CK(hipMemcpyAsync(db, hb, o_st, hipMemcpyHostToDevice, nullptr));
+    LSCQP_CK(hipMemcpyAsync(db, hb, o_st, hipMemcpyHostToDevice, st));
     int rc = lscqp_optimize_goal_device(h, n, (lscqp_header*)(db + o_hdr), (const lscqp_row*)(db + o_rows), (const uint64_t*)(db + o_off),
-                                        (const lscqp_box*)(db + o_sfc), (int32_t*)(db + o_st), nullptr);
+                                        (const lscqp_box*)(db + o_sfc), (int32_t*)(db + o_st), st);
     if (rc != LSCQP_OK) return rc;
-    LSCQP_CK(hipMemcpyAsync(hb + o_hdr, db + o_hdr, b_hdr + b_st, hipMemcpyDeviceToHost, nullptr));
-    LSCQP_CK(hipStreamSynchronize(nullptr));
+    LSCQP_CK(hipMemcpyAsync(hb + o_hdr, db + o_hdr, b_hdr + b_st, hipMemcpyDeviceToHost, st));
+    LSCQP_CK(hipStreamSynchronize(st));
     memcpy(hdr, hb + o_hdr, sizeof(lscqp_header) * n);
     memcpy(status_out, hb + o_st, sizeof(int32_t) * n);
 #undef LSCQP_CK
@@ -484,6 +471,12 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
 int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
                       const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
                       double* obj_out, int32_t* status_out, lscqp_info* info_out) {
+    return lscqp_solve_batch_stream(h, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out, nullptr);
+}
+
+int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                             const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out,
+                             double* obj_out, int32_t* status_out, lscqp_info* info_out, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -511,22 +504,11 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     // layout: [hdr | rows | offsets | sfc | x_init] = one contiguous input region, [x | obj | status | info] = one output region
     const size_t b_in = b_hdr + b_rows + b_off + b_sfc + b_xi, b_out = b_x + b_obj + b_st + b_info;
     const size_t total = b_in + b_out;
-    if (total > h->d_cap) {
-        if (h->d_buf) (void)hipFree(h->d_buf);
-        h->d_buf = nullptr;
-        h->d_cap = 0;
-        if (hipMalloc(&h->d_buf, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
-        h->d_cap = total;
-    }
-    if (total > h->h_cap) {
-        if (h->h_buf) (void)hipHostFree(h->h_buf);
-        h->h_buf = nullptr;
-        h->h_cap = 0;
-        if (hipHostMalloc(&h->h_buf, total, hipHostMallocDefault) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipHostMalloc failed");
-        h->h_cap = total;
-    }
-    char* const dbase = (char*)h->d_buf;
-    char* const hbase = (char*)h->h_buf;
+    lscqp::SlotGuard sg{*h->pool, h->pool->acquire(total)};
+    if (!sg.slot) return fail(LSCQP_ERR_HIP, "staging allocation failed (hipMalloc / hipHostMalloc / stream)");
+    hipStream_t st = stream ? (hipStream_t)stream : sg.slot->stream;  // the caller's stream, or the slot's private one
+    char* const dbase = (char*)sg.slot->d;
+    char* const hbase = (char*)sg.slot->h;
     const size_t o_hdr = 0, o_rows = o_hdr + b_hdr, o_off = o_rows + b_rows, o_sfc = o_off + b_off, o_xi = o_sfc + b_sfc,
                  o_x = b_in, o_obj = o_x + b_x, o_st = o_obj + b_obj, o_info = o_st + b_st;
     lscqp_header* d_hdr = (lscqp_header*)(dbase + o_hdr);
@@ -549,13 +531,13 @@ int lscqp_solve_batch(lscqp_handle h, int64_t n, const lscqp_header* hdr, const 
     else memset(hbase + o_off, 0, sizeof(uint64_t) * (n + 1));
     if (h->desc.use_sfc) memcpy(hbase + o_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M);
     if (d_xi) memcpy(hbase + o_xi, x_init, sizeof(double) * n * h->nv);
-    LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, nullptr));
+    LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, st));
     // (retry = 1: instances a warm start did not bring to OPTIMAL are solved once more from the default start by a second pass
     // on the device, before the results are copied back)
-    int rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, 1, nullptr);
+    int rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, 1, st);
     if (rc != LSCQP_OK) return rc;
-    LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, nullptr));
-    LSCQP_CK(hipStreamSynchronize(nullptr));
+    LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+    LSCQP_CK(hipStreamSynchronize(st));
     memcpy(x_out, hbase + o_x, sizeof(double) * n * h->nv);
     memcpy(obj_out, hbase + o_obj, sizeof(double) * n);
     memcpy(status_out, hbase + o_st, sizeof(int32_t) * n);

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/lscqp.h"
+#include "lscqp_staging.hpp"
 
 #pragma clang fp contract(off)
 
@@ -40,10 +41,9 @@ struct lscqp_map_s {
     int radius_cells;
     uint8_t* d_occ;
     int32_t* d_nearest;
-    // staging of the host-pointer corridor call (one pinned buffer, one copy each way)
-    void* d_stage = nullptr;
-    void* h_stage = nullptr;
-    size_t stage_cap = 0;
+    // staging of the host-pointer corridor call: a pinned buffer + device mirror + private stream per concurrent call (the map
+    // handle is shared by all agents' CollisionConstraints: two threads must never share a staging buffer)
+    lscqp::StagePool* pool = nullptr;
 };
 
 namespace lscsfc {
@@ -426,6 +426,7 @@ int lscqp_map_create(const double* boxes, int64_t n_boxes, const double* world_m
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     lscqp_map_s* mp = new lscqp_map_s();
+    mp->pool = new lscqp::StagePool();
     mp->res = resolution;
     int64_t nvox = 1;
     for (int k = 0; k < 3; k++) {
@@ -520,8 +521,7 @@ void lscqp_map_destroy(lscqp_map mp) {
     if (!mp) return;
     if (mp->d_occ) (void)hipFree(mp->d_occ);
     if (mp->d_nearest) (void)hipFree(mp->d_nearest);
-    if (mp->d_stage) (void)hipFree(mp->d_stage);
-    if (mp->h_stage) (void)hipHostFree(mp->h_stage);
+    delete mp->pool;
     delete mp;
 }
 
@@ -568,26 +568,20 @@ int lscqp_construct_sfc(lscqp_map mp, int32_t mode, int32_t M, int64_t n, const 
     const size_t b_p = al(n * 9 * sizeof(double)), b_r = al(n * sizeof(double)), b_s = al(n * M * sizeof(lscqp_box)),
                  b_st = al(n * sizeof(int32_t));
     const size_t total = b_p + b_r + b_s + b_st;  // [points | radius | boxes (in/out) | status (out)]
-    if (total > mp->stage_cap) {
-        if (mp->d_stage) (void)hipFree(mp->d_stage);
-        if (mp->h_stage) (void)hipHostFree(mp->h_stage);
-        mp->d_stage = mp->h_stage = nullptr;
-        mp->stage_cap = 0;
-        if (hipMalloc(&mp->d_stage, total) != hipSuccess || hipHostMalloc(&mp->h_stage, total, hipHostMallocDefault) != hipSuccess)
-            return lscqp_set_error_(LSCQP_ERR_HIP, "staging allocation failed");
-        mp->stage_cap = total;
-    }
-    char* const hb = (char*)mp->h_stage;
-    char* const db = (char*)mp->d_stage;
+    lscqp::SlotGuard sg{*mp->pool, mp->pool->acquire(total)};
+    if (!sg.slot) return lscqp_set_error_(LSCQP_ERR_HIP, "staging allocation failed");
+    hipStream_t st = sg.slot->stream;
+    char* const hb = (char*)sg.slot->h;
+    char* const db = (char*)sg.slot->d;
     memcpy(hb, points, n * 9 * sizeof(double));
     memcpy(hb + b_p, radius, n * sizeof(double));
     memcpy(hb + b_p + b_r, sfc, n * M * sizeof(lscqp_box));
-    LSCSFC_HIP(hipMemcpyAsync(db, hb, b_p + b_r + b_s, hipMemcpyHostToDevice, nullptr));
+    LSCSFC_HIP(hipMemcpyAsync(db, hb, b_p + b_r + b_s, hipMemcpyHostToDevice, st));
     const int rc = lscqp_construct_sfc_raw_(mp, mode, M, n, (const double*)db, (const double*)(db + b_p), (lscqp_box*)(db + b_p + b_r),
-                                            (int32_t*)(db + b_p + b_r + b_s), nullptr);
+                                            (int32_t*)(db + b_p + b_r + b_s), st);
     if (rc != LSCQP_OK) return rc;
-    LSCSFC_HIP(hipMemcpyAsync(hb + b_p + b_r, db + b_p + b_r, b_s + b_st, hipMemcpyDeviceToHost, nullptr));
-    LSCSFC_HIP(hipStreamSynchronize(nullptr));
+    LSCSFC_HIP(hipMemcpyAsync(hb + b_p + b_r, db + b_p + b_r, b_s + b_st, hipMemcpyDeviceToHost, st));
+    LSCSFC_HIP(hipStreamSynchronize(st));
     memcpy(sfc, hb + b_p + b_r, n * M * sizeof(lscqp_box));
     memcpy(status_out, hb + b_p + b_r + b_s, n * sizeof(int32_t));
     return LSCQP_OK;

@@ -102,6 +102,8 @@ public:
     std::set<int> getDynamicObstacles() const { return dynamic_obstacle_indices; }
     bool isDynamicObstacle(int oi) const { return dynamic_obstacle_indices.find(oi) != dynamic_obstacle_indices.end(); }
     bool slackObstaclesEmpty() const { return dynamic_obstacle_indices.empty(); }
+    // (additive: the reference declares the set but nothing ever inserts into it, src/collision_constraints.cpp:495-503)
+    void markDynamicObstacle(int oi) { dynamic_obstacle_indices.insert(oi); }
     // Setter (:514-543)
     void setLSC(int oi, int m, const points_t& obs_control_points, const vector3d& normal_vector, const std::vector<double>& ds) {
         for (int i = 0; i < param.n + 1; i++) lscs[oi][m][i] = LSC(obs_control_points[i], normal_vector, ds[i]);

@@ -46,6 +46,12 @@ public:
     // Solves every item in one launch.  results[i] is filled for every item; ok[i] == false where the reference
     // would have thrown PlanningReport::QPFAILED (the caller substitutes initial_traj, src/traj_planner.cpp:767-797).
     void solveBatch(const std::vector<BatchItem>& items, std::vector<TrajOptResult>& results, std::vector<bool>& ok);
+    // Multi-GPU (one host process, G devices; include/lscqp.h "multi-GPU"): with a communicator set, solveBatch cuts the
+    // items into contiguous blocks over as many devices as the batch justifies (lscqp_comm_devices_for) and solves them
+    // concurrently; results come back in item order.  The communicator is shared by all TrajOptimizer objects of the process
+    // (the reference has one per agent) and owned by the caller.  nullptr (default): single device.
+    static void setCommunicator(lscqp_comm comm) { communicator() = comm; }
+    int lastDevicesUsed() const { return last_devices_used; }
     const std::vector<double>& lastRawSolution() const { return raw_x; }
     int lastIterations() const { return last_iterations; }
 
@@ -58,6 +64,11 @@ private:
     lscqp_handle handle = nullptr;
     std::vector<double> raw_x;
     int last_iterations = 0;
+    int last_devices_used = 1;
+    static lscqp_comm& communicator() {
+        static lscqp_comm c = nullptr;
+        return c;
+    }
 
     void configure();
     [[nodiscard]] int getTerminalSegments_old(const Agent& agent) const;

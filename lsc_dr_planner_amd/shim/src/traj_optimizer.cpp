@@ -96,6 +96,14 @@ void TrajOptimizer::pack(const Agent& agent, const CollisionConstraints& constra
                 // the reference tests ||normal|| < SP_EPSILON_FLOAT with point3d's float norm (:409); make the same
                 // decision here so borderline rows agree bit for bit
                 if (lsc.normal_vector.norm() < SP_EPSILON_FLOAT) r.nx = r.ny = r.nz = 0.0;
+                // An obstacle in constraints' dynamic-obstacle set gets a slack variable eps in (-inf, 0] on its rows
+                // (src/traj_optimizer.cpp:272-283, 423-425) that appears in NO cost term (:285-316): such a row can always be
+                // satisfied by its own slack, i.e. it never binds.  Dropping the row (zero normal: the solver skips it like
+                // :409-411) is the same QP.  (The set is never populated in the reference, src/collision_constraints.cpp:495-503.)
+                if (constraints.isDynamicObstacle((int)oi)) {
+                    r.nx = r.ny = r.nz = 0.0;
+                    r.b = -1.0;
+                }
                 rows.push_back(r);
             }
     if (param.world_use_octomap)
@@ -154,8 +162,18 @@ void TrajOptimizer::solveBatch(const std::vector<BatchItem>& items, std::vector<
     std::vector<int32_t> status(nq);
     std::vector<lscqp_info> info(nq);
     if (rows.empty()) rows.resize(1);
-    int rc = lscqp_solve_batch(handle, (int64_t)nq, hdr.data(), rows.data(), off.data(), boxes.empty() ? nullptr : boxes.data(),
+    int rc;
+    if (communicator()) {
+        int32_t used = 1;
+        rc = lscqp_solve_batch_sharded(handle, communicator(), (int64_t)nq, hdr.data(), rows.data(), off.data(),
+                                       boxes.empty() ? nullptr : boxes.data(), warm ? x_init.data() : nullptr, raw_x.data(), obj.data(),
+                                       status.data(), info.data(), &used);
+        last_devices_used = used;
+    } else {
+        rc = lscqp_solve_batch(handle, (int64_t)nq, hdr.data(), rows.data(), off.data(), boxes.empty() ? nullptr : boxes.data(),
                                warm ? x_init.data() : nullptr, raw_x.data(), obj.data(), status.data(), info.data());
+        last_devices_used = 1;
+    }
     if (rc != LSCQP_OK) throw std::runtime_error(std::string("[TrajOptimizer] ") + lscqp_last_error());
     results.resize(nq);
     ok.assign(nq, false);

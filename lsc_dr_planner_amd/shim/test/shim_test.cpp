@@ -315,6 +315,100 @@ static int scenario_sfc(const char* world_csv) {
     return 0;
 }
 
+// Multi-GPU behind the reference's class surface: TrajOptimizer::solveBatch with a communicator over every visible device
+// (G = 1 on a single-GPU box: same code path, one block), against the same batch without a communicator.
+static int scenario_sharded() {
+    Param param;
+    Mission mission;
+    mission.world_min = point3d(-40, -40, 0);
+    mission.world_max = point3d(40, 40, 6);
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    TrajOptimizer opt(param, mission, B);
+    const int N = 300;
+    std::vector<Agent> agents;
+    std::vector<std::unique_ptr<CollisionConstraints>> cons;
+    std::vector<traj_t> inits;
+    for (int q = 0; q < N; q++) {
+        const float x = -30.0f + 2.0f * (q % 30), y = -9.0f + 2.0f * (q / 30), z = 1.0f + 0.1f * (q % 7);
+        const point3d p(x, y, z), wp(x + 0.5f * ((q % 3) - 1), y + 0.5f * ((q % 5) / 2 - 1), z);
+        Agent a = make_agent(p, wp, wp);
+        a.current_state.velocity = point3d(0.1f * (q % 4), -0.05f * (q % 3), 0.0f);
+        agents.push_back(a);
+        cons.emplace_back(new CollisionConstraints(param, mission));
+        cons.back()->initializeLSC(1);
+        const point3d obs(x + 0.6f, y + 0.1f * (q % 5), z);
+        for (int m = 0; m < param.M; m++) {
+            cons.back()->setLSC(0, m, obs, (p - obs).normalized(), 0.31);
+            cons.back()->setSFC(m, Box(point3d(x - 1.5f, y - 1.5f, 0.4f), point3d(x + 1.5f, y + 1.5f, 3.0f)));
+        }
+        traj_t init(param.M, param.n, param.dt);
+        init.planConstVelTraj(a.current_state.position, a.current_state.velocity);
+        inits.push_back(init);
+    }
+    std::vector<TrajOptimizer::BatchItem> items(N);
+    for (int q = 0; q < N; q++) items[q] = TrajOptimizer::BatchItem{&agents[q], cons[q].get(), &inits[q]};
+    std::vector<TrajOptResult> r0, r1;
+    std::vector<bool> ok0, ok1;
+    opt.solveBatch(items, r0, ok0);
+    const std::vector<double> raw0 = opt.lastRawSolution();
+    lscqp_comm comm = nullptr;
+    if (lscqp_comm_create(0, nullptr, &comm) != LSCQP_OK) {
+        printf("{\"scenario\": \"sharded\", \"error\": \"%s\"}\n", lscqp_last_error());
+        return 1;
+    }
+    lscqp_comm_set_min_agents_per_device(comm, 64);
+    TrajOptimizer::setCommunicator(comm);
+    opt.solveBatch(items, r1, ok1);
+    const std::vector<double> raw1 = opt.lastRawSolution();
+    TrajOptimizer::setCommunicator(nullptr);
+    int n_ok = 0;
+    bool same = raw0.size() == raw1.size();
+    for (int q = 0; q < N; q++) n_ok += (ok0[q] && ok1[q]) ? 1 : 0;
+    for (size_t i = 0; same && i < raw0.size(); i++) same = raw0[i] == raw1[i];
+    printf("{\"scenario\": \"sharded\", \"devices\": %d, \"devices_used\": %d, \"devices_for_300\": %d, \"backend\": \"%s\", \"n\": %d, "
+           "\"ok\": %d, \"bit_identical\": %s}\n",
+           lscqp_comm_size(comm), opt.lastDevicesUsed(), lscqp_comm_devices_for(comm, N), lscqp_comm_backend(comm), N, n_ok,
+           same ? "true" : "false");
+    lscqp_comm_destroy(comm);
+    return 0;
+}
+
+// An obstacle in the dynamic-obstacle set has a free slack on its rows in the reference (src/traj_optimizer.cpp:272-283,
+// 423-425, no cost term): the QP is the one without those rows.
+static int scenario_dynamic_obstacle() {
+    Param param;
+    Mission mission;
+    mission.world_min = point3d(-5, -5, 0);
+    mission.world_max = point3d(5, 5, 2.5);
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    TrajOptimizer opt(param, mission, B);
+    Agent a = make_agent(point3d(0, 0, 1), point3d(0.5f, 0.1f, 1), point3d(0.5f, 0.1f, 1));
+    const point3d obs0(0.45f, 0.05f, 1.0f), obs1(-0.2f, 0.5f, 1.2f);
+    auto fill = [&](CollisionConstraints& c, bool with0) {
+        c.initializeLSC(with0 ? 2 : 1);
+        for (int m = 0; m < param.M; m++) {
+            int oi = 0;
+            if (with0) c.setLSC(oi++, m, obs0, (a.current_state.position - obs0).normalized(), 0.35);
+            c.setLSC(oi, m, obs1, (a.current_state.position - obs1).normalized(), 0.31);
+            c.setSFC(m, Box(point3d(-0.55f, -0.65f, 0.45f), point3d(0.95f, 0.75f, 1.65f)));
+        }
+    };
+    CollisionConstraints hard(param, mission), slack(param, mission), without(param, mission);
+    fill(hard, true);
+    fill(slack, true);
+    slack.markDynamicObstacle(0);
+    fill(without, false);
+    traj_t init(param.M, param.n, param.dt);
+    init.planConstVelTraj(a.current_state.position, a.current_state.velocity);
+    const double c_hard = opt.solve(a, hard, init, true).total_qp_cost;
+    const double c_slack = opt.solve(a, slack, init, true).total_qp_cost;
+    const double c_without = opt.solve(a, without, init, true).total_qp_cost;
+    printf("{\"scenario\": \"dynamic_obstacle\", \"hard\": %.15g, \"slack\": %.15g, \"without\": %.15g}\n", c_hard, c_slack, c_without);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string s = argc > 1 ? argv[1] : "host";
     if (s == "host") return scenario_host();
@@ -322,6 +416,8 @@ int main(int argc, char** argv) {
     if (s == "pair") return scenario_pair();
     if (s == "infeasible") return scenario_infeasible();
     if (s == "goal") return scenario_goal();
+    if (s == "sharded") return scenario_sharded();
+    if (s == "dynamic_obstacle") return scenario_dynamic_obstacle();
     if (s == "csv" && argc > 2) return scenario_csv(argv[2]);
     if (s == "sfc" && argc > 2) return scenario_sfc(argv[2]);
     fprintf(stderr, "usage: shim_test host|kat|pair|infeasible|goal\n");

@@ -22,7 +22,8 @@ def shim_exe(api):
 def run(exe, scenario):
     out = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    return [json.loads(l) for l in out.stdout.strip().splitlines()]
+    # (RCCL prints a version banner on stdout when a communicator is initialised: only the JSON lines are the driver's)
+    return [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")]
 
 
 def test_host_logic(shim_exe):
@@ -157,3 +158,23 @@ def test_corridors_through_the_shim_match_oracle(shim_exe, oracle, tmp_path):
     mp.construct_sfc(oracle.SFC_FROM_POINT, pts(f32(2.7, 2.4, 0.6), f32(-3.0, -2.5, 0.6), f32(-3.0, -2.5, 0.6)), 0.15, sfc)
     same("sfc_point")
     assert res["sfc_invalid"]["threw"] is True  # std::invalid_argument("Invalid initial SFC"), :377-379
+
+
+@pytest.mark.gpu
+def test_solve_batch_over_a_communicator(shim_exe):
+    """TrajOptimizer::solveBatch with a communicator over every visible device (lscqp_solve_batch_sharded through the C++ class
+    surface; one device on the test box): same results as without, bit for bit; RCCL initialised by the C++ host itself."""
+    r = run(shim_exe, "sharded")[0]
+    assert r["n"] == 300 and r["ok"] == 300 and r["bit_identical"]
+    assert r["devices"] >= 1 and r["devices_used"] == min(r["devices"], 300 // 64) == r["devices_for_300"]
+    assert "rccl" in r["backend"]
+
+
+@pytest.mark.gpu
+def test_dynamic_obstacle_rows_have_a_free_slack(shim_exe):
+    """Reference src/traj_optimizer.cpp:272-283, 423-425: the rows of an obstacle in the dynamic-obstacle set carry a slack in
+    (-inf, 0] with no cost, i.e. they never bind: the optimum is the one of the QP without that obstacle, and differs from the
+    hard-row optimum when the obstacle's rows are active."""
+    r = run(shim_exe, "dynamic_obstacle")[0]
+    assert abs(r["slack"] - r["without"]) <= 1e-9 * max(1.0, abs(r["without"]))
+    assert r["hard"] > r["without"] + 1e-6
