@@ -48,16 +48,166 @@ def to_dev(torch, a, dev):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
 
+# BASELINE.json configs at their own shapes (SURVEY.md section 8 size table).  "c1" is the headline (the metric is quoted on it);
+# the others are measured on one GPU in the `configs` section of the JSON line and can be made the timed workload with
+# --config (that is how tools/profile_round.py traces each kernel instance on its own).
+CONFIGS = {
+    "c0": dict(agents=10, segments=10, obs=9, dim=2, style="forest", precision="f64", rows="f64",
+               what="configs[0] forest10 replica: 10 agents x M=10, dim 2 (the reference's own launch shape; CPLEX there)"),
+    "c1": dict(agents=64, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
+               what="configs[1]: 64 agents x M=5 x ~20 LSC half-spaces/seg, fp64"),
+    "c2": dict(agents=512, segments=6, obs=20, dim=3, style="maze", precision="f64", rows="f64",
+               what="configs[2]: 512 agents dense-maze LSC set, M=6, fp64 (whole batch on one GPU)"),
+    "c3s": dict(agents=128, segments=10, obs=40, dim=3, style="forest", precision="f64", rows="f64",
+                what="configs[3], the per-GPU shard of 8: 128 agents x M=10 x 40 LSC + SFC, fp64 (nz = 84)"),
+    "c3": dict(agents=1024, segments=10, obs=40, dim=3, style="forest", precision="f64", rows="f64",
+               what="configs[3] whole: 1024 agents x M=10 x 40 LSC + SFC, fp64, on ONE GPU"),
+    "c4": dict(agents=4096, segments=5, obs=20, dim=3, style="forest", precision="mixed", rows="f32",
+               what="configs[4]: 4096 agents x M=5, fp32 PDIP (float32 factorisation, 16-byte rows) with fp64 residual check"),
+    "c4_f64": dict(agents=4096, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
+                   what="configs[4] shape in fp64 (32-byte rows): the comparison the mixed-precision instance is judged against"),
+}
+
+
+def percentile_latency(torch, call, max_calls=1050, max_seconds=6.0, skip=50):
+    """p50 / p99 of enqueue -> results readable over up to `max_calls` calls (SURVEY.md 8d asks for >= 1000), cut at a time budget."""
+    lat = []
+    t_end = time.perf_counter() + max_seconds
+    for i in range(max_calls):
+        a = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - a)
+        if time.perf_counter() > t_end and i >= skip + 200:
+            break
+    lat = np.array(lat[skip:]) * 1e3
+    return float(np.percentile(lat, 50)), float(np.percentile(lat, 99)), int(len(lat))
+
+
+def oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample, budget_s=2.5):
+    """The CPU oracle (a port: CPLEX cannot exist here) on a bounded sample of the batch: QP/s with the best thread count."""
+    N = len(build["p0"])
+    sel = np.arange(min(sample, N))
+    cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    ag = np.zeros(len(sel), O.AGENT_DTYPE)
+    for f in ("p0", "v0", "a0", "goal", "next_waypoint"):
+        ag[f] = build[f][sel]
+    ag["vmax"], ag["amax"], ag["radius"], ag["nominal_velocity"], ag["n_obs"] = 1.0, 2.0, 0.15, 1.0, n_obs_eff
+    lsc = np.ascontiguousarray(build["lsc"][sel]).reshape(-1)
+    loff = np.arange(len(sel)) * n_obs_eff * M * 6
+    sfc_o = np.ascontiguousarray(build["sfc"][sel]).reshape(-1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best = None
+    for th in sorted({1, 8, 32, min(64, avail), min(len(sel), avail)}):
+        if th > avail:
+            continue
+        a = time.perf_counter()
+        R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=th)
+        dtm = time.perf_counter() - a
+        if best is None or dtm < best[1]:
+            best = (th, dtm, R)
+        if dtm > budget_s:
+            break
+    cores, _, R = best
+    reps, tcpu = 0, 0.0
+    a = time.perf_counter()
+    while tcpu < budget_s and reps < 200:
+        R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)
+        reps += 1
+        tcpu = time.perf_counter() - a
+    return dict(value=len(sel) * reps / tcpu, unit="QP/s", cores=cores, kind="port", visible_cpus=avail,
+                sample="first %d QPs of the batch x %d repetitions, oracle/lscqp_oracle.c (dense fp64 PDIP, OpenMP over agents), %.1f s" % (
+                    len(sel), reps, tcpu)), R, sel
+
+
+def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_seconds=4.0):
+    """One BASELINE config at its own shape on this GPU: kernel time (HIP events), QP/s, latency percentiles, HBM fraction,
+    iterations, oracle parity + CPU baseline on a bounded sample."""
+    N, M, dim, n_obs = cfg["agents"], cfg["segments"], cfg["dim"], cfg["obs"]
+
+    def factory(sw, **kw):
+        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **kw))
+
+    sw, sol64, b, (hdr, rows, off, sfc) = make_batch(api, synth, factory, N, M, dim, n_obs, seed=3000 + N + M, style=cfg["style"], warm_steps=3)
+    kw = {}
+    if cfg["precision"] == "mixed":
+        kw["precision"] = api.PRECISION_MIXED
+    if cfg["rows"] == "f32":
+        kw["row_format"] = api.ROWS_F32
+    sol = factory(sw, **kw) if kw else sol64
+    nv = sol.nv
+    dh, do, ds = (to_dev(torch, a, dev) for a in (hdr, off, sfc))
+    dr = to_dev(torch, sol.rows_in_format(rows), dev)
+    dxi = torch.from_numpy(api.x_init_from_swarm(b, dim)).to(dev)
+    dx = torch.zeros(N * nv, dtype=torch.float64, device=dev)
+    dob = torch.zeros(N, dtype=torch.float64, device=dev)
+    dst = torch.zeros(N, dtype=torch.int32, device=dev)
+    dinfo = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
+
+    def call():
+        sol.solve_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi)
+
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    # >= 1000 calls where that fits a bounded time (the slowest config, 1024 x M=10, needs ~10 s for them)
+    p50, p99, nlat = percentile_latency(torch, call, max_seconds=min(14.0, max(lat_seconds, 1.15e-3 * ms * 1100)))
+    info = dinfo.cpu().numpy().view(api.INFO_DTYPE)
+    st = dst.cpu().numpy()
+    bq = sol.algorithmic_bytes(sw.n_obs)
+    out = {"config": key, "what": cfg["what"], "agents": N, "segments": M, "dim": dim, "lsc_neighbours": sw.n_obs, "style": cfg["style"],
+           "precision": cfg["precision"], "rows": cfg["rows"], "rows_per_qp": sol.num_inequalities(sw.n_obs),
+           "kernel_ms": ms, "qp_per_s": N / (ms * 1e-3), "latency_ms": {"p50": p50, "p99": p99, "calls": nlat},
+           "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
+           "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()),
+           "non_optimal": int((st != 0).sum()), "second_pass": int(((info["flags"] & api.INFO_REPAIRED) != 0).sum()),
+           "floor_accepted": int(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum())}
+    if O is not None:
+        # (rows rounded to float32 are a different problem instance than the oracle's fp64 rows: parity is taken on fp64 rows)
+        cpu, R, sel = oracle_baseline(O, sw, b, M, dim, sw.n_obs, sample=64 if M < 10 else 32)
+        out["cpu_baseline"] = cpu
+        if cfg["rows"] == "f64":
+            xg, og = dx.cpu().numpy().reshape(N, nv)[sel], dob.cpu().numpy()[sel]
+            ok = (R["status"] == 0) & (st[sel] == 0)
+            if ok.any():
+                out["parity_vs_oracle"] = {"max_abs_dx": float(np.abs(xg - R["x"])[ok].max()), "compared": int(ok.sum()),
+                                           "max_rel_dobj": float((np.abs(og - R["obj"]) / np.maximum(1.0, np.abs(R["obj"])))[ok].max())}
+    return out
+
+
+def newest_profile(pattern):
+    """profiles/<tag>_... with the highest (round, version) tag, numerically: r02_v11 > r02_v9 > r01_v11."""
+    import glob
+    import re
+
+    def tagkey(path):
+        m = re.match(r"r(\d+)_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    fs = sorted(glob.glob(os.path.join(HERE, "profiles", pattern)), key=tagkey)
+    return fs[-1] if fs else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--agents", type=int, default=64, help="agents per GPU per step (BASELINE configs[1]: 64)")
-    ap.add_argument("--segments", type=int, default=5)
-    ap.add_argument("--obs", type=int, default=20)
-    ap.add_argument("--dim", type=int, default=3)
-    ap.add_argument("--style", default="forest")
+    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS), help="BASELINE config that is the timed workload (default c1 = the headline)")
+    ap.add_argument("--agents", type=int, default=None, help="agents per GPU per step (overrides the config's)")
+    ap.add_argument("--segments", type=int, default=None)
+    ap.add_argument("--obs", type=int, default=None)
+    ap.add_argument("--dim", type=int, default=None)
+    ap.add_argument("--style", default=None)
+    ap.add_argument("--precision", default=None, choices=["f64", "mixed"])
+    ap.add_argument("--rows", default=None, choices=["f64", "f32"])
     ap.add_argument("--allgather", action="store_true", help="all-gather solved trajectories over RCCL every step")
     ap.add_argument("--pipeline", action="store_true",
                     help="step = all-gather of the plans (N > 1) -> LSC generation on the device -> QP solve (SURVEY 8f-1); "
@@ -71,6 +221,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the latency loops (their launches would mix into a kernel trace of the timed steps)")
     args = ap.parse_args()
+    cfg0 = CONFIGS[args.config]
+    for k in ("agents", "segments", "obs", "dim", "style", "precision", "rows"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg0[k])
 
     import torch
 
@@ -86,6 +240,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    coll_backend = "none (single process)"
     if world > 1:
         import torch.distributed as dist
 
@@ -105,21 +260,32 @@ def main():
                     pass
                 os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+                coll_backend = "gloo (RCCL probe failed)"
+            else:
+                coll_backend = "rccl via torch.distributed nccl backend, %d ranks" % dist.get_world_size()
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            coll_backend = "%s (LSCQP_BENCH_BACKEND), %d ranks" % (backend, dist.get_world_size())
 
     from lsc_dr_planner_amd import api, synth
 
     M, dim, n_obs, N = args.segments, args.dim, args.obs, args.agents
 
+    solver_kw = {}
+    if args.precision == "mixed":
+        solver_kw["precision"] = api.PRECISION_MIXED
+    if args.rows == "f32":
+        solver_kw["row_format"] = api.ROWS_F32
+
     def solver_factory(sw):
-        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **solver_kw))
 
     sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed=1000 + rank,
                                                        style=args.style, warm_steps=3)
     n_obs_eff = sw.n_obs
     nv = sol.nv
-    d_hdr, d_rows, d_off, d_sfc = (to_dev(torch, a, dev) for a in (hdr, rows, off, sfc))
+    d_hdr, d_off, d_sfc = (to_dev(torch, a, dev) for a in (hdr, off, sfc))
+    d_rows = to_dev(torch, sol.rows_in_format(rows), dev)
     # TrajOptimizer::solve's initial_traj (the shifted previous plan): the solver's primal start
     d_xinit = None if args.cold_start else torch.from_numpy(api.x_init_from_swarm(build, dim)).to(dev)
     d_x = torch.zeros(N * nv, dtype=torch.float64, device=dev)
@@ -249,18 +415,18 @@ def main():
     bytes_per_qp = sol.algorithmic_bytes(n_obs_eff)
     achieved = bytes_per_qp * N / (kernel_ms * 1e-3)
     # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the value comes from the
-    # committed rocprofv3 --pmc passes of THIS command (profiles/*_pmc_traffic.json, tools/profile_round.py) and is only reported when the
-    # kernel instance and batch size match; otherwise null.
+    # committed rocprofv3 --pmc passes of THIS command (profiles/<tag>_<config>_pmc.json of the newest tag, numerically
+    # sorted; tools/profile_round.py) and is only reported when kernel shape, precision and batch size match; otherwise null.
     traffic, traffic_src, valu = None, None, None
     try:
-        import glob
-
-        pf = sorted(glob.glob(os.path.join(HERE, "profiles", "*_pmc_traffic.json")))[-1]  # newest tag of the round
-        pm = json.load(open(pf))
+        pf = newest_profile("*_%s_pmc.json" % args.config)
+        pm = json.load(open(pf)) if pf else {}
         kname = (pm.get("kernel") or "").replace(" ", "")
-        if pm.get("qps_per_launch") == N and ("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) in kname and n_obs_eff == 20:
+        want_t = "float" if args.precision == "mixed" else "double"
+        if (pm.get("qps_per_launch") == N and ("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) in kname and want_t in kname
+                and pm.get("lsc_neighbours") == n_obs_eff):
             traffic = pm["traffic_bytes_per_launch"]
-            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)" % os.path.basename(pf)
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)" % os.path.basename(pf)
             sq = pm.get("sq") or {}
             if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAVES"):
                 # the limit this kernel actually runs into (SURVEY.md 8d asks for it next to the HBM figure): the share of a
@@ -268,7 +434,8 @@ def main():
                 valu = {"valu_active_frac_of_wave_lifetime": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
                         "valu_instructions_per_wavefront": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"],
                         "lds_instructions_per_wavefront": sq["SQ_INSTS_LDS"] / sq["SQ_WAVES"],
-                        "wavefronts_per_launch": sq["SQ_WAVES"], "source": "profiles/%s (rocprofv3 --pmc SQ_*)" % os.path.basename(pf)}
+                        "wavefronts_per_launch": sq["SQ_WAVES"], "dispatch": pm.get("dispatch"),
+                        "source": "profiles/%s (rocprofv3 --pmc SQ_*)" % os.path.basename(pf)}
     except Exception:
         pass
     out = {
@@ -282,11 +449,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f64" if args.precision == "f64" else "f64 iterate and residuals, f32 factorisation",
         "data": "synthetic",
         "config": {
-            "workload": "%d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
-                        "fp64 batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (N, M, n_obs_eff, dim, args.style),
+            "workload": "%s -- %d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
+                        "%s batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (
+                            cfg0["what"] if (N, M, n_obs, dim) == (cfg0["agents"], cfg0["segments"], cfg0["obs"], cfg0["dim"]) else "custom shape",
+                            N, M, n_obs_eff, dim, args.style, "fp64" if args.precision == "f64" else "mixed-precision"),
+            "baseline_config": args.config, "precision": args.precision, "row_format": args.rows, "collective_backend": coll_backend,
             "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
             "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline), "hip_graph": bool(args.graph),
             "warm_start": "initial_traj (shifted previous plan) as primal start" if d_xinit is not None else "none",
@@ -296,7 +466,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W>" % (M, dim), "kernel_ms": kernel_ms,
+            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (M, dim, "float" if args.precision == "mixed" else "double"), "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N, "valu": valu,
         },
         "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
@@ -361,53 +531,24 @@ def main():
             "compared": int(ok.sum()),
         }
 
-    # ---- informational: throughput vs batch size on this GPU (not the headline) -------------------------------
+    # ---- every BASELINE config at its own shape, on this GPU (the headline above stays configs[1]) ---------------------
     if world == 1 and not args.no_extra:
-        extra = []
-        for nb in (512, 4096):
+        O = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O  # the checker / CPU baseline, never the thing measured
+        sweep = []
+        for key in ("c0", "c2", "c3s", "c3", "c4_f64", "c4"):
             try:
-                sw2, sol2, b2, (h2, r2, o2, s2) = make_batch(api, synth, solver_factory, nb, M, dim, n_obs, seed=2000 + nb,
-                                                             style=args.style, warm_steps=3)
-                dh, dr, do, ds = (to_dev(torch, a, dev) for a in (h2, r2, o2, s2))
-                dxi = None if args.cold_start else torch.from_numpy(api.x_init_from_swarm(b2, dim)).to(dev)
-                dx = torch.zeros(nb * nv, dtype=torch.float64, device=dev)
-                dob = torch.zeros(nb, dtype=torch.float64, device=dev)
-                dst = torch.zeros(nb, dtype=torch.int32, device=dev)
-                for _ in range(3):
-                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None, d_x_init=dxi)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                reps = 20
-                for _ in range(reps):
-                    sol2.solve_device(nb, sw2.n_obs, dh, dr, do, ds, dx, dob, dst, None, d_x_init=dxi)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / reps
-                bq = sol2.algorithmic_bytes(sw2.n_obs)
-                extra.append({"agents": nb, "kernel_ms": ms, "qp_per_s": nb / (ms * 1e-3),
-                              "hbm_frac": bq * nb / (ms * 1e-3) / HBM_PEAK, "non_optimal": int((dst.cpu().numpy() != 0).sum())})
-                if nb == 4096:
-                    # BASELINE configs[4] (4096 agents x 5 segments, 16-byte rows): the same batch with the rows stored as
-                    # float32 (LSCQP_ROWS_F32: half the bytes; the arithmetic and the result format stay fp64)
-                    sol3 = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw2.world_min, world_max=sw2.world_max, row_format=api.ROWS_F32))
-                    dr3 = to_dev(torch, sol3.rows_in_format(r2), dev)
-                    for _ in range(3):
-                        sol3.solve_device(nb, sw2.n_obs, dh, dr3, do, ds, dx, dob, dst, None, d_x_init=dxi)
-                    torch.cuda.synchronize()
-                    e0.record()
-                    for _ in range(reps):
-                        sol3.solve_device(nb, sw2.n_obs, dh, dr3, do, ds, dx, dob, dst, None, d_x_init=dxi)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms3 = e0.elapsed_time(e1) / reps
-                    bq3 = sol3.algorithmic_bytes(sw2.n_obs)
-                    extra.append({"agents": nb, "rows": "f32 (16 B)", "algorithmic_bytes_per_qp": bq3, "kernel_ms": ms3,
-                                  "qp_per_s": nb / (ms3 * 1e-3), "hbm_frac": bq3 * nb / (ms3 * 1e-3) / HBM_PEAK,
-                                  "non_optimal": int((dst.cpu().numpy() != 0).sum())})
-            except Exception as ex:  # informational only
-                extra.append({"agents": nb, "error": str(ex)[:200]})
-        out["extra_batch_sweep"] = extra
+                sweep.append(measure_config(torch, api, synth, dev, key, CONFIGS[key], O=O,
+                                            lat_seconds=1.5 if args.no_latency else 4.0))
+            except Exception as ex:  # one failing shape must not take the headline line with it
+                sweep.append({"config": key, "error": "%s: %s" % (type(ex).__name__, str(ex)[:300])})
+        out["configs"] = sweep
+        by = {c.get("config"): c for c in sweep}
+        if "kernel_ms" in by.get("c4", {}) and "kernel_ms" in by.get("c4_f64", {}):
+            out["mixed_vs_fp64_at_4096"] = {"fp64_qp_per_s": by["c4_f64"]["qp_per_s"], "mixed_qp_per_s": by["c4"]["qp_per_s"],
+                                            "ratio": by["c4"]["qp_per_s"] / by["c4_f64"]["qp_per_s"],
+                                            "iters_fp64": by["c4_f64"]["iters_mean"], "iters_mixed": by["c4"]["iters_mean"]}
 
     print(json.dumps(out))
     if dist is not None:

@@ -1,14 +1,15 @@
 """Collect the profile artefacts of one round ON THE GPU BOX and write them under gpurun_out/profiles_<tag>/.
 
-    python tools/profile_round.py r01_v3
+    python tools/profile_round.py r02_v1 [c1 c4_f64 c4 c3s ...]      (default: every BASELINE config of bench.py)
 
-Runs, each as its own process / rocprofv3 pass (counters never share a run with the trace, see the task's rocprofv3 rule):
-  1. python bench.py                                              -> <tag>_bench.json
-  2. rocprofv3 --kernel-trace --stats -- python bench.py (short)  -> <tag>_kernel_stats.csv + bench line under rocprof
-  3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (3 passes)    -> <tag>_pmc_traffic.json
+Per config (bench.py --config <c>: that config is then the timed workload, nothing else launches the QP kernel):
+  1. rocprofv3 --kernel-trace --stats -- python bench.py --config <c> ...   -> <tag>_<c>_kernel_stats.csv (+ the bench line)
+  2. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes, never together with a trace)
+                                                                             -> <tag>_<c>_pmc.json
+and once: the plain `python bench.py` line (-> <tag>_bench.json) and the kernels either side of the QP.
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are KB and need
-separate passes; contiguous 16 B/lane streaming reads are tallied at half their size on gfx950 (x2), other patterns are
-to be calibrated on a known byte count -- done below against the kernel's exactly known input volume.
+separate passes; contiguous 16 B/lane streaming reads are tallied at half their size on gfx950 (x2), other patterns are to be
+calibrated on a known byte count -- done below against the kernel's exactly known input volume.
 """
 import csv
 import glob
@@ -18,138 +19,132 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+which = sys.argv[2:] or ["c1", "c4_f64", "c4", "c3s", "c3", "c2", "c0"]
 OUT = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
 os.makedirs(OUT, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-BENCH_SHORT = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-extra",
-               "--no-latency"]  # the default step counts; no side loops, so the trace averages the timed 64-QP launches
+STEPS = {"c1": 200, "c0": 200, "c2": 100, "c3s": 60, "c3": 20, "c4": 60, "c4_f64": 60}
+
+
+def bench_cmd(c):
+    return [sys.executable, os.path.join(ROOT, "bench.py"), "--config", c, "--steps", str(STEPS.get(c, 50)), "--warmup", "10",
+            "--no-cpu-baseline", "--no-extra", "--no-latency"]  # no side loops: the trace averages the timed launches alone
 
 
 def run(cmd, log):
-    if os.environ.get("REPARSE") == "1":  # only re-read the files of an earlier run
-        return 0
     with open(os.path.join(OUT, log), "w") as f:
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT)
-    return r.returncode
+        return subprocess.run(cmd, cwd="/tmp", env=env, stdout=f, stderr=subprocess.STDOUT).returncode
 
 
 def last_json(path):
     for line in reversed(open(path).read().splitlines()):
         line = line.strip()
         if line.startswith("{"):
-            return json.loads(line)
+            try:
+                return json.loads(line)
+            except Exception:
+                pass
     return None
 
 
-# 1. plain bench
-run([sys.executable, os.path.join(ROOT, "bench.py")], tag + "_bench.log")
-b = last_json(os.path.join(OUT, tag + "_bench.log"))
-json.dump(b, open(os.path.join(OUT, tag + "_bench.json"), "w"))
+def profile_config(c):
+    from bench import CONFIGS
 
-# 2. kernel trace
-d = os.path.join(OUT, "trace")
-run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + BENCH_SHORT, tag + "_trace.log")
-bj = last_json(os.path.join(OUT, tag + "_trace.log"))
-json.dump(bj, open(os.path.join(OUT, tag + "_bench_under_rocprof.json"), "w"))
-for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
-    rows = list(csv.reader(open(f)))
-    with open(os.path.join(OUT, tag + "_kernel_stats.csv"), "w", newline="") as g:
-        csv.writer(g, quoting=csv.QUOTE_ALL).writerows(rows[:6])
-
-
-# 3. counters
-def pmc(counters, name):
-    dd = os.path.join(OUT, "pmc_" + name)
-    run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", dd, "--"] + BENCH_SHORT, tag + "_pmc_" + name + ".log")
-    acc, disp = {}, {}
-    for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):
+    N = CONFIGS[c]["agents"]
+    res = {"config": c, "what": CONFIGS[c]["what"], "command": " ".join(["python", "bench.py"] + bench_cmd(c)[2:])}
+    # 1. kernel trace
+    d = os.path.join(OUT, "trace_" + c)
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench_cmd(c), "%s_%s_trace.log" % (tag, c))
+    bj = last_json(os.path.join(OUT, "%s_%s_trace.log" % (tag, c)))
+    res["bench_under_rocprof"] = bj and {k: bj[k] for k in ("value", "ms_per_step", "roofline", "solver", "config")}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(f)))
+        keep = [rows[0]] + [r for r in rows[1:] if "lscqp_pdip_kernel" in r[0]]
+        with open(os.path.join(OUT, "%s_%s_kernel_stats.csv" % (tag, c)), "w", newline="") as g:
+            csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
+        res["kernel_stats"] = [dict(zip(rows[0], r)) for r in keep[1:]]
+    # (the launches of the warm-up replans through the host entry have the same grid: the stats above average them in too; the
+    # per-dispatch trace gives the timed launches alone: the LAST steps+warmup dispatches of each kernel)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        per = {}
         for r in csv.DictReader(open(f)):
-            if "lscqp_pdip_kernel" not in r["Kernel_Name"]:
-                continue
-            # only the timed workload: 64 workgroups (one per QP; 64 or 128 threads each, by the launch policy); other
-            # launches belong to the parity / latency legs
-            if int(r["Grid_Size"]) != 64 * int(r["Workgroup_Size"]):
-                continue
-            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-            disp = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Kernel_Name") if k in r}
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}, disp
+            if "lscqp_pdip_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) == N * int(r["Workgroup_Size"]):
+                per.setdefault(r["Kernel_Name"], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        res["timed_launches"] = {}
+        for k, v in per.items():
+            v.sort()
+            last = [dur for _, dur in v[-STEPS.get(c, 50):]]
+            res["timed_launches"][k] = {"launches": len(last), "avg_ns": sum(last) / len(last), "min_ns": min(last), "max_ns": max(last)}
 
+    # 2. counters, one pass each
+    def pmc(counters, name):
+        dd = os.path.join(OUT, "pmc_%s_%s" % (c, name))
+        run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", dd, "--"] + bench_cmd(c), "%s_%s_pmc_%s.log" % (tag, c, name))
+        acc, disp = {}, {}
+        for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "lscqp_pdip_kernel" not in r["Kernel_Name"] or int(r["Grid_Size"]) != N * int(r["Workgroup_Size"]):
+                    continue
+                kn = r["Kernel_Name"]
+                acc.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                disp[kn] = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size") if k in r}
+        return {kn: {k: sum(v) / len(v) for k, v in cs.items()} for kn, cs in acc.items()}, disp
 
-fetch, nf, disp = pmc(["FETCH_SIZE"], "fetch")
-write, nw, _ = pmc(["WRITE_SIZE"], "write")
-sq, ns, _ = pmc(["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU",
+    fetch, disp = pmc(["FETCH_SIZE"], "fetch")
+    write, _ = pmc(["WRITE_SIZE"], "write")
+    sq, _ = pmc(["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU",
                  "SQ_WAIT_INST_ANY"], "sq")
-res = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (three separate passes) -- python bench.py --steps 200 "
-              "--warmup 20 --no-cpu-baseline --no-extra --no-latency; dispatches of the PDIP kernel with 64 workgroups (= the 64-QP batch) only",
-    "kernel": disp.get("Kernel_Name"),
-    "qps_per_launch": 64,
-    "launches_averaged": nf.get("FETCH_SIZE"),
-    "FETCH_SIZE_KB_raw": fetch.get("FETCH_SIZE"),
-    "WRITE_SIZE_KB_raw": write.get("WRITE_SIZE"),
-    "correction": "MI355X_MICROARCH.md (HBM): both counters are KB; FETCH_SIZE is doubled for contiguous 16 B/lane streaming reads "
-                  "and must be calibrated on a known byte count for other patterns (see fetch_calibration); WRITE_SIZE taken as is",
-    "sq": sq,
-    "dispatch": disp,
-}
-if b:
-    res["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_qp"] * 64
-if fetch.get("FETCH_SIZE") is not None and write.get("WRITE_SIZE") is not None:
-    # The guide's x2 is for contiguous 16 B/lane streaming reads and asks to calibrate other patterns on a known byte
-    # count.  This kernel's reads are known exactly: every input byte (rows 32 B/lane at 32 B lane stride, headers,
-    # boxes, offsets) is read once, = algorithmic bytes minus the outputs.  If the raw counter already equals that
-    # volume the factor is 1, otherwise the guide's 2 is applied.
-    out_bytes = 64 * (8 * 90 + 16)
-    in_bytes = res.get("algorithmic_bytes_per_launch", 0) - out_bytes
-    raw = 1024.0 * fetch["FETCH_SIZE"]
-    cal = 1.0 if in_bytes and abs(raw - in_bytes) <= 0.1 * in_bytes else 2.0
-    res["fetch_calibration"] = {"factor": cal, "known_input_bytes": in_bytes, "raw_fetch_bytes": raw,
-                                "note": "factor 1: raw FETCH_SIZE already equals the input volume that is read exactly once; "
-                                        "with the guide's streaming-read factor 2 it would be %.0f bytes" % (2 * raw)}
-    res["traffic_bytes_per_launch"] = cal * raw + 1024.0 * write["WRITE_SIZE"]
-json.dump(res, open(os.path.join(OUT, tag + "_pmc_traffic.json"), "w"), indent=1)
-
-# 4. the LSC-generation kernel at 4096 agents: trace + traffic, same rules
-GEN = [sys.executable, os.path.join(ROOT, "tools", "bench_lscgen.py"), "4096"]
-dg = os.path.join(OUT, "trace_lscgen")
-run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", dg, "--"] + GEN, tag + "_lscgen_trace.log")
-gen = {"bench": last_json(os.path.join(OUT, tag + "_lscgen_trace.log"))}
-for f in glob.glob(os.path.join(dg, "**", "*kernel_stats.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "generate_lsc_kernel" in r["Name"]:
-            gen["kernel_stats"] = {k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")}
+    kernels = sorted(disp)  # mixed precision: the float instance and the fp64 second pass
+    main = next((k for k in kernels if "float" in k), kernels[0] if kernels else None)
+    res.update({"kernels": kernels, "kernel": main, "qps_per_launch": N, "lsc_neighbours": bj and bj["config"]["lsc_neighbours"],
+                "dispatch": disp.get(main), "dispatch_all": disp, "sq": sq.get(main), "sq_all": sq,
+                "FETCH_SIZE_KB_raw": {k: v.get("FETCH_SIZE") for k, v in fetch.items()},
+                "WRITE_SIZE_KB_raw": {k: v.get("WRITE_SIZE") for k, v in write.items()},
+                "correction": "MI355X_MICROARCH.md (HBM): both counters are KB; FETCH_SIZE is doubled for contiguous 16 B/lane streaming "
+                              "reads and must be calibrated on a known byte count for other patterns (fetch_calibration); WRITE_SIZE as is"})
+    if bj:
+        alg = bj["roofline"]["algorithmic_bytes_per_qp"] * N
+        res["algorithmic_bytes_per_launch"] = alg
+        raw_f = 1024.0 * sum(v.get("FETCH_SIZE", 0.0) for v in fetch.values())
+        raw_w = 1024.0 * sum(v.get("WRITE_SIZE", 0.0) for v in write.values())
+        nv = bj["config"]["dim"] * bj["config"]["segments"] * 6
+        in_bytes = alg - N * (8 * nv + 16)
+        # every input byte is read exactly once (rows at 32 or 16 B/lane stride, headers, boxes, offsets, initial trajectories):
+        # if the raw counter already equals that volume the factor is 1, otherwise the guide's 2
+        cal = 1.0 if in_bytes and abs(raw_f - in_bytes) <= 0.15 * in_bytes else 2.0
+        res["fetch_calibration"] = {"factor": cal, "known_input_bytes": in_bytes, "raw_fetch_bytes": raw_f}
+        res["traffic_bytes_per_launch"] = cal * raw_f + raw_w
+        if main in res.get("timed_launches", {}):
+            t = sum(v["avg_ns"] for v in res["timed_launches"].values()) * 1e-9
+            res["roofline_from_trace"] = {"step_time_s": t, "achieved_GBps": alg / t / 1e9, "frac_of_8TBps": alg / t / 8.0e12}
+    json.dump(res, open(os.path.join(OUT, "%s_%s_pmc.json" % (tag, c)), "w"), indent=1)
+    return res
 
 
-def pmc_gen(counter):
-    dd = os.path.join(OUT, "pmc_lscgen_" + counter)
-    run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", dd, "--"] + GEN, tag + "_lscgen_pmc_" + counter + ".log")
-    vals = []
-    for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "generate_lsc_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                vals.append(float(r["Counter_Value"]))
-    return sum(vals) / len(vals) if vals else None
-
-
-gf, gw = pmc_gen("FETCH_SIZE"), pmc_gen("WRITE_SIZE")
-gen["FETCH_SIZE_KB_raw"], gen["WRITE_SIZE_KB_raw"] = gf, gw
-gen["note"] = ("rows written = 409600 units x 192 B = 78.6 MB; inputs (control points of 4096 agents, neighbour ids) 3.4 MB, re-read "
-               "from L2 by the 20 agents that share a neighbour; FETCH_SIZE raw (KB) as reported, x2 if read as contiguous 16 B/lane "
-               "streaming per MI355X_MICROARCH.md; WRITE_SIZE as reported")
-json.dump(gen, open(os.path.join(OUT, tag + "_lscgen.json"), "w"), indent=1)
-# 5. the other kernels either side of the QP (CLSC / BVC generation, safety metrics, voxel map, corridors)
-NEXT = [sys.executable, os.path.join(ROOT, "tools", "bench_next_rows.py"), "4096"]
-dn = os.path.join(OUT, "trace_next_rows")
-run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", dn, "--"] + NEXT, tag + "_next_rows_trace.log")
-lines = [l for l in open(os.path.join(OUT, tag + "_next_rows_trace.log")).read().splitlines() if l.startswith("{")]
-with open(os.path.join(OUT, tag + "_next_rows.jsonl"), "w") as f:
-    f.write("\n".join(lines) + "\n")
-for f in glob.glob(os.path.join(dn, "**", "*kernel_stats.csv"), recursive=True):
-    rows = list(csv.reader(open(f)))
-    keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ("generate_lsc_kernel", "safety_metrics", "construct_sfc", "nearest_",
-                                                                        "rasterise", "select_neighbours", "shift_traj", "goal_kernel", "validate_step"))]
-    with open(os.path.join(OUT, tag + "_next_rows_kernel_stats.csv"), "w", newline="") as g:
-        csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
-
-print(json.dumps({"bench": b and {k: b[k] for k in ("value", "ms_per_step")}, "pmc": {k: res.get(k) for k in ("FETCH_SIZE_KB_raw", "WRITE_SIZE_KB_raw", "traffic_bytes_per_launch")}}))
+summary = {}
+if "nobench" not in os.environ.get("PROFILE_SKIP", ""):
+    run([sys.executable, os.path.join(ROOT, "bench.py")], tag + "_bench.log")
+    b = last_json(os.path.join(OUT, tag + "_bench.log"))
+    json.dump(b, open(os.path.join(OUT, tag + "_bench.json"), "w"))
+    summary["bench"] = b and {k: b[k] for k in ("value", "ms_per_step")}
+for c in which:
+    r = profile_config(c)
+    summary[c] = {"timed": r.get("timed_launches"), "traffic": r.get("traffic_bytes_per_launch"), "alg": r.get("algorithmic_bytes_per_launch"),
+                  "dispatch": r.get("dispatch")}
+if "nonext" not in os.environ.get("PROFILE_SKIP", ""):
+    # the kernels either side of the QP (generation, neighbour selection, safety metrics, voxel map, corridors)
+    NEXT = [sys.executable, os.path.join(ROOT, "tools", "bench_next_rows.py"), "4096"]
+    dn = os.path.join(OUT, "trace_next_rows")
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", dn, "--"] + NEXT, tag + "_next_rows_trace.log")
+    lines = [l for l in open(os.path.join(OUT, tag + "_next_rows_trace.log")).read().splitlines() if l.startswith("{")]
+    with open(os.path.join(OUT, tag + "_next_rows.jsonl"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    for f in glob.glob(os.path.join(dn, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.reader(open(f)))
+        keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ("generate_lsc_kernel", "safety_metrics", "construct_sfc", "nearest_",
+                                                                            "rasterise", "select_neighbours", "shift_traj", "goal_kernel", "validate_step"))]
+        with open(os.path.join(OUT, tag + "_next_rows_kernel_stats.csv"), "w", newline="") as g:
+            csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
+print(json.dumps(summary))
