@@ -36,9 +36,13 @@ def make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed, style, warm_s
     for _ in range(warm_steps):
         b = sw.build()
         hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
-        r = sol.solve_host(hdr, rows, off, sfc, want_info=False)
-        if (r["status"] != 0).any():
+        x0 = api.x_init_from_swarm(b, dim)
+        r = sol.solve_host(hdr, rows, off, sfc, want_info=False, x_init=x0)
+        bad = r["status"] != 0
+        if bad.mean() > 0.02:
             raise RuntimeError("warm-up replan produced non-optimal instances: %s" % np.bincount(r["status"]))
+        # what the planner does with a failed QP: it keeps the initial trajectory (reference src/traj_planner.cpp:767-797)
+        r["x"][bad] = x0[bad]
         sw.advance(r["x"])
     b = sw.build()
     return sw, sol, b, api.batch_from_swarm(b, sw.n_obs, M)

@@ -1409,10 +1409,23 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 __syncthreads();  // the flags sit in the scratch matrix, which the next phase overwrites
 #endif
             }
-            if (pivot_bad) {  // uniform over the QP's lanes
+            // W > 1 with nz <= 64: the system lives in wavefront 0, the other wavefronts factorise an identity matrix, so only
+            // wavefront 0 can see a failed pivot -- and a break taken by one wavefront alone would leave the others iterating
+            // against mismatched barriers until the iteration limit (seen: one QP of a 512-QP dense-maze batch held its launch for
+            // 1.6 ms instead of 0.25 ms).  Wavefront 0 posts its verdict in LDS and every wavefront reads it after the next
+            // barrier the iteration has anyway (behind the predictor solve); a breakdown costs one wasted solve.
+            auto numeric_exit = [&]() {
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 restore = status == LSCQP_STATUS_OPTIMAL;
-                break;
+            };
+            constexpr bool POSTED_PIVOT_FLAG = (W > 1 && NZ <= 64);
+            if constexpr (POSTED_PIVOT_FLAG) {
+                if (lane == 0) red_[3] = pivot_bad ? 1.0 : 0.0;  // (slot 3 of the reduction scratch is never used by the reductions)
+            } else {
+                if (pivot_bad) {  // uniform over the QP's lanes
+                    numeric_exit();
+                    break;
+                }
             }
             // broadcast of lane j's value to all lanes of the QP: v_readlane (W = 1) or an LDS slot + barrier (W = 2; one
             // slot per column and direction, so no slot is rewritten while a slower wavefront may still read it)
@@ -1538,6 +1551,12 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             }
 #endif
             LSCQP_BLOCK_SYNC();
+            if constexpr (POSTED_PIVOT_FLAG) {
+                if (red_[3] != 0.0) {  // uniform over the workgroup
+                    numeric_exit();
+                    break;
+                }
+            }
             expandT(dz_, dca_, false);
             LSCQP_BLOCK_SYNC();
             LSCQP_T(5);

@@ -412,3 +412,53 @@ def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_c
     sol.solve_device(*args)  # and the default start needs no help
     torch.cuda.synchronize()
     assert d_st.item() == 0 and abs(d_obj.item() - o["obj"]) <= OBJ_TOL * max(1.0, abs(o["obj"]))
+
+
+def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(api, oracle, torch_cuda):
+    """tests/golden/pivot_breakdown_w2.json: an M = 6 dense-maze instance whose factorisation breaks down after the acceptance tests
+    were met at the rounding floor.  In the two-wavefront instance only wavefront 0 holds the system and sees the failed pivot;
+    round 1 let it leave the loop alone, the other wavefront ran on against mismatched barriers to the iteration limit (1.6 ms
+    instead of 0.25 ms for the launch, and its share of x_out written from a garbage iterate).  Now the verdict is posted to the
+    whole workgroup: the launch is short, the result is the remembered accepted point and agrees with the oracle."""
+    torch = torch_cuda
+    g = H.load_golden("pivot_breakdown_w2")
+    M, dim, n_obs = g["M"], g["dim"], g["n_obs"]
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=g["world_min"], world_max=g["world_max"]))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=g["world_min"], world_max=g["world_max"])
+    hdr = np.zeros(1, api.HEADER_DTYPE)
+    for f, v in g["hdr"].items():
+        hdr[f][0] = v
+    hdr["n_obs"][0] = n_obs
+    R = np.array(g["rows"])
+    rows = np.zeros(len(R), api.ROW_DTYPE)
+    rows["nx"], rows["ny"], rows["nz"], rows["b"] = R[:, 0], R[:, 1], R[:, 2], R[:, 3]
+    sfc = np.zeros(M, api.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = g["sfc_min"], g["sfc_max"]
+    off = np.array([0, len(R)], dtype=np.uint64)
+    x0 = np.array(g["x_init"])[None]
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_x = torch.zeros(sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_st = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    d_info = torch.zeros(api.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    args = (1, n_obs, up(hdr), up(rows), up(off), up(sfc), d_x, d_obj, d_st)
+    sol.solve_device(*args, d_info=d_info, d_x_init=up(x0))  # a one-QP launch takes the two-wavefront instance
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    sol.solve_device(*args, d_info=d_info, d_x_init=up(x0))
+    e1.record()
+    torch.cuda.synchronize()
+    info = d_info.cpu().numpy().view(api.INFO_DTYPE)[0]
+    assert d_st.item() == 0 and info["iterations"] <= 12
+    assert e0.elapsed_time(e1) < 0.6, "the launch lasted %.2f ms: a wavefront ran on after the breakdown" % e0.elapsed_time(e1)
+    ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
+    lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+    lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)
+    lsc["d"] = R[:, 3].reshape(n_obs, M, 6)
+    o = oracle.solve(cls, ag, lsc, sfc)
+    assert o["status"] == 0
+    assert abs(o["obj"] - d_obj.item()) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - d_x.cpu().numpy()).max() <= 1e-6
+    # accepted by the fallback rule: the point is the remembered one and says so
+    assert (info["flags"] & api.INFO_FLOOR_ACCEPTED) and info["res_primal"] <= 1e-9 and info["res_dual"] <= 1e-6

@@ -70,7 +70,7 @@ def profile_config(c):
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
-            if "lscqp_pdip_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) == N * int(r["Workgroup_Size"]):
+            if "lscqp_pdip_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N * int(r["Workgroup_Size_X"]):
                 per.setdefault(r["Kernel_Name"], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         res["timed_launches"] = {}
         for k, v in per.items():
