@@ -187,6 +187,11 @@ int lscqp_destroy(lscqp_handle h);
 int lscqp_num_variables(lscqp_handle h);
 /* M, whether the class carries SFC rows, and the bytes of one packed row in the handle's row_format (32 or 16). */
 int lscqp_num_segments(lscqp_handle h);
+/* The largest number of obstacles per agent any compiled kernel instance of the handle's shape and precision holds: the n_obs_max
+ * beyond which lscqp_solve_batch_device returns LSCQP_ERR_UNSUPPORTED.  A caller that must not drop neighbours (the reference
+ * never does, src/multi_sync_simulator.cpp:318-333) sizes its row buffers from lscqp_select_neighbours_device's in-range counts,
+ * up to this bound. */
+int lscqp_max_obstacles(lscqp_handle h);
 int lscqp_uses_sfc(lscqp_handle h);
 int lscqp_row_bytes(lscqp_handle h);
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblscqp.so")
+LIB_PATH = os.environ.get("LSCQP_LIB") or os.path.join(_HERE, "liblscqp.so")  # (LSCQP_LIB: A/B builds of the development tools)
 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC, STATUS_CAPACITY = 0, 1, 2, 3, 4
 PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
@@ -91,7 +91,7 @@ def lib():
         L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
         L.lscqp_solve_batch_stream.restype = C.c_int
         L.lscqp_solve_batch_stream.argtypes = [vp, C.c_int64] + [vp] * 10
-        for f in ("lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes"):
+        for f in ("lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp]
         L.lscqp_comm_create.restype = C.c_int
@@ -162,7 +162,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex",
-                    "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
+                    "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
@@ -336,6 +336,9 @@ class Solver:
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
         self.desc = desc
+
+    def max_obstacles(self):
+        return lib().lscqp_max_obstacles(self._h)
 
     def algorithmic_bytes(self, n_obs):
         return lib().lscqp_algorithmic_bytes(self._h, n_obs)

@@ -10,8 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "csrc", "_obj")
-LIB = os.path.join(HERE, "liblscqp.so")
+_AB = os.environ.get("LSCQP_AB", "")  # development: LSCQP_AB=<name> builds liblscqp_<name>.so from its own object directory
+OBJ = os.path.join(HERE, "csrc", "_obj" + ("_" + _AB if _AB else ""))
+LIB = os.path.join(HERE, "liblscqp%s.so" % ("_" + _AB if _AB else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -disable-promote-alloca-to-vector: the kernel keeps its per-lane row state in small arrays indexed by fully unrolled
 # loops.  AMDGPUPromoteAlloca turns them into 512/1024-bit vector registers BEFORE the loops are unrolled and SROA could

@@ -401,10 +401,13 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
     float nx = (float)cp.x, ny = (float)cp.y, nz = (float)cp.z;
     float len = sqrtf(nx * nx + ny * ny + nz * nz);
     if (len < 1e-5f) {
+        // agent.current_goal_point - obstacles[oi].position: the obstacle's CURRENT position for every segment (:629-631), i.e. the
+        // first control point of its shifted plan, not the first control point of segment m
         const double* g = goal + 3 * a;
-        nx = (float)(g[0] - obs[0]);
-        ny = (float)(g[1] - obs[1]);
-        nz = (dim == 3) ? (float)(g[2] - obs[2]) / dwf : 0.0f;
+        const double* opos = traj + (gb * M) * 18;
+        nx = (float)(g[0] - opos[0]);
+        ny = (float)(g[1] - opos[1]);
+        nz = (dim == 3) ? (float)(g[2] - opos[2]) / dwf : 0.0f;
         len = sqrtf(nx * nx + ny * ny + nz * nz);
     }
     if (len > 0.0f) {

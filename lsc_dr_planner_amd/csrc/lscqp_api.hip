@@ -222,6 +222,14 @@ int lscqp_destroy(lscqp_handle h) {
 
 int lscqp_num_variables(lscqp_handle h) { return h ? h->nv : -1; }
 int lscqp_num_segments(lscqp_handle h) { return h ? h->desc.M : -1; }
+int lscqp_max_obstacles(lscqp_handle h) {
+    if (!h) return -1;
+    const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
+    int best = 0;
+    for (const Inst& i : kInst)
+        if (i.M == h->desc.M && i.dim == h->desc.dim && i.es == h->es && i.mixed == mixed && i.max_obs > best) best = i.max_obs;
+    return best;
+}
 int lscqp_uses_sfc(lscqp_handle h) { return h ? (h->desc.use_sfc ? 1 : 0) : -1; }
 int lscqp_row_bytes(lscqp_handle h) { return h ? (int)row_bytes(h) : -1; }
 

@@ -1165,6 +1165,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     }
                     hrow[zl ? lvz_ : 0] += (FT)dsum;  // dsum == 0 for lanes that are not c5 variables
                 }
+#if defined(LSCQP_AB_IMMEDIATE_PIVOT_EXIT) || defined(LSCQP_AB_POSTED_PIVOT_FLAG)
                 LSCQP_WAVE_LDS_SYNC();
                 // (W = 2 with nz <= 64: the system lives in wavefront 0; the other wavefront runs the same factorisation
                 // code on an identity matrix, so that it neither divides by zero nor leaves the uniform control flow)
@@ -1174,6 +1175,31 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     const FT v = hrow[cidx];
                     A[cidx] = zl ? v : (cidx == own_col ? (FT)1 : (FT)0);
                 }
+#else
+                // W > 1 with nz <= 64: the system fits wavefront 0, whose lanes assembled it; EVERY wavefront loads the same rows
+                // (lane & 63) and factorises the same matrix redundantly.  The verdict on a failed pivot is then identical in all
+                // wavefronts by construction -- a break taken by wavefront 0 alone would leave the others iterating against
+                // mismatched barriers until the iteration limit (seen: one QP of a 512-QP dense-maze batch held its launch for
+                // 1.6 ms instead of 0.25 ms) -- at the price of one barrier, with no flag to carry across the solves.
+                if constexpr (W > 1 && NZ <= 64) {
+                    __syncthreads();
+                    const int rsrc = lvz_ & 63;
+                    const bool zrow = rsrc < NZ;
+                    const FT* const src = &Hs[(zrow ? rsrc : NZ) * LDH];
+#pragma unroll
+                    for (int cidx = 0; cidx < NZ; cidx++) {
+                        const FT v = src[cidx];
+                        A[cidx] = zrow ? v : (FT)0;
+                    }
+                } else {
+                    LSCQP_WAVE_LDS_SYNC();
+#pragma unroll
+                    for (int cidx = 0; cidx < NZ; cidx++) {
+                        const FT v = hrow[cidx];
+                        A[cidx] = zl ? v : (FT)0;
+                    }
+                }
+#endif
             }
             LSCQP_T(3);
             LSCQP_STOP(4)
@@ -1418,7 +1444,11 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 restore = status == LSCQP_STATUS_OPTIMAL;
             };
+#ifdef LSCQP_AB_POSTED_PIVOT_FLAG  // measured alternative (+5 % on the 64-QP step: the later break costs registers)
             constexpr bool POSTED_PIVOT_FLAG = (W > 1 && NZ <= 64);
+#else
+            constexpr bool POSTED_PIVOT_FLAG = false;  // every wavefront factorises the same matrix: uniform by construction
+#endif
             if constexpr (POSTED_PIVOT_FLAG) {
                 if (lane == 0) red_[3] = pivot_bad ? 1.0 : 0.0;  // (slot 3 of the reduction scratch is never used by the reductions)
             } else {

@@ -63,9 +63,9 @@ def test_closed_loop_replan_matches_the_oracle(oracle):
 @pytest.mark.gpu
 def test_synthetic_forest_closed_loop_with_64_agents():
     """BASELINE configs[1]'s agent count in closed loop: 64 agents swapping sides through a synthetic forest (the reference's
-    world format), 20 neighbour slots per agent with up to ~40 agents within the 3 m communication range (the capacity rule of
-    the neighbour selection at work), M = 10 segments.  Every QP of 80 replans solves (a jammed warm start is re-launched cold),
-    nothing collides."""
+    world format), M = 10 segments, up to ~40 agents within the 3 m communication range.  The row slots start at 20 and follow
+    the in-range counts (the reference hands every in-range agent to the planner): NO agent's neighbour list is cut in any
+    replan.  Every QP of 80 replans solves (a jammed warm start is re-launched cold), nothing collides."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import closed_loop
 
@@ -73,3 +73,4 @@ def test_synthetic_forest_closed_loop_with_64_agents():
     assert log["qp_failed"] == 0 and log["invalid"] == 0, log
     assert log["min_safety_ratio"] >= 1.0 - 5e-6 and log["max_vel_excess"] <= 1e-5 and log["max_acc_excess"] <= 1e-5, log
     assert log["max_in_range"] > 20 and log["mean_progress_m"] > 3.0, log
+    assert log["truncated_agent_steps"] == 0 and log["row_slots"] >= log["max_in_range"], log

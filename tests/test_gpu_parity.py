@@ -462,3 +462,21 @@ def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(
     assert abs(o["obj"] - d_obj.item()) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - d_x.cpu().numpy()).max() <= 1e-6
     # accepted by the fallback rule: the point is the remembered one and says so
     assert (info["flags"] & api.INFO_FLOOR_ACCEPTED) and info["res_primal"] <= 1e-9 and info["res_dual"] <= 1e-6
+
+
+def test_log_replay_known_answers_on_the_gpu(api, oracle, torch_cuda):
+    """The 300+ log-derived known answers of later replans (tests/golden/kat_log_replay.json) in ONE batch through the C ABI."""
+    g = H.load_golden("kat_log_replay")
+    p = g["params"]
+    cls = H.oracle_class(oracle, p, use_sfc=False)
+    sol = api.Solver(H.abi_desc(api, p, use_sfc=False))
+    ags = [oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal"], next_waypoint=c["next_waypoint"], vmax=p["vmax"],
+                             amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"]) for c in g["cases"]]
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, [None] * len(ags), None, p["M"])
+    G = sol.solve_host(hdr, None, None, None)
+    assert (G["status"] == 0).all()
+    for q, c in enumerate(g["cases"]):
+        for st in c["states"]:
+            pos, vel, acc = oracle.state_at(cls, G["x"][q], st["t"] - c["t"])
+            assert np.abs(pos - st["p"][:2]).max() <= 1.5e-5 and np.abs(vel - st["v"][:2]).max() <= 2e-5
+            assert np.abs(acc - st["a"][:2]).max() <= 3e-4

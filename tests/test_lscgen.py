@@ -120,6 +120,55 @@ def test_gpu_generate_lsc_matches_oracle(api, oracle, N, M, dim, n_obs, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim", [3, 2])
+def test_gpu_fallback_normal_uses_the_obstacles_current_position_on_moving_plans(api, oracle, dim):
+    """Overlapping hulls on MOVING trajectories: the fallback normal is goal - obstacle POSITION (the first control point of the
+    neighbour's shifted plan) for every segment (reference src/traj_planner.cpp:629-631), not goal - first point of segment m.
+    With a stationary swarm (all control points equal) the two cannot be told apart; here every segment of the neighbour starts
+    somewhere else."""
+    import torch
+
+    N, M, n_obs = 6, 5, 2
+    rng = np.random.default_rng(17)
+    init = np.zeros((N, M, 6, 3))
+    for a in range(N):
+        start = rng.uniform(-1, 1, 3)
+        vel = rng.uniform(-1.0, 1.0, 3)
+        t = (np.arange(M * 6) * 0.04).reshape(M, 6)
+        init[a] = start + vel * t[..., None] + 0.02 * rng.normal(size=(M, 6, 3))
+    if dim == 2:
+        init[..., 2] = 1.0
+    init = np.float32(init).astype(np.float64)
+    nbr = np.array([[1, 2], [0, 2], [0, 1], [4, 5], [3, 5], [3, 4]], dtype=np.int32)
+    init[1] = init[0] + np.float32(1e-3)   # pairs (0,1) and (3,4) overlap in every segment -> fallback everywhere
+    init[4] = init[3]
+    goal = np.float32(rng.uniform(-3, 3, (N, 3))).astype(np.float64)
+    if dim == 2:
+        goal[:, 2] = 1.0
+    L = oracle.generate_lsc(init, nbr, 0.15, 2.0, goal, dim=dim)
+    want = api.pack_rows(L).reshape(N, n_obs, M, 6)
+    # the oracle itself: fallback direction = goal - first control point of the neighbour's plan, for the LAST segment too
+    fb = goal[3] - init[4, 0, 0]
+    if dim == 2:
+        fb[2] = 0.0
+    else:
+        fb[2] /= 2.0
+    fb = fb / np.linalg.norm(fb)
+    nz_out = fb[2] / 2.0 if dim == 3 else 0.0
+    assert np.abs(L["nrm"][3, 0, M - 1, 0] - np.array([fb[0], fb[1], nz_out])).max() <= 3e-7
+    dev = torch.device("cuda", 0)
+    sol = api.Solver(api.make_desc(M=M, dim=dim))
+    d_rows = torch.full((N * n_obs * M * 6 * 4,), float("nan"), dtype=torch.float64, device=dev)
+    sol.generate_lsc_device(N, n_obs, 0, torch.from_numpy(init.copy()).to(dev), torch.from_numpy(nbr).to(dev),
+                            torch.full((N,), 0.15, dtype=torch.float64, device=dev), torch.full((N,), 2.0, dtype=torch.float64, device=dev),
+                            torch.from_numpy(goal.copy()).to(dev), d_rows)
+    torch.cuda.synchronize()
+    got = d_rows.cpu().numpy().view(api.ROW_DTYPE).reshape(N, n_obs, M, 6)
+    for f, tol in (("nx", 2e-7), ("ny", 2e-7), ("nz", 2e-7), ("b", 2e-6)):
+        assert np.abs(got[f] - want[f]).max() <= tol, (f, np.abs(got[f] - want[f]).max())
+
+
+@pytest.mark.gpu
 def test_gpu_generated_rows_feed_the_solver(api, oracle):
     """shift -> generate -> solve entirely on the device equals the host pipeline (rows from the oracle restatement)."""
     import torch

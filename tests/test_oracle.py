@@ -155,3 +155,27 @@ def test_objective_includes_constant_terminal_term(oracle):
     # translation invariant (row sums ~1e-9), which leaves ~1e-9 * |x|^2 in the objective
     assert r["status"] == 0 and abs(r["obj"]) < 1e-8
     assert np.abs(r["x"].reshape(3, 30) - np.array([1, 2, 1])[:, None]).max() < 1e-6
+
+
+def test_log_replay_known_answers(oracle):
+    """tests/golden/kat_log_replay.json: 300+ LATER replans of the reference's own run (non-zero initial velocity and acceleration),
+    waypoints inferred by tools/make_golden_log_replay.py.  The restatement must land on the logged states at t + 0.1 s and
+    t + 0.2 s; the tolerances are those of inputs that are themselves known to six printed digits (position 1.5e-5 m, velocity
+    2e-5 m/s, acceleration 3e-4 m/s^2 -- wrong waypoint candidates miss by 1e-2 and more)."""
+    g = H.load_golden("kat_log_replay")
+    p = g["params"]
+    assert len(g["cases"]) >= 300
+    cls = H.oracle_class(oracle, p, use_sfc=False)
+    moving = 0
+    for c in g["cases"]:
+        ag = oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal"], next_waypoint=c["next_waypoint"], vmax=p["vmax"],
+                               amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"])
+        R = oracle.solve(cls, ag, None, None)
+        assert R["status"] == 0
+        for st in c["states"]:
+            pos, vel, acc = oracle.state_at(cls, R["x"], st["t"] - c["t"])
+            assert np.abs(pos - st["p"][:2]).max() <= 1.5e-5, (c["agent"], c["replan"])
+            assert np.abs(vel - st["v"][:2]).max() <= 2e-5, (c["agent"], c["replan"])
+            assert np.abs(acc - st["a"][:2]).max() <= 3e-4, (c["agent"], c["replan"])
+        moving += np.abs(c["a0"]).max() > 0.05
+    assert moving >= 100  # most of them start from a genuinely accelerating state

@@ -114,21 +114,29 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
     dim, z2d, radius = 2, float(g["z_2d"]), float(g["radius"])
     starts, desired = np.array(g["starts"], dtype=np.float64), np.array(g["goals"], dtype=np.float64)
     N = len(starts)
-    n_obs = N - 1 if n_obs is None else n_obs  # capacity of the row buffers per agent (the nearest n_obs if more are in range)
+    # Row slots per agent.  The reference hands EVERY in-range agent to the planner (src/multi_sync_simulator.cpp:318-333), so the
+    # slots follow the largest in-range count seen (lscqp_select_neighbours_device reports it) up to the largest compiled kernel
+    # instance of the shape (lscqp_max_obstacles); only beyond that are the nearest kept, and that is counted in the result
+    # (`truncated_agent_steps`) instead of happening silently.
     sol = api.Solver(api.make_desc(M=M, dim=dim, dt=dt, world_min=g["world_min"], world_max=g["world_max"]))
+    cap = sol.max_obstacles()
+    n_obs = min(N - 1, 8) if n_obs is None else n_obs
+    n_obs = max(1, min(n_obs, cap))
     wmap = api.WorldMap(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
     nv = sol.nv
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     upb = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
 
     # neighbours: chosen on the device each replan, the other agents within the communication range of the launch file (3 m)
-    d_nbr = torch.full((N * n_obs,), -1, dtype=torch.int32, device=dev)
+    def row_buffers(k):
+        return (torch.full((N * k,), -1, dtype=torch.int32, device=dev), up((np.arange(N + 1) * k * M * 6).astype(np.uint64).view(np.int64)),
+                torch.zeros(N * k * M * 6 * 4, dtype=torch.float64, device=dev))
+
+    d_nbr, d_off, d_rows = row_buffers(n_obs)
     d_ncount = torch.zeros(N, dtype=torch.int32, device=dev)
     comm_range = 3.0
     d_rad = torch.full((N,), radius, dtype=torch.float64, device=dev)
     d_dw = torch.full((N,), 2.0, dtype=torch.float64, device=dev)
-    d_off = up((np.arange(N + 1) * n_obs * M * 6).astype(np.uint64).view(np.int64))
-    d_rows = torch.zeros(N * n_obs * M * 6 * 4, dtype=torch.float64, device=dev)
     d_traj = torch.zeros(N * M * 6 * 3, dtype=torch.float64, device=dev)
     d_sfc = torch.zeros(N * M * 6, dtype=torch.float64, device=dev)
     d_sst = torch.zeros(N, dtype=torch.int32, device=dev)
@@ -177,6 +185,13 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
             sol.construct_sfc_device(wmap, api.SFC_FROM_HULL, N, up(P.reshape(-1)), d_rad, d_sfc, d_sst)
         d_goal_all = up(goal_pt)
         sol.select_neighbours_device(N, 0, N, n_obs, comm_range, up(state[:, :3]), d_nbr, d_ncount)  # broadcastMsgs' range filter
+        need = int(d_ncount.max().item())
+        if need > n_obs and n_obs < cap:  # more agents in range than slots: grow the row buffers and select again
+            n_obs = min(need, cap)
+            d_nbr, d_off, d_rows = row_buffers(n_obs)
+            sol.select_neighbours_device(N, 0, N, n_obs, comm_range, up(state[:, :3]), d_nbr, d_ncount)
+        log["row_slots"] = n_obs
+        log["truncated_agent_steps"] = log.get("truncated_agent_steps", 0) + int((d_ncount > n_obs).sum().item())
         sol.generate_constraints_device(api.GEN_CLSC, N, n_obs, 0, d_traj, d_nbr, d_rad, d_dw, d_goal_all, d_rows)
         hdr = np.zeros(N, api.HEADER_DTYPE)
         hdr["p0"], hdr["v0"], hdr["a0"] = state[:, 0:3], state[:, 3:6], state[:, 6:9]
