@@ -253,6 +253,35 @@ struct Cfg {
     // weights of the two-sided rows in LDS: [interval NX][vel NV][acc NA][comm NC]
     static constexpr int OV = NX, OA = NX + NV, OC = NX + NV + NA, NOM = NX + NV + NA + NC;
     static constexpr int LDH = NZ | 1;
+    // NESTED DISSECTION of the reduced system for classes with more than 64 rows (M = 10 in 3-D: nz = 84).  The (c3, c4)
+    // variables of a segment couple only to the neighbouring segments (through the C2 joins) and to the c5 variables; the c5
+    // variables of one axis are all coupled (communication-pair rows, src/traj_optimizer.cpp:476-500).  Separator S = the (c3, c4)
+    // of the middle segment MS + every c5; it cuts the rest into two independent banded blocks, L = (c3, c4) of segments
+    // 0..MS-1 and R = (c3, c4) of segments MS+1..M-2, which two wavefronts eliminate CONCURRENTLY (each with its share of the
+    // separator's Schur complement), then one wavefront factorises the separator.  Row length in registers: NB + NS instead of nz.
+    static constexpr bool ND = NZ > 64;
+    static constexpr int MS = (M - 1) / 2;
+    static constexpr int NB = 2 * DIM * MS;             // block L (wavefront 0): segments 0 .. MS-1, order (m, axis, j)
+    static constexpr int NBR = 2 * DIM * (M - 2 - MS);  // block R (wavefront 1): segments MS+1 .. M-2
+    static constexpr int NS = 2 * DIM + DIM * M;        // separator: (c3, c4) of segment MS, then c5 of (axis, segment)
+    static constexpr int BWB = 4 * DIM - 1;             // half bandwidth inside a block
+    static constexpr int NAR = ND ? NB + NS : NZ;       // entries of a lane's matrix row
+    static_assert(!ND || (ES_ && NB == NBR && NB + NS <= 64 && W >= 2 && FB_ == 8),
+                  "nested dissection: end-stop classes with two equal blocks, two or more wavefronts, fp64");
+    // z index (axis-major: k * NZA + a) of variable (axis k, segment m, j): j = 0, 1, 2 <-> c3, c4, c5; the last segment under the
+    // end stop has one variable
+    static constexpr int zi_kmj(int k, int m, int j) { return k * NZA + ((ES && m == M - 1) ? 3 * (M - 1) : 3 * m + j); }
+    // nested dissection: local column c of wavefront w (0: L | S, 1: R | S) -> z index
+    static constexpr int nd_zi(int w, int c) {
+        if (c < NB) {
+            const int seg = c / (2 * DIM), r = c % (2 * DIM);
+            return zi_kmj(r / 2, (w == 0 ? 0 : MS + 1) + seg, r % 2);
+        }
+        int s = c - NB;
+        if (s < 2 * DIM) return zi_kmj(s / 2, MS, s % 2);
+        s -= 2 * DIM;
+        return zi_kmj(s / M, s % M, 2);
+    }
     static_assert(NZ <= T, "lane-per-row kernel needs dim*(3M-2) <= 64*W");
     static_assert(CP <= T, "6M-3 <= 64*W");
     static_assert(W == 1 || W == 2 || W == 4, "1, 2 or 4 wavefronts per QP");
@@ -271,7 +300,11 @@ struct Cfg {
     static constexpr int o_col = o_red + (W > 1 ? 8 * W : 0);  // pivot-column / solve broadcast buffer, 2 x T
     static constexpr int o_zs = o_col + 2 * T + 2;  // the last point that met the acceptance tests (z), NZ
     static constexpr int o_H = ((o_zs + NZ + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH], scalars of FB_ bytes
-    static constexpr int o_rows = ((o_H + ((NZ + 1) * LDH * FB_ + 7) / 8 + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
+    // (nested dissection also parks the factor of the NS accumulator lanes there: [NZ + NS + 1][LDP])
+    static constexpr int LDP = NAR | 1;
+    static constexpr int H_DOUBLES = ND ? (((NZ + 1) * LDH > (NZ + NS + 1) * LDP) ? (NZ + 1) * LDH : (NZ + NS + 1) * LDP)
+                                        : ((NZ + 1) * LDH * FB_ + 7) / 8;
+    static constexpr int o_rows = ((o_H + H_DOUBLES + 1) / 2) * 2;  // + one dummy row for non-z lanes  // LSC row constants SoA nx,ny,nz,b [MAX_OBS*CP]
     static constexpr int NROW = MAX_OBS * CP;  // + one dead row per array
     static constexpr size_t lds_bytes() { return sizeof(double) * ((size_t)o_rows + 4 * ((size_t)NROW + 1)); }
 };
@@ -430,9 +463,50 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
 
     // ---- lane roles ---------------------------------------------------------------------------------------
     // z lane: row r = lane of the reduced system, r = k*NZA + a
-    const bool zl = lane < NZ;
-    const int zk = zl ? lane / NZA : 0;
-    const int za = zl ? lane % NZA : 0;
+    // (which z variable a lane owns: lane r <-> z index r for nz <= 64; the nested-dissection layout of Cfg for nz > 64)
+    auto lane_zi = [](int lv) -> int {
+        if constexpr (!C::ND) {
+            return lv < NZ ? lv : -1;
+        } else {
+            const int w = lv >> 6, t = lv & 63;
+            const bool own = (w == 0 && t < C::NB + C::NS) || (w == 1 && t < C::NB);
+            const int tc = own ? t : 0;
+            // C::nd_zi with run-time arguments
+            int zi;
+            if (tc < C::NB) {
+                const int seg = tc / (2 * DIM), r = tc % (2 * DIM);
+                zi = C::zi_kmj(r / 2, (w == 0 ? 0 : C::MS + 1) + seg, r % 2);
+            } else {
+                int s_ = tc - C::NB;
+                const bool mid = s_ < 2 * DIM;
+                const int s2 = mid ? s_ : s_ - 2 * DIM;
+                zi = mid ? C::zi_kmj(s2 / 2, C::MS, s2 % 2) : C::zi_kmj(s2 / M, s2 % M, 2);
+            }
+            return own ? zi : -1;
+        }
+    };
+    // scratch-matrix row of a lane (z lanes only; the others share the dummy row NZ)
+    auto lane_slot = [](int lv) -> int {
+        if constexpr (!C::ND) {
+            return lv < NZ ? lv : NZ;
+        } else {
+            const int w = lv >> 6, t = lv & 63;
+            return (w == 0 && t < C::NB + C::NS) ? t : (w == 1 && t < C::NB) ? C::NB + C::NS + t : NZ;
+        }
+    };
+    // where a lane parks its factor row while pass 2 runs (the scratch matrix is free then); nested dissection: [NZ + NS + 1][LDP]
+    auto park_ptr = [&](int lv) -> FT* {
+        if constexpr (C::ND) {
+            const int w = lv >> 6, t = lv & 63;
+            return Hs + ((w < 2 && t < C::NB + C::NS) ? w * (C::NB + C::NS) + t : NZ + C::NS) * C::LDP;
+        } else {
+            return &Hs[(lv < NZ ? lv : NZ) * LDH];
+        }
+    };
+    const int zi0 = lane_zi(lane);
+    const bool zl = zi0 >= 0;
+    const int zk = zl ? zi0 / NZA : 0;
+    const int za = zl ? zi0 % NZA : 0;
     const bool zlast = ES && (za == 3 * (M - 1));
     const int zm = zlast ? (M - 1) : za / 3;
     const int zj = zlast ? 0 : za % 3;
@@ -445,15 +519,18 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
 #define LSCQP_PHASE_LANE(name) \
     int name = lane;           \
     asm volatile("" : "+v"(name))
-    struct ZRole {  // row `lv` of the reduced system, lv = k*NZA + a
+    struct ZRole {  // the z variable of lane `lv`: z index zi = k*NZA + a, scratch row `slot`
         bool zl, zlast, has_next;
-        int zk, zm, zj, gbase, gnext;
+        int zk, zm, zj, gbase, gnext, zi, slot;
     };
-    auto zrole = [](int lv) -> ZRole {
+    auto zrole = [&](int lv) -> ZRole {
         ZRole R;
-        R.zl = lv < NZ;
-        R.zk = R.zl ? lv / NZA : 0;
-        const int za_ = R.zl ? lv % NZA : 0;
+        const int zi_ = lane_zi(lv);
+        R.zl = zi_ >= 0;
+        R.zi = R.zl ? zi_ : 0;
+        R.slot = lane_slot(lv);
+        R.zk = R.zl ? zi_ / NZA : 0;
+        const int za_ = R.zl ? zi_ % NZA : 0;
         R.zlast = ES && (za_ == 3 * (M - 1));
         R.zm = R.zlast ? (M - 1) : za_ / 3;
         R.zj = R.zlast ? 0 : za_ % 3;
@@ -486,9 +563,9 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     LSCQP_PHASE_LANE(lvz_);                                                                              \
     const ZRole ZR = zrole(lvz_);                                                                        \
     const bool zl = ZR.zl, zlast = ZR.zlast, has_next = ZR.has_next;                                     \
-    const int zk = ZR.zk, zm = ZR.zm, zj = ZR.zj, gbase = ZR.gbase, gnext = ZR.gnext;                    \
-    FT* const hrow = &Hs[(zl ? lvz_ : NZ) * LDH];                                                        \
-    (void)zlast, (void)has_next, (void)zk, (void)zm, (void)zj, (void)gbase, (void)gnext, (void)hrow
+    const int zk = ZR.zk, zm = ZR.zm, zj = ZR.zj, gbase = ZR.gbase, gnext = ZR.gnext, zi = ZR.zi;        \
+    FT* const hrow = &Hs[ZR.slot * LDH];                                                                 \
+    (void)zlast, (void)has_next, (void)zk, (void)zm, (void)zj, (void)gbase, (void)gnext, (void)hrow, (void)zi
 #define LSCQP_L_ROLES()                                                                                  \
     LSCQP_PHASE_LANE(lvl_);                                                                              \
     const LRole LR = lrole(lvl_);                                                                        \
@@ -513,8 +590,8 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     }
     if (zl) {
         const double cf1 = H->v0[zk] * dt * 0.2;
-        z_[lane] = H->a0[zk] * dt * dt * 0.05 + 2.0 * cf1;
-        FT* hrow0 = &Hs[lane * LDH];
+        z_[zi0] = H->a0[zk] * dt * dt * 0.05 + 2.0 * cf1;
+        FT* hrow0 = &Hs[lane_slot(lane) * LDH];
 #pragma unroll
         for (int cidx = 0; cidx < NZ; cidx++) hrow0[cidx] = (FT)0;  // entries outside the lane's pattern stay zero
         // Primal start from the caller's initial trajectory (TrajOptimizer::solve's `initial_traj`: the shifted previous
@@ -522,7 +599,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
         // equalities are re-imposed by c = c_fixed + T z below, so float32 rounding of the plan does no harm.
         if (x_init) {
             const double o_k = (zk == 0) ? org0 : (zk == 1) ? org1 : org2;
-            z_[lane] = x_init[q * NX + zk * P + 6 * zm + (zlast ? 5 : 3 + zj)] - o_k;
+            z_[zi0] = x_init[q * NX + zk * P + 6 * zm + (zlast ? 5 : 3 + zj)] - o_k;
         }
     }
     if (x_init) {  // uniform over the grid
@@ -631,7 +708,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 }
             } else if (u < C::SI + C::SV + C::SA) {  // acceleration (m,i): c[i+2]-2c[i+1]+c[i]   (:462-471)
                 const int a = lane + T * (u - C::SI - C::SV);
-                if (a < C::NA) {
+                if (a < C::NAR) {
                     const int k = a / (4 * M), r = a % (4 * M), m = r / 4, i = r % 4;
                     if (!(m == 0 && i < 1)) {
                         t_ix[u] = k * P + 6 * m + i;
@@ -824,7 +901,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
         }
     };
 
-    FT A[NZ];  // row `lane` of the reduced KKT matrix, then its LDL^T factors
+    FT A[C::NAR];  // the lane's row of the reduced KKT matrix (all nz columns, or L | S resp. R | S under nested dissection), then its LDL^T factors
     FT dinv_own = (FT)0;
     double res_p = 0, res_d = 0, res_gap = 0;
     double snap_p = 0, snap_d = 0, snap_gap = 0;  // residuals of the last point that met the acceptance tests (kept in zs_)
@@ -1163,25 +1240,39 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         const double old = (double)*t;
                         if (use) *t = (FT)(near ? (old - w) : -w);
                     }
-                    hrow[zl ? lvz_ : 0] += (FT)dsum;  // dsum == 0 for lanes that are not c5 variables
+                    hrow[zi] += (FT)dsum;  // dsum == 0 for lanes that are not c5 variables (zi = 0 for lanes without a variable)
                 }
-#if defined(LSCQP_AB_IMMEDIATE_PIVOT_EXIT) || defined(LSCQP_AB_POSTED_PIVOT_FLAG)
-                LSCQP_WAVE_LDS_SYNC();
-                // (W = 2 with nz <= 64: the system lives in wavefront 0; the other wavefront runs the same factorisation
-                // code on an identity matrix, so that it neither divides by zero nor leaves the uniform control flow)
-                const int own_col = (W > 1 && NZ <= 64 && lvz_ >= 64) ? (lvz_ & 63) : -1;
-#pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) {
-                    const FT v = hrow[cidx];
-                    A[cidx] = zl ? v : (cidx == own_col ? (FT)1 : (FT)0);
-                }
-#else
                 // W > 1 with nz <= 64: the system fits wavefront 0, whose lanes assembled it; EVERY wavefront loads the same rows
                 // (lane & 63) and factorises the same matrix redundantly.  The verdict on a failed pivot is then identical in all
                 // wavefronts by construction -- a break taken by wavefront 0 alone would leave the others iterating against
                 // mismatched barriers until the iteration limit (seen: one QP of a 512-QP dense-maze batch held its launch for
-                // 1.6 ms instead of 0.25 ms) -- at the price of one barrier, with no flag to carry across the solves.
-                if constexpr (W > 1 && NZ <= 64) {
+                // 1.6 ms instead of 0.25 ms) -- at the price of one barrier, with no flag to carry across the solves (measured
+                // alternative: wavefront 0 posts a flag that all read behind the predictor solve, +5 % on the 64-QP step).
+                if constexpr (C::ND) {
+                    // nested dissection: wavefront 0 holds rows L | S over columns L | S, wavefront 1 rows R | (accumulator of S)
+                    // over columns R | S.  The accumulator lane of separator variable s starts from K[s][R] (assembled by the S
+                    // lane of wavefront 0 in ITS scratch row) and an all-zero separator block.
+                    __syncthreads();
+                    const int wv_ = __builtin_amdgcn_readfirstlane(lvz_ >> 6);
+                    const int t_ = lvz_ & 63;
+                    const bool acc = (wv_ == 1) && t_ >= C::NB && t_ < C::NB + C::NS;        // accumulator lane
+                    const bool rowl = (wv_ == 0 && t_ < C::NB + C::NS) || (wv_ == 1 && t_ < C::NB);
+                    const FT* const src = &Hs[(acc ? t_ : (rowl ? ZR.slot : NZ)) * LDH];  // (S lane t of wavefront 0 has slot t)
+                    if (wv_ == 0) {
+                        static_for<0, C::NAR>([&](auto Cc) {
+                            constexpr int c = decltype(Cc)::value;
+                            const FT v = src[C::nd_zi(0, c)];
+                            A[c] = rowl ? v : (FT)0;
+                        });
+                    } else {
+                        static_for<0, C::NAR>([&](auto Cc) {
+                            constexpr int c = decltype(Cc)::value;
+                            const FT v = src[C::nd_zi(1, c)];
+                            A[c] = (rowl || (acc && c < C::NB)) ? v : (FT)0;
+                        });
+                    }
+                    __syncthreads();  // the scratch matrix is reused for the hand-overs of the factorisation
+                } else if constexpr (W > 1 && NZ <= 64) {
                     __syncthreads();
                     const int rsrc = lvz_ & 63;
                     const bool zrow = rsrc < NZ;
@@ -1199,7 +1290,6 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         A[cidx] = zl ? v : (FT)0;
                     }
                 }
-#endif
             }
             LSCQP_T(3);
             LSCQP_STOP(4)
@@ -1301,57 +1391,80 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             });
 #endif
             } else {
-#ifdef LSCQP_FACT_LOCKSTEP
-                // Measured alternative (-DLSCQP_FACT_LOCKSTEP): both row blocks eliminate column j together; the pivot
-                // column goes through LDS (double buffered) with one s_barrier per column: 125 k cycles at nz = 84.
-                int lf = lane;
-                asm volatile("" : "+v"(lf));
-                static_for<0, NZ>([&](auto Jc) {
-                    constexpr int j = decltype(Jc)::value;
-                    double* const cb = col_ + (j & 1) * T;
-                    cb[lane] = A[j];
-                    __syncthreads();
-                    const double d = cb[j];
-                    pivot_bad = pivot_bad || !(d > 1e-300);
-                    const double invd = fast_rcp(d);
-                    dinv_own = (lf == j) ? invd : dinv_own;
-                    const double li = (lf > j) ? A[j] * invd : 0.0;
-                    static_for<j + 1, NZ>([&](auto Kc) {
-                        constexpr int k = decltype(Kc)::value;
-                        A[k] = fma(-li, cb[k], A[k]);
-                    });
-                    A[j] = (lf > j) ? li : A[j];
-                });
-#else
-                // nz > 64: BLOCKED LDL^T over the two row blocks (rows 0..63 in wavefront 0, the rest in wavefront 1).
-                //   1. wavefront 0 eliminates columns 0..63 of its own rows without any barrier: inside the block the
-                //      pivot row goes over both pipes as in the one-wavefront case, the entries of columns >= 64 (the
-                //      unscaled upper block U12) are broadcast with v_readlane;
-                //   2. U12 and 1/d go to LDS (the scratch matrix is free at this point), ONE barrier;
-                //   3. wavefront 1 forms its rows of L21 = U12' D^-1, the Schur complement A22 -= L21 U12 (uniform LDS
-                //      reads) and factorises the remaining (nz-64)^2 block with v_readlane.
-                // 3 barriers instead of 84; the branches on the wavefront id are scalar.
-                constexpr int N1 = NZ - 64;
+                // nz > 64: NESTED DISSECTION over two wavefronts (layout: Cfg).
+                //   1. both wavefronts eliminate their own banded block (NB pivots, concurrently, no barrier): per pivot the
+                //      in-block band (<= BWB columns) and the NS separator columns; the separator rows of wavefront 0 and the
+                //      accumulator rows of wavefront 1 collect the two shares of the Schur complement on the way;
+                //   2. ONE hand-over through LDS: wavefront 1's share of the separator block is added to wavefront 0's;
+                //   3. wavefront 0 factorises the NS x NS separator (dense, pivot row over both pipes as in the one-wavefront case).
+                // Pivot rows are read as pivot COLUMNS (symmetry) from a per-wavefront LDS column buffer; the column of the next
+                // pivot is published as soon as it is final.  The branches on the wavefront id are scalar.
+                constexpr int NB = C::NB, NS = C::NS, NA = C::NAR, BWB = C::BWB;
                 const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
                 int lf = lane & 63;
                 asm volatile("" : "+v"(lf));
-                double* const U12s = Hs;                  // [64][N1]
-                double* const dinvs = Hs + 64 * N1;       // [64]
-                double* const flag = Hs + 64 * N1 + 64;   // [2] pivot failures of the two blocks
-                if (wv == 0) {
-                    col_[lf] = A[0];
+                double* const colw = col_ + 2 * 64 * (wv & 1);
+                double* const Sx = reinterpret_cast<double*>(Hs);  // [NS][NS]: wavefront 1's share of the separator block
+                double* const flag = Sx + NS * NS;                  // [2] pivot failures
+                if (wv < 2) {
+                    colw[lf] = A[0];
                     double d = bcast(A[0], 0);
                     double invd = fast_rcp(d);
-                    static_for<0, 64>([&](auto Jc) {
+                    static_for<0, NB>([&](auto Jc) {
                         constexpr int j = decltype(Jc)::value;
-                        constexpr int n = 63 - j;  // trailing entries inside the block, k = j+1 .. 63
+                        constexpr int b1 = (j + BWB < NB - 1) ? j + BWB : NB - 1;  // last in-block column of the band
+                        const double* const cb = colw + (j & 1) * 64;
+                        double* const cbn = colw + ((j + 1) & 1) * 64;
+                        pivot_bad = pivot_bad || !pivot_ok<double>(d);
+                        dinv_own = (lf == j) ? invd : dinv_own;
+                        const double li = (lf > j) ? A[j] * invd : 0.0;
+                        if constexpr (j + 1 < NB) {  // the next pivot column first: its broadcast and reciprocal overlap the rest
+                            A[j + 1] = fma(-li, bcast(A[j + 1], j), A[j + 1]);
+                            cbn[lf] = A[j + 1];
+                            d = bcast(A[j + 1], j + 1);
+                            invd = fast_rcp(d);
+                        }
+                        static_for<j + 2, b1 + 1>([&](auto Kc) {
+                            constexpr int k = decltype(Kc)::value;
+                            A[k] = fma(-li, cb[k], A[k]);
+                        });
+                        static_for<NB, NA>([&](auto Kc) {
+                            constexpr int k = decltype(Kc)::value;
+                            A[k] = fma(-li, cb[k], A[k]);
+                        });
+                        A[j] = (lf > j) ? li : A[j];
+                        asm volatile("" ::: "memory");  // LDS program order between the steps
+                    });
+                }
+                {   // hand-over of wavefront 1's share (single predicated stores; everything else is masked arithmetically)
+                    const bool give = (wv == 1) && lf >= NB && lf < NB + NS;
+                    const int srow = (lf >= NB && lf < NB + NS) ? lf - NB : 0;
+                    static_for<0, NS>([&](auto Cc) {
+                        constexpr int c = decltype(Cc)::value;
+                        if (give) Sx[srow * NS + c] = A[NB + c];
+                    });
+                    if (lf == 0 && wv < 2) flag[wv] = pivot_bad ? 1.0 : 0.0;
+                    __syncthreads();
+                    const double take = (wv == 0 && lf >= NB && lf < NB + NS) ? 1.0 : 0.0;
+                    static_for<0, NS>([&](auto Cc) {
+                        constexpr int c = decltype(Cc)::value;
+                        A[NB + c] = fma(take, Sx[srow * NS + c], A[NB + c]);
+                    });
+                }
+                if (wv == 0) {  // the separator: dense LDL^T on columns / lanes NB .. NA-1
+                    colw[lf] = A[NB];
+                    double d = bcast(A[NB], NB);
+                    double invd = fast_rcp(d);
+                    static_for<NB, NA>([&](auto Jc) {
+                        constexpr int j = decltype(Jc)::value;
+                        constexpr int n = NA - j - 1;
                         constexpr int r0 = (n * LSCQP_FACT_HYBRID + 50) / 100;
                         constexpr int nr = n <= 4 ? n : (r0 < 3 ? 4 : r0 + 1);
                         constexpr int nl = n - (nr < n ? nr : n);
                         constexpr int NR = n - nl;
-                        const double* const cb = col_ + (j & 1) * 64;
-                        double* const cbn = col_ + ((j + 1) & 1) * 64;
-                        pivot_bad = pivot_bad || !(d > 1e-300);
+                        const double* const cb = colw + (j & 1) * 64;
+                        double* const cbn = colw + ((j + 1) & 1) * 64;
+                        pivot_bad = pivot_bad || !pivot_ok<double>(d);
                         dinv_own = (lf == j) ? invd : dinv_own;
                         const double li = (lf > j) ? A[j] * invd : 0.0;
                         double ul[nl > 0 ? nl : 1];
@@ -1378,84 +1491,22 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                             constexpr int t = decltype(Tc)::value;
                             A[j + 1 + NR + t] = fma(-li, ul[t], A[j + 1 + NR + t]);
                         });
-                        // the upper block: columns 64 .. nz-1 of the pivot row, v_readlane in batches of 8
-                        static_for<0, (N1 + 7) / 8>([&](auto Cc) {
-                            constexpr int k0 = 64 + decltype(Cc)::value * 8;
-                            double ub[8];
-                            static_for<0, 8>([&](auto Tc) {
-                                constexpr int t = decltype(Tc)::value;
-                                if constexpr (k0 + t < NZ) ub[t] = bcast(A[k0 + t], j);
-                            });
-                            static_for<0, 8>([&](auto Tc) {
-                                constexpr int t = decltype(Tc)::value;
-                                if constexpr (k0 + t < NZ) A[k0 + t] = fma(-li, ub[t], A[k0 + t]);
-                            });
-                        });
                         A[j] = (lf > j) ? li : A[j];
                         asm volatile("" ::: "memory");
                     });
-                    static_for<0, N1>([&](auto Cc) {
-                        constexpr int c = decltype(Cc)::value;
-                        U12s[lf * N1 + c] = A[64 + c];
-                    });
-                    dinvs[lf] = dinv_own;
-                    if (lf == 0) flag[0] = pivot_bad ? 1.0 : 0.0;
-                }
-                __syncthreads();
-                if (wv == 1) {
-                    const bool row = lf < N1;  // the other lanes of this wavefront hold no row of the system
-                    static_for<0, 64>([&](auto Jc) {
-                        constexpr int j = decltype(Jc)::value;
-                        const double l = U12s[j * N1 + (row ? lf : 0)] * dinvs[j];  // L21[row][j]
-                        const double lj = row ? l : 0.0;
-                        // Schur complement with the UNSCALED upper entries: A22[row][c] -= L21[row][j] U12[j][c]
-                        static_for<0, N1>([&](auto Cc) {
-                            constexpr int c = decltype(Cc)::value;
-                            A[64 + c] = fma(-lj, U12s[j * N1 + c], A[64 + c]);
-                        });
-                        A[j] = lj;
-                    });
-                    static_for<0, N1>([&](auto Jc) {  // the remaining block, pivot row by v_readlane
-                        constexpr int jj = decltype(Jc)::value;
-                        const double d = bcast(A[64 + jj], jj);
-                        pivot_bad = pivot_bad || !(d > 1e-300);
-                        const double invd = fast_rcp(d);
-                        dinv_own = (lf == jj) ? invd : dinv_own;
-                        const double li = (lf > jj && row) ? A[64 + jj] * invd : 0.0;
-                        static_for<jj + 1, N1>([&](auto Kc) {
-                            constexpr int kk = decltype(Kc)::value;
-                            A[64 + kk] = fma(-li, bcast(A[64 + kk], jj), A[64 + kk]);
-                        });
-                        A[64 + jj] = (lf > jj && row) ? li : A[64 + jj];
-                    });
-                    if (lf == 0) flag[1] = pivot_bad ? 1.0 : 0.0;
+                    if (lf == 0) flag[0] = (pivot_bad || flag[0] != 0.0) ? 1.0 : 0.0;
                 }
                 __syncthreads();
                 pivot_bad = (flag[0] != 0.0) || (flag[1] != 0.0);
                 __syncthreads();  // the flags sit in the scratch matrix, which the next phase overwrites
-#endif
             }
-            // W > 1 with nz <= 64: the system lives in wavefront 0, the other wavefronts factorise an identity matrix, so only
-            // wavefront 0 can see a failed pivot -- and a break taken by one wavefront alone would leave the others iterating
-            // against mismatched barriers until the iteration limit (seen: one QP of a 512-QP dense-maze batch held its launch for
-            // 1.6 ms instead of 0.25 ms).  Wavefront 0 posts its verdict in LDS and every wavefront reads it after the next
-            // barrier the iteration has anyway (behind the predictor solve); a breakdown costs one wasted solve.
             auto numeric_exit = [&]() {
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 restore = status == LSCQP_STATUS_OPTIMAL;
             };
-#ifdef LSCQP_AB_POSTED_PIVOT_FLAG  // measured alternative (+5 % on the 64-QP step: the later break costs registers)
-            constexpr bool POSTED_PIVOT_FLAG = (W > 1 && NZ <= 64);
-#else
-            constexpr bool POSTED_PIVOT_FLAG = false;  // every wavefront factorises the same matrix: uniform by construction
-#endif
-            if constexpr (POSTED_PIVOT_FLAG) {
-                if (lane == 0) red_[3] = pivot_bad ? 1.0 : 0.0;  // (slot 3 of the reduction scratch is never used by the reductions)
-            } else {
-                if (pivot_bad) {  // uniform over the QP's lanes
-                    numeric_exit();
-                    break;
-                }
+            if (pivot_bad) {  // uniform over the QP's lanes (nz <= 64 with several wavefronts: every wavefront factorises the same matrix)
+                numeric_exit();
+                break;
             }
             // broadcast of lane j's value to all lanes of the QP: v_readlane (W = 1) or an LDS slot + barrier (W = 2; one
             // slot per column and direction, so no slot is rewritten while a slower wavefront may still read it)
@@ -1482,62 +1533,61 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
 #else
 #define LSCQP_FACTOR_ENTRY(j) A[j]
 #endif
-            // nz > 64 (two wavefronts hold the rows): blocked triangular solves.  Rows 0..63 live in wavefront 0, the rest
-            // in wavefront 1; inside a wavefront the column-oriented substitution broadcasts with v_readlane as in the
-            // one-wavefront case, and the coupling between the two row blocks is ONE hand-off through LDS per
-            // direction (2 barriers per solve instead of one per column: 168 -> 2).  The branches on the wavefront id
-            // are uniform (scalar), so no lane-masked region is created.
+            // nz > 64: the triangular solves of the nested-dissection factor.  Forward: both wavefronts substitute through their
+            // own block concurrently (the separator / accumulator rows collect the two shares of the separator's right-hand side),
+            // ONE hand-over, wavefront 0 runs forward and backward through the separator (its own block rows follow along in the
+            // same broadcasts), ONE hand-over of the separator's solution, both wavefronts finish their blocks backward.
             // (generic lambda: instantiated only for the nz > 64 instances; called twice: must not become a real call)
             auto solve_blocked = [&](double b, auto) __attribute__((always_inline)) -> double {
+                constexpr int NB = C::NB, NS = C::NS, NA = C::NAR;
                 const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
                 int ll_ = lane & 63;
                 asm volatile("" : "+v"(ll_));
-                constexpr int N1 = NZ - 64;  // rows of the second block
-                // ---- forward: L w = b (unit lower) ----
-                if (wv == 0) {
-                    static_for<0, 64>([&](auto Jc) {
+                double* const hand = col_;  // [64] hand-over buffer (the column buffers are idle during the solves)
+                const bool sep = ll_ >= NB && ll_ < NB + NS;
+                const int srow = sep ? ll_ - NB : 0;
+                // ---- forward through the blocks: L w = b (unit lower) ----
+                if (wv < 2) {
+                    static_for<0, NB>([&](auto Jc) {
                         constexpr int j = decltype(Jc)::value;
                         const double wj = bcast(b, j);
                         b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
                     });
-                    col_[ll_] = b;  // w_0 .. w_63
                 }
-                __syncthreads();
-                if (wv == 1) {
-                    static_for<0, 64>([&](auto Jc) {  // L21 w_1 (rows >= 64: every entry is below the diagonal)
-                        constexpr int j = decltype(Jc)::value;
-                        b = fma(-A[j], col_[j], b);
-                    });
-                    static_for<0, N1>([&](auto Jc) {
-                        constexpr int jj = decltype(Jc)::value;
-                        const double wj = bcast(b, jj);
-                        b = fma(-((ll_ > jj) ? A[64 + jj] : 0.0), wj, b);
-                    });
-                }
-                // ---- backward: (D L') x = w; row i of the upper factor is A[j > i] of lane i ----
-                asm volatile("" : "+v"(ll_));
-                if (wv == 1) {
-                    static_for<0, N1>([&](auto Jc) {
-                        constexpr int jj = N1 - 1 - decltype(Jc)::value;
-                        const double xj = bcast(b * dinv_own, jj);
-                        b = fma(-((ll_ < jj) ? A[64 + jj] : 0.0), xj, b);
-                    });
-                    col_[64 + ll_] = b * dinv_own;  // x_64 .. (lanes beyond the system carry zeros: dinv_own = 0 there)
-                }
+                if (wv == 1 && sep) hand[srow] = b;  // accumulator rows started from 0: their value IS wavefront 1's share
                 __syncthreads();
                 if (wv == 0) {
-                    static_for<0, N1>([&](auto Jc) {  // U12 x_2 (rows < 64 <= column)
-                        constexpr int jj = decltype(Jc)::value;
-                        b = fma(-A[64 + jj], col_[64 + jj], b);
+                    b += sep ? hand[srow] : 0.0;
+                    static_for<NB, NA>([&](auto Jc) {  // forward through the separator
+                        constexpr int j = decltype(Jc)::value;
+                        const double wj = bcast(b, j);
+                        b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
                     });
-                    static_for<0, 64>([&](auto Jc) {
-                        constexpr int j = 63 - decltype(Jc)::value;
+                    // ---- backward: (D L') x = w; row i of the upper factor is A[j > i] of lane i ----
+                    asm volatile("" : "+v"(ll_));
+                    static_for<NB, NA>([&](auto Jc) {
+                        constexpr int j = NA - 1 - (decltype(Jc)::value - NB);
+                        const double xj = bcast(b * dinv_own, j);
+                        b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);  // (the block rows of wavefront 0 take their separator part here)
+                    });
+                }
+                if (wv == 0 && sep) hand[srow] = b * dinv_own;  // the separator's solution (wavefront 1 reads hand only after the barrier)
+                __syncthreads();
+                if (wv == 1) {  // block rows of wavefront 1: U[i][S] x_S
+                    static_for<0, NS>([&](auto Cc) {
+                        constexpr int c = decltype(Cc)::value;
+                        b = fma(-A[NB + c], hand[c], b);  // (accumulator lanes compute a value nobody uses)
+                    });
+                }
+                if (wv < 2) {
+                    asm volatile("" : "+v"(ll_));
+                    static_for<0, NB>([&](auto Jc) {
+                        constexpr int j = NB - 1 - decltype(Jc)::value;
                         const double xj = bcast(b * dinv_own, j);
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);
                     });
                 }
-                const double x = b * dinv_own;  // (final once the lane's own column has been broadcast)
-                return x;
+                return b * dinv_own;  // (final once the lane's own column has been broadcast; 0 for lanes without a row)
             };
             // (mixed precision: the right-hand side is rounded to float32, the direction comes back as fp64; no refinement --
             // the residuals the NEXT iteration computes are fp64, so an inexact direction costs iterations, not accuracy:
@@ -1569,24 +1619,18 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
 
             // ============ predictor ========================================================================
             const double dza = solve(-gcost + ga);
-            if (zl) dz_[lane] = dza;
+            if (zl) dz_[zi0] = dza;
 #ifndef LSCQP_SOLVE_FROM_LDS
             // park the factor in the lane's scratch-matrix row while pass 2 runs: A[] is then dead across the pass,
             // which removes most register spills of the pass
             {
                 LSCQP_PHASE_LANE(lvp_);
-                FT* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
+                FT* const prow = park_ptr(lvp_);
 #pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = A[cidx];
+                for (int cidx = 0; cidx < C::NAR; cidx++) prow[cidx] = A[cidx];
             }
 #endif
             LSCQP_BLOCK_SYNC();
-            if constexpr (POSTED_PIVOT_FLAG) {
-                if (red_[3] != 0.0) {  // uniform over the workgroup
-                    numeric_exit();
-                    break;
-                }
-            }
             expandT(dz_, dca_, false);
             LSCQP_BLOCK_SYNC();
             LSCQP_T(5);
@@ -1685,21 +1729,25 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
 #ifndef LSCQP_SOLVE_FROM_LDS
                 // (W = 1: lanes without a row parked zeros in the shared dummy row, nothing to mask; with more wavefronts the
                 // dummy row holds whatever the last lane parked)
+                {
+                    const FT* const prow = park_ptr(lvz_);
+                    const bool has_row = C::ND ? ((lvz_ >> 6) < 2 && (lvz_ & 63) < C::NB + C::NS) : (W == 1 || zl);
 #pragma unroll
-                for (int cidx = 0; cidx < NZ; cidx++) {
-                    const FT v = hrow[cidx];
-                    A[cidx] = (W == 1 || zl) ? v : (FT)0;
+                    for (int cidx = 0; cidx < C::NAR; cidx++) {
+                        const FT v = prow[cidx];
+                        A[cidx] = has_row ? v : (FT)0;
+                    }
                 }
 #endif
             }
             const double dzc = solve(-gcost + gb);
             {  // the scratch row must be all-zero outside the assembly pattern again
                 LSCQP_PHASE_LANE(lvp_);
-                FT* const hrow = &Hs[(lvp_ < NZ ? lvp_ : NZ) * LDH];
+                FT* const hrow = &Hs[lane_slot(lvp_) * LDH];
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) hrow[cidx] = (FT)0;
             }
-            if (zl) dz_[lane] = dzc;  // expandT(dca_) finished reading dz_ before
+            if (zl) dz_[zi0] = dzc;  // expandT(dca_) finished reading dz_ before
             LSCQP_BLOCK_SYNC();
             expandT(dz_, dc_, false);
             LSCQP_BLOCK_SYNC();
@@ -1806,7 +1854,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             LSCQP_T(8);
             LSCQP_STOP(9)
             // ============ update of z and the control points =================================================
-            if (zl) z_[lane] += alpha * dzc;
+            if (zl) z_[zi0] += alpha * dzc;
             LSCQP_BLOCK_SYNC();
             // c = c_fixed + T z, recomputed from z so the eliminated equalities hold to rounding every iteration
             expandT(z_, c_, true);
