@@ -358,6 +358,53 @@ int lscqp_select_neighbours_device(lscqp_handle h, int64_t n_agents, int64_t fir
 int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, double z_2d, const double* d_x_prev,
                             double* d_traj, void* stream);
 
+/* lscqp_generate_constraints_device writing into a row buffer that holds n_obs_total obstacle slots per agent: the n_obs
+ * neighbour slots of this call go to slots slot0 .. slot0 + n_obs - 1 of each agent's block (the other slots belong to another
+ * producer, e.g. lscqp_generate_lsc_obstacles_device).  n_obs_total = n_obs, slot0 = 0 is lscqp_generate_constraints_device. */
+int lscqp_generate_constraints_device_ex(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                         const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                         const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
+                                         int32_t slot0, void* stream);
+
+/* The NON-AGENT branches of TrajPlanner::generateLSC (reference src/traj_planner.cpp:611-657) with what feeds them:
+ * constant-velocity prediction of a dynamic obstacle (obstaclePredictionWithPrevSol :283-285, Trajectory::planConstVelTraj,
+ * src/trajectory.cpp:79-91), checkObstacleDisturbance (:312-319), obstacleSizePredictionWithConstAcc (:321-358: the obstacle's
+ * radius grows with 1/2 max_acc t^2 over the uncertainty horizon, plus a velocity guard of the planning agent), downwashBetween
+ * for a non-agent (:1235-1237), the z component of the relative hull dropped for obstacles taller than obs_downwash_threshold
+ * (:1188-1191), margin d = predicted size + agent radius (:646-648), and the fallback normal (:624-633).
+ * (normalVectorDynamicObs, :1207-1227, is dead code in the reference: col_pred_obs_indices is never filled.)
+ *   d_obstacle_ids [n_agents][n_dyn]  index into d_obstacles of each local agent's obstacles, < 0 = none -> all-zero rows
+ *   d_obstacles    [..]               the obstacle table (include/obstacle.hpp:13-27, the fields the planner reads)
+ *   d_traj         [n_total][M][n+1][3]  initial trajectories (only the local agents' are read), d_radius [n_total]
+ *   d_goal         [n_agents][3]      current goal points of the local agents;  d_hdr [n_agents]: v0 and amax[0] (velocity guard)
+ *   rows go to slots slot0 .. slot0 + n_dyn - 1 of each agent's block of n_obs_total slots in d_rows_out. */
+typedef struct lscqp_obstacle {
+    double position[3];
+    double velocity[3];
+    double radius, downwash, max_acc;
+    int32_t type; /* 0 = DYNAMICOBSTACLE, 1 = AGENT (include/sp_const.hpp:135-138) */
+    int32_t reserved;
+} lscqp_obstacle;
+typedef struct lscqp_obstacle_param { /* src/param.cpp:63-67, 106-108 */
+    double obs_uncertainty_horizon; /* obs/uncertainty_horizon (1) */
+    double velocity_guard_ratio;    /* obs/velocity_guard_ratio (0.75) */
+    double obs_downwash_threshold;  /* plan/obs_downwash_threshold (3.0) */
+    double reset_threshold;         /* plan/reset_threshold (0.1; 0.5 in the launch files) */
+    int32_t obs_size_prediction;    /* obs/size_prediction (true) */
+    int32_t use_velocity_guard;     /* obs/use_velocity_guard (true) */
+} lscqp_obstacle_param;
+int lscqp_generate_lsc_obstacles_device(lscqp_handle h, const lscqp_obstacle_param* param, int64_t n_agents, int32_t n_dyn,
+                                        int64_t first_agent, const double* d_traj, const int32_t* d_obstacle_ids,
+                                        const lscqp_obstacle* d_obstacles, const double* d_radius, const double* d_goal,
+                                        const lscqp_header* d_hdr, lscqp_row* d_rows_out, int32_t n_obs_total, int32_t slot0, void* stream);
+
+/* initialTrajPlanningPrevSol / obstaclePredictionWithPrevSol when the simulation step is SHORTER than a segment
+ * (multisim_time_step < dt, reference src/traj_planner.cpp:296-306, 413-421): segment 0 of the new initial trajectory :=
+ * prev_traj[0].subSegment(fraction, 1) (Segment::subSegment, src/trajectory.cpp:15-49), the other segments are kept.
+ * fraction = multisim_time_step / dt in (0, 1); layouts and float32 truncation as lscqp_shift_traj_device. */
+int lscqp_shift_traj_partial_device(lscqp_handle h, int64_t n, double fraction, double z_2d, const double* d_x_prev, double* d_traj,
+                                    void* stream);
+
 /* Algorithmic HBM bytes of one lscqp_generate_lsc_device call: rows written + every agent's control points,
  * neighbour list, radius, downwash and goal read once. */
 int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t n_total);

@@ -31,6 +31,15 @@ ROWS_F64, ROWS_F32 = 0, 1
 BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)])
 SAFETY_DTYPE = np.dtype([("safety_ratio", "f8"), ("closest_agent", "i4"), ("sample", "i4"), ("vel_excess_ratio", "f8", 3),
                          ("acc_excess_ratio", "f8", 3)])
+OBSTACLE_DTYPE = np.dtype([("position", "f8", 3), ("velocity", "f8", 3), ("radius", "f8"), ("downwash", "f8"), ("max_acc", "f8"),
+                           ("type", "i4"), ("reserved", "i4")])  # lscqp_obstacle
+
+
+class ObstacleParam(C.Structure):  # lscqp_obstacle_param
+    _fields_ = [("obs_uncertainty_horizon", C.c_double), ("velocity_guard_ratio", C.c_double), ("obs_downwash_threshold", C.c_double),
+                ("reset_threshold", C.c_double), ("obs_size_prediction", C.c_int32), ("use_velocity_guard", C.c_int32)]
+
+
 INFO_DTYPE = np.dtype([("iterations", "i4"), ("flags", "i4"), ("res_primal", "f8"), ("res_dual", "f8"),
                        ("gap", "f8")])
 assert HEADER_DTYPE.itemsize == 256 and ROW_DTYPE.itemsize == 32 and BOX_DTYPE.itemsize == 48
@@ -126,6 +135,12 @@ def lib():
         L.lscqp_generate_lsc_device.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_generate_constraints_device.restype = C.c_int
         L.lscqp_generate_constraints_device.argtypes = [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7
+        L.lscqp_generate_constraints_device_ex.restype = C.c_int
+        L.lscqp_generate_constraints_device_ex.argtypes = [vp, C.c_int32, C.c_int64, C.c_int32, C.c_int64] + [vp] * 6 + [C.c_int32, C.c_int32, vp]
+        L.lscqp_generate_lsc_obstacles_device.restype = C.c_int
+        L.lscqp_generate_lsc_obstacles_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int64] + [vp] * 7 + [C.c_int32, C.c_int32, vp]
+        L.lscqp_shift_traj_partial_device.restype = C.c_int
+        L.lscqp_shift_traj_partial_device.argtypes = [vp, C.c_int64, C.c_double, C.c_double, vp, vp, vp]
         L.lscqp_select_neighbours_device.restype = C.c_int
         L.lscqp_select_neighbours_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, vp, vp, vp, vp]
         L.lscqp_shift_traj_device.restype = C.c_int
@@ -166,7 +181,8 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
-                    "lscqp_shift_traj_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
+                    "lscqp_shift_traj_device", "lscqp_shift_traj_partial_device", "lscqp_generate_constraints_device_ex",
+                    "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
                     "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_last_error", "lscqp_version"]
 
@@ -531,6 +547,42 @@ class Solver:
         s = stream if stream is not None else torch.cuda.current_stream()
         rc = lib().lscqp_shift_traj_device(self._h, n, int(shift), float(z_2d), C.c_void_p(d_x_prev.data_ptr()), C.c_void_p(d_traj.data_ptr()),
                                            C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def shift_traj_partial_device(self, n, d_x_prev, d_traj, fraction, z_2d=1.0, stream=None):
+        """multisim_time_step < dt: segment 0 := subSegment(fraction, 1) of the previous plan's, the others kept."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_shift_traj_partial_device(self._h, n, float(fraction), float(z_2d), C.c_void_p(d_x_prev.data_ptr()),
+                                                   C.c_void_p(d_traj.data_ptr()), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def generate_constraints_device_ex(self, mode, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal_all,
+                                       d_rows, n_obs_total, slot0, stream=None):
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_generate_constraints_device_ex(self._h, int(mode), n_agents, n_obs, first_agent, C.c_void_p(d_traj.data_ptr()),
+                                                        C.c_void_p(d_neighbours.data_ptr()), C.c_void_p(d_radius.data_ptr()),
+                                                        C.c_void_p(d_downwash.data_ptr()), C.c_void_p(d_goal_all.data_ptr()),
+                                                        C.c_void_p(d_rows.data_ptr()), int(n_obs_total), int(slot0), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def generate_lsc_obstacles_device(self, param, n_agents, n_dyn, first_agent, d_traj, d_ids, d_obstacles, d_radius, d_goal, d_hdr, d_rows,
+                                      n_obs_total, slot0, stream=None):
+        """generateLSC for non-agent obstacles (param: ObstacleParam; d_obstacles: OBSTACLE_DTYPE table on the device)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_generate_lsc_obstacles_device(self._h, C.cast(C.byref(param), C.c_void_p), n_agents, n_dyn, first_agent,
+                                                       C.c_void_p(d_traj.data_ptr()), C.c_void_p(d_ids.data_ptr()),
+                                                       C.c_void_p(d_obstacles.data_ptr()), C.c_void_p(d_radius.data_ptr()),
+                                                       C.c_void_p(d_goal.data_ptr()), C.c_void_p(d_hdr.data_ptr()), C.c_void_p(d_rows.data_ptr()),
+                                                       int(n_obs_total), int(slot0), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
                                                                 const double* __restrict__ downwash,
                                                                 const double* __restrict__ goal,
                                                                 const double* __restrict__ goal_all, int rows_f32,
-                                                                lscqp_row* __restrict__ out) {
+                                                                int32_t n_obs_total, int32_t slot0, lscqp_row* __restrict__ out) {
     __shared__ double4 stage[kThreads * 6];  // the block's rows in output order: [lane][row], 32 B each (48 KiB)
     const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     const bool live = t < n_units;
@@ -439,10 +439,17 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
         const int rix = k * kThreads + threadIdx.x;  // row index within the block
         if (base_row + rix < n_rows) {
             const double4 v = stage[rix];
+            // destination: the unit's rows inside an agent's block of n_obs_total obstacle slots, starting at slot0 (the
+            // identity when this generator fills all slots)
+            int64_t dst = base_row + rix;
+            if (n_obs_total != n_obs || slot0 != 0) {
+                const int64_t u = dst / 6, kk = dst % 6, mm = u % M, ao_ = u / M;
+                dst = (((ao_ / n_obs) * n_obs_total + slot0 + (ao_ % n_obs)) * M + mm) * 6 + kk;
+            }
             if (rows_f32)
-                o4f[base_row + rix] = float4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+                o4f[dst] = float4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
             else
-                o4[base_row + rix] = v;
+                o4[dst] = v;
         }
     }
 }
@@ -465,6 +472,145 @@ __global__ __launch_bounds__(kThreads) void shift_traj_kernel(int M, int dim, in
     o[0] = (double)(float)x[(0 * M + ms) * 6 + is];
     o[1] = (double)(float)x[(1 * M + ms) * 6 + is];
     o[2] = (dim == 3) ? (double)(float)x[(2 * M + ms) * 6 + is] : (double)(float)z_2d;
+}
+
+// initialTrajPlanningPrevSol / obstaclePredictionWithPrevSol when the simulation step is SHORTER than a segment
+// (multisim_time_step < dt, reference src/traj_planner.cpp:296-306, 413-421): segment 0 := prev_traj[0].subSegment(fraction, 1)
+// (Segment::subSegment, src/trajectory.cpp:15-49: control points x (B A B^-1), W = B A B^-1 computed by the host in double), the other
+// segments are kept.  Same layouts and float32 truncation as shift_traj_kernel.
+struct SubSegW {
+    double w[36];
+};
+__global__ __launch_bounds__(kThreads) void shift_traj_partial_kernel(int M, int dim, int64_t n, SubSegW W, double z_2d,
+                                                                      const double* __restrict__ x_prev, double* __restrict__ traj) {
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n * M * 6) return;
+    const int i = (int)(t % 6);
+    const int m = (int)((t / 6) % M);
+    const int64_t a = t / (6 * M);
+    const double* x = x_prev + a * dim * M * 6;
+    double* o = traj + ((a * M + m) * 6 + i) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double v;
+        if (k == 2 && dim != 3) {
+            v = (double)(float)z_2d;  // every control point of the previous plan sits at z_2d: the sub-segment too
+        } else if (m == 0) {
+            v = 0;
+#pragma unroll
+            for (int l = 0; l < 6; l++) v += (double)(float)x[(k * M + 0) * 6 + l] * W.w[l * 6 + i];
+            v = (double)(float)v;
+        } else {
+            v = (double)(float)x[(k * M + m) * 6 + i];
+        }
+        o[k] = v;
+    }
+}
+
+// generateLSC for NON-AGENT obstacles (reference src/traj_planner.cpp:611-657): constant-velocity prediction
+// (obstaclePredictionWithPrevSol :283-285 with Trajectory::planConstVelTraj, src/trajectory.cpp:79-91), disturbance reset (:312-319),
+// size prediction under bounded acceleration (:321-358), downwashBetween for a non-agent (:1235-1237), the z component of the
+// relative hull dropped for tall dynamic obstacles (:1188-1191), margin d = predicted size + agent radius (:646-648), fallback
+// normal (:624-633).  One lane per (agent a, obstacle slot o, segment m); rows go to slots slot0 .. slot0+n_dyn-1 of the agent's
+// block of n_obs_total obstacle slots.  Compiled without FMA contraction like the rest of this file's float32 restatements.
+__global__ __launch_bounds__(kThreads) void generate_lsc_obstacle_kernel(int M, int dim, double dt, lscqp_obstacle_param P, int64_t n_units,
+                                                                         int32_t n_dyn, int64_t first_agent, const double* __restrict__ traj,
+                                                                         const int32_t* __restrict__ ids, const lscqp_obstacle* __restrict__ table,
+                                                                         const double* __restrict__ radius, const double* __restrict__ goal,
+                                                                         const lscqp_header* __restrict__ hdr, int rows_f32, int32_t n_obs_total,
+                                                                         int32_t slot0, const double* __restrict__ binv3, lscqp_row* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= n_units) return;
+    const int m = (int)(t % M);
+    const int64_t ao = t / M;
+    const int o = (int)(ao % n_dyn);
+    const int64_t a = ao / n_dyn;
+    const int64_t ga = first_agent + a;
+    const int32_t id = ids[a * n_dyn + o];
+    const int64_t row0 = (((a * n_obs_total) + slot0 + o) * M + m) * 6;
+    double4* o4 = reinterpret_cast<double4*>(out);
+    float4* o4f = reinterpret_cast<float4*>(out);
+    auto put = [&](int i, double4 v) {
+        if (rows_f32)
+            o4f[row0 + i] = float4{(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+        else
+            o4[row0 + i] = v;
+    };
+    if (id < 0) {  // no obstacle in this slot: all-zero rows, which the solver drops (:409-411)
+        for (int i = 0; i < 6; i++) put(i, double4{0, 0, 0, 0});
+        return;
+    }
+    const lscqp_obstacle ob = table[id];
+    const double r_own = radius[ga];
+    // prediction of segment m: p + v * (float)time, time accumulated in double from 0 in steps of dt / n (planConstVelTraj).
+    // checkObstacleDisturbance compares its start point with the obstacle's position: identical by construction.
+    double time = 0;
+    for (int s_ = 0; s_ < m * 6; s_++) time += dt / 5;
+    P3 pobs[6];
+    const double* own = traj + (ga * M + m) * 18;
+    const double dw = (dim == 3) ? (r_own + ob.downwash * ob.radius) / (r_own + ob.radius) : 1.0;
+    const float dwf = (float)dw;
+    const bool flat = ob.type == 0 && ob.downwash > P.obs_downwash_threshold;
+    float relf[6][3];
+    P3 rel[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float tf = (float)time;
+        const float bx = (float)ob.position[0] + (float)ob.velocity[0] * tf, by = (float)ob.position[1] + (float)ob.velocity[1] * tf,
+                    bz = (float)ob.position[2] + (float)ob.velocity[2] * tf;
+        time += dt / 5;
+        pobs[i] = {(double)bx, (double)by, (double)bz};
+        float azf = (float)own[3 * i + 2], bzf = bz;
+        if (dim == 3) {
+            azf = azf / dwf;
+            bzf = bzf / dwf;
+        }
+        relf[i][0] = (float)own[3 * i] - bx;
+        relf[i][1] = (float)own[3 * i + 1] - by;
+        relf[i][2] = (dim == 3 && !flat) ? azf - bzf : 0.0f;
+        rel[i] = {(double)relf[i][0], (double)relf[i][1], (double)relf[i][2]};
+    }
+    const P3 cp = hull_closest_point(rel, dim == 2 || flat);
+    float nx = (float)cp.x, ny = (float)cp.y, nz = (float)cp.z;
+    float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    if (len < 1e-5f) {
+        const double* g = goal + 3 * a;
+        nx = (float)(g[0] - ob.position[0]);
+        ny = (float)(g[1] - ob.position[1]);
+        nz = (dim == 3) ? (float)(g[2] - ob.position[2]) / dwf : 0.0f;
+        len = sqrtf(nx * nx + ny * ny + nz * nz);
+    }
+    if (len > 0.0f) {
+        nx /= len;
+        ny /= len;
+        nz /= len;
+    }
+    // predicted size of segment m (obstacleSizePredictionWithConstAcc); binv3: rows 0..2 of B^-1 (host, closed form)
+    double guard = 0;
+    if (P.use_velocity_guard) {
+        const float vx = (float)hdr[a].v0[0], vy = (float)hdr[a].v0[1], vz = (float)hdr[a].v0[2];
+        guard = P.velocity_guard_ratio * (double)(vx * vx + vy * vy + vz * vz) / hdr[a].amax[0];
+    }
+    const int Mu = (int)((P.obs_uncertainty_horizon + 1e-9) / dt);
+    const bool grow = P.obs_size_prediction && ob.type == 0;
+    const double onx = (double)nx, ony = (double)ny;
+    const double onz = (dim == 3) ? (double)(float)((double)nz / dw) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double size = ob.radius;
+        if (grow) {
+            if (m < Mu) {
+                const double c0 = 0.5 * ob.max_acc * pow(m * dt, 2), c1 = ob.max_acc * m * dt * dt, c2 = 0.5 * ob.max_acc * pow(dt, 2);
+                size = ob.radius + guard + (c0 * binv3[i] + c1 * binv3[6 + i] + c2 * binv3[12 + i]);
+            } else {
+                size = ob.radius + guard + 0.5 * ob.max_acc * pow(Mu * dt, 2);
+            }
+        }
+        const double d = size + r_own;
+        put(i, double4{onx, ony, onz, d + (onx * pobs[i].x + ony * pobs[i].y + onz * pobs[i].z)});
+    }
 }
 
 // MultiSyncSimulator::broadcastMsgs (reference src/multi_sync_simulator.cpp:305-352): agent i receives every other agent j
@@ -613,7 +759,7 @@ extern "C" int lscqp_select_neighbours_raw_(int64_t n_agents, int64_t first_agen
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
-                                       lscqp_row* d_rows_out, void* stream) {
+                                       int32_t n_obs_total, int32_t slot0, lscqp_row* d_rows_out, void* stream) {
     const int64_t n_units = n_agents * (int64_t)n_obs * M;
     if (n_units == 0) return LSCQP_OK;
     const unsigned blocks = (unsigned)((n_units + lscgen::kThreads - 1) / lscgen::kThreads);
@@ -621,7 +767,35 @@ extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agent
                  : mode == LSCQP_GEN_BVC ? lscgen::generate_lsc_kernel<LSCQP_GEN_BVC>
                                          : lscgen::generate_lsc_kernel<LSCQP_GEN_LSC>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n_units, n_obs, first_agent, d_traj,
-                       d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, rows_f32, d_rows_out);
+                       d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, rows_f32, n_obs_total, slot0, d_rows_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
+
+extern "C" int lscqp_shift_traj_partial_raw_(int M, int dim, int64_t n, const double* w36, double z_2d, const double* d_x_prev, double* d_traj,
+                                             void* stream) {
+    const int64_t total = n * M * 6;
+    if (total == 0) return LSCQP_OK;
+    lscgen::SubSegW W;
+    for (int i = 0; i < 36; i++) W.w[i] = w36[i];
+    const unsigned blocks = (unsigned)((total + lscgen::kThreads - 1) / lscgen::kThreads);
+    hipLaunchKernelGGL(lscgen::shift_traj_partial_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n, W, z_2d,
+                       d_x_prev, d_traj);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
+
+extern "C" int lscqp_generate_lsc_obstacles_raw_(int M, int dim, double dt, const lscqp_obstacle_param* p, int64_t n_agents, int32_t n_dyn,
+                                                 int64_t first_agent, const double* d_traj, const int32_t* d_ids, const lscqp_obstacle* d_table,
+                                                 const double* d_radius, const double* d_goal, const lscqp_header* d_hdr, int rows_f32,
+                                                 int32_t n_obs_total, int32_t slot0, const double* d_binv3, lscqp_row* d_rows_out, void* stream) {
+    const int64_t n_units = n_agents * (int64_t)n_dyn * M;
+    if (n_units == 0) return LSCQP_OK;
+    const unsigned blocks = (unsigned)((n_units + lscgen::kThreads - 1) / lscgen::kThreads);
+    hipLaunchKernelGGL(lscgen::generate_lsc_obstacle_kernel, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, dt, *p, n_units,
+                       n_dyn, first_agent, d_traj, d_ids, d_table, d_radius, d_goal, d_hdr, rows_f32, n_obs_total, slot0, d_binv3, d_rows_out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;

@@ -25,7 +25,13 @@ LSCQP_INSTANCES(LSCQP_DECL)
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
-                                       lscqp_row* d_rows_out, void* stream);
+                                       int32_t n_obs_total, int32_t slot0, lscqp_row* d_rows_out, void* stream);
+extern "C" int lscqp_shift_traj_partial_raw_(int M, int dim, int64_t n, const double* w36, double z_2d, const double* d_x_prev, double* d_traj,
+                                             void* stream);
+extern "C" int lscqp_generate_lsc_obstacles_raw_(int M, int dim, double dt, const lscqp_obstacle_param* p, int64_t n_agents, int32_t n_dyn,
+                                                 int64_t first_agent, const double* d_traj, const int32_t* d_ids, const lscqp_obstacle* d_table,
+                                                 const double* d_radius, const double* d_goal, const lscqp_header* d_hdr, int rows_f32,
+                                                 int32_t n_obs_total, int32_t slot0, const double* d_binv3, lscqp_row* d_rows_out, void* stream);
 extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
 extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
@@ -245,13 +251,94 @@ int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, i
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     return lscqp_generate_lsc_raw_(LSCQP_GEN_LSC, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
-                                   d_downwash, d_goal, nullptr, h->dev.rows_f32, d_rows_out, stream);
+                                   d_downwash, d_goal, nullptr, h->dev.rows_f32, n_obs, 0, d_rows_out, stream);
 }
 
 int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                       const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
                                       const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, void* stream) {
+    return lscqp_generate_constraints_device_ex(h, mode, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius, d_downwash, d_goal_all,
+                                                d_rows_out, n_obs, 0, stream);
+}
+
+// rows 0..2 of B^-1 for n = 5 (monomial -> Bernstein, closed form C(j,i) / C(n,i)): the size polynomial of
+// obstacleSizePredictionWithConstAcc has monomial coefficients (c0, c1, c2, 0, 0, 0)
+static const double* device_binv3() {
+    static double* d[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!d[dev]) {
+        auto C5 = [](int n_, int k_) { double r = 1; for (int i = 1; i <= k_; i++) r = r * (n_ - k_ + i) / i; return r; };
+        double hbuf[18];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 6; j++) hbuf[i * 6 + j] = (j >= i) ? C5(j, i) / C5(5, i) : 0.0;
+        if (hipMalloc(&d[dev], sizeof hbuf) != hipSuccess) return nullptr;
+        if (hipMemcpy(d[dev], hbuf, sizeof hbuf, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    }
+    return d[dev];
+}
+
+int lscqp_generate_lsc_obstacles_device(lscqp_handle h, const lscqp_obstacle_param* param, int64_t n_agents, int32_t n_dyn,
+                                        int64_t first_agent, const double* d_traj, const int32_t* d_obstacle_ids,
+                                        const lscqp_obstacle* d_obstacles, const double* d_radius, const double* d_goal,
+                                        const lscqp_header* d_hdr, lscqp_row* d_rows_out, int32_t n_obs_total, int32_t slot0, void* stream) {
+    if (!h || !param) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_agents < 0 || n_dyn < 0 || first_agent < 0 || slot0 < 0 || n_obs_total < slot0 + n_dyn)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes (n_obs_total >= slot0 + n_dyn required)");
+    if (h->desc.M > 32) return fail(LSCQP_ERR_UNSUPPORTED, "obstacle prediction supports M <= 32");
+    if (n_agents == 0 || n_dyn == 0) return LSCQP_OK;
+    if (!d_traj || !d_obstacle_ids || !d_obstacles || !d_radius || !d_goal || !d_hdr || !d_rows_out)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    const double* binv3 = device_binv3();
+    if (!binv3) return fail(LSCQP_ERR_HIP, "constant upload failed");
+    return lscqp_generate_lsc_obstacles_raw_(h->desc.M, h->desc.dim, h->desc.dt, param, n_agents, n_dyn, first_agent, d_traj, d_obstacle_ids,
+                                             d_obstacles, d_radius, d_goal, d_hdr, h->dev.rows_f32, n_obs_total, slot0, binv3, d_rows_out, stream);
+}
+
+int lscqp_shift_traj_partial_device(lscqp_handle h, int64_t n, double fraction, double z_2d, const double* d_x_prev, double* d_traj,
+                                    void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    if (!(fraction > 0.0 && fraction < 1.0)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "fraction = multisim_time_step / dt must lie in (0, 1)");
+    if (n == 0) return LSCQP_OK;
+    if (!d_x_prev || !d_traj) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    // W = B A B^-1 (src/trajectory.cpp:24-38): B Bernstein -> monomial (include/polynomial.hpp:281-294), A(i,j) = C(i,j) a^j b^(i-j) for
+    // t -> a t + b with b = fraction, a = 1 - fraction, B^-1 in closed form
+    auto Cn = [](int n_, int k_) { double r = 1; for (int i = 1; i <= k_; i++) r = r * (n_ - k_ + i) / i; return k_ > n_ ? 0.0 : r; };
+    double B[6][6], Bi[6][6], A[6][6], BA[6][6], W[36];
+    const double b = fraction, a = 1.0 - fraction;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            B[i][j] = (j >= i) ? Cn(5, i) * Cn(5 - i, 5 - j) * (((j - i) & 1) ? -1.0 : 1.0) : 0.0;
+            Bi[i][j] = (j >= i) ? Cn(j, i) / Cn(5, i) : 0.0;
+            A[i][j] = (j <= i) ? Cn(i, j) * std::pow(a, j) * std::pow(b, i - j) : 0.0;
+        }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            BA[i][j] = 0;
+            for (int l = 0; l < 6; l++) BA[i][j] += B[i][l] * A[l][j];
+        }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) {
+            double v = 0;
+            for (int l = 0; l < 6; l++) v += BA[i][l] * Bi[l][j];
+            W[i * 6 + j] = v;
+        }
+    return lscqp_shift_traj_partial_raw_(h->desc.M, h->desc.dim, n, W, z_2d, d_x_prev, d_traj, stream);
+}
+
+int lscqp_generate_constraints_device_ex(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                         const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                         const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
+                                         int32_t slot0, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (slot0 < 0 || n_obs_total < slot0 + n_obs) return fail(LSCQP_ERR_INVALID_ARGUMENT, "n_obs_total >= slot0 + n_obs required");
     if (mode != LSCQP_GEN_LSC && mode != LSCQP_GEN_CLSC && mode != LSCQP_GEN_BVC)
         return fail(LSCQP_ERR_INVALID_ARGUMENT, "mode must be LSCQP_GEN_LSC, LSCQP_GEN_CLSC or LSCQP_GEN_BVC");
     if (n_agents < 0 || n_obs < 0 || first_agent < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
@@ -262,7 +349,7 @@ int lscqp_generate_constraints_device(lscqp_handle h, int32_t mode, int64_t n_ag
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     return lscqp_generate_lsc_raw_(mode, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
-                                   d_downwash, d_goal_all + 3 * first_agent, d_goal_all, h->dev.rows_f32, d_rows_out, stream);
+                                   d_downwash, d_goal_all + 3 * first_agent, d_goal_all, h->dev.rows_f32, n_obs_total, slot0, d_rows_out, stream);
 }
 
 int lscqp_shift_traj_device(lscqp_handle h, int64_t n, int32_t shift_segments, double z_2d, const double* d_x_prev, double* d_traj,

@@ -14,6 +14,39 @@ public:
     T lastPoint() const { return control_points.back(); }
     T operator[](int idx) const { return control_points[idx]; }
     T& operator[](int idx) { return control_points[idx]; }
+    // Control points of the piece [t_normalized_0, t_normalized_f] of this segment (src/trajectory.cpp:15-49): the row vectors of
+    // the control points times B A B^-1, t -> a t + b, evaluated in double and rounded by T's constructor; segment_time scales with
+    // a.  (The reference's generic template logs "Wrong usage"; like there, only 3-component point types are meaningful.)
+    Segment<T> subSegment(double t_normalized_0, double t_normalized_f, const Eigen::MatrixXd& B, const Eigen::MatrixXd& B_inv) const {
+        const double b = t_normalized_0, a = t_normalized_f - t_normalized_0;
+        const int n = (int)control_points.size() - 1;
+        Eigen::MatrixXd A = Eigen::MatrixXd::Zero(n + 1, n + 1);
+        for (int i = 0; i < n + 1; i++)
+            for (int j = 0; j < i + 1; j++) A(i, j) = nChoosek(i, j) * std::pow(a, j) * std::pow(b, i - j);
+        Segment<T> sub_segment;
+        sub_segment.segment_time = segment_time * a;
+        sub_segment.control_points.resize(n + 1);
+        std::vector<double> out(3 * (n + 1));
+        for (int k = 0; k < 3; k++) {
+            std::vector<double> c(n + 1), t1(n + 1), t2(n + 1);
+            for (int i = 0; i < n + 1; i++) c[i] = control_points[i](k);
+            for (int j = 0; j < n + 1; j++) {
+                t1[j] = 0;
+                for (int l = 0; l < n + 1; l++) t1[j] += c[l] * B(l, j);
+            }
+            for (int j = 0; j < n + 1; j++) {
+                t2[j] = 0;
+                for (int l = 0; l < n + 1; l++) t2[j] += t1[l] * A(l, j);
+            }
+            for (int j = 0; j < n + 1; j++) {
+                double v = 0;
+                for (int l = 0; l < n + 1; l++) v += t2[l] * B_inv(l, j);
+                out[3 * j + k] = v;
+            }
+        }
+        for (int i = 0; i < n + 1; i++) sub_segment.control_points[i] = T((float)out[3 * i], (float)out[3 * i + 1], (float)out[3 * i + 2]);
+        return sub_segment;
+    }
 };
 
 template <typename T>

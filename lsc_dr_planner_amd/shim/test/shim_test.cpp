@@ -409,6 +409,22 @@ static int scenario_dynamic_obstacle() {
     return 0;
 }
 
+// Segment::subSegment (src/trajectory.cpp:15-49): the piece [0.5, 1] of a segment
+static int scenario_subsegment() {
+    Param param;
+    Eigen::MatrixXd B, B_inv;
+    buildBernsteinBasis(param.n, B, B_inv);
+    Segment<point3d> s;
+    s.segment_time = 0.2;
+    const float pts[6][3] = {{0.0f, 0.0f, 1.0f}, {0.1f, 0.02f, 1.0f}, {0.25f, 0.1f, 1.05f}, {0.45f, 0.3f, 1.1f}, {0.6f, 0.55f, 1.2f}, {0.7f, 0.9f, 1.25f}};
+    for (auto& p : pts) s.control_points.push_back(point3d(p[0], p[1], p[2]));
+    Segment<point3d> h = s.subSegment(0.5, 1.0, B, B_inv);
+    printf("{\"scenario\": \"subsegment\", \"segment_time\": %.17g, \"cp\": [", h.segment_time);
+    for (int i = 0; i < 6; i++) printf("[%.9g, %.9g, %.9g]%s", h[i].x(), h[i].y(), h[i].z(), i < 5 ? ", " : "");
+    printf("]}\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string s = argc > 1 ? argv[1] : "host";
     if (s == "host") return scenario_host();
@@ -417,6 +433,7 @@ int main(int argc, char** argv) {
     if (s == "infeasible") return scenario_infeasible();
     if (s == "goal") return scenario_goal();
     if (s == "sharded") return scenario_sharded();
+    if (s == "subsegment") return scenario_subsegment();
     if (s == "dynamic_obstacle") return scenario_dynamic_obstacle();
     if (s == "csv" && argc > 2) return scenario_csv(argv[2]);
     if (s == "sfc" && argc > 2) return scenario_sfc(argv[2]);

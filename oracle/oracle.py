@@ -53,7 +53,7 @@ _REFERENCE = "/root/reference"
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscmode_oracle.c", "lscsfc_oracle.c", "Makefile", "lscqp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lscqp_oracle.c", "lscgen_oracle.c", "lscgoal_oracle.c", "lscpost_oracle.c", "lscmode_oracle.c", "lscsfc_oracle.c", "lscpred_oracle.c", "Makefile", "lscqp_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
@@ -116,6 +116,11 @@ def lib():
         _lib.orc_hull_closest_point.argtypes = [dp, C.c_int, dp]
         _lib.orc_generate_lsc.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp, dp, dp, C.c_void_p]
         _lib.orc_generate_mode.argtypes = [C.c_int] * 6 + [dp, ip, dp, dp, dp, C.c_void_p]
+        _lib.orc_sub_segment.argtypes = [dp, C.c_double, C.c_double, dp]
+        _lib.orc_shift_prev_plan.argtypes = [C.c_int, C.c_double, dp, dp]
+        _lib.orc_const_vel_traj.argtypes = [C.c_int, C.c_double, dp, dp, dp]
+        _lib.orc_obstacle_sizes.argtypes = [C.c_int, C.c_void_p, C.c_void_p, dp, C.c_double, dp]
+        _lib.orc_generate_lsc_obstacle.argtypes = [C.c_int, C.c_int, C.c_void_p, dp, dp, C.c_double, dp, C.c_double, C.c_void_p, C.c_void_p]
         _lib.orc_select_neighbours.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, dp, ip, ip]
         _lib.orc_segseg_closest.restype = C.c_double
         _lib.orc_segseg_closest.argtypes = [dp] * 6
@@ -281,6 +286,74 @@ def generate_lsc(traj, neighbours, radius, downwash, goal, dim=3, first_agent=0)
 
 
 MODE_LSC, MODE_CLSC, MODE_BVC = 0, 1, 2
+
+
+OBSTACLE_DTYPE = np.dtype([("position", "f8", 3), ("velocity", "f8", 3), ("radius", "f8"), ("downwash", "f8"), ("max_acc", "f8"),
+                           ("type", "i4"), ("pad", "i4")])  # orc_obstacle == lscqp_obstacle
+
+
+class ObsParam(C.Structure):  # orc_obs_param
+    _fields_ = [("dt", C.c_double), ("obs_uncertainty_horizon", C.c_double), ("velocity_guard_ratio", C.c_double),
+                ("obs_downwash_threshold", C.c_double), ("reset_threshold", C.c_double), ("obs_size_prediction", C.c_int),
+                ("use_velocity_guard", C.c_int)]
+
+
+def obs_param(dt=0.2, obs_uncertainty_horizon=1.0, velocity_guard_ratio=0.75, obs_downwash_threshold=3.0, reset_threshold=0.1,
+              obs_size_prediction=True, use_velocity_guard=True):
+    """Defaults of src/param.cpp:63-67, 106-108."""
+    return ObsParam(dt, obs_uncertainty_horizon, velocity_guard_ratio, obs_downwash_threshold, reset_threshold,
+                    int(obs_size_prediction), int(use_velocity_guard))
+
+
+def sub_segment(cp, t0, tf):
+    """Segment<point3d>::subSegment (reference src/trajectory.cpp:15-49): cp (6, 3) -> (6, 3)."""
+    cp = np.ascontiguousarray(cp, dtype=np.float64).reshape(6, 3)
+    out = np.zeros((6, 3))
+    lib().orc_sub_segment(_dp(cp), C.c_double(t0), C.c_double(tf), _dp(out))
+    return out
+
+
+def shift_prev_plan(prev, fraction):
+    """initialTrajPlanningPrevSol (reference src/traj_planner.cpp:399-423): prev (N, M, 6, 3) -> (N, M, 6, 3); fraction =
+    multisim_time_step / dt (1: shift by a segment, < 1: sub-segment of segment 0)."""
+    prev = np.ascontiguousarray(prev, dtype=np.float64)
+    out = np.zeros_like(prev)
+    for a in range(prev.shape[0]):
+        pa = np.ascontiguousarray(prev[a])
+        oa = np.zeros_like(pa)
+        lib().orc_shift_prev_plan(prev.shape[1], C.c_double(fraction), _dp(pa), _dp(oa))
+        out[a] = oa
+    return out
+
+
+def const_vel_traj(M, dt, pos, vel):
+    out = np.zeros((M, 6, 3))
+    lib().orc_const_vel_traj(M, C.c_double(dt), _dp(np.ascontiguousarray(pos, dtype=np.float64)), _dp(np.ascontiguousarray(vel, dtype=np.float64)), _dp(out))
+    return out
+
+
+def obstacle_sizes(M, param, obstacle, v_agent, amax0):
+    out = np.zeros((M, 6))
+    o = np.ascontiguousarray(obstacle, dtype=OBSTACLE_DTYPE).reshape(1)
+    lib().orc_obstacle_sizes(M, C.byref(param), o.ctypes.data_as(C.c_void_p), _dp(np.ascontiguousarray(v_agent, dtype=np.float64)),
+                             C.c_double(amax0), _dp(out))
+    return out
+
+
+def generate_lsc_obstacles(param, own_traj, goal, r_own, v_agent, amax0, obstacles, dim=3):
+    """generateLSC for non-agent obstacles (reference src/traj_planner.cpp:611-657 with the prediction / size steps before it):
+    own_traj (M, 6, 3), obstacles OBSTACLE_DTYPE[n] -> LSC_DTYPE[n, M, 6]."""
+    own = np.ascontiguousarray(own_traj, dtype=np.float64)
+    M = own.shape[0]
+    obs = np.ascontiguousarray(obstacles, dtype=OBSTACLE_DTYPE).reshape(-1)
+    out = np.zeros((len(obs), M, 6), LSC_DTYPE)
+    for i in range(len(obs)):
+        oi = np.zeros((M, 6), LSC_DTYPE)
+        lib().orc_generate_lsc_obstacle(M, dim, C.byref(param), _dp(own), _dp(np.ascontiguousarray(goal, dtype=np.float64)), C.c_double(r_own),
+                                        _dp(np.ascontiguousarray(v_agent, dtype=np.float64)), C.c_double(amax0),
+                                        obs[i:i + 1].ctypes.data_as(C.c_void_p), oi.ctypes.data_as(C.c_void_p))
+        out[i] = oi
+    return out
 
 
 def generate_constraints(mode, traj, neighbours, radius, downwash, goal_all, dim=3, first_agent=0):
