@@ -64,7 +64,11 @@ enum {
 enum {
     LSCQP_PLANNER_DLSC = 0,
     LSCQP_PLANNER_LSC = 1,
-    LSCQP_PLANNER_BVC = 2
+    LSCQP_PLANNER_BVC = 2,
+    LSCQP_PLANNER_RSFC = 3 /* RECIPROCALRSFC: no end-stop rows, and the z variables of segment 0 are bounded by +-100 instead of the
+                              world box (src/traj_optimizer.cpp:255-258).  That planner runs with slack_mode COLLISIONCONSTRAINT:
+                              every LSC row then carries a slack in (-inf, 0] that appears in no cost term (:272-283, 423-425), i.e.
+                              no LSC row can bind -- callers pass n_obs = 0 (the shim does) */
 };
 
 /* Problem class: everything TrajOptimizer caches from Param/Mission at construction

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LSCQP_LIB") or os.path.join(_HERE, "liblscqp.so")  # 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC, STATUS_CAPACITY = 0, 1, 2, 3, 4
 PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
 INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED = 1, 2, 4  # lscqp_info.flags
-PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC = 0, 1, 2
+PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC, PLANNER_RSFC = 0, 1, 2, 3
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
 SFC_INIT, SFC_FROM_HULL, SFC_FROM_POINT = 0, 1, 2  # lscqp_construct_sfc_device modes
 GEN_LSC, GEN_CLSC, GEN_BVC = 0, 1, 2  # lscqp_generate_constraints_device modes (include/lscqp.h)

@@ -190,6 +190,7 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.n_obs_max = 0;
     c.rows_f32 = d->row_format == LSCQP_ROWS_F32;
     c.repair = 0;
+    c.rsfc = d->planner_mode == LSCQP_PLANNER_RSFC;
     return LSCQP_OK;
 }
 

@@ -42,6 +42,7 @@ struct DevClass {
     int use_sfc;
     int n_obs_max;  // number of obstacles the launch must accommodate (<= NSLOT * G of the instance)
     int rows_f32;   // lscqp_class_desc.row_format == LSCQP_ROWS_F32
+    int rsfc;       // LSCQP_PLANNER_RSFC: z bounds of segment 0 are +-100, not the world box (src/traj_optimizer.cpp:255-258)
     int repair;     // second pass over a batch: only instances whose status_out is neither OPTIMAL nor CAPACITY are solved
 };
 
@@ -683,6 +684,10 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         // (org[] is only ever indexed with constants: a dynamic index would put it in scratch memory)
                         const double ok_ = (k == 0) ? org0 : (k == 1) ? org1 : org2;
                         double lo = cls.world_min[k] - ok_, hi = cls.world_max[k] - ok_;  // :252-253,260-265
+                        if (cls.rsfc && k == 2 && m == 0) {  // :255-258
+                            lo = -100.0 - ok_;
+                            hi = 100.0 - ok_;
+                        }
                         if (cls.use_sfc) {                                                // :372-397
                             lo = fmax(lo, sfc[q * M + m].bmin[k] - ok_);
                             hi = fmin(hi, sfc[q * M + m].bmax[k] - ok_);

@@ -34,8 +34,9 @@ void TrajOptimizer::configure() {
     d.phi = param.phi;
     d.phi_n = param.phi_n;
     d.dim = param.world_dimension;
-    d.planner_mode = (param.planner_mode == PlannerMode::LSC) ? LSCQP_PLANNER_LSC
-                     : (param.planner_mode == PlannerMode::BVC) ? LSCQP_PLANNER_BVC : LSCQP_PLANNER_DLSC;
+    d.planner_mode = (param.planner_mode == PlannerMode::LSC)   ? LSCQP_PLANNER_LSC
+                     : (param.planner_mode == PlannerMode::BVC) ? LSCQP_PLANNER_BVC
+                     : (param.planner_mode == PlannerMode::RECIPROCALRSFC) ? LSCQP_PLANNER_RSFC : LSCQP_PLANNER_DLSC;
     d.use_sfc = param.world_use_octomap ? 1 : 0;
     d.dt = param.dt;
     d.control_input_weight = param.control_input_weight;
@@ -45,8 +46,6 @@ void TrajOptimizer::configure() {
         d.world_min[k] = mission.world_min(k);
         d.world_max[k] = mission.world_max(k);
     }
-    if (param.slack_mode == SlackMode::COLLISIONCONSTRAINT || param.planner_mode == PlannerMode::RECIPROCALRSFC)
-        throw std::invalid_argument("[TrajOptimizer] slack_mode COLLISIONCONSTRAINT / RECIPROCALRSFC is not supported by the HIP solver");
     int rc = handle ? lscqp_update(handle, &d) : lscqp_create(&d, &handle);
     if (rc == LSCQP_ERR_INVALID_ARGUMENT || rc == LSCQP_ERR_UNSUPPORTED) throw std::invalid_argument(lscqp_last_error());
     if (rc != LSCQP_OK) throw std::runtime_error(lscqp_last_error());
@@ -100,7 +99,8 @@ void TrajOptimizer::pack(const Agent& agent, const CollisionConstraints& constra
                 // (src/traj_optimizer.cpp:272-283, 423-425) that appears in NO cost term (:285-316): such a row can always be
                 // satisfied by its own slack, i.e. it never binds.  Dropping the row (zero normal: the solver skips it like
                 // :409-411) is the same QP.  (The set is never populated in the reference, src/collision_constraints.cpp:495-503.)
-                if (constraints.isDynamicObstacle((int)oi)) {
+                // slack_mode COLLISIONCONSTRAINT (the RECIPROCALRSFC planner, src/param.cpp:157-161) gives EVERY obstacle such a slack.
+                if (param.slack_mode == SlackMode::COLLISIONCONSTRAINT || constraints.isDynamicObstacle((int)oi)) {
                     r.nx = r.ny = r.nz = 0.0;
                     r.b = -1.0;
                 }

@@ -130,7 +130,7 @@ void orc_count(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, orc_s
     memset(out, 0, sizeof(*out));
     out->nv = dim * P;
     /* :318-353 six rows per axis (five if M == 1), :356-368, :502-511 */
-    out->neq = dim * (M > 1 ? 6 : 5) + dim * (M - 2 > 0 ? (M - 2) * phi : 0) + (c->planner_lsc ? dim * (phi - 1) : 0);
+    out->neq = dim * (M > 1 ? 6 : 5) + dim * (M - 2 > 0 ? (M - 2) * phi : 0) + (c->planner_lsc == 1 ? dim * (phi - 1) : 0);
     if (c->use_sfc) out->n_sfc = 2 * dim * (P - phi);
     for (int oi = 0; oi < a->n_obs; oi++)
         for (int m = 0; m < M; m++)
@@ -167,6 +167,10 @@ void orc_assemble(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, co
                 } else {
                     lb[row] = c->world_min[k];
                     ub[row] = c->world_max[k];
+                    if (k == 2 && m == 0 && c->planner_lsc == 2) { /* RECIPROCALRSFC, "to avoid numerical error" (:255-258) */
+                        lb[row] = -100;
+                        ub[row] = 100;
+                    }
                 }
             }
 
@@ -246,7 +250,7 @@ void orc_assemble(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, co
             }
         free(Ab);
     }
-    if (c->planner_lsc) { /* :504-511 */
+    if (c->planner_lsc == 1) { /* :504-511 */
         for (int k = 0; k < dim; k++) {
             int m = M - 1;
             for (int i = 1; i < phi; i++) {

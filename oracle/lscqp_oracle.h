@@ -39,7 +39,7 @@ extern "C" {
 
 typedef struct orc_class {
     int M, n, phi, phi_n, dim;
-    int planner_lsc;  /* param.planner_mode == PlannerMode::LSC */
+    int planner_lsc;  /* 1: param.planner_mode == PlannerMode::LSC (end-stop rows); 0: DLSC / BVC; 2: RECIPROCALRSFC (z bounds of segment 0) */
     int use_sfc;      /* param.world_use_octomap */
     double dt, w_c, w_t, comm_range;
     double world_min[3], world_max[3];

@@ -159,7 +159,7 @@ def make_class(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_ls
                world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1):
     c = OrcClass()
     c.M, c.n, c.phi, c.phi_n, c.dim = M, n, phi, phi_n, dim
-    c.planner_lsc, c.use_sfc = int(planner_lsc), int(use_sfc)
+    c.planner_lsc, c.use_sfc = int(planner_lsc), int(use_sfc)  # (planner_lsc: True / 1 = LSC, False / 0 = DLSC or BVC, 2 = RECIPROCALRSFC)
     c.dt, c.w_c, c.w_t, c.comm_range = dt, w_c, w_t, comm_range
     for k in range(3):
         c.world_min[k] = world_min[k]

@@ -480,3 +480,26 @@ def test_log_replay_known_answers_on_the_gpu(api, oracle, torch_cuda):
             pos, vel, acc = oracle.state_at(cls, G["x"][q], st["t"] - c["t"])
             assert np.abs(pos - st["p"][:2]).max() <= 1.5e-5 and np.abs(vel - st["v"][:2]).max() <= 2e-5
             assert np.abs(acc - st["a"][:2]).max() <= 3e-4
+
+
+def test_rsfc_planner_mode_relaxes_the_z_bounds_of_the_first_segment(api, oracle, torch_cuda):
+    """RECIPROCALRSFC (reference src/traj_optimizer.cpp:255-258): the z variables of segment 0 are bounded by +-100 instead of the world
+    box ("to avoid numerical error"), and there are no end-stop rows.  An agent just under the world ceiling, still climbing but
+    already braking at the limit: its first segment has to overshoot the ceiling by a few millimetres.  With the world box on
+    segment 0 (DLSC) that QP is infeasible on both sides; in RSFC mode it is feasible and GPU and oracle agree on the optimum."""
+    M, dim = 5, 3
+    wmin, wmax = [-5, -5, 0], [5, 5, 2.5]
+    ag = oracle.make_agent(p0=[0, 0, 2.495], v0=[0, 0, 0.18], a0=[0, 0, -1.9], goal=[0.5, 0, 2.0], next_waypoint=[0.5, 0, 2.0])
+    for name, mode_abi, mode_orc in (("dlsc", api.PLANNER_DLSC, 0), ("rsfc", api.PLANNER_RSFC, 2)):
+        sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=mode_abi, use_sfc=False, world_min=wmin, world_max=wmax))
+        cls = oracle.make_class(M=M, dim=dim, planner_lsc=mode_orc, use_sfc=False, world_min=wmin, world_max=wmax)
+        hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, [ag], [None], None, M)
+        G = sol.solve_host(hdr, None, None, None)
+        o = oracle.solve(cls, ag, None, None)
+        if name == "dlsc":
+            assert G["status"][0] != 0 and o["status"] != 0
+            continue
+        assert G["status"][0] == 0 and o["status"] == 0
+        assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= X_TOL
+        z = G["x"][0].reshape(dim, M, 6)[2]
+        assert z[0, 3:].max() > 2.5 + 1e-3 and z[1:].max() <= 2.5 + 1e-9  # segment 0 overshoots, later segments keep the world box
