@@ -59,7 +59,7 @@ def build(force=False, verbose=False, jobs=None):
     objs.append(api_o)
     api_src = os.path.join(CSRC, "lscqp_api.hip")
     if force or _newer(api_o, hdrs + [api_src]):
-        tasks.append([HIPCC] + FLAGS + ["-c", api_src, "-o", api_o])
+        tasks.append([HIPCC] + FLAGS + os.environ.get("LSCQP_EXTRA_F64_FLAGS", "").split() + ["-c", api_src, "-o", api_o])
     post_o = os.path.join(OBJ, "lscpost.o")
     objs.append(post_o)
     post_src = os.path.join(CSRC, "lscpost.hip")

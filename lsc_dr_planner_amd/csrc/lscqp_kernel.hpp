@@ -235,6 +235,9 @@ __device__ unsigned long long lscqp_dbg_cycles[16];
 // FB_ = bytes of the scalar the reduced matrix is held, factorised and substituted in: 8 (fp64), or 4 for the MIXED-PRECISION
 // instances (BASELINE configs[4]: float32 LDL^T / substitutions steering an iteration whose residuals, multipliers, control
 // points and stopping tests stay fp64; tools/proto_fp32.py).
+#ifndef LSCQP_ND_MIN_M
+#define LSCQP_ND_MIN_M 10  // nested dissection below 64 rows from this horizon on (measured: see Cfg::ND)
+#endif
 template <int M_, int DIM_, bool ES_, int NSLOT_, int W_ = 1, int FB_ = 8>
 struct Cfg {
     static constexpr int M = M_, DIM = DIM_, NSLOT = NSLOT_, W = W_;
@@ -260,8 +263,11 @@ struct Cfg {
     // of the middle segment MS + every c5; it cuts the rest into two independent banded blocks, L = (c3, c4) of segments
     // 0..MS-1 and R = (c3, c4) of segments MS+1..M-2, which two wavefronts eliminate CONCURRENTLY (each with its share of the
     // separator's Schur complement), then one wavefront factorises the separator.  Row length in registers: NB + NS instead of nz.
-    static constexpr bool ND = NZ > 64;
     static constexpr int MS = (M - 1) / 2;
+    // ... and wherever two wavefronts per QP are used and the two blocks come out equal (M = 6, 10): M = 10 in 2-D 56 dense pivots
+    // -> 16 + 24 (-7 % on the forest10 replica), M = 6 in 3-D 48 -> 12 + 24
+    static constexpr bool ND = (NZ > 64) || (W >= 2 && ES_ && FB_ == 8 && M >= LSCQP_ND_MIN_M && (2 * DIM * MS == 2 * DIM * (M - 2 - MS)) &&
+                                             (2 * DIM * MS + 2 * DIM + DIM * M <= 64));
     static constexpr int NB = 2 * DIM * MS;             // block L (wavefront 0): segments 0 .. MS-1, order (m, axis, j)
     static constexpr int NBR = 2 * DIM * (M - 2 - MS);  // block R (wavefront 1): segments MS+1 .. M-2
     static constexpr int NS = 2 * DIM + DIM * M;        // separator: (c3, c4) of segment MS, then c5 of (axis, segment)
@@ -1301,7 +1307,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
 
             // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
-            if constexpr (W == 1 || NZ <= 64) {
+            if constexpr (!C::ND) {
 #ifndef LSCQP_FACT_READLANE
             // Pivot-row broadcast over BOTH pipes.  A v_readlane costs ~8 cycles of VALU issue (16 per fp64 value, next
             // to 4.6 for the FMA it feeds); a uniform-address ds_read_b64 costs ~11 cycles of the LDS pipe and none of
@@ -1516,7 +1522,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             // broadcast of lane j's value to all lanes of the QP: v_readlane (W = 1) or an LDS slot + barrier (W = 2; one
             // slot per column and direction, so no slot is rewritten while a slower wavefront may still read it)
             auto bcast_q = [&](FT v, int j, int ls, double* slots) -> FT {
-                if constexpr (W == 1 || NZ <= 64) {
+                if constexpr (!C::ND) {
                     return bcast(v, j);
                 } else {
                     if (ls == j) slots[j] = v;
@@ -1598,7 +1604,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             // the residuals the NEXT iteration computes are fp64, so an inexact direction costs iterations, not accuracy:
             // +0.4 iterations on the forest class, tools/proto_fp32.py)
             auto solve = [&](double b64) __attribute__((always_inline)) -> double {
-                if constexpr (W > 1 && NZ > 64) return solve_blocked(b64, 0);
+                if constexpr (C::ND) return solve_blocked(b64, 0);
                 FT b = (FT)b64;
                 int ls = (NZ <= 64) ? (lane & 63) : lane;  // opaque per call, see the factorisation
                 asm volatile("" : "+v"(ls));
