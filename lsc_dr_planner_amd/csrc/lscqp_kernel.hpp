@@ -270,7 +270,7 @@ struct Cfg {
                                              (2 * DIM * MS + 2 * DIM + DIM * M <= 64));
     static constexpr int NB = 2 * DIM * MS;             // block L (wavefront 0): segments 0 .. MS-1, order (m, axis, j)
     static constexpr int NBR = 2 * DIM * (M - 2 - MS);  // block R (wavefront 1): segments MS+1 .. M-2
-    static constexpr int NS = 2 * DIM + DIM * M;        // separator: (c3, c4) of segment MS, then c5 of (axis, segment)
+    static constexpr int NS = 2 * DIM + DIM * M;        // separator: (c3, c4) of segment MS, then c5 of (segment, axis)
     static constexpr int BWB = 4 * DIM - 1;             // half bandwidth inside a block
     static constexpr int NAR = ND ? NB + NS : NZ;       // entries of a lane's matrix row
     static_assert(!ND || (ES_ && NB == NBR && NB + NS <= 64 && W >= 2 && FB_ == 8),
@@ -287,7 +287,13 @@ struct Cfg {
         int s = c - NB;
         if (s < 2 * DIM) return zi_kmj(s / 2, MS, s % 2);
         s -= 2 * DIM;
-        return zi_kmj(s / M, s % M, 2);
+        return zi_kmj(s % DIM, s / DIM, 2);
+    }
+    // Separator columns a block can reach (before and after fill-in): (c3, c4) of segment m couple to c5 of segments m-1, m, m+1
+    // only, so block L (segments 0 .. MS-1) never touches c5 of segments > MS and block R (MS+1 .. M-2) never c5 of segments
+    // < MS: the block phase and the hand-over skip those columns (21 resp. 24 of 36 at M = 10 in 3-D).
+    static constexpr bool nd_touched(int w, int sc) {
+        return sc < 2 * DIM || (w == 0 ? sc < 2 * DIM + (MS + 1) * DIM : sc >= 2 * DIM + MS * DIM);
     }
     static_assert(NZ <= T, "lane-per-row kernel needs dim*(3M-2) <= 64*W");
     static_assert(CP <= T, "6M-3 <= 64*W");
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 int s_ = tc - C::NB;
                 const bool mid = s_ < 2 * DIM;
                 const int s2 = mid ? s_ : s_ - 2 * DIM;
-                zi = mid ? C::zi_kmj(s2 / 2, C::MS, s2 % 2) : C::zi_kmj(s2 / M, s2 % M, 2);
+                zi = mid ? C::zi_kmj(s2 / 2, C::MS, s2 % 2) : C::zi_kmj(s2 % DIM, s2 / DIM, 2);
             }
             return own ? zi : -1;
         }
@@ -1417,7 +1423,12 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 double* const colw = col_ + 2 * 64 * (wv & 1);
                 double* const Sx = reinterpret_cast<double*>(Hs);  // [NS][NS]: wavefront 1's share of the separator block
                 double* const flag = Sx + NS * NS;                  // [2] pivot failures
-                if (wv < 2) {
+                // (one instantiation per wavefront: the separator columns a block can reach differ, Cfg::nd_touched.  The separator
+                // entries of the pivot row go over BOTH pipes: every second one is read from lane j's own registers with
+                // v_readlane, the others from the published pivot column in LDS -- two wavefronts share the CU's one LDS pipe
+                // here, and with all of them on it the phase was LDS bound: 34.7 k cycles for 24 pivots.)
+                auto block_phase = [&](auto Wc) {
+                    constexpr int w_ = decltype(Wc)::value;
                     colw[lf] = A[0];
                     double d = bcast(A[0], 0);
                     double invd = fast_rcp(d);
@@ -1439,27 +1450,36 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                             constexpr int k = decltype(Kc)::value;
                             A[k] = fma(-li, cb[k], A[k]);
                         });
-                        static_for<NB, NA>([&](auto Kc) {
-                            constexpr int k = decltype(Kc)::value;
-                            A[k] = fma(-li, cb[k], A[k]);
+                        static_for<0, NS>([&](auto Kc) {
+                            constexpr int sc = decltype(Kc)::value;
+                            if constexpr (C::nd_touched(w_, sc)) {
+                                constexpr int k = NB + sc;
+                                const double u = (sc & 1) ? cb[k] : bcast(A[k], j);
+                                A[k] = fma(-li, u, A[k]);
+                            }
                         });
                         A[j] = (lf > j) ? li : A[j];
                         asm volatile("" ::: "memory");  // LDS program order between the steps
                     });
-                }
+                };
+                if (wv == 0) block_phase(std::integral_constant<int, 0>{});
+                if (wv == 1) block_phase(std::integral_constant<int, 1>{});
+                LSCQP_T(14);  // (development timing: the block phase of the nested dissection)
                 {   // hand-over of wavefront 1's share (single predicated stores; everything else is masked arithmetically)
                     const bool give = (wv == 1) && lf >= NB && lf < NB + NS;
                     const int srow = (lf >= NB && lf < NB + NS) ? lf - NB : 0;
                     static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
-                        if (give) Sx[srow * NS + c] = A[NB + c];
+                        if constexpr (C::nd_touched(1, c)) {
+                            if (give) Sx[srow * NS + c] = A[NB + c];
+                        }
                     });
                     if (lf == 0 && wv < 2) flag[wv] = pivot_bad ? 1.0 : 0.0;
                     __syncthreads();
                     const double take = (wv == 0 && lf >= NB && lf < NB + NS) ? 1.0 : 0.0;
-                    static_for<0, NS>([&](auto Cc) {
+                    static_for<0, NS>([&](auto Cc) {  // (rows of separator variables wavefront 1 cannot reach hold zeros there)
                         constexpr int c = decltype(Cc)::value;
-                        A[NB + c] = fma(take, Sx[srow * NS + c], A[NB + c]);
+                        if constexpr (C::nd_touched(1, c)) A[NB + c] = fma(take, Sx[srow * NS + c], A[NB + c]);
                     });
                 }
                 if (wv == 0) {  // the separator: dense LDL^T on columns / lanes NB .. NA-1
@@ -1587,7 +1607,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 if (wv == 1) {  // block rows of wavefront 1: U[i][S] x_S
                     static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
-                        b = fma(-A[NB + c], hand[c], b);  // (accumulator lanes compute a value nobody uses)
+                        if constexpr (C::nd_touched(1, c)) b = fma(-A[NB + c], hand[c], b);  // (accumulator lanes compute a value nobody uses)
                     });
                 }
                 if (wv < 2) {

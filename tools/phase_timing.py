@@ -65,6 +65,8 @@ print("status ok:", (dst.cpu().numpy() == 0).all(), "iters total", nit, "mean", 
 for i, nm in enumerate(names):
     print("%-16s %10.0f cycles/iter/QP  %5.1f%%" % (nm, buf[i] / max(nit, 1), 100.0 * buf[i] / tot))
 print("total cycles/iter/QP %.0f" % (tot / nit))
+if buf[14]:
+    print("nested dissection: block phase %.0f cycles/iter/QP (in addition to `factor` above = hand-over + separator)" % (buf[14] / max(nit, 1)))
 pro = [buf[i] / N for i in (11, 12, 13, 15)]
 print("prologue %.0f cycles/QP (header+cp init %.0f, row staging %.0f, two-sided setup %.0f, start point %.0f), epilogue %.0f cycles/QP, "
       "loop %.0f cycles/QP (%.2f iterations)" % (sum(pro), pro[0], pro[1], pro[2], pro[3], buf[10] / N, (tot - buf[10]) / N, nit / N))
