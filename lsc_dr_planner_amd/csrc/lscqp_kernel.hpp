@@ -203,6 +203,9 @@ __device__ __forceinline__ bool pivot_ok(FT d) {
 #ifndef LSCQP_FACT_HYBRID
 #define LSCQP_FACT_HYBRID 5  // percent of a pivot row (beyond the first 4 entries) broadcast with v_readlane
 #endif
+#ifndef LSCQP_NEAR_CONFIRM
+#define LSCQP_NEAR_CONFIRM 2  // consecutive iterations with the gap at its target and the stationarity below 1e-8 before a point is accepted
+#endif
 #ifndef LSCQP_CENTRALITY_GAMMA
 #define LSCQP_CENTRALITY_GAMMA 1e-4
 #endif
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     floor_cnt++;
                     if (rdn <= 1e-8 * gls) {
                         near_cnt++;
-                        if (rdn <= 10.0 * tol * gls || near_cnt >= 2) {
+                        if (rdn <= 10.0 * tol * gls || near_cnt >= LSCQP_NEAR_CONFIRM) {
                             status = LSCQP_STATUS_OPTIMAL;
                             break;
                         }
@@ -1654,9 +1657,12 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             // ============ predictor ========================================================================
             const double dza = solve(-gcost + ga);
             if (zl) dz_[zi0] = dza;
+            LSCQP_BLOCK_SYNC();
 #ifndef LSCQP_SOLVE_FROM_LDS
             // park the factor in the lane's scratch-matrix row while pass 2 runs: A[] is then dead across the pass,
-            // which removes most register spills of the pass
+            // which removes most register spills of the pass.  (Behind the barrier: in the multi-wavefront instances other
+            // wavefronts LOADED their copy of these rows after the assembly; every wavefront has finished its factorisation,
+            // hence those loads, when it arrives here.)
             {
                 LSCQP_PHASE_LANE(lvp_);
                 FT* const prow = park_ptr(lvp_);
@@ -1664,7 +1670,6 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 for (int cidx = 0; cidx < C::NAR; cidx++) prow[cidx] = A[cidx];
             }
 #endif
-            LSCQP_BLOCK_SYNC();
             expandT(dz_, dca_, false);
             LSCQP_BLOCK_SYNC();
             LSCQP_T(5);
