@@ -503,3 +503,30 @@ def test_rsfc_planner_mode_relaxes_the_z_bounds_of_the_first_segment(api, oracle
         assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= X_TOL
         z = G["x"][0].reshape(dim, M, 6)[2]
         assert z[0, 3:].max() > 2.5 + 1e-3 and z[1:].max() <= 2.5 + 1e-9  # segment 0 overshoots, later segments keep the world box
+
+
+def test_log_known_answer_with_an_active_lsc_row_on_the_gpu(api, oracle, torch_cuda):
+    """The reference-logged replan that only active LSC rows explain (tests/golden/kat_log_active.json): goal LP and QP through the C ABI."""
+    g = H.load_golden("kat_log_active")
+    p, c = g["params"], g["cases"][0]
+    cls = H.oracle_class(oracle, p, use_sfc=False)
+    sol = api.Solver(H.abi_desc(api, p, use_sfc=False))
+    L = np.zeros((len(c["neighbours"]), p["M"], 6), oracle.LSC_DTYPE)
+    L["p"], L["nrm"], L["d"] = c["lsc_p"], c["lsc_nrm"], c["lsc_d"]
+    ag = oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal_before_lp"], next_waypoint=c["next_waypoint"], vmax=p["vmax"],
+                           amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"], n_obs=len(L))
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, [ag], [L], None, p["M"])
+    hdr2, gst = sol.optimize_goal_host(hdr, rows, off, None)  # GoalOptimizer: the goal moves off the waypoint
+    assert gst[0] == 0 and np.abs(np.float32(hdr2["goal"][0]) - np.array(c["goal"])).max() <= 1e-7
+    hdr2["goal"][0] = c["goal"]  # (float32 like agent.current_goal_point)
+    ag_new = oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal"], next_waypoint=c["next_waypoint"], vmax=p["vmax"],
+                               amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"], n_obs=len(L))
+    hdr2["terminal_segments"][0] = oracle.terminal_segments(cls, ag_new)  # getTerminalSegments_old reads the goal AFTER goalPlanning
+    G = sol.solve_host(hdr2, rows, off, None)
+    assert G["status"][0] == 0
+    for st in c["states"]:
+        pos, vel, acc = oracle.state_at(cls, G["x"][0], st["t"] - c["t"])
+        assert np.abs(pos - st["p"][:2]).max() <= 1.5e-5 and np.abs(vel - st["v"][:2]).max() <= 2e-5 and np.abs(acc - st["a"][:2]).max() <= 3e-4
+    o = oracle.solve(cls, oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal"], next_waypoint=c["next_waypoint"], vmax=p["vmax"],
+                                            amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"], n_obs=len(L)), L, None)
+    assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= X_TOL

@@ -179,3 +179,47 @@ def test_log_replay_known_answers(oracle):
             assert np.abs(acc - st["a"][:2]).max() <= 3e-4, (c["agent"], c["replan"])
         moving += np.abs(c["a0"]).max() > 0.05
     assert moving >= 100  # most of them start from a genuinely accelerating state
+
+
+def _active_case(oracle):
+    g = H.load_golden("kat_log_active")
+    p, c = g["params"], g["cases"][0]
+    cls = H.oracle_class(oracle, p, use_sfc=False)
+    L = np.zeros((len(c["neighbours"]), p["M"], 6), oracle.LSC_DTYPE)
+    L["p"], L["nrm"], L["d"] = c["lsc_p"], c["lsc_nrm"], c["lsc_d"]
+    return p, c, cls, L
+
+
+def _state_errors(oracle, cls, c, x):
+    e = dict(p=0.0, v=0.0, a=0.0)
+    for st in c["states"]:
+        pos, vel, acc = oracle.state_at(cls, x, st["t"] - c["t"])
+        e["p"] = max(e["p"], np.abs(pos - st["p"][:2]).max())
+        e["v"] = max(e["v"], np.abs(vel - st["v"][:2]).max())
+        e["a"] = max(e["a"], np.abs(acc - st["a"][:2]).max())
+    return e
+
+
+def test_log_known_answer_with_an_active_lsc_row(oracle):
+    """tests/golden/kat_log_active.json (tools/make_golden_log_active.py): replan 7 of agent 6 of the reference's own run, t = 1.4 s,
+    two agents in range.  Its CLSC rows come from the neighbours' previous plans (certified by the log-replay fixture), GoalOptimizer
+    moves the goal off the waypoint (t = 0.06), and the QP's optimum carries a non-zero LSC multiplier.  WITH the rows the
+    restatement lands on the logged states within the log's input precision; WITHOUT them it misses velocity and acceleration by
+    more than ten times that -- reference-logged motion that only the LSC rows explain."""
+    p, c, cls, L = _active_case(oracle)
+    mk = lambda n_obs, goal: oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=goal, next_waypoint=c["next_waypoint"], vmax=p["vmax"],  # noqa: E731
+                                               amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"], n_obs=n_obs)
+    # the goal LP (GoalOptimizer restated) reproduces the fixture's goal from the previous goal point and the inferred waypoint
+    st, goal, t = oracle.goal_opt(cls, c["goal_before_lp"], c["next_waypoint"], lsc=L)
+    assert st == 0 and abs(t - c["goal_lp_t"]) <= 1e-12 and 0.01 < t < 0.5
+    assert np.abs(np.float32(goal) - np.array(c["goal"])).max() <= 1e-7
+    R = oracle.solve(cls, mk(len(L), c["goal"]), L, None)
+    assert R["status"] == 0
+    e = _state_errors(oracle, cls, c, R["x"])
+    assert e["p"] <= 1.5e-5 and e["v"] <= 2e-5 and e["a"] <= 3e-4, e
+    sz = oracle.count(cls, mk(len(L), c["goal"]), L)
+    lam = R["lam"][sz.n_sfc:sz.n_sfc + sz.n_lsc]
+    assert lam.max() > 1e-3 and abs(lam.max() - c["max_lsc_multiplier"]) <= 1e-6 * lam.max() + 1e-9
+    R0 = oracle.solve(cls, mk(0, c["goal"]), None, None)
+    e0 = _state_errors(oracle, cls, c, R0["x"])
+    assert e0["v"] >= 10 * 2e-5 and e0["a"] >= 10 * 3e-4, e0
