@@ -487,8 +487,9 @@ int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_
  *     LSCQP_SFC_FROM_POINT  constructSFCFromPoint (:396-412): the last box := expandSFCFromPoint(last point) with the
  *                           goal-ordered axis candidates (setAxisCand :1134-1170), else the previous box (status 0)
  *   with isObstacleInSFC (:777-808), isSFCInBoundary (:810-817) and expandSFC (:819-946) in the reference's float32 /
- *   double arithmetic.  One deviation: where the reference's distance-map query finds no cell within max_dist it measures
- *   against a phantom cell at the world origin (the default-constructed closest_point, :796-800); here that is "no obstacle".
+ *   double arithmetic -- including its quirk: where the distance-map query finds no cell within max_dist (or the sample lies
+ *   outside the map) `closest_point` stays default-constructed and the sample is measured against a cell at the WORLD ORIGIN
+ *   (:796-800), which cuts corridors short within margin + res/2 of the origin.  (Round 1 treated that case as "no obstacle".)
  *   d_points [n][3][3]  per agent: position (INIT) or last point of the initial trajectory, current goal point, next waypoint
  *   d_radius [n]        Agent::radius (the margin)       d_sfc [n][M] boxes, updated in place       d_status_out [n] */
 typedef struct lscqp_map_s* lscqp_map;

@@ -173,10 +173,12 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
     for (int64_t base = 0; base < total; base += kSfcThreads * kU) {
         float p[kU][3];
         int v[kU][3], code[kU];
+        bool live[kU];
 #pragma unroll
         for (int u = 0; u < kU; u++) {
             const int64_t idx = base + u * kSfcThreads + lane;
             bool inside = idx < total;
+            live[u] = inside;
             const int64_t ii = inside ? idx : 0;
             int it[3];
             if (small) {
@@ -197,12 +199,15 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
         bool hit = false;
 #pragma unroll
         for (int u = 0; u < kU; u++) {
-            if (code[u] >> 24) {
+            if (live[u]) {
+                // no occupied cell within max_dist, or a sample outside the distance map: the reference's closest_point stays
+                // default-constructed and it measures against a cell at the WORLD ORIGIN (:796-800) -- reproduced
+                const bool have = (code[u] >> 24) != 0;
                 const int off[3] = {(code[u] & 255) - 128, ((code[u] >> 8) & 255) - 128, ((code[u] >> 16) & 255) - 128};
                 double dist = 0;
                 for (int k = 0; k < 3; k++) {
                     // keyToCoord: cell centre (key + 0.5) res as float; closest point of the cell box; L-infinity distance
-                    const float c = (float)(((double)(v[u][k] + off[k] + mp.key0[k]) + 0.5) * res);
+                    const float c = have ? (float)(((double)(v[u][k] + off[k] + mp.key0[k]) + 0.5) * res) : 0.0f;
                     const float cmin = c - delta, cmax = c + delta;
                     const float q = p[u][k] < cmin ? cmin : (p[u][k] > cmax ? cmax : p[u][k]);
                     const double dk = fabs((double)(q - p[u][k]));

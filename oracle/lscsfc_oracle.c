@@ -21,9 +21,8 @@
  * by the first candidate in (dz, dy, |dx| with negative first) order.  PARITY UNPINNED at such ties; the construction as a
  * whole is pinned through the reference's own run: the corridor of forest10's agent 1 must put its -x face at 2.55, the
  * value that reproduces the reference's result log to its printed digits (tests/golden/kat_log.json).
- * One deliberate deviation: when no occupied cell lies within maxdist the reference's query leaves `closest_point` at its
- * default (0,0,0) and then measures the distance to a phantom cell at the world origin (:796-800); here "no cell within
- * maxdist" means "no obstacle".
+ * Kept from the reference: when no occupied cell lies within maxdist (or the sample is outside the map) its query leaves
+ * `closest_point` at its default (0,0,0) and the sample is measured against a phantom cell at the world origin (:796-800).
  *
  * float32 semantics: boxes and points are octomap::point3d (3 x float); the statements below keep float where the
  * reference stores a point3d component and double where it computes in double.  Compiled without FMA contraction.
@@ -145,14 +144,16 @@ static int obstacle_in(const orc_map* mp, const boxf* b, double margin) {
                     v[k] = key_of((double)p[k], res) - mp->key0[k];          /* worldToMap */
                     if (v[k] < 0 || v[k] >= mp->dims[k]) inside = 0;
                 }
-                if (!inside) continue; /* outside the distance map: no information (see header) */
-                const int code = mp->nearest[((size_t)v[2] * mp->dims[1] + v[1]) * mp->dims[0] + v[0]];
-                if (!(code >> 24)) continue;
+                /* getDistanceAndClosestObstacle leaves `closest_point` untouched when the sample lies outside the distance map or no
+                 * occupied cell is within max_dist; the caller's point3d is default-constructed, so the reference then measures
+                 * against a cell at the WORLD ORIGIN (:796-800).  Reproduced: near the origin corridors are cut short by it. */
+                const int code = inside ? mp->nearest[((size_t)v[2] * mp->dims[1] + v[1]) * mp->dims[0] + v[0]] : 0;
+                const int have = (code >> 24) != 0;
                 const int off[3] = {(code & 255) - 128, ((code >> 8) & 255) - 128, ((code >> 16) & 255) - 128};
                 double dist = 0;
                 for (int k = 0; k < 3; k++) {
                     /* mapToWorld / keyToCoord: cell centre (key + 0.5) res as float; cell box = centre -+ delta (floats) */
-                    const float c = (float)(((double)(v[k] + off[k] + mp->key0[k]) + 0.5) * res);
+                    const float c = have ? (float)(((double)(v[k] + off[k] + mp->key0[k]) + 0.5) * res) : 0.0f;
                     const float cmin = c - delta, cmax = c + delta;
                     const float q = p[k] < cmin ? cmin : (p[k] > cmax ? cmax : p[k]); /* Box::closestPoint */
                     const double dk = fabs((double)(q - p[k]));                        /* LInfinityDistance, float difference */

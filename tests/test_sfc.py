@@ -66,6 +66,27 @@ def test_forest10_corridors_pin_and_invariants(oracle):
                 assert not _clear_of_obstacles(occ, mp.key0, g["resolution"], lo2, hi2, g["radius"] - 1e-4), (q, k, side)
 
 
+def test_reference_quirk_phantom_cell_at_the_world_origin(oracle):
+    """Where no occupied cell lies within max_dist, DynamicEDTOctomap::getDistanceAndClosestObstacle leaves `closest_point` untouched;
+    the reference's point3d is default-constructed, so isObstacleInSFC measures against a cell at the WORLD ORIGIN
+    (src/collision_constraints.cpp:796-800).  In an EMPTY world the only thing that can stop a corridor short of the world boundary is
+    that phantom: every corridor is cut so that none of its sample points comes within margin + res/2 (L-infinity) of the origin."""
+    wmin, wmax = np.array([-3.0, -3.0, 0.0]), np.array([3.0, 3.0, 2.5])
+    mp = oracle.Map(np.zeros((0, 6)), wmin, wmax, 0.1, 1.0)
+    starts = np.float32([[1.5, 1.2, 1.0], [-1.0, 2.0, 0.6], [2.0, -2.0, 2.0], [0.5, 0.4, 0.5]]).astype(np.float64)
+    sfc = np.zeros((len(starts), 3), oracle.BOX_DTYPE)
+    st = mp.construct_sfc(oracle.SFC_INIT, _pts(starts), 0.15, sfc)
+    assert (st == 1).all()
+    full = 0
+    for q in range(len(starts)):
+        lo, hi = sfc[q, 0]["bmin"], sfc[q, 0]["bmax"]
+        # the box's sample lattice (box_min + i * res) never comes within margin + res/2 of the origin in all three axes at once
+        near = [np.any(np.abs(np.arange(lo[k], hi[k] + 1e-6, 0.1)) < 0.15 + 0.05 + 1e-5) for k in range(3)]
+        assert not all(near), (q, lo, hi)
+        full += int(np.all(lo <= wmin + 0.15 + 1e-4) and np.all(hi >= wmax - 0.15 - 1e-4))
+    assert full == 0  # an empty world would otherwise give every agent the whole world box
+
+
 def test_map_rasterisation_and_nearest_field(oracle):
     g, mp = _forest(oracle)
     occ, near = mp.occ(), mp.nearest()
@@ -150,12 +171,17 @@ def test_gpu_map_matches_oracle(api, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", ["forest10", "random3d"])
+@pytest.mark.parametrize("world", ["forest10", "random3d", "sparse_origin"])
 def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world):
     import torch
 
     rng = np.random.default_rng(11)
-    if world == "forest10":
+    if world == "sparse_origin":  # few obstacles: the phantom cell at the world origin (:796-800) decides many corridors
+        wmin, wmax = np.array([-4.0, -4.0, 0.0]), np.array([4.0, 4.0, 2.5])
+        boxes = np.array([[2.5, 2.5, 1.0, 0.5, 0.5, 2.0], [-3.0, 1.0, 0.5, 0.4, 0.4, 1.0]])
+        starts = rng.uniform([-2.0, -2.0, 0.3], [2.0, 2.0, 2.2], (200, 3))
+        M, dim = 5, 3
+    elif world == "forest10":
         g = H.load_golden("forest10_world")
         boxes, wmin, wmax = np.array(g["boxes"]), np.array(g["world_min"]), np.array(g["world_max"])
         starts = np.concatenate([np.array(g["starts"]), np.c_[rng.uniform(-4.8, 4.8, (150, 2)), np.full(150, 0.6)]])
