@@ -30,3 +30,25 @@ def test_bench_prints_one_contract_line():
     assert b["parity"]["max_rel_dobj"] <= 1e-8 and b["parity"]["max_abs_dx"] <= 1e-6
     # value is whole-job throughput of the timed steps
     assert abs(b["value"] - 64 * 1e3 / b["ms_per_step"]) <= 1e-6 * b["value"]
+
+
+@pytest.mark.gpu
+def test_bench_line_covers_every_baseline_config_at_its_own_shape():
+    """The default invocation (what the driver runs): next to the configs[1] headline, every other BASELINE config is measured at
+    its own shape on this GPU -- QP/s, p50 / p99 over 1000 calls, HBM fraction, iterations, oracle parity and CPU baseline."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    by = {c["config"]: c for c in b["configs"]}
+    assert set(by) == {"c0", "c2", "c3s", "c3", "c4_f64", "c4"}
+    shapes = {"c0": (10, 10, 2), "c2": (512, 6, 3), "c3s": (128, 10, 3), "c3": (1024, 10, 3), "c4_f64": (4096, 5, 3), "c4": (4096, 5, 3)}
+    for k, c in by.items():
+        assert "error" not in c, c
+        assert (c["agents"], c["segments"], c["dim"]) == shapes[k]
+        assert c["non_optimal"] == 0 and c["latency_ms"]["calls"] >= 1000 and c["qp_per_s"] > 0 and 0 < c["hbm_frac"] < 1
+        assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port"
+        if c["rows"] == "f64":
+            assert c["parity_vs_oracle"]["max_abs_dx"] <= 1e-6 and c["parity_vs_oracle"]["max_rel_dobj"] <= 1e-8
+    assert by["c4"]["precision"] == "mixed" and by["c4"]["rows"] == "f32" and by["c3"]["lsc_neighbours"] == 40
+    assert b["config"]["baseline_config"] == "c1" and "mixed_vs_fp64_at_4096" in b
