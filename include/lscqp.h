@@ -519,7 +519,7 @@ int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs);
 /* Human-readable description of the last error on this thread. */
 const char* lscqp_last_error(void);
 
-/* "lscqp 0.1 gfx950 ..." */
+/* "lscqp <major>.<minor> (gfx950, ...)" */
 const char* lscqp_version(void);
 
 #ifdef __cplusplus

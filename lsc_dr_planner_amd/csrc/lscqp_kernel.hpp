@@ -3,10 +3,12 @@
 // Replaces the arithmetic of TrajOptimizer::solve (reference src/traj_optimizer.cpp:18-156: CPLEX) for the
 // model TrajOptimizer::populatebyrow builds (src/traj_optimizer.cpp:216-514).  Not a translation of either:
 //
-//   * ONE WAVEFRONT (64 lanes) PER QP, one workgroup per wavefront; the kernel is issue/latency bound on fp64 VALU,
-//     so everything is organised to minimise the instruction count of one Mehrotra iteration.  Classes whose reduced
-//     system has more than 64 rows (M = 10 in 3-D: nz = 84) run the same code with W = 2 wavefronts per QP: lane ->
-//     thread of the workgroup, wave reductions -> wave + LDS, v_readlane broadcasts -> LDS columns + s_barrier.
+//   * ONE WORKGROUP OF W WAVEFRONTS PER QP (W = 1: the throughput form; W = 2 / 4: row passes on several SIMDs for batches
+//     that leave the chip idle); the kernel is issue/latency bound on fp64 VALU, so everything is organised to minimise the
+//     instruction count of one Mehrotra iteration.  With W > 1: lane -> thread of the workgroup, wave reductions -> wave + LDS.
+//     Reduced systems of up to 64 rows are factorised by every wavefront redundantly (uniform verdict on a failed pivot);
+//     larger ones (M = 10 in 3-D: nz = 84) and M = 10 in 2-D with W >= 2 use a NESTED DISSECTION over two wavefronts (Cfg::ND).
+//     FT = float instantiates the mixed-precision form (float32 matrix / factor / substitutions, everything else fp64).
 //   * The equality rows (:318-368, 502-511) are eliminated analytically: per axis the free variables are
 //     z = (c3,c4,c5) of every segment (one scalar for the last segment under the LSC end stop);
 //     (c0,c1,c2) of segment m+1 = TB (c3,c4,c5) of segment m, TB = [[0,0,1],[0,-1,2],[1,-4,4]].
@@ -21,7 +23,7 @@
 //     wave instruction never mixes types.
 //   * Reduced matrix: every lane builds its row from per-(axis,segment) 6x6 local blocks; LDL^T and the two
 //     triangular solves run entirely in registers with v_readlane broadcasts of the pivot row.
-//   * All arithmetic fp64, in coordinates translated to the agent's position.
+//   * All arithmetic fp64 (FT = double), in coordinates translated to the agent's position.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
