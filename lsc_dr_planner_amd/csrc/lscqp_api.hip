@@ -61,13 +61,16 @@ namespace {
 
 struct Inst {
     int M, dim, es, max_obs, waves, mixed;
+    int heavy;  // one wavefront carrying more than 12 LSC slots per lane: the row state no longer fits the register file
+                // (936 - 1432 B/lane of scratch measured for <6,3,.,20,1>, <5,3,.,24,1>, <10,2,.,24,1>) -- 2.3x slower per QP than the
+                // two-wavefront instance of the shape at every batch size (M = 6, 512 .. 2048 QPs)
     size_t lds;  // bytes of LDS per workgroup
     lscqp::launch_fn fn;
 };
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
 #define LSCQP_ROW(M, D, E, S, W, X) \
-    {M, D, E, max_obs_of(M, S, W), W, X, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
+    {M, D, E, max_obs_of(M, S, W), W, X, (S > 12 && W == 1) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
@@ -88,7 +91,9 @@ const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t 
         if (!(i.M == M && i.dim == dim && i.es == es && i.mixed == mixed && i.max_obs >= n_obs)) continue;
         if (pin_w && i.waves != pin_w && !mixed) continue;
         bool better = !best;
-        if (best) {
+        if (best && i.heavy != best->heavy) {
+            better = i.heavy < best->heavy;  // a spilling instance only when nothing else holds the obstacles
+        } else if (best) {
             const bool one_wg_per_cu = i.lds > lscqp::kMaxLdsBytes / 2 && best->lds > lscqp::kMaxLdsBytes / 2;
             if (i.waves != best->waves)
                 better = (small || one_wg_per_cu) ? (i.waves > best->waves) : (i.waves < best->waves);
