@@ -61,7 +61,7 @@ namespace {
 
 struct Inst {
     int M, dim, es, max_obs, waves, mixed;
-    int heavy;  // one wavefront whose state no longer fits the register file: more than 12 LSC slots per lane (936 - 1432 B/lane of
+    int heavy;  // an instance whose state no longer fits the register file: more than 12 LSC slots per lane (376 - 1432 B/lane of
                 // scratch measured for <6,3,.,20,1>, <5,3,.,24,1>, <10,2,.,24,1>: 2.3x slower per QP than the two-wavefront
                 // instance of the shape at every batch size, M = 6, 512 .. 2048 QPs) or a long matrix row (M >= 7: 108 - 192 B/lane;
                 // M = 10 in 2-D: 1.4x slower than the two-wavefront nested-dissection instance at 512 .. 4096 QPs)
@@ -71,7 +71,7 @@ struct Inst {
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
 #define LSCQP_ROW(M, D, E, S, W, X) \
-    {M, D, E, max_obs_of(M, S, W), W, X, (W == 1 && (S > 12 || M >= 7)) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
+    {M, D, E, max_obs_of(M, S, W), W, X, (S > 12 || (W == 1 && M >= 7)) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
