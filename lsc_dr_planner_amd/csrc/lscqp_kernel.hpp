@@ -815,7 +815,13 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     // shorter tail (maximum over a 64-QP batch 5-6; smaller mu0 lowers the mean further but lengthens the tail).
     // With the caller's initial trajectory as primal start the residuals start smaller and a tighter start pays
     // (mu0 = 1e-3, slack floor 0.03: 3.3 -> 3.2 iterations; from hover the same setting lengthens the tail).
-    const double MU0 = x_init ? 1e-3 : 3e-3, S0MIN = x_init ? 0.03 : 0.1;
+#ifndef LSCQP_WARM_MU0
+#define LSCQP_WARM_MU0 1e-3
+#endif
+#ifndef LSCQP_WARM_S0
+#define LSCQP_WARM_S0 0.03
+#endif
+    const double MU0 = x_init ? LSCQP_WARM_MU0 : 3e-3, S0MIN = x_init ? LSCQP_WARM_S0 : 0.1;
     int status = LSCQP_STATUS_ITER_LIMIT;
     double m_tot = 0;
     SD r_s[NSLOT], r_l[NSLOT];  // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
