@@ -94,6 +94,10 @@ const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t 
         bool better = !best;
         if (best && i.heavy != best->heavy) {
             better = i.heavy < best->heavy;  // a spilling instance only when nothing else holds the obstacles
+        } else if (best && i.max_obs != best->max_obs && (i.max_obs >= 2 * best->max_obs || best->max_obs >= 2 * i.max_obs)) {
+            // slots beyond n_obs are processed as dead rows: an instance with twice the capacity needed is the slower one
+            // (forest10 replica, 9 neighbours: <10,2,.,5,2> 0.230 ms, the 40-obstacle <10,2,.,10,4> 0.273 ms)
+            better = i.max_obs < best->max_obs;
         } else if (best) {
             const bool one_wg_per_cu = i.lds > lscqp::kMaxLdsBytes / 2 && best->lds > lscqp::kMaxLdsBytes / 2;
             if (i.waves != best->waves)
