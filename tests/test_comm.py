@@ -60,6 +60,29 @@ def test_sharded_solve_equals_the_single_device_solve(api, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(row_format=1), dict(precision=1), dict(row_format=1, precision=1)], ids=["rows_f32", "mixed", "mixed+rows_f32"])
+def test_sharded_solve_follows_the_handles_row_format_and_precision(api, kw):
+    """The sharded entry stages rows in the handle's storage format (16-byte rows are cut at 16-byte offsets) and runs the handle's
+    precision mode, second pass included: identical to the single-device call."""
+    from lsc_dr_planner_amd import synth
+
+    comm = api.Comm()
+    comm.set_min_agents_per_device(32)
+    N, M, dim = 130, 5, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=9, seed=31)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **kw))
+    b = sw.build()
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+    hdr["n_obs"][::4] = 5  # ragged: the offsets stay, fewer obstacles are read
+    x0 = api.x_init_from_swarm(b, dim)
+    G1 = sol.solve_host(hdr, rows, off, sfc, x_init=x0)
+    GS = sol.solve_sharded(comm, hdr, rows, off, sfc, x_init=x0)
+    assert (G1["status"] == 0).all() and np.array_equal(G1["status"], GS["status"])
+    assert np.array_equal(G1["x"], GS["x"]) and np.array_equal(G1["obj"], GS["obj"]) and np.array_equal(G1["info"]["flags"], GS["info"]["flags"])
+    comm.close()
+
+
+@pytest.mark.gpu
 def test_allgather_of_solved_trajectories_over_rccl(api):
     """lscqp_allgather: every device ends up with every block, in device order (broadcastMsgs' device analogue)."""
     import torch
