@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 }
             } else if (u < C::SI + C::SV + C::SA) {  // acceleration (m,i): c[i+2]-2c[i+1]+c[i]   (:462-471)
                 const int a = lane + T * (u - C::SI - C::SV);
-                if (a < C::NAR) {
+                if (a < C::NA) {
                     const int k = a / (4 * M), r = a % (4 * M), m = r / 4, i = r % 4;
                     if (!(m == 0 && i < 1)) {
                         t_ix[u] = k * P + 6 * m + i;

@@ -31,3 +31,11 @@ def api():
         B.build()
     A.lib()
     return A
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch

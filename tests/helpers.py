@@ -113,3 +113,34 @@ def kkt_from_primal(O, cls, ag, lsc, sfc, x, act_tols=(1e-7, 1e-6, 1e-5, 1e-4, 1
     eqv = np.abs(Aeq @ x - beq).max()
     iqv = max((G @ x - h).max() if len(h) else 0.0, (lb - x).max(), (x - ub).max(), 0.0)
     return stat, eqv, iqv
+
+
+def log_units(value, logged):
+    """|value - logged| in units of the sixth significant digit of `logged` (the precision of the reference's csv log)"""
+    u = 10.0 ** (np.floor(np.log10(abs(logged))) - 5) if logged != 0 else 1e-6
+    return abs(value - logged) / max(u, 1e-6)
+
+
+def pipeline_case_arrays(O, p, c):
+    """One kat_log_pipeline case -> (LSC_DTYPE[n_nbr, M, 6] or None, BOX_DTYPE[M], agent factory(goal))"""
+    M = p["M"]
+    L = None
+    if c["neighbours"]:
+        L = np.zeros((len(c["neighbours"]), M, 6), O.LSC_DTYPE)
+        L["p"], L["nrm"], L["d"] = np.float32(c["lsc_p"]), np.float32(c["lsc_nrm"]), c["lsc_d"]
+    box = np.zeros(M, O.BOX_DTYPE)
+    box["bmin"], box["bmax"] = np.float32(c["sfc_min"]), np.float32(c["sfc_max"])
+    mk = lambda goal: O.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=goal, next_waypoint=c["next_waypoint"], vmax=p["vmax"],  # noqa: E731
+                                   amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"], n_obs=len(c["neighbours"]))
+    return L, box, mk
+
+
+def logged_state_units(O, cls, c, x):
+    """largest deviation of the solution x from the logged states of case c, in units of the log's sixth digit"""
+    err = 0.0
+    for st in c["states"]:
+        got = O.state_at(cls, x, st["t"] - c["t"])
+        for g, l in zip(got, (st["p"], st["v"], st["a"])):
+            for gk, lk in zip(g[:2], l[:2]):
+                err = max(err, log_units(gk, lk))
+    return err

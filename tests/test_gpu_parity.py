@@ -19,14 +19,6 @@ KKT_TOL = 1e-8
 X_TOL = 1e-6
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-
-    assert torch.cuda.is_available(), "GPU tests need a HIP device"
-    return torch
-
-
 def _check_against_oracle(O, cls, G, R, sel=None):
     ok = (R["status"] == 0)
     assert ok.all(), "oracle failed on %s" % np.where(~ok)[0]
@@ -302,7 +294,9 @@ def _compiled_instances():
     txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lsc_dr_planner_amd", "csrc",
                             "lscqp_launch.hpp")).read()
     body = txt[txt.index("#define LSCQP_INSTANCES"):]
-    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
+    inst = [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)\)", body)]
+    assert len(inst) >= 20, "the instance list of lscqp_launch.hpp was not parsed"
+    return [i[:5] for i in inst if i[5] == 0]  # (the mixed-precision instances have their own tests)
 
 
 @pytest.mark.parametrize("M,dim,es,nslot,waves", _compiled_instances())
@@ -530,3 +524,76 @@ def test_log_known_answer_with_an_active_lsc_row_on_the_gpu(api, oracle, torch_c
     o = oracle.solve(cls, oracle.make_agent(p0=c["p0"], v0=c["v0"], a0=c["a0"], goal=c["goal"], next_waypoint=c["next_waypoint"], vmax=p["vmax"],
                                             amax=p["amax"], radius=p["radius"], nominal_velocity=p["nominal_velocity"], n_obs=len(L)), L, None)
     assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= X_TOL
+
+
+def test_log_pipeline_cases_on_the_gpu(api, oracle, torch_cuda):
+    """tests/golden/kat_log_pipeline.json, the self-contained replans of the reference's logged mission (strongest active LSC rows,
+    strongest active corridor faces, goals held back by GoalOptimizer): goal LP and QP of all of them in ONE ragged batch through
+    the C ABI, against the logged states and against the oracle."""
+    g = H.load_golden("kat_log_pipeline")
+    p, cases = g["params"], g["cases"]
+    M = p["M"]
+    cls = H.oracle_class(oracle, p, use_sfc=True)
+    sol = api.Solver(H.abi_desc(api, p, use_sfc=True))
+    arrs = [H.pipeline_case_arrays(oracle, p, c) for c in cases]
+    ags = [mk(c["goal_before_lp"]) for (L, box, mk), c in zip(arrs, cases)]
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, [a[0] for a in arrs], [a[1] for a in arrs], M)
+    hdr2, gst = sol.optimize_goal_host(hdr, rows, off, sfc)
+    assert (gst == 0).all()
+    for q, c in enumerate(cases):
+        assert np.abs(np.float32(hdr2["goal"][q]) - np.array(c["goal"])).max() <= 1e-7, (q, hdr2["goal"][q], c["goal"])
+        hdr2["goal"][q] = c["goal"]  # float32 like agent.current_goal_point
+        hdr2["terminal_segments"][q] = oracle.terminal_segments(cls, arrs[q][2](c["goal"]))  # read AFTER goalPlanning
+    G = sol.solve_host(hdr2, rows, off, sfc)
+    assert (G["status"] == 0).all(), G["status"]
+    for q, c in enumerate(cases):
+        assert H.logged_state_units(oracle, cls, c, G["x"][q]) <= c["match_units_of_6th_digit"] + 30
+        assert abs(G["obj"][q] - c["oracle_obj"]) <= OBJ_TOL * max(1.0, abs(c["oracle_obj"]))
+        o = oracle.solve(cls, arrs[q][2](c["goal"]), arrs[q][0], arrs[q][1])
+        assert np.abs(o["x"] - G["x"][q]).max() <= X_TOL
+
+
+@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (7, 3), (10, 2), (10, 3), (5, 2), (8, 2)])
+def test_dynamic_limits_bind_on_every_axis_and_in_every_segment(api, oracle, torch_cuda, request, M, dim):
+    """A long hop under tight, per-axis different acceleration limits (and, second case, velocity limits): the optimum rides the
+    limits on every axis, from the first segments (speeding up) to the last ones (braking) -- rows of src/traj_optimizer.cpp:448-471 far
+    beyond the first dim*(3M-2) of their family.  Every compiled wavefront count of the shape must agree with the oracle.
+    (Regression: the acceleration rows with index >= the matrix-row length were once dropped; the random swarms never noticed, the
+    reference's own logged mission did -- tests/golden/kat_log_pipeline.json replans 40 and 59.)"""
+    import os
+
+    wmin, wmax = [-20, -20, -20 if dim == 3 else 0], [20, 20, 20 if dim == 3 else 2.5]
+    z0 = 0.0 if dim == 3 else 1.0
+    goal = [2.0, -1.5, 1.2 if dim == 3 else z0]
+    cases = [dict(vmax=[3, 3, 3], amax=[0.6, 0.45, 0.3]), dict(vmax=[0.8, 0.5, 0.3], amax=[2.0, 1.5, 1.0])]
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=False, comm_range=0.0, world_min=wmin, world_max=wmax)
+    ags = [oracle.make_agent(p0=[0, 0, z0], v0=[0.1, 0, 0], a0=[0, 0.05, 0], goal=goal, next_waypoint=goal, nominal_velocity=1.0, **c) for c in cases]
+    O = [oracle.solve(cls, ag, None, None) for ag in ags]
+    for o, ag, fam in zip(O, ags, ("acc", "vel")):
+        assert o["status"] == 0
+        sz = oracle.count(cls, ag, None)
+        first = sz.n_sfc + sz.n_lsc + (sz.n_vel if fam == "acc" else 0)
+        n = sz.n_acc if fam == "acc" else sz.n_vel
+        act = np.nonzero(o["lam"][first:first + n] > 1e-6)[0]
+        if fam == "acc":  # the family is ordered axis by axis: active rows at the start of the first axis and at the braking end of the last
+            assert (act >= n - n // dim // 3).any() and (act < n // dim // 3).any(), act
+        else:
+            assert len(act) > 0 or M < 6, act
+    sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=False, comm_range=0.0, world_min=wmin, world_max=wmax))
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, [None, None], None, M)
+    request.addfinalizer(lambda: os.environ.pop("LSCQP_WAVES", None))
+    ran = 0
+    for pin in (None, "1", "2", "4"):
+        os.environ.pop("LSCQP_WAVES", None)
+        if pin:
+            os.environ["LSCQP_WAVES"] = pin
+        try:
+            G = sol.solve_host(hdr, None, None, None)
+        except api.LscqpError as e:
+            assert pin and e.code == api.ERR_UNSUPPORTED, e
+            continue
+        ran += 1
+        for q, o in enumerate(O):
+            assert G["status"][q] == 0
+            assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= X_TOL, (pin, q)
+    assert ran >= 2

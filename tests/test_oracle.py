@@ -223,3 +223,52 @@ def test_log_known_answer_with_an_active_lsc_row(oracle):
     R0 = oracle.solve(cls, mk(0, c["goal"]), None, None)
     e0 = _state_errors(oracle, cls, c, R0["x"])
     assert e0["v"] >= 10 * 2e-5 and e0["a"] >= 10 * 3e-4, e0
+
+
+def test_log_pipeline_replay_table():
+    """tests/golden/kat_log_pipeline.json (tools/make_golden_log_pipeline.py): the reference's whole logged mission -- 10 agents x 79
+    replans -- replayed through the restated pipeline (previous plans -> generateCLSC rows -> corridors over the forest10 map ->
+    GoalOptimizer -> TrajOptimizer).  Every one of the 790 replans reproduces the twelve logged numbers of its next two log lines
+    to the log's input precision; dozens of them with ACTIVE LSC rows, hundreds with active corridor faces."""
+    g = H.load_golden("kat_log_pipeline")
+    tab, st = g["replay"], g["stats"]
+    assert st["tried"] == st["matched"] == len(tab) == 790 and not st["chains_ended"]
+    assert sorted((r["replan"], r["agent"]) for r in tab) == [(k, a) for k in range(79) for a in range(10)]
+    m = np.array([r["match"] for r in tab])
+    assert m.max() <= 400 and np.median(m) <= 60 and (m > 150).sum() <= 60
+    assert sum(r["lam_lsc"] > 1e-6 for r in tab) == st["lsc_active"] >= 60
+    assert sum(r["lam_sfc"] > 1e-6 for r in tab) == st["sfc_active"] >= 300
+    assert sum(r["goal_lp_t"] > 1e-9 for r in tab) >= 100  # GoalOptimizer held the goal back from the waypoint
+    assert max(len(r["neighbours"]) for r in tab) == 9
+
+
+def test_log_pipeline_cases(oracle):
+    """The self-contained cases of the same fixture: goal LP and QP re-run from the stored rows / boxes land on the logged states
+    exactly as the replay did, and the stored multipliers say which constraint families the optimum leans on."""
+    g = H.load_golden("kat_log_pipeline")
+    p = g["params"]
+    cls = H.oracle_class(oracle, p, use_sfc=True)
+    n_lsc = n_sfc = n_goal = 0
+    assert 20 <= len(g["cases"]) <= 64
+    for c in g["cases"]:
+        L, box, mk = H.pipeline_case_arrays(oracle, p, c)
+        st, goal, t = oracle.goal_opt(cls, c["goal_before_lp"], c["next_waypoint"], lsc=L, sfc_last=box[p["M"] - 1])
+        assert st == 0 and abs(t - c["goal_lp_t"]) <= 1e-9 and np.abs(np.float32(goal) - np.array(c["goal"])).max() <= 1e-7
+        R = oracle.solve(cls, mk(c["goal"]), L, box)
+        assert R["status"] == 0 and abs(R["obj"] - c["oracle_obj"]) <= 1e-9 * max(1.0, abs(c["oracle_obj"]))
+        assert H.logged_state_units(oracle, cls, c, R["x"]) <= c["match_units_of_6th_digit"] + 2 <= 402
+        sz = oracle.count(cls, mk(c["goal"]), L)
+        lam = R["lam"]
+        if sz.n_lsc:
+            assert abs(lam[sz.n_sfc:sz.n_sfc + sz.n_lsc].max() - c["max_lsc_multiplier"]) <= 1e-5 * max(1.0, c["max_lsc_multiplier"])
+        n_lsc += c["max_lsc_multiplier"] > 1e-3
+        n_sfc += c["max_sfc_multiplier"] > 1e-3
+        n_goal += c["goal_lp_t"] > 1e-6
+    assert n_lsc >= 10 and n_sfc >= 10 and n_goal >= 4
+    # the LSC rows matter: without them the strongest case misses the log by far more than the replay's acceptance bound
+    c = max(g["cases"], key=lambda c: c["max_lsc_multiplier"])
+    L, box, mk = H.pipeline_case_arrays(oracle, p, c)
+    ag0 = mk(c["goal"])
+    ag0["n_obs"] = 0
+    R0 = oracle.solve(cls, ag0, None, box)
+    assert R0["status"] != 0 or H.logged_state_units(oracle, cls, c, R0["x"]) >= 10 * 400
