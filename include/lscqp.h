@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LSCQP_VERSION_MAJOR 0
-#define LSCQP_VERSION_MINOR 5
+#define LSCQP_VERSION_MINOR 6
 
 /* ---- return codes of the API calls themselves (misuse / runtime errors) ---- */
 enum {
@@ -508,6 +508,92 @@ int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map map, int32_t mode, int6
 /* Same, HOST pointers, synchronous; M boxes per agent (sfc is read and updated in place). */
 int lscqp_construct_sfc(lscqp_map map, int32_t mode, int32_t M, int64_t n, const double* points, const double* radius,
                         lscqp_box* sfc, int32_t* status_out);
+
+/* ---- the caller of the path: one replan of a batch of agents as one chain of device work ----------
+ *
+ * Device analogue of TrajPlanner::plan / planImpl (reference src/traj_planner.cpp:33-60, 117-139) run for every local agent of
+ * the mission at once, and of the loop around it in MultiSyncSimulator (src/multi_sync_simulator.cpp:305-400).  A plan object
+ * owns the state the reference's planners carry from replan to replan -- previous plans (TrajPlanner::prev_traj), current goal
+ * points, corridors -- plus the work buffers, all in HBM, and enqueues
+ *     obstaclePrediction / initialTrajPlanning (PREVIOUSSOLUTION, :273-310, 399-423)  lscqp_shift_traj(_partial)_device
+ *     broadcastMsgs' range filter (src/multi_sync_simulator.cpp:318-333)              lscqp_select_neighbours_device
+ *     constructLSC (:552-569)                                                         lscqp_generate_constraints_device
+ *     constructSFC / generateSFC (:571-579, 738-753; initializeSFC on the first replan) lscqp_construct_sfc_device
+ *     goalPlanningWithGridBasedPlanner (:545-550)                                     lscqp_optimize_goal_device; the goal is then
+ *                                                                                     held as point3d (float32) and
+ *                                                                                     getTerminalSegments_old is evaluated with
+ *                                                                                     octomap's float32 arithmetic
+ *     trajOptimization (:755-803)                                                     lscqp_solve_batch_device_ex with the initial
+ *                                                                                     trajectory as the start and the device-side
+ *                                                                                     second pass; a QP that is not OPTIMAL leaves
+ *                                                                                     desired_traj = initial_traj (failsafe :796-797)
+ *     prev_traj = desired_traj (:51); AgentManager::doStep (src/agent_manager.cpp:29-50)  plans updated in place;
+ *                                                                                     lscqp_validate_step_device (isSolValid is
+ *                                                                                     reported, not acted on: the reference consults
+ *                                                                                     it in DLSC mode only, :763-766)
+ * on ONE stream, with no host synchronisation, allocation or copy in between.  lscqp_plan_step_graph captures that chain once in
+ * a hipGraph and replays it: one graph launch per replan instead of ten kernel launches.
+ * Host work that remains is what the survey leaves out of scope: the grid planner / MAPF layer writes each local agent's next
+ * waypoint into LSCQP_PLAN_BUF_WAYPOINT before the step (and, unless closed_loop is set, the simulator writes the agents' states).
+ * Dynamic (non-agent) obstacles are not part of the chain (lscqp_generate_lsc_obstacles_device is available separately).
+ * Sharding (section 8e): rank r owns the agents [first_agent, first_agent + n_agents) of n_total; its plan needs every agent's
+ * previous plan, state and goal point, so the owners' slices of LSCQP_PLAN_BUF_PLAN / _STATE / _GOAL are all-gathered between
+ * steps (lscqp_allgather; the layout is [n_total][...] on every rank, so the gather is in place). */
+typedef struct lscqp_plan_s* lscqp_plan;
+typedef struct lscqp_agent_param { /* the Agent fields the chain reads (include/sp_const.hpp Agent; mission file values) */
+    double radius, downwash;
+    double max_vel[3], max_acc[3];
+    double nominal_velocity;
+} lscqp_agent_param;
+typedef struct lscqp_plan_desc {
+    int64_t n_agents;        /* local agents */
+    int64_t n_total;         /* agents of the mission (each other's obstacles) */
+    int64_t first_agent;     /* global id of local agent 0 */
+    int32_t n_obs;           /* row slots per agent: in-range agents beyond it are cut to the nearest ones and reported in
+                                LSCQP_PLAN_BUF_IN_RANGE (> n_obs), never silently */
+    int32_t constraint_mode; /* LSCQP_GEN_LSC / _CLSC / _BVC (constructLSC's switch, :555-566) */
+    int32_t sfc_mode;        /* LSCQP_SFC_FROM_HULL (goal mode grid_based_planner) or LSCQP_SFC_FROM_POINT; ignored without a map */
+    int32_t optimize_goal;   /* != 0: GoalOptimizer moves the goal point towards the waypoint (goal mode grid_based_planner);
+                                0: the goal points are left as the caller set them (static goal modes) */
+    int32_t closed_loop;     /* != 0: the local agents' next states (doStep) become their current states for the next replan */
+    int32_t reserved;
+    double time_step;        /* multisim_time_step: == dt shifts the plans by one segment, < dt uses Segment::subSegment */
+    double z_2d;             /* world_z_2d of 2-D missions */
+} lscqp_plan_desc;
+/* Buffers of a plan (device pointers through lscqp_plan_buffer; lscqp_plan_upload / _download copy synchronously).
+ * "all": [n_total] entries indexed by global id; "local": [n_agents] entries. */
+#define LSCQP_PLAN_BUF_STATE 0        /* in   all    double[9]: position, velocity, acceleration (float32 values, as State holds them) */
+#define LSCQP_PLAN_BUF_WAYPOINT 1     /* in   local  double[3]: agent.next_waypoint */
+#define LSCQP_PLAN_BUF_PLAN 2         /* i/o  all    double[dim*M*6]: previous plans in, the local agents' new plans out */
+#define LSCQP_PLAN_BUF_GOAL 3         /* i/o  all    double[3]: current goal points; the local agents' are updated */
+#define LSCQP_PLAN_BUF_HEADER 4       /* out  local  lscqp_header of the last replan */
+#define LSCQP_PLAN_BUF_ROWS 5         /* out  local  lscqp_row[n_obs*M*6] of the last replan */
+#define LSCQP_PLAN_BUF_SFC 6          /* i/o  local  lscqp_box[M]: corridors */
+#define LSCQP_PLAN_BUF_STATUS 7       /* out  local  int32: LSCQP_STATUS_* of the QP */
+#define LSCQP_PLAN_BUF_GOAL_STATUS 8  /* out  local  int32: LSCQP_STATUS_* of the goal LP */
+#define LSCQP_PLAN_BUF_SFC_STATUS 9   /* out  local  int32: 1 = corridor updated, 0 = previous box kept / seed inside an obstacle */
+#define LSCQP_PLAN_BUF_VALID 10       /* out  local  int32: isSolValid */
+#define LSCQP_PLAN_BUF_IN_RANGE 11    /* out  local  int32: agents within communication range */
+#define LSCQP_PLAN_BUF_NEXT_STATE 12  /* out  local  double[9]: state at time_step along the new plan */
+#define LSCQP_PLAN_BUF_OBJECTIVE 13   /* out  local  double */
+#define LSCQP_PLAN_BUF_INFO 14        /* out  local  lscqp_info */
+#define LSCQP_PLAN_BUF_COUNT 15
+/* agents [n_total] (host).  map: required exactly when the class uses corridors.  The class's row_format must be LSCQP_ROWS_F64. */
+int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc, const lscqp_agent_param* agents, lscqp_plan* out);
+void lscqp_plan_destroy(lscqp_plan plan);
+/* Mission start (host pointers, synchronous): every agent hovers at its start position [n_total][3] (the plans the reference's
+ * planners start from, planner_seq < 2), goal points := goal_points, or the start positions if NULL (AgentManager's constructor),
+ * waypoints := the goal points; the next step is a FIRST replan (initializeSFC). */
+int lscqp_plan_reset(lscqp_plan plan, const double* start_positions, const double* goal_points);
+void* lscqp_plan_buffer(lscqp_plan plan, int32_t which, uint64_t* bytes_out);
+int lscqp_plan_upload(lscqp_plan plan, int32_t which, const void* host, uint64_t offset, uint64_t bytes);
+int lscqp_plan_download(lscqp_plan plan, int32_t which, void* host, uint64_t offset, uint64_t bytes);
+/* One replan of all local agents, asynchronous on `stream` (hipStream_t as void*; NULL = default stream). */
+int lscqp_plan_step(lscqp_plan plan, void* stream);
+/* The same through a hipGraph captured at the first call that is not a first replan (that one runs eagerly: it differs, and it
+ * warms the kernels' one-time attributes up).  Results are bit-for-bit those of lscqp_plan_step. */
+int lscqp_plan_step_graph(lscqp_plan plan, void* stream);
+int64_t lscqp_plan_graph_nodes(lscqp_plan plan); /* nodes of the captured graph, 0 before the capture */
 
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */

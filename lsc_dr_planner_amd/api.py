@@ -169,6 +169,24 @@ def lib():
         L.lscqp_construct_sfc_device.argtypes = [vp, vp, C.c_int32, C.c_int64] + [vp] * 5
         L.lscqp_validate_step_device.restype = C.c_int
         L.lscqp_validate_step_device.argtypes = [vp, C.c_int64, C.c_double, C.c_double] + [vp] * 6
+        L.lscqp_plan_create.restype = C.c_int
+        L.lscqp_plan_create.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_void_p)]
+        L.lscqp_plan_destroy.restype = None
+        L.lscqp_plan_destroy.argtypes = [vp]
+        L.lscqp_plan_reset.restype = C.c_int
+        L.lscqp_plan_reset.argtypes = [vp, vp, vp]
+        L.lscqp_plan_buffer.restype = C.c_void_p
+        L.lscqp_plan_buffer.argtypes = [vp, C.c_int32, vp]
+        L.lscqp_plan_upload.restype = C.c_int
+        L.lscqp_plan_upload.argtypes = [vp, C.c_int32, vp, C.c_uint64, C.c_uint64]
+        L.lscqp_plan_download.restype = C.c_int
+        L.lscqp_plan_download.argtypes = [vp, C.c_int32, vp, C.c_uint64, C.c_uint64]
+        L.lscqp_plan_step.restype = C.c_int
+        L.lscqp_plan_step.argtypes = [vp, vp]
+        L.lscqp_plan_step_graph.restype = C.c_int
+        L.lscqp_plan_step_graph.argtypes = [vp, vp]
+        L.lscqp_plan_graph_nodes.restype = C.c_int64
+        L.lscqp_plan_graph_nodes.argtypes = [vp]
         L.lscqp_last_error.restype = C.c_char_p
         L.lscqp_version.restype = C.c_char_p
         _lib = L
@@ -184,6 +202,8 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_shift_traj_device", "lscqp_shift_traj_partial_device", "lscqp_generate_constraints_device_ex",
                     "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
                     "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
+                    "lscqp_plan_create", "lscqp_plan_destroy", "lscqp_plan_reset", "lscqp_plan_buffer", "lscqp_plan_upload", "lscqp_plan_download",
+                    "lscqp_plan_step", "lscqp_plan_step_graph", "lscqp_plan_graph_nodes",
                     "lscqp_last_error", "lscqp_version"]
 
 
@@ -252,6 +272,97 @@ class WorldMap:
             self.close()
         except Exception:
             pass
+
+
+AGENT_PARAM_DTYPE = np.dtype([("radius", "f8"), ("downwash", "f8"), ("max_vel", "f8", 3), ("max_acc", "f8", 3), ("nominal_velocity", "f8")])
+
+
+class PlanDesc(C.Structure):  # lscqp_plan_desc
+    _fields_ = [("n_agents", C.c_int64), ("n_total", C.c_int64), ("first_agent", C.c_int64), ("n_obs", C.c_int32), ("constraint_mode", C.c_int32),
+                ("sfc_mode", C.c_int32), ("optimize_goal", C.c_int32), ("closed_loop", C.c_int32), ("reserved", C.c_int32),
+                ("time_step", C.c_double), ("z_2d", C.c_double)]
+
+
+(PLAN_STATE, PLAN_WAYPOINT, PLAN_PLAN, PLAN_GOAL, PLAN_HEADER, PLAN_ROWS, PLAN_SFC, PLAN_STATUS, PLAN_GOAL_STATUS, PLAN_SFC_STATUS, PLAN_VALID,
+ PLAN_IN_RANGE, PLAN_NEXT_STATE, PLAN_OBJECTIVE, PLAN_INFO) = range(15)
+
+
+class Plan:
+    """lscqp_plan: one replan of a batch of agents as one chain of device work (include/lscqp.h, "the caller of the path"), eager
+    (`step`) or through a captured hipGraph (`step_graph`).  Buffers are addressed by the PLAN_* constants; `get` / `put` copy
+    synchronously, `pointer` returns the device address."""
+
+    _DT = {PLAN_STATE: np.float64, PLAN_WAYPOINT: np.float64, PLAN_PLAN: np.float64, PLAN_GOAL: np.float64, PLAN_STATUS: np.int32,
+           PLAN_GOAL_STATUS: np.int32, PLAN_SFC_STATUS: np.int32, PLAN_VALID: np.int32, PLAN_IN_RANGE: np.int32, PLAN_NEXT_STATE: np.float64,
+           PLAN_OBJECTIVE: np.float64}
+
+    def __init__(self, solver, world_map, n_agents, n_obs, agents, n_total=None, first_agent=0, constraint_mode=1, sfc_mode=1,
+                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0):
+        self._p = None
+        n_total = n_agents if n_total is None else n_total
+        d = PlanDesc()
+        d.n_agents, d.n_total, d.first_agent, d.n_obs = n_agents, n_total, first_agent, n_obs
+        d.constraint_mode, d.sfc_mode, d.optimize_goal, d.closed_loop = constraint_mode, sfc_mode, int(optimize_goal), int(closed_loop)
+        d.time_step = float(solver.desc.dt if time_step is None else time_step)
+        d.z_2d = float(z_2d)
+        ag = np.ascontiguousarray(agents, dtype=AGENT_PARAM_DTYPE)
+        if ag.shape != (n_total,):
+            raise ValueError("agents: one AGENT_PARAM_DTYPE record per agent of the mission")
+        h = C.c_void_p()
+        rc = lib().lscqp_plan_create(solver._h, world_map._h if world_map is not None else None, C.byref(d), ag.ctypes.data_as(C.c_void_p), C.byref(h))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        self._p, self._solver, self._map = h, solver, world_map  # (keeps the solver and the map alive)
+        self.n_agents, self.n_total, self.first_agent, self.n_obs, self.M, self.nv = n_agents, n_total, first_agent, n_obs, solver.desc.M, solver.nv
+        self._dt = dict(self._DT)
+        self._dt.update({PLAN_HEADER: HEADER_DTYPE, PLAN_ROWS: ROW_DTYPE, PLAN_SFC: BOX_DTYPE, PLAN_INFO: INFO_DTYPE})
+
+    def close(self):
+        if self._p:
+            lib().lscqp_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def reset(self, start_positions, goal_points=None):
+        sp = np.ascontiguousarray(start_positions, dtype=np.float64).reshape(self.n_total, 3)
+        gp = None if goal_points is None else np.ascontiguousarray(goal_points, dtype=np.float64).reshape(self.n_total, 3)
+        self._check(lib().lscqp_plan_reset(self._p, sp.ctypes.data_as(C.c_void_p), None if gp is None else gp.ctypes.data_as(C.c_void_p)))
+
+    def pointer(self, which):
+        nb = C.c_uint64()
+        ptr = lib().lscqp_plan_buffer(self._p, which, C.byref(nb))
+        return ptr, nb.value
+
+    def get(self, which):
+        _, nb = self.pointer(which)
+        out = np.zeros(nb // np.dtype(self._dt[which]).itemsize, dtype=self._dt[which])
+        self._check(lib().lscqp_plan_download(self._p, which, out.ctypes.data_as(C.c_void_p), 0, nb))
+        return out
+
+    def put(self, which, array, first=0):
+        """array: entries [first, first + len) of the buffer, in units of the buffer's record (an agent's 9 doubles, ...)."""
+        a = np.ascontiguousarray(array, dtype=self._dt[which])
+        _, nb = self.pointer(which)
+        per = {PLAN_STATE: 72, PLAN_WAYPOINT: 24, PLAN_GOAL: 24, PLAN_PLAN: 8 * self.nv, PLAN_SFC: 48 * self.M}.get(which)
+        if per is None:
+            raise ValueError("not an input buffer")
+        self._check(lib().lscqp_plan_upload(self._p, which, a.ctypes.data_as(C.c_void_p), first * per, a.nbytes))
+
+    def step(self, stream=None, graph=False):
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._check((lib().lscqp_plan_step_graph if graph else lib().lscqp_plan_step)(self._p, sp))
+
+    def graph_nodes(self):
+        return int(lib().lscqp_plan_graph_nodes(self._p))
 
 
 def shard_range(n, n_used, g):

@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # split them into scalars; every single-element access then moves a whole 16/32-register tuple between AGPRs and VGPRs
 # (measured on MI355X: 0.192 -> 0.158 ms per 64-QP batch, 0.875 -> 0.671 ms per 4096-QP batch, scratch 336 -> 0 B/lane).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector",
-         "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + os.environ.get("LSCQP_EXTRA_FLAGS", "").split()
 
 
 def instances():
@@ -80,6 +80,11 @@ def build(force=False, verbose=False, jobs=None):
     comm_src = os.path.join(CSRC, "lscqp_comm.hip")
     if force or _newer(comm_o, hdrs + [comm_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", comm_src, "-o", comm_o])
+    plan_o = os.path.join(OBJ, "lscplan.o")
+    objs.append(plan_o)
+    plan_src = os.path.join(CSRC, "lscplan.hip")
+    if force or _newer(plan_o, hdrs + [plan_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", plan_src, "-o", plan_o])
     gen_o = os.path.join(OBJ, "lscgen.o")
     objs.append(gen_o)
     gen_src = os.path.join(CSRC, "lscgen.hip")

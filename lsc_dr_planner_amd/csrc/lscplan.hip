@@ -1,0 +1,435 @@
+// lscplan.hip — one replan of a whole batch of agents as ONE chain of device work, gfx950 only: the device analogue of
+//   TrajPlanner::plan / planImpl          reference src/traj_planner.cpp:33-60, 117-139
+//   MultiSyncSimulator's per-agent loop   src/multi_sync_simulator.cpp:305-352 (who is whose obstacle), :354-400 (plan, doStep)
+// planImpl's steps map onto the kernels of this library, all enqueued on one stream without a host round trip:
+//   obstaclePrediction + initialTrajPlanning (PrevSol)  -> lscqp_shift_traj(_partial)_device over every agent's previous plan
+//   broadcastMsgs' range filter                         -> lscqp_select_neighbours_device
+//   constructLSC                                        -> lscqp_generate_constraints_device (LSC / CLSC / BVC)
+//   constructSFC                                        -> lscqp_construct_sfc_device (initializeSFC on the first replan)
+//   goalPlanning (grid-based planner goal mode)         -> lscqp_optimize_goal_device, result held as point3d (float32)
+//   trajOptimization + failsafe (:755-803)              -> lscqp_solve_batch_device_ex (+ device-side second pass), failed QPs
+//                                                          keep the initial trajectory
+//   prev_traj = desired_traj; AgentManager::doStep      -> the plan buffer is updated in place; lscqp_validate_step_device
+// Two small kernels of this file glue them: `prepare` (headers, corridor seed points, the initial trajectory in the solver's
+// layout) and `commit` (failsafe, goal point).  Because nothing in the chain synchronises, allocates or copies through the
+// host, the whole replan can be captured once in a hipGraph and replayed (lscqp_plan_step_graph): one graph launch instead of
+// ten kernel launches per replan.  What stays on the host is what is out of scope: the waypoints of the
+// grid planner / MAPF layer, written into the plan's waypoint buffer before each step.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lscqp.h"
+
+extern "C" int lscqp_set_error_(int code, const char* msg);
+extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h);
+
+namespace lscplan {
+
+constexpr int kThreads = 64;
+
+struct Shape {
+    int M, dim, nv, n_obs;
+    int64_t n_agents, n_total, first_agent;
+    double z_2d, dt;
+};
+
+// headers + corridor seed points + initial trajectory in the solver's layout; thread t serves agent t of the mission for
+// the position table and local agent t for the rest
+__global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_replan, const double* __restrict__ state,
+                                                            const double* __restrict__ waypoint, const double* __restrict__ goal,
+                                                            const double* __restrict__ traj, const lscqp_agent_param* __restrict__ par,
+                                                            double* __restrict__ pos, lscqp_header* __restrict__ hdr,
+                                                            double* __restrict__ points, double* __restrict__ x_init) {
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t < s.n_total)
+        for (int k = 0; k < 3; k++) pos[t * 3 + k] = state[t * 9 + k];
+    if (t >= s.n_agents) return;
+    const int64_t g = s.first_agent + t;
+    lscqp_header H;
+    memset(&H, 0, sizeof H);
+    const lscqp_agent_param A = par[g];
+    for (int k = 0; k < 3; k++) {
+        H.p0[k] = state[g * 9 + k];
+        H.v0[k] = state[g * 9 + 3 + k];
+        H.a0[k] = state[g * 9 + 6 + k];
+        H.goal[k] = goal[g * 3 + k];
+        H.next_waypoint[k] = waypoint[t * 3 + k];
+        H.vmax[k] = A.max_vel[k];
+        H.amax[k] = A.max_acc[k];
+    }
+    H.radius = A.radius;
+    H.nominal_velocity = A.nominal_velocity;
+    H.n_obs = s.n_obs;
+    H.terminal_segments = 0;  // set by finalize_goal_kernel once the goal LP has moved the goal
+    hdr[t] = H;
+    const double* tr = traj + g * s.M * 18;
+    double* P = points + t * 9;
+    for (int k = 0; k < 3; k++) {
+        // generateSFC (src/traj_planner.cpp:738-753): the agent's position on the first replan, afterwards the hull
+        // {initial_traj.lastPoint(), current_goal_point} and the next waypoint
+        P[k] = first_replan ? H.p0[k] : tr[((s.M - 1) * 6 + 5) * 3 + k];
+        P[3 + k] = first_replan ? H.p0[k] : H.goal[k];
+        P[6 + k] = first_replan ? H.p0[k] : H.next_waypoint[k];
+    }
+    double* xi = x_init + t * s.nv;
+    for (int k = 0; k < s.dim; k++)
+        for (int m = 0; m < s.M; m++)
+            for (int i = 0; i < 6; i++) xi[(k * s.M + m) * 6 + i] = tr[(m * 6 + i) * 3 + k];
+}
+
+// after the goal LP: agent.current_goal_point is a point3d (GoalOptimizer::solve returns one, src/goal_optimizer.cpp:7-55), and
+// getTerminalSegments_old (src/traj_optimizer.cpp:530-538) reads it with octomap's float32 vector arithmetic
+__global__ __launch_bounds__(kThreads) void finalize_goal_kernel(Shape s, lscqp_header* __restrict__ hdr) {
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= s.n_agents) return;
+    lscqp_header* H = hdr + t;
+    float d[3];
+    for (int k = 0; k < 3; k++) {
+        const float gk = (float)H->goal[k];
+        H->goal[k] = (double)gk;
+        d[k] = gk - (float)H->p0[k];
+    }
+    const float nsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double ideal_flight_time = sqrt((double)nsq) / H->nominal_velocity;
+    int ts = (int)((s.M * s.dt - ideal_flight_time + 1e-9) / s.dt);
+    H->terminal_segments = ts > 1 ? ts : 1;
+}
+
+// failsafe of trajOptimization (:796-797: a failed solve leaves desired_traj = initial_traj), prev_traj = desired_traj (:51),
+// and the goal point the planner carries into the next replan
+__global__ __launch_bounds__(kThreads) void commit_kernel(Shape s, const int32_t* __restrict__ status, const lscqp_header* __restrict__ hdr,
+                                                           const double* __restrict__ x_new, const double* __restrict__ x_init,
+                                                           double* __restrict__ x_plan, double* __restrict__ goal) {
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= s.n_agents * s.nv) return;
+    const int64_t q = e / s.nv, j = e - q * s.nv;
+    const bool ok = status[q] == LSCQP_STATUS_OPTIMAL;
+    x_plan[(s.first_agent + q) * s.nv + j] = ok ? x_new[e] : x_init[e];
+    if (j < 3) goal[(s.first_agent + q) * 3 + j] = hdr[q].goal[j];
+}
+
+}  // namespace lscplan
+
+struct lscqp_plan_s {
+    lscqp_handle h = nullptr;
+    lscqp_map map = nullptr;
+    lscqp_plan_desc d;
+    lscplan::Shape s;
+    int device = 0;
+    bool first = true;
+    int64_t steps = 0;
+    void* buf[LSCQP_PLAN_BUF_COUNT] = {};
+    size_t bytes[LSCQP_PLAN_BUF_COUNT] = {};
+    // private buffers
+    lscqp_agent_param* par = nullptr;
+    double *radius = nullptr, *downwash = nullptr, *traj = nullptr, *pos = nullptr, *points = nullptr, *x_init = nullptr, *x_new = nullptr;
+    int32_t* nbr = nullptr;
+    uint64_t* off = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;
+    std::vector<void*> owned;
+};
+
+namespace {
+
+int hip_fail(hipError_t e, const char* what) {
+    return lscqp_set_error_(LSCQP_ERR_HIP, (std::string(what) + ": " + hipGetErrorString(e)).c_str());
+}
+
+template <class T>
+int dalloc(lscqp_plan_s* p, T** out, size_t count) {
+    void* ptr = nullptr;
+    const size_t b = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&ptr, b);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan buffer)");
+    e = hipMemset(ptr, 0, b);
+    if (e != hipSuccess) return hip_fail(e, "hipMemset(plan buffer)");
+    p->owned.push_back(ptr);
+    *out = (T*)ptr;
+    return LSCQP_OK;
+}
+
+template <class T>
+int dalloc_pub(lscqp_plan_s* p, int which, size_t count) {
+    T* ptr = nullptr;
+    const int rc = dalloc(p, &ptr, count);
+    if (rc != LSCQP_OK) return rc;
+    p->buf[which] = ptr;
+    p->bytes[which] = count * sizeof(T);
+    return LSCQP_OK;
+}
+
+#define PLAN_TRY(call)                 \
+    do {                               \
+        const int rc_ = (call);        \
+        if (rc_ != LSCQP_OK) return rc_; \
+    } while (0)
+
+// the whole replan on `stream`; nothing here synchronises, allocates or touches host memory (capturable)
+int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
+    const lscplan::Shape& s = p->s;
+    lscqp_handle h = p->h;
+    double* state = (double*)p->buf[LSCQP_PLAN_BUF_STATE];
+    double* waypoint = (double*)p->buf[LSCQP_PLAN_BUF_WAYPOINT];
+    double* x_plan = (double*)p->buf[LSCQP_PLAN_BUF_PLAN];
+    double* goal = (double*)p->buf[LSCQP_PLAN_BUF_GOAL];
+    lscqp_header* hdr = (lscqp_header*)p->buf[LSCQP_PLAN_BUF_HEADER];
+    lscqp_row* rows = (lscqp_row*)p->buf[LSCQP_PLAN_BUF_ROWS];
+    lscqp_box* sfc = (lscqp_box*)p->buf[LSCQP_PLAN_BUF_SFC];
+    int32_t* status = (int32_t*)p->buf[LSCQP_PLAN_BUF_STATUS];
+    int32_t* goal_status = (int32_t*)p->buf[LSCQP_PLAN_BUF_GOAL_STATUS];
+    int32_t* sfc_status = (int32_t*)p->buf[LSCQP_PLAN_BUF_SFC_STATUS];
+    int32_t* valid = (int32_t*)p->buf[LSCQP_PLAN_BUF_VALID];
+    int32_t* count = (int32_t*)p->buf[LSCQP_PLAN_BUF_IN_RANGE];
+    double* state_out = (double*)p->buf[LSCQP_PLAN_BUF_NEXT_STATE];
+    double* obj = (double*)p->buf[LSCQP_PLAN_BUF_OBJECTIVE];
+    lscqp_info* info = (lscqp_info*)p->buf[LSCQP_PLAN_BUF_INFO];
+    const double fraction = p->d.time_step / s.dt;
+    // obstaclePredictionWithPrevSol / initialTrajPlanningPrevSol for every agent of the mission (:273-310, 399-423)
+    if (fraction >= 1.0 - 1e-9)
+        PLAN_TRY(lscqp_shift_traj_device(h, s.n_total, 1, s.z_2d, x_plan, p->traj, stream));
+    else
+        PLAN_TRY(lscqp_shift_traj_partial_device(h, s.n_total, fraction, s.z_2d, x_plan, p->traj, stream));
+    const int64_t nt = s.n_total > s.n_agents ? s.n_total : s.n_agents;
+    hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)((nt + lscplan::kThreads - 1) / lscplan::kThreads)), dim3(lscplan::kThreads), 0, stream,
+                       s, first_replan ? 1 : 0, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init);
+    if (p->map)
+        PLAN_TRY(lscqp_construct_sfc_device(h, p->map, first_replan ? LSCQP_SFC_INIT : p->d.sfc_mode, s.n_agents, p->points,
+                                            p->radius + s.first_agent, sfc, sfc_status, stream));
+    PLAN_TRY(lscqp_select_neighbours_device(h, s.n_agents, s.first_agent, s.n_total, s.n_obs, lscqp_class_desc_of_(h)->communication_range, p->pos, p->nbr, count,
+                                            stream));
+    if (s.n_obs > 0)
+        PLAN_TRY(lscqp_generate_constraints_device(h, p->d.constraint_mode, s.n_agents, s.n_obs, s.first_agent, p->traj, p->nbr, p->radius,
+                                                   p->downwash, goal, rows, stream));
+    if (p->d.optimize_goal)
+        PLAN_TRY(lscqp_optimize_goal_device(h, s.n_agents, hdr, rows, p->off, p->map ? sfc : nullptr, goal_status, stream));
+    const unsigned nb = (unsigned)((s.n_agents + lscplan::kThreads - 1) / lscplan::kThreads);
+    hipLaunchKernelGGL(lscplan::finalize_goal_kernel, dim3(nb), dim3(lscplan::kThreads), 0, stream, s, hdr);
+    PLAN_TRY(lscqp_solve_batch_device_ex(h, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj, status,
+                                         info, 1, stream));
+    const int64_t ne = s.n_agents * s.nv;
+    hipLaunchKernelGGL(lscplan::commit_kernel, dim3((unsigned)((ne + lscplan::kThreads - 1) / lscplan::kThreads)), dim3(lscplan::kThreads), 0, stream, s,
+                       status, hdr, p->x_new, p->x_init, x_plan, goal);
+    PLAN_TRY(lscqp_validate_step_device(h, s.n_agents, p->d.time_step, s.z_2d, x_plan + s.first_agent * s.nv, hdr, p->map ? sfc : nullptr, valid,
+                                        state_out, stream));
+    if (p->d.closed_loop) {
+        const hipError_t e = hipMemcpyAsync(state + s.first_agent * 9, state_out, sizeof(double) * 9 * s.n_agents, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(next state)");
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "HIP launch failed (plan step)");
+    return LSCQP_OK;
+}
+
+void drop_graph(lscqp_plan_s* p) {
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->exec = nullptr;
+    p->graph = nullptr;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc, const lscqp_agent_param* agents, lscqp_plan* out) {
+    if (!h || !desc || !agents || !out) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    if (desc->n_agents <= 0 || desc->first_agent < 0 || desc->n_total < desc->first_agent + desc->n_agents)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes (n_agents > 0, n_total >= first_agent + n_agents required)");
+    if (desc->n_obs < 0) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "negative n_obs");
+    if (desc->n_obs > lscqp_max_obstacles(h))
+        return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "n_obs exceeds the largest compiled kernel instance of the shape (lscqp_max_obstacles)");
+    if (desc->constraint_mode != LSCQP_GEN_LSC && desc->constraint_mode != LSCQP_GEN_CLSC && desc->constraint_mode != LSCQP_GEN_BVC)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "constraint_mode must be LSCQP_GEN_LSC, LSCQP_GEN_CLSC or LSCQP_GEN_BVC");
+    if (desc->sfc_mode != LSCQP_SFC_FROM_HULL && desc->sfc_mode != LSCQP_SFC_FROM_POINT)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "sfc_mode must be LSCQP_SFC_FROM_HULL or LSCQP_SFC_FROM_POINT");
+    const int uses_sfc = lscqp_uses_sfc(h);
+    if ((uses_sfc != 0) != (map != nullptr))
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "a map is required exactly when the solver class uses corridors (use_sfc)");
+    const int M = lscqp_num_segments(h), nv = lscqp_num_variables(h);
+    const double dt_probe = lscqp_class_desc_of_(h)->dt;
+    if (!(desc->time_step > 0) || desc->time_step > dt_probe * (1 + 1e-9))
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "0 < time_step <= dt required (multisim_time_step, src/traj_planner.cpp:401-421)");
+    if (lscqp_row_bytes(h) != (int)sizeof(lscqp_row))
+        return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "the plan chain uses 32-byte rows (row_format = LSCQP_ROWS_F64)");
+    lscqp_plan_s* p = new lscqp_plan_s();
+    p->h = h;
+    p->map = map;
+    p->d = *desc;
+    p->s.M = M;
+    p->s.dim = nv / (6 * M);
+    p->s.nv = nv;
+    p->s.n_obs = desc->n_obs;
+    p->s.n_agents = desc->n_agents;
+    p->s.n_total = desc->n_total;
+    p->s.first_agent = desc->first_agent;
+    p->s.z_2d = desc->z_2d;
+    p->s.dt = dt_probe;
+    if (hipGetDevice(&p->device) != hipSuccess) {
+        delete p;
+        return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    }
+    const size_t n = (size_t)desc->n_agents, nt = (size_t)desc->n_total, P = (size_t)M * 6, no = (size_t)desc->n_obs;
+    int rc = LSCQP_OK;
+    auto ok = [&](int r) { return rc == LSCQP_OK && (rc = r) == LSCQP_OK; };
+    ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_STATE, nt * 9)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_WAYPOINT, n * 3)) &&
+        ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_PLAN, nt * nv)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_GOAL, nt * 3)) &&
+        ok(dalloc_pub<lscqp_header>(p, LSCQP_PLAN_BUF_HEADER, n)) && ok(dalloc_pub<lscqp_row>(p, LSCQP_PLAN_BUF_ROWS, n * no * P)) &&
+        ok(dalloc_pub<lscqp_box>(p, LSCQP_PLAN_BUF_SFC, n * M)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_STATUS, n)) &&
+        ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_GOAL_STATUS, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_SFC_STATUS, n)) &&
+        ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_VALID, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_IN_RANGE, n)) &&
+        ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_NEXT_STATE, n * 9)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_OBJECTIVE, n)) &&
+        ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
+        ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
+        ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
+        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1));
+    if (rc == LSCQP_OK) {
+        std::vector<double> r(nt), w(nt);
+        std::vector<uint64_t> off(n + 1);
+        for (size_t i = 0; i < nt; i++) {
+            r[i] = agents[i].radius;
+            w[i] = agents[i].downwash;
+        }
+        for (size_t i = 0; i <= n; i++) off[i] = (uint64_t)(i * no * P);
+        hipError_t e = hipMemcpy(p->par, agents, nt * sizeof(lscqp_agent_param), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->radius, r.data(), nt * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->downwash, w.data(), nt * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(p->off, off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->cap, hipStreamNonBlocking);
+        if (e != hipSuccess) rc = hip_fail(e, "plan set-up");
+    }
+    if (rc != LSCQP_OK) {
+        lscqp_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return LSCQP_OK;
+}
+
+void lscqp_plan_destroy(lscqp_plan p) {
+    if (!p) return;
+    DeviceGuard g(p->device);
+    (void)hipDeviceSynchronize();
+    drop_graph(p);
+    if (p->cap) (void)hipStreamDestroy(p->cap);
+    for (void* q : p->owned) (void)hipFree(q);
+    delete p;
+}
+
+int lscqp_plan_reset(lscqp_plan p, const double* start_positions, const double* goal_points) {
+    if (!p || !start_positions) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard g(p->device);
+    const lscplan::Shape& s = p->s;
+    const size_t nt = (size_t)s.n_total, P = (size_t)s.M * 6;
+    std::vector<double> st(nt * 9, 0.0), x(nt * s.nv), gl(nt * 3);
+    for (size_t a = 0; a < nt; a++) {
+        for (int k = 0; k < 3; k++) {
+            // State holds point3d; a 2-D mission flies at z = world_z_2d (src/agent_manager.cpp:40-42)
+            const double v = (k < s.dim) ? (double)(float)start_positions[a * 3 + k] : (double)(float)s.z_2d;
+            st[a * 9 + k] = v;
+            gl[a * 3 + k] = goal_points ? (double)(float)goal_points[a * 3 + k] : v;  // AgentManager ctor: current_goal_point = start
+        }
+        for (int k = 0; k < s.dim; k++)
+            for (size_t j = 0; j < P; j++) x[a * s.nv + k * P + j] = st[a * 9 + k];
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(p->buf[LSCQP_PLAN_BUF_STATE], st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->buf[LSCQP_PLAN_BUF_PLAN], x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->buf[LSCQP_PLAN_BUF_GOAL], gl.data(), gl.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->buf[LSCQP_PLAN_BUF_WAYPOINT], gl.data() + s.first_agent * 3, (size_t)s.n_agents * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "plan reset");
+    p->first = true;
+    p->steps = 0;
+    return LSCQP_OK;
+}
+
+void* lscqp_plan_buffer(lscqp_plan p, int32_t which, uint64_t* bytes_out) {
+    if (!p || which < 0 || which >= LSCQP_PLAN_BUF_COUNT) {
+        lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "unknown plan buffer");
+        return nullptr;
+    }
+    if (bytes_out) *bytes_out = p->bytes[which];
+    return p->buf[which];
+}
+
+int lscqp_plan_upload(lscqp_plan p, int32_t which, const void* host, uint64_t offset, uint64_t bytes) {
+    if (!p || !host || which < 0 || which >= LSCQP_PLAN_BUF_COUNT) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "bad argument");
+    if (offset + bytes > p->bytes[which]) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "range exceeds the buffer");
+    DeviceGuard g(p->device);
+    const hipError_t e = hipMemcpy((char*)p->buf[which] + offset, host, bytes, hipMemcpyHostToDevice);
+    return e == hipSuccess ? LSCQP_OK : hip_fail(e, "plan upload");
+}
+
+int lscqp_plan_download(lscqp_plan p, int32_t which, void* host, uint64_t offset, uint64_t bytes) {
+    if (!p || !host || which < 0 || which >= LSCQP_PLAN_BUF_COUNT) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "bad argument");
+    if (offset + bytes > p->bytes[which]) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "range exceeds the buffer");
+    DeviceGuard g(p->device);
+    const hipError_t e = hipMemcpy(host, (const char*)p->buf[which] + offset, bytes, hipMemcpyDeviceToHost);  // waits for the device
+    return e == hipSuccess ? LSCQP_OK : hip_fail(e, "plan download");
+}
+
+int lscqp_plan_step(lscqp_plan p, void* stream) {
+    if (!p) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null plan");
+    DeviceGuard g(p->device);
+    const int rc = enqueue(p, p->first, (hipStream_t)stream);
+    if (rc != LSCQP_OK) return rc;
+    p->first = false;
+    p->steps++;
+    return LSCQP_OK;
+}
+
+int lscqp_plan_step_graph(lscqp_plan p, void* stream) {
+    if (!p) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null plan");
+    // the first replan differs (initializeSFC) and it also warms the kernels' one-time function attributes up: eager
+    if (p->first) return lscqp_plan_step(p, stream);
+    DeviceGuard g(p->device);
+    if (!p->exec) {
+        hipError_t e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
+        const int rc = enqueue(p, false, p->cap);
+        hipGraph_t gr = nullptr;
+        e = hipStreamEndCapture(p->cap, &gr);
+        if (rc != LSCQP_OK) {
+            if (gr) (void)hipGraphDestroy(gr);
+            return rc;
+        }
+        if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+        p->graph = gr;
+        e = hipGraphInstantiate(&p->exec, gr, nullptr, nullptr, 0);
+        if (e != hipSuccess) {
+            drop_graph(p);
+            return hip_fail(e, "hipGraphInstantiate");
+        }
+    }
+    const hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+    p->steps++;
+    return LSCQP_OK;
+}
+
+int64_t lscqp_plan_graph_nodes(lscqp_plan p) {
+    if (!p || !p->graph) return 0;
+    size_t n = 0;
+    if (hipGraphGetNodes(p->graph, nullptr, &n) != hipSuccess) return -1;
+    return (int64_t)n;
+}
+
+}  // extern "C"

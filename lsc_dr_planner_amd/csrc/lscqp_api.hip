@@ -204,6 +204,8 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     return LSCQP_OK;
 }
 
+extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h) { return &h->desc; }  // for lscplan.hip
+
 static inline size_t row_bytes(lscqp_handle h) { return h->dev.rows_f32 ? sizeof(lscqp_row_f32) : sizeof(lscqp_row); }
 
 extern "C" {
@@ -654,6 +656,6 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
 
 const char* lscqp_last_error(void) { return g_err.c_str(); }
 
-const char* lscqp_version(void) { return "lscqp 0.5 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics)"; }
+const char* lscqp_version(void) { return "lscqp 0.6 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics, whole-replan chain + hipGraph)"; }
 
 }  // extern "C"

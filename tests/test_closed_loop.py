@@ -74,3 +74,52 @@ def test_synthetic_forest_closed_loop_with_64_agents():
     assert log["min_safety_ratio"] >= 1.0 - 5e-6 and log["max_vel_excess"] <= 1e-5 and log["max_acc_excess"] <= 1e-5, log
     assert log["max_in_range"] > 20 and log["mean_progress_m"] > 3.0, log
     assert log["truncated_agent_steps"] == 0 and log["row_slots"] >= log["max_in_range"], log
+
+
+@pytest.mark.gpu
+def test_device_pipeline_replays_the_reference_log(oracle):
+    """The reference's own logged mission (forest10_10, 10 agents x 79 replans; tests/golden/sim_log_states.json) flown again with EVERY
+    row of the path on the device: each replan takes the agents' logged states and the waypoints the replay fixture inferred
+    (tests/golden/kat_log_pipeline.json `replay`; the grid planner / MAPF layer that produced them is out of scope), everything
+    else -- shifted previous plans, agents in range, CLSC rows, corridors over the voxel map, goal LP, trajectory QP -- is the
+    device chain's own state from replan to replan.  Every replan must land on the next two logged lines (positions, velocities,
+    accelerations) to the precision of the log's six digits, and on the goal point of the CPU replay."""
+    import json
+
+    import numpy as np
+
+    from tests import helpers as H
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop
+
+    g = H.load_golden("kat_log_pipeline")
+    S = H.load_golden("sim_log_states")
+    W = json.load(open(os.path.join(ROOT, "tests", "golden", "forest10_world.json")))
+    p = g["params"]
+    K, N = 79, 10
+    pos, vel, acc, t = np.array(S["pos"]), np.array(S["vel"]), np.array(S["acc"]), np.array(S["t"])
+    way, goal, match, n_nbr = np.zeros((K, N, 3)), np.zeros((K, N, 3)), np.zeros((K, N)), np.zeros((K, N), int)
+    way[..., 2] = goal[..., 2] = W["z_2d"]
+    for r in g["replay"]:
+        way[r["replan"], r["agent"], :2], goal[r["replan"], r["agent"], :2], match[r["replan"], r["agent"]] = r["waypoint"], r["goal"], r["match"]
+        n_nbr[r["replan"], r["agent"]] = len(r["neighbours"])
+    state = np.concatenate([pos[0:2 * K:2], vel[0:2 * K:2], acc[0:2 * K:2]], axis=2)
+    state[..., 2] = W["z_2d"]
+    log = closed_loop.run(W, steps=K, script=dict(waypoint=way, state=state))
+    assert log["qp_failed"] == 0 and log["invalid"] == 0 and log["goal_infeasible"] == 0 and log.get("truncated_agent_steps", 0) == 0, {
+        k: v for k, v in log.items() if k not in ("x", "goal", "n_in_range")}
+    cls = H.oracle_class(oracle, p, use_sfc=True)
+    worst, n_rep = 0.0, 0
+    for k in range(K):
+        assert np.array_equal(log["n_in_range"][k], n_nbr[k])  # broadcastMsgs' range filter saw the same agents
+        assert np.abs(np.float32(log["goal"][k][:, :2]) - goal[k, :, :2]).max() <= 2e-6, (k, log["goal"][k], goal[k])
+        for a in range(N):
+            err = 0.0
+            for j in (2 * k + 1, 2 * k + 2):
+                got = oracle.state_at(cls, log["x"][k][a], t[j] - t[2 * k])
+                for gv, lv in zip(got, (pos[j, a], vel[j, a], acc[j, a])):
+                    err = max(err, max(H.log_units(gv[i], lv[i]) for i in range(2)))
+            assert err <= match[k, a] + 40, (k, a, err, match[k, a])
+            worst, n_rep = max(worst, err), n_rep + 1
+    assert n_rep == 790 and worst <= 440

@@ -1,0 +1,137 @@
+"""lscqp_plan (include/lscqp.h, "the caller of the path"): the whole replan of a batch of agents as one chain of device work --
+the device analogue of TrajPlanner::planImpl (reference src/traj_planner.cpp:117-139) -- eager and through a captured hipGraph,
+checked against the reference's own logged mission."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mission():
+    g = H.load_golden("kat_log_pipeline")
+    S = H.load_golden("sim_log_states")
+    W = json.load(open(os.path.join(ROOT, "tests", "golden", "forest10_world.json")))
+    K, N = 79, 10
+    pos, vel, acc, t = np.array(S["pos"]), np.array(S["vel"]), np.array(S["acc"]), np.array(S["t"])
+    way, goal, match, n_nbr = np.zeros((K, N, 3)), np.zeros((K, N, 3)), np.zeros((K, N)), np.zeros((K, N), int)
+    way[..., 2] = goal[..., 2] = W["z_2d"]
+    for r in g["replay"]:
+        k, a = r["replan"], r["agent"]
+        way[k, a, :2], goal[k, a, :2], match[k, a], n_nbr[k, a] = r["waypoint"], r["goal"], r["match"], len(r["neighbours"])
+    state = np.concatenate([pos[0:2 * K:2], vel[0:2 * K:2], acc[0:2 * K:2]], axis=2)
+    state[..., 2] = W["z_2d"]
+    return g, W, dict(K=K, N=N, pos=pos, vel=vel, acc=acc, t=t, way=way, goal=goal, match=match, n_nbr=n_nbr, state=state)
+
+
+def _make_plan(api, W, N, n_obs=9, closed_loop=False):
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, n_obs, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, optimize_goal=True,
+                    closed_loop=closed_loop, z_2d=W["z_2d"])
+    return sol, wmap, plan
+
+
+def _fly(api, torch, plan, W, m, graph):
+    plan.reset(np.array(W["starts"], dtype=np.float64))
+    xs, goals, counts = [], [], []
+    for k in range(m["K"]):
+        plan.put(api.PLAN_STATE, m["state"][k])
+        plan.put(api.PLAN_WAYPOINT, m["way"][k])
+        plan.step(graph=graph)
+        torch.cuda.synchronize()
+        st = plan.get(api.PLAN_STATUS)
+        assert (st == 0).all() and (plan.get(api.PLAN_GOAL_STATUS) == 0).all(), (k, st)
+        xs.append(plan.get(api.PLAN_PLAN).reshape(m["N"], -1))
+        goals.append(plan.get(api.PLAN_GOAL).reshape(m["N"], 3))
+        counts.append(plan.get(api.PLAN_IN_RANGE))
+    return np.array(xs), np.array(goals), np.array(counts)
+
+
+@pytest.mark.gpu
+def test_plan_chain_replays_the_reference_log_eagerly_and_as_a_graph(api, oracle, torch_cuda):
+    """The reference's logged mission (forest10_10: 10 agents x 79 replans) flown again by lscqp_plan_step: per replan the host only
+    writes the logged states and the waypoints the replay fixture inferred; shifted plans, range filter, CLSC rows, corridors, goal LP
+    (held as float32), terminal segments, QP, failsafe and plan update all run in the plan's chain.  Every replan lands on the next two
+    logged lines to the log's precision and on the CPU replay's goal point (float32, at most one ulp apart).  The captured hipGraph gives the same
+    bits as the eager chain."""
+    import torch
+
+    g, W, m = _mission()
+    sol, wmap, plan = _make_plan(api, W, m["N"])
+    x_e, goal_e, cnt_e = _fly(api, torch, plan, W, m, graph=False)
+    assert plan.graph_nodes() == 0
+    x_g, goal_g, cnt_g = _fly(api, torch, plan, W, m, graph=True)
+    assert plan.graph_nodes() >= 8
+    assert np.array_equal(x_e, x_g) and np.array_equal(goal_e, goal_g) and np.array_equal(cnt_e, cnt_g)
+    assert np.array_equal(cnt_e, m["n_nbr"])  # broadcastMsgs' range filter saw the same agents as the replay
+    # the goal points of the CPU replay, to the last float32 bit but for a handful that sit one ulp away (the LP's step t differs in
+    # the last bits of its fp64 value between the two implementations, and the goal is rounded to float32 afterwards)
+    ga, gb = np.float32(goal_e[..., :2]), np.float32(m["goal"][..., :2])
+    assert (np.abs(ga - gb) <= np.spacing(np.maximum(np.abs(gb), np.float32(1.0)))).all() and (ga != gb).sum() <= 8
+    cls = H.oracle_class(oracle, g["params"], use_sfc=True)
+    worst = 0.0
+    for k in range(m["K"]):
+        for a in range(m["N"]):
+            err = 0.0
+            for j in (2 * k + 1, 2 * k + 2):
+                got = oracle.state_at(cls, x_e[k, a], m["t"][j] - m["t"][2 * k])
+                for gv, lv in zip(got, (m["pos"][j, a], m["vel"][j, a], m["acc"][j, a])):
+                    err = max(err, max(H.log_units(gv[i], lv[i]) for i in range(2)))
+            assert err <= m["match"][k, a] + 40, (k, a, err, m["match"][k, a])
+            worst = max(worst, err)
+    assert worst <= 440
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_plan_closed_loop_graph_is_faster_than_the_eager_chain_and_keeps_the_mission_safe(api, torch_cuda):
+    """Closed loop on the device (the plan steps its own agents: doStep's state becomes the next replan's state), waypoints fixed at
+    the mission goals' first grid step: 60 replans eager, 60 through the graph -- same bits, no failed QP, and the graph replay
+    takes less host + device time per replan."""
+    import torch
+
+    g, W, m = _mission()
+    sol, wmap, plan = _make_plan(api, W, m["N"], closed_loop=True)
+    starts = np.array(W["starts"], dtype=np.float64)
+    out = {}
+    for mode in ("eager", "graph"):
+        plan.reset(starts)
+        plan.put(api.PLAN_WAYPOINT, m["way"][0])
+        plan.step(graph=False)  # first replan (initializeSFC): eager in both runs
+        plan.put(api.PLAN_WAYPOINT, m["way"][5])  # half a metre on, then held: the agents fly there and hover
+        plan.step(graph=(mode == "graph"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(60):
+            plan.step(graph=(mode == "graph"))
+        torch.cuda.synchronize()
+        out[mode] = (time.perf_counter() - t0) / 60, plan.get(api.PLAN_PLAN).copy(), plan.get(api.PLAN_STATE).copy()
+        assert (plan.get(api.PLAN_STATUS) == 0).all()
+    assert np.array_equal(out["eager"][1], out["graph"][1]) and np.array_equal(out["eager"][2], out["graph"][2])
+    print("replan chain, 10 agents x M10: eager %.1f us, graph %.1f us per replan" % (out["eager"][0] * 1e6, out["graph"][0] * 1e6))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(dict(eager_us=out["eager"][0] * 1e6, graph_us=out["graph"][0] * 1e6, nodes=plan.graph_nodes()),
+              open(os.path.join(ROOT, "gpurun_out", "plan_chain_timing.json"), "w"))
+    assert out["graph"][0] <= out["eager"][0] * 1.05
+    plan.close()
+
+
+def test_plan_entry_points_validate_their_arguments(api):
+    """No GPU needed: the create call checks its arguments before it touches the device."""
+    import ctypes as C
+
+    L = api.lib()
+    d = api.PlanDesc()
+    h = C.c_void_p()
+    assert L.lscqp_plan_create(None, None, C.byref(d), None, C.byref(h)) == api.ERR_INVALID_ARGUMENT
+    assert L.lscqp_plan_step(None, None) == api.ERR_INVALID_ARGUMENT and L.lscqp_plan_step_graph(None, None) == api.ERR_INVALID_ARGUMENT
+    assert L.lscqp_plan_graph_nodes(None) == 0
+    L.lscqp_plan_destroy(None)

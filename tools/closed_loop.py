@@ -104,7 +104,10 @@ def random_forest_world(n_agents=64, side=24.0, n_boxes=150, seed=0, clearance=0
             "z_2d": z, "radius": 0.15, "starts": [[p[0], p[1], z] for p in starts], "goals": [[p[0], p[1], z] for p in goals]}
 
 
-def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=None, n_obs=None):
+def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=None, n_obs=None, script=None):
+    """script (optional): {"waypoint": (K, N, 3), "state": (K, N, 9)} -- replay of a recorded mission: replan k takes every agent's
+    state and waypoint from the script instead of the loop's own step / router (the plans, goal points, corridors and neighbour sets are
+    still the loop's own), and the result carries every replan's solution (`x`, (K, N, nv)) and goal point (`goal`, (K, N, 3))."""
     import torch
 
     from lsc_dr_planner_amd import api
@@ -160,7 +163,7 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
     torch.cuda.synchronize()
     assert (d_sst.cpu().numpy() == 1).all(), "a start point lies inside an inflated obstacle"
 
-    router = GridRouter(g, wmap.download()[0], wmap.key0)
+    router = GridRouter(g, wmap.download()[0], wmap.key0) if script is None else None
     waypoint = starts.copy()  # first waypoint: the start node itself; it advances in the loop
     goal_pt = starts.copy()   # agent.current_goal_point
     log = {"steps": steps, "agents": N, "qp_failed": 0, "invalid": 0, "sfc_kept": 0, "goal_infeasible": 0, "min_safety_ratio": np.inf,
@@ -176,9 +179,12 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
         # the waypoint advances to the next node of the grid path once the agent is close to the current one (the reference's
         # planner hands out one grid step at a time, which keeps the QP's communication-range rows |x - waypoint| <= R/2
         # satisfiable); the current goal point is the outcome of the previous goal LP (src/traj_planner.cpp:545-549)
-        for a in range(N):
-            if np.abs(state[a, :2] - waypoint[a, :2]).max() < 0.3:
-                waypoint[a, :2] = router.next_waypoint(waypoint[a], desired[a])[0]
+        if script is not None:
+            state, waypoint = np.array(script["state"][step], dtype=np.float64), np.array(script["waypoint"][step], dtype=np.float64)
+        else:
+            for a in range(N):
+                if np.abs(state[a, :2] - waypoint[a, :2]).max() < 0.3:
+                    waypoint[a, :2] = router.next_waypoint(waypoint[a], desired[a])[0]
         waypoint = np.float32(waypoint).astype(np.float64)
         if step > 0:
             P = np.stack([last, goal_pt, waypoint], axis=1)
@@ -242,6 +248,10 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
         state = d_state.cpu().numpy().reshape(N, 9)
         d_xprev.copy_(d_x.view(N, nv))
         goal_pt = d_hdr.cpu().numpy().view(api.HEADER_DTYPE)["goal"].copy()  # the goal LP's result is the next current goal point
+        if script is not None:
+            log.setdefault("x", []).append(x_new.copy())
+            log.setdefault("goal", []).append(goal_pt.copy())
+            log.setdefault("n_in_range", []).append(d_ncount.cpu().numpy().copy())
         log["max_in_range"] = int(max(log.get("max_in_range", 0), d_ncount.cpu().numpy().max()))
         log["qp_failed"] += int((qst != 0).sum())
         log["invalid"] += int(((qst == 0) & (valid != 1)).sum())
