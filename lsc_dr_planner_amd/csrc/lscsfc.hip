@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/lscqp.h"
@@ -48,11 +49,18 @@ struct lscqp_map_s {
 
 namespace lscsfc {
 
+// The map as the corridor kernel sees it.  Scalar members with selecting accessors, NOT arrays: one dynamically indexed array
+// member makes the compiler keep the whole by-value kernel argument in scratch memory, and every `world_min[k]` of the expansion
+// loop becomes a memory round trip (measured: 2 500 cycles per expansion step, half of the kernel).
 struct MapView {
     double res;
-    float world_min[3], world_max[3];
-    int key0[3], dims[3];
+    float wmin0, wmin1, wmin2, wmax0, wmax1, wmax2;
+    int key00, key01, key02, dims0, dims1, dims2;
     const int32_t* nearest;
+    __host__ __device__ __forceinline__ float world_min(int k) const { return k == 0 ? wmin0 : (k == 1 ? wmin1 : wmin2); }
+    __host__ __device__ __forceinline__ float world_max(int k) const { return k == 0 ? wmax0 : (k == 1 ? wmax1 : wmax2); }
+    __host__ __device__ __forceinline__ int key0(int k) const { return k == 0 ? key00 : (k == 1 ? key01 : key02); }
+    __host__ __device__ __forceinline__ int dims(int k) const { return k == 0 ? dims0 : (k == 1 ? dims1 : dims2); }
 };
 
 __host__ __device__ inline int key_of(double coord, double res) { return (int)floor((1.0 / res) * coord); }  // coordToKey
@@ -148,7 +156,10 @@ __global__ void nearest_z_kernel(int nx, int ny, int nz, int64_t nvox, int R, co
 }
 
 // ---- corridor construction: one workgroup per agent -------------------------------------------------------------------
-constexpr int kSfcThreads = 256;  // one workgroup (4 wavefronts) per agent: a 50 x 50-cell slab is 5 000 sample points
+#ifndef LSCSFC_THREADS
+#define LSCSFC_THREADS 512
+#endif
+constexpr int kSfcThreads = LSCSFC_THREADS;  // one workgroup (8 wavefronts) per agent: a batch of look-ahead tests is 5 - 20 k sample points
 
 struct BoxF {
     float lo[3], hi[3];
@@ -191,10 +202,10 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
             }
             for (int k = 0; k < 3; k++) {
                 p[u][k] = (float)((double)b.lo[k] + (double)it[k] * res);  // search_point(i) = box_min(i) + iter * res
-                v[u][k] = key_of((double)p[u][k], res) - mp.key0[k];       // worldToMap
-                inside = inside && v[u][k] >= 0 && v[u][k] < mp.dims[k];
+                v[u][k] = key_of((double)p[u][k], res) - mp.key0(k);       // worldToMap
+                inside = inside && v[u][k] >= 0 && v[u][k] < mp.dims(k);
             }
-            code[u] = inside ? mp.nearest[((int64_t)v[u][2] * mp.dims[1] + v[u][1]) * mp.dims[0] + v[u][0]] : 0;
+            code[u] = inside ? mp.nearest[((int64_t)v[u][2] * mp.dims(1) + v[u][1]) * mp.dims(0) + v[u][0]] : 0;
         }
         bool hit = false;
 #pragma unroll
@@ -207,7 +218,7 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
                 double dist = 0;
                 for (int k = 0; k < 3; k++) {
                     // keyToCoord: cell centre (key + 0.5) res as float; closest point of the cell box; L-infinity distance
-                    const float c = have ? (float)(((double)(v[u][k] + off[k] + mp.key0[k]) + 0.5) * res) : 0.0f;
+                    const float c = have ? (float)(((double)(v[u][k] + off[k] + mp.key0(k)) + 0.5) * res) : 0.0f;
                     const float cmin = c - delta, cmax = c + delta;
                     const float q = p[u][k] < cmin ? cmin : (p[u][k] > cmax ? cmax : p[u][k]);
                     const double dk = fabs((double)(q - p[u][k]));
@@ -224,8 +235,8 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
 __device__ bool in_boundary(const MapView& mp, const BoxF& b, double margin) {  // :810-817
     bool ok = true;
     for (int k = 0; k < 3; k++) {
-        ok = ok && ((double)b.lo[k] > (double)mp.world_min[k] + margin - 1e-5);
-        ok = ok && ((double)b.hi[k] < (double)mp.world_max[k] - margin + 1e-5);
+        ok = ok && ((double)b.lo[k] > (double)mp.world_min(k) + margin - 1e-5);
+        ok = ok && ((double)b.hi[k] < (double)mp.world_max(k) - margin + 1e-5);
     }
     return ok;
 }
@@ -261,45 +272,289 @@ __device__ void axis_order(const BoxF& b, const float* goal, int* cand) {  // se
     }
 }
 
-// expandSFC (:819-881 without goal, :883-946 with it)
-__device__ bool expand_sfc(const MapView& mp, const BoxF& initial, const float* goal, double margin, BoxF& out) {
-    if (obstacle_in(mp, initial, margin)) return false;
-    int cand[6] = {0, 1, 2, 3, 4, 5}, ncand = 6;
-    if (goal) axis_order(initial, goal, cand);
+// floor(x / res) without the fp64 division where that is provably the same number: q = x * (1 / res) differs from x / res by a few
+// ulp of q, so unless q lies within 1e-9 of an integer both have the same floor; otherwise the division is carried out.
+__device__ __forceinline__ double floor_div(double x, double res, double rinv) {
+    const double q = x * rinv, f = floor(q);
+    if (q - f < 1e-9 || f + 1.0 - q < 1e-9 || !(fabs(q) < 1e6)) return floor(x / res);
+    return f;
+}
+
+// One step of the reference's inner loop body (:838-857 / :903-922): accept the candidate, then grow it by one cell along
+// cand[i] and make the new layer the box to test.  Indexed by a loop so the boxes stay in registers.
+__device__ __forceinline__ void grow(BoxF& sfc, BoxF& sfc_cand, BoxF& sfc_update, int axis, double res) {
+    sfc = sfc_cand;
+    sfc_update = sfc_cand;
+    for (int k = 0; k < 3; k++) {
+        if (axis == k) {
+            sfc_update.hi[k] = sfc_cand.lo[k];
+            sfc_cand.lo[k] = (float)((double)sfc_cand.lo[k] - res);
+            sfc_update.lo[k] = sfc_cand.lo[k];
+        }
+        if (axis == k + 3) {
+            sfc_update.lo[k] = sfc_cand.hi[k];
+            sfc_cand.hi[k] = (float)((double)sfc_cand.hi[k] + res);
+            sfc_update.hi[k] = sfc_cand.hi[k];
+        }
+    }
+}
+
+// The boxes of the next kAhead tests of the expansion loop, assuming each passes, are known in advance (pure arithmetic on the
+// box state): they are tested TOGETHER, and the first test that fails decides how far the state advances.  Within a batch
+//   * a sample point's coordinate, its map key and the centre of a map cell depend on ONE axis each, so they are tabulated per
+//     (box, axis) / per axis in LDS by the reference's own expressions (a few hundred evaluations per batch instead of three
+//     fp64 chains per sample point);
+//   * a lane owns a COLUMN of a box -- the sample points along the box's thinnest axis -- so that the index arithmetic is paid
+//     once per column and the column's nearest-cell loads are independent and in flight together; the columns of all boxes form
+//     one index space, padded per box to whole wavefronts (a wavefront works on one box, its parameters are wave-uniform), x
+//     running fastest where x is not the thin axis (consecutive lanes read consecutive words of the map);
+//   * one barrier per batch instead of one per 512 points.
+// Every sample point is classified by exactly the comparisons the sequential loop makes (the distance is a maximum of float
+// differences, compared in double against margin + 1e-5), so the outcome is bit for bit the reference's; only the order of
+// evaluation differs.  (Forest10 world: 66-100 tests, 50-80 k sample points per corridor; 315 us as a chain of dependent
+// 512-point rounds with the fp64 chains per point.)
+#ifdef LSCSFC_DEBUG
+__device__ unsigned long long sfc_dbg[16];
+#define SFC_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&sfc_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define SFC_DBG(i, v) do { } while (0)
+#endif
+constexpr int kAhead = 16;
+constexpr int kTab = 3072;    // entries of the per-(box, axis) tables of a batch
+constexpr int kCell = 1024;   // largest map extent (cells per axis) with the cell-centre table in LDS
+struct Ahead {
+    float lo[kAhead][3];    // minimum corner of box j
+    int n[kAhead][3];
+    int tab[kAhead][3];     // offset of the (box, axis) table
+    int axes[kAhead];       // thin axis | fast column axis << 2 | slow column axis << 4
+    int cols[kAhead];       // columns of box j
+    int first[kAhead + 1];  // prefix sums of the boxes' column counts, in wavefronts (64 columns)
+    int fail;               // first failing test of the batch (kAhead: none)
+    float ptab[kTab + 4];   // search_point(k) = box_min(k) + iter * res                      (:786-790)
+    int vtab[kTab + 4];     // its map index, -1 outside the distance map                      (worldToMap)
+    float ctab[3][kCell];   // centre of map cell v along axis k: keyToCoord, (key + 0.5) res as float
+};
+
+__device__ void fill_cell_table(const MapView& mp, Ahead& A) {
+    for (int k = 0; k < 3; k++)
+        for (int v = threadIdx.x; v < mp.dims(k) && v < kCell; v += kSfcThreads)
+            A.ctab[k][v] = (float)(((double)(v + mp.key0(k)) + 0.5) * mp.res);
+    __syncthreads();
+}
+
+// |closest point of the cell box - p| along axis k (Box::closestPoint, float arithmetic)
+__device__ __forceinline__ float axis_dist(const Ahead& A, int k, bool have, int v, int code, float p, float delta) {
+    const int off = ((code >> (8 * k)) & 255) - 128;
+    const float c = have ? A.ctab[k][v + off] : 0.0f;
+    const float cmin = c - delta, cmax = c + delta;
+    const float q = p < cmin ? cmin : (p > cmax ? cmax : p);
+    return fabsf(q - p);
+}
+
+// tests the J recorded boxes; returns the index of the first one holding an obstacle, kAhead if none
+__device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double margin) {
     const double res = mp.res;
+    const float delta = (float)(0.5 * res);
+    const int lane = threadIdx.x;
+    const long long tt0_ = clock64();
+    for (int t = lane >> 6; t < 3 * J; t += kSfcThreads / 64) {  // per-(box, axis) tables, one per wavefront at a time
+        const int j = t / 3, k = t - 3 * j;
+        const int n = A.n[j][k], o = A.tab[j][k];
+        const int key0 = mp.key0(k), dimk = mp.dims(k);
+        const double lo = (double)A.lo[j][k];
+        for (int it = lane & 63; it < n; it += 64) {
+            const float p = (float)(lo + (double)it * res);
+            const int v = key_of((double)p, res) - key0;
+            A.ptab[o + it] = p;
+            A.vtab[o + it] = (v >= 0 && v < dimk) ? v : -1;
+        }
+    }
+    __syncthreads();
+    SFC_DBG(7, clock64() - tt0_);
+    const long long tt1_ = clock64();
+    const int total = A.first[J] * 64;
+    const double thr = margin + 1e-5;
+    // (selected, not indexed: an indexed array of kernel arguments is copied to scratch memory)
+    auto stride = [&](int k) -> int64_t { return k == 0 ? 1 : (k == 1 ? (int64_t)mp.dims(0) : (int64_t)mp.dims(0) * mp.dims(1)); };
+    for (int base = 0; base < total; base += kSfcThreads) {
+        const int stop = *(volatile int*)&A.fail;  // tests behind a failure already found need not be finished
+        const int idx = base + lane;
+        const int chunk = __builtin_amdgcn_readfirstlane(idx >> 6);  // wave-uniform: boxes are padded to whole wavefronts
+        if (chunk >= A.first[J]) continue;
+        int j = 0;
+        for (int t = 1; t < kAhead; t++) j += (t < J && chunk >= A.first[t]) ? 1 : 0;
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (j > stop) continue;
+        const int ax = __builtin_amdgcn_readfirstlane(A.axes[j]);
+        const int la = ax & 3, ca = (ax >> 2) & 3, cb = (ax >> 4) & 3;
+        const int col = idx - A.first[j] * 64;
+        const bool live = col < A.cols[j];
+        // column -> (fast, slow) iterations.  col < 2^22 (the batch is cut there): a float quotient is off by at most one
+        const int na = __builtin_amdgcn_readfirstlane(A.n[j][ca]), nl = __builtin_amdgcn_readfirstlane(A.n[j][la]);
+        const int cc = live ? col : 0;
+        int ib = (int)((float)cc * (1.0f / (float)na));
+        int ia = cc - ib * na;
+        if (ia < 0) ib--, ia += na;
+        if (ia >= na) ib++, ia -= na;
+        const int ea = A.tab[j][ca] + ia, eb = A.tab[j][cb] + ib, el = __builtin_amdgcn_readfirstlane(A.tab[j][la]);
+        const float pa = A.ptab[ea], pb = A.ptab[eb];
+        const int va = A.vtab[ea], vb = A.vtab[eb];
+        const bool inab = live && va >= 0 && vb >= 0;
+        const int64_t base_ab = (int64_t)va * stride(ca) + (int64_t)vb * stride(cb);
+        const int64_t sl = stride(la);
+        bool hit = false;
+        // all nearest-cell loads of a group are issued before the first is used: the map is read from beyond the L2 (it is cold
+        // at every kernel start), ~2 000 cycles per dependent group -- so the whole column is ONE group whenever it fits
+        auto group = [&](auto KZ, int z0) {
+            constexpr int kZ = decltype(KZ)::value;
+            int code[kZ], vl[kZ];
+            float pl[kZ];
+#pragma unroll
+            for (int z = 0; z < kZ; z++) {
+                const int zi = (z0 + z < nl) ? z0 + z : nl - 1;  // (the tail repeats the last point: same verdict)
+                vl[z] = A.vtab[el + zi];
+                pl[z] = A.ptab[el + zi];
+                code[z] = (inab && vl[z] >= 0) ? mp.nearest[base_ab + (int64_t)vl[z] * sl] : 0;
+            }
+#pragma unroll
+            for (int z = 0; z < kZ; z++) {
+                // no occupied cell within max_dist, or a sample outside the distance map: the reference's closest_point stays
+                // default-constructed and it measures against a cell at the WORLD ORIGIN (:796-800) -- reproduced
+                const bool have = (code[z] >> 24) != 0;
+                float dist = axis_dist(A, ca, have, va, code[z], pa, delta);  // LInfinityDistance of float differences:
+                const float db = axis_dist(A, cb, have, vb, code[z], pb, delta);   // their maximum is a float, widened exactly
+                const float dl = axis_dist(A, la, have, vl[z], code[z], pl[z], delta);
+                dist = dist < db ? db : dist;
+                dist = dist < dl ? dl : dist;
+                hit = hit || ((double)dist < thr);
+            }
+        };
+        if (nl <= 2) {
+            group(std::integral_constant<int, 2>{}, 0);
+        } else if (nl <= 8) {
+            group(std::integral_constant<int, 8>{}, 0);
+        } else if (nl <= 16) {
+            group(std::integral_constant<int, 16>{}, 0);
+        } else {
+            for (int z0 = 0; z0 < nl; z0 += 32) group(std::integral_constant<int, 32>{}, z0);
+        }
+        if (live && hit) atomicMin(&A.fail, j);
+    }
+    __syncthreads();
+    SFC_DBG(8, clock64() - tt1_);
+    SFC_DBG(11, (total + kSfcThreads - 1) / kSfcThreads);
+    const int f = A.fail;
+    __syncthreads();  // (the next batch resets A.fail)
+    return f;
+}
+
+// expandSFC (:819-881 without goal, :883-946 with it)
+__device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tables, const BoxF& initial, bool use_goal, const float* goal, double margin,
+                                           BoxF& out) {
+    if (obstacle_in(mp, initial, margin)) return false;
+    // the candidate directions, one per nibble (an indexed register array would live in scratch memory: one memory round trip per
+    // expansion step)
+    unsigned cands = 0x543210u;
+    int ncand = 6;
+    if (use_goal) {
+        int cand[6];
+        axis_order(initial, goal, cand);
+        cands = 0;
+        for (int t = 0; t < 6; t++) cands |= (unsigned)cand[t] << (4 * t);
+    }
+    auto cand_at = [&](int t) -> int { return (int)((cands >> (4 * t)) & 15u); };
+    const double res = mp.res, rinv = 1.0 / res;
     BoxF sfc = initial, sfc_cand, sfc_update;
     int i = -1;
     while (ncand > 0) {
         sfc_cand = sfc;
         sfc_update = sfc;
-        while (in_boundary(mp, sfc_update, 0) && !obstacle_in(mp, sfc_update, margin)) {
-            i++;
-            if (i >= ncand) i = 0;
-            const int axis = cand[i];
-            sfc = sfc_cand;
-            sfc_update = sfc_cand;
-            for (int k = 0; k < 3; k++) {  // indexed by a loop so the boxes stay in registers
-                if (axis == k) {
-                    sfc_update.hi[k] = sfc_cand.lo[k];
-                    sfc_cand.lo[k] = (float)((double)sfc_cand.lo[k] - res);
-                    sfc_update.lo[k] = sfc_cand.lo[k];
+        bool failed = false;
+        while (!failed) {
+            // the tests ahead: box j is what the loop condition sees after j passes
+            const long long tg0_ = clock64();
+            BoxF s = sfc, c = sfc_cand, u = sfc_update;
+            int ii = i, J = 0, jstop = kAhead;  // jstop: first test that fails on the world boundary
+            bool alone = !tables;                // a box beyond the batch's limits is tested on its own, the sequential way
+            int chunks = 0, used = 0;
+            for (int j = 0; j < kAhead && tables; j++) {
+                if (!in_boundary(mp, u, 0)) {
+                    jstop = j;
+                    break;
                 }
-                if (axis == k + 3) {
-                    sfc_update.lo[k] = sfc_cand.hi[k];
-                    sfc_cand.hi[k] = (float)((double)sfc_cand.hi[k] + res);
-                    sfc_update.hi[k] = sfc_cand.hi[k];
+                int n[3];
+                for (int k = 0; k < 3; k++) n[k] = (int)floor_div((double)(u.hi[k] - u.lo[k]) + 1e-5, res, rinv) + 1;
+                // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
+                const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
+                const int need = empty ? 0 : n[0] + n[1] + n[2];
+                // thin axis: the columns run along it (ties: the later axis, so that x stays a column axis)
+                const int la = (n[2] <= n[1] && n[2] <= n[0]) ? 2 : (n[1] <= n[0] ? 1 : 0);
+                const int ca = la == 0 ? 1 : 0, cb = la == 2 ? 1 : 2;
+                const int64_t ncol = empty ? 0 : (la == 2 ? (int64_t)n[0] * n[1] : (la == 1 ? (int64_t)n[0] * n[2] : (int64_t)n[1] * n[2]));
+                if ((int64_t)chunks * 64 + ncol > (1 << 22) || used + need > kTab || (!empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads))) {
+                    alone = (j == 0);
+                    break;
                 }
+                if (threadIdx.x == 0) {  // (the previous batch's readers are behind the barriers that end obstacle_in_batch)
+                    int o = used;
+                    for (int k = 0; k < 3; k++) {
+                        A.lo[j][k] = u.lo[k];
+                        A.n[j][k] = empty ? 0 : n[k];  // (no table entries, no columns)
+                        A.tab[j][k] = o;
+                        o += empty ? 0 : n[k];
+                    }
+                    if (j == 0) A.first[0] = 0, A.fail = kAhead;
+                    A.axes[j] = la | (ca << 2) | (cb << 4);
+                    A.cols[j] = (int)ncol;
+                    A.first[j + 1] = chunks + (int)((ncol + 63) >> 6);
+                }
+                chunks += (int)((ncol + 63) >> 6);
+                used += need;
+                J++;
+                ii++;
+                if (ii >= ncand) ii = 0;
+                grow(s, c, u, cand_at(ii), res);
             }
+            __syncthreads();
+            SFC_DBG(9, clock64() - tg0_);
+            SFC_DBG(0, 1); SFC_DBG(1, J); SFC_DBG(2, chunks); SFC_DBG(3, alone ? 1 : 0);
+            const long long t0_ = clock64();
+            int jfail;
+            if (alone) {
+                if (!in_boundary(mp, sfc_update, 0)) {
+                    jfail = 0;
+                } else {
+                    jfail = obstacle_in(mp, sfc_update, margin) ? 0 : kAhead;
+                }
+                J = 1;
+                jstop = kAhead;
+            } else {
+                jfail = J > 0 ? obstacle_in_batch(mp, A, J, margin) : kAhead;
+            }
+            SFC_DBG(4, clock64() - t0_);
+            const int jf = jfail < jstop ? jfail : jstop;  // first failing test of this batch, kAhead if none was seen
+            const int passes = jf < J ? jf : J;
+            const long long tr0_ = clock64();
+            for (int j = 0; j < passes; j++) {
+                i++;
+                if (i >= ncand) i = 0;
+                grow(sfc, sfc_cand, sfc_update, cand_at(i), res);
+            }
+            SFC_DBG(10, clock64() - tr0_);
+            failed = jf <= J && jf < kAhead;
         }
         if (i < 0) return false;  // initial box outside the world: the reference erases begin() - 1 here (undefined)
-        for (int j = 0; j < 5; j++) cand[j] = (j >= i) ? cand[j + 1] : cand[j];
+        {  // erase direction i
+            const unsigned below = cands & ((1u << (4 * i)) - 1u);
+            cands = below | ((cands >> (4 * (i + 1))) << (4 * i));
+        }
         ncand--;
         i = (i > 0) ? i - 1 : ncand - 1;
     }
     const double delta = margin - ((int)(margin / res) * res);  // margin compensation, :868-877
     for (int k = 0; k < 3; k++) {
-        if ((double)sfc.lo[k] > (double)mp.world_min[k] + 1e-5) sfc.lo[k] = (float)((double)sfc.lo[k] - delta);
-        if ((double)sfc.hi[k] < (double)mp.world_max[k] - 1e-5) sfc.hi[k] = (float)((double)sfc.hi[k] + delta);
+        if ((double)sfc.lo[k] > (double)mp.world_min(k) + 1e-5) sfc.lo[k] = (float)((double)sfc.lo[k] - delta);
+        if ((double)sfc.hi[k] < (double)mp.world_max(k) - 1e-5) sfc.hi[k] = (float)((double)sfc.hi[k] + delta);
     }
     out = sfc;
     return true;
@@ -335,12 +590,54 @@ __global__ __launch_bounds__(kSfcThreads) void construct_sfc_kernel(MapView mp, 
     lscqp_box* S = sfc + a * M;
     BoxF ini, out, prev;
     bool ok;
-    if (mode == LSCQP_SFC_INIT) {  // initializeSFC :366-384
-        for (int k = 0; k < 3; k++) {
-            ini.lo[k] = (float)(floor((double)P[0][k] / res) * res);
-            ini.hi[k] = (float)(ceil((double)P[0][k] / res) * res);
+    __shared__ Ahead A;
+    const bool tables = mp.dims(0) <= kCell && mp.dims(1) <= kCell && mp.dims(2) <= kCell;  // (larger worlds: sequential tests)
+    if (tables) fill_cell_table(mp, A);
+#ifdef LSCSFC_DEBUG
+    const long long tk0_ = clock64();
+    struct Fin { long long t; __device__ ~Fin() { SFC_DBG(5, clock64() - t); SFC_DBG(6, 1); } } fin_{tk0_};
+#endif
+    // ONE call site of expand_sfc (so that it is inlined and the map stays in registers): the modes differ in the initial box,
+    // in the goal-ordered directions, and constructSFCFromConvexHull may make a second attempt
+    if (mode != LSCQP_SFC_INIT)
+        for (int k = 0; k < 3; k++) prev.lo[k] = (float)S[M - 1].bmin[k], prev.hi[k] = (float)S[M - 1].bmax[k];
+    float hull_mn[3], hull_mx[3];  // hull + next waypoint
+    for (int k = 0; k < 3; k++) {
+        float mn = P[0][k], mx = P[0][k];
+        for (int i = 1; i < 3; i++) {
+            mn = P[i][k] < mn ? P[i][k] : mn;
+            mx = P[i][k] > mx ? P[i][k] : mx;
         }
-        ok = expand_sfc(mp, ini, nullptr, margin, out);
+        hull_mn[k] = mn, hull_mx[k] = mx;
+    }
+    ok = false;
+    const int attempts = mode == LSCQP_SFC_FROM_HULL ? 2 : 1;
+    for (int att = 0; att < attempts && !ok; att++) {
+        if (mode == LSCQP_SFC_FROM_HULL && att == 0) {  // constructSFCFromConvexHull :414-436: hull + next waypoint, aligned by round() (:692-722)
+            for (int k = 0; k < 3; k++) {
+                ini.lo[k] = (float)(round((double)hull_mn[k] / res) * res);
+                ini.hi[k] = (float)(round((double)hull_mx[k] / res) * res);
+            }
+        } else if (mode == LSCQP_SFC_FROM_HULL) {  // the hull alone, inside the previous box, aligned outwards (:724-775)
+            for (int k = 0; k < 3; k++) {
+                const float mn = P[0][k] < P[1][k] ? P[0][k] : P[1][k], mx = P[0][k] > P[1][k] ? P[0][k] : P[1][k];
+                ini.lo[k] = (float)(floor((double)mn / res) * res);
+                ini.hi[k] = (float)(ceil((double)mx / res) * res);
+            }
+            clip_to_prev(prev, ini, res);
+        } else {  // initializeSFC :366-384; constructSFCFromPoint :396-412, expandSFCFromPoint :666-690
+            for (int k = 0; k < 3; k++) {
+                ini.lo[k] = (float)(floor((double)P[0][k] / res) * res);
+                ini.hi[k] = (float)(ceil((double)P[0][k] / res) * res);
+            }
+            if (mode == LSCQP_SFC_FROM_POINT) clip_to_prev(prev, ini, res);
+        }
+        ok = expand_sfc(mp, A, tables, ini, mode == LSCQP_SFC_FROM_POINT, P[1], margin, out);
+        if (ok && mode == LSCQP_SFC_FROM_HULL && att == 0)  // isSuperSetOfConvexHull :135-150
+            for (int k = 0; k < 3; k++)
+                ok = ok && !((double)hull_mn[k] < (double)out.lo[k] - 1e-5 || (double)hull_mx[k] > (double)out.hi[k] + 1e-5);
+    }
+    if (mode == LSCQP_SFC_INIT) {
         if (ok)
             for (int t = threadIdx.x; t < M * 6; t += kSfcThreads) {
                 const int m = t / 6, c = t % 6;
@@ -353,45 +650,6 @@ __global__ __launch_bounds__(kSfcThreads) void construct_sfc_kernel(MapView mp, 
             }
         if (threadIdx.x == 0) status[a] = ok ? 1 : 0;
         return;
-    }
-    for (int k = 0; k < 3; k++) prev.lo[k] = (float)S[M - 1].bmin[k], prev.hi[k] = (float)S[M - 1].bmax[k];
-    if (mode == LSCQP_SFC_FROM_HULL) {  // constructSFCFromConvexHull :414-436
-        for (int k = 0; k < 3; k++) {   // hull + next waypoint, aligned by round() (:692-722)
-            float mn = P[0][k], mx = P[0][k];
-            for (int i = 1; i < 3; i++) {
-                mn = P[i][k] < mn ? P[i][k] : mn;
-                mx = P[i][k] > mx ? P[i][k] : mx;
-            }
-            ini.lo[k] = (float)(round((double)mn / res) * res);
-            ini.hi[k] = (float)(round((double)mx / res) * res);
-        }
-        ok = expand_sfc(mp, ini, nullptr, margin, out);
-        if (ok) {  // isSuperSetOfConvexHull :135-150
-            for (int k = 0; k < 3; k++) {
-                float mn = P[0][k], mx = P[0][k];
-                for (int i = 1; i < 3; i++) {
-                    mn = P[i][k] < mn ? P[i][k] : mn;
-                    mx = P[i][k] > mx ? P[i][k] : mx;
-                }
-                ok = ok && !((double)mn < (double)out.lo[k] - 1e-5 || (double)mx > (double)out.hi[k] + 1e-5);
-            }
-        }
-        if (!ok) {  // the hull alone, inside the previous box, aligned outwards (:724-775)
-            for (int k = 0; k < 3; k++) {
-                const float mn = P[0][k] < P[1][k] ? P[0][k] : P[1][k], mx = P[0][k] > P[1][k] ? P[0][k] : P[1][k];
-                ini.lo[k] = (float)(floor((double)mn / res) * res);
-                ini.hi[k] = (float)(ceil((double)mx / res) * res);
-            }
-            clip_to_prev(prev, ini, res);
-            ok = expand_sfc(mp, ini, nullptr, margin, out);
-        }
-    } else {  // constructSFCFromPoint :396-412, expandSFCFromPoint :666-690
-        for (int k = 0; k < 3; k++) {
-            ini.lo[k] = (float)(floor((double)P[0][k] / res) * res);
-            ini.hi[k] = (float)(ceil((double)P[0][k] / res) * res);
-        }
-        clip_to_prev(prev, ini, res);
-        ok = expand_sfc(mp, ini, P[1], margin, out);
     }
     // sfcs[m] = sfcs[m + 1] for m < M - 1, then the new (or the kept) last box.  Every lane moves whole elements; the
     // values were all read before any is overwritten only if the shift is staged, so stage it in registers.
@@ -421,6 +679,14 @@ __global__ __launch_bounds__(kSfcThreads) void construct_sfc_kernel(MapView mp, 
     } while (0)
 
 extern "C" {
+
+#ifdef LSCSFC_DEBUG
+int lscsfc_dbg_read(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lscsfc::sfc_dbg), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lscsfc::sfc_dbg), z, sizeof z); }
+    return 0;
+}
+#endif
 
 int lscqp_map_create(const double* boxes, int64_t n_boxes, const double* world_min, const double* world_max, double resolution,
                      double max_dist, lscqp_map* out) {
@@ -548,7 +814,10 @@ int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const dou
                              int32_t* d_status_out, void* stream) {
     lscsfc::MapView v;
     v.res = mp->res;
-    for (int k = 0; k < 3; k++) v.world_min[k] = mp->world_min[k], v.world_max[k] = mp->world_max[k], v.key0[k] = mp->key0[k], v.dims[k] = mp->dims[k];
+    v.wmin0 = mp->world_min[0], v.wmin1 = mp->world_min[1], v.wmin2 = mp->world_min[2];
+    v.wmax0 = mp->world_max[0], v.wmax1 = mp->world_max[1], v.wmax2 = mp->world_max[2];
+    v.key00 = mp->key0[0], v.key01 = mp->key0[1], v.key02 = mp->key0[2];
+    v.dims0 = mp->dims[0], v.dims1 = mp->dims[1], v.dims2 = mp->dims[2];
     v.nearest = mp->d_nearest;
     hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(lscsfc::kSfcThreads), 0, (hipStream_t)stream, v, mode, M, n, d_points, d_radius,
                        d_sfc, d_status_out);
