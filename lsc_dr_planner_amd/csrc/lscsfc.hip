@@ -11,8 +11,9 @@
 // Not a translation: the reference grows one box per agent on the CPU, asking an octree-backed distance map point by
 // point.  Here the map is a dense voxel grid in HBM (1 B occupancy + 4 B nearest-cell code per voxel; 288 GB holds
 // kilometre-scale worlds at 0.1 m), its nearest-cell field is built by three separable passes (exact Euclidean, 3 x (2R+1)
-// reads per voxel instead of (2R+1)^3), and one workgroup owns one agent's corridor: the box state is uniform across the
-// group, its 256 lanes test the sample points of a slab in parallel and vote, so a slab test costs ceil(points / 512) steps.
+// reads per voxel instead of (2R+1)^3), and one workgroup (16 wavefronts) owns one agent's corridor: the box state is uniform
+// across the group; the next 8 tests of the expansion loop are known in advance and are evaluated together, a lane per column of
+// sample points (obstacle_in_batch below), and the first test that fails decides how far the box has grown.
 //
 // Arithmetic: boxes and points are octomap::point3d (float) in the reference; every statement below keeps float where
 // the reference stores a point3d component and double where it computes in double, and the file is compiled without
@@ -157,9 +158,11 @@ __global__ void nearest_z_kernel(int nx, int ny, int nz, int64_t nvox, int R, co
 
 // ---- corridor construction: one workgroup per agent -------------------------------------------------------------------
 #ifndef LSCSFC_THREADS
-#define LSCSFC_THREADS 512
+#define LSCSFC_THREADS 1024
 #endif
-constexpr int kSfcThreads = LSCSFC_THREADS;  // one workgroup (8 wavefronts) per agent: a batch of look-ahead tests is 5 - 20 k sample points
+constexpr int kSfcThreads = LSCSFC_THREADS;  // one workgroup (16 wavefronts) per agent.  The batch test is a chain of LDS and map round trips per
+                                             // wavefront, so more wavefronts per CU is what pays: 256 / 512 / 1024 threads: 335 / 204 / 171 us per launch
+                                             // (forest10, 10 agents; the 1024-thread build spills 172 B per lane and still wins)
 
 struct BoxF {
     float lo[3], hi[3];
@@ -311,21 +314,32 @@ __device__ __forceinline__ void grow(BoxF& sfc, BoxF& sfc_cand, BoxF& sfc_update
 //   * one barrier per batch instead of one per 512 points.
 // Every sample point is classified by exactly the comparisons the sequential loop makes (the distance is a maximum of float
 // differences, compared in double against margin + 1e-5), so the outcome is bit for bit the reference's; only the order of
-// evaluation differs.  (Forest10 world: 66-100 tests, 50-80 k sample points per corridor; 315 us as a chain of dependent
-// 512-point rounds with the fp64 chains per point.)
+// evaluation differs.  Forest10 world, 10 agents per launch (about 100 tests and 200-450 k sample points per corridor): 315 us as a
+// chain of dependent 512-point rounds with the fp64 chains per point -> 171 us; 64 agents in a synthetic forest 552 -> 270 us.
+// Measured and dropped: the corridor's part of the map staged in LDS (the rounds are bound by the CU's LDS pipe and by
+// instruction issue, not by the map reads: slower), integer quick verdicts before the exact comparison (slower), 16 and 24
+// tests per batch (more wasted look-ahead than saved barriers).
 #ifdef LSCSFC_DEBUG
 __device__ unsigned long long sfc_dbg[16];
 #define SFC_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&sfc_dbg[i], (unsigned long long)(v)); } while (0)
 #else
 #define SFC_DBG(i, v) do { } while (0)
 #endif
-constexpr int kAhead = 16;
+#ifndef LSCSFC_GROUP
+#define LSCSFC_GROUP 8
+#endif
+#ifndef LSCSFC_AHEAD
+#define LSCSFC_AHEAD 8
+#endif
+constexpr int kAhead = LSCSFC_AHEAD;
 constexpr int kTab = 3072;    // entries of the per-(box, axis) tables of a batch
 constexpr int kCell = 1024;   // largest map extent (cells per axis) with the cell-centre table in LDS
 struct Ahead {
     float lo[kAhead][3];    // minimum corner of box j
     int n[kAhead][3];
     int tab[kAhead][3];     // offset of the (box, axis) table
+    float F[6][kAhead + 1]; // face d of the candidate box after c growths of direction d (d < 3: lo[d], else hi[d - 3])
+    int meta[kAhead];       // 1: inside the world boundary | 2: beyond the batch's limits
     int axes[kAhead];       // thin axis | fast column axis << 2 | slow column axis << 4
     int cols[kAhead];       // columns of box j
     int first[kAhead + 1];  // prefix sums of the boxes' column counts, in wavefronts (64 columns)
@@ -433,10 +447,8 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
             group(std::integral_constant<int, 2>{}, 0);
         } else if (nl <= 8) {
             group(std::integral_constant<int, 8>{}, 0);
-        } else if (nl <= 16) {
-            group(std::integral_constant<int, 16>{}, 0);
         } else {
-            for (int z0 = 0; z0 < nl; z0 += 32) group(std::integral_constant<int, 32>{}, z0);
+            for (int z0 = 0; z0 < nl; z0 += LSCSFC_GROUP) group(std::integral_constant<int, LSCSFC_GROUP>{}, z0);
         }
         if (live && hit) atomicMin(&A.fail, j);
     }
@@ -463,6 +475,9 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
         for (int t = 0; t < 6; t++) cands |= (unsigned)cand[t] << (4 * t);
     }
     auto cand_at = [&](int t) -> int { return (int)((cands >> (4 * t)) & 15u); };
+    auto face = [](const BoxF& b, int d) -> float {
+        return d == 0 ? b.lo[0] : (d == 1 ? b.lo[1] : (d == 2 ? b.lo[2] : (d == 3 ? b.hi[0] : (d == 4 ? b.hi[1] : b.hi[2]))));
+    };
     const double res = mp.res, rinv = 1.0 / res;
     BoxF sfc = initial, sfc_cand, sfc_update;
     int i = -1;
@@ -471,49 +486,90 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
         sfc_update = sfc;
         bool failed = false;
         while (!failed) {
-            // the tests ahead: box j is what the loop condition sees after j passes
+            // The tests ahead: box j is what the loop condition sees after j passes.  A face of the candidate box only moves when
+            // its own direction is grown, by the reference's float step each time, so the faces after c growths are six short
+            // tables (one lane each); lane j then assembles box j from them and sizes it, and a uniform scan over the <= kAhead
+            // records decides how many tests the batch holds.  (Growing the boxes one after the other in every lane -- dependent
+            // fp64 chains -- cost 1 600 cycles per test, as much as testing them.)
             const long long tg0_ = clock64();
-            BoxF s = sfc, c = sfc_cand, u = sfc_update;
-            int ii = i, J = 0, jstop = kAhead;  // jstop: first test that fails on the world boundary
-            bool alone = !tables;                // a box beyond the batch's limits is tested on its own, the sequential way
-            int chunks = 0, used = 0;
-            for (int j = 0; j < kAhead && tables; j++) {
-                if (!in_boundary(mp, u, 0)) {
-                    jstop = j;
-                    break;
+            __syncthreads();  // (the previous batch's readers of A are done)
+            if (threadIdx.x < 6) {
+                const int d = threadIdx.x;
+                float x = face(sfc_cand, d);
+                A.F[d][0] = x;
+                for (int c = 1; c <= kAhead; c++) {
+                    x = (float)((double)x + (d < 3 ? -res : res));
+                    A.F[d][c] = x;
                 }
+            }
+            __syncthreads();
+            if (threadIdx.x < kAhead && tables) {
+                const int j = threadIdx.x;
+                BoxF u = sfc_update;
+                if (j > 0) {
+                    unsigned cp = 0;
+                    int ii = i;
+                    for (int t = 1; t < j; t++) {
+                        ii++;
+                        if (ii >= ncand) ii = 0;
+                        cp += 1u << (5 * cand_at(ii));
+                    }
+                    ii++;
+                    if (ii >= ncand) ii = 0;
+                    const int d = cand_at(ii);
+                    for (int k = 0; k < 3; k++) {
+                        const int cl = (int)((cp >> (5 * k)) & 31u), ch = (int)((cp >> (5 * (k + 3))) & 31u);
+                        u.lo[k] = A.F[k][cl];
+                        u.hi[k] = A.F[k + 3][ch];
+                        if (d == k) u.hi[k] = u.lo[k], u.lo[k] = A.F[k][cl + 1];
+                        if (d == k + 3) u.lo[k] = u.hi[k], u.hi[k] = A.F[k + 3][ch + 1];
+                    }
+                }
+                const bool inb = in_boundary(mp, u, 0);
                 int n[3];
                 for (int k = 0; k < 3; k++) n[k] = (int)floor_div((double)(u.hi[k] - u.lo[k]) + 1e-5, res, rinv) + 1;
                 // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
                 const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
-                const int need = empty ? 0 : n[0] + n[1] + n[2];
                 // thin axis: the columns run along it (ties: the later axis, so that x stays a column axis)
                 const int la = (n[2] <= n[1] && n[2] <= n[0]) ? 2 : (n[1] <= n[0] ? 1 : 0);
                 const int ca = la == 0 ? 1 : 0, cb = la == 2 ? 1 : 2;
                 const int64_t ncol = empty ? 0 : (la == 2 ? (int64_t)n[0] * n[1] : (la == 1 ? (int64_t)n[0] * n[2] : (int64_t)n[1] * n[2]));
-                if ((int64_t)chunks * 64 + ncol > (1 << 22) || used + need > kTab || (!empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads))) {
+                const bool over = !empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads || ncol > (1 << 22));
+                for (int k = 0; k < 3; k++) {
+                    A.lo[j][k] = u.lo[k];
+                    A.n[j][k] = empty ? 0 : n[k];  // (no table entries, no columns)
+                }
+                A.axes[j] = la | (ca << 2) | (cb << 4);
+                A.cols[j] = over ? 0 : (int)ncol;
+                A.meta[j] = (inb ? 1 : 0) | (over ? 2 : 0);
+            }
+            __syncthreads();
+            int J = 0, jstop = kAhead;  // jstop: first test that fails on the world boundary
+            bool alone = !tables;        // a box beyond the batch's limits is tested on its own, the sequential way
+            int chunks = 0, used = 0;
+            for (int j = 0; j < kAhead && tables; j++) {
+                const int meta = A.meta[j], ncol = A.cols[j];
+                if (!(meta & 1)) {
+                    jstop = j;
+                    break;
+                }
+                const int need = A.n[j][0] + A.n[j][1] + A.n[j][2];
+                if ((meta & 2) || (int64_t)chunks * 64 + ncol > (1 << 22) || used + need > kTab) {
                     alone = (j == 0);
                     break;
                 }
-                if (threadIdx.x == 0) {  // (the previous batch's readers are behind the barriers that end obstacle_in_batch)
+                if (threadIdx.x == 0) {
                     int o = used;
                     for (int k = 0; k < 3; k++) {
-                        A.lo[j][k] = u.lo[k];
-                        A.n[j][k] = empty ? 0 : n[k];  // (no table entries, no columns)
                         A.tab[j][k] = o;
-                        o += empty ? 0 : n[k];
+                        o += A.n[j][k];
                     }
                     if (j == 0) A.first[0] = 0, A.fail = kAhead;
-                    A.axes[j] = la | (ca << 2) | (cb << 4);
-                    A.cols[j] = (int)ncol;
-                    A.first[j + 1] = chunks + (int)((ncol + 63) >> 6);
+                    A.first[j + 1] = chunks + ((ncol + 63) >> 6);
                 }
-                chunks += (int)((ncol + 63) >> 6);
+                chunks += (ncol + 63) >> 6;
                 used += need;
                 J++;
-                ii++;
-                if (ii >= ncand) ii = 0;
-                grow(s, c, u, cand_at(ii), res);
             }
             __syncthreads();
             SFC_DBG(9, clock64() - tg0_);
@@ -535,10 +591,31 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
             const int jf = jfail < jstop ? jfail : jstop;  // first failing test of this batch, kAhead if none was seen
             const int passes = jf < J ? jf : J;
             const long long tr0_ = clock64();
-            for (int j = 0; j < passes; j++) {
+            if (alone) {
+                for (int j = 0; j < passes; j++) {
+                    i++;
+                    if (i >= ncand) i = 0;
+                    grow(sfc, sfc_cand, sfc_update, cand_at(i), res);
+                }
+            } else if (passes > 0) {  // the state after `passes` growths, from the face tables
+                unsigned cp = 0;
+                for (int t = 1; t < passes; t++) {
+                    i++;
+                    if (i >= ncand) i = 0;
+                    cp += 1u << (5 * cand_at(i));
+                }
                 i++;
                 if (i >= ncand) i = 0;
-                grow(sfc, sfc_cand, sfc_update, cand_at(i), res);
+                const int d = cand_at(i);
+                for (int k = 0; k < 3; k++) {
+                    const int cl = (int)((cp >> (5 * k)) & 31u), ch = (int)((cp >> (5 * (k + 3))) & 31u);
+                    sfc.lo[k] = A.F[k][cl];
+                    sfc.hi[k] = A.F[k + 3][ch];
+                    sfc_cand.lo[k] = sfc_update.lo[k] = sfc.lo[k];
+                    sfc_cand.hi[k] = sfc_update.hi[k] = sfc.hi[k];
+                    if (d == k) sfc_update.hi[k] = sfc.lo[k], sfc_cand.lo[k] = sfc_update.lo[k] = A.F[k][cl + 1];
+                    if (d == k + 3) sfc_update.lo[k] = sfc.hi[k], sfc_cand.hi[k] = sfc_update.hi[k] = A.F[k + 3][ch + 1];
+                }
             }
             SFC_DBG(10, clock64() - tr0_);
             failed = jf <= J && jf < kAhead;

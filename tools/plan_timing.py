@@ -43,7 +43,7 @@ def main():
     for mode in ("eager", "graph"):
         plan.reset(starts)
         way = starts.copy()
-        t_dev = t_host = 0.0
+        t_dev = t_host = t_sub = 0.0
         failed = cut = 0
         for k in range(a.steps):
             t0 = time.perf_counter()
@@ -54,14 +54,16 @@ def main():
             plan.put(api.PLAN_WAYPOINT, np.float32(way).astype(np.float64))
             t1 = time.perf_counter()
             plan.step(graph=(mode == "graph"))
+            t1s = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             t_host += t1 - t0
             if k >= 2:
                 t_dev += t2 - t1
+                t_sub += t1s - t1
             failed += int((plan.get(api.PLAN_STATUS) != 0).sum())
             cut += int((plan.get(api.PLAN_IN_RANGE) > n_obs).sum())
-        out[mode] = dict(replan_us=t_dev / (a.steps - 2) * 1e6, host_waypoints_us=t_host / a.steps * 1e6, failed_qps=failed, cut_neighbour_lists=cut,
+        out[mode] = dict(replan_us=t_dev / (a.steps - 2) * 1e6, host_submit_us=t_sub / (a.steps - 2) * 1e6, host_waypoints_us=t_host / a.steps * 1e6, failed_qps=failed, cut_neighbour_lists=cut,
                          progress_m=float((np.linalg.norm(desired[:, :2] - starts[:, :2], axis=1) - np.linalg.norm(desired[:, :2] - plan.get(api.PLAN_STATE).reshape(N, 9)[:, :2], axis=1)).mean()))
     out["graph_nodes"] = plan.graph_nodes()
     print(json.dumps(out))
