@@ -199,6 +199,44 @@ def newest_profile(pattern):
     return fs[-1] if fs else None
 
 
+def replan_chain(torch, api, replans=60):
+    """The whole replan of configs[0]'s mission as ONE chain of device work (lscqp_plan: shifted plans, range filter, CLSC rows,
+    corridors over the forest10 voxel map, goal LP, QP, failsafe, doStep), eager and through the captured hipGraph: informational,
+    next to the QP figures above.  Closed loop on the device; every agent flies towards a waypoint one grid step from its start."""
+    import time
+
+    W = json.load(open(os.path.join(HERE, "tests", "golden", "forest10_world.json")))
+    N = len(W["starts"])
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, N - 1, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, closed_loop=True, z_2d=W["z_2d"])
+    starts, goals = np.array(W["starts"], dtype=np.float64), np.array(W["goals"], dtype=np.float64)
+    way = starts.copy()
+    way[:, :2] += 0.5 * np.sign(np.round(goals[:, :2] - starts[:, :2], 6))
+    res = {"workload": "forest10 mission: 10 agents x M10 x 9 neighbour slots, CLSC + corridors + goal LP + QP per replan", "replans": replans}
+    for mode in ("eager", "graph"):
+        plan.reset(starts)
+        plan.put(api.PLAN_WAYPOINT, starts)
+        plan.step()
+        plan.put(api.PLAN_WAYPOINT, np.float32(way).astype(np.float64))
+        plan.step(graph=(mode == "graph"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replans):
+            plan.step(graph=(mode == "graph"))
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        res[mode] = {"us_per_replan": (t2 - t0) / replans * 1e6, "host_submit_us_per_replan": (t1 - t0) / replans * 1e6,
+                     "failed_qps_last_replan": int((plan.get(api.PLAN_STATUS) != 0).sum())}
+    res["graph_nodes"] = plan.graph_nodes()
+    plan.close()
+    wmap.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -553,6 +591,11 @@ def main():
             out["mixed_vs_fp64_at_4096"] = {"fp64_qp_per_s": by["c4_f64"]["qp_per_s"], "mixed_qp_per_s": by["c4"]["qp_per_s"],
                                             "ratio": by["c4"]["qp_per_s"] / by["c4_f64"]["qp_per_s"],
                                             "iters_fp64": by["c4_f64"]["iters_mean"], "iters_mixed": by["c4"]["iters_mean"]}
+
+        try:
+            out["replan_chain"] = replan_chain(torch, api)
+        except Exception as ex:
+            out["replan_chain"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
     print(json.dumps(out))
     if dist is not None:

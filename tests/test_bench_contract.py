@@ -52,3 +52,8 @@ def test_bench_line_covers_every_baseline_config_at_its_own_shape():
             assert c["parity_vs_oracle"]["max_abs_dx"] <= 1e-6 and c["parity_vs_oracle"]["max_rel_dobj"] <= 1e-8
     assert by["c4"]["precision"] == "mixed" and by["c4"]["rows"] == "f32" and by["c3"]["lsc_neighbours"] == 40
     assert b["config"]["baseline_config"] == "c1" and "mixed_vs_fp64_at_4096" in b
+    # the whole replan of the forest10 mission as one device chain, eager and as a hipGraph (informational)
+    rc = b["replan_chain"]
+    assert "error" not in rc, rc
+    assert rc["graph_nodes"] >= 8 and 0 < rc["graph"]["us_per_replan"] < 5000 and rc["eager"]["failed_qps_last_replan"] == 0
+    assert rc["graph"]["host_submit_us_per_replan"] <= rc["eager"]["host_submit_us_per_replan"] * 1.5

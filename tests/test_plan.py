@@ -124,6 +124,45 @@ def test_plan_closed_loop_graph_is_faster_than_the_eager_chain_and_keeps_the_mis
     plan.close()
 
 
+@pytest.mark.gpu
+def test_plan_sharded_over_two_owners_equals_the_single_plan(api, torch_cuda):
+    """Section 8e layout of the chain: two plans own agents 0-4 and 5-9 of the same mission (as two ranks would); after every replan the
+    owners' slices of the plan and goal buffers are exchanged (what lscqp_allgather does between GPUs; here through the host) -- the first
+    20 replans of the logged mission give bit for bit the plans of the single 10-agent plan."""
+    import torch
+
+    g, W, m = _mission()
+    N, K, h = m["N"], 20, 5
+    sol, wmap, whole = _make_plan(api, W, N)
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    parts = [api.Plan(sol, wmap, h, 9, ag, n_total=N, first_agent=f, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"])
+             for f in (0, h)]
+    starts = np.array(W["starts"], dtype=np.float64)
+    for p in [whole] + parts:
+        p.reset(starts)
+    for k in range(K):
+        whole.put(api.PLAN_STATE, m["state"][k])
+        whole.put(api.PLAN_WAYPOINT, m["way"][k])
+        whole.step()
+        for r, p in enumerate(parts):
+            p.put(api.PLAN_STATE, m["state"][k])
+            p.put(api.PLAN_WAYPOINT, m["way"][k][r * h:(r + 1) * h])
+            p.step()
+        torch.cuda.synchronize()
+        x = [p.get(api.PLAN_PLAN).reshape(N, -1) for p in parts]
+        gl = [p.get(api.PLAN_GOAL).reshape(N, 3) for p in parts]
+        x_all, g_all = np.concatenate([x[0][:h], x[1][h:]]), np.concatenate([gl[0][:h], gl[1][h:]])
+        for p in parts:  # the all-gather: every owner receives the other's slice
+            p.put(api.PLAN_PLAN, x_all)
+            p.put(api.PLAN_GOAL, g_all)
+        assert np.array_equal(x_all, whole.get(api.PLAN_PLAN).reshape(N, -1)), k
+        assert np.array_equal(g_all, whole.get(api.PLAN_GOAL).reshape(N, 3)), k
+        assert np.array_equal(np.concatenate([p.get(api.PLAN_IN_RANGE) for p in parts]), whole.get(api.PLAN_IN_RANGE))
+    for p in [whole] + parts:
+        p.close()
+
+
 def test_plan_entry_points_validate_their_arguments(api):
     """No GPU needed: the create call checks its arguments before it touches the device."""
     import ctypes as C
