@@ -597,3 +597,63 @@ def test_dynamic_limits_bind_on_every_axis_and_in_every_segment(api, oracle, tor
             assert G["status"][q] == 0
             assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= X_TOL, (pin, q)
     assert ran >= 2
+
+
+@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (7, 3), (10, 2), (10, 3), (5, 2), (8, 2)])
+def test_every_row_family_binds_somewhere_along_the_horizon(api, oracle, torch_cuda, request, M, dim):
+    """Three more scenarios that make the optimum lean on rows all along the horizon (a strong terminal weight on every segment pulls
+    the agent towards a goal it cannot reach): (a) under tight velocity / acceleration limits with the waypoint-range rows
+    (src/traj_optimizer.cpp:448-471, 494-497) -- dozens of active rows per family, first to last index; (b) with loose limits through
+    corridors that narrow late in the horizon -- corridor faces of the last segments (:372-397); (c) loose limits, wide corridors -- the
+    communication-range pair rows (:482-487).  The oracle's multipliers state the premise; every compiled wavefront count must reproduce its optimum."""
+    import os
+
+    wmin, wmax = [-20, -20, -20 if dim == 3 else 0], [20, 20, 20 if dim == 3 else 2.5]
+    z0 = 0.0 if dim == 3 else 1.0
+    goal = [6.0, -5.0, z0 + (4.0 if dim == 3 else 0)]
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, comm_range=3.0, w_t=50.0, world_min=wmin, world_max=wmax)
+    wide, late = np.zeros(M, oracle.BOX_DTYPE), np.zeros(M, oracle.BOX_DTYPE)
+    for b in (wide, late):
+        b["bmin"], b["bmax"] = [-3, -3, -3 if dim == 3 else 0], [3, 3, 3 if dim == 3 else 2.5]
+    for m in range(M // 2, M):
+        late["bmin"][m], late["bmax"][m] = [-3, 0.0, -3 if dim == 3 else 0], [-0.2, 3, 0.7 if dim == 3 else 2.5]
+    common = dict(p0=[-1.2, 0.9, z0], v0=[0.3, -0.2, 0], a0=[0, 0, 0], goal=goal, next_waypoint=[0, 0, z0], nominal_velocity=100.0, radius=0.15)
+    loose = oracle.make_agent(vmax=[30, 30, 30], amax=[400, 400, 400], **common)
+    ags = [oracle.make_agent(vmax=[2.0, 1.5, 1.0], amax=[8, 6, 4], **common), loose, loose]
+    boxes = [wide, late, wide]
+    O = [oracle.solve(cls, ag, None, b) for ag, b in zip(ags, boxes)]
+    act = []
+    for o, ag in zip(O, ags):
+        assert o["status"] == 0
+        sz, a, fam = oracle.count(cls, ag, None), 0, {}
+        for name, n in (("sfc", sz.n_sfc), ("lsc", sz.n_lsc), ("vel", sz.n_vel), ("acc", sz.n_acc), ("comm", sz.n_comm)):
+            fam[name] = (n, np.nonzero(o["lam"][a:a + n] > 1e-6)[0])
+            a += n
+        act.append(fam)
+    for name in ("vel", "acc"):  # (a): many active rows, spread over the family (velocity rows: into its last tenth)
+        n, idx = act[0][name]
+        assert len(idx) >= 15 and idx.max() - idx.min() >= n // 3, (name, idx)
+        assert name == "acc" or idx.max() >= n - n // 10, (name, idx)
+    assert len(act[0]["comm"][1]) >= 1 and len(act[2]["comm"][1]) >= 6  # (c) loose limits, wide corridor: the pair rows hold the agent back
+    n, idx = act[1]["sfc"]
+    assert len(idx) >= 20 and idx.max() >= n - n // 10, idx  # (b): faces of the last segments
+    sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=True, comm_range=3.0, w_t=50.0, world_min=wmin, world_max=wmax))
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, [None, None, None], boxes, M)
+    request.addfinalizer(lambda: os.environ.pop("LSCQP_WAVES", None))
+    ran = 0
+    for pin in (None, "1", "2", "4"):
+        os.environ.pop("LSCQP_WAVES", None)
+        if pin:
+            os.environ["LSCQP_WAVES"] = pin
+        try:
+            G = sol.solve_host(hdr, None, None, sfc)
+        except api.LscqpError as e:
+            assert pin and e.code == api.ERR_UNSUPPORTED, e
+            continue
+        ran += 1
+        for q, o in enumerate(O):
+            assert G["status"][q] == 0, (pin, q, G["status"])
+            # (objective to the stated bar; x to 5e-6 m here: with dozens of corridor faces active a control point of the last
+            # segments sits in a direction the min-jerk Hessian barely sees -- objective 3e-11 apart, that coordinate 1.2e-6 m)
+            assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= 5e-6, (pin, q)
+    assert ran >= 2
