@@ -241,7 +241,10 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
  * rows are never dropped -- so pass the true maximum; LSCQP_ERR_UNSUPPORTED if no compiled instance holds n_obs_max.
  * retry != 0: a second pass over the batch on the same stream re-solves, from the default start, the instances that the
  * first pass did not bring to OPTIMAL (jammed / diverged warm starts; what lscqp_solve_batch does for its callers) --
- * no host round trip, ~3 us when there is nothing to repair.  In LSCQP_PRECISION_MIXED the fp64 second pass always runs. */
+ * no host round trip, ~3 us when there is nothing to repair.  Where the shape has a compiled instance that eliminates the
+ * reduced system in the other order (natural vs nested dissection: M = 10 in 2-D), the second pass runs on that one, also for
+ * batches without a start trajectory: a factorisation that breaks down in one order usually survives in the other.
+ * In LSCQP_PRECISION_MIXED the fp64 second pass always runs. */
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                                 const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,

@@ -61,6 +61,7 @@ namespace {
 
 struct Inst {
     int M, dim, es, max_obs, waves, mixed;
+    int nd;     // nested-dissection elimination order (lscqp_kernel.hpp Cfg::ND); 0: the natural order
     int heavy;  // an instance whose state no longer fits the register file: more than 12 LSC slots per lane (376 - 1432 B/lane of
                 // scratch measured for <6,3,.,20,1>, <5,3,.,24,1>, <10,2,.,24,1>: 2.3x slower per QP than the two-wavefront
                 // instance of the shape at every batch size, M = 6, 512 .. 2048 QPs) or a long matrix row (M >= 7: 108 - 192 B/lane;
@@ -71,7 +72,7 @@ struct Inst {
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
 #define LSCQP_ROW(M, D, E, S, W, X) \
-    {M, D, E, max_obs_of(M, S, W), W, X, (S > 12 || (W == 1 && M >= 7)) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
+    {M, D, E, max_obs_of(M, S, W), W, X, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::ND ? 1 : 0, (S > 12 || (W == 1 && M >= 7)) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
@@ -106,6 +107,18 @@ const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t 
                 better = i.max_obs < best->max_obs;
         }
         if (better) best = &i;
+    }
+    return best;
+}
+// An fp64 instance of the same shape that eliminates in the OTHER order (natural vs nested dissection), smallest capacity that holds
+// n_obs; nullptr if the shape has none.  A pivot that cancels to <= 0 in one order late in the iteration usually survives in the other
+// (tools/sweep_class_params.py: M = 10 in 2-D, 1 of ~570 feasible instances far outside the reference's parameters), so the second
+// pass of a `retry` call runs on it.
+const Inst* other_order_instance(const Inst* first, int n_obs) {
+    const Inst* best = nullptr;
+    for (const Inst& i : kInst) {
+        if (!(i.M == first->M && i.dim == first->dim && i.es == first->es && i.mixed == 0 && i.max_obs >= n_obs && i.nd != first->nd)) continue;
+        if (!best || i.max_obs < best->max_obs) best = &i;
     }
     return best;
 }
@@ -559,10 +572,11 @@ int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, co
     // not finish (same start).  retry: the fp64 kernel re-solves from the DEFAULT start what a warm start did not bring to
     // OPTIMAL -- a jammed or diverged warm start (ITER_LIMIT / NUMERIC, or relabelled INFEASIBLE on its primal residual) says
     // nothing about the problem, a cold start proves infeasibility independently of x_init.
-    if (mixed || (retry && d_x_init)) {
+    const Inst* alt = retry ? other_order_instance(inst64, n_obs_max) : nullptr;
+    if (mixed || (retry && (d_x_init || alt))) {
         cls.repair = 1;
-        e = inst64->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
-                       d_info_out, (hipStream_t)stream);
+        e = (alt ? alt : inst64)->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
+                                     d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));
     }
     return LSCQP_OK;

@@ -16,6 +16,10 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0; tot = 0; inf_both = 0
 for trial in range(60):
     M, dim = [(5, 3), (10, 2), (6, 3), (10, 3)][trial % 4]
+    if os.environ.get("SWEEP_SHAPE") and "%d,%d" % (M, dim) != os.environ["SWEEP_SHAPE"]:  # (same draws per trial: advance the generator anyway)
+        skip = True
+    else:
+        skip = False
     dt = float(rng.choice([0.1, 0.2, 0.3, 0.5]))
     w_c = float(10 ** rng.uniform(-3, 0)); w_t = float(10 ** rng.uniform(-1, 2)); R = float(rng.choice([0.0, 2.0, 3.0, 6.0]))
     wmin, wmax = [-10, -10, 0], [10, 10, 2.5 if dim == 2 else 5]
@@ -49,6 +53,8 @@ for trial in range(60):
                 L["p"][o_] = c; L["nrm"][o_] = nrm; L["d"][o_] = rng.uniform(0.1, 0.9) * np.linalg.norm(p0 - c)
         ags.append(oracle.make_agent(p0=p0, v0=v0, a0=a0, goal=goal, next_waypoint=wp, vmax=vmax, amax=amax, nominal_velocity=float(rng.uniform(0.5, 3)), radius=0.15, n_obs=nob))
         boxes.append(box); Ls.append(L)
+    if skip:
+        continue
     hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, Ls, boxes, M)
     G = sol.solve_host(hdr, rows if any(l is not None for l in Ls) else None, off, sfc)
     for q in range(n):
