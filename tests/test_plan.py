@@ -163,6 +163,47 @@ def test_plan_sharded_over_two_owners_equals_the_single_plan(api, torch_cuda):
         p.close()
 
 
+@pytest.mark.gpu
+def test_plan_with_a_simulation_step_shorter_than_a_segment(api, oracle, torch_cuda):
+    """multisim_time_step < dt (reference src/traj_planner.cpp:413-421): the chain then re-plans from the state at time_step along the
+    plan and starts from prev_traj with segment 0 := subSegment(time_step / dt, 1).  Closed loop, 12 replans of the forest10 mission at
+    time_step = dt / 2: every QP solves, each replan starts exactly where the previous plan is at time_step (position, velocity,
+    acceleration: the QP's equality rows), and the new plan's start of segment 1 stays within millimetres of the previous plan's."""
+    import torch
+
+    g, W, m = _mission()
+    N = m["N"]
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, 9, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, closed_loop=True, time_step=0.1, z_2d=W["z_2d"])
+    plan.reset(np.array(W["starts"], dtype=np.float64))
+    cls = H.oracle_class(oracle, g["params"], use_sfc=True)
+    prev_x = None
+    for k in range(12):
+        plan.put(api.PLAN_WAYPOINT, m["way"][min(k // 2, m["K"] - 1)])
+        plan.step(graph=(k >= 3))
+        torch.cuda.synchronize()
+        assert (plan.get(api.PLAN_STATUS) == 0).all(), (k, plan.get(api.PLAN_STATUS))
+        x = plan.get(api.PLAN_PLAN).reshape(N, -1)
+        hdr = plan.get(api.PLAN_HEADER)
+        nxt = plan.get(api.PLAN_NEXT_STATE).reshape(N, 9)
+        for a in range(N):
+            pos, vel, acc = oracle.state_at(cls, x[a], 0.1)
+            assert np.abs(pos - nxt[a, 0:2]).max() <= 1e-6 and np.abs(vel - nxt[a, 3:5]).max() <= 1e-5 and np.abs(acc - nxt[a, 6:8]).max() <= 1e-3
+            if prev_x is not None:  # this replan started where the previous plan was at 0.1 s
+                p0, v0, a0 = oracle.state_at(cls, prev_x[a], 0.1)
+                assert np.abs(p0 - hdr["p0"][a][:2]).max() <= 1e-6 and np.abs(v0 - hdr["v0"][a][:2]).max() <= 1e-5
+                # ... and from the previous plan cut at 0.1 s: the junction to segment 1 is the previous plan's, up to the re-optimisation
+                j_prev, _, _ = oracle.state_at(cls, prev_x[a], 0.2)
+                j_new, _, _ = oracle.state_at(cls, x[a], 0.1)
+                assert np.abs(j_prev - j_new).max() <= 0.05
+        prev_x = x
+    assert plan.graph_nodes() >= 8
+    plan.close()
+
+
 def test_plan_entry_points_validate_their_arguments(api):
     """No GPU needed: the create call checks its arguments before it touches the device."""
     import ctypes as C
