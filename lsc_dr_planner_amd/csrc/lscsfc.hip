@@ -162,6 +162,7 @@ __global__ void nearest_z_kernel(int nx, int ny, int nz, int64_t nvox, int R, co
 #endif
 constexpr int kSfcThreads = LSCSFC_THREADS;  // one workgroup (16 wavefronts) per agent.  The batch test is a chain of LDS and map round trips per
                                              // wavefront, so more wavefronts per CU is what pays: 256 / 512 / 1024 threads: 335 / 204 / 171 us per launch
+                                             // (before the look-ahead boxes were assembled by one wavefront: 137 us now)
                                              // (forest10, 10 agents; the 1024-thread build spills 172 B per lane and still wins)
 
 struct BoxF {
@@ -315,7 +316,7 @@ __device__ __forceinline__ void grow(BoxF& sfc, BoxF& sfc_cand, BoxF& sfc_update
 // Every sample point is classified by exactly the comparisons the sequential loop makes (the distance is a maximum of float
 // differences, compared in double against margin + 1e-5), so the outcome is bit for bit the reference's; only the order of
 // evaluation differs.  Forest10 world, 10 agents per launch (about 100 tests and 200-450 k sample points per corridor): 315 us as a
-// chain of dependent 512-point rounds with the fp64 chains per point -> 171 us; 64 agents in a synthetic forest 552 -> 270 us.
+// chain of dependent 512-point rounds with the fp64 chains per point -> 137 us; 64 agents in a synthetic forest 552 -> 218 us.
 // Measured and dropped: the corridor's part of the map staged in LDS (the rounds are bound by the CU's LDS pipe and by
 // instruction issue, not by the map reads: slower), integer quick verdicts before the exact comparison (slower), 16 and 24
 // tests per batch (more wasted look-ahead than saved barriers).
@@ -339,7 +340,7 @@ struct Ahead {
     int n[kAhead][3];
     int tab[kAhead][3];     // offset of the (box, axis) table
     float F[6][kAhead + 1]; // face d of the candidate box after c growths of direction d (d < 3: lo[d], else hi[d - 3])
-    int meta[kAhead];       // 1: inside the world boundary | 2: beyond the batch's limits
+    int verdict[4];         // of the scan over the records: tests in the batch, first boundary failure, "test box 0 alone", column chunks
     int axes[kAhead];       // thin axis | fast column axis << 2 | slow column axis << 4
     int cols[kAhead];       // columns of box j
     int first[kAhead + 1];  // prefix sums of the boxes' column counts, in wavefronts (64 columns)
@@ -503,10 +504,14 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 }
             }
             __syncthreads();
-            if (threadIdx.x < kAhead && tables) {
+            // (wavefront 0 alone: lane j assembles and sizes box j, a shuffle scan over the lanes places the boxes in the batch's index
+            // space and a ballot finds where the batch ends; the other wavefronts wait at the barrier instead of competing for the SIMDs
+            // and the LDS pipe with sixteen copies of the same scalar work)
+            if (threadIdx.x < 64) {
                 const int j = threadIdx.x;
+                const bool mine = j < kAhead && tables;
                 BoxF u = sfc_update;
-                if (j > 0) {
+                if (mine && j > 0) {
                     unsigned cp = 0;
                     int ii = i;
                     for (int t = 1; t < j; t++) {
@@ -533,45 +538,46 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 // thin axis: the columns run along it (ties: the later axis, so that x stays a column axis)
                 const int la = (n[2] <= n[1] && n[2] <= n[0]) ? 2 : (n[1] <= n[0] ? 1 : 0);
                 const int ca = la == 0 ? 1 : 0, cb = la == 2 ? 1 : 2;
-                const int64_t ncol = empty ? 0 : (la == 2 ? (int64_t)n[0] * n[1] : (la == 1 ? (int64_t)n[0] * n[2] : (int64_t)n[1] * n[2]));
-                const bool over = !empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads || ncol > (1 << 22));
-                for (int k = 0; k < 3; k++) {
-                    A.lo[j][k] = u.lo[k];
-                    A.n[j][k] = empty ? 0 : n[k];  // (no table entries, no columns)
+                const int64_t ncol64 = empty ? 0 : (la == 2 ? (int64_t)n[0] * n[1] : (la == 1 ? (int64_t)n[0] * n[2] : (int64_t)n[1] * n[2]));
+                const bool over = !empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads || ncol64 > (1 << 22));
+                const int ncol = (mine && !over) ? (int)ncol64 : 0;
+                const int need = (mine && !empty) ? n[0] + n[1] + n[2] : 0;
+                const int mychunks = (ncol + 63) >> 6;
+                int pc = mychunks, pu = need;  // inclusive prefix sums over the lanes
+                for (int d = 1; d < kAhead; d <<= 1) {
+                    const int tc = __shfl_up(pc, d), tu = __shfl_up(pu, d);
+                    if (j >= d) pc += tc, pu += tu;
                 }
-                A.axes[j] = la | (ca << 2) | (cb << 4);
-                A.cols[j] = over ? 0 : (int)ncol;
-                A.meta[j] = (inb ? 1 : 0) | (over ? 2 : 0);
-            }
-            __syncthreads();
-            int J = 0, jstop = kAhead;  // jstop: first test that fails on the world boundary
-            bool alone = !tables;        // a box beyond the batch's limits is tested on its own, the sequential way
-            int chunks = 0, used = 0;
-            for (int j = 0; j < kAhead && tables; j++) {
-                const int meta = A.meta[j], ncol = A.cols[j];
-                if (!(meta & 1)) {
-                    jstop = j;
-                    break;
-                }
-                const int need = A.n[j][0] + A.n[j][1] + A.n[j][2];
-                if ((meta & 2) || (int64_t)chunks * 64 + ncol > (1 << 22) || used + need > kTab) {
-                    alone = (j == 0);
-                    break;
-                }
-                if (threadIdx.x == 0) {
-                    int o = used;
+                const int ec = pc - mychunks, eu = pu - need;  // what lies before box j
+                // the batch ends at the first box outside the world boundary (that test fails without looking at the map: jstop) or
+                // beyond the batch's limits (jbrk; box 0 beyond them is tested on its own, the sequential way)
+                const unsigned long long mstop = __builtin_amdgcn_ballot_w64(mine && !inb);
+                const unsigned long long mbrk = __builtin_amdgcn_ballot_w64(mine && (over || (int64_t)ec * 64 + ncol > (1 << 22) || eu + need > kTab));
+                const int jstop_ = mstop ? __builtin_ctzll(mstop) : kAhead, jbrk = mbrk ? __builtin_ctzll(mbrk) : kAhead;
+                const int J_ = tables ? (jstop_ < jbrk ? jstop_ : jbrk) : 0;
+                const bool alone_ = !tables || (jbrk == 0 && jstop_ > 0);
+                if (mine && j < J_) {
                     for (int k = 0; k < 3; k++) {
-                        A.tab[j][k] = o;
-                        o += A.n[j][k];
+                        A.lo[j][k] = u.lo[k];
+                        A.n[j][k] = empty ? 0 : n[k];  // (no table entries, no columns)
                     }
-                    if (j == 0) A.first[0] = 0, A.fail = kAhead;
-                    A.first[j + 1] = chunks + ((ncol + 63) >> 6);
+                    A.tab[j][0] = eu, A.tab[j][1] = eu + (empty ? 0 : n[0]), A.tab[j][2] = eu + (empty ? 0 : n[0] + n[1]);
+                    A.axes[j] = la | (ca << 2) | (cb << 4);
+                    A.cols[j] = ncol;
+                    A.first[j + 1] = pc;
                 }
-                chunks += (ncol + 63) >> 6;
-                used += need;
-                J++;
+                if (j == 0) {
+                    A.first[0] = 0, A.fail = kAhead;
+                    A.verdict[0] = J_, A.verdict[1] = tables ? jstop_ : kAhead, A.verdict[2] = alone_ ? 1 : 0;
+                }
+                // chunks of the whole batch: the inclusive sum at its last box
+                const int total_chunks = __shfl(pc, J_ > 0 ? J_ - 1 : 0);
+                if (j == 0) A.verdict[3] = J_ > 0 ? total_chunks : 0;
             }
             __syncthreads();
+            int J = A.verdict[0], jstop = A.verdict[1];
+            const bool alone = A.verdict[2] != 0;
+            const int chunks = A.verdict[3];
             SFC_DBG(9, clock64() - tg0_);
             SFC_DBG(0, 1); SFC_DBG(1, J); SFC_DBG(2, chunks); SFC_DBG(3, alone ? 1 : 0);
             const long long t0_ = clock64();
