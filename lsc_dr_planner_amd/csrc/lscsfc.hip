@@ -12,7 +12,7 @@
 // point.  Here the map is a dense voxel grid in HBM (1 B occupancy + 4 B nearest-cell code per voxel; 288 GB holds
 // kilometre-scale worlds at 0.1 m), its nearest-cell field is built by three separable passes (exact Euclidean, 3 x (2R+1)
 // reads per voxel instead of (2R+1)^3), and one workgroup (16 wavefronts) owns one agent's corridor: the box state is uniform
-// across the group; the next 8 tests of the expansion loop are known in advance and are evaluated together, a lane per column of
+// across the group; the next 12 tests of the expansion loop are known in advance and are evaluated together, a lane per column of
 // sample points (obstacle_in_batch below), and the first test that fails decides how far the box has grown.
 //
 // Arithmetic: boxes and points are octomap::point3d (float) in the reference; every statement below keeps float where
@@ -162,7 +162,7 @@ __global__ void nearest_z_kernel(int nx, int ny, int nz, int64_t nvox, int R, co
 #endif
 constexpr int kSfcThreads = LSCSFC_THREADS;  // one workgroup (16 wavefronts) per agent.  The batch test is a chain of LDS and map round trips per
                                              // wavefront, so more wavefronts per CU is what pays: 256 / 512 / 1024 threads: 335 / 204 / 171 us per launch
-                                             // (before the look-ahead boxes were assembled by one wavefront: 137 us now)
+                                             // (before the look-ahead boxes were assembled by one wavefront: 131 us now, with 12 tests per batch and 4 loads per group)
                                              // (forest10, 10 agents; the 1024-thread build spills 172 B per lane and still wins)
 
 struct BoxF {
@@ -316,10 +316,9 @@ __device__ __forceinline__ void grow(BoxF& sfc, BoxF& sfc_cand, BoxF& sfc_update
 // Every sample point is classified by exactly the comparisons the sequential loop makes (the distance is a maximum of float
 // differences, compared in double against margin + 1e-5), so the outcome is bit for bit the reference's; only the order of
 // evaluation differs.  Forest10 world, 10 agents per launch (about 100 tests and 200-450 k sample points per corridor): 315 us as a
-// chain of dependent 512-point rounds with the fp64 chains per point -> 137 us; 64 agents in a synthetic forest 552 -> 218 us.
+// chain of dependent 512-point rounds with the fp64 chains per point -> 131 us; 64 agents in a synthetic forest 552 -> 208 us.
 // Measured and dropped: the corridor's part of the map staged in LDS (the rounds are bound by the CU's LDS pipe and by
-// instruction issue, not by the map reads: slower), integer quick verdicts before the exact comparison (slower), 16 and 24
-// tests per batch (more wasted look-ahead than saved barriers).
+// instruction issue, not by the map reads: slower), integer quick verdicts before the exact comparison (slower).
 #ifdef LSCSFC_DEBUG
 __device__ unsigned long long sfc_dbg[16];
 #define SFC_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&sfc_dbg[i], (unsigned long long)(v)); } while (0)
@@ -327,10 +326,10 @@ __device__ unsigned long long sfc_dbg[16];
 #define SFC_DBG(i, v) do { } while (0)
 #endif
 #ifndef LSCSFC_GROUP
-#define LSCSFC_GROUP 8
+#define LSCSFC_GROUP 4
 #endif
 #ifndef LSCSFC_AHEAD
-#define LSCSFC_AHEAD 8
+#define LSCSFC_AHEAD 12
 #endif
 constexpr int kAhead = LSCSFC_AHEAD;
 constexpr int kTab = 3072;    // entries of the per-(box, axis) tables of a batch
