@@ -241,9 +241,11 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
  * rows are never dropped -- so pass the true maximum; LSCQP_ERR_UNSUPPORTED if no compiled instance holds n_obs_max.
  * retry != 0: a second pass over the batch on the same stream re-solves, from the default start, the instances that the
  * first pass did not bring to OPTIMAL (jammed / diverged warm starts; what lscqp_solve_batch does for its callers) --
- * no host round trip, ~3 us when there is nothing to repair.  Where the shape has a compiled instance that eliminates the
- * reduced system in the other order (natural vs nested dissection: M = 10 in 2-D), the second pass runs on that one, also for
- * batches without a start trajectory: a factorisation that breaks down in one order usually survives in the other.
+ * no host round trip, ~3 us when there is nothing to repair.  retry == 2: the second pass runs on the compiled instance that
+ * eliminates the reduced system in the OTHER order (natural vs nested dissection; M = 10 in 2-D has both), also for batches
+ * without a start trajectory -- a factorisation that breaks down in one order usually survives in the other; that instance costs
+ * ~35 us to launch even with nothing to repair, so it is not what retry == 1 does.  The host-pointer entries run it by themselves,
+ * and only for batches that still hold a non-OPTIMAL instance after the first call.
  * In LSCQP_PRECISION_MIXED the fp64 second pass always runs. */
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
@@ -559,9 +561,11 @@ typedef struct lscqp_plan_desc {
     int32_t optimize_goal;   /* != 0: GoalOptimizer moves the goal point towards the waypoint (goal mode grid_based_planner);
                                 0: the goal points are left as the caller set them (static goal modes) */
     int32_t closed_loop;     /* != 0: the local agents' next states (doStep) become their current states for the next replan */
-    int32_t reserved;
+    int32_t safety_samples;  /* > 0: the step ends with the safety figures of MultiSyncSimulator::update over this many samples of the
+                                new plans (lscqp_safety_metrics_device; needs n_agents == n_total: every agent's new plan), 0: off */
     double time_step;        /* multisim_time_step: == dt shifts the plans by one segment, < dt uses Segment::subSegment */
     double z_2d;             /* world_z_2d of 2-D missions */
+    double record_time_step; /* spacing of the safety samples (multisim_save_time_step) */
 } lscqp_plan_desc;
 /* Buffers of a plan (device pointers through lscqp_plan_buffer; lscqp_plan_upload / _download copy synchronously).
  * "all": [n_total] entries indexed by global id; "local": [n_agents] entries. */
@@ -580,7 +584,8 @@ typedef struct lscqp_plan_desc {
 #define LSCQP_PLAN_BUF_NEXT_STATE 12  /* out  local  double[9]: state at time_step along the new plan */
 #define LSCQP_PLAN_BUF_OBJECTIVE 13   /* out  local  double */
 #define LSCQP_PLAN_BUF_INFO 14        /* out  local  lscqp_info */
-#define LSCQP_PLAN_BUF_COUNT 15
+#define LSCQP_PLAN_BUF_SAFETY 15      /* out  local  lscqp_safety (safety_samples > 0) */
+#define LSCQP_PLAN_BUF_COUNT 16
 /* agents [n_total] (host).  map: required exactly when the class uses corridors.  The class's row_format must be LSCQP_ROWS_F64. */
 int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc, const lscqp_agent_param* agents, lscqp_plan* out);
 void lscqp_plan_destroy(lscqp_plan plan);

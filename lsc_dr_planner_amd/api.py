@@ -279,12 +279,12 @@ AGENT_PARAM_DTYPE = np.dtype([("radius", "f8"), ("downwash", "f8"), ("max_vel", 
 
 class PlanDesc(C.Structure):  # lscqp_plan_desc
     _fields_ = [("n_agents", C.c_int64), ("n_total", C.c_int64), ("first_agent", C.c_int64), ("n_obs", C.c_int32), ("constraint_mode", C.c_int32),
-                ("sfc_mode", C.c_int32), ("optimize_goal", C.c_int32), ("closed_loop", C.c_int32), ("reserved", C.c_int32),
-                ("time_step", C.c_double), ("z_2d", C.c_double)]
+                ("sfc_mode", C.c_int32), ("optimize_goal", C.c_int32), ("closed_loop", C.c_int32), ("safety_samples", C.c_int32),
+                ("time_step", C.c_double), ("z_2d", C.c_double), ("record_time_step", C.c_double)]
 
 
 (PLAN_STATE, PLAN_WAYPOINT, PLAN_PLAN, PLAN_GOAL, PLAN_HEADER, PLAN_ROWS, PLAN_SFC, PLAN_STATUS, PLAN_GOAL_STATUS, PLAN_SFC_STATUS, PLAN_VALID,
- PLAN_IN_RANGE, PLAN_NEXT_STATE, PLAN_OBJECTIVE, PLAN_INFO) = range(15)
+ PLAN_IN_RANGE, PLAN_NEXT_STATE, PLAN_OBJECTIVE, PLAN_INFO, PLAN_SAFETY) = range(16)
 
 
 class Plan:
@@ -297,7 +297,7 @@ class Plan:
            PLAN_OBJECTIVE: np.float64}
 
     def __init__(self, solver, world_map, n_agents, n_obs, agents, n_total=None, first_agent=0, constraint_mode=1, sfc_mode=1,
-                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0):
+                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0, safety_samples=0, record_time_step=0.1):
         self._p = None
         n_total = n_agents if n_total is None else n_total
         d = PlanDesc()
@@ -305,6 +305,7 @@ class Plan:
         d.constraint_mode, d.sfc_mode, d.optimize_goal, d.closed_loop = constraint_mode, sfc_mode, int(optimize_goal), int(closed_loop)
         d.time_step = float(solver.desc.dt if time_step is None else time_step)
         d.z_2d = float(z_2d)
+        d.safety_samples, d.record_time_step = int(safety_samples), float(record_time_step)
         ag = np.ascontiguousarray(agents, dtype=AGENT_PARAM_DTYPE)
         if ag.shape != (n_total,):
             raise ValueError("agents: one AGENT_PARAM_DTYPE record per agent of the mission")
@@ -315,7 +316,7 @@ class Plan:
         self._p, self._solver, self._map = h, solver, world_map  # (keeps the solver and the map alive)
         self.n_agents, self.n_total, self.first_agent, self.n_obs, self.M, self.nv = n_agents, n_total, first_agent, n_obs, solver.desc.M, solver.nv
         self._dt = dict(self._DT)
-        self._dt.update({PLAN_HEADER: HEADER_DTYPE, PLAN_ROWS: ROW_DTYPE, PLAN_SFC: BOX_DTYPE, PLAN_INFO: INFO_DTYPE})
+        self._dt.update({PLAN_HEADER: HEADER_DTYPE, PLAN_ROWS: ROW_DTYPE, PLAN_SFC: BOX_DTYPE, PLAN_INFO: INFO_DTYPE, PLAN_SAFETY: SAFETY_DTYPE})
 
     def close(self):
         if self._p:
@@ -538,7 +539,7 @@ class Solver:
             return None if t is None else C.c_void_p(t.data_ptr())
 
         rc = lib().lscqp_solve_batch_device_ex(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
-                                               p(d_obj), p(d_status), p(d_info), int(bool(retry)), C.c_void_p(s.cuda_stream))
+                                               p(d_obj), p(d_status), p(d_info), int(retry), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

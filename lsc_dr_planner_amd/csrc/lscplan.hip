@@ -218,6 +218,9 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
                        status, hdr, p->x_new, p->x_init, x_plan, goal);
     PLAN_TRY(lscqp_validate_step_device(h, s.n_agents, p->d.time_step, s.z_2d, x_plan + s.first_agent * s.nv, hdr, p->map ? sfc : nullptr, valid,
                                         state_out, stream));
+    if (p->d.safety_samples > 0)  // MultiSyncSimulator::update's safety ratio / excess ratios over the step just planned (:486-577)
+        PLAN_TRY(lscqp_safety_metrics_device(h, s.n_agents, s.first_agent, s.n_total, p->d.safety_samples, p->d.record_time_step, s.z_2d, x_plan,
+                                             p->radius, p->downwash, hdr, (lscqp_safety*)p->buf[LSCQP_PLAN_BUF_SAFETY], stream));
     if (p->d.closed_loop) {
         const hipError_t e = hipMemcpyAsync(state + s.first_agent * 9, state_out, sizeof(double) * 9 * s.n_agents, hipMemcpyDeviceToDevice, stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(next state)");
@@ -268,6 +271,9 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
     const double dt_probe = lscqp_class_desc_of_(h)->dt;
     if (!(desc->time_step > 0) || desc->time_step > dt_probe * (1 + 1e-9))
         return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "0 < time_step <= dt required (multisim_time_step, src/traj_planner.cpp:401-421)");
+    if (desc->safety_samples < 0 || (desc->safety_samples > 0 && (desc->n_agents != desc->n_total || !(desc->record_time_step > 0))))
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT,
+                                "safety_samples needs every agent's new plan on this device (n_agents == n_total) and record_time_step > 0");
     if (lscqp_row_bytes(h) != (int)sizeof(lscqp_row))
         return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "the plan chain uses 32-byte rows (row_format = LSCQP_ROWS_F64)");
     lscqp_plan_s* p = new lscqp_plan_s();
@@ -297,7 +303,7 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_GOAL_STATUS, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_SFC_STATUS, n)) &&
         ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_VALID, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_IN_RANGE, n)) &&
         ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_NEXT_STATE, n * 9)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_OBJECTIVE, n)) &&
-        ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
+        ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc_pub<lscqp_safety>(p, LSCQP_PLAN_BUF_SAFETY, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
         ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
         ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
         ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1));

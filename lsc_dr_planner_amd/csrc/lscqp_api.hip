@@ -564,15 +564,26 @@ int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, co
     }
     lscqp::DevClass cls = h->dev;
     cls.n_obs_max = n_obs_max;
-    hipError_t e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out,
-                            (hipStream_t)stream);
+    hipError_t e = hipSuccess;
+    if (retry == -2) {  // (internal) only the repair pass, on the other-order instance: the statuses of a first pass are in d_status_out
+        const Inst* other = other_order_instance(inst64, n_obs_max);
+        if (!other) return LSCQP_OK;
+        cls.repair = 1;
+        e = other->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (other-order pass): ") + hipGetErrorString(e));
+        return LSCQP_OK;
+    }
+    e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
     // Second pass over the batch, same stream, no host round trip: a workgroup whose instance is already OPTIMAL (or was
     // refused for capacity) returns at once.  Mixed precision: the fp64 kernel re-solves what the float32 factorisation could
     // not finish (same start).  retry: the fp64 kernel re-solves from the DEFAULT start what a warm start did not bring to
     // OPTIMAL -- a jammed or diverged warm start (ITER_LIMIT / NUMERIC, or relabelled INFEASIBLE on its primal residual) says
     // nothing about the problem, a cold start proves infeasibility independently of x_init.
-    const Inst* alt = retry ? other_order_instance(inst64, n_obs_max) : nullptr;
+    // retry = 2: the second pass on the instance of the other elimination order (also for cold batches).  Not the default of a retry:
+    // the natural-order instances of the shapes that have both spill to scratch, and a kernel with a private segment costs ~35 us to
+    // launch even when every workgroup returns at once (measured: 38.7 vs 4.6 us per call on the forest10 replica).
+    const Inst* alt = retry == 2 ? other_order_instance(inst64, n_obs_max) : nullptr;
     if (mixed || (retry && (d_x_init || alt))) {
         cls.repair = 1;
         e = (alt ? alt : inst64)->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
@@ -660,6 +671,19 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     if (rc != LSCQP_OK) return rc;
     LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
     LSCQP_CK(hipStreamSynchronize(st));
+    {   // instances that are still not OPTIMAL get one more pass where the shape has an instance with the other elimination order
+        // (a factorisation that breaks down in one order usually survives in the other); only batches with such instances pay for it
+        const int32_t* st_h = (const int32_t*)(hbase + o_st);
+        bool any = false;
+        for (int64_t q = 0; q < n && !any; q++) any = st_h[q] != LSCQP_STATUS_OPTIMAL && st_h[q] != LSCQP_STATUS_CAPACITY;
+        const Inst* first = any ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : nullptr;
+        if (first && other_order_instance(first, n_obs_max)) {
+            rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, st);
+            if (rc != LSCQP_OK) return rc;
+            LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+            LSCQP_CK(hipStreamSynchronize(st));
+        }
+    }
     memcpy(x_out, hbase + o_x, sizeof(double) * n * h->nv);
     memcpy(obj_out, hbase + o_obj, sizeof(double) * n);
     memcpy(status_out, hbase + o_st, sizeof(int32_t) * n);

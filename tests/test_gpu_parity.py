@@ -657,3 +657,40 @@ def test_every_row_family_binds_somewhere_along_the_horizon(api, oracle, torch_c
             # segments sits in a direction the min-jerk Hessian barely sees -- objective 3e-11 apart, that coordinate 1.2e-6 m)
             assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= 5e-6, (pin, q)
     assert ran >= 2
+
+
+def test_breakdown_under_one_elimination_order_is_repaired_on_the_other(api, oracle, torch_cuda):
+    """tests/golden/nd_breakdown_m10d2.json (tools/make_golden_nd_breakdown.py): a feasible M = 10, 2-D instance from the sweep far outside
+    the reference's parameters on which the nested-dissection instance ends NUMERIC at iteration 11 (a pivot of the late-iteration matrix
+    cancels to <= 0).  The natural elimination order solves it: the host-pointer entry runs that second pass by itself, the device
+    entry on request (retry = 2)."""
+    import torch
+
+    g = H.load_golden("nd_breakdown_m10d2")
+    par = g["params"]
+    M, dim = par["M"], par["dim"]
+    cls = oracle.make_class(use_sfc=True, **par)
+    ag = oracle.make_agent(**g["agent"])
+    box = np.zeros(M, oracle.BOX_DTYPE)
+    box["bmin"], box["bmax"] = g["sfc_min"], g["sfc_max"]
+    o = oracle.solve(cls, ag, None, box)
+    assert o["status"] == 0 and abs(o["obj"] - g["oracle_obj"]) <= 1e-9 * abs(g["oracle_obj"])
+    sol = api.Solver(api.make_desc(use_sfc=True, **par))
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, [ag], [None], [box], M)
+    G = sol.solve_host(hdr, None, None, sfc)  # first pass (nested dissection) + the other-order pass
+    assert G["status"][0] == 0
+    assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= X_TOL
+    # the device entry: plain call (what the first pass alone does), then with retry = 2
+    dev = torch.device("cuda", 0)
+    d_hdr = torch.from_numpy(hdr.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_sfc = torch.from_numpy(sfc.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_rows = torch.zeros(32, dtype=torch.uint8, device=dev)
+    out = []
+    for retry in (0, 2):
+        d_x, d_obj, d_st = torch.zeros(sol.nv, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        sol.solve_device(1, 0, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, retry=retry)
+        torch.cuda.synchronize()
+        out.append((int(d_st.item()), d_x.cpu().numpy()))
+    assert out[0][0] in (api.STATUS_OPTIMAL, api.STATUS_NUMERIC, api.STATUS_INFEASIBLE)  # (NUMERIC today; not a promise)
+    assert out[1][0] == api.STATUS_OPTIMAL and np.abs(out[1][1] - o["x"]).max() <= X_TOL

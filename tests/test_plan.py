@@ -215,3 +215,35 @@ def test_plan_entry_points_validate_their_arguments(api):
     assert L.lscqp_plan_step(None, None) == api.ERR_INVALID_ARGUMENT and L.lscqp_plan_step_graph(None, None) == api.ERR_INVALID_ARGUMENT
     assert L.lscqp_plan_graph_nodes(None) == 0
     L.lscqp_plan_destroy(None)
+
+
+@pytest.mark.gpu
+def test_plan_safety_figures_at_the_end_of_the_step(api, torch_cuda):
+    """safety_samples > 0: the chain ends with MultiSyncSimulator::update's safety figures of the new plans (lscqp_safety_metrics_device):
+    over the first 30 replans of the logged mission no agent comes closer than the sum of the radii, no limit is exceeded, and the
+    closest pair the reference's summary reports (safety ratio 1.02089 for the whole run) is not undercut."""
+    import torch
+
+    g, W, m = _mission()
+    N = m["N"]
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, 9, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"], safety_samples=2, record_time_step=0.1)
+    plan.reset(np.array(W["starts"], dtype=np.float64))
+    worst = np.inf
+    for k in range(30):
+        plan.put(api.PLAN_STATE, m["state"][k])
+        plan.put(api.PLAN_WAYPOINT, m["way"][k])
+        plan.step(graph=(k >= 2))
+        torch.cuda.synchronize()
+        saf = plan.get(api.PLAN_SAFETY)
+        assert (plan.get(api.PLAN_STATUS) == 0).all()
+        assert saf["safety_ratio"].min() >= 1.0 - 5e-6 and saf["vel_excess_ratio"].max() <= 1e-5 and saf["acc_excess_ratio"].max() <= 1e-5, (k, saf)
+        worst = min(worst, saf["safety_ratio"].min())
+    assert 1.0 <= worst + 5e-6 and worst < 5.0
+    assert plan.graph_nodes() >= 9
+    plan.close()
+    with pytest.raises(api.LscqpError):  # the figures need every agent's new plan on the device
+        api.Plan(sol, wmap, 5, 9, ag, n_total=N, constraint_mode=api.GEN_CLSC, z_2d=W["z_2d"], safety_samples=2)
