@@ -694,3 +694,108 @@ def test_breakdown_under_one_elimination_order_is_repaired_on_the_other(api, ora
         out.append((int(d_st.item()), d_x.cpu().numpy()))
     assert out[0][0] in (api.STATUS_OPTIMAL, api.STATUS_NUMERIC, api.STATUS_INFEASIBLE)  # (NUMERIC today; not a promise)
     assert out[1][0] == api.STATUS_OPTIMAL and np.abs(out[1][1] - o["x"]).max() <= X_TOL
+
+
+@pytest.mark.parametrize("M,dim,n_obs", [(5, 3, 20), (5, 3, 48), (6, 3, 20), (10, 2, 9), (10, 2, 40), (10, 3, 40), (7, 3, 12), (8, 2, 12)])
+def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, request, M, dim, n_obs):
+    """Index test of the LSC rows: one QP per obstacle slot, whose ONLY non-zero rows sit in that slot (segment oi mod M, all six
+    control points) and block the straight way to the goal -- whatever slot, segment or lane a row is staged in, it has to bind.  The
+    oracle's multipliers state the premise; every compiled wavefront count of the shape that holds n_obs must reproduce the optimum."""
+    import os
+
+    wmin, wmax = [-10, -10, -10 if dim == 3 else 0], [10, 10, 10 if dim == 3 else 2.5]
+    z0 = 0.0 if dim == 3 else 1.0
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=False, world_min=wmin, world_max=wmax)
+    ags, Ls = [], []
+    free = oracle.solve(cls, oracle.make_agent(p0=[0, 0, z0], v0=[0.2, 0, 0], a0=[0, 0, 0], goal=[1.0, 0.1, z0], next_waypoint=[1.0, 0.1, z0]), None, None)
+    xfree = free["x"].reshape(dim, M, 6)[0]
+    for oi in range(n_obs):
+        m = oi % M
+        L = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+        xb = 0.6 * xfree[m].max()  # stop the free trajectory at 60 % of where it gets to in segment m
+        L["p"][oi, m] = [xb, 0.0, z0]
+        L["nrm"][oi, m] = [-1.0, 0.0, 0.0]
+        L["d"][oi, m] = 0.0
+        ags.append(oracle.make_agent(p0=[0, 0, z0], v0=[0.2, 0, 0], a0=[0, 0, 0], goal=[1.0, 0.1, z0], next_waypoint=[1.0, 0.1, z0], n_obs=n_obs))
+        Ls.append(L)
+    O = [oracle.solve(cls, ag, L, None) for ag, L in zip(ags, Ls)]
+    n_active = 0
+    for o, ag, L in zip(O, ags, Ls):
+        assert o["status"] == 0
+        sz = oracle.count(cls, ag, L)
+        n_active += o["lam"][sz.n_sfc:sz.n_sfc + sz.n_lsc].max() > 1e-6
+    assert n_active >= n_obs - n_obs // M - 1, n_active  # (a plane on segment 0 only holds its last three control points: may stay inactive)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=False, world_min=wmin, world_max=wmax))
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, Ls, None, M)
+    request.addfinalizer(lambda: os.environ.pop("LSCQP_WAVES", None))
+    ran = 0
+    for pin in (None, "1", "2", "4"):
+        os.environ.pop("LSCQP_WAVES", None)
+        if pin:
+            os.environ["LSCQP_WAVES"] = pin
+        try:
+            G = sol.solve_host(hdr, rows, off, None)
+        except api.LscqpError as e:
+            assert pin and e.code == api.ERR_UNSUPPORTED, e
+            continue
+        ran += 1
+        for q, o in enumerate(O):
+            assert G["status"][q] == 0, (pin, q)
+            assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= X_TOL, (pin, q)
+    assert ran >= 1
+
+
+@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (10, 2), (10, 3), (7, 3), (5, 2)])
+def test_one_binding_corridor_face_per_segment_axis_and_side(api, oracle, torch_cuda, request, M, dim):
+    """Index test of the corridor rows: one QP per (segment, axis, side) whose corridor is wide open except for that one face, placed
+    across the way to the goal (src/traj_optimizer.cpp:372-397)."""
+    import os
+
+    wmin, wmax = [-10, -10, -10 if dim == 3 else 0], [10, 10, 10 if dim == 3 else 2.5]
+    z0 = 0.0 if dim == 3 else 1.0
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=wmin, world_max=wmax)
+    ags, boxes = [], []
+    wide = np.zeros(M, oracle.BOX_DTYPE)
+    wide["bmin"], wide["bmax"] = [-5, -5, -5 if dim == 3 else 0], [5, 5, 5 if dim == 3 else 2.5]
+    for m in range(1, M):
+        for k in range(dim):
+            for side in (0, 1):
+                sgn = 1.0 if side else -1.0  # the goal lies on the side of the face
+                goal = [0.0, 0.0, z0]
+                goal[k] += sgn * 1.0
+                goal[(k + 1) % dim] += 0.1
+                box = wide.copy()
+                free = oracle.solve(cls, oracle.make_agent(p0=[0, 0, z0], v0=[0, 0, 0], a0=[0, 0, 0], goal=goal, next_waypoint=goal), None, wide)
+                reach = 0.6 * np.abs(free["x"].reshape(dim, M, 6)[k, m] - (z0 if k == 2 else 0.0)).max()  # 60 % of the free displacement
+                base = z0 if k == 2 else 0.0
+                if side:
+                    box["bmax"][m][k] = base + reach
+                else:
+                    box["bmin"][m][k] = base - reach
+                ags.append(oracle.make_agent(p0=[0, 0, z0], v0=[0, 0, 0], a0=[0, 0, 0], goal=goal, next_waypoint=goal))
+                boxes.append(box)
+    O = [oracle.solve(cls, ag, None, b) for ag, b in zip(ags, boxes)]
+    n_active = 0
+    for o, ag in zip(O, ags):
+        assert o["status"] == 0
+        sz = oracle.count(cls, ag, None)
+        n_active += o["lam"][:sz.n_sfc].max() > 1e-6
+    assert n_active >= len(ags) - 2 * dim, (n_active, len(ags))
+    sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=True, world_min=wmin, world_max=wmax))
+    hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, [None] * len(ags), boxes, M)
+    request.addfinalizer(lambda: os.environ.pop("LSCQP_WAVES", None))
+    ran = 0
+    for pin in (None, "1", "2", "4"):
+        os.environ.pop("LSCQP_WAVES", None)
+        if pin:
+            os.environ["LSCQP_WAVES"] = pin
+        try:
+            G = sol.solve_host(hdr, None, None, sfc)
+        except api.LscqpError as e:
+            assert pin and e.code == api.ERR_UNSUPPORTED, e
+            continue
+        ran += 1
+        for q, o in enumerate(O):
+            assert G["status"][q] == 0, (pin, q)
+            assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= X_TOL, (pin, q)
+    assert ran >= 2
