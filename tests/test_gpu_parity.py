@@ -696,8 +696,10 @@ def test_breakdown_under_one_elimination_order_is_repaired_on_the_other(api, ora
     assert out[1][0] == api.STATUS_OPTIMAL and np.abs(out[1][1] - o["x"]).max() <= X_TOL
 
 
-@pytest.mark.parametrize("M,dim,n_obs", [(5, 3, 20), (5, 3, 48), (6, 3, 20), (10, 2, 9), (10, 2, 40), (10, 3, 40), (7, 3, 12), (8, 2, 12)])
-def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, request, M, dim, n_obs):
+@pytest.mark.parametrize("M,dim,n_obs,variant", [(5, 3, 20, ""), (5, 3, 48, ""), (6, 3, 20, ""), (10, 2, 9, ""), (10, 2, 40, ""), (10, 3, 40, ""), (7, 3, 12, ""),
+                                                (8, 2, 12, ""), (5, 3, 10, "dlsc"), (5, 2, 12, "dlsc"), (10, 2, 10, "dlsc"), (5, 3, 20, "rows_f32"),
+                                                (10, 2, 9, "rows_f32"), (5, 3, 20, "mixed"), (10, 2, 9, "mixed")])
+def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, request, M, dim, n_obs, variant):
     """Index test of the LSC rows: one QP per obstacle slot, whose ONLY non-zero rows sit in that slot (segment oi mod M, all six
     control points) and block the straight way to the goal -- whatever slot, segment or lane a row is staged in, it has to bind.  The
     oracle's multipliers state the premise; every compiled wavefront count of the shape that holds n_obs must reproduce the optimum."""
@@ -705,14 +707,16 @@ def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, reques
 
     wmin, wmax = [-10, -10, -10 if dim == 3 else 0], [10, 10, 10 if dim == 3 else 2.5]
     z0 = 0.0 if dim == 3 else 1.0
-    cls = oracle.make_class(M=M, dim=dim, use_sfc=False, world_min=wmin, world_max=wmax)
+    # variants: the DLSC instances (no end-stop rows), 16-byte rows, the mixed-precision instances
+    lsc_mode = variant != "dlsc"
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=False, planner_lsc=lsc_mode, world_min=wmin, world_max=wmax)
     ags, Ls = [], []
     free = oracle.solve(cls, oracle.make_agent(p0=[0, 0, z0], v0=[0.2, 0, 0], a0=[0, 0, 0], goal=[1.0, 0.1, z0], next_waypoint=[1.0, 0.1, z0]), None, None)
     xfree = free["x"].reshape(dim, M, 6)[0]
     for oi in range(n_obs):
         m = oi % M
         L = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
-        xb = 0.6 * xfree[m].max()  # stop the free trajectory at 60 % of where it gets to in segment m
+        xb = float(np.float32(0.6 * xfree[m].max()))  # stop the free trajectory at 60 % of where it gets to in segment m (a float32 value: exact in 16-byte rows)
         L["p"][oi, m] = [xb, 0.0, z0]
         L["nrm"][oi, m] = [-1.0, 0.0, 0.0]
         L["d"][oi, m] = 0.0
@@ -725,7 +729,10 @@ def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, reques
         sz = oracle.count(cls, ag, L)
         n_active += o["lam"][sz.n_sfc:sz.n_sfc + sz.n_lsc].max() > 1e-6
     assert n_active >= n_obs - n_obs // M - 1, n_active  # (a plane on segment 0 only holds its last three control points: may stay inactive)
-    sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=False, world_min=wmin, world_max=wmax))
+    sol = api.Solver(api.make_desc(M=M, dim=dim, use_sfc=False, world_min=wmin, world_max=wmax,
+                                   planner_mode=api.PLANNER_LSC if lsc_mode else api.PLANNER_DLSC,
+                                   row_format=api.ROWS_F32 if variant == "rows_f32" else api.ROWS_F64,
+                                   precision=api.PRECISION_MIXED if variant == "mixed" else api.PRECISION_F64))
     hdr, rows, off, sfc = H.abi_batch(api, oracle, cls, ags, Ls, None, M)
     request.addfinalizer(lambda: os.environ.pop("LSCQP_WAVES", None))
     ran = 0
