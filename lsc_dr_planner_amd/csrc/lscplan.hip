@@ -37,48 +37,52 @@ struct Shape {
     double z_2d, dt;
 };
 
-// headers + corridor seed points + initial trajectory in the solver's layout; thread t serves agent t of the mission for
-// the position table and local agent t for the rest
+// headers + corridor seed points + initial trajectory in the solver's layout: one wavefront per agent of the mission (the position
+// table covers all of them, the rest the local ones); the lanes share the plan's control points
 __global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_replan, const double* __restrict__ state,
                                                             const double* __restrict__ waypoint, const double* __restrict__ goal,
                                                             const double* __restrict__ traj, const lscqp_agent_param* __restrict__ par,
                                                             double* __restrict__ pos, lscqp_header* __restrict__ hdr,
                                                             double* __restrict__ points, double* __restrict__ x_init) {
-    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (t < s.n_total)
-        for (int k = 0; k < 3; k++) pos[t * 3 + k] = state[t * 9 + k];
-    if (t >= s.n_agents) return;
-    const int64_t g = s.first_agent + t;
-    lscqp_header H;
-    memset(&H, 0, sizeof H);
-    const lscqp_agent_param A = par[g];
-    for (int k = 0; k < 3; k++) {
-        H.p0[k] = state[g * 9 + k];
-        H.v0[k] = state[g * 9 + 3 + k];
-        H.a0[k] = state[g * 9 + 6 + k];
-        H.goal[k] = goal[g * 3 + k];
-        H.next_waypoint[k] = waypoint[t * 3 + k];
-        H.vmax[k] = A.max_vel[k];
-        H.amax[k] = A.max_acc[k];
-    }
-    H.radius = A.radius;
-    H.nominal_velocity = A.nominal_velocity;
-    H.n_obs = s.n_obs;
-    H.terminal_segments = 0;  // set by finalize_goal_kernel once the goal LP has moved the goal
-    hdr[t] = H;
+    const int64_t g = blockIdx.x;  // global agent id
+    const int lane = threadIdx.x;
+    if (g >= s.n_total) return;
+    if (lane < 3) pos[g * 3 + lane] = state[g * 9 + lane];
+    const int64_t t = g - s.first_agent;  // local id
+    if (t < 0 || t >= s.n_agents) return;
     const double* tr = traj + g * s.M * 18;
-    double* P = points + t * 9;
-    for (int k = 0; k < 3; k++) {
+    if (lane == 0) {
+        lscqp_header H;
+        memset(&H, 0, sizeof H);
+        const lscqp_agent_param A = par[g];
+        for (int k = 0; k < 3; k++) {
+            H.p0[k] = state[g * 9 + k];
+            H.v0[k] = state[g * 9 + 3 + k];
+            H.a0[k] = state[g * 9 + 6 + k];
+            H.goal[k] = goal[g * 3 + k];
+            H.next_waypoint[k] = waypoint[t * 3 + k];
+            H.vmax[k] = A.max_vel[k];
+            H.amax[k] = A.max_acc[k];
+        }
+        H.radius = A.radius;
+        H.nominal_velocity = A.nominal_velocity;
+        H.n_obs = s.n_obs;
+        H.terminal_segments = 0;  // set by finalize_goal_kernel once the goal LP has moved the goal
+        hdr[t] = H;
+    }
+    if (lane < 9) {
         // generateSFC (src/traj_planner.cpp:738-753): the agent's position on the first replan, afterwards the hull
         // {initial_traj.lastPoint(), current_goal_point} and the next waypoint
-        P[k] = first_replan ? H.p0[k] : tr[((s.M - 1) * 6 + 5) * 3 + k];
-        P[3 + k] = first_replan ? H.p0[k] : H.goal[k];
-        P[6 + k] = first_replan ? H.p0[k] : H.next_waypoint[k];
+        const int which = lane / 3, k = lane - 3 * which;
+        const double p0k = state[g * 9 + k];
+        const double v = which == 0 ? tr[((s.M - 1) * 6 + 5) * 3 + k] : (which == 1 ? goal[g * 3 + k] : waypoint[t * 3 + k]);
+        points[t * 9 + lane] = first_replan ? p0k : v;
     }
     double* xi = x_init + t * s.nv;
-    for (int k = 0; k < s.dim; k++)
-        for (int m = 0; m < s.M; m++)
-            for (int i = 0; i < 6; i++) xi[(k * s.M + m) * 6 + i] = tr[(m * 6 + i) * 3 + k];
+    for (int e = lane; e < s.nv; e += kThreads) {  // x_init[k][m][i] = traj[m][i][k]
+        const int k = e / (6 * s.M), r = e - k * 6 * s.M;
+        xi[e] = tr[r * 3 + k];
+    }
 }
 
 // after the goal LP: agent.current_goal_point is a point3d (GoalOptimizer::solve returns one, src/goal_optimizer.cpp:7-55), and
@@ -196,8 +200,7 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
         PLAN_TRY(lscqp_shift_traj_device(h, s.n_total, 1, s.z_2d, x_plan, p->traj, stream));
     else
         PLAN_TRY(lscqp_shift_traj_partial_device(h, s.n_total, fraction, s.z_2d, x_plan, p->traj, stream));
-    const int64_t nt = s.n_total > s.n_agents ? s.n_total : s.n_agents;
-    hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)((nt + lscplan::kThreads - 1) / lscplan::kThreads)), dim3(lscplan::kThreads), 0, stream,
+    hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)s.n_total), dim3(lscplan::kThreads), 0, stream,
                        s, first_replan ? 1 : 0, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init);
     if (p->map)
         PLAN_TRY(lscqp_construct_sfc_device(h, p->map, first_replan ? LSCQP_SFC_INIT : p->d.sfc_mode, s.n_agents, p->points,
