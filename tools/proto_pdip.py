@@ -66,7 +66,7 @@ def solve32(fac, b):
 
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
-          tol=1e-10, max_iter=60, verbose=False, fp32=None):
+          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -187,6 +187,12 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
                 for j in range(3):
                     z[k * nzA + 3 * m + (0 if last else j)] = init[m, 5 if last else 3 + j, k]
     mu0, s0 = (1e-3, 0.03) if warm else (3e-3, 0.1)
+    if mu0_s0 is not None:
+        mu0, s0 = mu0_s0
+    if mu0 < 0:  # experiment: mu0 scaled with the start's worst constraint violation (|mu0| = violation per unit factor)
+        viol = max(0.0, -(Gz @ z - hz).min())
+        base_mu = 1e-3 if warm else 3e-3
+        mu0 = base_mu * min(30.0, max(1.0, viol / (-mu0)))
     s = np.maximum(Gz @ z - hz, 0.0)
     s = np.maximum(s, s0)
     lam = mu0 / s  # centred start: every product s*lam = mu0
@@ -276,6 +282,31 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         if neg.any(): a = min(a, (-s[neg] / ds[neg]).min())
         neg = dl < 0
         if neg.any(): a = min(a, (-lam[neg] / dl[neg]).min())
+        # experiment: Gondzio's multiple centrality correctors on top of the Mehrotra direction (one extra solve each): aim a little
+        # beyond the current step, pull the outlying complementarity products of the trial point back into [0.1, 10] x target
+        for _g in range(gondzio if it >= gondzio_from else 0):
+            a_cur = min(1.0, 0.9995 * a) if a < 1e299 else 1.0
+            if a_cur >= 0.9:
+                break
+            a_t = min(1.0, 1.08 * a_cur + 0.08)
+            v = (s + a_t * ds) * (lam + a_t * dl)
+            mu_t = sigma * mu
+            t = np.clip(v, 0.1 * mu_t, 10 * mu_t) - v
+            t = np.maximum(t, -10 * mu_t)
+            dzc = lin(t / s) + 0 * dz  # K dz = G'(t/s) - (-grad) ... the corrector solves with rhs = G'(t/s) only
+            dzc = dzc - lin(np.zeros(mrows))  # remove the -grad part that lin() adds
+            dsc = Gz @ dzc
+            dlc = t / s - w * dsc
+            dz2, ds2, dl2 = dz + dzc, ds + dsc, dl + dlc
+            a2 = 1e300
+            neg = ds2 < 0
+            if neg.any(): a2 = min(a2, (-s[neg] / ds2[neg]).min())
+            neg = dl2 < 0
+            if neg.any(): a2 = min(a2, (-lam[neg] / dl2[neg]).min())
+            if min(1.0, 0.9995 * a2) >= 1.01 * a_cur:
+                dz, ds, dl, a = dz2, ds2, dl2, a2
+            else:
+                break
         tau = max(0.9995, 1.0 - mu) if sigma < 1e-4 else 0.9995  # adaptive fraction to the boundary (kernel: same rule)
         a_std = min(1.0, 0.9995 * a)
         a = min(1.0, tau * a)
