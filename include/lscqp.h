@@ -599,7 +599,8 @@ int lscqp_plan_download(lscqp_plan plan, int32_t which, void* host, uint64_t off
 /* One replan of all local agents, asynchronous on `stream` (hipStream_t as void*; NULL = default stream). */
 int lscqp_plan_step(lscqp_plan plan, void* stream);
 /* The same through a hipGraph captured at the first call that is not a first replan (that one runs eagerly: it differs, and it
- * warms the kernels' one-time attributes up).  Results are bit-for-bit those of lscqp_plan_step. */
+ * warms the kernels' one-time attributes up).  Results are bit-for-bit those of lscqp_plan_step.  The captured launches carry the
+ * solver class by value: after lscqp_update on the handle the plan has to be destroyed and created again. */
 int lscqp_plan_step_graph(lscqp_plan plan, void* stream);
 int64_t lscqp_plan_graph_nodes(lscqp_plan plan); /* nodes of the captured graph, 0 before the capture */
 
