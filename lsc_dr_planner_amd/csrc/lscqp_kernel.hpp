@@ -1091,8 +1091,9 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             if ((it & 3) == 2) {
                 // (round 2: the stall has to show at two checks in a row -- a feasible instance started far below its multipliers'
                 // scale crept for ten iterations and then converged; see mu_scale above)
-                // (... unless it is flat: less than 5 % in four iterations, where the feasible creepers showed 15 %)
-                stalled = (it >= 10 && max_rp > 1e-4 && max_rp > 0.7 * (double)rp_ref) ? stalled + 1 + (max_rp > 0.95 * (double)rp_ref ? 1 : 0) : 0;
+                // (no shortcut for a flat residual either: a feasible M = 10, 40-neighbour instance sat at 5e-4 m for four iterations
+                // around the tenth and converged afterwards -- tools/stress_parity.py, shape 5, seed 114)
+                stalled = (it >= 10 && max_rp > 1e-4 && max_rp > 0.7 * (double)rp_ref) ? stalled + 1 : 0;
                 if (stalled >= 2 || (it >= 10 && max_rp > 1e-5 && sum_pinf > 1e6)) {  // uniform over the QP's lanes
                     status = LSCQP_STATUS_INFEASIBLE;
                     break;

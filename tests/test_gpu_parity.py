@@ -806,3 +806,22 @@ def test_one_binding_corridor_face_per_segment_axis_and_side(api, oracle, torch_
             assert G["status"][q] == 0, (pin, q)
             assert abs(o["obj"] - G["obj"][q]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][q]).max() <= X_TOL, (pin, q)
     assert ran >= 2
+
+
+def test_feasible_instance_whose_residual_pauses_around_the_tenth_iteration(api, oracle, torch_cuda):
+    """tools/stress_parity.py, shape (24 x M10 x 40 neighbours, forest), seed 114, first batch from hover: instance 14 holds its primal
+    residual at 5e-4 m for four iterations around the tenth and converges afterwards.  The single-check stall rule of round 1 (and a
+    'flat residual' shortcut tried in round 2) reported it INFEASIBLE; the stall now has to show at two checks in a row."""
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(24, M=10, dim=3, n_obs=40, seed=114, style="forest")
+    cls = oracle.make_class(M=10, dim=3, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=10, dim=3, world_min=sw.world_min, world_max=sw.world_max))
+    b = sw.build()
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, 10)
+    G = sol.solve_host(hdr, rows, off, sfc)
+    ag, lsc, loff, sfco = H.swarm_oracle_inputs(oracle, sw, b)
+    R = oracle.solve_batch(cls, ag, lsc, loff, sfco, threads=8)
+    assert (R["status"] == 0).all() and (G["status"] == 0).all(), (G["status"], G["info"]["iterations"])
+    assert G["info"]["iterations"][14] >= 14
+    _check_against_oracle(oracle, cls, G, R)
