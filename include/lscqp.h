@@ -581,7 +581,8 @@ typedef struct lscqp_plan_desc {
 #define LSCQP_PLAN_BUF_SFC_STATUS 9   /* out  local  int32: 1 = corridor updated, 0 = previous box kept / seed inside an obstacle */
 #define LSCQP_PLAN_BUF_VALID 10       /* out  local  int32: isSolValid */
 #define LSCQP_PLAN_BUF_IN_RANGE 11    /* out  local  int32: agents within communication range */
-#define LSCQP_PLAN_BUF_NEXT_STATE 12  /* out  local  double[9]: state at time_step along the new plan */
+#define LSCQP_PLAN_BUF_NEXT_STATE 12  /* out  local  double[9]: state at time_step along the new plan (closed_loop: the local slice of
+                                         LSCQP_PLAN_BUF_STATE itself) */
 #define LSCQP_PLAN_BUF_OBJECTIVE 13   /* out  local  double */
 #define LSCQP_PLAN_BUF_INFO 14        /* out  local  lscqp_info */
 #define LSCQP_PLAN_BUF_SAFETY 15      /* out  local  lscqp_safety (safety_samples > 0) */

@@ -224,10 +224,8 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     if (p->d.safety_samples > 0)  // MultiSyncSimulator::update's safety ratio / excess ratios over the step just planned (:486-577)
         PLAN_TRY(lscqp_safety_metrics_device(h, s.n_agents, s.first_agent, s.n_total, p->d.safety_samples, p->d.record_time_step, s.z_2d, x_plan,
                                              p->radius, p->downwash, hdr, (lscqp_safety*)p->buf[LSCQP_PLAN_BUF_SAFETY], stream));
-    if (p->d.closed_loop) {
-        const hipError_t e = hipMemcpyAsync(state + s.first_agent * 9, state_out, sizeof(double) * 9 * s.n_agents, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(next state)");
-    }
+    // (closed loop: LSCQP_PLAN_BUF_NEXT_STATE is the local agents' slice of the state buffer itself, so doStep's result is the next
+    // replan's current state without a copy)
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "HIP launch failed (plan step)");
     return LSCQP_OK;
@@ -305,11 +303,15 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         ok(dalloc_pub<lscqp_box>(p, LSCQP_PLAN_BUF_SFC, n * M)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_STATUS, n)) &&
         ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_GOAL_STATUS, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_SFC_STATUS, n)) &&
         ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_VALID, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_IN_RANGE, n)) &&
-        ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_NEXT_STATE, n * 9)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_OBJECTIVE, n)) &&
+        (desc->closed_loop ? true : ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_NEXT_STATE, n * 9))) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_OBJECTIVE, n)) &&
         ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc_pub<lscqp_safety>(p, LSCQP_PLAN_BUF_SAFETY, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
         ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
         ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
         ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1));
+    if (rc == LSCQP_OK && desc->closed_loop) {
+        p->buf[LSCQP_PLAN_BUF_NEXT_STATE] = (double*)p->buf[LSCQP_PLAN_BUF_STATE] + desc->first_agent * 9;
+        p->bytes[LSCQP_PLAN_BUF_NEXT_STATE] = n * 9 * sizeof(double);
+    }
     if (rc == LSCQP_OK) {
         std::vector<double> r(nt), w(nt);
         std::vector<uint64_t> off(n + 1);

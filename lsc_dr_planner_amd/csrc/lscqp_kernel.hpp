@@ -1145,10 +1145,13 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 // thousand, which the default start solves in a handful of iterations (tests/golden/warm_start_jam.json).  If the
                 // gap has not improved tenfold within six such iterations the row state is re-centred ONCE at the current control
                 // points (every product back to mu0) and the iteration carries on from there.
-                // (counted only for a warm-started iteration that is already close, gap <= 1e-4: a cold start is primal feasible
-                // from the first iteration on and legitimately spends many iterations bringing a large gap down)
+                // (counted only for an iteration that is already close, gap <= 1e-4: before that many iterations are legitimately
+                // spent bringing a large gap down)
 #ifndef LSCQP_NO_RECENTRE  // (A/B switch; carrying the test costs ~1 % of a step, measured with tools/_bis builds)
-                if (res_gap > tol && res_gap <= 1e-4 && x_init != nullptr) {
+                // (round 2: counted from the default start too -- 2 of 67 000 instances of a 100-seed sweep from hover sat at a gap
+                // of 1e-6 for fifty iterations, 4e-6 m from the optimum; the tenfold-in-six test is cumulative, so the slow linear
+                // phase of a hard instance, 6-8x per iteration, does not trip it)
+                if (res_gap > tol && res_gap <= 1e-4) {
                     if ((float)res_gap <= 0.1f * gap_mark) {
                         gap_mark = (float)res_gap;
                         jam_since = 0;
