@@ -1,6 +1,7 @@
 // Test driver of the C++ shim: exercises the reference's class surface (TrajOptimizer / CollisionConstraints /
 // Trajectory) end to end and prints one JSON object per scenario for tests/test_shim.py.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <goal_optimizer.hpp>
@@ -425,8 +426,90 @@ static int scenario_subsegment() {
     return 0;
 }
 
+// The whole replan as one chain of device work from a C++ host: world CSV + mission file (one line per
+// agent: start x y z, goal x y z) -> map, plan, `replans` closed-loop replans through the captured hipGraph with the waypoint one grid
+// step towards the goal.  Prints the statuses, the worst safety ratio and a fingerprint of the final plans.
+static int scenario_plan(const char* world_csv, const char* mission_txt, int replans) {
+    std::vector<double> starts, goals;
+    {
+        FILE* f = fopen(mission_txt, "r");
+        if (!f) return 2;
+        double v[6];
+        while (fscanf(f, "%lf %lf %lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+            starts.insert(starts.end(), v, v + 3);
+            goals.insert(goals.end(), v + 3, v + 6);
+        }
+        fclose(f);
+    }
+    const int n = (int)(starts.size() / 3);
+    lscqp_class_desc cd;
+    memset(&cd, 0, sizeof cd);
+    cd.M = 10, cd.n = 5, cd.phi = 3, cd.phi_n = 1, cd.dim = 2;
+    cd.planner_mode = LSCQP_PLANNER_LSC, cd.use_sfc = 1;
+    cd.dt = 0.2, cd.control_input_weight = 0.01, cd.terminal_weight = 1.0, cd.communication_range = 3.0;
+    const double wmin[3] = {-5, -5, 0}, wmax[3] = {5, 5, 2.5};
+    for (int k = 0; k < 3; k++) cd.world_min[k] = wmin[k], cd.world_max[k] = wmax[k];
+    lscqp_handle h = nullptr;
+    lscqp_map map = nullptr;
+    lscqp_plan plan = nullptr;
+    auto fail = [&](const char* what) {
+        printf("{\"scenario\": \"plan\", \"error\": \"%s: %s\"}\n", what, lscqp_last_error());
+        return 1;
+    };
+    if (lscqp_create(&cd, &h) != LSCQP_OK) return fail("lscqp_create");
+    if (lscqp_map_create_from_csv(world_csv, wmin, wmax, 0.1, 1.0, &map) != LSCQP_OK) return fail("lscqp_map_create_from_csv");
+    lscqp_plan_desc pd;
+    memset(&pd, 0, sizeof pd);
+    pd.n_agents = pd.n_total = n;
+    pd.n_obs = n - 1 < lscqp_max_obstacles(h) ? n - 1 : lscqp_max_obstacles(h);
+    pd.constraint_mode = LSCQP_GEN_CLSC, pd.sfc_mode = LSCQP_SFC_FROM_HULL, pd.optimize_goal = 1, pd.closed_loop = 1;
+    pd.safety_samples = 2, pd.record_time_step = 0.1;
+    pd.time_step = 0.2, pd.z_2d = starts[2];
+    std::vector<lscqp_agent_param> ap(n);
+    for (auto& a : ap) {
+        a.radius = 0.15, a.downwash = 2.0, a.nominal_velocity = 1.0;
+        for (int k = 0; k < 3; k++) a.max_vel[k] = 1.0, a.max_acc[k] = 2.0;
+    }
+    if (lscqp_plan_create(h, map, &pd, ap.data(), &plan) != LSCQP_OK) return fail("lscqp_plan_create");
+    if (lscqp_plan_reset(plan, starts.data(), nullptr) != LSCQP_OK) return fail("lscqp_plan_reset");
+    std::vector<double> way(starts);
+    for (int a = 0; a < n; a++)
+        for (int k = 0; k < 2; k++) {
+            const double d = goals[3 * a + k] - starts[3 * a + k];
+            way[3 * a + k] = (double)(float)(starts[3 * a + k] + (d > 1e-6 ? 0.5 : (d < -1e-6 ? -0.5 : 0.0)));
+        }
+    std::vector<int32_t> status(n);
+    std::vector<lscqp_safety> saf(n);
+    int failed = 0;
+    double worst = 1e300;
+    for (int r = 0; r < replans; r++) {
+        if (lscqp_plan_upload(plan, LSCQP_PLAN_BUF_WAYPOINT, r == 0 ? starts.data() : way.data(), 0, 24u * n) != LSCQP_OK) return fail("upload");
+        if (lscqp_plan_step_graph(plan, nullptr) != LSCQP_OK) return fail("lscqp_plan_step_graph");
+        if (lscqp_plan_download(plan, LSCQP_PLAN_BUF_STATUS, status.data(), 0, 4u * n) != LSCQP_OK) return fail("download");
+        if (lscqp_plan_download(plan, LSCQP_PLAN_BUF_SAFETY, saf.data(), 0, sizeof(lscqp_safety) * n) != LSCQP_OK) return fail("download");
+        for (int a = 0; a < n; a++) {
+            failed += status[a] != LSCQP_STATUS_OPTIMAL;
+            worst = saf[a].safety_ratio < worst ? saf[a].safety_ratio : worst;
+        }
+    }
+    const int nv = lscqp_num_variables(h);
+    std::vector<double> x((size_t)n * nv), st((size_t)n * 9);
+    lscqp_plan_download(plan, LSCQP_PLAN_BUF_PLAN, x.data(), 0, 8u * x.size());
+    lscqp_plan_download(plan, LSCQP_PLAN_BUF_STATE, st.data(), 0, 8u * st.size());
+    double sum = 0;
+    for (double v : x) sum += v;
+    printf("{\"scenario\": \"plan\", \"agents\": %d, \"replans\": %d, \"failed\": %d, \"worst_safety_ratio\": %.9g, \"graph_nodes\": %lld, "
+           "\"plan_sum\": %.17g, \"state0\": [%.9g, %.9g, %.9g]}\n",
+           n, replans, failed, worst, (long long)lscqp_plan_graph_nodes(plan), sum, st[0], st[1], st[2]);
+    lscqp_plan_destroy(plan);
+    lscqp_map_destroy(map);
+    lscqp_destroy(h);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     std::string s = argc > 1 ? argv[1] : "host";
+    if (s == "plan" && argc > 3) return scenario_plan(argv[2], argv[3], argc > 4 ? atoi(argv[4]) : 20);
     if (s == "host") return scenario_host();
     if (s == "kat") return scenario_kat(true);
     if (s == "pair") return scenario_pair();

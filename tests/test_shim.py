@@ -178,3 +178,43 @@ def test_dynamic_obstacle_rows_have_a_free_slack(shim_exe):
     r = run(shim_exe, "dynamic_obstacle")[0]
     assert abs(r["slack"] - r["without"]) <= 1e-9 * max(1.0, abs(r["without"]))
     assert r["hard"] > r["without"] + 1e-6
+
+
+@pytest.mark.gpu
+def test_plan_chain_from_a_cpp_host_equals_the_python_binding(shim_exe, api, tmp_path):
+    """INTEGRATION.md section 9 compiled and run: a C++ host drives lscqp_plan_* (world CSV -> map -> plan -> 20 closed-loop replans of
+    the forest10 mission through the captured hipGraph, safety figures included).  The final plans give the same checksum as the
+    same mission flown through the Python binding, the first agent's final state is identical."""
+    import torch
+
+    g = H.load_golden("forest10_world")
+    world = tmp_path / "forest10.csv"
+    np.savetxt(world, np.array(g["boxes"]), delimiter=",", fmt="%.17g")
+    mission = tmp_path / "mission.txt"
+    np.savetxt(mission, np.c_[np.array(g["starts"]), np.array(g["goals"])], fmt="%.17g")
+    out = subprocess.run([shim_exe, "plan", str(world), str(mission), "20"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    r = [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")][0]
+    assert "error" not in r, r
+    assert r["agents"] == 10 and r["failed"] == 0 and r["graph_nodes"] >= 9 and r["worst_safety_ratio"] >= 1.0 - 5e-6
+    N = 10
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=g["world_min"], world_max=g["world_max"]))
+    wmap = api.WorldMap(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = 0.15, 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, 9, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, closed_loop=True, z_2d=g["starts"][0][2],
+                    safety_samples=2, record_time_step=0.1)
+    starts, goals = np.array(g["starts"], dtype=np.float64), np.array(g["goals"], dtype=np.float64)
+    way = starts.copy()
+    d = goals[:, :2] - starts[:, :2]
+    way[:, :2] = np.float32(starts[:, :2] + np.where(d > 1e-6, 0.5, np.where(d < -1e-6, -0.5, 0.0)))
+    plan.reset(starts)
+    for k in range(20):
+        plan.put(api.PLAN_WAYPOINT, starts if k == 0 else way)
+        plan.step(graph=True)
+        torch.cuda.synchronize()
+    x = plan.get(api.PLAN_PLAN)
+    assert abs(float(np.sum(x)) - r["plan_sum"]) <= 1e-9  # (the two sums run in different orders)
+    st = plan.get(api.PLAN_STATE).reshape(N, 9)
+    assert np.array_equal(np.float32(st[0, :3]), np.float32(r["state0"]))
+    plan.close()
