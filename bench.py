@@ -134,6 +134,8 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
 
     sw, sol64, b, (hdr, rows, off, sfc) = make_batch(api, synth, factory, N, M, dim, n_obs, seed=3000 + N + M, style=cfg["style"], warm_steps=3)
     kw = {}
+    if cfg.get("warm_start") == "tight":
+        kw["warm_start"] = api.WARM_TIGHT
     if cfg["precision"] == "mixed":
         kw["precision"] = api.PRECISION_MIXED
     if cfg["rows"] == "f32":
@@ -591,6 +593,14 @@ def main():
             out["mixed_vs_fp64_at_4096"] = {"fp64_qp_per_s": by["c4_f64"]["qp_per_s"], "mixed_qp_per_s": by["c4"]["qp_per_s"],
                                             "ratio": by["c4"]["qp_per_s"] / by["c4_f64"]["qp_per_s"],
                                             "iters_fp64": by["c4_f64"]["iters_mean"], "iters_mixed": by["c4"]["iters_mean"]}
+        # the optional tight centring of warm starts (lscqp_class_desc.warm_start) on the throughput shape: informational
+        try:
+            tcfg = dict(CONFIGS["c4_f64"], warm_start="tight", what="configs[4] shape in fp64 with LSCQP_WARM_TIGHT")
+            t = measure_config(torch, api, synth, dev, "c4_f64", tcfg, O=None, lat_seconds=1.0)
+            out["tight_warm_start_at_4096"] = {"qp_per_s": t["qp_per_s"], "kernel_ms": t["kernel_ms"], "iters_mean": t["iters_mean"], "iters_max": t["iters_max"],
+                                               "non_optimal": t["non_optimal"], "ratio_to_default": t["qp_per_s"] / by["c4_f64"]["qp_per_s"] if "qp_per_s" in by.get("c4_f64", {}) else None}
+        except Exception as ex:
+            out["tight_warm_start_at_4096"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
         try:
             out["replan_chain"] = replan_chain(torch, api)

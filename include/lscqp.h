@@ -101,7 +101,21 @@ typedef struct lscqp_class_desc {
     int32_t max_iter;  /* default 60 */
     int32_t precision; /* LSCQP_PRECISION_* below */
     double tol;        /* relative duality-gap tolerance, 0 = default 1e-10 */
+    int32_t warm_start; /* LSCQP_WARM_* below: how an instance that comes with an initial trajectory is centred */
+    int32_t reserved_;
 } lscqp_class_desc;
+
+/* Centring of warm-started instances (x_init given).  Every complementarity product starts at mu0 with the slacks floored at s0.
+ *   LSCQP_WARM_DEFAULT  (mu0, s0) = (1e-3, 3 cm): safe whatever the quality of the initial trajectory; the shortest TAIL, which is
+ *                       what bounds a small batch (a launch lasts as long as its slowest QP).
+ *   LSCQP_WARM_TIGHT    (1e-7, 3 mm): presumes the initial trajectory is close to the optimum with the right rows near their bounds --
+ *                       the shifted previous plan of a replanning loop usually is.  An instance whose first step comes out shorter
+ *                       than 0.6 returns to the default centring after that iteration.  Fewer iterations on average where the start
+ *                       is good (4096 x M5 x 20: 3.1 -> 2.2, +6..15 % QP/s; agents holding position: 7.1 -> 4.8) with a longer tail
+ *                       everywhere -- 64 x M5: 0.106 -> 0.129 ms, the M = 10 shapes 10..50 % slower, single instances run to the
+ *                       iteration limit and are re-solved by the second pass.  A throughput option, not a default. */
+#define LSCQP_WARM_DEFAULT 0
+#define LSCQP_WARM_TIGHT 1
 
 /* Arithmetic of the interior-point iteration (lscqp_class_desc.precision).
  *   LSCQP_PRECISION_F64    everything fp64 (default; what the reference's CPLEX call computes in, src/traj_optimizer.cpp:66-70).
@@ -566,6 +580,11 @@ typedef struct lscqp_plan_desc {
     double time_step;        /* multisim_time_step: == dt shifts the plans by one segment, < dt uses Segment::subSegment */
     double z_2d;             /* world_z_2d of 2-D missions */
     double record_time_step; /* spacing of the safety samples (multisim_save_time_step) */
+    int32_t tight_warm_start; /* != 0: the plan's QP solves centre their warm starts in LSCQP_WARM_TIGHT mode whatever the handle's class
+                                 says (a private clone of the class).  Pays where the plans barely change from replan to replan (agents
+                                 holding position: forest10 chain 413 -> 320 us); with agents on the move it does not (10 agents: equal,
+                                 64 / 256 agents: 20 % slower, the batch waits for its slowest QP) -- hence off by default */
+    int32_t reserved_;
 } lscqp_plan_desc;
 /* Buffers of a plan (device pointers through lscqp_plan_buffer; lscqp_plan_upload / _download copy synchronously).
  * "all": [n_total] entries indexed by global id; "local": [n_agents] entries. */

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("LSCQP_LIB") or os.path.join(_HERE, "liblscqp.so")  # 
 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC, STATUS_CAPACITY = 0, 1, 2, 3, 4
 PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
+WARM_DEFAULT, WARM_TIGHT = 0, 1  # lscqp_class_desc.warm_start
 INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED = 1, 2, 4  # lscqp_info.flags
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC, PLANNER_RSFC = 0, 1, 2, 3
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
@@ -52,7 +53,7 @@ class ClassDesc(C.Structure):
         ("planner_mode", C.c_int32), ("use_sfc", C.c_int32), ("row_format", C.c_int32),
         ("dt", C.c_double), ("control_input_weight", C.c_double), ("terminal_weight", C.c_double),
         ("communication_range", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
-        ("max_iter", C.c_int32), ("precision", C.c_int32), ("tol", C.c_double),
+        ("max_iter", C.c_int32), ("precision", C.c_int32), ("tol", C.c_double), ("warm_start", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -209,8 +210,9 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
 
 def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
               world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0, row_format=ROWS_F64,
-              precision=PRECISION_F64):
+              precision=PRECISION_F64, warm_start=0):
     d = ClassDesc()
+    d.warm_start = warm_start
     d.row_format = row_format
     d.precision = precision
     d.M, d.n, d.phi, d.phi_n, d.dim = M, n, phi, phi_n, dim
@@ -280,7 +282,8 @@ AGENT_PARAM_DTYPE = np.dtype([("radius", "f8"), ("downwash", "f8"), ("max_vel", 
 class PlanDesc(C.Structure):  # lscqp_plan_desc
     _fields_ = [("n_agents", C.c_int64), ("n_total", C.c_int64), ("first_agent", C.c_int64), ("n_obs", C.c_int32), ("constraint_mode", C.c_int32),
                 ("sfc_mode", C.c_int32), ("optimize_goal", C.c_int32), ("closed_loop", C.c_int32), ("safety_samples", C.c_int32),
-                ("time_step", C.c_double), ("z_2d", C.c_double), ("record_time_step", C.c_double)]
+                ("time_step", C.c_double), ("z_2d", C.c_double), ("record_time_step", C.c_double), ("tight_warm_start", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 (PLAN_STATE, PLAN_WAYPOINT, PLAN_PLAN, PLAN_GOAL, PLAN_HEADER, PLAN_ROWS, PLAN_SFC, PLAN_STATUS, PLAN_GOAL_STATUS, PLAN_SFC_STATUS, PLAN_VALID,
@@ -297,7 +300,7 @@ class Plan:
            PLAN_OBJECTIVE: np.float64}
 
     def __init__(self, solver, world_map, n_agents, n_obs, agents, n_total=None, first_agent=0, constraint_mode=1, sfc_mode=1,
-                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0, safety_samples=0, record_time_step=0.1):
+                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0, safety_samples=0, record_time_step=0.1, tight_warm_start=False):
         self._p = None
         n_total = n_agents if n_total is None else n_total
         d = PlanDesc()
@@ -306,6 +309,7 @@ class Plan:
         d.time_step = float(solver.desc.dt if time_step is None else time_step)
         d.z_2d = float(z_2d)
         d.safety_samples, d.record_time_step = int(safety_samples), float(record_time_step)
+        d.tight_warm_start = int(tight_warm_start)
         ag = np.ascontiguousarray(agents, dtype=AGENT_PARAM_DTYPE)
         if ag.shape != (n_total,):
             raise ValueError("agents: one AGENT_PARAM_DTYPE record per agent of the mission")

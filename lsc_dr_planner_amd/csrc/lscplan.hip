@@ -120,6 +120,8 @@ __global__ __launch_bounds__(kThreads) void commit_kernel(Shape s, const int32_t
 }  // namespace lscplan
 
 struct lscqp_plan_s {
+    lscqp_handle hq = nullptr;  // the handle the QP solves run on: the caller's, or a private clone of its class in LSCQP_WARM_TIGHT mode
+    bool own_hq = false;
     lscqp_handle h = nullptr;
     lscqp_map map = nullptr;
     lscqp_plan_desc d;
@@ -214,7 +216,7 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
         PLAN_TRY(lscqp_optimize_goal_device(h, s.n_agents, hdr, rows, p->off, p->map ? sfc : nullptr, goal_status, stream));
     const unsigned nb = (unsigned)((s.n_agents + lscplan::kThreads - 1) / lscplan::kThreads);
     hipLaunchKernelGGL(lscplan::finalize_goal_kernel, dim3(nb), dim3(lscplan::kThreads), 0, stream, s, hdr);
-    PLAN_TRY(lscqp_solve_batch_device_ex(h, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj, status,
+    PLAN_TRY(lscqp_solve_batch_device_ex(p->hq, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj, status,
                                          info, 1, stream));
     const int64_t ne = s.n_agents * s.nv;
     hipLaunchKernelGGL(lscplan::commit_kernel, dim3((unsigned)((ne + lscplan::kThreads - 1) / lscplan::kThreads)), dim3(lscplan::kThreads), 0, stream, s,
@@ -279,6 +281,16 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "the plan chain uses 32-byte rows (row_format = LSCQP_ROWS_F64)");
     lscqp_plan_s* p = new lscqp_plan_s();
     p->h = h;
+    p->hq = h;
+    if (desc->tight_warm_start && lscqp_class_desc_of_(h)->warm_start != LSCQP_WARM_TIGHT) {
+        lscqp_class_desc cd = *lscqp_class_desc_of_(h);
+        cd.warm_start = LSCQP_WARM_TIGHT;
+        if (lscqp_create(&cd, &p->hq) != LSCQP_OK) {
+            delete p;
+            return LSCQP_ERR_INVALID_ARGUMENT;  // (lscqp_create has set the message)
+        }
+        p->own_hq = true;
+    }
     p->map = map;
     p->d = *desc;
     p->s.M = M;
@@ -342,6 +354,7 @@ void lscqp_plan_destroy(lscqp_plan p) {
     drop_graph(p);
     if (p->cap) (void)hipStreamDestroy(p->cap);
     for (void* q : p->owned) (void)hipFree(q);
+    if (p->own_hq) lscqp_destroy(p->hq);
     delete p;
 }
 

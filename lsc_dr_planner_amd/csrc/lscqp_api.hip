@@ -214,6 +214,12 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.rows_f32 = d->row_format == LSCQP_ROWS_F32;
     c.repair = 0;
     c.rsfc = d->planner_mode == LSCQP_PLANNER_RSFC;
+    if (d->warm_start != LSCQP_WARM_DEFAULT && d->warm_start != LSCQP_WARM_TIGHT)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "warm_start must be LSCQP_WARM_DEFAULT or LSCQP_WARM_TIGHT");
+    // (the build-time knobs LSCQP_WARM_MU0 / LSCQP_WARM_S0 of the kernel header are the default mode's values)
+    c.warm_mu0 = d->warm_start == LSCQP_WARM_TIGHT ? 1e-7 : LSCQP_WARM_MU0;
+    c.warm_s0 = d->warm_start == LSCQP_WARM_TIGHT ? 0.003 : LSCQP_WARM_S0;
+    c.warm_net = d->warm_start == LSCQP_WARM_TIGHT ? 0.6 : 0.0;
     return LSCQP_OK;
 }
 

@@ -46,6 +46,8 @@ struct DevClass {
     int rows_f32;   // lscqp_class_desc.row_format == LSCQP_ROWS_F32
     int rsfc;       // LSCQP_PLANNER_RSFC: z bounds of segment 0 are +-100, not the world box (src/traj_optimizer.cpp:255-258)
     int repair;     // second pass over a batch: only instances whose status_out is neither OPTIMAL nor CAPACITY are solved
+    double warm_mu0, warm_s0;  // centring of an instance that comes with an initial trajectory (lscqp_class_desc.warm_start)
+    double warm_net;           // > 0: first-step length below which such an instance returns to the (1e-3, 0.03) centring
 };
 
 // Q_base * dt^5 for n = 5, phi = 3 (integers)
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     // 3 on M = 5, 6, 10); inside it the factor is 1 and nothing changes.
     const double pull = (double)ts * cls.w_t * fmax(fabs(goal0), fmax(fabs(goal1), fabs(goal2)));
     const double mu_scale = fmin(1e3, fmax(1.0, 0.25 * pull));
-    const double MU0 = (x_init ? LSCQP_WARM_MU0 : LSCQP_COLD_MU0) * mu_scale, S0MIN = x_init ? LSCQP_WARM_S0 : 0.1;
+    const double MU0 = (x_init ? cls.warm_mu0 : LSCQP_COLD_MU0) * mu_scale, S0MIN = x_init ? cls.warm_s0 : 0.1;
     int status = LSCQP_STATUS_ITER_LIMIT;
     double m_tot = 0;
     SD r_s[NSLOT], r_l[NSLOT];  // LSC row state: slack, multiplier (lambda == 0 marks a dead slot)
@@ -948,6 +950,8 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     int it = 0, near_cnt = 0, floor_cnt = 0;
     float rp_ref = 3.0e38f;  // primal residual four iterations ago (infeasibility test below)
     int stalled = 0;         // consecutive checks at which it had not shrunk by 30 %
+    float alpha_first = 1.0f;  // step length of the first iteration (safety net of the tight warm start)
+    bool net_done = false;
     float gap_mark = 3.0e38f;  // jam test: the gap when it last improved tenfold, iterations since, done once
     int jam_since = 0;
     bool recentred = false;
@@ -1165,11 +1169,17 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             // (never once a point that meets the gap target has been seen: then the iteration is polishing its stationarity
             // residual, not jammed, and that point is the fallback the exits below rely on)
 #ifndef LSCQP_NO_RECENTRE
-            if (!recentred && jam_since >= 6 && floor_cnt == 0) {  // uniform over the QP's lanes
+            // Safety net of the TIGHT warm start (lscqp_class_desc.warm_start = LSCQP_WARM_TIGHT): it presumes that the caller's initial trajectory is
+            // close to the optimum with the right rows near their bounds.  Where it is not, the first step is short (the iterate is
+            // boxed in by slacks of 3 mm) and the iteration would crawl; such an instance goes back to the round-1 centring after that
+            // one iteration.  (tools/proto_pdip.py `early_recentre`: on 60 instances dumped from the forest10 closed loop 10.6 -> 6.1
+            // iterations with it, two instances +2; without it single instances take 18-23.)
+            const bool net = cls.warm_net > 0 && x_init != nullptr && it == 1 && !net_done && (double)alpha_first < cls.warm_net;
+            if (net || (!recentred && jam_since >= 6 && floor_cnt == 0)) {  // uniform over the QP's lanes
                 double cnt_ = 0;
                 bool bad_ = false;
-                centre_rows(1e-3, 0.03, cnt_, bad_);
-                recentred = true;
+                centre_rows(1e-3 * mu_scale, 0.03, cnt_, bad_);
+                if (net) net_done = true; else recentred = true;
                 rp_ref = 3.0e38f;
                 near_cnt = 0;
                 LSCQP_BLOCK_SYNC();
@@ -1920,6 +1930,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             LSCQP_T(8);
             LSCQP_STOP(9)
             // ============ update of z and the control points =================================================
+            if (it == 0) alpha_first = (float)alpha;
             if (zl) z_[zi0] += alpha * dzc;
             LSCQP_BLOCK_SYNC();
             // c = c_fixed + T z, recomputed from z so the eliminated equalities hold to rounding every iteration
@@ -1952,7 +1963,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
         res_gap = snap_gap;
         flags |= LSCQP_INFO_FLOOR_ACCEPTED;
     }
-    if (recentred) flags |= LSCQP_INFO_RECENTRED;
+    if (recentred || net_done) flags |= LSCQP_INFO_RECENTRED;
 
     // ---- epilogue: objective, control points back in the world frame ---------------------------------------
     const double obj = objective(true, lane);

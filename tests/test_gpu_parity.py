@@ -825,3 +825,31 @@ def test_feasible_instance_whose_residual_pauses_around_the_tenth_iteration(api,
     assert (R["status"] == 0).all() and (G["status"] == 0).all(), (G["status"], G["info"]["iterations"])
     assert G["info"]["iterations"][14] >= 14
     _check_against_oracle(oracle, cls, G, R)
+
+
+@pytest.mark.parametrize("N,M,dim,n_obs,style,seed", [(48, 5, 3, 20, "forest", 21), (16, 10, 2, 9, "forest", 22), (24, 10, 3, 40, "forest", 23), (32, 6, 3, 20, "maze", 24)])
+def test_tight_warm_start_mode_reaches_the_same_optimum(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed):
+    """lscqp_class_desc.warm_start = LSCQP_WARM_TIGHT (an option for throughput batches): every complementarity product starts at 1e-7 with
+    the slacks floored at 3 mm, an instance whose first step is short returns to the default centring.  Same optimum as the default mode
+    and as the oracle on replanning swarms; fewer iterations in total on the M = 5 forest class (3 -> 2), not on the M = 10 shapes."""
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    base = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    tight = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, warm_start=api.WARM_TIGHT))
+    it_base = it_tight = 0
+    for step in range(5):
+        b = sw.build()
+        hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+        xi = api.x_init_from_swarm(b, dim)
+        A, B = base.solve_host(hdr, rows, off, sfc, x_init=xi), tight.solve_host(hdr, rows, off, sfc, x_init=xi)
+        assert (A["status"] == 0).all() and (B["status"] == 0).all(), (A["status"], B["status"])
+        ag, lsc, loff, sfco = H.swarm_oracle_inputs(oracle, sw, b)
+        R = oracle.solve_batch(cls, ag, lsc, loff, sfco, threads=8)
+        _check_against_oracle(oracle, cls, B, R)
+        if step >= 1:
+            it_base += A["info"]["iterations"].sum()
+            it_tight += B["info"]["iterations"].sum()
+        sw.advance(B["x"])
+    assert M != 5 or it_tight < 0.8 * it_base, (it_tight, it_base)

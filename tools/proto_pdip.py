@@ -66,7 +66,7 @@ def solve32(fac, b):
 
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
-          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None):
+          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -211,6 +211,21 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             print(it, "rp %.2e rd %.2e mu %.2e" % (np.abs(rp).max(), np.abs(rd).max() / gscale, mu))
         pinf = lam @ np.abs(rp)
         gls = max(gscale, np.abs(grad).max())
+        # experiment: a TIGHT warm start (mu0_s0) with a safety net -- if the primal residual has not dropped tenfold by iteration
+        # `early_recentre[0]`, the initial trajectory was not as good as assumed: back to the loose centring early_recentre[1:]
+        if it == 0:
+            rp0 = np.abs(rp).max()
+        trig = False
+        if early_recentre is not None and warm and not recentred and it == early_recentre[0]:
+            if len(early_recentre) > 4 and early_recentre[4] == "alpha":
+                trig = a_first < early_recentre[3]
+            else:
+                trig = np.abs(rp).max() > (early_recentre[3] if len(early_recentre) > 3 else 0.1) * rp0
+        if trig:
+            s = np.maximum(Gz @ z - hz, early_recentre[2])
+            lam = early_recentre[1] / s
+            recentred, rp_ref, near_cnt = True, 3.0e38, 0
+            continue
         if np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-8 * gls and mu * mrows + pinf <= tol * (1 + abs(objz + objc)):
             near_cnt += 1
             if np.abs(rd).max() <= 10 * tol * gls or near_cnt >= 2:
@@ -315,6 +330,8 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             if (sn * ln).min() >= 1e-4 * (sn @ ln) / mrows:
                 break
             a = a_std if (_bt == 0 and a_std < a) else 0.7 * a
+        if it == 0:
+            a_first = a
         z = z + a * dz; s = s + a * ds; lam = lam + a * dl
     x = np.concatenate([cfix[k] + T @ z[k * nzA:(k + 1) * nzA] for k in range(dim)])
     # objective: the same polynomial integral as x'(w_c Q)x, evaluated through third differences (stable)

@@ -20,6 +20,7 @@ GEN = None  # --gen 0|1|2: the rows come from the device generator (generateLSC 
 if "--gen" in sys.argv:
     GEN = int(sys.argv[sys.argv.index("--gen") + 1])
 WARM = "--warm" in sys.argv  # hand the initial trajectory (shifted previous plan) to the solver as primal start
+TIGHT = "--tight" in sys.argv  # lscqp_class_desc.warm_start = LSCQP_WARM_TIGHT
 shapes = [(48, 5, 3, 20, "forest"), (32, 6, 3, 20, "maze"), (16, 10, 2, 9, "forest"), (24, 7, 3, 12, "maze"), (32, 4, 3, 12, "forest"),
           (24, 10, 3, 40, "forest"), (40, 5, 2, 12, "forest"), (24, 8, 2, 12, "maze")]
 if "--shape" in sys.argv:
@@ -32,7 +33,7 @@ for (N, M, dim, n_obs, style) in shapes:
     for seed in range(100, 100 + n_seeds):
         sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
         cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
-        sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+        sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, warm_start=api.WARM_TIGHT if TIGHT else api.WARM_DEFAULT))
         for step in range(3):
             b = sw.build()
             hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
