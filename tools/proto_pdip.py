@@ -193,6 +193,9 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         viol = max(0.0, -(Gz @ z - hz).min())
         base_mu = 1e-3 if warm else 3e-3
         mu0 = base_mu * min(30.0, max(1.0, viol / (-mu0)))
+    global LAST_START
+    r0_ = Gz @ z - hz
+    LAST_START = dict(viol=float(max(0.0, -r0_.min())), near3mm=int((r0_ < 0.003).sum()), near3cm=int((r0_ < 0.03).sum()), rows=int(len(r0_)))
     s = np.maximum(Gz @ z - hz, 0.0)
     s = np.maximum(s, s0)
     lam = mu0 / s  # centred start: every product s*lam = mu0
