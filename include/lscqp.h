@@ -623,6 +623,15 @@ int lscqp_plan_step(lscqp_plan plan, void* stream);
  * solver class by value: after lscqp_update on the handle the plan has to be destroyed and created again. */
 int lscqp_plan_step_graph(lscqp_plan plan, void* stream);
 int64_t lscqp_plan_graph_nodes(lscqp_plan plan); /* nodes of the captured graph, 0 before the capture */
+/* One replan of a mission spread over the devices of a communicator (section 8e): plans[g] was created with device g of `c` current
+ * (its own handle and map live there too) and owns the block [first_agent, first_agent + n_agents) of the n_total agents, blocks
+ * consecutive in device order and covering the mission.  Every plan's chain is enqueued on its device's stream
+ * (lscqp_comm_stream), eagerly or through its graph, followed on the same streams by the one exchange the reference has --
+ * MultiSyncSimulator::broadcastMsgs, src/multi_sync_simulator.cpp:305-352: every planner receives the others' previous plans --
+ * as an in-place RCCL exchange of the owners' slices of LSCQP_PLAN_BUF_PLAN / _STATE / _GOAL (grouped ncclAllGather for equal
+ * blocks, one ncclBroadcast per owner otherwise).  Asynchronous: lscqp_comm_synchronize waits for all devices.  Waypoints are
+ * written per plan before the call, as for lscqp_plan_step. */
+int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_graph);
 
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */

@@ -188,6 +188,8 @@ def lib():
         L.lscqp_plan_step_graph.argtypes = [vp, vp]
         L.lscqp_plan_graph_nodes.restype = C.c_int64
         L.lscqp_plan_graph_nodes.argtypes = [vp]
+        L.lscqp_plan_group_step.restype = C.c_int
+        L.lscqp_plan_group_step.argtypes = [vp, vp, C.c_int32]
         L.lscqp_last_error.restype = C.c_char_p
         L.lscqp_version.restype = C.c_char_p
         _lib = L
@@ -204,7 +206,7 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
                     "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_plan_create", "lscqp_plan_destroy", "lscqp_plan_reset", "lscqp_plan_buffer", "lscqp_plan_upload", "lscqp_plan_download",
-                    "lscqp_plan_step", "lscqp_plan_step_graph", "lscqp_plan_graph_nodes",
+                    "lscqp_plan_step", "lscqp_plan_step_graph", "lscqp_plan_graph_nodes", "lscqp_plan_group_step",
                     "lscqp_last_error", "lscqp_version"]
 
 
@@ -415,6 +417,16 @@ class Comm:
 
     def synchronize(self):
         rc = lib().lscqp_comm_synchronize(self._h)
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def plan_group_step(self, plans, graph=False):
+        """lscqp_plan_group_step: plans[g] lives on device g and owns its block of the mission's agents; every plan's replan is
+        enqueued on its device's stream, followed by the in-place RCCL exchange of the owners' plan / state / goal slices."""
+        if len(plans) != self.size:
+            raise ValueError("one plan per device of the communicator")
+        arr = (C.c_void_p * self.size)(*[p._p.value for p in plans])
+        rc = lib().lscqp_plan_group_step(self._h, arr, int(bool(graph)))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

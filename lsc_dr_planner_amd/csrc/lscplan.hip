@@ -449,6 +449,9 @@ int lscqp_plan_step_graph(lscqp_plan p, void* stream) {
     return LSCQP_OK;
 }
 
+const lscqp_plan_desc* lscqp_plan_desc_of_(lscqp_plan p) { return &p->d; }  // (library-internal: lscqp_comm.hip)
+int lscqp_plan_device_(lscqp_plan p) { return p->device; }
+
 int64_t lscqp_plan_graph_nodes(lscqp_plan p) {
     if (!p || !p->graph) return 0;
     size_t n = 0;

@@ -25,6 +25,8 @@
 #include "lscqp_staging.hpp"
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
+extern "C" const lscqp_plan_desc* lscqp_plan_desc_of_(lscqp_plan p);  // lscplan.hip
+extern "C" int lscqp_plan_device_(lscqp_plan p);
 
 namespace {
 
@@ -33,6 +35,7 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -55,6 +58,7 @@ struct Rccl {
         LSCQP_SYM(CommInitAll, ncclCommInitAll)
         LSCQP_SYM(CommDestroy, ncclCommDestroy)
         LSCQP_SYM(AllGather, ncclAllGather)
+        LSCQP_SYM(Broadcast, ncclBroadcast)
         LSCQP_SYM(GroupStart, ncclGroupStart)
         LSCQP_SYM(GroupEnd, ncclGroupEnd)
         LSCQP_SYM(GetErrorString, ncclGetErrorString)
@@ -344,6 +348,68 @@ int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lsc
         c->pool[g]->release(S.slot);
     }
     return rc;
+}
+
+// One replan of a mission whose agents are spread over the communicator's devices: plan g (created with device g of the communicator
+// current, on its own handle and map) owns the agents [first_agent, first_agent + n_agents) of n_total.  Every plan's chain is
+// enqueued on its device's stream, then the owners' slices of the previous plans, states and goal points -- what the next replan's
+// obstacle prediction, range filter and constraint generation read of the OTHER agents (reference
+// src/multi_sync_simulator.cpp:305-352, broadcastMsgs) -- are exchanged in place over RCCL on the same streams: one grouped
+// ncclAllGather per buffer when the blocks are equal, grouped ncclBroadcasts (one per owner) when the last block is short.
+// Asynchronous; lscqp_comm_synchronize waits.
+int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_graph) {
+    if (!c || !plans) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    const int G = c->G;
+    int64_t next = 0, n_total = -1;
+    bool equal = true;
+    for (int g = 0; g < G; g++) {
+        if (!plans[g]) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null plan in the group (one plan per device of the communicator)");
+        const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[g]);
+        if (lscqp_plan_device_(plans[g]) != c->dev[g])
+            return fail(LSCQP_ERR_INVALID_ARGUMENT, "plan g of the group must live on device g of the communicator");
+        if (n_total < 0) n_total = d->n_total;
+        if (d->n_total != n_total) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the plans of a group describe the same mission: n_total differs");
+        if (d->first_agent != next)
+            return fail(LSCQP_ERR_INVALID_ARGUMENT, "the plans of a group own consecutive blocks of agents in device order");
+        next += d->n_agents;
+        if (d->n_agents != lscqp_plan_desc_of_(plans[0])->n_agents) equal = false;
+    }
+    if (next != n_total) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the blocks of the group do not cover the mission (sum of n_agents != n_total)");
+    DeviceGuard dg;
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int g = 0; g < G; g++) {
+        if (hipSetDevice(c->dev[g]) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipSetDevice failed");
+        const int rc = use_graph ? lscqp_plan_step_graph(plans[g], c->stream[g]) : lscqp_plan_step(plans[g], c->stream[g]);
+        if (rc != LSCQP_OK) return rc;
+    }
+    if (!c->rccl_ok) return LSCQP_OK;  // (single device without RCCL, see lscqp_comm_create: the one plan owns every agent)
+    static const int kExchanged[3] = {LSCQP_PLAN_BUF_PLAN, LSCQP_PLAN_BUF_STATE, LSCQP_PLAN_BUF_GOAL};
+    ncclResult_t r = c->rccl.GroupStart();
+    for (int b = 0; b < 3 && r == ncclSuccess; b++) {
+        for (int g = 0; g < G && r == ncclSuccess; g++) {
+            if (hipSetDevice(c->dev[g]) != hipSuccess) {
+                (void)c->rccl.GroupEnd();
+                return fail(LSCQP_ERR_HIP, "hipSetDevice failed");
+            }
+            uint64_t bytes = 0;
+            double* const base = (double*)lscqp_plan_buffer(plans[g], kExchanged[b], &bytes);
+            const size_t per = (size_t)(bytes / sizeof(double) / (uint64_t)n_total);  // doubles per agent
+            if (equal) {
+                const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[g]);
+                r = c->rccl.AllGather(base + (size_t)d->first_agent * per, base, (size_t)d->n_agents * per, ncclDouble, c->comms[g], c->stream[g]);
+            } else {
+                for (int o = 0; o < G && r == ncclSuccess; o++) {
+                    const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[o]);
+                    double* const blk = base + (size_t)d->first_agent * per;
+                    r = c->rccl.Broadcast(blk, blk, (size_t)d->n_agents * per, ncclDouble, o, c->comms[g], c->stream[g]);
+                }
+            }
+        }
+    }
+    const ncclResult_t r2 = c->rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(LSCQP_ERR_HIP, std::string("RCCL exchange of the plans: ") + c->rccl.GetErrorString(r));
+    return LSCQP_OK;
 }
 
 }  // extern "C"

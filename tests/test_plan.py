@@ -164,6 +164,50 @@ def test_plan_sharded_over_two_owners_equals_the_single_plan(api, torch_cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_plan_group_step_over_the_communicator_equals_the_plain_step(api, torch_cuda, graph):
+    """lscqp_plan_group_step (section 8e for the chain): the plans of a mission, one per device of a communicator, stepped on the
+    communicator's streams and followed by the in-place RCCL exchange of the owners' plan / state / goal slices.  The GPU box has one
+    device, so the group is one plan owning every agent: the exchange runs through RCCL (a one-rank ncclAllGather in place) and must
+    leave the closed loop bit for bit where plain lscqp_plan_step calls take it.  A group that does not cover the mission, or whose
+    plans are not one per device, is refused."""
+    g, W, m = _mission()
+    N, K = m["N"], 15
+    sol, wmap, ref = _make_plan(api, W, N, closed_loop=True)
+    sol2, wmap2, grp = _make_plan(api, W, N, closed_loop=True)
+    comm = api.Comm(1)
+    assert comm.size == 1
+    starts = np.array(W["starts"], dtype=np.float64)
+    ref.reset(starts)
+    grp.reset(starts)
+    for k in range(K):
+        ref.put(api.PLAN_WAYPOINT, m["way"][k])
+        grp.put(api.PLAN_WAYPOINT, m["way"][k])
+        ref.step(graph=graph)
+        comm.plan_group_step([grp], graph=graph)
+        torch_cuda.cuda.synchronize()
+        comm.synchronize()
+        for which in (api.PLAN_PLAN, api.PLAN_STATE, api.PLAN_GOAL, api.PLAN_STATUS):
+            assert np.array_equal(ref.get(which), grp.get(which)), (k, which)
+    assert (grp.get(api.PLAN_STATUS) == 0).all()
+    if graph:
+        assert grp.graph_nodes() == ref.graph_nodes() > 0
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    half = api.Plan(sol, wmap, 5, 9, ag, n_total=N, first_agent=0, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"])
+    with pytest.raises(api.LscqpError, match="cover the mission"):
+        comm.plan_group_step([half])
+    late = api.Plan(sol, wmap, 5, 9, ag, n_total=N, first_agent=5, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"])
+    with pytest.raises(api.LscqpError, match="consecutive blocks"):
+        comm.plan_group_step([late])
+    with pytest.raises(ValueError):
+        comm.plan_group_step([half, late])
+    for p in (ref, grp, half, late):
+        p.close()
+    comm.close()
+
+
+@pytest.mark.gpu
 def test_plan_with_a_simulation_step_shorter_than_a_segment(api, oracle, torch_cuda):
     """multisim_time_step < dt (reference src/traj_planner.cpp:413-421): the chain then re-plans from the state at time_step along the
     plan and starts from prev_traj with segment 0 := subSegment(time_step / dt, 1).  Closed loop, 12 replans of the forest10 mission at
