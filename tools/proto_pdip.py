@@ -335,6 +335,11 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             a = a_std if (_bt == 0 and a_std < a) else 0.7 * a
         if it == 0:
             a_first = a
+        if verbose:  # which row stopped the step: the smallest ratio among -s/ds (primal) and -lam/dl (dual)
+            rs = np.where(ds < 0, -s / np.where(ds < 0, ds, -1.0), np.inf); rl = np.where(dl < 0, -lam / np.where(dl < 0, dl, -1.0), np.inf)
+            i_s, i_l = int(rs.argmin()), int(rl.argmin())
+            print("   alpha %.4f sigma %.2e | primal block row %d ratio %.3f (s %.2e lam %.2e) | dual block row %d ratio %.3f (s %.2e lam %.2e) | rows %d"
+                  % (a, sigma, i_s, rs[i_s], s[i_s], lam[i_s], i_l, rl[i_l], s[i_l], lam[i_l], mrows))
         z = z + a * dz; s = s + a * ds; lam = lam + a * dl
     x = np.concatenate([cfix[k] + T @ z[k * nzA:(k + 1) * nzA] for k in range(dim)])
     # objective: the same polynomial integral as x'(w_c Q)x, evaluated through third differences (stable)
