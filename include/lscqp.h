@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LSCQP_VERSION_MAJOR 0
-#define LSCQP_VERSION_MINOR 6
+#define LSCQP_VERSION_MINOR 7
 
 /* ---- return codes of the API calls themselves (misuse / runtime errors) ---- */
 enum {

@@ -700,6 +700,6 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
 
 const char* lscqp_last_error(void) { return g_err.c_str(); }
 
-const char* lscqp_version(void) { return "lscqp 0.6 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics, whole-replan chain + hipGraph)"; }
+const char* lscqp_version(void) { return "lscqp 0.7 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics, whole-replan chain + hipGraph, sharded over a communicator)"; }
 
 }  // extern "C"
