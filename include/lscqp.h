@@ -534,7 +534,8 @@ int lscqp_construct_sfc(lscqp_map map, int32_t mode, int32_t M, int64_t n, const
  * the mission at once, and of the loop around it in MultiSyncSimulator (src/multi_sync_simulator.cpp:305-400).  A plan object
  * owns the state the reference's planners carry from replan to replan -- previous plans (TrajPlanner::prev_traj), current goal
  * points, corridors -- plus the work buffers, all in HBM, and enqueues
- *     obstaclePrediction / initialTrajPlanning (PREVIOUSSOLUTION, :273-310, 399-423)  lscqp_shift_traj(_partial)_device
+ *     obstaclePrediction / initialTrajPlanning (:228-319, 360-423; all three modes,    lscqp_shift_traj(_partial)_device + the chain's
+ *       checkObstacleDisturbance)                                                       prepare step
  *     broadcastMsgs' range filter (src/multi_sync_simulator.cpp:318-333)              lscqp_select_neighbours_device
  *     constructLSC (:552-569)                                                         lscqp_generate_constraints_device
  *     constructSFC / generateSFC (:571-579, 738-753; initializeSFC on the first replan) lscqp_construct_sfc_device
@@ -584,8 +585,19 @@ typedef struct lscqp_plan_desc {
                                  says (a private clone of the class).  Pays where the plans barely change from replan to replan (agents
                                  holding position: forest10 chain 413 -> 320 us); with agents on the move it does not (10 agents: equal,
                                  64 / 256 agents: 20 % slower, the batch waits for its slowest QP) -- hence off by default */
+    int32_t prediction_mode;  /* how the OTHER agents' trajectories are predicted (obstaclePrediction, src/traj_planner.cpp:228-253):
+                                 LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION (0, the launch files' default: their shifted previous plans; constant
+                                 velocity on the first replan, :276-279), _FROM_POSITION (they stay where they are) or _FROM_VELOCITY
+                                 (Trajectory::planConstVelTraj from the current state) */
+    int32_t initial_traj_mode; /* the planning agent's own initial trajectory (initialTrajPlanning, :360-423): same three values */
     int32_t reserved_;
+    double reset_threshold;   /* checkObstacleDisturbance (:312-319, plan/reset_threshold, 0.1 in the launch files): an agent whose predicted
+                                 trajectory starts further than this from its current position is predicted to stay where it is
+                                 (a disturbed or externally moved robot; only with closed_loop == 0 can that happen).  <= 0: no check */
 } lscqp_plan_desc;
+#define LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION 0
+#define LSCQP_TRAJ_FROM_POSITION 1
+#define LSCQP_TRAJ_FROM_VELOCITY 2
 /* Buffers of a plan (device pointers through lscqp_plan_buffer; lscqp_plan_upload / _download copy synchronously).
  * "all": [n_total] entries indexed by global id; "local": [n_agents] entries. */
 #define LSCQP_PLAN_BUF_STATE 0        /* in   all    double[9]: position, velocity, acceleration (float32 values, as State holds them) */

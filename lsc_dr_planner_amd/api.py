@@ -285,7 +285,10 @@ class PlanDesc(C.Structure):  # lscqp_plan_desc
     _fields_ = [("n_agents", C.c_int64), ("n_total", C.c_int64), ("first_agent", C.c_int64), ("n_obs", C.c_int32), ("constraint_mode", C.c_int32),
                 ("sfc_mode", C.c_int32), ("optimize_goal", C.c_int32), ("closed_loop", C.c_int32), ("safety_samples", C.c_int32),
                 ("time_step", C.c_double), ("z_2d", C.c_double), ("record_time_step", C.c_double), ("tight_warm_start", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("prediction_mode", C.c_int32), ("initial_traj_mode", C.c_int32), ("reserved_", C.c_int32), ("reset_threshold", C.c_double)]
+
+
+TRAJ_FROM_PREVIOUS_SOLUTION, TRAJ_FROM_POSITION, TRAJ_FROM_VELOCITY = 0, 1, 2
 
 
 (PLAN_STATE, PLAN_WAYPOINT, PLAN_PLAN, PLAN_GOAL, PLAN_HEADER, PLAN_ROWS, PLAN_SFC, PLAN_STATUS, PLAN_GOAL_STATUS, PLAN_SFC_STATUS, PLAN_VALID,
@@ -302,7 +305,8 @@ class Plan:
            PLAN_OBJECTIVE: np.float64}
 
     def __init__(self, solver, world_map, n_agents, n_obs, agents, n_total=None, first_agent=0, constraint_mode=1, sfc_mode=1,
-                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0, safety_samples=0, record_time_step=0.1, tight_warm_start=False):
+                 optimize_goal=True, closed_loop=False, time_step=None, z_2d=1.0, safety_samples=0, record_time_step=0.1, tight_warm_start=False,
+                 prediction_mode=TRAJ_FROM_PREVIOUS_SOLUTION, initial_traj_mode=TRAJ_FROM_PREVIOUS_SOLUTION, reset_threshold=0.1):
         self._p = None
         n_total = n_agents if n_total is None else n_total
         d = PlanDesc()
@@ -312,6 +316,7 @@ class Plan:
         d.z_2d = float(z_2d)
         d.safety_samples, d.record_time_step = int(safety_samples), float(record_time_step)
         d.tight_warm_start = int(tight_warm_start)
+        d.prediction_mode, d.initial_traj_mode, d.reset_threshold = int(prediction_mode), int(initial_traj_mode), float(reset_threshold)
         ag = np.ascontiguousarray(agents, dtype=AGENT_PARAM_DTYPE)
         if ag.shape != (n_total,):
             raise ValueError("agents: one AGENT_PARAM_DTYPE record per agent of the mission")

@@ -285,6 +285,7 @@ __device__ __forceinline__ double segseg_closest(F3 s1, F3 e1, F3 s2, F3 e2, F3&
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, int64_t n_units, int32_t n_obs, int64_t first_agent,
                                                                 const double* __restrict__ traj,
+                                                                const double* __restrict__ own_traj,
                                                                 const int32_t* __restrict__ neighbours,
                                                                 const double* __restrict__ radius,
                                                                 const double* __restrict__ downwash,
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
         const bool tr = (MODE == LSCQP_GEN_BVC) || dim != 2;
         const double collision_dist = r_obs + r_own;
         auto cpt = [&](int64_t g, int mm, int i) -> F3 {
-            const double* p = traj + ((g * M + mm) * 6 + i) * 3;
+            // (own_traj: the planning agent's initial trajectory kept apart from the predicted trajectories, [local agent][M][6][3])
+            const double* p = (own_traj && g == ga) ? own_traj + ((a * M + mm) * 6 + i) * 3 : traj + ((g * M + mm) * 6 + i) * 3;
             return F3{(float)p[0], (float)p[1], (float)p[2]};
         };
         auto trf = [&](F3 p) -> F3 {
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void generate_lsc_kernel(int M, int dim, 
     // downwashBetween, both agents (:1229-1240); 2-D missions plan in the plane
     const double dw = (dim == 3) ? (downwash[ga] * r_own + downwash[gb] * r_obs) / (r_own + r_obs) : 1.0;
     const float dwf = (float)dw;
-    const double* own = traj + (ga * M + m) * 18;
+    const double* own = own_traj ? own_traj + (a * M + m) * 18 : traj + (ga * M + m) * 18;
     const double* obs = traj + (gb * M + m) * 18;
     P3 pobs[6];
     float relf[6][3];
@@ -757,7 +759,7 @@ extern "C" int lscqp_select_neighbours_raw_(int64_t n_agents, int64_t first_agen
 }
 
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
-                                       const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                       const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
                                        int32_t n_obs_total, int32_t slot0, lscqp_row* d_rows_out, void* stream) {
     const int64_t n_units = n_agents * (int64_t)n_obs * M;
@@ -767,7 +769,7 @@ extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agent
                  : mode == LSCQP_GEN_BVC ? lscgen::generate_lsc_kernel<LSCQP_GEN_BVC>
                                          : lscgen::generate_lsc_kernel<LSCQP_GEN_LSC>;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(lscgen::kThreads), 0, (hipStream_t)stream, M, dim, n_units, n_obs, first_agent, d_traj,
-                       d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, rows_f32, n_obs_total, slot0, d_rows_out);
+                       d_own_traj, d_neighbours, d_radius, d_downwash, d_goal, d_goal_all, rows_f32, n_obs_total, slot0, d_rows_out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;

@@ -26,6 +26,10 @@
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h);
+extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                               const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
+                                               const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
+                                               int32_t slot0, void* stream);
 
 namespace lscplan {
 
@@ -35,53 +39,99 @@ struct Shape {
     int M, dim, nv, n_obs;
     int64_t n_agents, n_total, first_agent;
     double z_2d, dt;
+    int prediction_mode, initial_traj_mode;  // LSCQP_TRAJ_FROM_*
+    double reset_threshold;                  // checkObstacleDisturbance, <= 0: off
 };
 
-// headers + corridor seed points + initial trajectory in the solver's layout: one wavefront per agent of the mission (the position
-// table covers all of them, the rest the local ones); the lanes share the plan's control points
+// Trajectory::planConstVelTraj (src/trajectory.cpp:79-91): control point (m, i) = current_state + velocity * time in point3d (float)
+// arithmetic, `time` a double that advances by segment_time / n after EVERY control point -- n + 1 steps per segment, so segment m
+// starts at 1.2 m dt: the reference's own quirk, kept -- and is narrowed to float by Vector3::operator*(float).
+__device__ __forceinline__ double const_vel_point(double p, double v, int idx, double dt) {
+#pragma clang fp contract(off)
+    double time = 0;
+    for (int q = 0; q < idx; q++) time += dt / 5;
+    const float step = (float)v * (float)time;
+    return (double)((float)p + step);
+}
+
+// One wavefront per agent of the mission.  For every agent: its position (range filter) and its PREDICTED trajectory as the others'
+// obstacle -- obstaclePrediction (src/traj_planner.cpp:228-253): the shifted previous plan that lscqp_shift_traj left in `traj`
+// (PREVIOUSSOLUTION; constant velocity while planner_seq < 2, :276-279), or planConstVelTraj from the current state (POSITION /
+// VELOCITY), then checkObstacleDisturbance (:312-319): a prediction that starts further than reset_threshold from where the agent is
+// becomes "stays where it is".  For the local agents also: header, corridor seed points, and the INITIAL trajectory
+// (initialTrajPlanning :360-423, same three sources but never reset: AgentManager's is_disturbed stays false) in the generator's layout
+// (`own`) and in the solver's (`x_init`).  The initial trajectory is taken before the prediction overwrites the agent's entry of `traj`.
 __global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_replan, const double* __restrict__ state,
                                                             const double* __restrict__ waypoint, const double* __restrict__ goal,
-                                                            const double* __restrict__ traj, const lscqp_agent_param* __restrict__ par,
+                                                            double* traj, const lscqp_agent_param* __restrict__ par,
                                                             double* __restrict__ pos, lscqp_header* __restrict__ hdr,
-                                                            double* __restrict__ points, double* __restrict__ x_init) {
+                                                            double* __restrict__ points, double* __restrict__ x_init, double* __restrict__ own) {
     const int64_t g = blockIdx.x;  // global agent id
     const int lane = threadIdx.x;
     if (g >= s.n_total) return;
     if (lane < 3) pos[g * 3 + lane] = state[g * 9 + lane];
     const int64_t t = g - s.first_agent;  // local id
-    if (t < 0 || t >= s.n_agents) return;
-    const double* tr = traj + g * s.M * 18;
-    if (lane == 0) {
-        lscqp_header H;
-        memset(&H, 0, sizeof H);
-        const lscqp_agent_param A = par[g];
-        for (int k = 0; k < 3; k++) {
-            H.p0[k] = state[g * 9 + k];
-            H.v0[k] = state[g * 9 + 3 + k];
-            H.a0[k] = state[g * 9 + 6 + k];
-            H.goal[k] = goal[g * 3 + k];
-            H.next_waypoint[k] = waypoint[t * 3 + k];
-            H.vmax[k] = A.max_vel[k];
-            H.amax[k] = A.max_acc[k];
+    const bool local = t >= 0 && t < s.n_agents;
+    double* tr = traj + g * s.M * 18;
+    const int P18 = s.M * 18;
+    if (local) {
+        const bool prev = s.initial_traj_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION && !first_replan;
+        const bool still = s.initial_traj_mode == LSCQP_TRAJ_FROM_POSITION;
+        auto init_at = [&](int r, int k) -> double {  // control point r = 6 m + i, axis k
+            return prev ? tr[r * 3 + k] : const_vel_point(state[g * 9 + k], still ? 0.0 : state[g * 9 + 3 + k], r, s.dt);
+        };
+        if (lane == 0) {
+            lscqp_header H;
+            memset(&H, 0, sizeof H);
+            const lscqp_agent_param A = par[g];
+            for (int k = 0; k < 3; k++) {
+                H.p0[k] = state[g * 9 + k];
+                H.v0[k] = state[g * 9 + 3 + k];
+                H.a0[k] = state[g * 9 + 6 + k];
+                H.goal[k] = goal[g * 3 + k];
+                H.next_waypoint[k] = waypoint[t * 3 + k];
+                H.vmax[k] = A.max_vel[k];
+                H.amax[k] = A.max_acc[k];
+            }
+            H.radius = A.radius;
+            H.nominal_velocity = A.nominal_velocity;
+            H.n_obs = s.n_obs;
+            H.terminal_segments = 0;  // set by finalize_goal_kernel once the goal LP has moved the goal
+            hdr[t] = H;
         }
-        H.radius = A.radius;
-        H.nominal_velocity = A.nominal_velocity;
-        H.n_obs = s.n_obs;
-        H.terminal_segments = 0;  // set by finalize_goal_kernel once the goal LP has moved the goal
-        hdr[t] = H;
+        if (lane < 9) {
+            // generateSFC (src/traj_planner.cpp:738-753): the agent's position on the first replan, afterwards the hull
+            // {initial_traj.lastPoint(), current_goal_point} and the next waypoint
+            const int which = lane / 3, k = lane - 3 * which;
+            const double p0k = state[g * 9 + k];
+            const double v = which == 0 ? init_at((s.M - 1) * 6 + 5, k) : (which == 1 ? goal[g * 3 + k] : waypoint[t * 3 + k]);
+            points[t * 9 + lane] = first_replan ? p0k : v;
+        }
+        double* xi = x_init + t * s.nv;
+        for (int e = lane; e < s.nv; e += kThreads) {  // x_init[k][m][i] = initial_traj[m][i][k]
+            const int k = e / (6 * s.M), r = e - k * 6 * s.M;
+            xi[e] = init_at(r, k);
+        }
+        double* ow = own + t * P18;
+        for (int e = lane; e < P18; e += kThreads) ow[e] = init_at(e / 3, e % 3);
     }
-    if (lane < 9) {
-        // generateSFC (src/traj_planner.cpp:738-753): the agent's position on the first replan, afterwards the hull
-        // {initial_traj.lastPoint(), current_goal_point} and the next waypoint
-        const int which = lane / 3, k = lane - 3 * which;
-        const double p0k = state[g * 9 + k];
-        const double v = which == 0 ? tr[((s.M - 1) * 6 + 5) * 3 + k] : (which == 1 ? goal[g * 3 + k] : waypoint[t * 3 + k]);
-        points[t * 9 + lane] = first_replan ? p0k : v;
+    // the agent as an obstacle of the others
+    const bool keep = s.prediction_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION && !first_replan;
+    bool reset = false;
+    if (s.reset_threshold > 0) {
+#pragma clang fp contract(off)
+        // (startPoint() - position).norm(): float differences, float sum of squares, sqrt in double (octomath::Vector3)
+        const float dx = (float)(keep ? tr[0] : state[g * 9 + 0]) - (float)state[g * 9 + 0];
+        const float dy = (float)(keep ? tr[1] : state[g * 9 + 1]) - (float)state[g * 9 + 1];
+        const float dz = (float)(keep ? tr[2] : state[g * 9 + 2]) - (float)state[g * 9 + 2];
+        reset = sqrt((double)(dx * dx + dy * dy + dz * dz)) > s.reset_threshold;
     }
-    double* xi = x_init + t * s.nv;
-    for (int e = lane; e < s.nv; e += kThreads) {  // x_init[k][m][i] = traj[m][i][k]
-        const int k = e / (6 * s.M), r = e - k * 6 * s.M;
-        xi[e] = tr[r * 3 + k];
+    if (!keep || reset) {
+        const bool still = reset || s.prediction_mode == LSCQP_TRAJ_FROM_POSITION;
+        for (int e = lane; e < P18; e += kThreads) {
+            const int k = e % 3;
+            tr[e] = const_vel_point(state[g * 9 + k], still ? 0.0 : state[g * 9 + 3 + k], e / 3, s.dt);
+        }
     }
 }
 
@@ -133,7 +183,7 @@ struct lscqp_plan_s {
     size_t bytes[LSCQP_PLAN_BUF_COUNT] = {};
     // private buffers
     lscqp_agent_param* par = nullptr;
-    double *radius = nullptr, *downwash = nullptr, *traj = nullptr, *pos = nullptr, *points = nullptr, *x_init = nullptr, *x_new = nullptr;
+    double *radius = nullptr, *downwash = nullptr, *traj = nullptr, *pos = nullptr, *points = nullptr, *x_init = nullptr, *x_new = nullptr, *own = nullptr;
     int32_t* nbr = nullptr;
     uint64_t* off = nullptr;
     hipGraph_t graph = nullptr;
@@ -198,20 +248,21 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     lscqp_info* info = (lscqp_info*)p->buf[LSCQP_PLAN_BUF_INFO];
     const double fraction = p->d.time_step / s.dt;
     // obstaclePredictionWithPrevSol / initialTrajPlanningPrevSol for every agent of the mission (:273-310, 399-423)
-    if (fraction >= 1.0 - 1e-9)
+    const bool from_plans = !first_replan && (s.prediction_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION || s.initial_traj_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION);
+    if (from_plans && fraction >= 1.0 - 1e-9)
         PLAN_TRY(lscqp_shift_traj_device(h, s.n_total, 1, s.z_2d, x_plan, p->traj, stream));
-    else
+    else if (from_plans)
         PLAN_TRY(lscqp_shift_traj_partial_device(h, s.n_total, fraction, s.z_2d, x_plan, p->traj, stream));
     hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)s.n_total), dim3(lscplan::kThreads), 0, stream,
-                       s, first_replan ? 1 : 0, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init);
+                       s, first_replan ? 1 : 0, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init, p->own);
     if (p->map)
         PLAN_TRY(lscqp_construct_sfc_device(h, p->map, first_replan ? LSCQP_SFC_INIT : p->d.sfc_mode, s.n_agents, p->points,
                                             p->radius + s.first_agent, sfc, sfc_status, stream));
     PLAN_TRY(lscqp_select_neighbours_device(h, s.n_agents, s.first_agent, s.n_total, s.n_obs, lscqp_class_desc_of_(h)->communication_range, p->pos, p->nbr, count,
                                             stream));
     if (s.n_obs > 0)
-        PLAN_TRY(lscqp_generate_constraints_device(h, p->d.constraint_mode, s.n_agents, s.n_obs, s.first_agent, p->traj, p->nbr, p->radius,
-                                                   p->downwash, goal, rows, stream));
+        PLAN_TRY(lscqp_generate_constraints_own_(h, p->d.constraint_mode, s.n_agents, s.n_obs, s.first_agent, p->traj, p->own, p->nbr, p->radius,
+                                                 p->downwash, goal, rows, s.n_obs, 0, stream));
     if (p->d.optimize_goal)
         PLAN_TRY(lscqp_optimize_goal_device(h, s.n_agents, hdr, rows, p->off, p->map ? sfc : nullptr, goal_status, stream));
     const unsigned nb = (unsigned)((s.n_agents + lscplan::kThreads - 1) / lscplan::kThreads);
@@ -267,6 +318,10 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "constraint_mode must be LSCQP_GEN_LSC, LSCQP_GEN_CLSC or LSCQP_GEN_BVC");
     if (desc->sfc_mode != LSCQP_SFC_FROM_HULL && desc->sfc_mode != LSCQP_SFC_FROM_POINT)
         return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "sfc_mode must be LSCQP_SFC_FROM_HULL or LSCQP_SFC_FROM_POINT");
+    for (const int32_t mode : {desc->prediction_mode, desc->initial_traj_mode})
+        if (mode != LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION && mode != LSCQP_TRAJ_FROM_POSITION && mode != LSCQP_TRAJ_FROM_VELOCITY)
+            return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "prediction_mode / initial_traj_mode must be LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION, _FROM_POSITION or _FROM_VELOCITY");
+    if (!(desc->reset_threshold == desc->reset_threshold)) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "reset_threshold is NaN");
     const int uses_sfc = lscqp_uses_sfc(h);
     if ((uses_sfc != 0) != (map != nullptr))
         return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "a map is required exactly when the solver class uses corridors (use_sfc)");
@@ -302,6 +357,9 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
     p->s.first_agent = desc->first_agent;
     p->s.z_2d = desc->z_2d;
     p->s.dt = dt_probe;
+    p->s.prediction_mode = desc->prediction_mode;
+    p->s.initial_traj_mode = desc->initial_traj_mode;
+    p->s.reset_threshold = desc->reset_threshold;
     if (hipGetDevice(&p->device) != hipSuccess) {
         delete p;
         return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
@@ -318,7 +376,7 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         (desc->closed_loop ? true : ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_NEXT_STATE, n * 9))) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_OBJECTIVE, n)) &&
         ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc_pub<lscqp_safety>(p, LSCQP_PLAN_BUF_SAFETY, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
         ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
-        ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
+        ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->own, n * P * 3)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
         ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1));
     if (rc == LSCQP_OK && desc->closed_loop) {
         p->buf[LSCQP_PLAN_BUF_NEXT_STATE] = (double*)p->buf[LSCQP_PLAN_BUF_STATE] + desc->first_agent * 9;

@@ -23,7 +23,7 @@ LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
-                                       const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
+                                       const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
                                        int32_t n_obs_total, int32_t slot0, lscqp_row* d_rows_out, void* stream);
 extern "C" int lscqp_shift_traj_partial_raw_(int M, int dim, int64_t n, const double* w36, double z_2d, const double* d_x_prev, double* d_traj,
@@ -282,7 +282,7 @@ int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, i
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_generate_lsc_raw_(LSCQP_GEN_LSC, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
+    return lscqp_generate_lsc_raw_(LSCQP_GEN_LSC, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, nullptr, d_neighbours, d_radius,
                                    d_downwash, d_goal, nullptr, h->dev.rows_f32, n_obs, 0, d_rows_out, stream);
 }
 
@@ -365,10 +365,25 @@ int lscqp_shift_traj_partial_device(lscqp_handle h, int64_t n, double fraction, 
     return lscqp_shift_traj_partial_raw_(h->desc.M, h->desc.dim, n, W, z_2d, d_x_prev, d_traj, stream);
 }
 
+// (library-internal, lscplan.hip) lscqp_generate_constraints_device_ex with the planning agents' initial trajectories kept apart from
+// the predicted trajectories of the agents as obstacles: d_own_traj [n_agents][M][6][3], NULL = rows d_traj[first_agent + a]
+extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                               const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
+                                               const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
+                                               int32_t slot0, void* stream);
+
 int lscqp_generate_constraints_device_ex(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                          const double* d_traj, const int32_t* d_neighbours, const double* d_radius,
                                          const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
                                          int32_t slot0, void* stream) {
+    return lscqp_generate_constraints_own_(h, mode, n_agents, n_obs, first_agent, d_traj, nullptr, d_neighbours, d_radius, d_downwash, d_goal_all,
+                                           d_rows_out, n_obs_total, slot0, stream);
+}
+
+int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
+                                    const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
+                                    const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
+                                    int32_t slot0, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (slot0 < 0 || n_obs_total < slot0 + n_obs) return fail(LSCQP_ERR_INVALID_ARGUMENT, "n_obs_total >= slot0 + n_obs required");
     if (mode != LSCQP_GEN_LSC && mode != LSCQP_GEN_CLSC && mode != LSCQP_GEN_BVC)
@@ -380,7 +395,7 @@ int lscqp_generate_constraints_device_ex(lscqp_handle h, int32_t mode, int64_t n
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_generate_lsc_raw_(mode, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_neighbours, d_radius,
+    return lscqp_generate_lsc_raw_(mode, h->desc.M, h->desc.dim, n_agents, n_obs, first_agent, d_traj, d_own_traj, d_neighbours, d_radius,
                                    d_downwash, d_goal_all + 3 * first_agent, d_goal_all, h->dev.rows_f32, n_obs_total, slot0, d_rows_out, stream);
 }
 

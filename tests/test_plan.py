@@ -207,6 +207,124 @@ def test_plan_group_step_over_the_communicator_equals_the_plain_step(api, torch_
     comm.close()
 
 
+def _agents(api, W, N):
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
+    return ag
+
+
+def _const_vel_traj(pos, vel, M, dt):
+    """Trajectory::planConstVelTraj (reference src/trajectory.cpp:79-91) in numpy: point3d arithmetic, the double clock advancing by
+    dt / n after every control point (n + 1 times per segment)."""
+    out = np.zeros((len(pos), M, 6, 3))
+    time = 0.0
+    for m in range(M):
+        for i in range(6):
+            out[:, m, i, :] = (np.float32(pos) + np.float32(vel) * np.float32(time)).astype(np.float64)
+            time += dt / 5
+    return out
+
+
+@pytest.mark.gpu
+def test_plan_predicts_a_disturbed_agent_to_stay_where_it_is(api, torch_cuda):
+    """checkObstacleDisturbance (reference src/traj_planner.cpp:312-319) inside the chain: an agent whose predicted trajectory starts
+    further than reset_threshold from where it is now is predicted to stay there -- for the OTHERS; its own initial trajectory is not
+    touched (AgentManager's is_disturbed stays false).  Six logged replans, then agent 3 is moved by 0.32 m: the others' rows equal
+    bit for bit those of a plan without the check in which agent 3's previous plan was replaced by hand with "hover at the new
+    position", agent 3's own rows equal those of a plan without the check, and the check did change something."""
+    g, W, m = _mission()
+    N, K0, who = m["N"], 6, 3
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    kw = dict(constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"])
+    A = api.Plan(sol, wmap, N, 9, _agents(api, W, N), reset_threshold=0.1, **kw)
+    B = api.Plan(sol, wmap, N, 9, _agents(api, W, N), reset_threshold=0.0, **kw)
+    D = api.Plan(sol, wmap, N, 9, _agents(api, W, N), reset_threshold=0.0, **kw)
+    for p in (A, B, D):
+        p.reset(np.array(W["starts"], dtype=np.float64))
+        for k in range(K0):
+            p.put(api.PLAN_STATE, m["state"][k])
+            p.put(api.PLAN_WAYPOINT, m["way"][k])
+            p.step()
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(A.get(api.PLAN_ROWS), D.get(api.PLAN_ROWS))  # (no disturbance so far: the check is silent)
+    state = m["state"][K0].copy()
+    state[who, 0] = np.float32(state[who, 0] + 0.25)
+    state[who, 1] = np.float32(state[who, 1] - 0.2)
+    x = B.get(api.PLAN_PLAN).reshape(N, 2, 60)
+    x[who, 0, :], x[who, 1, :] = state[who, 0], state[who, 1]
+    B.put(api.PLAN_PLAN, x.reshape(N, -1))
+    for p in (A, B, D):
+        p.put(api.PLAN_STATE, state)
+        p.put(api.PLAN_WAYPOINT, m["way"][K0])
+        p.step()
+    torch_cuda.cuda.synchronize()
+    rows = {n: p.get(api.PLAN_ROWS).reshape(N, -1) for n, p in (("A", A), ("B", B), ("D", D))}
+    others = [a for a in range(N) if a != who]
+    assert np.array_equal(rows["A"][others], rows["B"][others])
+    assert np.array_equal(rows["A"][who], rows["D"][who])
+    assert not np.array_equal(rows["A"][others], rows["D"][others]), "agent 3 is nobody's neighbour: the case tests nothing"
+    assert (A.get(api.PLAN_IN_RANGE) == D.get(api.PLAN_IN_RANGE)).all()
+    for p in (A, B, D):
+        p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pred,init", [("VELOCITY", "VELOCITY"), ("POSITION", "POSITION"), ("VELOCITY", "PREVIOUS_SOLUTION"), ("PREVIOUS_SOLUTION", "POSITION")])
+def test_plan_prediction_and_initial_trajectory_modes(api, torch_cuda, pred, init):
+    """obstaclePrediction / initialTrajPlanning in their three modes (reference src/traj_planner.cpp:228-253, 360-423): the rows the
+    chain generates on its second replan equal, bit for bit, lscqp_generate_constraints_device run agent by agent on trajectories put
+    together by hand -- the agent's own entry from its mode, the others' from theirs; constant-velocity trajectories follow
+    Trajectory::planConstVelTraj (numpy restatement above), previous-solution ones come from lscqp_shift_traj_device."""
+    torch = torch_cuda
+    g, W, m = _mission()
+    N, M, n_obs, dev = m["N"], 10, 9, torch.device("cuda", 0)
+    sol = api.Solver(api.make_desc(M=M, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    mode = dict(PREVIOUS_SOLUTION=api.TRAJ_FROM_PREVIOUS_SOLUTION, POSITION=api.TRAJ_FROM_POSITION, VELOCITY=api.TRAJ_FROM_VELOCITY)
+    plan = api.Plan(sol, wmap, N, n_obs, _agents(api, W, N), constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"],
+                    prediction_mode=mode[pred], initial_traj_mode=mode[init], reset_threshold=0.0)
+    plan.reset(np.array(W["starts"], dtype=np.float64))
+    for k in (0, 1, 2):
+        plan.put(api.PLAN_STATE, m["state"][k])
+        plan.put(api.PLAN_WAYPOINT, m["way"][k])
+        plan.step()
+    torch.cuda.synchronize()
+    k = 6  # (any state may follow with closed_loop = 0: one with the agents on the move)
+    state = m["state"][k]
+    x_prev, goal_all = plan.get(api.PLAN_PLAN), plan.get(api.PLAN_GOAL)
+    plan.put(api.PLAN_STATE, state)
+    plan.put(api.PLAN_WAYPOINT, m["way"][k])
+    plan.step()
+    torch.cuda.synchronize()
+    got = plan.get(api.PLAN_ROWS).reshape(N, -1)
+    assert (plan.get(api.PLAN_STATUS) >= 0).all()
+    # the same rows, put together by hand
+    d_prev = torch.from_numpy(x_prev).to(dev)
+    d_shift = torch.zeros(N * M * 18, dtype=torch.float64, device=dev)
+    sol.shift_traj_device(N, d_prev, d_shift, z_2d=W["z_2d"])
+    shifted = d_shift.cpu().numpy().reshape(N, M, 6, 3)
+    source = dict(PREVIOUS_SOLUTION=shifted, POSITION=_const_vel_traj(state[:, 0:3], np.zeros((N, 3)), M, 0.2),
+                  VELOCITY=_const_vel_traj(state[:, 0:3], state[:, 3:6], M, 0.2))
+    d_pos = torch.from_numpy(np.ascontiguousarray(state[:, 0:3])).to(dev)
+    d_nbr = torch.zeros(N * n_obs, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+    sol.select_neighbours_device(N, 0, N, n_obs, 3.0, d_pos, d_nbr, d_cnt)
+    d_radius = torch.full((N,), float(W["radius"]), dtype=torch.float64, device=dev)
+    d_down = torch.full((N,), 2.0, dtype=torch.float64, device=dev)
+    d_goal = torch.from_numpy(goal_all).to(dev)
+    for a in range(N):
+        traj = source[pred].copy()
+        traj[a] = source[init][a]
+        d_traj = torch.from_numpy(traj.reshape(-1)).to(dev)
+        d_rows = torch.zeros(n_obs * M * 6 * 4, dtype=torch.float64, device=dev)
+        sol.generate_constraints_device(api.GEN_CLSC, 1, n_obs, a, d_traj, d_nbr[a * n_obs:(a + 1) * n_obs].contiguous(), d_radius, d_down, d_goal, d_rows)
+        torch.cuda.synchronize()
+        want = d_rows.cpu().numpy().view(api.ROW_DTYPE)
+        assert np.array_equal(got[a], want), (pred, init, a)
+    plan.close()
+
+
 @pytest.mark.gpu
 def test_plan_with_a_simulation_step_shorter_than_a_segment(api, oracle, torch_cuda):
     """multisim_time_step < dt (reference src/traj_planner.cpp:413-421): the chain then re-plans from the state at time_step along the
