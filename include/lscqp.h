@@ -586,9 +586,10 @@ typedef struct lscqp_plan_desc {
                                  holding position: forest10 chain 413 -> 320 us); with agents on the move it does not (10 agents: equal,
                                  64 / 256 agents: 20 % slower, the batch waits for its slowest QP) -- hence off by default */
     int32_t prediction_mode;  /* how the OTHER agents' trajectories are predicted (obstaclePrediction, src/traj_planner.cpp:228-253):
-                                 LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION (0, the launch files' default: their shifted previous plans; constant
-                                 velocity on the first replan, :276-279), _FROM_POSITION (they stay where they are) or _FROM_VELOCITY
-                                 (Trajectory::planConstVelTraj from the current state) */
+                                 LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION (0; mode/planner lsc and dlsc, src/param.cpp:127-166: their shifted
+                                 previous plans; constant velocity on the first replan, :276-279), _FROM_POSITION (mode/planner bvc:
+                                 they stay where they are) or _FROM_VELOCITY (circle_test: Trajectory::planConstVelTraj from the
+                                 current state) */
     int32_t initial_traj_mode; /* the planning agent's own initial trajectory (initialTrajPlanning, :360-423): same three values */
     int32_t reserved_;
     double reset_threshold;   /* checkObstacleDisturbance (:312-319, plan/reset_threshold, 0.1 in the launch files): an agent whose predicted
