@@ -369,6 +369,20 @@ class Plan:
             raise ValueError("not an input buffer")
         self._check(lib().lscqp_plan_upload(self._p, which, a.ctypes.data_as(C.c_void_p), first * per, a.nbytes))
 
+    def tensor(self, which):
+        """Zero-copy torch view of a float64 buffer of the plan (PLAN_PLAN, PLAN_STATE, PLAN_GOAL, ...): what
+        sharding.exchange_plan_buffers exchanges between the ranks of a torch.distributed job."""
+        import torch
+
+        if np.dtype(self._dt[which]) != np.float64:
+            raise ValueError("not a float64 buffer")
+        ptr, nb = self.pointer(which)
+
+        class _View:
+            __cuda_array_interface__ = dict(shape=(nb // 8,), typestr="<f8", data=(ptr, False), version=2)
+
+        return torch.as_tensor(_View(), device="cuda")
+
     def step(self, stream=None, graph=False):
         sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
         self._check((lib().lscqp_plan_step_graph if graph else lib().lscqp_plan_step)(self._p, sp))

@@ -48,3 +48,29 @@ def reduce_safety_metrics(safety_ratio_local, vel_excess_local, acc_excess_local
         dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
     return mn[0], mx[:3], mx[3:]
+
+
+def exchange_plan_buffers(buffers, n_total, group=None):
+    """The exchange step of a sharded replan chain (lscqp_plan with first_agent / n_agents = shard_range(n_total, world, rank)): every
+    rank holds the buffers of ALL agents -- previous plans, states, goal points: what the next replan's obstacle prediction, range
+    filter and constraint generation read of the other agents (reference src/multi_sync_simulator.cpp:305-352, broadcastMsgs) --
+    and has just rewritten its own block.  `buffers`: 1-D contiguous tensors of n_total * k elements each (api.Plan.tensor(which) for
+    PLAN_PLAN, PLAN_STATE, PLAN_GOAL: zero-copy views of the plan's device buffers), updated IN PLACE: one broadcast per owner and
+    buffer (blocks may be ragged; k doubles per agent, ~1 KB for a plan: latency bound whatever the collective).  The single-process
+    analogue behind the C ABI is lscqp_plan_group_step."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    work = []
+    for buf in buffers:
+        assert buf.dim() == 1 and buf.is_contiguous() and buf.numel() % n_total == 0
+        per = buf.numel() // n_total
+        for r in range(world):
+            lo, hi = shard_range(n_total, world, r)
+            if hi > lo:
+                src = r if group is None else dist.get_global_rank(group, r)
+                work.append(dist.broadcast(buf[lo * per:hi * per], src=src, group=group, async_op=True))
+    for w in work:
+        w.wait()

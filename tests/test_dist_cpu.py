@@ -73,3 +73,35 @@ def test_two_rank_gloo_allgather(tmp_path, oracle):
     S = oracle.safety_metrics(cls, ag, R["x"], sw.radius, sw.downwash, 2, 0.05)
     want = np.concatenate([[S[:, 0].min()], S[:, 3:6].max(axis=0), S[:, 6:9].max(axis=0)])
     assert np.array_equal(s0, s1) and np.array_equal(s0, want) and want[1] > 0
+
+
+def _exchange_worker(rank, world, port, n_total, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lsc_dr_planner_amd import sharding
+
+    lo, hi = sharding.shard_range(n_total, world, rank)
+    bufs = []
+    for per in (120, 9, 3):  # plans (dim * M * 6), states, goal points
+        b = torch.full((n_total * per,), -1.0, dtype=torch.float64)   # stale copies of the others' blocks
+        own = torch.arange(lo * per, hi * per, dtype=torch.float64) + 1000.0 * per
+        b[lo * per:hi * per] = own                                    # the block this rank has just replanned
+        bufs.append(b)
+    sharding.exchange_plan_buffers(bufs, n_total)
+    np.save(os.path.join(out_dir, "b_%d.npy" % rank), torch.cat(bufs).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_exchange_of_plan_buffers(tmp_path):
+    """The chain's exchange step between ranks (sharding.exchange_plan_buffers; behind the C ABI: lscqp_plan_group_step): after it every
+    rank holds every owner's block of the plan / state / goal buffers, ragged blocks included (7 agents: 4 + 3)."""
+    n_total = 7
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_exchange_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    b0, b1 = np.load(tmp_path / "b_0.npy"), np.load(tmp_path / "b_1.npy")
+    assert np.array_equal(b0, b1)
+    want = np.concatenate([np.arange(n_total * per, dtype=np.float64) + 1000.0 * per for per in (120, 9, 3)])
+    assert np.array_equal(b0, want)

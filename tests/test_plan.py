@@ -207,6 +207,49 @@ def test_plan_group_step_over_the_communicator_equals_the_plain_step(api, torch_
     comm.close()
 
 
+@pytest.mark.gpu
+def test_plan_tensor_views_carry_the_exchange_between_two_owners(api, torch_cuda):
+    """Plan.tensor: zero-copy torch views of the plan's device buffers -- what sharding.exchange_plan_buffers hands to torch.distributed
+    in a one-process-per-GPU job.  Two owners (agents 0-4 and 5-9) on one device, closed loop; after every replan each owner's block of
+    the plan / state / goal views is copied into the other owner's views ON THE DEVICE (what the broadcasts do between ranks): 12
+    replans equal the single 10-agent plan bit for bit."""
+    torch = torch_cuda
+    from lsc_dr_planner_amd import sharding
+
+    g, W, m = _mission()
+    N, K = m["N"], 12
+    sol, wmap, whole = _make_plan(api, W, N, closed_loop=True)
+    parts = []
+    for r in range(2):
+        lo, hi = sharding.shard_range(N, 2, r)
+        parts.append(api.Plan(sol, wmap, hi - lo, 9, _agents(api, W, N), n_total=N, first_agent=lo, constraint_mode=api.GEN_CLSC,
+                              sfc_mode=api.SFC_FROM_HULL, closed_loop=True, z_2d=W["z_2d"]))
+    starts = np.array(W["starts"], dtype=np.float64)
+    for p in [whole] + parts:
+        p.reset(starts)
+    views = [[p.tensor(w) for w in (api.PLAN_PLAN, api.PLAN_STATE, api.PLAN_GOAL)] for p in parts]
+    assert np.array_equal(views[0][0].cpu().numpy(), parts[0].get(api.PLAN_PLAN))
+    for k in range(K):
+        whole.put(api.PLAN_WAYPOINT, m["way"][k])
+        whole.step()
+        for r, p in enumerate(parts):
+            lo, hi = sharding.shard_range(N, 2, r)
+            p.put(api.PLAN_WAYPOINT, m["way"][k][lo:hi])
+            p.step()
+        torch.cuda.synchronize()
+        for b in range(3):
+            per = views[0][b].numel() // N
+            for r in range(2):
+                lo, hi = sharding.shard_range(N, 2, r)
+                views[1 - r][b][lo * per:hi * per].copy_(views[r][b][lo * per:hi * per])
+        torch.cuda.synchronize()
+        for w in (api.PLAN_PLAN, api.PLAN_STATE, api.PLAN_GOAL):
+            assert np.array_equal(parts[0].get(w), whole.get(w)) and np.array_equal(parts[1].get(w), whole.get(w)), (k, w)
+    sharding.exchange_plan_buffers(views[0], N)  # (no process group: nothing to exchange, nothing touched)
+    for p in [whole] + parts:
+        p.close()
+
+
 def _agents(api, W, N):
     ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
     ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
