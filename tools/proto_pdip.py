@@ -31,6 +31,7 @@ def build_T(M, end_stop):
     return T, nzA
 
 
+FINISH_LOG = []
 PIVOT_FLOOR = 0.0
 JACOBI = True
 
@@ -66,7 +67,7 @@ def solve32(fac, b):
 
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
-          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None):
+          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -234,6 +235,56 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             if np.abs(rd).max() <= 10 * tol * gls or near_cnt >= 2:
                 status = 0
                 break
+        # experiment: FINITE TERMINATION.  finish = (gap trigger, method, rho): once the residuals have converged and the relative gap is
+        # below the trigger, the active set is read off the iterate (s < lam), the equality-constrained QP on it is solved -- exactly
+        # ("kkt") or as the kernel could, by the method of multipliers on the reduced matrix with weight rho on the active rows and
+        # none on the others ("alm": ONE factorisation, three solves) -- and the point is taken if it is primal feasible and the active
+        # rows' multipliers are non-negative.  One attempt per tenfold decrease of the gap; counts as an iteration.
+        global FINISH_LOG
+        if finish is not None and np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-8 * gls:
+            gap_rel_ = (mu * mrows + pinf) / (1 + abs(objz + objc))
+            if gap_rel_ <= finish[0] and gap_rel_ <= 0.1 * locals().get("fin_mark", 3e38):
+                fin_mark = gap_rel_
+                act = s < lam
+                GA, hA = Gz[act], hz[act]
+                nA = int(act.sum())
+                if finish[1] in ("kkt", "refine"):
+                    for _round in range(4 if finish[1] == "refine" else 1):  # "refine": a few active-set exchanges (drop negative multipliers, add violated rows)
+                        GA, hA = Gz[act], hz[act]
+                        nA = int(act.sum())
+                        KK = np.block([[Kfull, -GA.T], [GA, np.zeros((nA, nA))]])
+                        try:
+                            sol_ = np.linalg.lstsq(KK, np.concatenate([-gfull, hA]), rcond=None)[0]
+                            zf, lf = sol_[:nz], sol_[nz:]
+                        except np.linalg.LinAlgError:
+                            zf = None
+                            break
+                        viol_ = (Gz @ zf - hz) < -1e-9
+                        neg_ = np.zeros(mrows, bool)
+                        neg_[np.where(act)[0][lf < -1e-9 * max(1.0, np.abs(lf).max(initial=0))]] = True
+                        if finish[1] != "refine" or not (viol_.any() or neg_.any()):
+                            break
+                        act = (act & ~neg_) | viol_
+                else:
+                    rho = finish[2]
+                    Kp = Kfull + rho * GA.T @ GA
+                    Lc = np.linalg.cholesky(Kp)
+                    lf = lam[act].copy()
+                    zf = z
+                    for _r in range(3):
+                        zf = np.linalg.solve(Lc.T, np.linalg.solve(Lc, -gfull + GA.T @ (lf + rho * hA)))
+                        lf = lf + rho * (hA - GA @ zf)
+                ok_ = zf is not None
+                if ok_:
+                    slack_ = Gz @ zf - hz
+                    ok_ = slack_.min() >= -1e-9 and (nA == 0 or lf.min() >= -1e-9 * max(1.0, np.abs(lf).max())) and np.abs(GA @ zf - hA).max(initial=0) <= 1e-9
+                    ok_ = ok_ and np.abs(Kfull @ zf + gfull - GA.T @ lf).max() <= 1e-8 * gls
+                FINISH_LOG.append((it, nA, bool(ok_)))
+                if ok_:
+                    z = zf
+                    it += 1
+                    status = 0
+                    break
         # infeasible instances: the primal residual stalls above 1e-4, or the multipliers run away (same test as the kernel)
         if it % 4 == 2:
             if it >= 10 and ((np.abs(rp).max() > 1e-4 and np.abs(rp).max() > 0.7 * rp_ref) or (np.abs(rp).max() > 1e-5 and pinf > 1e6)):
