@@ -67,7 +67,7 @@ def solve32(fac, b):
 
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
-          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None):
+          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None, sigma_pow=3.0):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -341,7 +341,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         neg = dla < 0
         if neg.any(): aa = min(aa, (-lam[neg] / dla[neg]).min())
         mu_aff = (s + aa * dsa) @ (lam + aa * dla) / mrows
-        sigma = (mu_aff / mu) ** 3
+        sigma = (mu_aff / mu) ** sigma_pow
         q = (sigma * mu - dsa * dla) / s - w * rp
         dz = lin(q)
         ds = Gz @ dz + rp
