@@ -250,6 +250,35 @@ def test_plan_tensor_views_carry_the_exchange_between_two_owners(api, torch_cuda
         p.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_plan_of_a_single_agent_without_neighbour_slots(api, torch_cuda, graph):
+    """The empty end of the chain: one agent, n_obs = 0 (no row buffer, no range filter hits, the constraint generation is skipped, the
+    goal LP and the QP see corridor rows only).  Agent 0 of the forest10 mission alone, closed loop, its logged waypoints: every replan
+    solves, the plan starts at the current state, stays inside its corridors, and the agent gets somewhere."""
+    g, W, m = _mission()
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    plan = api.Plan(sol, wmap, 1, 0, _agents(api, W, 1), constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, closed_loop=True, z_2d=W["z_2d"])
+    start = np.array(W["starts"][0:1], dtype=np.float64)
+    plan.reset(start)
+    for k in range(40):
+        plan.put(api.PLAN_WAYPOINT, m["way"][k][0:1])
+        before = plan.get(api.PLAN_STATE).reshape(1, 9)
+        plan.step(graph=graph)
+        torch_cuda.cuda.synchronize()
+        assert plan.get(api.PLAN_STATUS)[0] == 0 and plan.get(api.PLAN_GOAL_STATUS)[0] == 0, k
+        assert plan.get(api.PLAN_VALID)[0] == 1 and plan.get(api.PLAN_IN_RANGE)[0] == 0
+        x = plan.get(api.PLAN_PLAN).reshape(2, 10, 6)
+        assert np.abs(x[:, 0, 0] - before[0, :2]).max() < 1e-6  # (float32 truncation of the plan)
+        box = plan.get(api.PLAN_SFC)
+        for mseg in range(10):
+            assert (x[:, mseg, :] >= box["bmin"][mseg][:2, None] - 1e-6).all() and (x[:, mseg, :] <= box["bmax"][mseg][:2, None] + 1e-6).all()
+    moved = np.linalg.norm(plan.get(api.PLAN_STATE).reshape(1, 9)[0, :2] - start[0, :2])
+    assert moved > 2.0, moved
+    plan.close()
+
+
 def _agents(api, W, N):
     ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
     ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
