@@ -279,6 +279,79 @@ def test_plan_of_a_single_agent_without_neighbour_slots(api, torch_cuda, graph):
     plan.close()
 
 
+def _world_3d(n_agents=12):
+    """An 8 x 8 x 4 m room with six boxes (two of them floating), agents on a tilted ring swapping sides: start / goal pairs antipodal."""
+    ang = np.linspace(0, 2 * np.pi, n_agents, endpoint=False)
+    starts = np.c_[3.0 * np.cos(ang), 3.0 * np.sin(ang), 2.0 + 0.8 * np.sin(2 * ang)]
+    starts = np.round(starts * 4) / 4
+    goals = np.c_[-starts[:, 0], -starts[:, 1], 4.0 - starts[:, 2]]
+    boxes = [[0.0, 0.0, 1.0, 0.6, 0.6, 2.0], [1.5, -1.0, 2.75, 0.5, 0.5, 1.5], [-1.5, 1.25, 0.75, 0.5, 0.5, 1.5], [0.0, 2.0, 2.0, 0.8, 0.4, 0.6],
+             [0.5, -2.25, 2.5, 0.4, 0.8, 0.5], [-2.0, -0.5, 2.0, 0.4, 0.4, 4.0]]
+    return dict(boxes=boxes, world_min=[-4.0, -4.0, 0.0], world_max=[4.0, 4.0, 4.0], resolution=0.1, max_dist=1.0, radius=0.15,
+                starts=starts, goals=goals)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["LSC", "BVC"])
+def test_plan_chain_in_three_dimensions_with_static_goals(api, oracle, torch_cuda, mode):
+    """The chain at BASELINE configs[1]'s class -- M = 5, three dimensions, downwash 2 -- in the modes the forest10 replay does not
+    touch: generateLSC (mode/planner dlsc) resp. generateBVC with prediction and initial trajectory from the current position
+    (mode/planner bvc), corridors from constructSFCFromPoint, static goal points (no goal LP), every agent every other's neighbour.
+    Twelve agents swap sides of a room with six boxes, 45 replans in closed loop through the captured graph: every QP solves and is
+    valid, nobody comes closer than the downwash ellipsoids allow (safety ratio >= 1 up to the float32 truncation of the plans) and
+    no limit is exceeded, the agents make way; and three replans are re-solved by the CPU oracle from the chain's own header, row and
+    corridor buffers at the QP's parity bar."""
+    W = _world_3d()
+    N, M = len(W["starts"]), 5
+    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    kw = dict(constraint_mode=api.GEN_LSC) if mode == "LSC" else dict(constraint_mode=api.GEN_BVC, prediction_mode=api.TRAJ_FROM_POSITION,
+                                                                       initial_traj_mode=api.TRAJ_FROM_POSITION)
+    plan = api.Plan(sol, wmap, N, N - 1, _agents(api, W, N), sfc_mode=api.SFC_FROM_POINT, optimize_goal=False, closed_loop=True,
+                    safety_samples=2, record_time_step=0.1, **kw)
+    plan.reset(W["starts"], W["goals"])
+    cls = oracle.make_class(M=M, dim=3, use_sfc=True, comm_range=0.0, world_min=W["world_min"], world_max=W["world_max"])
+    worst_ratio, failed = 1e9, 0
+    for k in range(45):
+        plan.step(graph=True)
+        torch_cuda.cuda.synchronize()
+        st = plan.get(api.PLAN_STATUS)
+        failed += int((st != 0).sum())
+        assert (plan.get(api.PLAN_VALID)[st == 0] == 1).all(), k
+        assert (plan.get(api.PLAN_IN_RANGE) == N - 1).all()
+        S = plan.get(api.PLAN_SAFETY)
+        worst_ratio = min(worst_ratio, float(S["safety_ratio"].min()))
+        # (the figures are taken on the float32 plans: a 2e-7 m rounding of a control point is 20 / dt^2 = 500 times that in acceleration)
+        assert S["vel_excess_ratio"].max() <= 1e-5 and S["acc_excess_ratio"].max() <= 2e-4, k
+        if k in (3, 15, 30):
+            hdr, rows, sfc = plan.get(api.PLAN_HEADER), plan.get(api.PLAN_ROWS).reshape(N, N - 1, M, 6), plan.get(api.PLAN_SFC).reshape(N, M)
+            x, obj, info = plan.get(api.PLAN_PLAN).reshape(N, -1), plan.get(api.PLAN_OBJECTIVE), plan.get(api.PLAN_INFO)
+            for q in range(N):
+                if st[q] != 0:
+                    continue
+                ag = oracle.make_agent(p0=hdr["p0"][q], v0=hdr["v0"][q], a0=hdr["a0"][q], goal=hdr["goal"][q], next_waypoint=hdr["next_waypoint"][q],
+                                       vmax=hdr["vmax"][q], amax=hdr["amax"][q], radius=hdr["radius"][q], nominal_velocity=hdr["nominal_velocity"][q],
+                                       n_obs=N - 1)
+                lsc = np.zeros((N - 1, M, 6), oracle.LSC_DTYPE)
+                lsc["nrm"][..., 0], lsc["nrm"][..., 1], lsc["nrm"][..., 2], lsc["d"] = rows["nx"][q], rows["ny"][q], rows["nz"][q], rows["b"][q]
+                box = np.zeros(M, oracle.BOX_DTYPE)
+                box["bmin"], box["bmax"] = sfc["bmin"][q], sfc["bmax"][q]
+                o = oracle.solve(cls, ag, lsc, box)
+                assert o["status"] == 0, (k, q)
+                assert abs(o["obj"] - obj[q]) <= 1e-8 * max(1.0, abs(o["obj"])), (k, q, o["obj"], obj[q])
+                # (a point accepted by the fallback rule -- flagged; the objective bar holds, its stationarity is 1e-7 instead of 1e-8
+                # relative -- may sit some 1e-5 m along a flat direction: BVC cells leave the z axis of a blocked agent almost free)
+                floor = bool(info["flags"][q] & api.INFO_FLOOR_ACCEPTED)
+                assert np.abs(o["x"] - x[q]).max() <= (5e-5 if floor else 2e-6), (k, q, floor)
+    assert failed == 0, failed
+    assert worst_ratio >= 1.0 - 5e-6, worst_ratio
+    state = plan.get(api.PLAN_STATE).reshape(N, 9)
+    progress = np.linalg.norm(W["goals"] - W["starts"], axis=1) - np.linalg.norm(W["goals"] - state[:, :3], axis=1)
+    assert progress.mean() > 1.5, progress
+    assert plan.graph_nodes() >= 8
+    plan.close()
+
+
 def _agents(api, W, N):
     ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
     ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = W["radius"], 2.0, 1.0, 2.0, 1.0
