@@ -292,7 +292,7 @@ def _world_3d(n_agents=12):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["LSC", "BVC"])
+@pytest.mark.parametrize("mode", ["LSC", "BVC", "LSC-nomap"])
 def test_plan_chain_in_three_dimensions_with_static_goals(api, oracle, torch_cuda, mode):
     """The chain at BASELINE configs[1]'s class -- M = 5, three dimensions, downwash 2 -- in the modes the forest10 replay does not
     touch: generateLSC (mode/planner dlsc) resp. generateBVC with prediction and initial trajectory from the current position
@@ -303,14 +303,15 @@ def test_plan_chain_in_three_dimensions_with_static_goals(api, oracle, torch_cud
     corridor buffers at the QP's parity bar."""
     W = _world_3d()
     N, M = len(W["starts"]), 5
-    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, world_min=W["world_min"], world_max=W["world_max"]))
-    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
-    kw = dict(constraint_mode=api.GEN_LSC) if mode == "LSC" else dict(constraint_mode=api.GEN_BVC, prediction_mode=api.TRAJ_FROM_POSITION,
+    corridors = mode != "LSC-nomap"  # (world/use_octomap = false: no map, no corridor rows -- the class is built with use_sfc = 0)
+    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, use_sfc=corridors, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"]) if corridors else None
+    kw = dict(constraint_mode=api.GEN_LSC) if mode != "BVC" else dict(constraint_mode=api.GEN_BVC, prediction_mode=api.TRAJ_FROM_POSITION,
                                                                        initial_traj_mode=api.TRAJ_FROM_POSITION)
     plan = api.Plan(sol, wmap, N, N - 1, _agents(api, W, N), sfc_mode=api.SFC_FROM_POINT, optimize_goal=False, closed_loop=True,
                     safety_samples=2, record_time_step=0.1, **kw)
     plan.reset(W["starts"], W["goals"])
-    cls = oracle.make_class(M=M, dim=3, use_sfc=True, comm_range=0.0, world_min=W["world_min"], world_max=W["world_max"])
+    cls = oracle.make_class(M=M, dim=3, use_sfc=corridors, comm_range=0.0, world_min=W["world_min"], world_max=W["world_max"])
     worst_ratio, failed = 1e9, 0
     for k in range(45):
         plan.step(graph=True)
