@@ -279,6 +279,55 @@ def test_plan_of_a_single_agent_without_neighbour_slots(api, torch_cuda, graph):
     plan.close()
 
 
+@pytest.mark.gpu
+def test_plan_chain_with_512_agents(api, torch_cuda):
+    """The chain at the agent count of BASELINE configs[2]: 512 agents on a ring of 49 m radius (0.6 m apart: about ten of them within
+    the 3 m communication range of each) around a synthetic forest of 600 pillars, M = 10, 2-D, 20 neighbour slots, safety figures on.
+    Ten replans through the captured graph, every agent heading for the opposite side: every QP solves and is valid, no neighbour list
+    is cut, nobody comes closer than the radii allow, the graph replays what the eager chain does (plans bit for bit)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import closed_loop
+
+    N = 512
+    W = closed_loop.random_forest_world(N, side=110.0, n_boxes=600, seed=3)
+    starts = np.array(W["starts"], dtype=np.float64)
+    assert np.unique(starts, axis=0).shape[0] == N  # (the 0.5 m snap of the ring leaves them apart)
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    plans = [api.Plan(sol, wmap, N, 20, _agents(api, W, N), constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, closed_loop=True,
+                      z_2d=W["z_2d"], safety_samples=2, record_time_step=0.1) for _ in range(2)]
+    goals = np.array(W["goals"], dtype=np.float64)
+    way = starts + 0.5 * (goals - starts) / np.linalg.norm(goals - starts, axis=1, keepdims=True)  # half a metre inwards: what a router hands out
+    way[:, 2] = W["z_2d"]
+    for p in plans:
+        p.reset(starts)
+    worst = 1e9
+    for k in range(10):
+        for graph, p in zip((False, True), plans):
+            p.put(api.PLAN_WAYPOINT, np.float32(way).astype(np.float64))
+            p.step(graph=graph)
+        torch_cuda.cuda.synchronize()
+        e, gph = plans
+        assert np.array_equal(e.get(api.PLAN_PLAN), gph.get(api.PLAN_PLAN)), k
+        st = gph.get(api.PLAN_STATUS)
+        assert (st == 0).all(), (k, np.bincount(st))
+        assert (gph.get(api.PLAN_VALID) == 1).all() and (gph.get(api.PLAN_GOAL_STATUS) == 0).all()
+        cnt = gph.get(api.PLAN_IN_RANGE)
+        assert cnt.max() <= 20 and cnt.min() >= 4, (cnt.min(), cnt.max())
+        worst = min(worst, float(gph.get(api.PLAN_SAFETY)["safety_ratio"].min()))
+        state = gph.get(api.PLAN_STATE).reshape(N, 9)
+        step_in = np.abs(state[:, :2] - way[:, :2]).max(axis=1) < 0.3
+        way[step_in, :2] += 0.5 * (goals[step_in, :2] - way[step_in, :2]) / np.linalg.norm(goals[step_in, :2] - way[step_in, :2], axis=1, keepdims=True)
+    assert worst >= 1.0 - 5e-6, worst
+    moved = np.linalg.norm(plans[1].get(api.PLAN_STATE).reshape(N, 9)[:, :2] - starts[:, :2], axis=1)
+    assert moved.mean() > 0.5, moved.mean()
+    assert plans[1].graph_nodes() >= 8
+    for p in plans:
+        p.close()
+
+
 def _world_3d(n_agents=12):
     """An 8 x 8 x 4 m room with six boxes (two of them floating), agents on a tilted ring swapping sides: start / goal pairs antipodal."""
     ang = np.linspace(0, 2 * np.pi, n_agents, endpoint=False)
