@@ -236,6 +236,58 @@ def replan_chain(torch, api, replans=60):
     res["graph_nodes"] = plan.graph_nodes()
     plan.close()
     wmap.close()
+    res["c1_class"] = replan_chain_3d(torch, api)
+    return res
+
+
+def replan_chain_3d(torch, api, N=64, replans=30, radii=(10.0, 10.0, 4.0)):
+    """The same chain at configs[1]'s class, in the reference's default modes: 64 agents x M = 5 in three dimensions (downwash 2), 20
+    neighbour slots, CLSC rows, corridors from the convex hull over a room with 24 boxes, goal LP -- agents on a sphere swapping sides,
+    closed loop through the captured graph.  The host plays the router (a waypoint 0.75 m ahead on the straight line to the goal,
+    written before every replan); the time is the step's alone (launch to completion), the first 12 replans fly untimed."""
+    import time
+
+    rng = np.random.default_rng(7)
+    i = np.arange(N) + 0.5
+    phi, th = np.arccos(1 - 2 * i / N), np.pi * (1 + 5 ** 0.5) * i  # Fibonacci lattice
+    starts = np.round((np.c_[np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)] * list(radii) + [0, 0, radii[2] + 1.0]) * 4) / 4
+    goals = np.c_[-starts[:, 0], -starts[:, 1], 2 * (radii[2] + 1.0) - starts[:, 2]]
+    boxes = []
+    while len(boxes) < 24:
+        c = np.r_[rng.uniform(-0.7 * radii[0], 0.7 * radii[0], 2), rng.uniform(1.5, 2 * radii[2] + 0.5)]
+        if np.abs(starts - c).max(axis=1).min() > 1.2:
+            boxes.append([c[0], c[1], c[2], 0.8, 0.8, 0.8])
+    wmin, wmax = [-radii[0] - 2.0, -radii[1] - 2.0, 0.0], [radii[0] + 2.0, radii[1] + 2.0, 2 * radii[2] + 2.0]
+    sol = api.Solver(api.make_desc(M=5, dim=3, dt=0.2, world_min=wmin, world_max=wmax))
+    wmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = 0.15, 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, 20, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, optimize_goal=True, closed_loop=True)
+    plan.reset(starts)
+    t_dev, failed, cut, it_sum, it_max = 0.0, 0, 0, 0.0, 0
+    for k in range(12 + replans):
+        pos = plan.get(api.PLAN_STATE).reshape(N, 9)[:, :3]
+        d = goals - pos
+        dist = np.linalg.norm(d, axis=1, keepdims=True)
+        way = pos + d / np.maximum(dist, 1e-9) * np.minimum(dist, 0.75)
+        plan.put(api.PLAN_WAYPOINT, np.float32(way).astype(np.float64))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan.step(graph=True)
+        torch.cuda.synchronize()
+        if k >= 12:
+            t_dev += time.perf_counter() - t0
+            info = plan.get(api.PLAN_INFO)
+            failed += int((plan.get(api.PLAN_STATUS) != 0).sum())
+            cut += int((plan.get(api.PLAN_IN_RANGE) > 20).sum())
+            it_sum += float(info["iterations"].mean())
+            it_max = max(it_max, int(info["iterations"].max()))
+    moved = float(np.linalg.norm(plan.get(api.PLAN_STATE).reshape(N, 9)[:, :3] - starts, axis=1).mean())
+    res = {"workload": "64 agents x M5 x 20 neighbour slots in 3-D: CLSC rows + corridors + goal LP + QP per replan, hipGraph, waypoints from the host",
+           "replans": replans, "us_per_replan": t_dev / replans * 1e6, "failed_qps": failed, "cut_neighbour_lists": cut,
+           "iters_mean": it_sum / replans, "iters_max": it_max, "mean_distance_flown_m": moved}
+    plan.close()
+    wmap.close()
     return res
 
 

@@ -520,6 +520,12 @@ int lscqp_map_create(const double* boxes, int64_t n_boxes, const double* world_m
 int lscqp_map_create_from_csv(const char* path, const double* world_min, const double* world_max, double resolution,
                               double max_dist, lscqp_map* out);
 void lscqp_map_destroy(lscqp_map map);
+/* Optional acceleration of the corridor construction, once per map (set-up time: not concurrently with corridor launches on the map):
+ * a summed-area table over the cells that could make an isObstacleInSFC test fail for an agent of radius <= max_radius.  A box of
+ * sample points whose cell range holds none of them passes its test without a single point being evaluated -- in open space that
+ * is every test of expandSFC, the whole-box re-tests included; all other boxes are evaluated exactly as without the table, so the
+ * corridors are the same bit for bit.  4 bytes per map cell.  lscqp_plan_create calls it with the largest radius of its agents. */
+int lscqp_map_prepare(lscqp_map map, double max_radius);
 int lscqp_map_info(lscqp_map map, int32_t* dims, int32_t* key0);
 int lscqp_map_download(lscqp_map map, uint8_t* occ, int32_t* nearest);
 int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map map, int32_t mode, int64_t n, const double* d_points,

@@ -204,7 +204,7 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_shift_traj_partial_device", "lscqp_generate_constraints_device_ex",
                     "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
-                    "lscqp_map_download", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
+                    "lscqp_map_download", "lscqp_map_prepare", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_plan_create", "lscqp_plan_destroy", "lscqp_plan_reset", "lscqp_plan_buffer", "lscqp_plan_upload", "lscqp_plan_download",
                     "lscqp_plan_step", "lscqp_plan_step_graph", "lscqp_plan_graph_nodes", "lscqp_plan_group_step",
                     "lscqp_last_error", "lscqp_version"]
@@ -256,6 +256,14 @@ class WorldMap:
         dims, key0 = np.zeros(3, np.int32), np.zeros(3, np.int32)
         lib().lscqp_map_info(self._h, dims.ctypes.data_as(C.c_void_p), key0.ctypes.data_as(C.c_void_p))
         self.dims, self.key0 = dims, key0
+
+    def prepare(self, max_radius):
+        """lscqp_map_prepare: the free-space table that lets the corridor kernel pass tests in open space without sampling."""
+        lib().lscqp_map_prepare.restype = C.c_int
+        lib().lscqp_map_prepare.argtypes = [C.c_void_p, C.c_double]
+        rc = lib().lscqp_map_prepare(self._h, float(max_radius))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     def download(self):
         """(occ uint8, nearest int32), both shaped (dims[2], dims[1], dims[0])."""

@@ -334,6 +334,14 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
                                 "safety_samples needs every agent's new plan on this device (n_agents == n_total) and record_time_step > 0");
     if (lscqp_row_bytes(h) != (int)sizeof(lscqp_row))
         return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "the plan chain uses 32-byte rows (row_format = LSCQP_ROWS_F64)");
+    if (map) {  // the corridor kernel's free-space table for the agents of this mission (no-op if the map already has one that serves them)
+        double rmax = 0;
+        for (int64_t i = 0; i < desc->n_total; i++) rmax = agents[i].radius > rmax ? agents[i].radius : rmax;
+        if (rmax > 0) {
+            const int rc = lscqp_map_prepare(map, rmax);
+            if (rc != LSCQP_OK) return rc;
+        }
+    }
     lscqp_plan_s* p = new lscqp_plan_s();
     p->h = h;
     p->hq = h;

@@ -43,6 +43,8 @@ struct lscqp_map_s {
     int radius_cells;
     uint8_t* d_occ;
     int32_t* d_nearest;
+    int32_t* d_sat = nullptr;  // lscqp_map_prepare: summed-area table of the cells that are NOT provably free for agents up to sat_margin
+    double sat_margin = 0;
     // staging of the host-pointer corridor call: a pinned buffer + device mirror + private stream per concurrent call (the map
     // handle is shared by all agents' CollisionConstraints: two threads must never share a staging buffer)
     lscqp::StagePool* pool = nullptr;
@@ -58,6 +60,8 @@ struct MapView {
     float wmin0, wmin1, wmin2, wmax0, wmax1, wmax2;
     int key00, key01, key02, dims0, dims1, dims2;
     const int32_t* nearest;
+    const int32_t* sat;  // (NULL: lscqp_map_prepare was not called)
+    double sat_margin;
     __host__ __device__ __forceinline__ float world_min(int k) const { return k == 0 ? wmin0 : (k == 1 ? wmin1 : wmin2); }
     __host__ __device__ __forceinline__ float world_max(int k) const { return k == 0 ? wmax0 : (k == 1 ? wmax1 : wmax2); }
     __host__ __device__ __forceinline__ int key0(int k) const { return k == 0 ? key00 : (k == 1 ? key01 : key02); }
@@ -84,6 +88,57 @@ __global__ void rasterise_kernel(const double* __restrict__ boxes, double res, i
         const int x = lo[0] + (int)(t % ex) - kx0, y = lo[1] + (int)((t / ex) % ey) - ky0, z = lo[2] + (int)(t / ((int64_t)ex * ey)) - kz0;
         if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
         occ[((int64_t)z * ny + y) * nx + x] = 1;
+    }
+}
+
+// ---- "provably free" summary of the map (lscqp_map_prepare) ------------------------------------------------------------------
+// A test of the expansion (isObstacleInSFC, reference src/collision_constraints.cpp:779-808) asks whether ANY sample point of a box
+// lies within margin of the nearest occupied cell of the cell it falls into.  For a cell v, every sample p that maps to v lies in
+// v's closed interval per axis (p -> key is a floor), so its distance to the box of the nearest occupied cell v + off is at least
+// (max_k |off_k| - 1) res; without an occupied cell within max_dist the reference measures against a cell at the world origin
+// (:796-800), at least the gap between v's interval and [-res/2, res/2] away.  A cell whose bound exceeds margin + 1e-5 by more than
+// 1e-4 (float rounding of the sample, the centre and the half cell: a few 1e-5 at 100 m) can not make any test fail.  The table holds
+// the 3-D inclusive prefix sums of the OTHER cells: a box whose samples all fall into the map and whose cell range sums to zero
+// passes without a single sample being evaluated -- in open space that is every test, whole-box re-tests of a million points
+// included; every other box goes through the exact evaluation as before, so the boxes stay bit for bit the reference's.
+__global__ void classify_free_kernel(int nx, int ny, int nz, int kx0, int ky0, int kz0, double res, double margin, const int32_t* __restrict__ nearest,
+                                     int32_t* __restrict__ notfree) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    if (v >= nvox) return;
+    const int x = (int)(v % nx), y = (int)((v / nx) % ny), z = (int)(v / ((int64_t)nx * ny));
+    const int code = nearest[v];
+    const double need = margin + 1e-5 + 1e-4;
+    double bound;
+    if ((code >> 24) != 0) {
+        int mo = 0;
+        for (int k = 0; k < 3; k++) {
+            const int off = ((code >> (8 * k)) & 255) - 128;
+            const int ao = off < 0 ? -off : off;
+            mo = ao > mo ? ao : mo;
+        }
+        bound = (double)(mo - 1) * res;
+    } else {
+        const int key[3] = {x + kx0, y + ky0, z + kz0};
+        bound = 0;
+        for (int k = 0; k < 3; k++) {
+            const double a = (double)key[k] * res, b = (double)(key[k] + 1) * res;  // the cell's interval
+            const double gap = a - 0.5 * res > 0 ? a - 0.5 * res : (-0.5 * res - b > 0 ? -0.5 * res - b : 0.0);
+            bound = gap > bound ? gap : bound;
+        }
+    }
+    notfree[v] = bound >= need ? 0 : 1;
+}
+
+// inclusive prefix sums along one axis: a thread per line (stride: elements between neighbours of the line)
+__global__ void prefix_axis_kernel(int64_t n_lines, int len, int64_t stride, int64_t line_a, int64_t mul_a, int64_t mul_b, int32_t* __restrict__ t) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lines) return;
+    int32_t* p = t + (l % line_a) * mul_a + (l / line_a) * mul_b;
+    int32_t run = 0;
+    for (int i = 0; i < len; i++) {
+        run += p[(int64_t)i * stride];
+        p[(int64_t)i * stride] = run;
     }
 }
 
@@ -169,6 +224,36 @@ struct BoxF {
     float lo[3], hi[3];
 };
 
+// true: none of the map cells [x0, x1] x [y0, y1] x [z0, z1] (inside the map) can make a test fail (lscqp_map_prepare's table)
+__device__ __forceinline__ bool cells_free(const MapView& mp, int x0, int x1, int y0, int y1, int z0, int z1) {
+    const int64_t sy = mp.dims(0), sz = (int64_t)mp.dims(0) * mp.dims(1);
+    auto at = [&](int x, int y, int z) -> int64_t {  // prefix sum up to (x, y, z) inclusive; -1 on any axis: empty
+        return (x < 0 || y < 0 || z < 0) ? 0 : (int64_t)mp.sat[x + y * sy + z * sz];
+    };
+    const int xa = x0 - 1, ya = y0 - 1, za = z0 - 1;
+    const int64_t cnt = at(x1, y1, z1) - at(xa, y1, z1) - at(x1, ya, z1) - at(x1, y1, za) + at(xa, ya, z1) + at(xa, y1, za) + at(x1, ya, za) - at(xa, ya, za);
+    return cnt == 0;
+}
+
+// true: no sample point of the box (n[k] points from lo[k] in steps of res) can be within margin of an obstacle -- see lscqp_map_prepare
+__device__ __forceinline__ bool surely_free(const MapView& mp, double margin, float lo0, float lo1, float lo2, int n0, int n1, int n2) {
+    if (mp.sat == nullptr || !(margin <= mp.sat_margin)) return false;
+    const double res = mp.res;
+    int a[3], b[3];
+    const float lo[3] = {lo0, lo1, lo2};
+    const int n[3] = {n0, n1, n2};
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float pf = lo[k], pl = (float)((double)lo[k] + (double)(n[k] - 1) * res);  // first and last sample, as the tests form them
+        a[k] = key_of((double)pf, res) - mp.key0(k);
+        b[k] = key_of((double)pl, res) - mp.key0(k);
+        inside = inside && a[k] >= 0 && b[k] < mp.dims(k) && a[k] <= b[k];
+    }
+    if (!inside) return false;  // (a sample outside the distance map is measured against the origin cell: the exact path handles it)
+    return cells_free(mp, a[0], b[0], a[1], b[1], a[2], b[2]);
+}
+
 // isObstacleInSFC (:777-808): the block's lanes take the sample points of the box in turn and vote
 __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
     const double res = mp.res;
@@ -177,6 +262,7 @@ __device__ bool obstacle_in(const MapView& mp, const BoxF& b, double margin) {
     for (int k = 0; k < 3; k++) n[k] = (int)floor(((double)(b.hi[k] - b.lo[k]) + 1e-5) / res) + 1;
     // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
     const int64_t total = (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) ? 0 : (int64_t)n[0] * n[1] * n[2];
+    if (total > 0 && surely_free(mp, margin, b.lo[0], b.lo[1], b.lo[2], n[0], n[1], n[2])) return false;  // (block-uniform)
     const int lane = threadIdx.x;
     // kU chunks of 64 points per vote: the kU nearest-cell loads of a lane are independent and in flight together, which is
     // what bounds a large slab (the loop is a chain of dependent HBM / L2 reads otherwise)
@@ -329,7 +415,10 @@ __device__ unsigned long long sfc_dbg[16];
 #define LSCSFC_GROUP 4
 #endif
 #ifndef LSCSFC_AHEAD
-#define LSCSFC_AHEAD 12
+#define LSCSFC_AHEAD 31  // boxes of a batch (<= 31: the growth counts of a batch are packed in 5-bit fields)
+#endif
+#ifndef LSCSFC_SAMPLED
+#define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing)
 #endif
 constexpr int kAhead = LSCSFC_AHEAD;
 constexpr int kTab = 3072;    // entries of the per-(box, axis) tables of a batch
@@ -395,9 +484,9 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
         const int idx = base + lane;
         const int chunk = __builtin_amdgcn_readfirstlane(idx >> 6);  // wave-uniform: boxes are padded to whole wavefronts
         if (chunk >= A.first[J]) continue;
-        int j = 0;
-        for (int t = 1; t < kAhead; t++) j += (t < J && chunk >= A.first[t]) ? 1 : 0;
-        j = __builtin_amdgcn_readfirstlane(j);
+        // the box this chunk belongs to: lane t asks "does box t + 1 start at or before it" (one LDS read per lane instead of a scan)
+        const int lt = lane & 63;
+        const int j = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lt + 1 < J && chunk >= A.first[lt + 1 < kAhead ? lt + 1 : kAhead]));
         if (j > stop) continue;
         const int ax = __builtin_amdgcn_readfirstlane(A.axes[j]);
         const int la = ax & 3, ca = (ax >> 2) & 3, cb = (ax >> 4) & 3;
@@ -410,7 +499,28 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
         int ia = cc - ib * na;
         if (ia < 0) ib--, ia += na;
         if (ia >= na) ib++, ia -= na;
-        const int ea = A.tab[j][ca] + ia, eb = A.tab[j][cb] + ib, el = __builtin_amdgcn_readfirstlane(A.tab[j][la]);
+        const int el = __builtin_amdgcn_readfirstlane(A.tab[j][la]);
+        if (nl >= 8 && mp.sat != nullptr && margin <= mp.sat_margin) {
+            // the 64 columns of this chunk with a long thin axis (a slab of a large 3-D box: 64 x nl samples; for the one-sample columns
+            // of a layer the table's eight reads cost more than the sample's one -- measured): if the cells they run
+            // through are provably free there is nothing to evaluate.  Wave-uniform: the chunk's columns span the rows ib0 .. ib1 of
+            // the slow axis -- one row: the fast range it covers, several: the whole fast range (conservative).
+            const int c0 = (chunk - A.first[j]) * 64, cl = A.cols[j] - 1;
+            const int c1 = c0 + 63 < cl ? c0 + 63 : cl;
+            const int ib0 = c0 / na, ib1 = c1 / na;
+            const int ia0 = ib0 == ib1 ? c0 - ib0 * na : 0, ia1 = ib0 == ib1 ? c1 - ib1 * na : na - 1;
+            const int ta = A.tab[j][ca], tb = A.tab[j][cb];
+            const int va0 = A.vtab[ta + ia0], va1 = A.vtab[ta + ia1], vb0 = A.vtab[tb + ib0], vb1 = A.vtab[tb + ib1];
+            const int vl0 = A.vtab[el], vl1 = A.vtab[el + nl - 1];
+            if (va0 >= 0 && va1 >= va0 && vb0 >= 0 && vb1 >= vb0 && vl0 >= 0 && vl1 >= vl0) {  // (-1: a sample outside the map)
+                // (ca, cb, la) is a permutation of (x, y, z)
+                const int x0 = ca == 0 ? va0 : (cb == 0 ? vb0 : vl0), x1 = ca == 0 ? va1 : (cb == 0 ? vb1 : vl1);
+                const int y0 = ca == 1 ? va0 : (cb == 1 ? vb0 : vl0), y1 = ca == 1 ? va1 : (cb == 1 ? vb1 : vl1);
+                const int z0 = ca == 2 ? va0 : (cb == 2 ? vb0 : vl0), z1 = ca == 2 ? va1 : (cb == 2 ? vb1 : vl1);
+                if (__builtin_amdgcn_readfirstlane((int)cells_free(mp, x0, x1, y0, y1, z0, z1))) continue;
+            }
+        }
+        const int ea = A.tab[j][ca] + ia, eb = A.tab[j][cb] + ib;
         const float pa = A.ptab[ea], pb = A.ptab[eb];
         const int va = A.vtab[ea], vb = A.vtab[eb];
         const bool inab = live && va >= 0 && vb >= 0;
@@ -533,7 +643,9 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 int n[3];
                 for (int k = 0; k < 3; k++) n[k] = (int)floor_div((double)(u.hi[k] - u.lo[k]) + 1e-5, res, rinv) + 1;
                 // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
-                const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
+                bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
+                // a box the map's summary proves free passes like an empty one: no table entries, no columns (lscqp_map_prepare)
+                empty = empty || (mine && inb && surely_free(mp, margin, u.lo[0], u.lo[1], u.lo[2], n[0], n[1], n[2]));
                 // thin axis: the columns run along it (ties: the later axis, so that x stays a column axis)
                 const int la = (n[2] <= n[1] && n[2] <= n[0]) ? 2 : (n[1] <= n[0] ? 1 : 0);
                 const int ca = la == 0 ? 1 : 0, cb = la == 2 ? 1 : 2;
@@ -553,7 +665,14 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 const unsigned long long mstop = __builtin_amdgcn_ballot_w64(mine && !inb);
                 const unsigned long long mbrk = __builtin_amdgcn_ballot_w64(mine && (over || (int64_t)ec * 64 + ncol > (1 << 22) || eu + need > kTab));
                 const int jstop_ = mstop ? __builtin_ctzll(mstop) : kAhead, jbrk = mbrk ? __builtin_ctzll(mbrk) : kAhead;
-                const int J_ = tables ? (jstop_ < jbrk ? jstop_ : jbrk) : 0;
+                // ... or behind the LSCSFC_SAMPLED-th box that has to be sampled: tests behind the first failure are wasted work, boxes
+                // the free-space table passes are not
+                const unsigned long long msamp = __builtin_amdgcn_ballot_w64(mine && ncol > 0);
+                const int before = __builtin_popcountll(msamp & ((1ull << j) - 1ull));
+                const unsigned long long mcap = __builtin_amdgcn_ballot_w64(mine && before >= LSCSFC_SAMPLED);
+                const int jcap = mcap ? __builtin_ctzll(mcap) : kAhead;
+                const int jlim = jbrk < jcap ? jbrk : jcap;
+                const int J_ = tables ? (jstop_ < jlim ? jstop_ : jlim) : 0;
                 const bool alone_ = !tables || (jbrk == 0 && jstop_ > 0);
                 if (mine && j < J_) {
                     for (int k = 0; k < 3; k++) {
@@ -874,8 +993,38 @@ void lscqp_map_destroy(lscqp_map mp) {
     if (!mp) return;
     if (mp->d_occ) (void)hipFree(mp->d_occ);
     if (mp->d_nearest) (void)hipFree(mp->d_nearest);
+    if (mp->d_sat) (void)hipFree(mp->d_sat);
     delete mp->pool;
     delete mp;
+}
+
+int lscqp_map_prepare(lscqp_map mp, double max_radius) {
+    if (!mp) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null map");
+    if (!(max_radius > 0)) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "max_radius > 0 required");
+    if (mp->d_sat && mp->sat_margin >= max_radius) return LSCQP_OK;  // (a table built for a larger margin serves the smaller ones)
+    const int nx = mp->dims[0], ny = mp->dims[1], nz = mp->dims[2];
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    hipError_t e = hipDeviceSynchronize();  // (no corridor launch may be reading the old table)
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)).c_str());
+    if (!mp->d_sat && (e = hipMalloc(&mp->d_sat, nvox * sizeof(int32_t))) != hipSuccess) {
+        mp->d_sat = nullptr;
+        return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("hipMalloc(free-space table): ") + hipGetErrorString(e)).c_str());
+    }
+    mp->sat_margin = 0;
+    hipLaunchKernelGGL(lscsfc::classify_free_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, 0, nx, ny, nz, mp->key0[0], mp->key0[1], mp->key0[2],
+                       mp->res, max_radius, mp->d_nearest, mp->d_sat);
+    // x lines: one per (y, z); y lines: one per (x, z); z lines: one per (x, y)
+    const int64_t lx = (int64_t)ny * nz, ly = (int64_t)nx * nz, lz = (int64_t)nx * ny;
+    hipLaunchKernelGGL(lscsfc::prefix_axis_kernel, dim3((unsigned)((lx + 255) / 256)), dim3(256), 0, 0, lx, nx, (int64_t)1, lx, (int64_t)nx, (int64_t)0, mp->d_sat);
+    hipLaunchKernelGGL(lscsfc::prefix_axis_kernel, dim3((unsigned)((ly + 255) / 256)), dim3(256), 0, 0, ly, ny, (int64_t)nx, (int64_t)nx, (int64_t)1, (int64_t)nx * ny, mp->d_sat);
+    hipLaunchKernelGGL(lscsfc::prefix_axis_kernel, dim3((unsigned)((lz + 255) / 256)), dim3(256), 0, 0, lz, nz, (int64_t)nx * ny, lz, (int64_t)1, (int64_t)0, mp->d_sat);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        (void)hipFree(mp->d_sat);
+        mp->d_sat = nullptr;
+        return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("free-space table: ") + hipGetErrorString(e)).c_str());
+    }
+    mp->sat_margin = max_radius;
+    return LSCQP_OK;
 }
 
 int lscqp_map_info(lscqp_map mp, int32_t* dims, int32_t* key0) {
@@ -901,6 +1050,8 @@ int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const dou
     v.key00 = mp->key0[0], v.key01 = mp->key0[1], v.key02 = mp->key0[2];
     v.dims0 = mp->dims[0], v.dims1 = mp->dims[1], v.dims2 = mp->dims[2];
     v.nearest = mp->d_nearest;
+    v.sat = mp->d_sat;
+    v.sat_margin = mp->sat_margin;
     hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(lscsfc::kSfcThreads), 0, (hipStream_t)stream, v, mode, M, n, d_points, d_radius,
                        d_sfc, d_status_out);
     const hipError_t e = hipGetLastError();

@@ -171,8 +171,11 @@ def test_gpu_map_matches_oracle(api, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prepared", [0.0, 0.25, 0.15], ids=["plain", "free_space_table", "table_for_smaller_agents"])
 @pytest.mark.parametrize("world", ["forest10", "random3d", "sparse_origin"])
-def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world):
+def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world, prepared):
+    """`prepared` > 0: lscqp_map_prepare's free-space table is in place -- tests of boxes it proves free are passed without sampling
+    (for the agents whose radius it covers: 0.15 leaves the 0.25 m agents on the exact path), the corridors must not change by a bit."""
     import torch
 
     rng = np.random.default_rng(11)
@@ -195,6 +198,8 @@ def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world):
     radius = np.where(np.arange(n) % 7 == 0, 0.25, 0.15)
     omap = oracle.Map(boxes, wmin, wmax, 0.1, 1.0)
     gmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    if prepared > 0:
+        gmap.prepare(prepared)
     sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=wmin, world_max=wmax))
     dev = torch.device("cuda", 0)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731

@@ -18,6 +18,7 @@ for seed in range(12):
     boxes=np.concatenate([c,s],axis=1)
     res=float(rng.choice([0.1,0.1,0.2,0.05]))
     om=O.Map(boxes,wmin,wmax,res,1.0); gm=api.WorldMap(boxes,wmin,wmax,res,1.0)
+    if "--prepare" in sys.argv: gm.prepare(0.25 if seed%3 else 0.15)  # lscqp_map_prepare: the free-space table (0.15: the larger agents stay on the exact path)
     occ,near=gm.download()
     assert np.array_equal(occ,om.occ()) and np.array_equal(near,om.nearest()),("map",seed)
     n=200; M=5
