@@ -97,18 +97,18 @@ __global__ void rasterise_kernel(const double* __restrict__ boxes, double res, i
 // v's closed interval per axis (p -> key is a floor), so its distance to the box of the nearest occupied cell v + off is at least
 // (max_k |off_k| - 1) res; without an occupied cell within max_dist the reference measures against a cell at the world origin
 // (:796-800), at least the gap between v's interval and [-res/2, res/2] away.  A cell whose bound exceeds margin + 1e-5 by more than
-// 1e-4 (float rounding of the sample, the centre and the half cell: a few 1e-5 at 100 m) can not make any test fail.  The table holds
+// 1e-4 + 4 ulp of the world's size (float rounding of the sample, the centre and the half cell) can not make any test fail.  The table holds
 // the 3-D inclusive prefix sums of the OTHER cells: a box whose samples all fall into the map and whose cell range sums to zero
 // passes without a single sample being evaluated -- in open space that is every test, whole-box re-tests of a million points
 // included; every other box goes through the exact evaluation as before, so the boxes stay bit for bit the reference's.
-__global__ void classify_free_kernel(int nx, int ny, int nz, int kx0, int ky0, int kz0, double res, double margin, const int32_t* __restrict__ nearest,
-                                     int32_t* __restrict__ notfree) {
+__global__ void classify_free_kernel(int nx, int ny, int nz, int kx0, int ky0, int kz0, double res, double margin, double slop,
+                                     const int32_t* __restrict__ nearest, int32_t* __restrict__ notfree) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nvox = (int64_t)nx * ny * nz;
     if (v >= nvox) return;
     const int x = (int)(v % nx), y = (int)((v / nx) % ny), z = (int)(v / ((int64_t)nx * ny));
     const int code = nearest[v];
-    const double need = margin + 1e-5 + 1e-4;
+    const double need = margin + 1e-5 + slop;
     double bound;
     if ((code >> 24) != 0) {
         int mo = 0;
@@ -1011,8 +1011,13 @@ int lscqp_map_prepare(lscqp_map mp, double max_radius) {
         return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("hipMalloc(free-space table): ") + hipGetErrorString(e)).c_str());
     }
     mp->sat_margin = 0;
+    // what the float arithmetic of the exact test can lose against the cell bound: the sample, the cell centre and centre -+ half a cell
+    // are floats of the world's magnitude (half an ulp each; 7.6e-6 per ulp at 100 m)
+    double wabs = 0;
+    for (int k = 0; k < 3; k++) wabs = fmax(wabs, fmax(fabs((double)mp->world_min[k]), fabs((double)mp->world_max[k])) + 2.0 * mp->res);
+    const double slop = 1e-4 + 4.0 * wabs * 1.1920929e-7;
     hipLaunchKernelGGL(lscsfc::classify_free_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, 0, nx, ny, nz, mp->key0[0], mp->key0[1], mp->key0[2],
-                       mp->res, max_radius, mp->d_nearest, mp->d_sat);
+                       mp->res, max_radius, slop, mp->d_nearest, mp->d_sat);
     // x lines: one per (y, z); y lines: one per (x, z); z lines: one per (x, y)
     const int64_t lx = (int64_t)ny * nz, ly = (int64_t)nx * nz, lz = (int64_t)nx * ny;
     hipLaunchKernelGGL(lscsfc::prefix_axis_kernel, dim3((unsigned)((lx + 255) / 256)), dim3(256), 0, 0, lx, nx, (int64_t)1, lx, (int64_t)nx, (int64_t)0, mp->d_sat);
