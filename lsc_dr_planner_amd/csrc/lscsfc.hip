@@ -423,6 +423,7 @@ __device__ unsigned long long sfc_dbg[16];
 constexpr int kAhead = LSCSFC_AHEAD;
 constexpr int kTab = 3072;    // entries of the per-(box, axis) tables of a batch
 constexpr int kCell = 1024;   // largest map extent (cells per axis) with the cell-centre table in LDS
+constexpr int kTodo = 8192;   // chunks of a batch the filter pass can list
 struct Ahead {
     float lo[kAhead][3];    // minimum corner of box j
     int n[kAhead][3];
@@ -433,6 +434,8 @@ struct Ahead {
     int cols[kAhead];       // columns of box j
     int first[kAhead + 1];  // prefix sums of the boxes' column counts, in wavefronts (64 columns)
     int fail;               // first failing test of the batch (kAhead: none)
+    int ntodo;              // chunks the free-space table could not clear (the filter pass of obstacle_in_batch)
+    int todo[kTodo];
     float ptab[kTab + 4];   // search_point(k) = box_min(k) + iter * res                      (:786-790)
     int vtab[kTab + 4];     // its map index, -1 outside the distance map                      (worldToMap)
     float ctab[3][kCell];   // centre of map cell v along axis k: keyToCoord, (key + 0.5) res as float
@@ -479,11 +482,46 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
     const double thr = margin + 1e-5;
     // (selected, not indexed: an indexed array of kernel arguments is copied to scratch memory)
     auto stride = [&](int k) -> int64_t { return k == 0 ? 1 : (k == 1 ? (int64_t)mp.dims(0) : (int64_t)mp.dims(0) * mp.dims(1)); };
-    for (int base = 0; base < total; base += kSfcThreads) {
+    // Filter pass (with the free-space table): every 64-column chunk of the batch is asked ONCE, by one lane, whether the cells its
+    // columns run through are provably free -- eight reads of the table instead of 64 x nl samples; what is left over (the chunks next
+    // to obstacles: a few per cent of a layer of a large box) is listed and only that is evaluated.  The list's order does not matter:
+    // the verdict is a minimum over the failing boxes.
+    const int all_chunks = A.first[J];
+    bool listed = false;
+    int n_rounds = all_chunks;
+    if (mp.sat != nullptr && margin <= mp.sat_margin && all_chunks >= 64 && all_chunks <= kTodo) {
+        if (lane == 0) A.ntodo = 0;
+        __syncthreads();
+        for (int c = lane; c < all_chunks; c += kSfcThreads) {
+            int j = 0;
+            for (int t = 1; t < J; t++) j += (c >= A.first[t]) ? 1 : 0;
+            const int ax = A.axes[j];
+            const int la = ax & 3, ca = (ax >> 2) & 3, cb = (ax >> 4) & 3;
+            const int na = A.n[j][ca], nl = A.n[j][la];
+            const int c0 = (c - A.first[j]) * 64, cl = A.cols[j] - 1;
+            const int c1 = c0 + 63 < cl ? c0 + 63 : cl;
+            const int ib0 = c0 / na, ib1 = c1 / na;
+            const int ia0 = ib0 == ib1 ? c0 - ib0 * na : 0, ia1 = ib0 == ib1 ? c1 - ib1 * na : na - 1;
+            const int ta = A.tab[j][ca], tb = A.tab[j][cb], tl = A.tab[j][la];
+            const int va0 = A.vtab[ta + ia0], va1 = A.vtab[ta + ia1], vb0 = A.vtab[tb + ib0], vb1 = A.vtab[tb + ib1];
+            const int vl0 = A.vtab[tl], vl1 = A.vtab[tl + nl - 1];
+            bool free_ = false;
+            if (va0 >= 0 && va1 >= va0 && vb0 >= 0 && vb1 >= vb0 && vl0 >= 0 && vl1 >= vl0) {  // (-1: a sample outside the map)
+                const int x0 = ca == 0 ? va0 : (cb == 0 ? vb0 : vl0), x1 = ca == 0 ? va1 : (cb == 0 ? vb1 : vl1);
+                const int y0 = ca == 1 ? va0 : (cb == 1 ? vb0 : vl0), y1 = ca == 1 ? va1 : (cb == 1 ? vb1 : vl1);
+                const int z0 = ca == 2 ? va0 : (cb == 2 ? vb0 : vl0), z1 = ca == 2 ? va1 : (cb == 2 ? vb1 : vl1);
+                free_ = cells_free(mp, x0, x1, y0, y1, z0, z1);
+            }
+            if (!free_) A.todo[atomicAdd(&A.ntodo, 1)] = c;
+        }
+        __syncthreads();
+        n_rounds = A.ntodo;
+        listed = true;
+    }
+    for (int r = lane >> 6; r < n_rounds; r += kSfcThreads / 64) {
         const int stop = *(volatile int*)&A.fail;  // tests behind a failure already found need not be finished
-        const int idx = base + lane;
-        const int chunk = __builtin_amdgcn_readfirstlane(idx >> 6);  // wave-uniform: boxes are padded to whole wavefronts
-        if (chunk >= A.first[J]) continue;
+        const int chunk = __builtin_amdgcn_readfirstlane(listed ? A.todo[r] : r);  // wave-uniform: boxes are padded to whole wavefronts
+        const int idx = chunk * 64 + (lane & 63);
         // the box this chunk belongs to: lane t asks "does box t + 1 start at or before it" (one LDS read per lane instead of a scan)
         const int lt = lane & 63;
         const int j = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lt + 1 < J && chunk >= A.first[lt + 1 < kAhead ? lt + 1 : kAhead]));
@@ -500,7 +538,7 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
         if (ia < 0) ib--, ia += na;
         if (ia >= na) ib++, ia -= na;
         const int el = __builtin_amdgcn_readfirstlane(A.tab[j][la]);
-        if (nl >= 8 && mp.sat != nullptr && margin <= mp.sat_margin) {
+        if (!listed && nl >= 8 && mp.sat != nullptr && margin <= mp.sat_margin) {
             // the 64 columns of this chunk with a long thin axis (a slab of a large 3-D box: 64 x nl samples; for the one-sample columns
             // of a layer the table's eight reads cost more than the sample's one -- measured): if the cells they run
             // through are provably free there is nothing to evaluate.  Wave-uniform: the chunk's columns span the rows ib0 .. ib1 of
@@ -564,7 +602,7 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
     }
     __syncthreads();
     SFC_DBG(8, clock64() - tt1_);
-    SFC_DBG(11, (total + kSfcThreads - 1) / kSfcThreads);
+    SFC_DBG(11, (n_rounds * 64 + kSfcThreads - 1) / kSfcThreads);
     const int f = A.fail;
     __syncthreads();  // (the next batch resets A.fail)
     return f;
