@@ -154,3 +154,15 @@ if CPU:
     om.construct_sfc(O.SFC_FROM_HULL, P2, sw.radius, sfc2)
     rec["cpu_oracle_ms_openmp"] = (time.perf_counter() - t0) * 1e3
 print(json.dumps(rec))
+# the same two launches with the map's free-space table in place (lscqp_map_prepare): identical boxes, tests in open space pass without sampling
+wm.prepare(float(np.max(sw.radius)))
+ref_init = None
+d_sfc.zero_()
+ms = timed(lambda: sol.construct_sfc_device(wm, api.SFC_INIT, N, d_P, d_r, d_sfc, d_st), reps=20)
+print(json.dumps({"kernel": "construct_sfc INIT with the free-space table", "agents": N, "kernel_ms": ms, "agents_per_s": N / ms * 1e3,
+                  "feasible_starts": int((d_st.cpu().numpy() == 1).sum())}))
+base_t = d_sfc.clone()
+assert torch.equal(base_t, base), "the free-space table changed a corridor"
+ms = timed(upd, reps=20) - ms_copy
+print(json.dumps({"kernel": "construct_sfc FROM_HULL with the free-space table", "agents": N, "kernel_ms": ms, "agents_per_s": N / ms * 1e3,
+                  "new_boxes": int((d_st.cpu().numpy() == 1).sum())}))
