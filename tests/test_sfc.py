@@ -239,6 +239,43 @@ def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world, prepared):
 
 
 @pytest.mark.gpu
+def test_map_prepare_is_idempotent_and_rebuilds_for_larger_agents(api):
+    """lscqp_map_prepare: a table built for a radius serves every smaller one (a second call is a no-op), a larger radius rebuilds it;
+    bad arguments are refused; the corridors of a 3-D world with few obstacles -- where almost every test is passed by the table --
+    are the ones the plain map gives, after every call."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    wmin, wmax = np.array([-6.0, -6.0, 0.0]), np.array([6.0, 6.0, 5.0])
+    boxes = np.array([[2.0, 1.0, 2.0, 0.6, 0.6, 0.6], [-2.5, -1.5, 3.0, 0.5, 0.8, 0.5], [0.5, -3.0, 1.0, 1.0, 0.4, 2.0]])
+    n, M = 96, 5
+    starts = np.float32(rng.uniform(wmin + 0.5, wmax - 0.5, (n, 3))).astype(np.float64)
+    radius = np.where(np.arange(n) % 3 == 0, 0.25, 0.15)
+    sol = api.Solver(api.make_desc(M=M, dim=3, world_min=wmin, world_max=wmax))
+    dev = torch.device("cuda", 0)
+    pts = torch.from_numpy(np.repeat(starts[:, None, :], 3, axis=1).reshape(-1).copy()).to(dev)
+    d_r = torch.from_numpy(radius).to(dev)
+
+    def corridors(m):
+        d_sfc = torch.zeros(n * M * 6, dtype=torch.float64, device=dev)
+        d_st = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        sol.construct_sfc_device(m, api.SFC_INIT, n, pts, d_r, d_sfc, d_st)
+        torch.cuda.synchronize()
+        return d_sfc.cpu().numpy(), d_st.cpu().numpy()
+
+    gmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    want = corridors(gmap)
+    assert want[1].sum() > n // 2
+    for r in (0.15, 0.1, 0.25, 0.25):  # build, no-op, rebuild, no-op
+        gmap.prepare(r)
+        got = corridors(gmap)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), r
+    with pytest.raises(api.LscqpError):
+        gmap.prepare(0.0)
+    gmap.close()
+
+
+@pytest.mark.gpu
 def test_gpu_chain_world_to_trajectory_reproduces_reference_log(api, oracle):
     """forest10, agent 1, first replan, everything on the device: world boxes -> voxel map -> initializeSFC -> goal LP ->
     trajectory QP.  The reference's own result log (tests/golden/kat_log.json) is the expected output."""
