@@ -126,6 +126,7 @@ def run(world_json, steps=40, M=10, dt=0.2, verbose=False, dump=None, keep_step=
     n_obs = min(N - 1, 8) if n_obs is None else n_obs
     n_obs = max(1, min(n_obs, cap))
     wmap = api.WorldMap(g["boxes"], g["world_min"], g["world_max"], g["resolution"], g["max_dist"])
+    wmap.prepare(radius)  # the corridor kernel's free-space table (same boxes, tests in open space pass without sampling)
     nv = sol.nv
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     upb = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
