@@ -77,6 +77,11 @@ public:
     DistanceMap(const DistanceMap&) = delete;
     DistanceMap& operator=(const DistanceMap&) = delete;
     lscqp_map handle() const { return map_; }
+    // optional, at set-up time (before the planners' threads start): the free-space table for agents up to max_radius -- the corridor
+    // tests in open space then pass without sampling, the boxes stay the same (lscqp_map_prepare)
+    void prepare(double max_radius) {
+        if (lscqp_map_prepare(map_, max_radius) != LSCQP_OK) throw std::runtime_error(std::string("[DistanceMap] ") + lscqp_last_error());
+    }
 
 private:
     lscqp_map map_ = nullptr;

@@ -290,6 +290,7 @@ static int scenario_sfc(const char* world_csv) {
     mission.world_max = point3d(5, 5, 2.5);
     CollisionConstraints cc(param, mission);
     auto dm = std::make_shared<DistanceMap>(std::string(world_csv), mission.world_min, mission.world_max, 0.1);
+    dm->prepare(0.15);  // (the free-space table: the boxes below must be the ones the plain map gives)
     cc.setDistmap(dm);
     auto show = [&](const char* name) {
         printf("{\"scenario\": \"%s\", \"boxes\": [", name);
