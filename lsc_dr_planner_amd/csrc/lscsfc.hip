@@ -415,7 +415,7 @@ __device__ unsigned long long sfc_dbg[16];
 #define LSCSFC_GROUP 4
 #endif
 #ifndef LSCSFC_AHEAD
-#define LSCSFC_AHEAD 31  // boxes of a batch (<= 31: the growth counts of a batch are packed in 5-bit fields)
+#define LSCSFC_AHEAD 63  // boxes of a batch (<= 63: lane j of wavefront 0 assembles box j)
 #endif
 #ifndef LSCSFC_SAMPLED
 #define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing)
@@ -623,6 +623,18 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
         for (int t = 0; t < 6; t++) cands |= (unsigned)cand[t] << (4 * t);
     }
     auto cand_at = [&](int t) -> int { return (int)((cands >> (4 * t)) & 15u); };
+    // growths per direction (one byte each) after m growths of the loop whose next candidate index is `base`: growth u takes candidate
+    // (base + u) mod ncand -- in closed form, the look-ahead asks for it at up to 62 growths
+    auto growths = [&](int base, int m) -> unsigned long long {
+        unsigned long long cp = 0;
+        for (int sidx = 0; sidx < ncand; sidx++) {
+            int r = (sidx - base) % ncand;  // the first growth that takes candidate sidx
+            if (r < 0) r += ncand;
+            const int cnt = m > r ? (m - 1 - r) / ncand + 1 : 0;
+            cp += (unsigned long long)cnt << (8 * cand_at(sidx));
+        }
+        return cp;
+    };
     auto face = [](const BoxF& b, int d) -> float {
         return d == 0 ? b.lo[0] : (d == 1 ? b.lo[1] : (d == 2 ? b.lo[2] : (d == 3 ? b.hi[0] : (d == 4 ? b.hi[1] : b.hi[2]))));
     };
@@ -659,18 +671,10 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 const bool mine = j < kAhead && tables;
                 BoxF u = sfc_update;
                 if (mine && j > 0) {
-                    unsigned cp = 0;
-                    int ii = i;
-                    for (int t = 1; t < j; t++) {
-                        ii++;
-                        if (ii >= ncand) ii = 0;
-                        cp += 1u << (5 * cand_at(ii));
-                    }
-                    ii++;
-                    if (ii >= ncand) ii = 0;
-                    const int d = cand_at(ii);
+                    const unsigned long long cp = growths(i + 1, j - 1);  // what lies before box j: j - 1 growths
+                    const int d = cand_at((i + j) % ncand);             // ... and the growth that makes it
                     for (int k = 0; k < 3; k++) {
-                        const int cl = (int)((cp >> (5 * k)) & 31u), ch = (int)((cp >> (5 * (k + 3))) & 31u);
+                        const int cl = (int)((cp >> (8 * k)) & 255ull), ch = (int)((cp >> (8 * (k + 3))) & 255ull);
                         u.lo[k] = A.F[k][cl];
                         u.hi[k] = A.F[k + 3][ch];
                         if (d == k) u.hi[k] = u.lo[k], u.lo[k] = A.F[k][cl + 1];
@@ -760,17 +764,11 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                     grow(sfc, sfc_cand, sfc_update, cand_at(i), res);
                 }
             } else if (passes > 0) {  // the state after `passes` growths, from the face tables
-                unsigned cp = 0;
-                for (int t = 1; t < passes; t++) {
-                    i++;
-                    if (i >= ncand) i = 0;
-                    cp += 1u << (5 * cand_at(i));
-                }
-                i++;
-                if (i >= ncand) i = 0;
+                const unsigned long long cp = growths(i + 1, passes - 1);
+                i = (i + passes) % ncand;
                 const int d = cand_at(i);
                 for (int k = 0; k < 3; k++) {
-                    const int cl = (int)((cp >> (5 * k)) & 31u), ch = (int)((cp >> (5 * (k + 3))) & 31u);
+                    const int cl = (int)((cp >> (8 * k)) & 255ull), ch = (int)((cp >> (8 * (k + 3))) & 255ull);
                     sfc.lo[k] = A.F[k][cl];
                     sfc.hi[k] = A.F[k + 3][ch];
                     sfc_cand.lo[k] = sfc_update.lo[k] = sfc.lo[k];
