@@ -339,7 +339,7 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         for (int64_t i = 0; i < desc->n_total; i++) rmax = agents[i].radius > rmax ? agents[i].radius : rmax;
         if (rmax > 0) {
             const int rc = lscqp_map_prepare(map, rmax);
-            if (rc != LSCQP_OK) return rc;
+            if (rc != LSCQP_OK && rc != LSCQP_ERR_UNSUPPORTED) return rc;  // (a map too large for the table: the corridors work without it)
         }
     }
     lscqp_plan_s* p = new lscqp_plan_s();

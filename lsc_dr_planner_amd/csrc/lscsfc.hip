@@ -1040,6 +1040,7 @@ int lscqp_map_prepare(lscqp_map mp, double max_radius) {
     if (mp->d_sat && mp->sat_margin >= max_radius) return LSCQP_OK;  // (a table built for a larger margin serves the smaller ones)
     const int nx = mp->dims[0], ny = mp->dims[1], nz = mp->dims[2];
     const int64_t nvox = (int64_t)nx * ny * nz;
+    if (nvox > 0x7fffffffLL) return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "the free-space table counts cells in 32 bits: map too large (the corridors work without it)");
     hipError_t e = hipDeviceSynchronize();  // (no corridor launch may be reading the old table)
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)).c_str());
     if (!mp->d_sat && (e = hipMalloc(&mp->d_sat, nvox * sizeof(int32_t))) != hipSuccess) {
