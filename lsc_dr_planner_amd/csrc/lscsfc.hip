@@ -235,6 +235,28 @@ __device__ __forceinline__ bool cells_free(const MapView& mp, int x0, int x1, in
     return cnt == 0;
 }
 
+// a coordinate so far from the world origin that a sample measured against the origin's phantom cell can not be within margin of it
+__device__ __forceinline__ bool far_from_origin(const MapView& mp, float p) { return (double)fabsf(p) - 0.5 * mp.res >= mp.sat_margin + 1e-3; }
+// vtab entry of such a sample beyond the map (the exact path sees "negative: outside", the table-driven paths "outside but harmless")
+constexpr int kBeyondFree = -2;
+
+// the cell range of n table entries from `tab` along one axis for the table-driven tests: 0 = not provable (a sample outside the map
+// that could be near the origin), 1 = [v0, v1], 2 = every entry is beyond the map and harmless (nothing to ask)
+__device__ __forceinline__ int cell_range(const int* vtab, int tab, int n, int& v0, int& v1) {
+    v0 = vtab[tab];
+    v1 = vtab[tab + n - 1];
+    if (v1 == kBeyondFree) {  // (a face on the world's far boundary: key = dims)
+        if (n == 1) return 2;
+        n--;
+        v1 = vtab[tab + n - 1];
+    }
+    if (v0 == kBeyondFree) {  // (a face on the near boundary whose float coordinate has drifted a hair below it: key = -1)
+        if (n == 1) return 2;
+        v0 = vtab[tab + 1];
+    }
+    return (v0 >= 0 && v1 >= v0) ? 1 : 0;
+}
+
 // true: no sample point of the box (n[k] points from lo[k] in steps of res) can be within margin of an obstacle -- see lscqp_map_prepare
 __device__ __forceinline__ bool surely_free(const MapView& mp, double margin, float lo0, float lo1, float lo2, int n0, int n1, int n2) {
     if (mp.sat == nullptr || !(margin <= mp.sat_margin)) return false;
@@ -248,6 +270,19 @@ __device__ __forceinline__ bool surely_free(const MapView& mp, double margin, fl
         const float pf = lo[k], pl = (float)((double)lo[k] + (double)(n[k] - 1) * res);  // first and last sample, as the tests form them
         a[k] = key_of((double)pf, res) - mp.key0(k);
         b[k] = key_of((double)pl, res) - mp.key0(k);
+        if (b[k] >= mp.dims(k)) {
+            // the last sample lies beyond the distance map (a box face on the world's far boundary: key = dims): such a sample is
+            // measured against the cell at the world origin whatever its other coordinates are, and this coordinate alone keeps it
+            // out of reach if it is far enough from 0
+            if (!far_from_origin(mp, pl)) return false;
+            if (n[k] == 1) return true;  // (every sample of the box is one of those)
+            b[k] = key_of((double)(float)((double)lo[k] + (double)(n[k] - 2) * res), res) - mp.key0(k);
+        }
+        if (a[k] < 0) {  // ... or the first one, on the near boundary (a float face a hair below it)
+            if (!far_from_origin(mp, pf)) return false;
+            if (n[k] == 1) return true;
+            a[k] = key_of((double)(float)((double)lo[k] + res), res) - mp.key0(k);
+        }
         inside = inside && a[k] >= 0 && b[k] < mp.dims(k) && a[k] <= b[k];
     }
     if (!inside) return false;  // (a sample outside the distance map is measured against the origin cell: the exact path handles it)
@@ -472,7 +507,7 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
             const float p = (float)(lo + (double)it * res);
             const int v = key_of((double)p, res) - key0;
             A.ptab[o + it] = p;
-            A.vtab[o + it] = (v >= 0 && v < dimk) ? v : -1;
+            A.vtab[o + it] = (v >= 0 && v < dimk) ? v : ((mp.sat != nullptr && far_from_origin(mp, p)) ? kBeyondFree : -1);
         }
     }
     __syncthreads();
@@ -503,10 +538,11 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
             const int ib0 = c0 / na, ib1 = c1 / na;
             const int ia0 = ib0 == ib1 ? c0 - ib0 * na : 0, ia1 = ib0 == ib1 ? c1 - ib1 * na : na - 1;
             const int ta = A.tab[j][ca], tb = A.tab[j][cb], tl = A.tab[j][la];
-            const int va0 = A.vtab[ta + ia0], va1 = A.vtab[ta + ia1], vb0 = A.vtab[tb + ib0], vb1 = A.vtab[tb + ib1];
-            const int vl0 = A.vtab[tl], vl1 = A.vtab[tl + nl - 1];
-            bool free_ = false;
-            if (va0 >= 0 && va1 >= va0 && vb0 >= 0 && vb1 >= vb0 && vl0 >= 0 && vl1 >= vl0) {  // (-1: a sample outside the map)
+            int va0, va1, vb0, vb1, vl0, vl1;
+            const int ra = cell_range(A.vtab, ta + ia0, ia1 - ia0 + 1, va0, va1), rb = cell_range(A.vtab, tb + ib0, ib1 - ib0 + 1, vb0, vb1);
+            const int rl = cell_range(A.vtab, tl, nl, vl0, vl1);
+            bool free_ = ra == 2 || rb == 2 || rl == 2;  // (all of the chunk's samples lie beyond the map, far from the origin)
+            if (!free_ && ra == 1 && rb == 1 && rl == 1) {  // (0: a sample outside the map that the exact path has to look at)
                 const int x0 = ca == 0 ? va0 : (cb == 0 ? vb0 : vl0), x1 = ca == 0 ? va1 : (cb == 0 ? vb1 : vl1);
                 const int y0 = ca == 1 ? va0 : (cb == 1 ? vb0 : vl0), y1 = ca == 1 ? va1 : (cb == 1 ? vb1 : vl1);
                 const int z0 = ca == 2 ? va0 : (cb == 2 ? vb0 : vl0), z1 = ca == 2 ? va1 : (cb == 2 ? vb1 : vl1);
@@ -517,6 +553,9 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
         __syncthreads();
         n_rounds = A.ntodo;
         listed = true;
+        SFC_DBG(12, all_chunks); SFC_DBG(13, n_rounds); SFC_DBG(14, 1);
+    } else {
+        SFC_DBG(15, all_chunks);
     }
     for (int r = lane >> 6; r < n_rounds; r += kSfcThreads / 64) {
         const int stop = *(volatile int*)&A.fail;  // tests behind a failure already found need not be finished
@@ -548,9 +587,11 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
             const int ib0 = c0 / na, ib1 = c1 / na;
             const int ia0 = ib0 == ib1 ? c0 - ib0 * na : 0, ia1 = ib0 == ib1 ? c1 - ib1 * na : na - 1;
             const int ta = A.tab[j][ca], tb = A.tab[j][cb];
-            const int va0 = A.vtab[ta + ia0], va1 = A.vtab[ta + ia1], vb0 = A.vtab[tb + ib0], vb1 = A.vtab[tb + ib1];
-            const int vl0 = A.vtab[el], vl1 = A.vtab[el + nl - 1];
-            if (va0 >= 0 && va1 >= va0 && vb0 >= 0 && vb1 >= vb0 && vl0 >= 0 && vl1 >= vl0) {  // (-1: a sample outside the map)
+            int va0, va1, vb0, vb1, vl0, vl1;
+            const int ra = cell_range(A.vtab, ta + ia0, ia1 - ia0 + 1, va0, va1), rb = cell_range(A.vtab, tb + ib0, ib1 - ib0 + 1, vb0, vb1);
+            const int rl = cell_range(A.vtab, el, nl, vl0, vl1);
+            if (ra == 2 || rb == 2 || rl == 2) continue;
+            if (ra == 1 && rb == 1 && rl == 1) {
                 // (ca, cb, la) is a permutation of (x, y, z)
                 const int x0 = ca == 0 ? va0 : (cb == 0 ? vb0 : vl0), x1 = ca == 0 ? va1 : (cb == 0 ? vb1 : vl1);
                 const int y0 = ca == 1 ? va0 : (cb == 1 ? vb0 : vl0), y1 = ca == 1 ? va1 : (cb == 1 ? vb1 : vl1);

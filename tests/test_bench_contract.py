@@ -58,4 +58,4 @@ def test_bench_line_covers_every_baseline_config_at_its_own_shape():
     assert rc["graph_nodes"] >= 8 and 0 < rc["graph"]["us_per_replan"] < 5000 and rc["eager"]["failed_qps_last_replan"] == 0
     assert rc["graph"]["host_submit_us_per_replan"] <= rc["eager"]["host_submit_us_per_replan"] * 1.5
     c1c = rc["c1_class"]  # the chain at the headline's class: 64 agents x M5 in 3-D
-    assert 0 < c1c["us_per_replan"] < 5000 and c1c["failed_qps"] == 0 and c1c["mean_distance_flown_m"] > 1.0, c1c
+    assert 0 < c1c["us_per_replan_after_12"] <= c1c["us_per_replan"] * 1.2 and 0 < c1c["us_per_replan"] < 5000 and c1c["failed_qps"] == 0 and c1c["mean_distance_flown_m"] > 1.0, c1c
