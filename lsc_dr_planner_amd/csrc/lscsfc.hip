@@ -237,6 +237,11 @@ __device__ __forceinline__ bool cells_free(const MapView& mp, int x0, int x1, in
 
 // a coordinate so far from the world origin that a sample measured against the origin's phantom cell can not be within margin of it
 __device__ __forceinline__ bool far_from_origin(const MapView& mp, float p) { return (double)fabsf(p) - 0.5 * mp.res >= mp.sat_margin + 1e-3; }
+// ... a whole range of samples [first, last] on one axis
+__device__ __forceinline__ bool range_far_from_origin(const MapView& mp, float first, float last) {
+    const double need = mp.sat_margin + 1e-3 + 0.5 * mp.res;
+    return (double)first >= need || -(double)last >= need;
+}
 // vtab entry of such a sample beyond the map (the exact path sees "negative: outside", the table-driven paths "outside but harmless")
 constexpr int kBeyondFree = -2;
 
@@ -265,6 +270,11 @@ __device__ __forceinline__ bool surely_free(const MapView& mp, double margin, fl
     const float lo[3] = {lo0, lo1, lo2};
     const int n[3] = {n0, n1, n2};
     bool inside = true;
+    // a sample outside the distance map is measured against the phantom cell at the world origin: harmless if ONE of its coordinates is
+    // far from 0 -- its own (far_from_origin), or any axis on which the whole box is (e.g. a box on the floor z = 0, away from x = y = 0)
+    bool any_far = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) any_far = any_far || range_far_from_origin(mp, lo[k], (float)((double)lo[k] + (double)(n[k] - 1) * res));
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float pf = lo[k], pl = (float)((double)lo[k] + (double)(n[k] - 1) * res);  // first and last sample, as the tests form them
@@ -274,12 +284,12 @@ __device__ __forceinline__ bool surely_free(const MapView& mp, double margin, fl
             // the last sample lies beyond the distance map (a box face on the world's far boundary: key = dims): such a sample is
             // measured against the cell at the world origin whatever its other coordinates are, and this coordinate alone keeps it
             // out of reach if it is far enough from 0
-            if (!far_from_origin(mp, pl)) return false;
+            if (!(any_far || far_from_origin(mp, pl))) return false;
             if (n[k] == 1) return true;  // (every sample of the box is one of those)
             b[k] = key_of((double)(float)((double)lo[k] + (double)(n[k] - 2) * res), res) - mp.key0(k);
         }
         if (a[k] < 0) {  // ... or the first one, on the near boundary (a float face a hair below it)
-            if (!far_from_origin(mp, pf)) return false;
+            if (!(any_far || far_from_origin(mp, pf))) return false;
             if (n[k] == 1) return true;
             a[k] = key_of((double)(float)((double)lo[k] + res), res) - mp.key0(k);
         }
@@ -503,11 +513,15 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
         const int n = A.n[j][k], o = A.tab[j][k];
         const int key0 = mp.key0(k), dimk = mp.dims(k);
         const double lo = (double)A.lo[j][k];
+        bool any_far = false;  // (the whole box far from the origin on some axis: its samples outside the map are harmless, see surely_free)
+        if (mp.sat != nullptr)
+            for (int m = 0; m < 3; m++)
+                any_far = any_far || (A.n[j][m] > 0 && range_far_from_origin(mp, A.lo[j][m], (float)((double)A.lo[j][m] + (double)(A.n[j][m] - 1) * res)));
         for (int it = lane & 63; it < n; it += 64) {
             const float p = (float)(lo + (double)it * res);
             const int v = key_of((double)p, res) - key0;
             A.ptab[o + it] = p;
-            A.vtab[o + it] = (v >= 0 && v < dimk) ? v : ((mp.sat != nullptr && far_from_origin(mp, p)) ? kBeyondFree : -1);
+            A.vtab[o + it] = (v >= 0 && v < dimk) ? v : ((mp.sat != nullptr && (any_far || far_from_origin(mp, p))) ? kBeyondFree : -1);
         }
     }
     __syncthreads();
