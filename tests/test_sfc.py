@@ -276,6 +276,53 @@ def test_map_prepare_is_idempotent_and_rebuilds_for_larger_agents(api):
 
 
 @pytest.mark.gpu
+def test_free_space_table_next_to_walls_floor_and_origin(api):
+    """Corridors that lie along the world's boundary have a sample OUTSIDE the distance map on every column (the face sits on the
+    boundary, its float coordinate a hair beyond it) -- measured against the phantom cell at the world origin.  The table-driven tests
+    treat such samples as harmless where one coordinate of the sample, or a whole axis of the box, is far from 0, and leave the rest to
+    the exact path: agents next to each wall, on the floor, under the ceiling, and around the world origin (which is ON the floor of
+    this room) get, bit for bit, the corridors of the plain map -- first replan and hull update."""
+    import torch
+
+    wmin, wmax = np.array([-6.0, -6.0, 0.0]), np.array([6.0, 6.0, 4.0])
+    boxes = np.array([[2.0, 1.5, 2.0, 0.6, 0.6, 0.6], [-3.0, -2.0, 1.0, 0.5, 0.5, 2.0], [0.8, -0.6, 0.4, 0.4, 0.4, 0.8]])
+    spots = [[-5.8, 0.5, 2.0], [5.8, -1.0, 2.0], [0.5, -5.8, 1.5], [1.0, 5.8, 3.0], [3.0, 3.0, 0.2], [-4.0, 2.0, 3.8], [0.3, 0.2, 0.2], [-0.4, 0.3, 0.3],
+             [0.0, 0.0, 1.5], [5.7, 5.7, 0.2], [-5.7, -5.7, 3.8], [0.2, -5.7, 0.2], [-5.8, 0.1, 0.2], [2.5, -3.0, 2.0]]
+    starts = np.float32(np.array(spots)).astype(np.float64)
+    n, M = len(starts), 5
+    radius = np.full(n, 0.15)
+    sol = api.Solver(api.make_desc(M=M, dim=3, world_min=wmin, world_max=wmax))
+    dev = torch.device("cuda", 0)
+    d_r = torch.from_numpy(radius).to(dev)
+    step = np.array([0.3, -0.2, 0.1])
+    inward = -np.sign(starts) * np.abs(step)
+    inward[:, 2] = np.where(starts[:, 2] > 2.0, -0.1, 0.1)
+    P1 = np.repeat(starts[:, None, :], 3, axis=1)
+    P2 = np.float32(np.stack([starts + 0.5 * inward, starts + inward, starts + inward], axis=1)).astype(np.float64)
+
+    def run(m):
+        out = []
+        d_sfc = torch.zeros(n * M * 6, dtype=torch.float64, device=dev)
+        d_st = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        for mode, P in ((api.SFC_INIT, P1), (api.SFC_FROM_HULL, P2)):
+            sol.construct_sfc_device(m, mode, n, torch.from_numpy(P.reshape(-1).copy()).to(dev), d_r, d_sfc, d_st)
+            torch.cuda.synchronize()
+            out.append((d_sfc.cpu().numpy().copy(), d_st.cpu().numpy().copy()))
+        return out
+
+    gmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    want = run(gmap)
+    assert want[0][1].sum() >= n - 2 and want[1][1].sum() >= n // 2
+    box0 = want[0][0].reshape(n, M, 6)[:, 0]
+    assert (box0[:, 0] <= wmin[0] + 1e-3).any() and (box0[:, 3] >= wmax[0] - 1e-3).any() and (box0[:, 2] <= 1e-3).any() and (box0[:, 5] >= wmax[2] - 1e-3).any()
+    gmap.prepare(0.15)
+    got = run(gmap)
+    for (a, sa), (b, sb) in zip(got, want):
+        assert np.array_equal(sa, sb) and np.array_equal(a, b)
+    gmap.close()
+
+
+@pytest.mark.gpu
 def test_gpu_chain_world_to_trajectory_reproduces_reference_log(api, oracle):
     """forest10, agent 1, first replan, everything on the device: world boxes -> voxel map -> initializeSFC -> goal LP ->
     trajectory QP.  The reference's own result log (tests/golden/kat_log.json) is the expected output."""
