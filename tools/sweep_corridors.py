@@ -8,7 +8,8 @@ from oracle import oracle as O
 dev=torch.device("cuda",0)
 up=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 nbad=0; tot=0
-for seed in range(12):
+SEEDS = range(*[int(v) for v in sys.argv[sys.argv.index("--seeds") + 1:sys.argv.index("--seeds") + 3]]) if "--seeds" in sys.argv else range(12)
+for seed in SEEDS:
     rng=np.random.default_rng(seed)
     dim=3 if seed%2 else 2
     wmin=np.array([-6.0,-6.0,0.0])+rng.choice([0,0.03,-0.27],3); wmax=np.array([6.0,6.0,3.0 if dim==3 else 2.5])+rng.choice([0,0.04,0.31],3)
