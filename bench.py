@@ -2,7 +2,10 @@
 """bench.py — QP solves/sec of the batched trajectory-QP hot path on N MI355X GPUs of one node.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+torch.distributed.run with one rank per GPU -- by the driver, or BY ITSELF: `python bench.py --gpus N` started without
+WORLD_SIZE in the environment re-launches itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1`, and every rank refuses to run unless WORLD_SIZE == --gpus and (over RCCL) N distinct devices
+exist.  Rank 0 prints ONE JSON line.
 
   * A "step" is one pass of the hot path (lscqp_solve_batch_device: the HIP PDIP kernel) over one batch of synthetic
     agents, inputs already resident in HBM.  The workload at every N is BASELINE.json configs[1] PER GPU:
@@ -11,6 +14,11 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
     own 64-agent swarm, no data-path collective (the QPs of one replan step are independent,
     reference src/multi_sync_simulator.cpp:354-362).  `--allgather` adds the RCCL all-gather of the solved control
     points after every step (the device analogue of broadcastMsgs, :305-352) for those who want it in the number.
+  * `--scaling strong --config c2|c3|c4` is the mode BASELINE's 8-GPU configs describe: ONE global batch (512 / 1024 / 4096
+    agents) cut into contiguous blocks of ceil(N/G) agents (sharding.shard_range == lscqp_shard_range), every rank solves its
+    block and the plans are all-gathered over RCCL EVERY step (broadcastMsgs, :305-352); value = global agents x steps / time.
+    `--single-process` runs the same split from ONE host process through lscqp_comm (ncclCommInitAll, one stream per device:
+    lscqp_solve_batch_sharded_device + lscqp_allgather), the deployment the reference's single ROS process would use.
   * roofline: algorithmic bytes (20 432 B per QP at this shape) x QPs per launch / the kernel's average
     launch duration, measured with HIP events on the launch stream over the timed region, against 8.0 TB/s.
   * cpu_baseline: the CPU oracle (oracle/, a port: CPLEX cannot exist here) on the same batch, rank 0, N = 1 only.
@@ -46,6 +54,11 @@ def make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed, style, warm_s
         sw.advance(r["x"])
     b = sw.build()
     return sw, sol, b, api.batch_from_swarm(b, sw.n_obs, M)
+
+
+def slice_build(build, n, lo, hi):
+    """The agents [lo, hi) of a synth.Swarm.build() dict (per-agent arrays are the ones whose first dimension is n)."""
+    return {k: (v[lo:hi] if getattr(v, "ndim", 0) >= 1 and v.shape[0] == n else v) for k, v in build.items()}
 
 
 def to_dev(torch, a, dev):
@@ -86,6 +99,20 @@ def percentile_latency(torch, call, max_calls=1050, max_seconds=6.0, skip=50):
             break
     lat = np.array(lat[skip:]) * 1e3
     return float(np.percentile(lat, 50)), float(np.percentile(lat, 99)), int(len(lat))
+
+
+def oracle_sample(O, sw, build, M, dim, n_obs_eff, sample, threads=4):
+    """The first `sample` QPs of the batch solved once by the CPU oracle (the checker): (result dict, selected indices)."""
+    N = len(build["p0"])
+    sel = np.arange(min(sample, N))
+    cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    ag = np.zeros(len(sel), O.AGENT_DTYPE)
+    for f in ("p0", "v0", "a0", "goal", "next_waypoint"):
+        ag[f] = build[f][sel]
+    ag["vmax"], ag["amax"], ag["radius"], ag["nominal_velocity"], ag["n_obs"] = 1.0, 2.0, 0.15, 1.0, n_obs_eff
+    R = O.solve_batch(cls, ag, np.ascontiguousarray(build["lsc"][sel]).reshape(-1), np.arange(len(sel)) * n_obs_eff * M * 6,
+                      np.ascontiguousarray(build["sfc"][sel]).reshape(-1), threads=threads)
+    return R, sel
 
 
 def oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample, budget_s=2.5):
@@ -297,6 +324,145 @@ def replan_chain_3d(torch, api, N=64, replans=41, radii=(10.0, 10.0, 4.0), skip=
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def single_process_main(args, torch):
+    """--single-process: ONE host process drives the G devices through lscqp_comm (the deployment of the reference's single ROS
+    process): the config's global batch in contiguous blocks of ceil(N/G), lscqp_solve_batch_sharded_device on the
+    communicator's streams, then lscqp_allgather of the plans (ncclCommInitAll communicators, grouped ncclAllGather) every step."""
+    from lsc_dr_planner_amd import api, sharding, synth
+
+    G, M, dim, n_obs, n_glob = args.gpus, args.segments, args.dim, args.obs, args.agents
+    torch.cuda.set_device(0)
+    kw = {}
+    if args.precision == "mixed":
+        kw["precision"] = api.PRECISION_MIXED
+    if args.rows == "f32":
+        kw["row_format"] = api.ROWS_F32
+
+    def factory(sw):
+        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **kw))
+
+    sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, factory, n_glob, M, dim, n_obs, seed=1000, style=args.style, warm_steps=3)
+    nv, n_obs_eff, per = sol.nv, sw.n_obs, -(-n_glob // G)
+    comm = api.Comm(G)
+    comm.set_min_agents_per_device(1)  # this run is TOLD how many devices to use; the library's own rule is reported below
+    rows2, sfc2, x0 = sol.rows_in_format(rows).reshape(n_glob, -1), sfc.reshape(n_glob, M), api.x_init_from_swarm(build, dim)
+    blocks, T = [], {k: [] for k in ("hdr", "rows", "off", "sfc", "xi", "x", "obj", "st", "info", "all")}
+    for g in range(G):
+        lo, hi = sharding.shard_range(n_glob, G, g)
+        blocks.append((lo, hi))
+        dev = torch.device("cuda", g)
+        n = hi - lo
+        T["hdr"].append(to_dev(torch, hdr[lo:hi], dev))
+        T["rows"].append(to_dev(torch, rows2[lo:hi], dev))
+        T["off"].append(to_dev(torch, np.arange(n + 1, dtype=np.uint64) * np.uint64(n_obs_eff * M * 6), dev))
+        T["sfc"].append(to_dev(torch, sfc2[lo:hi], dev))
+        T["xi"].append(None if args.cold_start else torch.from_numpy(np.ascontiguousarray(x0[lo:hi])).to(dev))
+        T["x"].append(torch.zeros(per * nv, dtype=torch.float64, device=dev))
+        T["obj"].append(torch.zeros(max(n, 1), dtype=torch.float64, device=dev))
+        T["st"].append(torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev))
+        T["info"].append(torch.zeros(max(n, 1) * 32, dtype=torch.uint8, device=dev))
+        T["all"].append(torch.zeros(G * per * nv, dtype=torch.float64, device=dev))
+    counts = [hi - lo for lo, hi in blocks]
+
+    def solve():
+        sol.solve_sharded_device(comm, counts, n_obs_eff, T["hdr"], T["rows"], T["off"], T["sfc"], T["x"], T["obj"], T["st"], T["info"],
+                                 d_x_init=None if args.cold_start else T["xi"])
+
+    def step():
+        solve()
+        comm.allgather(T["x"], T["all"], per * nv)
+
+    for _ in range(args.warmup):
+        step()
+    comm.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    comm.synchronize()
+    elapsed = time.perf_counter() - t0
+    # the solve kernel alone, HIP events on device 0's communicator stream (the stream the kernel is launched on)
+    s0 = torch.cuda.ExternalStream(comm.stream(0), device=torch.device("cuda", 0))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s0)
+    for _ in range(20):
+        solve()
+    e1.record(s0)
+    comm.synchronize()
+    kernel_ms = e0.elapsed_time(e1) / 20
+    lat = []
+    for _ in range(0 if args.no_latency else 260):
+        a = time.perf_counter()
+        step()
+        comm.synchronize()
+        lat.append(time.perf_counter() - a)
+    lat = np.array(lat[10:] or [float("nan")]) * 1e3
+    step()
+    comm.synchronize()
+    st = np.concatenate([T["st"][g].cpu().numpy()[: counts[g]] for g in range(G)])
+    it = np.concatenate([T["info"][g].cpu().numpy().view(api.INFO_DTYPE)["iterations"][: counts[g]] for g in range(G)])
+    x_all = np.concatenate([T["x"][g].cpu().numpy()[: counts[g] * nv] for g in range(G)]).reshape(n_glob, nv)
+    for g in range(G):  # every device must hold every owner's block after the exchange
+        view = T["all"][g].cpu().numpy().reshape(G, per * nv)
+        got = np.concatenate([view[o][: counts[o] * nv] for o in range(G)]).reshape(n_glob, nv)
+        if not np.array_equal(got, x_all):
+            raise SystemExit("bench.py: device %d does not hold the gathered plans of all owners" % g)
+    parity = None
+    if not args.no_cpu_baseline and args.rows == "f64":
+        from oracle import oracle as O
+
+        dxm, dom, cmp_n = 0.0, 0.0, 0
+        for g, (lo, hi) in enumerate(blocks):  # a sample of EVERY device's block against the oracle
+            bg = slice_build(build, n_glob, lo, hi)
+            Rk, sel = oracle_sample(O, sw, bg, M, dim, n_obs_eff, sample=min(hi - lo, 8 if M < 10 else 4))
+            og = T["obj"][g].cpu().numpy()[sel]
+            ok = (Rk["status"] == 0) & (st[lo:hi][sel] == 0)
+            dxm = max(dxm, float(np.abs(x_all[lo:hi][sel] - Rk["x"])[ok].max()))
+            dom = max(dom, float((np.abs(og - Rk["obj"]) / np.maximum(1.0, np.abs(Rk["obj"])))[ok].max()))
+            cmp_n += int(ok.sum())
+        parity = {"max_abs_dx": dxm, "max_rel_dobj": dom, "compared": cmp_n, "devices": G}
+    bq = sol.algorithmic_bytes(n_obs_eff)
+    achieved = bq * counts[0] / (kernel_ms * 1e-3)
+    out = {"metric": "qp_solves_per_sec", "value": n_glob * args.steps / elapsed, "unit": "QP/s", "n_gpus": G, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64" if args.precision == "f64" else "f64 iterate and residuals, f32 factorisation", "data": "synthetic",
+           "config": {"workload": "%s -- ONE batch of %d agents cut into blocks of <= %d per GPU x M=%d x %d LSC neighbours (dim=%d, %s swarm "
+                                  "after 3 warm-up replans), solve + all-gather of the plans per step" % (CONFIGS[args.config]["what"], n_glob, per, M, n_obs_eff, dim, args.style),
+                      "baseline_config": args.config, "precision": args.precision, "row_format": args.rows,
+                      "collective_backend": comm.backend, "launch": "single process, lscqp_comm (one stream + one RCCL communicator per device)",
+                      "agents_per_gpu": per, "agents_total": n_glob, "ranks": 1, "distinct_devices": G,
+                      "devices_by_crossover_rule": int(max(1, min(G, n_glob // 256))), "allgather": True,
+                      "allgather_bytes_per_rank_per_step": int(per * nv * 8), "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
+                      "parallelism": "agents sharded over %d GPU(s), one RCCL all-gather of the plans per step" % G},
+           "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                        "traffic": None, "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (M, dim, "float" if args.precision == "mixed" else "double"),
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_qp": bq, "qps_per_launch": counts[0]},
+           "latency_ms": {"sharded_step": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "calls": int(len(lat)),
+                                           "what": "solve of every block + all-gather, enqueue -> all streams synchronised"}},
+           "solver": {"non_optimal": int((st != 0).sum()), "iters_mean": float(it.mean()), "iters_max": int(it.max())}}
+    if parity is not None:
+        out["parity_all_ranks"] = parity
+    print(json.dumps(out))
+    comm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,7 +488,22 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the latency loops (their launches would mix into a kernel trace of the timed steps)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank owns --agents agents of its own swarm, no data-path collective.  strong: the "
+                         "config's agents are ONE global batch cut into contiguous blocks of ceil(N/G) (BASELINE configs[2..4]), "
+                         "the plans all-gathered every step")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive the --gpus devices from THIS process through lscqp_comm (ncclCommInitAll; one stream per device) "
+                         "instead of one process per GPU; implies --scaling strong")
+    ap.add_argument("--no-rank-parity", action="store_true", help="multi-rank runs: skip the per-rank oracle check of each rank's own block")
     args = ap.parse_args()
+    if args.single_process:
+        args.scaling = "strong"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ:
+        # started bare with --gpus N: launch one rank per GPU ourselves, exactly as the driver would
+        raise SystemExit(launch_ranks(args.gpus))
     cfg0 = CONFIGS[args.config]
     for k in ("agents", "segments", "obs", "dim", "style", "precision", "rows"):
         if getattr(args, k) is None:
@@ -333,11 +514,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not args.single_process:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the flag and the launch must agree (start it bare and it launches "
+                         "its own ranks, or under torch.distributed.run with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
     # one process per GPU.  (LSCQP_BENCH_BACKEND=gloo lets a 1-GPU box exercise the multi-rank code path: the ranks then
     # share the device and the collectives go through gloo; never used for reported numbers.)
     backend = os.environ.get("LSCQP_BENCH_BACKEND", "nccl")
+    if args.single_process:
+        if world != 1:
+            raise SystemExit("bench.py: --single-process drives all devices from one process; do not start it under a launcher")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py: --single-process --gpus %d needs %d devices, %d visible" % (args.gpus, args.gpus, torch.cuda.device_count()))
+        return single_process_main(args, torch)
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks need %d distinct devices, %d visible (LSCQP_BENCH_BACKEND=gloo shares devices, for "
+                         "tests only)" % (world, world, torch.cuda.device_count()))
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -382,19 +575,51 @@ def main():
     def solver_factory(sw):
         return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **solver_kw))
 
-    sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed=1000 + rank,
-                                                       style=args.style, warm_steps=3)
+    strong = args.scaling == "strong"
+    if strong and (args.pipeline or args.graph):
+        raise SystemExit("bench.py: --scaling strong times the solve + all-gather step; --pipeline / --graph are weak-scaling options")
+    n_glob = N  # agents of the whole job's step: one global batch (strong) or `world` independent swarms of N (weak)
+    if strong:
+        # ONE swarm for the whole job, built identically on every rank (same seed; the warm-up replans are carried by the rank's
+        # own GPU), then cut: rank r owns the contiguous block shard_range(n_glob, world, r) (reference agent order, src/mission.cpp:140-153)
+        from lsc_dr_planner_amd import sharding
+
+        sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, n_glob, M, dim, n_obs, seed=1000, style=args.style, warm_steps=3)
+        lo, hi = sharding.shard_range(n_glob, world, rank)
+        per = -(-n_glob // world)
+        N = hi - lo
+        if N <= 0:
+            raise SystemExit("bench.py: rank %d owns no agent (%d agents over %d ranks)" % (rank, n_glob, world))
+        build = slice_build(build, n_glob, lo, hi)
+        hdr, sfc = hdr[lo:hi], sfc.reshape(n_glob, M)[lo:hi]
+        rows = rows.reshape(n_glob, -1)[lo:hi].reshape(-1)
+        off = np.arange(N + 1, dtype=np.uint64) * np.uint64(sw.n_obs * M * 6)
+    else:
+        sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed=1000 + rank,
+                                                           style=args.style, warm_steps=3)
+        n_glob = world * N
     n_obs_eff = sw.n_obs
     nv = sol.nv
     d_hdr, d_off, d_sfc = (to_dev(torch, a, dev) for a in (hdr, off, sfc))
     d_rows = to_dev(torch, sol.rows_in_format(rows), dev)
     # TrajOptimizer::solve's initial_traj (the shifted previous plan): the solver's primal start
     d_xinit = None if args.cold_start else torch.from_numpy(api.x_init_from_swarm(build, dim)).to(dev)
-    d_x = torch.zeros(N * nv, dtype=torch.float64, device=dev)
+    n_pad = per if strong else N  # equal blocks for the collective: the last block of a ragged split is padded (never solved)
+    d_x = torch.zeros(n_pad * nv, dtype=torch.float64, device=dev)
     d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
     d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
     d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
-    d_all = torch.zeros(world * N * nv, dtype=torch.float64, device=dev) if ((args.allgather or args.pipeline) and world > 1) else None
+    gather = (args.allgather or args.pipeline or strong) and world > 1
+    d_all = torch.zeros(world * n_pad * nv, dtype=torch.float64, device=dev) if gather else None
+    # gloo (test-only backend, ranks sharing a device) carries the all-gather through host memory
+    h_all = torch.zeros(world * n_pad * nv, dtype=torch.float64) if (gather and coll_backend.startswith("gloo")) else None
+
+    def all_gather_plans():
+        if h_all is None:
+            dist.all_gather_into_tensor(d_all, d_x)
+        else:
+            dist.all_gather_into_tensor(h_all, d_x.cpu())
+            d_all.copy_(h_all)
     d_xwarm = torch.zeros(N * nv, dtype=torch.float64, device=dev)
     if args.pipeline:
         # every rank's swarm is independent (weak scaling); global agent id = rank * N + local id.  The rows are
@@ -413,7 +638,7 @@ def main():
         if args.pipeline:
             src = d_x
             if d_all is not None:
-                dist.all_gather_into_tensor(d_all, d_x)
+                all_gather_plans()
                 src = d_all
             sol.shift_traj_device(world * N, src, d_traj, z_2d=float(build["p0"][0][2]), shift=0)
             sol.generate_lsc_device(N, n_obs_eff, rank * N, d_traj, d_nbr, d_rad, d_dw, d_goal, d_rows)
@@ -422,7 +647,7 @@ def main():
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info,
                          d_x_init=(d_xwarm if (args.pipeline and d_xinit is not None) else d_xinit))
         if d_all is not None and not args.pipeline:
-            dist.all_gather_into_tensor(d_all, d_x)
+            all_gather_plans()
 
     if args.graph:
         if world != 1:
@@ -460,18 +685,68 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the launch stream
-    if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    def reduce(vals, op):
+        """all-reduce of a few doubles over the ranks (host tensors under gloo, device tensors under RCCL)."""
+        if dist is None:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=("cpu" if coll_backend.startswith("gloo") else dev))
+        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
+        return [float(v) for v in t.cpu()]
+
+    if d_all is not None and not args.pipeline:
+        # roofline.kernel_ms is the SOLVE kernel's launch duration: time it without the exchange that shares the step's stream
+        ek0, ek1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ek0.record()
+        for _ in range(20):
+            sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+        ek1.record()
+        torch.cuda.synchronize()
+        kernel_ms = ek0.elapsed_time(ek1) / 20
+    my_elapsed = elapsed
+    elapsed, kernel_ms = reduce([elapsed, kernel_ms], "max")
 
     status = d_st.cpu().numpy()
     iters = d_info.cpu().numpy().view(api.INFO_DTYPE)["iterations"]
-    n_bad = int((status != 0).sum())
+    n_bad = int(reduce([float((status != 0).sum())], "sum")[0])
+    n_ranks_seen, n_devices_seen, n_agents_seen = 1, 1, N
+    rank_parity = None
+    step_lat = None
     if dist is not None:
-        tb = torch.tensor([n_bad], dtype=torch.int64, device=dev)
-        dist.all_reduce(tb)
-        n_bad = int(tb[0])
+        # what actually ran: ranks, DISTINCT devices (by PCI bus id), agents solved per step over all ranks
+        bus = torch.cuda.get_device_properties(dev_index)
+        dev_id = hash((getattr(bus, "pci_bus_id", dev_index), getattr(bus, "pci_device_id", 0), getattr(bus, "pci_domain_id", 0), dev_index)) % (1 << 40)
+        ids = [None] * world
+        dist.all_gather_object(ids, (dev_id, N, my_elapsed))
+        n_ranks_seen, n_devices_seen, n_agents_seen = len(ids), len({i[0] for i in ids}), sum(i[1] for i in ids)
+        if d_all is not None and not args.pipeline:
+            # the exchange must have delivered every owner's block: compare this rank's view with its own block
+            mine = d_all.view(world, n_pad * nv)[rank][: N * nv]
+            if not torch.equal(mine, d_x[: N * nv]):
+                raise SystemExit("bench.py: rank %d: the all-gathered plans do not contain this rank's block" % rank)
+        if not args.no_rank_parity and not args.no_cpu_baseline and args.rows == "f64":
+            # every rank checks its OWN block against the oracle (a bounded sample: the oracle is a dense CPU solver)
+            from oracle import oracle as O
+
+            k = min(N, 16 if M < 10 else 6)
+            Rk, sel = oracle_sample(O, sw, build, M, dim, n_obs_eff, sample=k)
+            xg, og = d_x.cpu().numpy()[: N * nv].reshape(N, nv)[sel], d_obj.cpu().numpy()[sel]
+            ok = (Rk["status"] == 0) & (status[sel] == 0)
+            dxm = float(np.abs(xg - Rk["x"])[ok].max()) if ok.any() else float("inf")
+            dom = float((np.abs(og - Rk["obj"]) / np.maximum(1.0, np.abs(Rk["obj"])))[ok].max()) if ok.any() else float("inf")
+            dxm, dom = reduce([dxm, dom], "max")
+            rank_parity = {"max_abs_dx": dxm, "max_rel_dobj": dom, "compared_per_rank": int(k), "ranks": world,
+                           "compared": int(reduce([float(ok.sum())], "sum")[0])}
+        if strong and not args.no_latency:
+            # per-step latency of the sharded step (solve of the block + the all-gather), every rank taking part: max over ranks
+            ls = []
+            for _ in range(260):
+                a = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                ls.append(time.perf_counter() - a)
+            ls = np.array(ls[10:]) * 1e3
+            p50, p99 = reduce([float(np.percentile(ls, 50)), float(np.percentile(ls, 99))], "max")
+            step_lat = {"p50": p50, "p99": p99, "calls": int(len(ls)), "what": "solve of the rank's block + all-gather, enqueue -> readable, max over ranks"}
 
     if rank != 0:
         if dist is not None:
@@ -540,26 +815,32 @@ def main():
                         "source": "profiles/%s (rocprofv3 --pmc SQ_*)" % os.path.basename(pf)}
     except Exception:
         pass
+    if n_ranks_seen != args.gpus or n_agents_seen != n_glob or (world > 1 and backend == "nccl" and n_devices_seen != world):
+        raise SystemExit("bench.py: asked for %d GPUs and %d agents per step; ran %d ranks on %d distinct devices solving %d agents" % (
+            args.gpus, n_glob, n_ranks_seen, n_devices_seen, n_agents_seen))
     out = {
         "metric": "qp_solves_per_sec",
-        "value": world * N * args.steps / elapsed,
+        "value": n_glob * args.steps / elapsed,
         "unit": "QP/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64" if args.precision == "f64" else "f64 iterate and residuals, f32 factorisation",
         "data": "synthetic",
         "config": {
-            "workload": "%s -- %d agents/GPU x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
+            "workload": "%s -- %s x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
                         "%s batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (
-                            cfg0["what"] if (N, M, n_obs, dim) == (cfg0["agents"], cfg0["segments"], cfg0["obs"], cfg0["dim"]) else "custom shape",
-                            N, M, n_obs_eff, dim, args.style, "fp64" if args.precision == "f64" else "mixed-precision"),
+                            cfg0["what"] if (args.agents, M, n_obs, dim) == (cfg0["agents"], cfg0["segments"], cfg0["obs"], cfg0["dim"]) else "custom shape",
+                            ("ONE batch of %d agents cut into blocks of <= %d per GPU" % (n_glob, n_pad)) if strong else ("%d agents/GPU" % N),
+                            M, n_obs_eff, dim, args.style, "fp64" if args.precision == "f64" else "mixed-precision"),
             "baseline_config": args.config, "precision": args.precision, "row_format": args.rows, "collective_backend": coll_backend,
-            "agents_per_gpu": N, "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
+            "agents_per_gpu": n_pad, "agents_total": n_glob, "agents_solved_per_step_all_ranks": n_agents_seen,
+            "ranks": n_ranks_seen, "distinct_devices": n_devices_seen, "launch": "one process per GPU (torch.distributed)" if world > 1 else "single process",
+            "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
             "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline), "hip_graph": bool(args.graph),
             "warm_start": "initial_traj (shifted previous plan) as primal start" if d_xinit is not None else "none",
             "parallelism": ("agents sharded over %d GPU(s), " % world) +
@@ -578,6 +859,15 @@ def main():
                        "samples": {"device_resident": int(len(lat)), "single_qp": int(len(lat1)), "host_pointers": int(len(lath))}},
         "solver": {"non_optimal": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
     }
+    if rank_parity is not None:
+        out["parity_all_ranks"] = rank_parity
+    if step_lat is not None:
+        out["latency_ms"]["sharded_step"] = step_lat
+    if strong:
+        # north_star: "RCCL all-gather ... only when agent count justifies it" -- the library's stated rule (lscqp_comm_devices_for:
+        # clamp(n / 256, 1, G)) next to what this run was TOLD to use
+        out["config"]["devices_by_crossover_rule"] = int(max(1, min(world, n_glob // 256)))
+        out["config"]["allgather_bytes_per_rank_per_step"] = int(n_pad * nv * 8)
 
     # ---- CPU baseline: the oracle port on the same batch, all host cores --------------------------------------
     if world == 1 and not args.no_cpu_baseline:

@@ -569,6 +569,21 @@ class Solver:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
         return dict(x=x, obj=obj, status=status, info=info, devices_used=used.value)
 
+    def solve_sharded_device(self, comm, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, d_x_init=None, retry=False):
+        """lscqp_solve_batch_sharded_device: lists of per-device torch CUDA tensors (entry g lives on device g of `comm`), n[g] agents on
+        device g; asynchronous on the communicator's streams (comm.synchronize() waits)."""
+        G = comm.size
+        vp = C.c_void_p * G
+
+        def arr(ts):
+            return None if ts is None else vp(*[(None if t is None else t.data_ptr()) for t in ts])
+
+        nn = (C.c_int64 * G)(*[int(v) for v in n])
+        rc = lib().lscqp_solve_batch_sharded_device(self._h, comm._h, nn, int(n_obs_max), arr(d_hdr), arr(d_rows), arr(d_off), arr(d_sfc),
+                                                    arr(d_x_init), arr(d_x), arr(d_obj), arr(d_status), arr(d_info), int(bool(retry)))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
     # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
     def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None,
                      d_x_init=None, retry=False):

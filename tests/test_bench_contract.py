@@ -59,3 +59,87 @@ def test_bench_line_covers_every_baseline_config_at_its_own_shape():
     assert rc["graph"]["host_submit_us_per_replan"] <= rc["eager"]["host_submit_us_per_replan"] * 1.5
     c1c = rc["c1_class"]  # the chain at the headline's class: 64 agents x M5 in 3-D
     assert 0 < c1c["us_per_replan_after_12"] <= c1c["us_per_replan"] * 1.2 and 0 < c1c["us_per_replan"] < 5000 and c1c["failed_qps"] == 0 and c1c["mean_distance_flown_m"] > 1.0, c1c
+
+
+def _run_bench(argv, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    return out
+
+
+def test_gpus_flag_and_world_size_must_agree():
+    """`--gpus N` is not a label: a launch whose WORLD_SIZE differs is refused before anything runs (no device needed)."""
+    out = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0"}, timeout=120)
+    assert out.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in out.stderr
+    out = _run_bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0"}, timeout=120)
+    assert out.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_launches_two_ranks_weak_scaling():
+    """`python bench.py --gpus 2` started WITHOUT a launcher runs two ranks (here: sharing the one device, collectives over gloo --
+    LSCQP_BENCH_BACKEND=gloo exists for this test): n_gpus == 2, both ranks' agents in the value, every rank checked against the oracle."""
+    out = _run_bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-extra", "--no-latency"], {"LSCQP_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    b = json.loads(lines[0])
+    c = b["config"]
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and c["ranks"] == 2 and c["agents_total"] == 128 and c["agents_solved_per_step_all_ranks"] == 128
+    assert "gloo" in c["collective_backend"] and "2 ranks" in c["collective_backend"]
+    assert abs(b["value"] - 128 * 1e3 / b["ms_per_step"]) <= 1e-6 * b["value"]
+    pr = b["parity_all_ranks"]
+    assert pr["ranks"] == 2 and pr["compared"] == 32 and pr["max_abs_dx"] <= 1e-6 and pr["max_rel_dobj"] <= 1e-8
+    assert b["solver"]["non_optimal"] == 0
+    # without the test backend two ranks need two devices: on a one-GPU box the launch is refused, loudly
+    import torch
+
+    if torch.cuda.device_count() == 1:
+        out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra", "--no-latency"], timeout=300)
+        assert out.returncode != 0 and "distinct devices" in out.stderr
+
+
+@pytest.mark.gpu
+def test_strong_scaling_splits_one_batch_and_gathers_the_plans():
+    """BASELINE configs[2]'s mode: 512 agents as ONE batch over 2 ranks (256 each), the plans all-gathered every step; each rank's
+    block against the oracle; the gathered buffer holds the rank's own block."""
+    out = _run_bench(["--gpus", "2", "--scaling", "strong", "--config", "c2", "--steps", "10", "--warmup", "3", "--no-extra"],
+                     {"LSCQP_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    b = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    c = b["config"]
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and c["agents_total"] == 512 and c["agents_per_gpu"] == 256 and c["allgather"] is True
+    assert c["agents_solved_per_step_all_ranks"] == 512 and c["devices_by_crossover_rule"] == 2 and c["baseline_config"] == "c2"
+    assert c["allgather_bytes_per_rank_per_step"] == 256 * 108 * 8
+    assert abs(b["value"] - 512 * 1e3 / b["ms_per_step"]) <= 1e-6 * b["value"]
+    assert b["roofline"]["qps_per_launch"] == 256 and b["roofline"]["kernel_ms"] <= b["ms_per_step"]
+    pr = b["parity_all_ranks"]
+    assert pr["compared"] == 32 and pr["max_abs_dx"] <= 1e-6 and pr["max_rel_dobj"] <= 1e-8
+    assert b["latency_ms"]["sharded_step"]["calls"] >= 200 and b["solver"]["non_optimal"] == 0
+    # a ragged split: 10 agents over 3 ranks (4 + 4 + 2), the last block padded for the collective, never solved
+    out = _run_bench(["--gpus", "3", "--scaling", "strong", "--config", "c0", "--steps", "5", "--warmup", "2", "--no-extra", "--no-latency"],
+                     {"LSCQP_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    b = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert b["n_gpus"] == 3 and b["config"]["agents_per_gpu"] == 4 and b["config"]["agents_solved_per_step_all_ranks"] == 10
+    assert b["parity_all_ranks"]["compared"] == 10 and b["parity_all_ranks"]["max_abs_dx"] <= 1e-6
+
+
+@pytest.mark.gpu
+def test_single_process_communicator_bench():
+    """--single-process: the same split driven by ONE process through lscqp_comm (ncclCommInitAll + lscqp_solve_batch_sharded_device +
+    lscqp_allgather); one device here, the code path is the one G devices take."""
+    out = _run_bench(["--single-process", "--gpus", "1", "--config", "c2", "--steps", "10", "--warmup", "3", "--no-latency"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    b = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert b["n_gpus"] == 1 and b["scaling"] == "strong" and b["config"]["agents_total"] == 512 and "rccl" in b["config"]["collective_backend"]
+    assert b["solver"]["non_optimal"] == 0 and b["parity_all_ranks"]["max_abs_dx"] <= 1e-6 and b["parity_all_ranks"]["max_rel_dobj"] <= 1e-8
+    import torch
+
+    if torch.cuda.device_count() == 1:
+        out = _run_bench(["--single-process", "--gpus", "2", "--config", "c2", "--steps", "2", "--warmup", "1"], timeout=300)
+        assert out.returncode != 0 and "needs 2 devices" in out.stderr
