@@ -35,6 +35,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK = 78.6e12  # flop/s, MI355X fp64 vector (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+
+
+def valu_roofline(sol, n, n_obs, iterations, kernel_ms):
+    """The roof that binds: fp64 vector work of ONE launch = sum over its instances of
+    flops_fixed + iterations x flops_per_iteration + flops_last_pass, where the iterations are the kernel's own count of THIS run
+    (lscqp_info.iterations) and the per-iteration figure is read off the selected kernel instance's machine code at build time
+    (lscqp_instance_work), over the launch duration measured in this run; against MI355X's 78.6 TFLOP/s fp64 vector peak."""
+    w = sol.instance_work(n, n_obs)
+    it = np.asarray(iterations, dtype=np.float64)
+    flops = float((w["flops_fixed"] + w["flops_last_pass"] + it * w["flops_per_iteration"]).sum())
+    rate = flops / (kernel_ms * 1e-3)
+    # the launch lasts as long as its slowest instance: that wavefront's own issue rate (VALU instructions per second of the launch)
+    crit = w["valu_insts_fixed"] + float(it.max()) * w["valu_insts_per_iteration"]
+    return {"bound": "fp64 vector ALU", "fp64_flops_per_launch": flops, "fp64_flops_per_s": rate, "peak_flops_per_s": FP64_VECTOR_PEAK,
+            "frac_of_78.6e12": rate / FP64_VECTOR_PEAK, "kernel": w["kernel"], "wavefronts_per_qp": w["wavefronts"],
+            "flops_per_iteration": w["flops_per_iteration"], "valu_insts_per_iteration_per_wavefront": w["valu_insts_per_iteration"],
+            "iterations_sum": float(it.sum()), "iterations_max": int(it.max()),
+            "slowest_wavefront_valu_insts_per_us": crit / (kernel_ms * 1e3),
+            "source": "iterations: lscqp_info of this run; per-iteration counts: lscqp_instance_work (machine code of the instance, build time)"}
 
 
 def make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed, style, warm_steps):
@@ -200,6 +220,7 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
            "kernel_ms": ms, "qp_per_s": N / (ms * 1e-3), "latency_ms": {"p50": p50, "p99": p99, "calls": nlat},
            "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
            "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()),
+           "roofline_valu": valu_roofline(sol, N, sw.n_obs, info["iterations"], ms) if cfg["precision"] == "f64" else None,
            "non_optimal": int((st != 0).sum()), "second_pass": int(((info["flags"] & api.INFO_REPAIRED) != 0).sum()),
            "floor_accepted": int(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum())}
     if O is not None:
@@ -852,6 +873,7 @@ def main():
             "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (M, dim, "float" if args.precision == "mixed" else "double"), "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N, "valu": valu,
         },
+        "roofline_valu": valu_roofline(sol, N, n_obs_eff, iters, kernel_ms) if args.precision == "f64" else None,
         "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
                        "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99)),
                        "host_pointers_batch_p50": float(np.percentile(lath, 50)), "host_pointers_batch_p99": float(np.percentile(lath, 99)),

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define LSCQP_VERSION_MAJOR 0
-#define LSCQP_VERSION_MINOR 7
+#define LSCQP_VERSION_MINOR 8
 
 /* ---- return codes of the API calls themselves (misuse / runtime errors) ---- */
 enum {
@@ -651,6 +651,74 @@ int64_t lscqp_plan_graph_nodes(lscqp_plan plan); /* nodes of the captured graph,
  * blocks, one ncclBroadcast per owner otherwise).  Asynchronous: lscqp_comm_synchronize waits for all devices.  Waypoints are
  * written per plan before the call, as for lscqp_plan_step. */
 int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_graph);
+
+/* ---- work counters of a launch (the fp64-VALU figure next to the HBM one) -----------------------------
+ *
+ * The kernel is bound by fp64 vector issue, not by HBM; the figure that goes with that roof is
+ * "iterations x flops per iteration".  The iterations are the kernel's own count (lscqp_info.iterations, per instance); the flops
+ * of one pass through the iteration body are a property of the kernel instance's machine code and are read off it when the library
+ * is built (lsc_dr_planner_amd/isa_work.py: fp64 vector instructions between the position markers of the loop body; FMA = 2 flops
+ * per lane, any other fp64 arithmetic instruction 1; x 64 lanes x wavefronts per instance).  lscqp_instance_work reports them for
+ * the instance a launch of n QPs with n_obs_max obstacles selects -- the same selection lscqp_solve_batch_device makes.
+ *   flops of an instance that ran `it` iterations  =  flops_fixed + it * flops_per_iteration + flops_last_pass
+ * (the pass that detects convergence runs the residual pass and the test only).  These are the lane-flops the SIMDs EXECUTE,
+ * masked lanes and the in-line blocks most iterations skip included (about 12 % above the PMC instruction count), i.e. an upper
+ * bound of the useful work and the quantity the 78.6 TFLOP/s fp64 vector peak of MI355X is about. */
+typedef struct lscqp_work {
+    double flops_fixed;              /* prologue + epilogue */
+    double flops_per_iteration;
+    double flops_last_pass;
+    double f64_insts_per_iteration;  /* per wavefront */
+    double valu_insts_per_iteration; /* per wavefront, all vector-ALU instructions */
+    double lds_insts_per_iteration;  /* per wavefront */
+    double valu_insts_fixed;         /* per wavefront: prologue + epilogue + last pass */
+    int32_t wavefronts;              /* per QP */
+    int32_t nslot;                   /* LSC row slots per lane */
+    int32_t max_obstacles;           /* capacity of the instance */
+    int32_t lds_bytes;               /* per workgroup */
+    char kernel[96];                 /* "lscqp_pdip_kernel<M,DIM,ES,NSLOT,W,FT>" */
+} lscqp_work;
+int lscqp_instance_work(lscqp_handle h, int64_t n, int32_t n_obs_max, lscqp_work* out);
+
+/* ---- failure diagnostics (the reference's answer to a failed QP) -----------------------------------------------------------
+ *
+ * When CPLEX fails the reference exports the model as an LP file and runs the conflict refiner to NAME the rows that cannot hold
+ * together (src/traj_optimizer.cpp:103-137; :45-52 with param.log_solver), and its caller prints every SFC / LSC row that the
+ * fallback trajectory `initial_traj` violates, with obstacle, segment, control point and margin (src/traj_planner.cpp:767-797).
+ *   lscqp_diagnose[_device]  evaluates every row of the reference's model (populatebyrow, src/traj_optimizer.cpp:238-511) on the
+ *                            trajectories x [n][nv] (reference variable order, world frame): per row family the largest violation
+ *                            (<= 0: satisfied, then the smallest margin negated) and the number of rows violated by more than `tol`,
+ *                            plus the most violated row by name.  On initial_traj it IS the caller's debug loop; on the x_out of a
+ *                            non-OPTIMAL instance (the iterate the solver stopped at) it names the rows that instance cannot satisfy.
+ *                            Units are the reference's: metres for bounds / SFC / LSC (normal-weighted) / communication rows,
+ *                            m/s and m/s^2 for the dynamic limits, the row's own scaling for the equalities.
+ *   lscqp_dump_instance      one instance as a CPLEX LP file, rows and variable names (x_m_i, y_m_i, z_m_i) as populatebyrow
+ *                            creates them -- what cplex.exportModel writes to log/QPmodel_trajOpt.lp; HOST pointers, rows / sfc of
+ *                            THIS instance ([n_obs*P] rows, [M] boxes); needs no device.
+ *   lscqp_row_family_name    "SFC", "LSC", ... for messages. */
+enum {
+    LSCQP_ROW_BOUND = 0,         /* variable box = world box (:252-265) */
+    LSCQP_ROW_SFC = 1,           /* corridor faces (:372-397) */
+    LSCQP_ROW_LSC = 2,           /* LSC / BVC half-spaces (:399-437); obstacle = oi */
+    LSCQP_ROW_VEL = 3,           /* :448-453 */
+    LSCQP_ROW_ACC = 4,           /* :462-471 */
+    LSCQP_ROW_COMM_PAIR = 5,     /* :480-489; obstacle = mi (the segment whose first point the row ties to) */
+    LSCQP_ROW_COMM_WAYPOINT = 6, /* :492-498 */
+    LSCQP_ROW_EQUALITY = 7,      /* initial state, joins, end stop (:318-368, 502-511) */
+    LSCQP_ROW_FAMILIES = 8
+};
+typedef struct lscqp_diag { /* 128 bytes */
+    double worst[LSCQP_ROW_FAMILIES];    /* largest violation per family (0 for a family without rows) */
+    int32_t violated[LSCQP_ROW_FAMILIES]; /* rows violated by more than tol */
+    double violation;                     /* of the most violated row overall ... */
+    int32_t family, obstacle, segment, point, axis, reserved; /* ... and its name; -1 where a field does not apply */
+} lscqp_diag;
+int lscqp_diagnose_device(lscqp_handle h, int64_t n, const lscqp_header* d_hdr, const lscqp_row* d_rows, const uint64_t* d_row_offsets,
+                          const lscqp_box* d_sfc, const double* d_x, double tol, lscqp_diag* d_out, void* stream);
+int lscqp_diagnose(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets, const lscqp_box* sfc,
+                   const double* x, double tol, lscqp_diag* out);
+int lscqp_dump_instance(lscqp_handle h, const lscqp_header* hdr, const lscqp_row* rows, const lscqp_box* sfc, const char* path);
+const char* lscqp_row_family_name(int32_t family);
 
 /* Number of inequality rows populatebyrow adds for an agent with n_obs obstacles (SFC + LSC + velocity +
  * acceleration + communication, src/traj_optimizer.cpp:370-500), not counting rows dropped for tiny normals. */

@@ -45,6 +45,11 @@ INFO_DTYPE = np.dtype([("iterations", "i4"), ("flags", "i4"), ("res_primal", "f8
                        ("gap", "f8")])
 assert HEADER_DTYPE.itemsize == 256 and ROW_DTYPE.itemsize == 32 and BOX_DTYPE.itemsize == 48
 assert INFO_DTYPE.itemsize == 32
+# lscqp_diag (failure diagnostics): per row family the largest violation / count, and the most violated row by name
+ROW_BOUND, ROW_SFC, ROW_LSC, ROW_VEL, ROW_ACC, ROW_COMM_PAIR, ROW_COMM_WAYPOINT, ROW_EQUALITY, ROW_FAMILIES = range(9)
+DIAG_DTYPE = np.dtype([("worst", "f8", 8), ("violated", "i4", 8), ("violation", "f8"), ("family", "i4"), ("obstacle", "i4"),
+                       ("segment", "i4"), ("point", "i4"), ("axis", "i4"), ("reserved", "i4")])
+assert DIAG_DTYPE.itemsize == 128
 
 
 class ClassDesc(C.Structure):
@@ -55,6 +60,13 @@ class ClassDesc(C.Structure):
         ("communication_range", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
         ("max_iter", C.c_int32), ("precision", C.c_int32), ("tol", C.c_double), ("warm_start", C.c_int32), ("reserved_", C.c_int32),
     ]
+
+
+class Work(C.Structure):  # lscqp_work
+    _fields_ = [("flops_fixed", C.c_double), ("flops_per_iteration", C.c_double), ("flops_last_pass", C.c_double),
+                ("f64_insts_per_iteration", C.c_double), ("valu_insts_per_iteration", C.c_double), ("lds_insts_per_iteration", C.c_double),
+                ("valu_insts_fixed", C.c_double), ("wavefronts", C.c_int32), ("nslot", C.c_int32), ("max_obstacles", C.c_int32),
+                ("lds_bytes", C.c_int32), ("kernel", C.c_char * 96)]
 
 
 class LscqpError(RuntimeError):
@@ -192,6 +204,16 @@ def lib():
         L.lscqp_plan_group_step.argtypes = [vp, vp, C.c_int32]
         L.lscqp_last_error.restype = C.c_char_p
         L.lscqp_version.restype = C.c_char_p
+        L.lscqp_instance_work.restype = C.c_int
+        L.lscqp_instance_work.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(Work)]
+        L.lscqp_diagnose.restype = C.c_int
+        L.lscqp_diagnose.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.c_double, vp]
+        L.lscqp_diagnose_device.restype = C.c_int
+        L.lscqp_diagnose_device.argtypes = [vp, C.c_int64] + [vp] * 5 + [C.c_double, vp, vp]
+        L.lscqp_dump_instance.restype = C.c_int
+        L.lscqp_dump_instance.argtypes = [vp, vp, vp, vp, C.c_char_p]
+        L.lscqp_row_family_name.restype = C.c_char_p
+        L.lscqp_row_family_name.argtypes = [C.c_int32]
         _lib = L
     return _lib
 
@@ -207,6 +229,7 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_map_download", "lscqp_map_prepare", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
                     "lscqp_plan_create", "lscqp_plan_destroy", "lscqp_plan_reset", "lscqp_plan_buffer", "lscqp_plan_upload", "lscqp_plan_download",
                     "lscqp_plan_step", "lscqp_plan_step_graph", "lscqp_plan_graph_nodes", "lscqp_plan_group_step",
+                    "lscqp_instance_work", "lscqp_diagnose", "lscqp_diagnose_device", "lscqp_dump_instance", "lscqp_row_family_name",
                     "lscqp_last_error", "lscqp_version"]
 
 
@@ -511,6 +534,14 @@ class Solver:
     def max_obstacles(self):
         return lib().lscqp_max_obstacles(self._h)
 
+    def instance_work(self, n, n_obs_max):
+        """lscqp_instance_work: work counters (from the machine code) of the kernel instance a launch of n QPs would select."""
+        w = Work()
+        rc = lib().lscqp_instance_work(self._h, int(n), int(n_obs_max), C.byref(w))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        return {f: (getattr(w, f).decode() if f == "kernel" else getattr(w, f)) for f, _ in Work._fields_}
+
     def algorithmic_bytes(self, n_obs):
         return lib().lscqp_algorithmic_bytes(self._h, n_obs)
 
@@ -568,6 +599,40 @@ class Solver:
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
         return dict(x=x, obj=obj, status=status, info=info, devices_used=used.value)
+
+    # ---- failure diagnostics (include/lscqp.h) -------------------------------------------------------------
+    def diagnose_host(self, hdr, rows, row_offsets, sfc, x, tol=1e-9):
+        """lscqp_diagnose: every row of the reference's model evaluated on the trajectories x (n, nv) -> DIAG_DTYPE[n]."""
+        n = len(hdr)
+        hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE)
+        out = np.zeros(n, DIAG_DTYPE)
+        if rows is not None:
+            rows = self.rows_in_format(rows)
+            row_offsets = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+        if sfc is not None:
+            sfc = np.ascontiguousarray(sfc, dtype=BOX_DTYPE).reshape(-1)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(n, self.nv)
+
+        def p(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+        rc = lib().lscqp_diagnose(self._h, n, p(hdr), p(rows), p(row_offsets), p(sfc), p(x), float(tol), p(out))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+        return out
+
+    def dump_instance(self, hdr_one, rows_one, sfc_one, path):
+        """lscqp_dump_instance: ONE instance as a CPLEX LP file (what cplex.exportModel writes in the reference); needs no device."""
+        hdr = np.ascontiguousarray(hdr_one, dtype=HEADER_DTYPE).reshape(1)
+        rows = None if rows_one is None else self.rows_in_format(rows_one)
+        sfc = None if sfc_one is None else np.ascontiguousarray(sfc_one, dtype=BOX_DTYPE).reshape(-1)
+
+        def p(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+        rc = lib().lscqp_dump_instance(self._h, p(hdr), p(rows), p(sfc), os.fsencode(path))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     def solve_sharded_device(self, comm, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, d_x_init=None, retry=False):
         """lscqp_solve_batch_sharded_device: lists of per-device torch CUDA tensors (entry g lives on device g of `comm`), n[g] agents on

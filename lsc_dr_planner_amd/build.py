@@ -90,14 +90,58 @@ def build(force=False, verbose=False, jobs=None):
     gen_src = os.path.join(CSRC, "lscgen.hip")
     if force or _newer(gen_o, hdrs + [gen_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", gen_src, "-o", gen_o])
+    diag_o = os.path.join(OBJ, "lscqp_diag.o")
+    objs.append(diag_o)
+    diag_src = os.path.join(CSRC, "lscqp_diag.hip")
+    if force or _newer(diag_o, hdrs + [diag_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", diag_src, "-o", diag_o])
     if tasks:
         with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
             for msg in ex.map(_run, tasks):
                 if verbose and msg:
                     sys.stderr.write(msg)
+    # work counters of every instance, read off its machine code (isa_work.py) -> one small generated host TU
+    work_o = os.path.join(OBJ, "lscqp_work_table.o")
+    objs.append(work_o)
+    inst_objs = [o for o in objs if os.path.basename(o).startswith("inst_")]
+    if force or _newer(work_o, inst_objs + [os.path.join(HERE, "isa_work.py"), os.path.abspath(__file__)]):
+        _work_table(inst_objs, work_o, jobs)
+        tasks.append("work table")
     if tasks or not os.path.exists(LIB):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
     return LIB
+
+
+def _work_table(inst_objs, work_o, jobs=None):
+    import json
+    import tempfile
+
+    sys.path.insert(0, HERE)
+    import isa_work
+
+    def one(o):
+        js = o[:-2] + ".work.json"
+        if not _newer(js, [o, os.path.join(HERE, "isa_work.py")]):
+            return json.load(open(js))
+        with tempfile.TemporaryDirectory() as td:
+            w = isa_work.of_object(o, td)
+        json.dump(w, open(js, "w"))
+        return w
+
+    with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
+        works = list(ex.map(one, inst_objs))
+    src = os.path.join(OBJ, "lscqp_work_table.cpp")
+    with open(src, "w") as f:
+        f.write("// generated by lsc_dr_planner_amd/build.py from the instances' machine code (isa_work.py); per wavefront\n")
+        f.write("struct Row { int M, D, E, S, W, X; double t[12]; };\nstatic const Row kRows[] = {\n")
+        for o, w in zip(inst_objs, works):
+            key = os.path.basename(o)[5:-2].split("_")
+            vals = [w["%s_%s" % (a, b)] for a in ("iter", "last", "fixed") for b in ("fma_f64", "other_f64", "valu", "lds")]
+            f.write("    {%s, {%s}},\n" % (", ".join(key), ", ".join(str(v) for v in vals)))
+        f.write("};\nextern \"C\" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out12) {\n"
+                "    for (const Row& r : kRows)\n        if (r.M == M && r.D == D && r.E == E && r.S == S && r.W == W && r.X == X) {\n"
+                "            for (int i = 0; i < 12; i++) out12[i] = r.t[i];\n            return 0;\n        }\n    return 1;\n}\n")
+    _run(["g++", "-O1", "-fPIC", "-c", src, "-o", work_o])
 
 
 if __name__ == "__main__":

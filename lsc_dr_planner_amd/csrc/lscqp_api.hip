@@ -155,6 +155,7 @@ struct lscqp_solver {
     // staging of the host-pointer entry points: device buffer + pinned mirror + private stream per concurrent call
     // (one H2D and one D2H per host-pointer solve instead of eight small copies; lscqp_staging.hpp)
     lscqp::StagePool* pool = nullptr;
+    uint64_t generation = 0;  // bumped by lscqp_update: holders of state derived from the class (a captured plan graph) re-derive it
 };
 
 static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
@@ -224,6 +225,9 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
 }
 
 extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h) { return &h->desc; }  // for lscplan.hip
+extern "C" uint64_t lscqp_handle_generation_(lscqp_handle h) { return h->generation; }
+// (library-internal, lscqp_comm.hip) does a batch of this shape have a second chance on the instance with the other elimination order?
+extern "C" int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max);
 
 static inline size_t row_bytes(lscqp_handle h) { return h->dev.rows_f32 ? sizeof(lscqp_row_f32) : sizeof(lscqp_row); }
 
@@ -247,6 +251,7 @@ int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
     lscqp_solver tmp = *h;
     int rc = derive(&tmp, desc);
     if (rc != LSCQP_OK) return rc;
+    tmp.generation = h->generation + 1;
     *h = tmp;  // (the staging pool pointer travels with the copy)
     return LSCQP_OK;
 }
@@ -269,6 +274,41 @@ int lscqp_max_obstacles(lscqp_handle h) {
     return best;
 }
 int lscqp_uses_sfc(lscqp_handle h) { return h ? (h->desc.use_sfc ? 1 : 0) : -1; }
+
+// Work counters of the kernel instance a launch would select (include/lscqp.h): the per-wavefront instruction counts come from the
+// table the build reads off each instance's machine code (lsc_dr_planner_amd/isa_work.py -> lscqp_work_table_, generated TU).
+extern "C" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out12);
+int lscqp_instance_work(lscqp_handle h, int64_t n, int32_t n_obs_max, lscqp_work* out) {
+    if (!h || !out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
+    const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
+    int n_cu = cu_count();
+    if (n_cu <= 0) n_cu = 256;  // (no device in this process: MI355X's CU count decides the small-batch policy)
+    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
+    if (!inst) return fail(LSCQP_ERR_UNSUPPORTED, "no compiled kernel instance for this launch");
+    const int G = 64 * inst->waves / (6 * inst->M - 3) > 0 ? 64 * inst->waves / (6 * inst->M - 3) : 1;
+    const int nslot = inst->max_obs / G;
+    double t[12];
+    if (lscqp_work_table_(inst->M, inst->dim, inst->es, nslot, inst->waves, inst->mixed, t) != 0)
+        return fail(LSCQP_ERR_UNSUPPORTED, "the build holds no instruction counts for this kernel instance");
+    memset(out, 0, sizeof *out);
+    const double lanes = 64.0 * inst->waves;
+    // t: iter {fma, other, valu, lds}, last {..}, fixed {..} -- instructions per wavefront
+    out->flops_per_iteration = lanes * (2.0 * t[0] + t[1]);
+    out->flops_last_pass = lanes * (2.0 * t[4] + t[5]);
+    out->flops_fixed = lanes * (2.0 * t[8] + t[9]);
+    out->f64_insts_per_iteration = t[0] + t[1];
+    out->valu_insts_per_iteration = t[2];
+    out->lds_insts_per_iteration = t[3];
+    out->valu_insts_fixed = t[10] + t[6];
+    out->wavefronts = inst->waves;
+    out->nslot = nslot;
+    out->max_obstacles = inst->max_obs;
+    out->lds_bytes = (int32_t)inst->lds;
+    snprintf(out->kernel, sizeof out->kernel, "lscqp_pdip_kernel<%d,%d,%s,%d,%d,%s>", inst->M, inst->dim, inst->es ? "true" : "false", nslot,
+             inst->waves, inst->mixed ? "float" : "double");
+    return LSCQP_OK;
+}
 int lscqp_row_bytes(lscqp_handle h) { return h ? (int)row_bytes(h) : -1; }
 
 int lscqp_generate_lsc_device(lscqp_handle h, int64_t n_agents, int32_t n_obs, int64_t first_agent, const double* d_traj,
@@ -713,8 +753,13 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     return LSCQP_OK;
 }
 
+int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max) {
+    const Inst* first = find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count());
+    return (first && other_order_instance(first, n_obs_max)) ? 1 : 0;
+}
+
 const char* lscqp_last_error(void) { return g_err.c_str(); }
 
-const char* lscqp_version(void) { return "lscqp 0.7 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics, whole-replan chain + hipGraph, sharded over a communicator)"; }
+const char* lscqp_version(void) { return "lscqp 0.8 (gfx950, fp64 / mixed-precision PDIP, 1-4 wavefronts per QP; constraint generation LSC/CLSC/BVC, corridors, goal LP, post-solve step, safety metrics, whole-replan chain + hipGraph, sharded over a communicator, failure diagnostics)"; }
 
 }  // extern "C"

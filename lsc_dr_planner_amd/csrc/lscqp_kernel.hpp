@@ -221,6 +221,10 @@ __device__ __forceinline__ bool pivot_ok(FT d) {
         status = 100 + (k);            \
         break;                         \
     }
+// Position markers for the build's instruction count (lsc_dr_planner_amd/isa_work.py reads the work of one iteration off the
+// machine code: SURVEY.md 8d's fp64-VALU figure): s_nop 13 = top of the iteration body, s_nop 12 = behind the convergence test
+// (where the last, partial pass leaves), s_nop 14 = end of the body.  The compiler itself emits s_nop 0..7 only; ~14 idle cycles each.
+#define LSCQP_MARK(k) asm volatile("s_nop " #k)
 #ifdef LSCQP_PHASE_TIMING
 __device__ unsigned long long lscqp_dbg_cycles[16];
 #define LSCQP_T(slot)                                                     \
@@ -968,6 +972,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     if (status != LSCQP_STATUS_INFEASIBLE)
         for (it = 0; it < cls.max_iter; it++) {
             LSCQP_T(0);
+            LSCQP_MARK(13);
             LSCQP_STOP(1)
             // ============ pass 1: residuals, weights, per-cp blocks =========================================
 #pragma unroll
@@ -1186,6 +1191,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 continue;
             }
 #endif
+            LSCQP_MARK(12);
             LSCQP_T(2);
             LSCQP_STOP(3)
 
@@ -1941,6 +1947,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 restore = status == LSCQP_STATUS_OPTIMAL;
                 break;
             }
+            LSCQP_MARK(14);
             LSCQP_T(9);
             LSCQP_STOP(10)
         }

@@ -48,7 +48,11 @@ struct lscqp_map_s {
     // staging of the host-pointer corridor call: a pinned buffer + device mirror + private stream per concurrent call (the map
     // handle is shared by all agents' CollisionConstraints: two threads must never share a staging buffer)
     lscqp::StagePool* pool = nullptr;
+    int device = 0;           // the device the grids live on: a plan on another device must not be handed this map
+    uint64_t generation = 0;  // bumped whenever the free-space table is rebuilt: captured graphs hold its margin by value
 };
+extern "C" int lscqp_map_device_(lscqp_map mp) { return mp->device; }
+extern "C" uint64_t lscqp_map_generation_(lscqp_map mp) { return mp->generation; }
 
 namespace lscsfc {
 
@@ -990,6 +994,7 @@ int lscqp_map_create(const double* boxes, int64_t n_boxes, const double* world_m
         return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
     lscqp_map_s* mp = new lscqp_map_s();
     mp->pool = new lscqp::StagePool();
+    (void)hipGetDevice(&mp->device);
     mp->res = resolution;
     int64_t nvox = 1;
     for (int k = 0; k < 3; k++) {
@@ -1103,6 +1108,7 @@ int lscqp_map_prepare(lscqp_map mp, double max_radius) {
         return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("hipMalloc(free-space table): ") + hipGetErrorString(e)).c_str());
     }
     mp->sat_margin = 0;
+    mp->generation++;
     // what the float arithmetic of the exact test can lose against the cell bound: the sample, the cell centre and centre -+ half a cell
     // are floats of the world's magnitude (half an ulp each; 7.6e-6 per ulp at 100 m)
     double wabs = 0;
@@ -1116,8 +1122,8 @@ int lscqp_map_prepare(lscqp_map mp, double max_radius) {
     hipLaunchKernelGGL(lscsfc::prefix_axis_kernel, dim3((unsigned)((ly + 255) / 256)), dim3(256), 0, 0, ly, ny, (int64_t)nx, (int64_t)nx, (int64_t)1, (int64_t)nx * ny, mp->d_sat);
     hipLaunchKernelGGL(lscsfc::prefix_axis_kernel, dim3((unsigned)((lz + 255) / 256)), dim3(256), 0, 0, lz, nz, (int64_t)nx * ny, lz, (int64_t)1, (int64_t)0, mp->d_sat);
     if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
-        (void)hipFree(mp->d_sat);
-        mp->d_sat = nullptr;
+        // the table stays allocated (a captured plan graph may still hold the pointer) but serves nobody: margin 0, and the bumped
+        // generation makes every plan drop its graph before the next replan
         return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("free-space table: ") + hipGetErrorString(e)).c_str());
     }
     mp->sat_margin = max_radius;

@@ -54,6 +54,9 @@ public:
     int lastDevicesUsed() const { return last_devices_used; }
     const std::vector<double>& lastRawSolution() const { return raw_x; }
     int lastIterations() const { return last_iterations; }
+    // the message of the last failed solve: which row of the model the solver could not satisfy (family, oi, m, i, violation) --
+    // what the reference's conflict refiner prints (src/traj_optimizer.cpp:105-135); empty after a successful solve
+    const std::string& lastConflict() const { return last_conflict; }
 
 private:
     Param param;
@@ -64,6 +67,7 @@ private:
     lscqp_handle handle = nullptr;
     std::vector<double> raw_x;
     int last_iterations = 0;
+    std::string last_conflict;
     int last_devices_used = 1;
     static lscqp_comm& communicator() {
         static lscqp_comm c = nullptr;

@@ -4,6 +4,7 @@
 #include <traj_optimizer.hpp>
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -177,10 +178,39 @@ void TrajOptimizer::solveBatch(const std::vector<BatchItem>& items, std::vector<
     if (rc != LSCQP_OK) throw std::runtime_error(std::string("[TrajOptimizer] ") + lscqp_last_error());
     results.resize(nq);
     ok.assign(nq, false);
+    last_conflict.clear();
+    const std::string QPmodel_path = param.package_path + "/log/QPmodel_trajOpt.lp";  // src/traj_optimizer.cpp:45
     for (size_t q = 0; q < nq; q++) {
         ok[q] = (status[q] == LSCQP_STATUS_OPTIMAL);
         results[q] = unpack(&raw_x[q * nv], obj[q]);
         last_iterations = info[q].iterations;
+        const lscqp_row* rq = rows.data() + off[q];
+        const lscqp_box* bq = boxes.empty() ? nullptr : boxes.data() + q * M;
+        // the reference exports the model with param.log_solver (:47-48) and, whatever that flag says, when the solve fails (:103, 147)
+        if (param.log_solver || !ok[q]) (void)lscqp_dump_instance(handle, &hdr[q], rq, bq, QPmodel_path.c_str());
+        if (!ok[q]) {
+            // ... and names the rows that cannot hold together (conflict refiner, :105-135).  Here: every row of the model evaluated
+            // on the iterate the interior-point method stopped at -- the rows it could not satisfy are the members of the conflict.
+            lscqp_diag dg;
+            const uint64_t off1[2] = {0, (uint64_t)hdr[q].n_obs * (uint64_t)(M * (n + 1))};
+            if (lscqp_diagnose(handle, 1, &hdr[q], rq, off1, bq, &raw_x[q * nv], 1e-6, &dg) == LSCQP_OK) {
+                char buf[320];
+                const bool infeasible = status[q] == LSCQP_STATUS_INFEASIBLE;
+                if (dg.family >= 0 && dg.violation > 1e-6)
+                    std::snprintf(buf, sizeof buf,
+                                  "[TrajOptimizer] %s at mav %d (status %d, %d iterations). Conflict: %s row, oi: %d, m: %d, i: %d, axis: %d, "
+                                  "violated by %g; violated rows SFC %d, LSC %d, vel %d, acc %d, comm %d",
+                                  infeasible ? "No solution" : "Solver failure", items[q].agent->id, (int)status[q], (int)info[q].iterations,
+                                  lscqp_row_family_name(dg.family), (int)dg.obstacle, (int)dg.segment, (int)dg.point, (int)dg.axis, dg.violation,
+                                  (int)dg.violated[LSCQP_ROW_SFC], (int)dg.violated[LSCQP_ROW_LSC], (int)dg.violated[LSCQP_ROW_VEL],
+                                  (int)dg.violated[LSCQP_ROW_ACC], (int)(dg.violated[LSCQP_ROW_COMM_PAIR] + dg.violated[LSCQP_ROW_COMM_WAYPOINT]));
+                else
+                    std::snprintf(buf, sizeof buf, "[TrajOptimizer] Solver failure at mav %d (status %d, %d iterations); no row of the last iterate is violated",
+                                  items[q].agent->id, (int)status[q], (int)info[q].iterations);
+                last_conflict = buf;
+                std::fprintf(stderr, "%s\n", buf);  // ROS_ERROR_STREAM in the reference
+            }
+        }
     }
 }
 

@@ -140,8 +140,17 @@ static int scenario_infeasible() {
         opt.solve(a, cons, init, true);
         printf("{\"scenario\": \"infeasible\", \"thrown\": \"nothing\"}\n");
     } catch (PlanningReport r) {
-        // the caller's fail-safe (src/traj_planner.cpp:767-797): result.desired_traj = initial_traj
-        printf("{\"scenario\": \"infeasible\", \"thrown\": \"%s\"}\n", r == PlanningReport::QPFAILED ? "QPFAILED" : "other");
+        // the caller's fail-safe (src/traj_planner.cpp:767-797): result.desired_traj = initial_traj.  Before throwing the optimizer has
+        // exported the model (log/QPmodel_trajOpt.lp under param.package_path, src/traj_optimizer.cpp:45,103) and named the conflict.
+        FILE* lp = fopen((param.package_path + "/log/QPmodel_trajOpt.lp").c_str(), "r");
+        long lp_bytes = 0;
+        if (lp) {
+            fseek(lp, 0, SEEK_END);
+            lp_bytes = ftell(lp);
+            fclose(lp);
+        }
+        printf("{\"scenario\": \"infeasible\", \"thrown\": \"%s\", \"conflict\": \"%s\", \"lp_bytes\": %ld}\n",
+               r == PlanningReport::QPFAILED ? "QPFAILED" : "other", opt.lastConflict().c_str(), lp_bytes);
     }
     return 0;
 }

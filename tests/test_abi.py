@@ -131,3 +131,22 @@ def test_next_row_entry_points_validate_and_accept_empty_batches(api):
         wmin, wmax = (C.c_double * 3)(-1, -1, 0), (C.c_double * 3)(1, 1, 1)
         assert L.lscqp_map_create(p, 0, wmin, wmax, 0.1, 1.0, C.byref(hm)) == api.ERR_NO_DEVICE
     s.close()
+
+
+def test_instance_work_counters_come_with_the_library(api):
+    """lscqp_instance_work (no device needed): the work counters of the kernel instance a launch would select, read off the machine
+    code when the library was built; every compiled fp64 shape has them and they scale as the kernel does."""
+    s5 = api.Solver(api.make_desc(M=5, dim=3))
+    small, big = s5.instance_work(64, 20), s5.instance_work(4096, 20)
+    assert small["wavefronts"] == 2 and big["wavefronts"] == 1 and "lscqp_pdip_kernel<5,3,true" in small["kernel"]
+    for w in (small, big):
+        assert w["flops_per_iteration"] > 5 * w["flops_last_pass"] > 0 and w["flops_fixed"] > 0
+        assert 2000 < w["f64_insts_per_iteration"] < w["valu_insts_per_iteration"] < 20000
+        # flops = 64 lanes x wavefronts x (2 x FMA + other fp64 instructions): between 1x and 2x the instruction count
+        lanes = 64 * w["wavefronts"]
+        assert lanes * w["f64_insts_per_iteration"] < w["flops_per_iteration"] < 2 * lanes * w["f64_insts_per_iteration"]
+    s10 = api.Solver(api.make_desc(M=10, dim=3))
+    w10 = s10.instance_work(128, 40)
+    assert w10["wavefronts"] == 4 and w10["flops_per_iteration"] > 2 * small["flops_per_iteration"] and w10["lds_bytes"] > 100000
+    with pytest.raises(api.LscqpError):
+        s5.instance_work(64, 500)  # no instance holds 500 obstacles

@@ -19,8 +19,8 @@ def shim_exe(api):
     return SB.build()
 
 
-def run(exe, scenario):
-    out = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120)
+def run(exe, scenario, cwd=None):
+    out = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120, cwd=cwd)
     assert out.returncode == 0, out.stderr
     # (RCCL prints a version banner on stdout when a communicator is initialised: only the JSON lines are the driver's)
     return [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -89,8 +89,16 @@ def test_shim_matches_oracle(shim_exe, oracle):
 
 
 @pytest.mark.gpu
-def test_qpfailed_is_thrown(shim_exe):
-    assert run(shim_exe, "infeasible")[0]["thrown"] == "QPFAILED"
+def test_qpfailed_is_thrown(shim_exe, tmp_path):
+    """Failure contract of TrajOptimizer::solve (reference src/traj_optimizer.cpp:103-152): QPFAILED is thrown, the model has been
+    exported as an LP file under package_path/log, and the conflict is named -- here the LSC row `x >= 50` that no point of the
+    world satisfies."""
+    os.makedirs(tmp_path / "log")
+    r = run(shim_exe, "infeasible", cwd=str(tmp_path))[0]
+    assert r["thrown"] == "QPFAILED"
+    assert "No solution at mav" in r["conflict"] and "LSC row, oi: 0" in r["conflict"] and r["lp_bytes"] > 5000
+    lp = open(tmp_path / "log" / "QPmodel_trajOpt.lp").read()
+    assert "Subject To" in lp and "x_4_5" in lp and lp.rstrip().endswith("End")
 
 
 @pytest.mark.gpu
