@@ -26,6 +26,9 @@
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h);
+extern "C" uint64_t lscqp_handle_generation_(lscqp_handle h);
+extern "C" int lscqp_map_device_(lscqp_map mp);
+extern "C" uint64_t lscqp_map_generation_(lscqp_map mp);
 extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                                const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                                const double* d_downwash, const double* d_goal_all, lscqp_row* d_rows_out, int32_t n_obs_total,
@@ -34,6 +37,7 @@ extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int
 namespace lscplan {
 
 constexpr int kThreads = 64;
+static_assert(kThreads == 64, "prepare_kernel hands data between the lanes of ONE wavefront (initial trajectory read before the prediction overwrites it)");
 
 struct Shape {
     int M, dim, nv, n_obs;
@@ -115,7 +119,9 @@ __global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_re
         double* ow = own + t * P18;
         for (int e = lane; e < P18; e += kThreads) ow[e] = init_at(e / 3, e % 3);
     }
-    // the agent as an obstacle of the others
+    // the agent as an obstacle of the others.  Every lane has finished reading tr[] (init_at above: x_init, own, the corridor seed
+    // points) before any lane overwrites it with the prediction below.
+    __syncthreads();
     const bool keep = s.prediction_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION && !first_replan;
     bool reset = false;
     if (s.reset_threshold > 0) {
@@ -189,6 +195,8 @@ struct lscqp_plan_s {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr;
+    // what the captured graph (and the tight-warm-start clone) was derived from: a later lscqp_update / lscqp_map_prepare bumps these
+    uint64_t h_gen = 0, map_gen = 0;
     std::vector<void*> owned;
 };
 
@@ -230,6 +238,7 @@ int dalloc_pub(lscqp_plan_s* p, int which, size_t count) {
 // the whole replan on `stream`; nothing here synchronises, allocates or touches host memory (capturable)
 int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     const lscplan::Shape& s = p->s;
+    if (s.n_agents == 0) return LSCQP_OK;  // an empty block of a sharded mission (9 agents over 4 devices: 3, 3, 3, 0): nothing to replan
     lscqp_handle h = p->h;
     double* state = (double*)p->buf[LSCQP_PLAN_BUF_STATE];
     double* waypoint = (double*)p->buf[LSCQP_PLAN_BUF_WAYPOINT];
@@ -291,6 +300,25 @@ void drop_graph(lscqp_plan_s* p) {
     p->graph = nullptr;
 }
 
+// The class constants travel to the kernels BY VALUE and the map view (table pointer + margin) likewise, so a captured graph -- and
+// the private WARM_TIGHT clone of the handle -- are snapshots.  lscqp_update(h) (TrajOptimizer::updateParam, src/traj_optimizer.cpp:158-160)
+// or lscqp_map_prepare after the capture would be silently ignored by the replayed graph while the eager chain sees the new values:
+// compare the generation counters before every step, drop the graph and re-derive the clone when they moved.
+int refresh(lscqp_plan_s* p) {
+    const uint64_t hg = lscqp_handle_generation_(p->h), mg = p->map ? lscqp_map_generation_(p->map) : 0;
+    if (hg == p->h_gen && mg == p->map_gen) return LSCQP_OK;
+    drop_graph(p);
+    if (p->own_hq && hg != p->h_gen) {
+        lscqp_class_desc cd = *lscqp_class_desc_of_(p->h);
+        cd.warm_start = LSCQP_WARM_TIGHT;
+        const int rc = lscqp_update(p->hq, &cd);
+        if (rc != LSCQP_OK) return rc;
+    }
+    p->h_gen = hg;
+    p->map_gen = mg;
+    return LSCQP_OK;
+}
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {
@@ -309,8 +337,10 @@ extern "C" {
 
 int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc, const lscqp_agent_param* agents, lscqp_plan* out) {
     if (!h || !desc || !agents || !out) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
-    if (desc->n_agents <= 0 || desc->first_agent < 0 || desc->n_total < desc->first_agent + desc->n_agents)
-        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes (n_agents > 0, n_total >= first_agent + n_agents required)");
+    // (n_agents == 0 is a legal plan: the empty last block of a mission sharded over more devices than ceil(N / G) blocks fill --
+    // it holds the all-agent buffers, takes part in lscqp_plan_group_step's exchange and replans nothing)
+    if (desc->n_agents < 0 || desc->n_total <= 0 || desc->first_agent < 0 || desc->n_total < desc->first_agent + desc->n_agents)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes (n_agents >= 0, n_total > 0, n_total >= first_agent + n_agents required)");
     if (desc->n_obs < 0) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "negative n_obs");
     if (desc->n_obs > lscqp_max_obstacles(h))
         return lscqp_set_error_(LSCQP_ERR_UNSUPPORTED, "n_obs exceeds the largest compiled kernel instance of the shape (lscqp_max_obstacles)");
@@ -342,18 +372,27 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
             if (rc != LSCQP_OK && rc != LSCQP_ERR_UNSUPPORTED) return rc;  // (a map too large for the table: the corridors work without it)
         }
     }
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess) return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    if (map && lscqp_map_device_(map) != cur_dev)
+        return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT,
+                                "the map lives on another device than the plan (create the map with the plan's device current: the corridor "
+                                "kernel dereferences the map's grids)");
     lscqp_plan_s* p = new lscqp_plan_s();
     p->h = h;
     p->hq = h;
     if (desc->tight_warm_start && lscqp_class_desc_of_(h)->warm_start != LSCQP_WARM_TIGHT) {
         lscqp_class_desc cd = *lscqp_class_desc_of_(h);
         cd.warm_start = LSCQP_WARM_TIGHT;
-        if (lscqp_create(&cd, &p->hq) != LSCQP_OK) {
+        const int rc_clone = lscqp_create(&cd, &p->hq);
+        if (rc_clone != LSCQP_OK) {
             delete p;
-            return LSCQP_ERR_INVALID_ARGUMENT;  // (lscqp_create has set the message)
+            return rc_clone;  // (lscqp_create has set the message)
         }
         p->own_hq = true;
     }
+    p->h_gen = lscqp_handle_generation_(h);
+    p->map_gen = map ? lscqp_map_generation_(map) : 0;
     p->map = map;
     p->d = *desc;
     p->s.M = M;
@@ -368,10 +407,7 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
     p->s.prediction_mode = desc->prediction_mode;
     p->s.initial_traj_mode = desc->initial_traj_mode;
     p->s.reset_threshold = desc->reset_threshold;
-    if (hipGetDevice(&p->device) != hipSuccess) {
-        delete p;
-        return lscqp_set_error_(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    }
+    p->device = cur_dev;
     const size_t n = (size_t)desc->n_agents, nt = (size_t)desc->n_total, P = (size_t)M * 6, no = (size_t)desc->n_obs;
     int rc = LSCQP_OK;
     auto ok = [&](int r) { return rc == LSCQP_OK && (rc = r) == LSCQP_OK; };
@@ -479,7 +515,9 @@ int lscqp_plan_download(lscqp_plan p, int32_t which, void* host, uint64_t offset
 int lscqp_plan_step(lscqp_plan p, void* stream) {
     if (!p) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null plan");
     DeviceGuard g(p->device);
-    const int rc = enqueue(p, p->first, (hipStream_t)stream);
+    int rc = refresh(p);
+    if (rc != LSCQP_OK) return rc;
+    rc = enqueue(p, p->first, (hipStream_t)stream);
     if (rc != LSCQP_OK) return rc;
     p->first = false;
     p->steps++;
@@ -489,8 +527,12 @@ int lscqp_plan_step(lscqp_plan p, void* stream) {
 int lscqp_plan_step_graph(lscqp_plan p, void* stream) {
     if (!p) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "null plan");
     // the first replan differs (initializeSFC) and it also warms the kernels' one-time function attributes up: eager
-    if (p->first) return lscqp_plan_step(p, stream);
+    if (p->first || p->s.n_agents == 0) return lscqp_plan_step(p, stream);
     DeviceGuard g(p->device);
+    {
+        const int rc_ = refresh(p);
+        if (rc_ != LSCQP_OK) return rc_;
+    }
     if (!p->exec) {
         hipError_t e = hipStreamBeginCapture(p->cap, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");

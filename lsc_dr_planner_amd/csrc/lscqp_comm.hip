@@ -27,6 +27,7 @@
 extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" const lscqp_plan_desc* lscqp_plan_desc_of_(lscqp_plan p);  // lscplan.hip
 extern "C" int lscqp_plan_device_(lscqp_plan p);
+extern "C" int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max);
 
 namespace {
 
@@ -247,11 +248,16 @@ int lscqp_allgather(lscqp_comm c, const double* const* d_send, double* const* d_
         return LSCQP_OK;
     }
     ncclResult_t r = c->rccl.GroupStart();
-    for (int g = 0; g < c->G && r == ncclSuccess; g++) {
-        if (hipSetDevice(c->dev[g]) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipSetDevice failed");
+    bool dev_failed = false;
+    for (int g = 0; g < c->G && r == ncclSuccess && !dev_failed; g++) {
+        if (hipSetDevice(c->dev[g]) != hipSuccess) {
+            dev_failed = true;  // (the group is closed below on every path: a thread left in group mode poisons every later RCCL call)
+            break;
+        }
         r = c->rccl.AllGather(d_send[g], d_recv[g], (size_t)count, ncclDouble, c->comms[g], c->stream[g]);
     }
     const ncclResult_t r2 = c->rccl.GroupEnd();
+    if (dev_failed) return fail(LSCQP_ERR_HIP, "hipSetDevice failed");
     if (r == ncclSuccess) r = r2;
     if (r != ncclSuccess) return fail(LSCQP_ERR_HIP, std::string("ncclAllGather: ") + c->rccl.GetErrorString(r));
     return LSCQP_OK;
@@ -336,8 +342,31 @@ int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lsc
         Shard& S = sh[g];
         if (!S.slot) continue;
         (void)hipSetDevice(c->dev[g]);
-        const hipError_t e = hipStreamSynchronize(c->stream[g]);
+        hipError_t e = hipStreamSynchronize(c->stream[g]);
         if (e != hipSuccess && rc == LSCQP_OK) rc = fail(LSCQP_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        if (rc == LSCQP_OK) {
+            // what lscqp_solve_batch does for a single device: instances that are still not OPTIMAL get one more pass on the instance
+            // with the other elimination order, where the shape has one -- so a sharded batch returns what the one-device call returns
+            const int32_t* st_h = (const int32_t*)((const char*)S.slot->h + S.o_st);
+            bool any = false;
+            for (int64_t q = 0; q < S.cnt && !any; q++) any = st_h[q] != LSCQP_STATUS_OPTIMAL && st_h[q] != LSCQP_STATUS_CAPACITY;
+            if (any && lscqp_has_other_order_(h, S.cnt, n_obs_max)) {
+                char* const db = (char*)S.slot->d;
+                char* const hb2 = (char*)S.slot->h;
+                const size_t b_hdr = al(sizeof(lscqp_header) * S.cnt);
+                const uint64_t r0 = n_obs_max > 0 ? row_offsets[S.first] : 0, r1 = n_obs_max > 0 ? row_offsets[S.first + S.cnt] : 0;
+                const size_t b_rows = al(rb * (size_t)(r1 - r0)), b_off = al(sizeof(uint64_t) * (S.cnt + 1));
+                const size_t o_rows = b_hdr, o_off = o_rows + b_rows, o_sfc = o_off + b_off;
+                rc = lscqp_solve_batch_device_ex(h, S.cnt, n_obs_max, (const lscqp_header*)db, (const lscqp_row*)(db + o_rows),
+                                                 (const uint64_t*)(db + o_off), use_sfc ? (const lscqp_box*)(db + o_sfc) : nullptr, nullptr,
+                                                 (double*)(db + S.o_x), (double*)(db + S.o_obj), (int32_t*)(db + S.o_st),
+                                                 (lscqp_info*)(db + S.o_info), -2, c->stream[g]);
+                if (rc == LSCQP_OK && hipMemcpyAsync(hb2 + S.b_in, db + S.b_in, S.b_out, hipMemcpyDeviceToHost, c->stream[g]) != hipSuccess)
+                    rc = fail(LSCQP_ERR_HIP, "hipMemcpyAsync (D2H) failed");
+                if (rc == LSCQP_OK && (e = hipStreamSynchronize(c->stream[g])) != hipSuccess)
+                    rc = fail(LSCQP_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+            }
+        }
         if (rc == LSCQP_OK) {
             const char* hb = (const char*)S.slot->h;
             memcpy(x_out + S.first * nv, hb + S.o_x, sizeof(double) * S.cnt * nv);
@@ -378,9 +407,16 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
     DeviceGuard dg;
     std::lock_guard<std::mutex> lk(c->mu);
     for (int g = 0; g < G; g++) {
-        if (hipSetDevice(c->dev[g]) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipSetDevice failed");
-        const int rc = use_graph ? lscqp_plan_step_graph(plans[g], c->stream[g]) : lscqp_plan_step(plans[g], c->stream[g]);
-        if (rc != LSCQP_OK) return rc;
+        int rc = hipSetDevice(c->dev[g]) == hipSuccess ? LSCQP_OK : fail(LSCQP_ERR_HIP, "hipSetDevice failed");
+        if (rc == LSCQP_OK) rc = use_graph ? lscqp_plan_step_graph(plans[g], c->stream[g]) : lscqp_plan_step(plans[g], c->stream[g]);
+        if (rc != LSCQP_OK) {
+            // the plans before g have replanned and the exchange has not run: the devices now disagree about the mission.  Say so --
+            // the caller has to lscqp_plan_reset the group (or re-upload the buffers) before it steps again.
+            const std::string why = lscqp_last_error();
+            char buf[160];
+            snprintf(buf, sizeof buf, "lscqp_plan_group_step: plan %d of %d failed after plans 0..%d had advanced, no exchange ran (reset the group): ", g, G, g - 1);
+            return fail(rc, buf + why);
+        }
     }
     if (!c->rccl_ok) return LSCQP_OK;  // (single device without RCCL, see lscqp_comm_create: the one plan owns every agent)
     static const int kExchanged[3] = {LSCQP_PLAN_BUF_PLAN, LSCQP_PLAN_BUF_STATE, LSCQP_PLAN_BUF_GOAL};
@@ -400,6 +436,7 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
             } else {
                 for (int o = 0; o < G && r == ncclSuccess; o++) {
                     const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[o]);
+                    if (d->n_agents == 0) continue;  // an empty block owns nothing (every rank skips it alike)
                     double* const blk = base + (size_t)d->first_agent * per;
                     r = c->rccl.Broadcast(blk, blk, (size_t)d->n_agents * per, ncclDouble, o, c->comms[g], c->stream[g]);
                 }

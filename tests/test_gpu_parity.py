@@ -694,6 +694,11 @@ def test_breakdown_under_one_elimination_order_is_repaired_on_the_other(api, ora
         out.append((int(d_st.item()), d_x.cpu().numpy()))
     assert out[0][0] in (api.STATUS_OPTIMAL, api.STATUS_NUMERIC, api.STATUS_INFEASIBLE)  # (NUMERIC today; not a promise)
     assert out[1][0] == api.STATUS_OPTIMAL and np.abs(out[1][1] - o["x"]).max() <= X_TOL
+    # the sharded host entry (TrajOptimizer::setCommunicator + solveBatch) repairs it like the one-device entry: same bits
+    comm = api.Comm(1)
+    S = sol.solve_sharded(comm, hdr, None, None, sfc)
+    assert S["status"][0] == 0 and np.array_equal(S["x"], G["x"]) and np.array_equal(S["obj"], G["obj"])
+    comm.close()
 
 
 @pytest.mark.parametrize("M,dim,n_obs,variant", [(5, 3, 20, ""), (5, 3, 48, ""), (6, 3, 20, ""), (10, 2, 9, ""), (10, 2, 40, ""), (10, 3, 40, ""), (7, 3, 12, ""),

@@ -604,3 +604,63 @@ def test_plan_safety_figures_at_the_end_of_the_step(api, torch_cuda):
     plan.close()
     with pytest.raises(api.LscqpError):  # the figures need every agent's new plan on the device
         api.Plan(sol, wmap, 5, 9, ag, n_total=N, constraint_mode=api.GEN_CLSC, z_2d=W["z_2d"], safety_samples=2)
+
+
+@pytest.mark.gpu
+def test_plan_with_an_empty_block_steps_as_a_no_op(api, torch_cuda):
+    """A mission of 9 agents over 4 devices is cut into 3 + 3 + 3 + 0 (lscqp_shard_range): the last device's plan owns no agent.  It
+    can be created, reset and stepped (eager and graph: nothing is enqueued), and keeps the all-agent buffers the exchange fills."""
+    g, W, m = _mission()
+    N = 9
+    assert [api.shard_range(N, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 3), (9, 0)]
+    sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    ag = _agents(api, W, N)
+    empty = api.Plan(sol, wmap, 0, 8, ag, n_total=N, first_agent=9, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, z_2d=W["z_2d"])
+    starts = np.array(W["starts"], dtype=np.float64)[:N]
+    empty.reset(starts)
+    before = empty.get(api.PLAN_PLAN).copy()
+    for graph in (False, True, True):
+        empty.step(graph=graph)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(before, empty.get(api.PLAN_PLAN)) and empty.graph_nodes() == 0
+    assert empty.get(api.PLAN_STATE).reshape(N, 9)[:, :2].tolist() == np.float32(starts[:, :2]).astype(np.float64).tolist()
+    empty.close()
+
+
+@pytest.mark.gpu
+def test_update_after_the_graph_capture_reaches_the_replayed_chain(api, torch_cuda):
+    """TrajOptimizer::updateParam (reference src/traj_optimizer.cpp:158-160) -> lscqp_update AFTER a plan has captured its graph: the
+    class constants travel to the kernels by value, so the captured graph is a snapshot -- the plan notices the handle's generation and
+    captures again.  Two plans on ONE handle, one eager and one replaying its graph, stay bit-identical across an update that changes
+    the terminal weight; and the update does change the plans (so the comparison is not vacuous).  Same for the tight-warm-start
+    clone of the handle that a plan may own."""
+    g, W, m = _mission()
+    N = m["N"]
+    for tight in (False, True):
+        sol = api.Solver(api.make_desc(M=10, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"]))
+        wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+        ag = _agents(api, W, N)
+        kw = dict(constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, optimize_goal=True, closed_loop=True, z_2d=W["z_2d"], tight_warm_start=tight)
+        pe, pg = api.Plan(sol, wmap, N, 9, ag, **kw), api.Plan(sol, wmap, N, 9, ag, **kw)
+        starts = np.array(W["starts"], dtype=np.float64)
+        for p in (pe, pg):
+            p.reset(starts)
+            p.put(api.PLAN_WAYPOINT, m["way"][0])
+            p.step()
+            p.put(api.PLAN_WAYPOINT, m["way"][5])
+        for _ in range(4):
+            pe.step(graph=False)
+            pg.step(graph=True)
+        torch_cuda.cuda.synchronize()
+        assert pg.graph_nodes() > 0 and np.array_equal(pe.get(api.PLAN_PLAN), pg.get(api.PLAN_PLAN))
+        x_before = pe.get(api.PLAN_PLAN).copy()
+        sol.update(api.make_desc(M=10, dim=2, dt=0.2, w_t=6.0, world_min=W["world_min"], world_max=W["world_max"]))
+        for _ in range(3):
+            pe.step(graph=False)
+            pg.step(graph=True)
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(pe.get(api.PLAN_PLAN), pg.get(api.PLAN_PLAN)) and np.array_equal(pe.get(api.PLAN_OBJECTIVE), pg.get(api.PLAN_OBJECTIVE))
+        assert (pe.get(api.PLAN_STATUS) == 0).all() and not np.array_equal(x_before, pe.get(api.PLAN_PLAN))
+        pe.close()
+        pg.close()
