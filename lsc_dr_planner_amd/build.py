@@ -90,6 +90,11 @@ def build(force=False, verbose=False, jobs=None):
     gen_src = os.path.join(CSRC, "lscgen.hip")
     if force or _newer(gen_o, hdrs + [gen_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", gen_src, "-o", gen_o])
+    gen_o = os.path.join(OBJ, "lscqp_generic.o")
+    objs.append(gen_o)
+    gen_src = os.path.join(CSRC, "lscqp_generic.hip")
+    if force or _newer(gen_o, hdrs + [gen_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", gen_src, "-o", gen_o])
     diag_o = os.path.join(OBJ, "lscqp_diag.o")
     objs.append(diag_o)
     diag_src = os.path.join(CSRC, "lscqp_diag.hip")

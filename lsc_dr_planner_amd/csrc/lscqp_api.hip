@@ -22,6 +22,14 @@
 LSCQP_INSTANCES(LSCQP_DECL)
 #undef LSCQP_DECL
 
+// the run-time-shaped instance (lscqp_generic.hip): every (M, dim, planner mode) / neighbour count the compiled table does not serve
+extern "C" int lscqp_generic_supports(int M, int dim, int es);
+extern "C" int lscqp_generic_max_obstacles(int M, int dim, int es);
+extern "C" size_t lscqp_generic_lds_bytes(int M, int dim, int es, int n_obs_max);
+extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, int dim, int es, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                                           const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
+                                           int32_t* status_out, lscqp_info* info_out, hipStream_t stream);
+
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
@@ -85,6 +93,10 @@ const Inst kInst[] = {
 // capacity.
 const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t n, int n_cu) {
     const Inst* best = nullptr;
+    // testing knob: LSCQP_FORCE_GENERIC=1 sends every fp64 launch to the run-time-shaped kernel (lscqp_generic.hip), also for shapes
+    // that have compiled instances -- so that kernel is tested on the shapes every fixture exists for
+    const char* fg = getenv("LSCQP_FORCE_GENERIC");
+    if (fg && fg[0] == '1' && !mixed) return nullptr;
     const bool small = n <= 2 * (int64_t)n_cu;
     // testing knob: LSCQP_WAVES=1|2 pins the wavefront count (every compiled instance has to be reachable by the tests)
     const char* pin = getenv("LSCQP_WAVES");
@@ -171,9 +183,11 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     const int es = (d->planner_mode == LSCQP_PLANNER_LSC) ? 1 : 0;
     if (d->precision != LSCQP_PRECISION_F64 && d->precision != LSCQP_PRECISION_MIXED)
         return fail(LSCQP_ERR_INVALID_ARGUMENT, "precision must be LSCQP_PRECISION_F64 or LSCQP_PRECISION_MIXED");
-    if (!shape_exists(d->M, d->dim, es, 0)) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "no compiled kernel instance for M=%d dim=%d end_stop=%d (compiled shapes: csrc/lscqp_launch.hpp; needs dim*(3M-2) <= 128)", d->M, d->dim, es);
+    // a shape without a compiled instance (csrc/lscqp_launch.hpp) is served by the run-time-shaped kernel (lscqp_generic.hip): the
+    // reference builds its QP for whatever param.M is (src/traj_optimizer.cpp:4-16)
+    if (!shape_exists(d->M, d->dim, es, 0) && !lscqp_generic_supports(d->M, d->dim, es)) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "no kernel for M=%d dim=%d end_stop=%d: neither a compiled instance (csrc/lscqp_launch.hpp) nor the run-time-shaped kernel (M <= 12)", d->M, d->dim, es);
         return fail(LSCQP_ERR_UNSUPPORTED, buf);
     }
     if (d->precision == LSCQP_PRECISION_MIXED && !shape_exists(d->M, d->dim, es, 1)) {
@@ -271,6 +285,10 @@ int lscqp_max_obstacles(lscqp_handle h) {
     int best = 0;
     for (const Inst& i : kInst)
         if (i.M == h->desc.M && i.dim == h->desc.dim && i.es == h->es && i.mixed == mixed && i.max_obs > best) best = i.max_obs;
+    if (!mixed) {  // beyond the compiled instances' register slots the run-time-shaped kernel takes over
+        const int g = lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es);
+        if (g > best) best = g;
+    }
     return best;
 }
 int lscqp_uses_sfc(lscqp_handle h) { return h ? (h->desc.use_sfc ? 1 : 0) : -1; }
@@ -285,7 +303,7 @@ int lscqp_instance_work(lscqp_handle h, int64_t n, int32_t n_obs_max, lscqp_work
     int n_cu = cu_count();
     if (n_cu <= 0) n_cu = 256;  // (no device in this process: MI355X's CU count decides the small-batch policy)
     const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
-    if (!inst) return fail(LSCQP_ERR_UNSUPPORTED, "no compiled kernel instance for this launch");
+    if (!inst) return fail(LSCQP_ERR_UNSUPPORTED, "no compiled kernel instance for this launch (the run-time-shaped kernel carries no instruction counts)");
     const int G = 64 * inst->waves / (6 * inst->M - 3) > 0 ? 64 * inst->waves / (6 * inst->M - 3) : 1;
     const int nslot = inst->max_obs / G;
     double t[12];
@@ -617,15 +635,30 @@ int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, co
     const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
     const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, cu_count());
     const Inst* inst64 = mixed ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : inst;
-    if (!inst || !inst64) {
-        char buf[200];
-        snprintf(buf, sizeof buf, "no compiled kernel instance of M=%d dim=%d%s holds %d obstacles per agent in registers",
-                 h->desc.M, h->desc.dim, mixed ? " (mixed precision)" : "", n_obs_max);
-        return fail(LSCQP_ERR_UNSUPPORTED, buf);
-    }
     lscqp::DevClass cls = h->dev;
     cls.n_obs_max = n_obs_max;
     hipError_t e = hipSuccess;
+    if (!inst || !inst64) {
+        // no compiled instance serves this launch (shape without one, or more obstacles than its register slots hold): the
+        // run-time-shaped kernel, fp64.  Same statuses, same second pass.
+        if (mixed || n_obs_max > lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) {
+            char buf[240];
+            snprintf(buf, sizeof buf, "no kernel of M=%d dim=%d%s holds %d obstacles per agent (compiled instances and the run-time-shaped kernel: %d)",
+                     h->desc.M, h->desc.dim, mixed ? " (mixed precision)" : "", n_obs_max, lscqp_max_obstacles(h));
+            return fail(LSCQP_ERR_UNSUPPORTED, buf);
+        }
+        if (retry == -2) return LSCQP_OK;  // (no other elimination order to try)
+        e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
+                                 d_info_out, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (run-time-shaped kernel): ") + hipGetErrorString(e));
+        if (retry && d_x_init) {
+            cls.repair = 1;
+            e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out,
+                                     d_info_out, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (run-time-shaped kernel, second pass): ") + hipGetErrorString(e));
+        }
+        return LSCQP_OK;
+    }
     if (retry == -2) {  // (internal) only the repair pass, on the other-order instance: the statuses of a first pass are in d_status_out
         const Inst* other = other_order_instance(inst64, n_obs_max);
         if (!other) return LSCQP_OK;

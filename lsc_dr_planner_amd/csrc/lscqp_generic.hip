@@ -1,0 +1,970 @@
+// lscqp_generic.hip — the run-time-shaped instance of the batched trajectory-QP solver: any (M, dim, planner mode) the reference
+// accepts and any number of obstacles the workgroup's registers hold, gfx950 only.
+//
+// The reference builds its QP for whatever param.M and constraints.getObsSize() are (src/traj_optimizer.cpp:4-16, 399-437;
+// src/param.cpp:71, 128-163); the register-resident kernel of lscqp_kernel.hpp exists as a table of compiled (M, dim, end stop,
+// slots, wavefronts) instances, chosen for speed.  THIS kernel serves everything the table does not: horizons without a compiled
+// instance (M = 9; the end-stop-free DLSC / BVC / RSFC classes at M != 5, 10; reduced systems of more than 64 rows without the
+// two equal blocks the nested dissection needs), and neighbour counts beyond a compiled instance's capacity.  Same model, same
+// interior-point iteration, same stopping rules and statuses as lscqp_kernel.hpp (its header comment and DESIGN.md section 2 describe
+// them; the numbered steps below cite it) -- organised for generality instead of issue rate:
+//   * one workgroup of 256 threads per QP, M / dim / end stop / n_obs are run-time values;
+//   * the reduced KKT matrix (nz = dim (3M - 2) or 3 dim M rows, <= 144) lives in LDS as a packed lower triangle and is factorised
+//     there (LDL^T, right-looking, two barriers per column); the substitutions run over LDS as well;
+//   * LSC rows: thread = (group g, control point cp), obstacles o = g, g + G, ... with G = floor(256 / (6M - 3)); row CONSTANTS are
+//     re-read from HBM / L2 in every pass (never staged), row STATE (s, lambda: 16 bytes per row) sits in LDS behind the matrix, sized
+//     per launch from n_obs_max: the capacity is what the CU's 160 KB leave -- about 90 obstacles at M = 10 in 3-D, > 500 at M = 5;
+//   * the structured two-sided rows (merged interval bounds, velocity / acceleration differences, communication pairs) are spread
+//     over the threads by row index, three per thread; their x-space contributions are GATHERED per control point in a fixed order
+//     (no atomics anywhere: results are bitwise reproducible).
+// It is several times slower per QP than a compiled instance of the same shape (the matrix is not in registers, the rows are re-read)
+// and is only selected when no instance serves the launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lscqp_kernel.hpp"  // DevClass, KQ, TBc, fast_rcp (shared with the compiled instances)
+#include "lscqp_launch.hpp"
+
+namespace lscqp_generic {
+
+using lscqp::DevClass;
+using lscqp::KQ;
+using lscqp::TBc;
+
+constexpr int kT = 256;     // threads per QP
+constexpr int kR2 = 3;      // two-sided rows per thread: ceil(NOM / 256) for every shape with LDS room
+constexpr int kMaxM = 12;
+
+struct Shape {
+    int M, dim, es;
+    int P, CP, NZA, NZ, NX, G;
+    int NV, NA, NCP, NC, OV, OA, OC, NOM;
+    // LDS carve, in doubles
+    int o_c, o_dca, o_dc, o_x1, o_x2, o_S, o_B, o_om, o_rv1, o_rv2, o_z, o_dz, o_zs, o_rhs, o_gc, o_dinv, o_col, o_lx, o_red, o_goal, o_H, o_rs, o_rl, total;
+    __host__ __device__ static Shape make(int M, int dim, int es, int n_obs_max) {
+        Shape s;
+        s.M = M, s.dim = dim, s.es = es;
+        s.P = 6 * M, s.CP = s.P - 3;
+        s.NZA = 3 * (M - 1) + (es ? 1 : 3);
+        s.NZ = dim * s.NZA, s.NX = dim * s.P;
+        s.G = kT / s.CP > 0 ? kT / s.CP : 1;
+        s.NV = dim * 5 * M, s.NA = dim * 4 * M, s.NCP = M * (M - 1) / 2, s.NC = dim * s.NCP;
+        s.OV = s.NX, s.OA = s.NX + s.NV, s.OC = s.OA + s.NA, s.NOM = s.OC + s.NC;
+        int o = 0;
+        auto take = [&](int n) {
+            const int at = o;
+            o += (n + 1) & ~1;
+            return at;
+        };
+        s.o_c = take(s.NX), s.o_dca = take(s.NX), s.o_dc = take(s.NX), s.o_x1 = take(s.NX), s.o_x2 = take(s.NX);
+        s.o_S = take(6 * s.P), s.o_B = take(dim * M * 36), s.o_om = take(s.NOM), s.o_rv1 = take(s.NOM), s.o_rv2 = take(s.NOM);
+        s.o_z = take(s.NZ), s.o_dz = take(s.NZ), s.o_zs = take(s.NZ), s.o_rhs = take(s.NZ), s.o_gc = take(s.NZ), s.o_dinv = take(s.NZ), s.o_col = take(s.NZ);
+        s.o_lx = take(2 * 3 * s.CP);  // LSC shares of two x-space vectors, per control point
+        s.o_red = take(3 * kT + 8), s.o_goal = take(4);
+        // the packed lower triangle of the reduced matrix; while the row passes run the same region holds the groups' partial sums
+        const int tri = s.NZ * (s.NZ + 1) / 2, part = s.G * s.CP * 12;
+        s.o_H = take(tri > part ? tri : part);
+        s.o_rs = take(n_obs_max * s.CP), s.o_rl = take(n_obs_max * s.CP);  // LSC row state [obstacle][control point]
+        s.total = o;
+        return s;
+    }
+};
+
+__device__ __forceinline__ double rcp2(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+__global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, int dim_, int es_, int64_t n, const lscqp_header* __restrict__ hdr,
+                                                          const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
+                                                          const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init,
+                                                          double* __restrict__ x_out, double* __restrict__ obj_out,
+                                                          int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Shape S = Shape::make(M_, dim_, es_, cls.n_obs_max);
+    const int M = S.M, DIM = S.dim, P = S.P, CP = S.CP, NZA = S.NZA, NZ = S.NZ, NX = S.NX, G = S.G;
+    const bool ES = S.es != 0;
+    double* const c_ = smem + S.o_c;
+    double* const dca_ = smem + S.o_dca;
+    double* const dc_ = smem + S.o_dc;
+    double* const X1 = smem + S.o_x1;  // pass 1: G' lambda            pass 2: G' (1/s)
+    double* const X2 = smem + S.o_x2;  // pass 1: G' q_aff             pass 2: G' (-ds_a dl_a / s - w rp)
+    double* const S_ = smem + S.o_S;
+    double* const B_ = smem + S.o_B;
+    double* const om_ = smem + S.o_om;
+    double* const rv1_ = smem + S.o_rv1;
+    double* const rv2_ = smem + S.o_rv2;
+    double* const z_ = smem + S.o_z;
+    double* const dz_ = smem + S.o_dz;
+    double* const zs_ = smem + S.o_zs;
+    double* const rhs_ = smem + S.o_rhs;
+    double* const gc_ = smem + S.o_gc;
+    double* const dinv_ = smem + S.o_dinv;
+    double* const col_ = smem + S.o_col;
+    double* const LX_ = smem + S.o_lx;
+    double* const red_ = smem + S.o_red;
+    double* const goal_ = smem + S.o_goal;
+    double* const H_ = smem + S.o_H;
+    double* const Rs_ = smem + S.o_rs;
+    double* const Rl_ = smem + S.o_rl;
+    const int tid = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    if (q >= n) return;
+    const lscqp_header* Hd = hdr + q;
+    int flags = 0, it_before = 0;
+    if (cls.repair) {
+        const int st0 = status_out[q];
+        if (st0 == LSCQP_STATUS_OPTIMAL || st0 == LSCQP_STATUS_CAPACITY) return;
+        flags |= LSCQP_INFO_REPAIRED;
+        if (info_out) it_before = info_out[q].iterations;
+    }
+    const int n_obs = Hd->n_obs;
+    if (n_obs > cls.n_obs_max) {  // refused, never truncated (see lscqp_kernel.hpp): the launch sized the row state for n_obs_max
+        for (int e = tid; e < NX; e += kT) x_out[q * NX + e] = x_init ? x_init[q * NX + e] : Hd->p0[e / P];
+        if (tid == 0) {
+            obj_out[q] = 0.0;
+            status_out[q] = LSCQP_STATUS_CAPACITY;
+            if (info_out) {
+                info_out[q].iterations = 0;
+                info_out[q].flags = flags;
+                info_out[q].res_primal = info_out[q].res_dual = info_out[q].gap = 0.0;
+            }
+        }
+        return;
+    }
+    const double dt = cls.dt;
+    const double org[3] = {Hd->p0[0], Hd->p0[1], Hd->p0[2]};
+    auto orgk = [&](int k) -> double { return k == 0 ? org[0] : (k == 1 ? org[1] : org[2]); };
+    const double g0 = Hd->goal[0] - org[0], g1 = Hd->goal[1] - org[1], g2 = Hd->goal[2] - org[2];
+    if (tid < 3) goal_[tid] = Hd->goal[tid] - Hd->p0[tid];
+    int ts = Hd->terminal_segments;
+    if (ts <= 0) {
+        ts = (int)((M * dt - sqrt(g0 * g0 + g1 * g1 + g2 * g2) / Hd->nominal_velocity + 1e-9) / dt);
+        if (ts < 1) ts = 1;
+    }
+    if (ts > M) ts = M;
+    const double q2s = cls.q2s, wt2 = 2.0 * cls.w_t;
+
+    // ---- block reductions through LDS, fixed order (bitwise reproducible) -----------------------------------
+    auto block_reduce3 = [&](double& a, double& b, double& c, bool max_a, bool max_b, bool max_c) {
+        __syncthreads();
+        red_[tid] = a;
+        red_[kT + tid] = b;
+        red_[2 * kT + tid] = c;
+        __syncthreads();
+        for (int w = kT / 2; w >= 1; w >>= 1) {
+            if (tid < w) {
+                red_[tid] = max_a ? fmax(red_[tid], red_[tid + w]) : red_[tid] + red_[tid + w];
+                red_[kT + tid] = max_b ? fmax(red_[kT + tid], red_[kT + tid + w]) : red_[kT + tid] + red_[kT + tid + w];
+                red_[2 * kT + tid] = max_c ? fmax(red_[2 * kT + tid], red_[2 * kT + tid + w]) : red_[2 * kT + tid] + red_[2 * kT + tid + w];
+            }
+            __syncthreads();
+        }
+        a = red_[0];
+        b = red_[kT];
+        c = red_[2 * kT];
+    };
+    auto block_sum = [&](double v) -> double {
+        double b = 0, c = 0;
+        block_reduce3(v, b, c, false, false, false);
+        return v;
+    };
+    auto block_max = [&](double v) -> double {
+        double b = 0, c = 0;
+        block_reduce3(v, b, c, true, true, true);
+        return v;
+    };
+
+    // ---- index helpers ------------------------------------------------------------------------------------------
+    auto zidx = [&](int m, int j) -> int { return (ES && m == M - 1) ? 3 * (M - 1) : 3 * m + j; };
+    // x-space vector = T * (z-space vector), all NX entries
+    auto expandT = [&](const double* zsrc, double* out, bool keep_fixed) {
+        for (int e = tid; e < NX; e += kT) {
+            const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
+            double v;
+            if (i >= 3) {
+                v = zsrc[k * NZA + zidx(m, i - 3)];
+            } else if (m >= 1) {
+                const double* zz = &zsrc[k * NZA + 3 * (m - 1)];
+                v = TBc(i, 0) * zz[0] + TBc(i, 1) * zz[1] + TBc(i, 2) * zz[2];
+            } else {
+                v = 0.0;
+            }
+            if (!(keep_fixed && cp < 3)) out[e] = v;
+        }
+    };
+    // (T' X)_zi: the x entries a z variable drives (its own control point(s), and c0..c2 of the next segment through TB)
+    auto gatherT = [&](const double* X, int zi) -> double {
+        const int k = zi / NZA, a = zi % NZA;
+        const bool zlast = ES && a == 3 * (M - 1);
+        const int m = zlast ? M - 1 : a / 3, j = zlast ? 0 : a % 3;
+        const double* xs = &X[k * P + 6 * m];
+        if (zlast) return xs[3] + xs[4] + xs[5];
+        double v = xs[3 + j];
+        if (m + 1 < M) {
+            const double* xn = &X[k * P + 6 * (m + 1)];
+            v += TBc(0, j) * xn[0] + TBc(1, j) * xn[1] + TBc(2, j) * xn[2];
+        }
+        return v;
+    };
+
+    // ---- control points: fixed part from (p0, v0, a0) (:321-338), free part from the initial trajectory or "stay at c2" ------------
+    for (int e = tid; e < NX; e += kT) {
+        const int k = e / P, cp = e % P;
+        const double cf1 = Hd->v0[k] * dt * 0.2;
+        const double cf2 = Hd->a0[k] * dt * dt * 0.05 + 2.0 * cf1;
+        c_[e] = (cp == 0) ? 0.0 : (cp == 1) ? cf1 : cf2;
+        dca_[e] = 0.0;
+        dc_[e] = 0.0;
+    }
+    for (int zi = tid; zi < NZ; zi += kT) {
+        const int k = zi / NZA, a = zi % NZA;
+        const bool zlast = ES && a == 3 * (M - 1);
+        const int m = zlast ? M - 1 : a / 3, j = zlast ? 0 : a % 3;
+        const double cf1 = Hd->v0[k] * dt * 0.2;
+        double v = Hd->a0[k] * dt * dt * 0.05 + 2.0 * cf1;
+        if (x_init) v = x_init[q * NX + k * P + 6 * m + (zlast ? 5 : 3 + j)] - orgk(k);
+        z_[zi] = v;
+    }
+    __syncthreads();
+    expandT(z_, c_, true);
+    __syncthreads();
+
+    // ---- two-sided rows: row r = tid + 256 u of [interval NX | velocity NV | acceleration NA | pair NC] -----------------------
+    // a row's value on an x-space vector v is cf0 v[i0] + cf1 v[i1] + cf2 v[i2]
+    int t_i0[kR2], t_i1[kR2], t_i2[kR2];
+    double t_c0[kR2], t_c1[kR2], t_c2[kR2];
+    bool t_on[kR2];
+    double t_lo[kR2], t_hi[kR2], t_sl[kR2], t_sh[kR2], t_ll[kR2], t_lh[kR2];
+    {
+        const double rho_pair = 0.5 * cls.comm_range - Hd->radius;  // :484
+        const double rho_wp = 0.5 * cls.comm_range - 1e-5;          // :495
+        const bool comm_on = cls.comm_range > 0;
+#pragma unroll
+        for (int u = 0; u < kR2; u++) {
+            const int r = tid + kT * u;
+            int i0 = 0, i1 = 0, i2 = 0;
+            double c0 = 0, c1 = 0, c2 = 0, lo = -1.0, hi = 1.0;
+            bool on = false;
+            if (r < S.OV) {  // interval on one control point: world box, corridor, (m, mi = 0) communication rows, waypoint rows
+                const int k = r / P, cp = r % P, m = cp / 6;
+                if (cp >= 3) {
+                    on = true;
+                    i0 = r, c0 = 1.0;
+                    const double ok_ = orgk(k);
+                    lo = cls.world_min[k] - ok_, hi = cls.world_max[k] - ok_;  // :252-253, 260-265
+                    if (cls.rsfc && k == 2 && m == 0) lo = -100.0 - ok_, hi = 100.0 - ok_;  // :255-258
+                    if (cls.use_sfc) {                                                  // :372-397
+                        lo = fmax(lo, sfc[q * M + m].bmin[k] - ok_);
+                        hi = fmin(hi, sfc[q * M + m].bmax[k] - ok_);
+                    }
+                    if (comm_on && cp % 6 == 5) {  // :482-487 with mi = 0, and :494-497
+                        const double wpk = Hd->next_waypoint[k] - ok_;
+                        lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
+                        hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
+                    }
+                }
+            } else if (r < S.OA) {  // velocity (m, i): c[i+1] - c[i], |.| <= vmax dt / n   (:448-453)
+                const int v = r - S.OV, k = v / (5 * M), rr = v % (5 * M), m = rr / 5, i = rr % 5;
+                if (!(m == 0 && i < 2)) {
+                    on = true;
+                    i0 = k * P + 6 * m + i, i1 = i0 + 1, c0 = -1.0, c1 = 1.0;
+                    hi = Hd->vmax[k] * dt * 0.2, lo = -hi;
+                }
+            } else if (r < S.OC) {  // acceleration (m, i): c[i+2] - 2 c[i+1] + c[i]   (:462-471)
+                const int a = r - S.OA, k = a / (4 * M), rr = a % (4 * M), m = rr / 4, i = rr % 4;
+                if (!(m == 0 && i < 1)) {
+                    on = true;
+                    i0 = k * P + 6 * m + i, i1 = i0 + 1, i2 = i0 + 2, c0 = 1.0, c1 = -2.0, c2 = 1.0;
+                    hi = Hd->amax[k] * dt * dt * 0.05, lo = -hi;
+                }
+            } else if (r < S.NOM) {  // pair (uu, up < uu): c[uu][5] - c[up+1][0]   (:482-487 with mi = up + 1 >= 1)
+                const int cc = r - S.OC, k = cc / S.NCP, ci = cc % S.NCP;
+                if (comm_on) {
+                    int uu = 1;
+                    while (uu * (uu + 1) / 2 <= ci) uu++;
+                    const int up = ci - uu * (uu - 1) / 2;
+                    on = true;
+                    i0 = k * P + 6 * (up + 1), i1 = k * P + 6 * uu + 5, c0 = -1.0, c1 = 1.0;
+                    hi = rho_pair, lo = -rho_pair;
+                }
+            }
+            t_i0[u] = i0, t_i1[u] = i1, t_i2[u] = i2, t_c0[u] = c0, t_c1[u] = c1, t_c2[u] = c2, t_on[u] = on, t_lo[u] = lo, t_hi[u] = hi;
+        }
+    }
+    auto row_val = [&](const double* v, int u) -> double { return t_c0[u] * v[t_i0[u]] + t_c1[u] * v[t_i1[u]] + t_c2[u] * v[t_i2[u]]; };
+    // x-space entry e of G2' rv for a per-row scalar array rv[NOM] of the two-sided rows, gathered in a fixed order
+    auto gather_rows = [&](const double* rv, int e) -> double {
+        const int k = e / P, cp = e % P, m = cp / 6, i = cp % 6;
+        double v = rv[e];  // interval
+        const double* rvV = &rv[S.OV + k * 5 * M + 5 * m];
+        if (i >= 1) v += rvV[i - 1];
+        if (i <= 4) v -= rvV[i];
+        const double* rvA = &rv[S.OA + k * 4 * M + 4 * m];
+        if (i >= 2) v += rvA[i - 2];
+        if (i >= 1 && i <= 4) v -= 2.0 * rvA[i - 1];
+        if (i <= 3) v += rvA[i];
+        const double* rvC = &rv[S.OC + k * S.NCP];
+        if (i == 5)
+            for (int up = 0; up < m; up++) v += rvC[m * (m - 1) / 2 + up];
+        if (i == 0 && m >= 1)
+            for (int uu = m; uu < M; uu++) v -= rvC[uu * (uu - 1) / 2 + (m - 1)];
+        return v;
+    };
+
+    // ---- LSC rows: thread (lg, lcp), obstacles o = lg + G u; constants from HBM / L2, state in registers ----------------------
+    const bool ll = tid < G * CP;
+    const int lg = ll ? tid / CP : 0, lcp = ll ? tid % CP : 0, lx = lcp + 3;
+    const uint64_t r0 = (n_obs > 0 && row_offsets) ? row_offsets[q] : 0;
+    struct Row {
+        double nx, ny, nz, b;
+    };
+    auto load_row = [&](int o) -> Row {  // row of obstacle o on this thread's control point, translated to the agent's origin;
+        Row R{0.0, 0.0, 0.0, -1.0};       // a dropped row (:409-411): n = 0, b = -1
+        {
+            double vx, vy, vz, vb;
+            const uint64_t e = r0 + (uint64_t)(o * P + lx);
+            if (cls.rows_f32) {
+                const float4 f = reinterpret_cast<const float4*>(rows)[e];
+                vx = f.x, vy = f.y, vz = f.z, vb = f.w;
+            } else {
+                const double4 v = *reinterpret_cast<const double4*>(&rows[e]);
+                vx = v.x, vy = v.y, vz = v.z, vb = v.w;
+            }
+            if (!(sqrt(vx * vx + vy * vy + vz * vz) < 1e-5)) {  // (:409-411)
+                R.nx = vx, R.ny = vy, R.nz = (DIM == 3) ? vz : 0.0;
+                R.b = vb - (vx * org[0] + vy * org[1] + (DIM == 3 ? vz * org[2] : 0.0));
+            }
+        }
+        return R;
+    };
+    const int o_end = ll ? n_obs : 0;  // this thread's rows: for (o = lg; o < o_end; o += G), state at [o * CP + lcp]
+
+    // ---- centred start (lscqp_kernel.hpp "initial slacks / multipliers") ---------------------------------------------------------
+    const double pull = (double)ts * cls.w_t * fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+    const double mu_scale = fmin(1e3, fmax(1.0, 0.25 * pull));
+    const double MU0 = (x_init ? cls.warm_mu0 : LSCQP_COLD_MU0) * mu_scale, S0MIN = x_init ? cls.warm_s0 : 0.1;
+    int status = LSCQP_STATUS_ITER_LIMIT;
+    auto centre_rows = [&](double mu_c, double s_c, double& cnt, bool& bad) {
+#pragma unroll
+        for (int u = 0; u < kR2; u++) {
+            double sl0 = 1.0, sh0 = 1.0, l0 = 0.0;
+            if (t_on[u]) {
+                const double y = row_val(c_, u);
+                if (t_lo[u] > t_hi[u]) bad = true;
+                sl0 = fmax(y - t_lo[u], s_c);
+                sh0 = fmax(t_hi[u] - y, s_c);
+                l0 = 1.0;
+                cnt += 2.0;
+            }
+            t_sl[u] = sl0, t_sh[u] = sh0;
+            t_ll[u] = l0 * mu_c * rcp2(sl0), t_lh[u] = l0 * mu_c * rcp2(sh0);
+        }
+        const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+        for (int o = lg; o < o_end; o += G) {
+            const Row R = load_row(o);
+            double s_init = 1.0, l_init = 0.0;
+            if ((R.nx != 0.0) || (R.ny != 0.0) || (R.nz != 0.0)) {
+                s_init = fmax(R.nx * cx + R.ny * cy + R.nz * cz - R.b, s_c);
+                l_init = mu_c * rcp2(s_init);
+                cnt += 1.0;
+            }
+            Rs_[o * CP + lcp] = s_init, Rl_[o * CP + lcp] = l_init;
+        }
+    };
+    double m_tot = 0;
+    {
+        double cnt = 0;
+        bool bad = false;
+        centre_rows(MU0, S0MIN, cnt, bad);
+        m_tot = block_sum(cnt);
+        if (block_max(bad ? 1.0 : 0.0) > 0.0) status = LSCQP_STATUS_INFEASIBLE;
+    }
+    const double inv_m = 1.0 / m_tot;
+
+    auto objective = [&](bool ref_rounding) -> double {  // cplex.getObjValue() (src/traj_optimizer.cpp:100), see lscqp_kernel.hpp
+        double part = 0.0;
+        if (tid < DIM * M) {
+            const int k = tid / M, m = tid % M;
+            const double* cc = &c_[k * P + 6 * m];
+            const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
+            const double j1 = (cc[4] - cc[1]) - 3.0 * (cc[3] - cc[2]);
+            const double j2 = (cc[5] - cc[2]) - 3.0 * (cc[4] - cc[3]);
+            const double quad = 0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
+            part = 0.5 * q2s * 3600.0 * quad;
+            if (ref_rounding) {
+                const double ok_ = Hd->p0[k];
+                double corr = 0;
+                for (int i = 0; i < 6; i++) {
+                    double r = 0;
+                    for (int ip = 0; ip < 6; ip++) r += cls.dQ[i * 6 + ip] * (cc[ip] + ok_);
+                    corr += r * (cc[i] + ok_);
+                }
+                part += cls.w_c * corr;
+            }
+            const double dgoal = cc[5] - goal_[k];
+            part += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
+        }
+        return block_sum(part);
+    };
+
+    // ---- the reduced matrix, packed lower triangle; x entries a z variable drives --------------------------------------------
+    auto tri = [](int i, int j) -> int { return i * (i + 1) / 2 + j; };  // j <= i
+    struct Drv {
+        int n, idx[4];
+        double w[4];
+    };
+    auto drive = [&](int zi) -> Drv {
+        Drv D;
+        const int k = zi / NZA, a = zi % NZA;
+        const bool zlast = ES && a == 3 * (M - 1);
+        const int m = zlast ? M - 1 : a / 3, j = zlast ? 0 : a % 3;
+        const int base = k * P + 6 * m;
+        if (zlast) {
+            D.n = 3;
+            for (int t = 0; t < 3; t++) D.idx[t] = base + 3 + t, D.w[t] = 1.0;
+            D.idx[3] = base, D.w[3] = 0.0;
+        } else {
+            D.n = 1;
+            D.idx[0] = base + 3 + j, D.w[0] = 1.0;
+            for (int t = 0; t < 3; t++) D.idx[1 + t] = base, D.w[1 + t] = 0.0;
+            if (m + 1 < M) {
+                D.n = 4;
+                for (int t = 0; t < 3; t++) D.idx[1 + t] = base + 6 + t, D.w[1 + t] = TBc(t, j);
+            }
+        }
+        return D;
+    };
+    const bool comm_on_k = cls.comm_range > 0;
+    // entry (a, b) of K = H + G'WG in x-space; B_ holds the same-axis same-segment 6x6 blocks
+    auto Kentry = [&](int a, int b) -> double {
+        const int ka = a / P, ca = a % P, ma = ca / 6, ia = ca % 6;
+        const int kb = b / P, cb = b % P, mb = cb / 6, ib = cb % 6;
+        double v = 0.0;
+        if (ka == kb) {
+            if (ma == mb) v += B_[((ka * M + ma) * 6 + ia) * 6 + ib];
+            if (comm_on_k) {  // off-diagonal entries of the communication pairs: (uu, 5) with (up + 1, 0), weight -w(uu, up)
+                const double* omc = &om_[S.OC + ka * S.NCP];
+                if (ia == 5 && ib == 0 && mb >= 1 && ma >= mb) v -= omc[ma * (ma - 1) / 2 + (mb - 1)];
+                if (ib == 5 && ia == 0 && ma >= 1 && mb >= ma) v -= omc[mb * (mb - 1) / 2 + (ma - 1)];
+            }
+        } else if (ca == cb && ca >= 3) {  // cross-axis block of the LSC rows on one control point
+            const int lo_ = ka < kb ? ka : kb, hi_ = ka < kb ? kb : ka;
+            const int so = (lo_ == 0) ? hi_ : 4;  // (0,1) -> 1, (0,2) -> 2, (1,2) -> 4
+            v += S_[ca * 6 + so];
+        }
+        return v;
+    };
+
+    double res_p = 0, res_d = 0, res_gap = 0, snap_p = 0, snap_d = 0, snap_gap = 0;
+    bool restore = false;
+    int it = 0, near_cnt = 0, floor_cnt = 0;
+    float rp_ref = 3.0e38f;
+    int stalled = 0;
+    float alpha_first = 1.0f;
+    bool net_done = false;
+    float gap_mark = 3.0e38f;
+    int jam_since = 0;
+    bool recentred = false;
+    const double tol = cls.tol;
+
+    if (status != LSCQP_STATUS_INFEASIBLE)
+        for (it = 0; it < cls.max_iter; it++) {
+            // ============ pass 1: residuals, weights, per-control-point blocks ===========================================
+            double sum_sl = 0, sum_pinf = 0, max_rp = 0;
+#pragma unroll
+            for (int u = 0; u < kR2; u++) {
+                const int r = tid + kT * u;
+                const double y = row_val(c_, u);
+                const double rpl = t_on[u] ? (y - t_lo[u]) - t_sl[u] : 0.0, rph = t_on[u] ? (t_hi[u] - y) - t_sh[u] : 0.0;
+                const double wl = t_ll[u] * rcp2(t_sl[u]), wh = t_lh[u] * rcp2(t_sh[u]);
+                sum_sl += t_sl[u] * t_ll[u] + t_sh[u] * t_lh[u];
+                sum_pinf += t_ll[u] * fabs(rpl) + t_lh[u] * fabs(rph);
+                max_rp = fmax(max_rp, fmax(fabs(rpl), fabs(rph)));
+                if (r < S.NOM) {
+                    om_[r] = wl + wh;
+                    rv1_[r] = t_ll[u] - t_lh[u];
+                    rv2_[r] = wh * rph - wl * rpl;
+                }
+            }
+            {
+                double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0, l0 = 0, l1 = 0, l2 = 0, a0 = 0, a1 = 0, a2 = 0;
+                const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+                for (int o = lg; o < o_end; o += G) {
+                    const Row R = load_row(o);
+                    const double s = Rs_[o * CP + lcp], lam = Rl_[o * CP + lcp];
+                    const double rp = (R.nx * cx + R.ny * cy + R.nz * cz - R.b) - s;
+                    const double w = lam * rcp2(s);
+                    sum_sl += s * lam;
+                    sum_pinf += lam * fabs(rp);
+                    max_rp = fmax(max_rp, fabs(rp));
+                    const double wx = w * R.nx, wy = w * R.ny, wz = w * R.nz;
+                    s00 += wx * R.nx, s01 += wx * R.ny, s02 += wx * R.nz, s11 += wy * R.ny, s12 += wy * R.nz, s22 += wz * R.nz;
+                    l0 += lam * R.nx, l1 += lam * R.ny, l2 += lam * R.nz;
+                    const double qa = -w * rp;
+                    a0 += qa * R.nx, a1 += qa * R.ny, a2 += qa * R.nz;
+                }
+                if (ll) {  // the groups' partial sums, combined below in group order
+                    double* pp = &H_[(lg * CP + lcp) * 12];
+                    pp[0] = s00, pp[1] = s01, pp[2] = s02, pp[3] = s11, pp[4] = s12, pp[5] = s22;
+                    pp[6] = l0, pp[7] = l1, pp[8] = l2, pp[9] = a0, pp[10] = a1, pp[11] = a2;
+                }
+            }
+            block_reduce3(sum_sl, sum_pinf, max_rp, false, false, true);  // (its barriers also publish om_, rv*, the partial sums)
+            const double mu = sum_sl * inv_m;
+            if (tid < CP) {
+                double acc[12];
+                for (int t = 0; t < 12; t++) acc[t] = 0.0;
+                for (int g = 0; g < G; g++)
+                    for (int t = 0; t < 12; t++) acc[t] += H_[(g * CP + tid) * 12 + t];
+                const int cp6 = (tid + 3) * 6;
+                for (int t = 0; t < 6; t++) S_[cp6 + t] = acc[t];
+                for (int t = 0; t < 3; t++) LX_[t * CP + tid] = acc[6 + t], LX_[(3 + t) * CP + tid] = acc[9 + t];
+            }
+            if (tid < 18) S_[tid] = 0.0;  // the initial state carries no LSC rows
+            __syncthreads();
+            for (int e = tid; e < NX; e += kT) {
+                const int k = e / P, cp = e % P;
+                const double lsc1 = cp >= 3 ? LX_[k * CP + cp - 3] : 0.0, lsc2 = cp >= 3 ? LX_[(3 + k) * CP + cp - 3] : 0.0;
+                X1[e] = gather_rows(rv1_, e) + lsc1;
+                X2[e] = gather_rows(rv2_, e) + lsc2;
+            }
+            __syncthreads();
+
+            // ============ cost gradient in z-space, residual norms, convergence ========================================
+            double rdn = 0, gls = 0;
+            for (int zi = tid; zi < NZ; zi += kT) {
+                const int k = zi / NZA, a = zi % NZA;
+                const bool zlast = ES && a == 3 * (M - 1);
+                const int m = zlast ? M - 1 : a / 3, j = zlast ? 0 : a % 3;
+                const double* cs = &c_[k * P + 6 * m];
+                double gx[6];  // gradient of the cost w.r.t. this segment's control points (the ones this z drives)
+                double gcost = 0;
+                for (int i = 3; i < 6; i++) {
+                    double gq = 0;
+                    for (int ip = 0; ip < 6; ip++) gq += KQ(i, ip) * cs[ip];
+                    gx[i] = q2s * gq;
+                }
+                gx[5] += (m >= M - ts) ? wt2 * (cs[5] - goal_[k]) : 0.0;
+                if (zlast) {
+                    gcost = gx[3] + gx[4] + gx[5];
+                } else {
+                    gcost = gx[3 + j];
+                    if (m + 1 < M) {
+                        const double* cn = &c_[k * P + 6 * (m + 1)];
+                        for (int r = 0; r < 3; r++) {
+                            double gq = 0;
+                            for (int ip = 0; ip < 6; ip++) gq += KQ(r, ip) * cn[ip];
+                            gcost += TBc(r, j) * q2s * gq;
+                        }
+                    }
+                }
+                const double gl = gatherT(X1, zi), ga = gatherT(X2, zi);
+                gc_[zi] = gcost;
+                rhs_[zi] = -gcost + ga;  // predictor right-hand side
+                rdn = fmax(rdn, fabs(gcost - gl));
+                gls = fmax(gls, fmax(fabs(gcost), fabs(gl)));
+            }
+            {
+                double dummy = 0;
+                block_reduce3(rdn, gls, dummy, true, true, true);
+            }
+            gls = fmax(1.0, gls);
+            res_p = max_rp;
+            res_d = rdn / gls;
+            if ((it & 3) == 2) {  // infeasibility: a primal residual that stalls, or runaway multipliers (see lscqp_kernel.hpp)
+                stalled = (it >= 10 && max_rp > 1e-4 && max_rp > 0.7 * (double)rp_ref) ? stalled + 1 : 0;
+                if (stalled >= 2 || (it >= 10 && max_rp > 1e-5 && sum_pinf > 1e6)) {
+                    status = LSCQP_STATUS_INFEASIBLE;
+                    break;
+                }
+                rp_ref = (float)max_rp;
+            }
+            if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {
+                res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false)));
+                if (res_gap <= tol || (res_gap <= 10.0 * tol && rdn <= 1e-7 * gls)) {
+                    for (int zi = tid; zi < NZ; zi += kT) zs_[zi] = z_[zi];
+                    snap_p = max_rp, snap_d = res_d, snap_gap = res_gap;
+                }
+                if (res_gap <= tol) {
+                    floor_cnt++;
+                    if (rdn <= 1e-8 * gls) {
+                        near_cnt++;
+                        if (rdn <= 10.0 * tol * gls || near_cnt >= LSCQP_NEAR_CONFIRM) {
+                            status = LSCQP_STATUS_OPTIMAL;
+                            break;
+                        }
+                    }
+                } else if (res_gap <= 10.0 * tol && rdn <= 1e-7 * gls) {
+                    floor_cnt++;
+                }
+                if (res_gap > tol && res_gap <= 1e-4) {
+                    if ((float)res_gap <= 0.1f * gap_mark) {
+                        gap_mark = (float)res_gap;
+                        jam_since = 0;
+                    } else {
+                        jam_since++;
+                    }
+                }
+            } else
+                res_gap = sum_sl + sum_pinf;
+            const bool net = cls.warm_net > 0 && x_init != nullptr && it == 1 && !net_done && (double)alpha_first < cls.warm_net;
+            if (net || (!recentred && jam_since >= 6 && floor_cnt == 0)) {
+                double cnt_ = 0;
+                bool bad_ = false;
+                centre_rows(1e-3 * mu_scale, 0.03, cnt_, bad_);
+                if (net) net_done = true; else recentred = true;
+                rp_ref = 3.0e38f;
+                near_cnt = 0;
+                __syncthreads();
+                continue;
+            }
+
+            // ============ assembly: same-axis same-segment blocks, then Hred = T'(H + G'WG)T, packed lower triangle ==========
+            for (int e = tid; e < DIM * M * 36; e += kT) {
+                const int k = e / (36 * M), m = (e / 36) % M, i = (e % 36) / 6, ip = e % 6;
+                double v = q2s * KQ(i, ip);
+                if (i == 5 && ip == 5 && m >= M - ts) v += wt2;
+                const double* omi = &om_[k * P + 6 * m];
+                const double* omv = &om_[S.OV + k * 5 * M + 5 * m];
+                const double* oma = &om_[S.OA + k * 4 * M + 4 * m];
+                const int d = ip - i;
+                if (d == 0) {
+                    v += omi[i] + S_[(6 * m + i) * 6 + (k == 0 ? 0 : (k == 1 ? 3 : 5))];
+                    if (i <= 4) v += omv[i];
+                    if (i >= 1) v += omv[i - 1];
+                    if (i <= 3) v += oma[i];
+                    if (i >= 1 && i <= 4) v += 4.0 * oma[i - 1];
+                    if (i >= 2) v += oma[i - 2];
+                    if (comm_on_k) {  // diagonal of the communication pairs
+                        const double* omc = &om_[S.OC + k * S.NCP];
+                        if (i == 5)
+                            for (int up = 0; up < m; up++) v += omc[m * (m - 1) / 2 + up];
+                        if (i == 0 && m >= 1)
+                            for (int uu = m; uu < M; uu++) v += omc[uu * (uu - 1) / 2 + (m - 1)];
+                    }
+                } else if (d == 1 || d == -1) {
+                    const int lo_ = i < ip ? i : ip;  // entries (lo, lo + 1)
+                    v -= omv[lo_];
+                    if (lo_ <= 3) v -= 2.0 * oma[lo_];
+                    if (lo_ >= 1) v -= 2.0 * oma[lo_ - 1];
+                } else if (d == 2 || d == -2) {
+                    const int lo_ = i < ip ? i : ip;
+                    v += oma[lo_];
+                }
+                B_[e] = v;
+            }
+            __syncthreads();
+            for (int e = tid; e < NZ * (NZ + 1) / 2; e += kT) {
+                int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                while (i * (i + 1) / 2 > e) i--;
+                while ((i + 1) * (i + 2) / 2 <= e) i++;
+                const int j = e - i * (i + 1) / 2;
+                const Drv Di = drive(i), Dj = drive(j);
+                double v = 0.0;
+                for (int a = 0; a < 4; a++)
+                    for (int b = 0; b < 4; b++) {
+                        const double w = Di.w[a] * Dj.w[b];
+                        if (w != 0.0) v += w * Kentry(Di.idx[a], Dj.idx[b]);
+                    }
+                H_[e] = v;
+            }
+            __syncthreads();
+
+            // ============ LDL^T in LDS, right-looking: after step j column j holds L[.][j], the diagonal d_j ======================
+            bool pivot_bad = false;
+            for (int j = 0; j < NZ; j++) {
+                const double d = H_[tri(j, j)];
+                if (!(d > 1e-300)) {  // uniform: every thread reads the same entry
+                    pivot_bad = true;
+                    break;
+                }
+                const double invd = rcp2(d);
+                for (int i = j + 1 + tid; i < NZ; i += kT) {
+                    const double a = H_[tri(i, j)];
+                    col_[i] = a;
+                    H_[tri(i, j)] = a * invd;
+                }
+                if (tid == 0) dinv_[j] = invd;
+                __syncthreads();
+                // trailing update, rows j+1 .. NZ-1: H[i][k] -= L[i][j] * (d L[k][j]);  a row is shared by `tpr` threads
+                const int nrow = NZ - j - 1;
+                const int tpr = nrow > 0 ? (kT / nrow > 0 ? kT / nrow : 1) : 1;
+                for (int w = tid; w < nrow * tpr; w += kT) {
+                    const int i = j + 1 + w / tpr, part = w % tpr;
+                    const double li = H_[tri(i, j)];
+                    for (int k = j + 1 + part; k <= i; k += tpr) H_[tri(i, k)] = fma(-li, col_[k], H_[tri(i, k)]);
+                }
+                __syncthreads();
+            }
+            if (pivot_bad) {
+                status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+                restore = status == LSCQP_STATUS_OPTIMAL;
+                break;
+            }
+            // solve Hred x = rhs_ in place: L w = b, then (D L') x = w
+            auto solve = [&]() {
+                for (int j = 0; j < NZ; j++) {
+                    __syncthreads();
+                    const double wj = rhs_[j];
+                    for (int i = j + 1 + tid; i < NZ; i += kT) rhs_[i] = fma(-H_[tri(i, j)], wj, rhs_[i]);
+                }
+                __syncthreads();
+                for (int i = tid; i < NZ; i += kT) rhs_[i] *= dinv_[i];
+                for (int j = NZ - 1; j >= 0; j--) {
+                    __syncthreads();
+                    const double xj = rhs_[j];
+                    for (int i = tid; i < j; i += kT) rhs_[i] = fma(-H_[tri(j, i)], xj, rhs_[i]);
+                }
+                __syncthreads();
+            };
+
+            // ============ predictor =============================================================================================
+            solve();
+            for (int zi = tid; zi < NZ; zi += kT) dz_[zi] = rhs_[zi];
+            __syncthreads();
+            expandT(dz_, dca_, false);
+            __syncthreads();
+            // ============ pass 2: affine step length, mu_aff, corrector right-hand side =========================================
+            double rmax = 1.0, sB = 0, dmy = 0;
+#pragma unroll
+            for (int u = 0; u < kR2; u++) {
+                const int r = tid + kT * u;
+                const double y = row_val(c_, u), dy = row_val(dca_, u);
+                const double rpl = (y - t_lo[u]) - t_sl[u], rph = (t_hi[u] - y) - t_sh[u];
+                const double isl = rcp2(t_sl[u]), ish = rcp2(t_sh[u]);
+                const double tl = (dy + rpl) * isl, th = (rph - dy) * ish;
+                const double rr = fmax(fmax(-tl, 1.0 + tl), fmax(-th, 1.0 + th));
+                rmax = fmax(rmax, t_on[u] ? rr : 1.0);
+                const double pl = -(dy + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dy) * t_lh[u] * (1.0 + th);
+                sB += t_on[u] ? (pl + ph) : 0.0;
+                if (r < S.NOM) {
+                    rv1_[r] = t_on[u] ? isl - ish : 0.0;
+                    rv2_[r] = t_on[u] ? (-pl - t_ll[u] * rpl) * isl - (-ph - t_lh[u] * rph) * ish : 0.0;
+                }
+            }
+            {
+                double b10 = 0, b11 = 0, b12 = 0, b20 = 0, b21 = 0, b22 = 0;
+                const double cx = c_[lx], cy = c_[P + lx], cz = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+                const double dx = dca_[lx], dy = dca_[P + lx], dzz = (DIM == 3) ? dca_[2 * P + lx] : 0.0;
+                for (int o = lg; o < o_end; o += G) {
+                    const Row R = load_row(o);
+                    const double s = Rs_[o * CP + lcp], l = Rl_[o * CP + lcp];
+                    const double rp = (R.nx * cx + R.ny * cy + R.nz * cz - R.b) - s;
+                    const double is = rcp2(s);
+                    const double ds = (R.nx * dx + R.ny * dy + R.nz * dzz) + rp;
+                    const double t = ds * is;
+                    rmax = fmax(rmax, (l > 0.0) ? fmax(-t, 1.0 + t) : 1.0);
+                    const double pa = -ds * l * (1.0 + t);
+                    sB += pa;
+                    const double t2 = (-pa - l * rp) * is;
+                    b10 += is * R.nx, b11 += is * R.ny, b12 += is * R.nz;
+                    b20 += t2 * R.nx, b21 += t2 * R.ny, b22 += t2 * R.nz;
+                }
+                // partial sums per (group, control point), combined in group order by the threads of group 0.  The factor occupies H_
+                // during this pass, so the shares go through the reduction scratch (3 x 256 doubles): two rounds of three values.
+                __syncthreads();
+                for (int round = 0; round < 2; round++) {
+                    if (ll) {
+                        red_[tid] = round == 0 ? b10 : b20;
+                        red_[kT + tid] = round == 0 ? b11 : b21;
+                        red_[2 * kT + tid] = round == 0 ? b12 : b22;
+                    }
+                    __syncthreads();
+                    if (tid < CP) {
+                        double a0 = 0, a1 = 0, a2 = 0;
+                        for (int g = 0; g < G; g++) a0 += red_[g * CP + tid], a1 += red_[kT + g * CP + tid], a2 += red_[2 * kT + g * CP + tid];
+                        LX_[(3 * round + 0) * CP + tid] = a0, LX_[(3 * round + 1) * CP + tid] = a1, LX_[(3 * round + 2) * CP + tid] = a2;
+                    }
+                    __syncthreads();
+                }
+            }
+            block_reduce3(rmax, sB, dmy, true, false, false);
+            for (int e = tid; e < NX; e += kT) {
+                const int k = e / P, cp = e % P;
+                X1[e] = gather_rows(rv1_, e) + (cp >= 3 ? LX_[k * CP + cp - 3] : 0.0);
+                X2[e] = gather_rows(rv2_, e) + (cp >= 3 ? LX_[(3 + k) * CP + cp - 3] : 0.0);
+            }
+            const double a_aff = rcp2(rmax);
+            const double mu_aff = ((1.0 - a_aff) * sum_sl + a_aff * a_aff * sB) * inv_m;
+            double sigma = fmax(mu_aff, 0.0) / mu;
+            sigma = sigma * sigma * sigma;
+            const double smu = sigma * mu;
+            __syncthreads();
+            // ============ corrector solve ======================================================================================
+            for (int zi = tid; zi < NZ; zi += kT) rhs_[zi] = -gc_[zi] + smu * gatherT(X1, zi) + gatherT(X2, zi);
+            __syncthreads();
+            solve();
+            for (int zi = tid; zi < NZ; zi += kT) dz_[zi] = rhs_[zi];
+            __syncthreads();
+            expandT(dz_, dc_, false);
+            __syncthreads();
+            // ============ pass 3: directions of the row state, step length ======================================================
+            rmax = 0.0;
+            double sdl = 0, sdd = 0;
+            double t_ds[2 * kR2], t_dl[2 * kR2];
+#pragma unroll
+            for (int u = 0; u < kR2; u++) {
+                const bool on = t_on[u];
+                const double y = row_val(c_, u), dya = row_val(dca_, u), dyc = row_val(dc_, u);
+                const double rpl = (y - t_lo[u]) - t_sl[u], rph = (t_hi[u] - y) - t_sh[u];
+                const double isl = rcp2(t_sl[u]), ish = rcp2(t_sh[u]);
+                const double tl = (dya + rpl) * isl, th = (rph - dya) * ish;
+                const double pl = -(dya + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dya) * t_lh[u] * (1.0 + th);
+                const double dsl = dyc + rpl, dsh = rph - dyc;
+                const double dll = (smu - pl) * isl - t_ll[u] - t_ll[u] * isl * dsl;
+                const double dlh = (smu - ph) * ish - t_lh[u] - t_lh[u] * ish * dsh;
+                const double ill = rcp2(on ? t_ll[u] : 1.0), ilh = rcp2(on ? t_lh[u] : 1.0);
+                const double rr = fmax(fmax(-dsl * isl, -dsh * ish), fmax(-dll * ill, -dlh * ilh));
+                rmax = fmax(rmax, on ? rr : 0.0);
+                t_ds[2 * u] = on ? dsl : 0.0, t_ds[2 * u + 1] = on ? dsh : 0.0;
+                t_dl[2 * u] = on ? dll : 0.0, t_dl[2 * u + 1] = on ? dlh : 0.0;
+                sdl += t_sl[u] * t_dl[2 * u] + t_ll[u] * t_ds[2 * u] + t_sh[u] * t_dl[2 * u + 1] + t_lh[u] * t_ds[2 * u + 1];
+                sdd += t_ds[2 * u] * t_dl[2 * u] + t_ds[2 * u + 1] * t_dl[2 * u + 1];
+            }
+            // The LSC rows' state lives in LDS and is only rewritten once the step length is final; their directions are recomputed
+            // from (c, dc_aff, dc) wherever they are needed (no room to keep them): for the ratio test, per trial of the centrality
+            // loop, and for the update.
+            struct Dir {
+                double s, l, ds, dl;
+            };
+            const double cx3 = c_[lx], cy3 = c_[P + lx], cz3 = (DIM == 3) ? c_[2 * P + lx] : 0.0;
+            const double ax3 = dca_[lx], ay3 = dca_[P + lx], az3 = (DIM == 3) ? dca_[2 * P + lx] : 0.0;
+            const double dx3 = dc_[lx], dy3 = dc_[P + lx], dz3 = (DIM == 3) ? dc_[2 * P + lx] : 0.0;
+            auto lsc_dir = [&](int o) -> Dir {
+                const Row R = load_row(o);
+                Dir D;
+                D.s = Rs_[o * CP + lcp], D.l = Rl_[o * CP + lcp];
+                const double rp = (R.nx * cx3 + R.ny * cy3 + R.nz * cz3 - R.b) - D.s;
+                const double is = rcp2(D.s);
+                const double dsa = (R.nx * ax3 + R.ny * ay3 + R.nz * az3) + rp;
+                const double pa = -dsa * D.l * (1.0 + dsa * is);
+                const double ds = (R.nx * dx3 + R.ny * dy3 + R.nz * dz3) + rp;
+                const bool act = D.l > 0.0;
+                D.dl = act ? ((smu - pa) * is - D.l - D.l * is * ds) : 0.0;
+                D.ds = act ? ds : 0.0;
+                return D;
+            };
+            for (int o = lg; o < o_end; o += G) {
+                const Dir D = lsc_dir(o);
+                if (D.l > 0.0) rmax = fmax(rmax, fmax(-D.ds * rcp2(D.s), -D.dl * rcp2(D.l)));
+                sdl += D.s * D.dl + D.l * D.ds;
+                sdd += D.ds * D.dl;
+            }
+            block_reduce3(sdl, sdd, rmax, false, false, true);
+            const double tau = (sigma < 1e-4) ? fmax(0.9995, 1.0 - mu) : 0.9995;
+            const double irmax = rcp2(rmax);
+            const double alpha_std = (rmax > 0.9995) ? 0.9995 * irmax : 1.0;
+            double alpha = (rmax > tau) ? tau * irmax : 1.0;
+            double applied = 0.0;
+            for (int bt = 0;; bt++) {  // centrality safeguard (see lscqp_kernel.hpp): no product below GAMMA * mu(alpha)
+                const double mu_a = (sum_sl + alpha * (sdl + alpha * sdd)) * inv_m;
+                const double delta = alpha - applied;
+                applied = alpha;
+                double pmin = 1e300;
+#pragma unroll
+                for (int u = 0; u < kR2; u++) {
+                    t_sl[u] = fma(delta, t_ds[2 * u], t_sl[u]), t_ll[u] = fma(delta, t_dl[2 * u], t_ll[u]);
+                    t_sh[u] = fma(delta, t_ds[2 * u + 1], t_sh[u]), t_lh[u] = fma(delta, t_dl[2 * u + 1], t_lh[u]);
+                    pmin = fmin(pmin, t_on[u] ? fmin(t_sl[u] * t_ll[u], t_sh[u] * t_lh[u]) : 1e300);
+                }
+                for (int o = lg; o < o_end; o += G) {
+                    const Dir D = lsc_dir(o);
+                    const double ns = fma(alpha, D.ds, D.s), nl = fma(alpha, D.dl, D.l);
+                    pmin = fmin(pmin, (nl > 0.0) ? ns * nl : 1e300);
+                }
+                pmin = -block_max(-pmin);
+                if (pmin >= LSCQP_CENTRALITY_GAMMA * mu_a || bt == 9) break;
+                alpha = (bt == 0 && alpha_std < alpha) ? alpha_std : 0.7 * alpha;
+            }
+            for (int o = lg; o < o_end; o += G) {  // (each thread rewrites only its own rows: no barrier needed before the next pass)
+                const Dir D = lsc_dir(o);
+                Rs_[o * CP + lcp] = fma(alpha, D.ds, D.s);
+                Rl_[o * CP + lcp] = fma(alpha, D.dl, D.l);
+            }
+            // ============ update of z and the control points ====================================================================
+            if (it == 0) alpha_first = (float)alpha;
+            for (int zi = tid; zi < NZ; zi += kT) z_[zi] += alpha * dz_[zi];
+            __syncthreads();
+            expandT(z_, c_, true);
+            __syncthreads();
+            if (!(alpha > 1e-12) || !(mu == mu)) {
+                status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
+                restore = status == LSCQP_STATUS_OPTIMAL;
+                break;
+            }
+        }
+    if (status == LSCQP_STATUS_ITER_LIMIT && (near_cnt > 0 || floor_cnt > 0)) {
+        status = LSCQP_STATUS_OPTIMAL;
+        restore = true;
+    }
+    if (status == LSCQP_STATUS_ITER_LIMIT && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
+    if (status == LSCQP_STATUS_NUMERIC && res_p > 1e-6) status = LSCQP_STATUS_INFEASIBLE;
+    if (restore) {
+        __syncthreads();
+        for (int zi = tid; zi < NZ; zi += kT) z_[zi] = zs_[zi];
+        __syncthreads();
+        expandT(z_, c_, true);
+        __syncthreads();
+        res_p = snap_p, res_d = snap_d, res_gap = snap_gap;
+        flags |= LSCQP_INFO_FLOOR_ACCEPTED;
+    }
+    if (recentred || net_done) flags |= LSCQP_INFO_RECENTRED;
+    __syncthreads();
+    const double obj = objective(true);
+    for (int e = tid; e < NX; e += kT) x_out[q * NX + e] = c_[e] + Hd->p0[e / P];
+    if (tid == 0) {
+        obj_out[q] = obj;
+        status_out[q] = status;
+        if (info_out) {
+            info_out[q].iterations = it + it_before;
+            info_out[q].flags = flags;
+            info_out[q].res_primal = res_p;
+            info_out[q].res_dual = res_d;
+            info_out[q].gap = res_gap;
+        }
+    }
+}
+
+}  // namespace lscqp_generic
+
+// what lscqp_api.hip needs to know about the run-time-shaped instance
+extern "C" int lscqp_generic_supports(int M, int dim, int es) {
+    if (M < 2 || M > lscqp_generic::kMaxM || dim < 2 || dim > 3) return 0;
+    const lscqp_generic::Shape s = lscqp_generic::Shape::make(M, dim, es, 0);
+    if ((s.NOM + lscqp_generic::kT - 1) / lscqp_generic::kT > lscqp_generic::kR2) return 0;
+    return sizeof(double) * (size_t)s.total <= lscqp::kMaxLdsBytes ? 1 : 0;
+}
+extern "C" size_t lscqp_generic_lds_bytes(int M, int dim, int es, int n_obs_max) {
+    return sizeof(double) * (size_t)lscqp_generic::Shape::make(M, dim, es, n_obs_max).total;
+}
+extern "C" int lscqp_generic_max_obstacles(int M, int dim, int es) {  // what the CU's LDS leaves for the row state (16 bytes per row)
+    if (!lscqp_generic_supports(M, dim, es)) return 0;
+    const lscqp_generic::Shape s = lscqp_generic::Shape::make(M, dim, es, 0);
+    const size_t left = lscqp::kMaxLdsBytes - sizeof(double) * (size_t)s.total;
+    int cap = (int)(left / (16 * (size_t)s.CP));
+    while (cap > 0 && lscqp_generic_lds_bytes(M, dim, es, cap) > lscqp::kMaxLdsBytes) cap--;  // (the carve rounds to even offsets)
+    return cap;
+}
+
+extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, int dim, int es, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                                           const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
+                                           int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
+    if (!lscqp_generic_supports(M, dim, es) || cls->n_obs_max > lscqp_generic_max_obstacles(M, dim, es)) return hipErrorInvalidValue;
+    const size_t lds = lscqp_generic_lds_bytes(M, dim, es, cls->n_obs_max);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lscqp_generic::pdip_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lscqp::kMaxLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lscqp_generic::pdip_generic_kernel, dim3((unsigned)n), dim3(lscqp_generic::kT), lds, stream, *cls, M, dim, es, n, hdr, rows,
+                       row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out);
+    return hipGetLastError();
+}

@@ -111,7 +111,7 @@ def _swarm_case(api, oracle, M, dim, n_obs, planner_lsc=True, seed=11):
     return sw, b, sol, cls, (hdr, rows, off, sfc), (ag, lsc, loff, sfc_o)
 
 
-@pytest.mark.parametrize("M,dim,n_obs,lsc_mode", [(5, 3, 3, True), (10, 2, 2, True), (5, 2, 2, False)])
+@pytest.mark.parametrize("M,dim,n_obs,lsc_mode", [(5, 3, 3, True), (10, 2, 2, True), (4, 3, 2, False), (9, 3, 2, True)])
 def test_lp_dump_is_the_reference_model_row_for_row(api, oracle, tmp_path, M, dim, n_obs, lsc_mode):
     """The LP file of an instance, parsed back, is the oracle's row-for-row assembly of populatebyrow: same objective, the same
     equality / inequality rows in the same order, the same bounds.  No device involved."""

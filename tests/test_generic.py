@@ -1,0 +1,92 @@
+"""The run-time-shaped kernel (csrc/lscqp_generic.hip): every (M, dim, planner mode) the reference accepts and neighbour counts beyond
+the compiled instances' register slots -- the reference builds its QP for whatever param.M / getObsSize() are
+(src/traj_optimizer.cpp:4-16, 399-437; src/param.cpp:71, 128-163).  Parity against the CPU oracle at the bar of test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+OBJ_TOL, KKT_TOL, X_TOL = 1e-8, 1e-8, 1e-6
+COMPILED_ES1 = {(5, 3), (6, 3), (7, 3), (4, 3), (3, 3), (2, 3), (10, 2), (8, 2), (5, 2), (10, 3)}
+COMPILED_ES0 = {(5, 3), (5, 2), (10, 2)}
+
+
+def test_every_shape_the_reference_accepts_has_a_kernel(api):
+    """No device needed: lscqp_create succeeds for every (2 <= M <= 12, dim 2 | 3, planner mode) -- compiled instance or the run-time-shaped
+    kernel -- and states a neighbour capacity; only M > 12 is refused."""
+    for M in range(2, 13):
+        for dim in (2, 3):
+            for mode in (api.PLANNER_LSC, api.PLANNER_DLSC, api.PLANNER_BVC, api.PLANNER_RSFC):
+                s = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=mode))
+                cap = s.max_obstacles()
+                assert cap >= 40, (M, dim, mode, cap)
+                if M <= 6:
+                    assert cap >= 64, (M, dim, mode, cap)
+    with pytest.raises(api.LscqpError):
+        api.Solver(api.make_desc(M=13, dim=3))
+
+
+def _swarm_vs_oracle(api, oracle, M, dim, n_obs, lsc_mode, N=8, steps=2, seed=3, warm=True):
+    from lsc_dr_planner_amd import synth
+
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed)
+    cls = oracle.make_class(M=M, dim=dim, planner_lsc=lsc_mode, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=api.PLANNER_LSC if lsc_mode else api.PLANNER_DLSC,
+                                   world_min=sw.world_min, world_max=sw.world_max))
+    worst = (0.0, 0.0)
+    for step in range(steps):
+        b = sw.build()
+        ag, lsc, off, sfc = H.swarm_oracle_inputs(oracle, sw, b)
+        R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=8)
+        hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+        hdr["terminal_segments"] = [oracle.terminal_segments(cls, ag[q:q + 1]) for q in range(N)]
+        G = sol.solve_host(hdr, rows, roff, sfcp, x_init=api.x_init_from_swarm(b, dim) if (warm and step > 0) else None)
+        assert (R["status"] == 0).all() and (G["status"] == 0).all(), (M, dim, lsc_mode, step, G["status"], R["status"])
+        dx = np.abs(G["x"] - R["x"]).max()
+        do = (np.abs(G["obj"] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))).max()
+        assert dx <= X_TOL and do <= OBJ_TOL, (M, dim, lsc_mode, step, dx, do)
+        q = step % N
+        stat, eqv, iqv = H.kkt_from_primal(oracle, cls, ag[q:q + 1], np.ascontiguousarray(b["lsc"][q]), np.ascontiguousarray(b["sfc"][q]), G["x"][q])
+        assert stat <= KKT_TOL and eqv <= KKT_TOL and iqv <= KKT_TOL, (M, dim, lsc_mode, step, stat, eqv, iqv)
+        worst = (max(worst[0], dx), max(worst[1], do))
+        sw.advance(G["x"])
+    return worst, G
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("lsc_mode", [True, False])
+def test_full_shape_grid_against_the_oracle(api, oracle, torch_cuda, dim, lsc_mode):
+    """The full (M, dim, end stop) grid, 2 <= M <= 10: shapes with a compiled instance run on it, the others on the run-time-shaped
+    kernel; both meet the oracle at the stated bar (cold first replan, warm-started second)."""
+    for M in range(2, 11):
+        _swarm_vs_oracle(api, oracle, M, dim, n_obs=4, lsc_mode=lsc_mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,dim,n_obs,lsc_mode", [(5, 3, 20, True), (10, 2, 9, True), (6, 3, 12, True), (10, 3, 24, True), (5, 3, 10, False), (3, 3, 6, True)])
+def test_generic_kernel_on_shapes_with_compiled_instances(api, oracle, torch_cuda, monkeypatch, M, dim, n_obs, lsc_mode):
+    """LSCQP_FORCE_GENERIC=1: the run-time-shaped kernel on the shapes every other fixture of the suite exists for -- it has to meet
+    the oracle where the compiled instances do, and the two kernels agree with each other far inside the bar."""
+    monkeypatch.delenv("LSCQP_FORCE_GENERIC", raising=False)
+    _, G_fast = _swarm_vs_oracle(api, oracle, M, dim, n_obs, lsc_mode, N=12, steps=3, seed=7)
+    monkeypatch.setenv("LSCQP_FORCE_GENERIC", "1")
+    _, G_gen = _swarm_vs_oracle(api, oracle, M, dim, n_obs, lsc_mode, N=12, steps=3, seed=7)
+    assert np.abs(G_fast["x"] - G_gen["x"]).max() <= 2e-7
+    assert (np.abs(G_fast["obj"] - G_gen["obj"]) / np.maximum(1.0, np.abs(G_fast["obj"]))).max() <= 1e-9
+    # bitwise reproducible: no atomics, fixed reduction orders
+    _, G_gen2 = _swarm_vs_oracle(api, oracle, M, dim, n_obs, lsc_mode, N=12, steps=3, seed=7)
+    assert np.array_equal(G_gen["x"], G_gen2["x"]) and np.array_equal(G_gen["obj"], G_gen2["obj"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,dim,n_obs", [(5, 3, 64), (6, 3, 64), (10, 2, 64), (10, 3, 64), (9, 3, 30)])
+def test_more_neighbours_than_any_compiled_instance_holds(api, oracle, torch_cuda, M, dim, n_obs):
+    """64 neighbours per agent: beyond the 48 / 40 of the largest compiled instances (every obstacle gets its rows in the reference,
+    src/traj_optimizer.cpp:399-437).  The launch falls through to the run-time-shaped kernel -- OPTIMAL at the oracle's optimum, never
+    CAPACITY."""
+    sol = api.Solver(api.make_desc(M=M, dim=dim))
+    assert sol.max_obstacles() >= n_obs
+    _swarm_vs_oracle(api, oracle, M, dim, n_obs, True, N=80, steps=2, seed=13)
