@@ -29,8 +29,9 @@ class TrajOptimizer {
 public:
     TrajOptimizer(const Param& param, const Mission& mission, const Eigen::MatrixXd& B);
     ~TrajOptimizer();
-    TrajOptimizer(const TrajOptimizer&) = delete;
-    TrajOptimizer& operator=(const TrajOptimizer&) = delete;
+    // copyable like the reference's class (implicit copy there): a copy owns its own solver handle of the same class
+    TrajOptimizer(const TrajOptimizer& other);
+    TrajOptimizer& operator=(const TrajOptimizer& other);
 
     TrajOptResult solve(const Agent& agent, const CollisionConstraints& constraints, const traj_t& initial_traj,
                         bool use_primal_algorithm);

@@ -25,6 +25,21 @@ TrajOptimizer::~TrajOptimizer() {
     if (handle) lscqp_destroy(handle);
 }
 
+TrajOptimizer::TrajOptimizer(const TrajOptimizer& o)
+    : param(o.param), mission(o.mission), B(o.B), M(o.M), n(o.n), phi(o.phi), dim(o.dim), dt(o.dt), handle(nullptr), raw_x(o.raw_x),
+      last_iterations(o.last_iterations), last_conflict(o.last_conflict), last_devices_used(o.last_devices_used) {
+    configure();  // its own handle
+}
+
+TrajOptimizer& TrajOptimizer::operator=(const TrajOptimizer& o) {
+    if (this == &o) return *this;
+    param = o.param, mission = o.mission, B = o.B;
+    M = o.M, n = o.n, phi = o.phi, dim = o.dim, dt = o.dt;
+    raw_x = o.raw_x, last_iterations = o.last_iterations, last_conflict = o.last_conflict, last_devices_used = o.last_devices_used;
+    configure();  // lscqp_update on the handle this object already owns
+    return *this;
+}
+
 // Everything buildQBase/buildAeqBase precomputed in the reference (src/traj_optimizer.cpp:13-15) happens inside
 // lscqp_create; the (n, phi) != (5, 3) and dim > 3 cases surface as std::invalid_argument exactly as there (:200, :249).
 void TrajOptimizer::configure() {

@@ -182,6 +182,18 @@ static int scenario_host() {
     Param p2 = param;
     p2.planner_mode = PlannerMode::DLSC;
     opt.updateParam(p2);
+    // copyable like the reference's class: a copy (and an assigned-to object) owns its own handle and outlives the original
+    bool copies_ok = false;
+    {
+        TrajOptimizer* first = new TrajOptimizer(param, mission, B);
+        TrajOptimizer copy(*first);
+        TrajOptimizer assigned(p2, mission, B);
+        assigned = *first;
+        delete first;
+        copy.updateParam(p2);
+        assigned.updateParam(param);
+        copies_ok = true;
+    }
     // container semantics
     CollisionConstraints cons(param, mission);
     cons.initializeLSC(3);
@@ -211,7 +223,7 @@ static int scenario_host() {
            threw_n ? "true" : "false", threw_dim ? "true" : "false", n_obs_seen, l.d, l.obs_control_point.z(), f.size(),
            f[3].d, f[3].normal_vector.y(), B(0, 0), B(0, 1));
     print_state("lin", s, true);
-    printf("\"solve_without_gpu\": \"%s\"}\n", no_device.c_str());
+    printf("\"copies_ok\": %s, \"solve_without_gpu\": \"%s\"}\n", copies_ok ? "true" : "false", no_device.c_str());
     return 0;
 }
 

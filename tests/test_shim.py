@@ -31,7 +31,7 @@ def test_host_logic(shim_exe):
 
     r = run(shim_exe, "host")[0]
     # constructor errors mirror the reference (std::invalid_argument, src/traj_optimizer.cpp:200, :249)
-    assert r["threw_n"] and r["threw_dim"]
+    assert r["threw_n"] and r["threw_dim"] and r["copies_ok"]
     # container: setLSC(oi, m, point, normal, d) fills all n+1 control points (src/collision_constraints.cpp:532-539)
     assert r["obs"] == 3 and r["lsc_d"] == 0.25 and r["lsc_pz"] == 3
     # Box::convertToLSCs: face 2i+1 = (-e_i, d = -box_max(i))  (src/collision_constraints.cpp:37-59)
