@@ -75,6 +75,11 @@ def build(force=False, verbose=False, jobs=None):
     sfc_src = os.path.join(CSRC, "lscsfc.hip")
     if force or _newer(sfc_o, hdrs + [sfc_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", sfc_src, "-o", sfc_o])
+    sfct_o = os.path.join(OBJ, "lscsfc_tp.o")
+    objs.append(sfct_o)
+    sfct_src = os.path.join(CSRC, "lscsfc_tp.hip")
+    if force or _newer(sfct_o, hdrs + [sfct_src, sfc_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", sfct_src, "-o", sfct_o])
     comm_o = os.path.join(OBJ, "lscqp_comm.o")
     objs.append(comm_o)
     comm_src = os.path.join(CSRC, "lscqp_comm.hip")

@@ -51,8 +51,10 @@ struct lscqp_map_s {
     int device = 0;           // the device the grids live on: a plan on another device must not be handed this map
     uint64_t generation = 0;  // bumped whenever the free-space table is rebuilt: captured graphs hold its margin by value
 };
+#ifndef LSCSFC_VARIANT_ONLY
 extern "C" int lscqp_map_device_(lscqp_map mp) { return mp->device; }
 extern "C" uint64_t lscqp_map_generation_(lscqp_map mp) { return mp->generation; }
+#endif
 
 namespace lscsfc {
 
@@ -470,9 +472,18 @@ __device__ unsigned long long sfc_dbg[16];
 #define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing)
 #endif
 constexpr int kAhead = LSCSFC_AHEAD;
-constexpr int kTab = 3072;    // entries of the per-(box, axis) tables of a batch
-constexpr int kCell = 1024;   // largest map extent (cells per axis) with the cell-centre table in LDS
-constexpr int kTodo = 8192;   // chunks of a batch the filter pass can list
+#ifndef LSCSFC_TAB
+#define LSCSFC_TAB 3072
+#endif
+#ifndef LSCSFC_CELL
+#define LSCSFC_CELL 1024
+#endif
+#ifndef LSCSFC_TODO
+#define LSCSFC_TODO 8192
+#endif
+constexpr int kTab = LSCSFC_TAB;    // entries of the per-(box, axis) tables of a batch
+constexpr int kCell = LSCSFC_CELL;  // largest map extent (cells per axis) with the cell-centre table in LDS
+constexpr int kTodo = LSCSFC_TODO;  // chunks of a batch the filter pass can list
 struct Ahead {
     float lo[kAhead][3];    // minimum corner of box j
     int n[kAhead][3];
@@ -873,7 +884,13 @@ __device__ void clip_to_prev(const BoxF& prev, BoxF& ini, double res) {  // :677
     }
 }
 
-__global__ __launch_bounds__(kSfcThreads) void construct_sfc_kernel(MapView mp, int mode, int M, int64_t n, const double* __restrict__ pts,
+// (A/B knob of the development builds: LSCSFC_WAVES_PER_EU caps the registers so that several smaller workgroups share a CU)
+#ifdef LSCSFC_WAVES_PER_EU
+#define LSCSFC_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(LSCSFC_WAVES_PER_EU, LSCSFC_WAVES_PER_EU)))
+#else
+#define LSCSFC_KERNEL_ATTR
+#endif
+__global__ __launch_bounds__(kSfcThreads) LSCSFC_KERNEL_ATTR void construct_sfc_kernel(MapView mp, int mode, int M, int64_t n, const double* __restrict__ pts,
                                                            const double* __restrict__ radius, lscqp_box* __restrict__ sfc,
                                                            int32_t* __restrict__ status) {
     const int64_t a = blockIdx.x;
@@ -973,6 +990,20 @@ __global__ __launch_bounds__(kSfcThreads) void construct_sfc_kernel(MapView mp, 
         const hipError_t e_ = (call);                                                                                 \
         if (e_ != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string(#call ": ") + hipGetErrorString(e_)).c_str()); \
     } while (0)
+
+#ifdef LSCSFC_VARIANT_ONLY
+// This translation unit is the THROUGHPUT build of the corridor kernel (lscsfc_tp.hip): the same source with 512 threads per agent and
+// the registers capped so that two workgroups share a CU; only its launcher is exported, the map and host entry points live in lscsfc.hip.
+extern "C" hipError_t lscsfc_launch_throughput_(const void* view, int mode, int M, int64_t n, const double* d_points, const double* d_radius,
+                                                lscqp_box* d_sfc, int32_t* d_status_out, void* stream) {
+    hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(lscsfc::kSfcThreads), 0, (hipStream_t)stream,
+                       *reinterpret_cast<const lscsfc::MapView*>(view), mode, M, n, d_points, d_radius, d_sfc, d_status_out);
+    return hipGetLastError();
+}
+#else
+extern "C" hipError_t lscsfc_launch_throughput_(const void* view, int mode, int M, int64_t n, const double* d_points, const double* d_radius,
+                                                lscqp_box* d_sfc, int32_t* d_status_out, void* stream);  // lscsfc_tp.hip
+extern "C" int lscsfc_throughput_max_cells_(void);
 
 extern "C" {
 
@@ -1155,9 +1186,33 @@ int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const dou
     v.nearest = mp->d_nearest;
     v.sat = mp->d_sat;
     v.sat_margin = mp->sat_margin;
-    hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(lscsfc::kSfcThreads), 0, (hipStream_t)stream, v, mode, M, n, d_points, d_radius,
-                       d_sfc, d_status_out);
-    const hipError_t e = hipGetLastError();
+    // Two builds of the one kernel source.  LATENCY (this file): 1024 threads per agent, one workgroup per CU -- the sixteen wavefronts
+    // shorten the chain of dependent tests of ONE corridor (171 / 204 / 335 us per corridor with 1024 / 512 / 256 threads), right while
+    // agents <= CUs.  THROUGHPUT (lscsfc_tp.hip): 256 threads per agent, registers capped at 128, batch tables cut to 35 KB of LDS: four
+    // workgroups per CU, the chains of four agents overlap -- 4096 agents 2.28 -> 1.06 ms with the free-space table, 2.89 -> 2.01 ms
+    // without.  Same statements, same boxes.
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        static int cached[64] = {};
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!cached[dev] && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached[dev] = prop.multiProcessorCount;
+            if (cached[dev]) n_cu = cached[dev];
+        }
+    }
+    const char* force = getenv("LSCSFC_VARIANT");  // testing knob: "latency" | "throughput"
+    const int tp_cells = lscsfc_throughput_max_cells_();  // (its cell-centre table is shorter: larger maps stay with the latency build)
+    const bool fits = mp->dims[0] <= tp_cells && mp->dims[1] <= tp_cells && mp->dims[2] <= tp_cells;
+    const bool tp = fits && (force ? (force[0] == 't') : (n > (int64_t)n_cu));
+    hipError_t e;
+    if (tp) {
+        e = lscsfc_launch_throughput_(&v, mode, M, n, d_points, d_radius, d_sfc, d_status_out, stream);
+    } else {
+        hipLaunchKernelGGL(lscsfc::construct_sfc_kernel, dim3((unsigned)n), dim3(lscsfc::kSfcThreads), 0, (hipStream_t)stream, v, mode, M, n, d_points,
+                           d_radius, d_sfc, d_status_out);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;
 }
@@ -1198,3 +1253,4 @@ int lscqp_construct_sfc(lscqp_map mp, int32_t mode, int32_t M, int64_t n, const 
 }
 
 }  // extern "C"
+#endif  // LSCSFC_VARIANT_ONLY

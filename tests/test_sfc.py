@@ -173,11 +173,15 @@ def test_gpu_map_matches_oracle(api, oracle, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("prepared", [0.0, 0.25, 0.15], ids=["plain", "free_space_table", "table_for_smaller_agents"])
 @pytest.mark.parametrize("world", ["forest10", "random3d", "sparse_origin"])
-def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world, prepared):
-    """`prepared` > 0: lscqp_map_prepare's free-space table is in place -- tests of boxes it proves free are passed without sampling
+@pytest.mark.parametrize("variant", ["latency", "throughput"])
+def test_gpu_corridors_match_oracle_bit_for_bit(api, oracle, world, prepared, variant, monkeypatch):
+    """`variant`: the two builds of the corridor kernel (1024 threads per agent, one workgroup per CU / 512 threads with capped registers,
+    two per CU: csrc/lscsfc_tp.hip), forced through LSCSFC_VARIANT -- a launch normally picks by agents > CUs.
+    `prepared` > 0: lscqp_map_prepare's free-space table is in place -- tests of boxes it proves free are passed without sampling
     (for the agents whose radius it covers: 0.15 leaves the 0.25 m agents on the exact path), the corridors must not change by a bit."""
     import torch
 
+    monkeypatch.setenv("LSCSFC_VARIANT", variant)
     rng = np.random.default_rng(11)
     if world == "sparse_origin":  # few obstacles: the phantom cell at the world origin (:796-800) decides many corridors
         wmin, wmax = np.array([-4.0, -4.0, 0.0]), np.array([4.0, 4.0, 2.5])

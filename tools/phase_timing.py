@@ -8,6 +8,7 @@ OUT = "/tmp/liblscqp_prof.so"
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 xflags = [a for a in sys.argv[1:] if a.startswith("-D")]
 M, D, N, NOBS, NSLOT, W = [int(v) for v in (args + ["5", "3", "64", "20", "10", "1"][len(args):])]
+MIXED = 1 if "--mixed" in sys.argv else 0  # the float32-factorisation instance (LSCQP_PRECISION_MIXED) instead of the fp64 one
 drv = r'''
 #include "lscqp_kernel.hpp"
 extern "C" int lscqp_dbg_read(unsigned long long* out, int reset) {
@@ -19,7 +20,7 @@ extern "C" int lscqp_dbg_read(unsigned long long* out, int reset) {
 if not os.path.exists(OUT) or "--rebuild" in sys.argv or True:
     open("/tmp/prof_drv.hip", "w").write(drv)
     # single TU so that the __device__ symbol is shared: include the instance + api sources
-    tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#define LSCQP_W %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT, W) + drv
+    tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#define LSCQP_W %d\n#define LSCQP_MIXED %d\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT, W, MIXED) + drv
     open(os.path.join("/tmp", "prof_tu.hip"), "w").write(tu)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector",
                            "-DLSCQP_PHASE_TIMING", "-I", SRC, "/tmp/prof_tu.hip", "-o", OUT] + xflags, stderr=subprocess.DEVNULL)
@@ -52,7 +53,7 @@ cls.tol = 1e-10; cls.max_iter = 60; cls.use_sfc = 1; cls.n_obs_max = sw.n_obs
 cls.warm_mu0, cls.warm_s0, cls.warm_net = (1e-7, 0.003, 0.6) if os.environ.get("TIGHT") else (1e-3, 0.03, 0.0)
 d_xi = torch.from_numpy(api.x_init_from_swarm(b, D)).to(dev) if os.environ.get("WARM", "1") != "0" else None
 XINIT = d_xi.data_ptr() if d_xi is not None else None
-fn = getattr(L, "lscqp_launch_%d_%d_1_%d_%d_0" % (M, D, NSLOT, W))
+fn = getattr(L, "lscqp_launch_%d_%d_1_%d_%d_%d" % (M, D, NSLOT, W, MIXED))
 fn.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
 def launch():
     rc = fn(C.byref(cls), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), XINIT, dx.data_ptr(), dob.data_ptr(), dst.data_ptr(), dinfo.data_ptr(), None)
@@ -63,7 +64,8 @@ launch(); torch.cuda.synchronize(); L.lscqp_dbg_read(buf, 1)
 it = dinfo.cpu().numpy().view(api.INFO_DTYPE)["iterations"]
 names = ["loop-top", "pass1", "grad/conv", "assembly", "factor", "solve1+expand", "pass2", "solve2+expand", "pass3", "update", "epilogue"]
 tot = sum(buf[i] for i in range(11)); nit = it.sum()
-print("status ok:", (dst.cpu().numpy() == 0).all(), "iters total", nit, "mean", it.mean())
+print("instance <%d,%d,true,%d,%d,%s>  %d QPs x %d neighbours" % (M, D, NSLOT, W, "float" if MIXED else "double", N, sw.n_obs))
+print("status: optimal", int((dst.cpu().numpy() == 0).sum()), "of", N, "(the float instance leaves the rest to the fp64 second pass)", "iters total", nit, "mean", it.mean())
 for i, nm in enumerate(names):
     print("%-16s %10.0f cycles/iter/QP  %5.1f%%" % (nm, buf[i] / max(nit, 1), 100.0 * buf[i] / tot))
 print("total cycles/iter/QP %.0f" % (tot / nit))

@@ -58,7 +58,7 @@ def profile_config(c):
     d = os.path.join(OUT, "trace_" + c)
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench_cmd(c), "%s_%s_trace.log" % (tag, c))
     bj = last_json(os.path.join(OUT, "%s_%s_trace.log" % (tag, c)))
-    res["bench_under_rocprof"] = bj and {k: bj[k] for k in ("value", "ms_per_step", "roofline", "solver", "config")}
+    res["bench_under_rocprof"] = bj and {k: bj.get(k) for k in ("value", "ms_per_step", "roofline", "roofline_valu", "solver", "config")}
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
         keep = [rows[0]] + [r for r in rows[1:] if "lscqp_pdip_kernel" in r[0]]
@@ -96,14 +96,32 @@ def profile_config(c):
     write, _ = pmc(["WRITE_SIZE"], "write")
     sq, _ = pmc(["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU",
                  "SQ_WAIT_INST_ANY"], "sq")
+    # instruction fetch (is a kernel whose loop body exceeds the 64 KB instruction cache thrashing it?) and the hardware's own count of
+    # fp64 vector instructions (cross-check of lscqp_instance_work's machine-code count); separate passes, the SQC block has few slots
+    ic, _ = pmc(["SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQC_ICACHE_MISSES_DUPLICATE"], "icache")
+    ic2, _ = pmc(["SQC_TC_INST_REQ", "SQ_IFETCH", "SQ_WAIT_ANY", "SQ_WAVES"], "ifetch")
+    fl, _ = pmc(["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_WAVES"], "f64")
     kernels = sorted(disp)  # mixed precision: the float instance and the fp64 second pass
     main = next((k for k in kernels if "float" in k), kernels[0] if kernels else None)
     res.update({"kernels": kernels, "kernel": main, "qps_per_launch": N, "lsc_neighbours": bj and bj["config"]["lsc_neighbours"],
                 "dispatch": disp.get(main), "dispatch_all": disp, "sq": sq.get(main), "sq_all": sq,
+                "icache": dict(ic.get(main) or {}, **(ic2.get(main) or {})), "f64_insts": fl.get(main),
                 "FETCH_SIZE_KB_raw": {k: v.get("FETCH_SIZE") for k, v in fetch.items()},
                 "WRITE_SIZE_KB_raw": {k: v.get("WRITE_SIZE") for k, v in write.items()},
                 "correction": "MI355X_MICROARCH.md (HBM): both counters are KB; FETCH_SIZE is doubled for contiguous 16 B/lane streaming "
                               "reads and must be calibrated on a known byte count for other patterns (fetch_calibration); WRITE_SIZE as is"})
+    if res["icache"].get("SQC_ICACHE_REQ"):
+        i = res["icache"]
+        res["icache"]["hit_rate"] = i.get("SQC_ICACHE_HITS", 0.0) / i["SQC_ICACHE_REQ"]
+        # one SQC->TC instruction request fetches one 64-byte line
+        res["icache"]["inst_bytes_from_L2_per_launch"] = 64.0 * i.get("SQC_TC_INST_REQ", 0.0)
+    if res.get("f64_insts") and res["f64_insts"].get("SQ_WAVES"):
+        f = res["f64_insts"]
+        per_wave = {k: f.get(k, 0.0) / f["SQ_WAVES"] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")}
+        res["f64_insts_per_wave"] = per_wave
+        res["f64_flops_per_launch_pmc"] = 64.0 * (f.get("SQ_INSTS_VALU_ADD_F64", 0) + f.get("SQ_INSTS_VALU_MUL_F64", 0) + 2.0 * f.get("SQ_INSTS_VALU_FMA_F64", 0) + f.get("SQ_INSTS_VALU_TRANS_F64", 0))
+        if bj and bj.get("roofline_valu"):
+            res["f64_flops_per_launch_static"] = bj["roofline_valu"]["fp64_flops_per_launch"]
     if bj:
         alg = bj["roofline"]["algorithmic_bytes_per_qp"] * N
         res["algorithmic_bytes_per_launch"] = alg

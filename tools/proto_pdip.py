@@ -67,7 +67,8 @@ def solve32(fac, b):
 
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
-          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None, sigma_pow=3.0):
+          tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None, sigma_pow=3.0,
+          dual_start=None, nbr_ids=None, state_out=None, split_steps=False):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -112,12 +113,15 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     rowsA = []  # per axis: (Gc (nr x P), lo, hi)
     rho_pair = 0.5 * comm_range - hdr["radius"]
     rho_wp = 0.5 * comm_range - 1e-5
+    keysA = []
     for k in range(dim):
         Gc, lo, hi = [], [], []
+        kk = []
         for m in range(M):
             for i in range(6):
                 if m == 0 and i < 3:
                     continue
+                kk.append(("I", k, m, i))
                 l, h = world_min[k], world_max[k]
                 if use_sfc:
                     l, h = max(l, sfc[m, 0, k]), min(h, sfc[m, 1, k])
@@ -129,22 +133,28 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             for i in range(5):
                 if m == 0 and i < 2:
                     continue
+                kk.append(("V", k, m, i))
                 e = np.zeros(P); e[6 * m + i + 1] = 1; e[6 * m + i] = -1
                 Gc.append(e); lo.append(-hdr["vmax"][k] * dt / 5); hi.append(hdr["vmax"][k] * dt / 5)
             for i in range(4):
                 if m == 0 and i < 1:
                     continue
+                kk.append(("A", k, m, i))
                 e = np.zeros(P); e[6 * m + i + 2] = 1; e[6 * m + i + 1] = -2; e[6 * m + i] = 1
                 Gc.append(e); lo.append(-hdr["amax"][k] * dt * dt / 20); hi.append(hdr["amax"][k] * dt * dt / 20)
         if comm_range > 0:
             for mi in range(1, M):
                 for m in range(mi, M):
+                    kk.append(("C", k, m, mi))
                     e = np.zeros(P); e[6 * m + 5] += 1; e[6 * mi + 0] += -1
                     Gc.append(e); lo.append(-rho_pair); hi.append(rho_pair)
         rowsA.append((np.array(Gc), np.array(lo), np.array(hi)))
+        keysA.append(kk)
     # one-sided dense G in z space:  G z >= h  (all rows)
     Gz, hz = [], []
+    keys = []
     for k in range(dim):
+        keys += [kq + ("lo",) for kq in keysA[k]] + [kq + ("hi",) for kq in keysA[k]]
         Gc, lo, hi = rowsA[k]
         GT = Gc @ T
         off = Gc @ cfix[k]
@@ -166,6 +176,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
                     g[k * nzA:(k + 1) * nzA] = nv3[k] * T[6 * m + i]
                     off += nv3[k] * cfix[k, 6 * m + i]
                 Gz.append(g[None, :]); hz.append(np.array([b - off]))
+                keys.append(("L", int(nbr_ids[oi]) if nbr_ids is not None else oi, m, i, "lo"))
     Gz = np.concatenate(Gz); hz = np.concatenate(hz)
     mrows = len(hz)
     Kfull = np.zeros((nz, nz)); gfull = np.zeros(nz)
@@ -200,6 +211,25 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     s = np.maximum(Gz @ z - hz, 0.0)
     s = np.maximum(s, s0)
     lam = mu0 / s  # centred start: every product s*lam = mu0
+    if dual_start is not None:
+        # experiment: DUAL warm start.  dual_start = (prev, rule): prev maps a row key of the PREVIOUS replan's QP to its final (s, lam);
+        # the row (fam, k, m, i) of this replan was row (fam, k, m + 1, i) then (the plan moved on by one segment), the new last
+        # segment takes the old last segment's.
+        prev, rule = dual_start
+        Mx = M - 1
+        res = Gz @ z - hz
+        hit = 0
+        for r_, kq in enumerate(keys):
+            fam = kq[0]
+            if fam == "C":
+                old = (fam, kq[1], min(kq[2] + 1, Mx), min(kq[3] + 1, Mx), kq[4])
+            else:
+                old = (fam, kq[1], min(kq[2] + 1, Mx), kq[3], kq[4])
+            if old in prev:
+                sp, lp = prev[old]
+                hit += 1
+                s[r_], lam[r_] = rule(res[r_], sp, lp, s[r_], lam[r_])
+        LAST_START["dual_hits"] = hit
     gscale = max(1.0, np.abs(gfull).max())
     objc = sum(0.5 * cfix[k] @ Hx_t @ cfix[k] + fx[k] @ cfix[k] for k in range(dim)) + w_t * ts * sum(
         hdr["goal"][k] ** 2 for k in range(dim))
@@ -349,8 +379,10 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         a = 1e300
         neg = ds < 0
         if neg.any(): a = min(a, (-s[neg] / ds[neg]).min())
+        a_pr = a
+        a_du = 1e300
         neg = dl < 0
-        if neg.any(): a = min(a, (-lam[neg] / dl[neg]).min())
+        if neg.any(): a = min(a, (-lam[neg] / dl[neg]).min()); a_du = (-lam[neg] / dl[neg]).min()
         # experiment: Gondzio's multiple centrality correctors on top of the Mehrotra direction (one extra solve each): aim a little
         # beyond the current step, pull the outlying complementarity products of the trial point back into [0.1, 10] x target
         for _g in range(gondzio if it >= gondzio_from else 0):
@@ -391,6 +423,19 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             i_s, i_l = int(rs.argmin()), int(rl.argmin())
             print("   alpha %.4f sigma %.2e | primal block row %d ratio %.3f (s %.2e lam %.2e) | dual block row %d ratio %.3f (s %.2e lam %.2e) | rows %d"
                   % (a, sigma, i_s, rs[i_s], s[i_s], lam[i_s], i_l, rl[i_l], s[i_l], lam[i_l], mrows))
+        if split_steps:
+            # experiment: separate primal and dual step lengths (as Ipopt takes them): (z, s) move by a_p, lam by a_d
+            tau_ = tau
+            ap = min(1.0, tau_ * a_pr); ad = min(1.0, tau_ * a_du)
+            for _bt in range(10):
+                sn = s + ap * ds; ln = lam + ad * dl
+                if (sn * ln).min() >= 1e-4 * (sn @ ln) / mrows:
+                    break
+                ap *= 0.7 if ap >= ad else 1.0
+                ad *= 0.7 if ad > ap else 1.0
+                if ap == ad: ap *= 0.7; ad *= 0.7
+            z = z + ap * dz; s = s + ap * ds; lam = lam + ad * dl
+            continue
         z = z + a * dz; s = s + a * ds; lam = lam + a * dl
     x = np.concatenate([cfix[k] + T @ z[k * nzA:(k + 1) * nzA] for k in range(dim)])
     # objective: the same polynomial integral as x'(w_c Q)x, evaluated through third differences (stable)
@@ -405,4 +450,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         for m in range(M - ts, M):
             obj += w_t * (c[6 * m + 5] - hdr["goal"][k]) ** 2
     x = x + np.repeat(org[:dim], P)
+    if state_out is not None:
+        state_out.clear()
+        state_out.update({kq: (float(s[r_]), float(lam[r_])) for r_, kq in enumerate(keys)})
     return x, obj, status, it
