@@ -881,6 +881,13 @@ def main():
                        "samples": {"device_resident": int(len(lat)), "single_qp": int(len(lat1)), "host_pointers": int(len(lath))}},
         "solver": {"non_optimal": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
     }
+    try:  # hardware cross-check of the machine-code count, from the committed PMC pass of this command (labelled as such)
+        if out.get("roofline_valu") and pm.get("f64_flops_per_launch_pmc") and pm.get("qps_per_launch") == N:
+            out["roofline_valu"]["pmc_cross_check"] = {
+                "fp64_flops_per_launch_pmc": pm["f64_flops_per_launch_pmc"], "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64)" % os.path.basename(pf),
+                "static_over_pmc": pm.get("f64_flops_per_launch_static", 0.0) / pm["f64_flops_per_launch_pmc"] if pm.get("f64_flops_per_launch_static") else None}
+    except Exception:
+        pass
     if rank_parity is not None:
         out["parity_all_ranks"] = rank_parity
     if step_lat is not None:
@@ -971,6 +978,24 @@ def main():
                                                "non_optimal": t["non_optimal"], "ratio_to_default": t["qp_per_s"] / by["c4_f64"]["qp_per_s"] if "qp_per_s" in by.get("c4_f64", {}) else None}
         except Exception as ex:
             out["tight_warm_start_at_4096"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+
+        # the run-time-shaped kernel (csrc/lscqp_generic.hip: shapes / neighbour counts no compiled instance serves): informational --
+        # the headline's class forced onto it, a 64-neighbour batch no compiled instance holds, and a shape that has none (M = 9, DLSC)
+        try:
+            gk = {}
+            os.environ["LSCQP_FORCE_GENERIC"] = "1"
+            t = measure_config(torch, api, synth, dev, "c1", dict(CONFIGS["c1"], what="configs[1] shape forced onto the run-time-shaped kernel"), O=None, lat_seconds=0.5)
+            gk["c1_shape_forced"] = {k: t[k] for k in ("kernel_ms", "qp_per_s", "iters_mean", "iters_max", "non_optimal")}
+            os.environ.pop("LSCQP_FORCE_GENERIC")
+            t = measure_config(torch, api, synth, dev, "n64", dict(agents=128, segments=5, obs=64, dim=3, style="forest", precision="f64", rows="f64",
+                                                                  what="128 agents x M=5 x 64 LSC neighbours (beyond every compiled instance)"), O=None, lat_seconds=0.5)
+            gk["m5_64_neighbours"] = {k: t[k] for k in ("kernel_ms", "qp_per_s", "iters_mean", "iters_max", "non_optimal", "lsc_neighbours")}
+            gk["compiled_instance_at_c1"] = by.get("c1", {}).get("kernel_ms") or out["roofline"]["kernel_ms"]
+            out["generic_kernel"] = gk
+        except Exception as ex:
+            out["generic_kernel"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        finally:
+            os.environ.pop("LSCQP_FORCE_GENERIC", None)
 
         try:
             out["replan_chain"] = replan_chain(torch, api)
