@@ -319,9 +319,10 @@ struct Cfg {
     static constexpr int o_S = o_x0 + 4 * NX;   // per-cp 3x3 sym blocks [P][6]
     static constexpr int o_om = o_S + 6 * P;    // two-sided row weights
     static constexpr int o_z = o_om + NOM;      // z, dz
-    static constexpr int o_goal = o_z + 2 * T;  // goal - p0 (4 doubles)
-    static constexpr int o_red = o_goal + 4;    // cross-wave reduction scratch (W > 1): 2 buffers x W waves x 4
+    static constexpr int o_goal = o_z + 2 * T;  // goal - p0 (4 doubles), then the origin p0 (4 doubles)
+    static constexpr int o_red = o_goal + 8;    // cross-wave reduction scratch (W > 1): 2 buffers x W waves x 4
     static constexpr int o_col = o_red + (W > 1 ? 8 * W : 0);  // pivot-column / solve broadcast buffer, 2 x T
+    static_assert(2 * T + 2 >= 32 + 6 * M, "the prologue parks the header (32 doubles) and the corridor boxes (6 M) in the column buffer");
     static constexpr int o_zs = o_col + 2 * T + 2;  // the last point that met the acceptance tests (z), NZ
     static constexpr int o_H = ((o_zs + NZ + 1) / 2) * 2;  // per-lane scratch rows of the reduced matrix [NZ][LDH], scalars of FB_ bytes
     // (nested dissection also parks the factor of the NS accumulator lanes there: [NZ + NS + 1][LDP])
@@ -440,7 +441,19 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     };
     const int64_t q = blockIdx.x;
     if (q >= n) return;
-    const lscqp_header* H = hdr + q;
+    // The header (256 B) and the instance's corridor boxes (48 B per segment) are fetched ONCE, one 8-byte load per lane, and parked in
+    // the pivot-column buffer (idle until the first factorisation); the prologue reads them from there.  Read field by field from
+    // global memory they were a string of dependent scalar / vector loads: 9.6 k + 11.9 k cycles of a 4096-QP launch's prologue per QP
+    // (header + control points, two-sided row set-up; tools/phase_timing.py) against 3.5 k + 5.2 k now.  `H` below points into LDS.
+    double* const org_ = goal_ + 4;
+    {
+        const double* hsrc = reinterpret_cast<const double*>(hdr + q);
+        const double* ssrc = reinterpret_cast<const double*>(sfc) + q * 6 * M;
+        for (int e = lane; e < 32 + (cls.use_sfc ? 6 * M : 0); e += T) col_[e] = e < 32 ? hsrc[e] : ssrc[e - 32];
+        __syncthreads();
+    }
+    const lscqp_header* H = reinterpret_cast<const lscqp_header*>(col_);
+    const lscqp_box* const sfcl = reinterpret_cast<const lscqp_box*>(col_ + 32);  // boxes of THIS instance, [M]
     int flags = 0;           // lscqp_info.flags
     int it_before = 0;       // iterations of an earlier pass over this instance
     if (cls.repair) {        // uniform over the workgroup
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     // long-lived VGPRs, as a register array hipcc selects between the elements through scratch memory.
     const double org0 = H->p0[0], org1 = H->p0[1], org2 = H->p0[2];
     const double goal0 = H->goal[0] - org0, goal1 = H->goal[1] - org1, goal2 = H->goal[2] - org2;
-    if (lane < 3) goal_[lane] = H->goal[lane] - H->p0[lane];
+    if (lane < 3) goal_[lane] = H->goal[lane] - H->p0[lane], org_[lane] = H->p0[lane];
     int ts = H->terminal_segments;
     if (ts <= 0) {  // src/traj_optimizer.cpp:530-538 in fp64
         const double d2 = goal0 * goal0 + goal1 * goal1 + goal2 * goal2;
@@ -640,27 +653,45 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     LSCQP_T(11);  // prologue a: header, control points, scratch rows
     // ---- stage LSC row constants: HBM (AoS 32 B, [oi][m][i]) -> LDS SoA [oi][cp], translated to the agent origin --
     {
-        const lscqp_row* R = rows + row_offsets[q];
+        const uint64_t roff = row_offsets[q];
+        const lscqp_row* R = rows + roff;
         const int nact = n_obs * CP;
-        for (int e = lane; e < nact; e += T) {
-            const int o = e / CP, cp = e % CP;
-            double4 v;
-            if (cls.rows_f32) {  // LSCQP_ROWS_F32: 16-byte rows, widened here; everything after this line is the same arithmetic
-                const float4 f = reinterpret_cast<const float4*>(rows)[row_offsets[q] + (uint64_t)(o * P + cp + 3)];
-                v = double4{(double)f.x, (double)f.y, (double)f.z, (double)f.w};
-            } else {
-                v = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
+        // The loads of a lane are issued LSCQP_STAGE_UNROLL at a time before any of them is consumed: with one load in flight per
+        // pass through the loop the staging was a chain of HBM round trips (25.5 k cycles per QP when 4096 QPs stage at once, 3.6 k in a
+        // 64-QP launch; tools/phase_timing.py).  Lanes past the end re-read row 0 of the instance (always present when nact > 0).
+#ifndef LSCQP_STAGE_UNROLL
+#define LSCQP_STAGE_UNROLL 4
+#endif
+        for (int e0 = lane; e0 < nact; e0 += T * LSCQP_STAGE_UNROLL) {
+            double4 v[LSCQP_STAGE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LSCQP_STAGE_UNROLL; u++) {
+                const int e = e0 + T * u;
+                const int ec = e < nact ? e : 0;
+                const int o = ec / CP, cp = ec % CP;
+                if (cls.rows_f32) {  // LSCQP_ROWS_F32: 16-byte rows, widened here; everything after this line is the same arithmetic
+                    const float4 f = reinterpret_cast<const float4*>(rows)[roff + (uint64_t)(o * P + cp + 3)];
+                    v[u] = double4{(double)f.x, (double)f.y, (double)f.z, (double)f.w};
+                } else {
+                    v[u] = *reinterpret_cast<const double4*>(&R[o * P + cp + 3]);
+                }
             }
-            double nx = v.x, ny = v.y, nz = (DIM == 3) ? v.z : 0.0;
-            double b = v.w - (v.x * org0 + v.y * org1 + (DIM == 3 ? v.z * org2 : 0.0));
-            if (sqrt(v.x * v.x + v.y * v.y + v.z * v.z) < 1e-5) {  // dropped like the reference does (:409-411)
-                nx = ny = nz = 0.0;
-                b = -1.0;
+#pragma unroll
+            for (int u = 0; u < LSCQP_STAGE_UNROLL; u++) {
+                const int e = e0 + T * u;
+                double nx = v[u].x, ny = v[u].y, nz = (DIM == 3) ? v[u].z : 0.0;
+                double b = v[u].w - (v[u].x * org0 + v[u].y * org1 + (DIM == 3 ? v[u].z * org2 : 0.0));
+                if (sqrt(v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z) < 1e-5) {  // dropped like the reference does (:409-411)
+                    nx = ny = nz = 0.0;
+                    b = -1.0;
+                }
+                if (e < nact) {
+                    Rnx[e] = nx;
+                    Rny[e] = ny;
+                    Rnz[e] = nz;
+                    Rb[e] = b;
+                }
             }
-            Rnx[e] = nx;
-            Rny[e] = ny;
-            Rnz[e] = nz;
-            Rb[e] = b;
         }
         if (lane == 0) {  // the dead row
             Rnx[NROW] = Rny[NROW] = Rnz[NROW] = 0.0;
@@ -712,8 +743,8 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                             hi = 100.0 - ok_;
                         }
                         if (cls.use_sfc) {                                                // :372-397
-                            lo = fmax(lo, sfc[q * M + m].bmin[k] - ok_);
-                            hi = fmin(hi, sfc[q * M + m].bmax[k] - ok_);
+                            lo = fmax(lo, sfcl[m].bmin[k] - ok_);
+                            hi = fmin(hi, sfcl[m].bmax[k] - ok_);
                         }
                         if (comm_on && cp % 6 == 5) {  // pairs (m, mi=0) :482-487 and waypoint rows :494-497
                             const double wpk = H->next_waypoint[k] - ok_;
@@ -905,7 +936,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
         double part = 0.5 * q2s * 3600.0 * quad;
         if (ref_rounding) {  // compile-time constant at both call sites
-            const double ok_ = H->p0[k];
+            const double ok_ = org_[k];  // (the header's copy in the column buffer is long gone by the epilogue)
             double corr = 0;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -1976,7 +2007,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     const double obj = objective(true, lane);
     for (int e = lane; e < NX; e += T) {
         const int k = e / P;
-        x_out[q * NX + e] = c_[e] + H->p0[k];
+        x_out[q * NX + e] = c_[e] + org_[k];
     }
     if (lane == 0) {
         obj_out[q] = obj;
