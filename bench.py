@@ -885,7 +885,8 @@ def main():
         if out.get("roofline_valu") and pm.get("f64_flops_per_launch_pmc") and pm.get("qps_per_launch") == N:
             out["roofline_valu"]["pmc_cross_check"] = {
                 "fp64_flops_per_launch_pmc": pm["f64_flops_per_launch_pmc"], "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64)" % os.path.basename(pf),
-                "static_over_pmc": pm.get("f64_flops_per_launch_static", 0.0) / pm["f64_flops_per_launch_pmc"] if pm.get("f64_flops_per_launch_static") else None}
+                "machine_code_count_over_pmc": out["roofline_valu"]["fp64_flops_per_launch"] / pm["f64_flops_per_launch_pmc"],
+                "note": "valid while the iteration counts of this run equal the profiled run's (same seeds: they do)"}
     except Exception:
         pass
     if rank_parity is not None:

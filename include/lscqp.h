@@ -662,13 +662,15 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
  * the instance a launch of n QPs with n_obs_max obstacles selects -- the same selection lscqp_solve_batch_device makes.
  *   flops of an instance that ran `it` iterations  =  flops_fixed + it * flops_per_iteration + flops_last_pass
  * (the pass that detects convergence runs the residual pass and the test only).  These are the lane-flops the SIMDs EXECUTE,
- * masked lanes and the in-line blocks most iterations skip included (about 12 % above the PMC instruction count), i.e. an upper
- * bound of the useful work and the quantity the 78.6 TFLOP/s fp64 vector peak of MI355X is about. */
+ * masked lanes and the in-line blocks most iterations skip included (about 15 % above the hardware's own SQ_INSTS_VALU_*_F64
+ * count, profiles/), i.e. an upper bound of the useful work and the quantity the 78.6 TFLOP/s fp64 vector peak of MI355X is about.
+ * Regions of the nested-dissection instances that only one or two of the workgroup's wavefronts execute are counted for those
+ * wavefronts only (the source brackets them with position markers). */
 typedef struct lscqp_work {
     double flops_fixed;              /* prologue + epilogue */
     double flops_per_iteration;
     double flops_last_pass;
-    double f64_insts_per_iteration;  /* per wavefront */
+    double f64_insts_per_iteration;  /* per wavefront (averaged over the workgroup's wavefronts where they run different code) */
     double valu_insts_per_iteration; /* per wavefront, all vector-ALU instructions */
     double lds_insts_per_iteration;  /* per wavefront */
     double valu_insts_fixed;         /* per wavefront: prologue + epilogue + last pass */

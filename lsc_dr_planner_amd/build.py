@@ -143,14 +143,17 @@ def _work_table(inst_objs, work_o, jobs=None):
     src = os.path.join(OBJ, "lscqp_work_table.cpp")
     with open(src, "w") as f:
         f.write("// generated by lsc_dr_planner_amd/build.py from the instances' machine code (isa_work.py); per wavefront\n")
-        f.write("struct Row { int M, D, E, S, W, X; double t[12]; };\nstatic const Row kRows[] = {\n")
+        f.write("struct Row { int M, D, E, S, W, X; double t[24]; };\nstatic const Row kRows[] = {\n")
         for o, w in zip(inst_objs, works):
             key = os.path.basename(o)[5:-2].split("_")
-            vals = [w["%s_%s" % (a, b)] for a in ("iter", "last", "fixed") for b in ("fma_f64", "other_f64", "valu", "lds")]
+            # per section: instructions every wavefront runs (fma, other fp64, valu, lds), then the ones only SOME wavefronts run, summed
+            # over those wavefronts (nested-dissection instances)
+            vals = [w["%s_%s" % (a, b)] for a in ("iter", "last", "fixed")
+                    for b in ("fma_f64", "other_f64", "valu", "lds", "partial_fma_f64", "partial_other_f64", "partial_valu", "partial_lds")]
             f.write("    {%s, {%s}},\n" % (", ".join(key), ", ".join(str(v) for v in vals)))
-        f.write("};\nextern \"C\" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out12) {\n"
+        f.write("};\nextern \"C\" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out24) {\n"
                 "    for (const Row& r : kRows)\n        if (r.M == M && r.D == D && r.E == E && r.S == S && r.W == W && r.X == X) {\n"
-                "            for (int i = 0; i < 12; i++) out12[i] = r.t[i];\n            return 0;\n        }\n    return 1;\n}\n")
+                "            for (int i = 0; i < 24; i++) out24[i] = r.t[i];\n            return 0;\n        }\n    return 1;\n}\n")
     _run(["g++", "-O1", "-fPIC", "-c", src, "-o", work_o])
 
 

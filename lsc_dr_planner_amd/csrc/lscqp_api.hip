@@ -295,7 +295,7 @@ int lscqp_uses_sfc(lscqp_handle h) { return h ? (h->desc.use_sfc ? 1 : 0) : -1; 
 
 // Work counters of the kernel instance a launch would select (include/lscqp.h): the per-wavefront instruction counts come from the
 // table the build reads off each instance's machine code (lsc_dr_planner_amd/isa_work.py -> lscqp_work_table_, generated TU).
-extern "C" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out12);
+extern "C" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out24);
 int lscqp_instance_work(lscqp_handle h, int64_t n, int32_t n_obs_max, lscqp_work* out) {
     if (!h || !out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
     if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
@@ -306,19 +306,21 @@ int lscqp_instance_work(lscqp_handle h, int64_t n, int32_t n_obs_max, lscqp_work
     if (!inst) return fail(LSCQP_ERR_UNSUPPORTED, "no compiled kernel instance for this launch (the run-time-shaped kernel carries no instruction counts)");
     const int G = 64 * inst->waves / (6 * inst->M - 3) > 0 ? 64 * inst->waves / (6 * inst->M - 3) : 1;
     const int nslot = inst->max_obs / G;
-    double t[12];
+    double t[24];
     if (lscqp_work_table_(inst->M, inst->dim, inst->es, nslot, inst->waves, inst->mixed, t) != 0)
         return fail(LSCQP_ERR_UNSUPPORTED, "the build holds no instruction counts for this kernel instance");
     memset(out, 0, sizeof *out);
-    const double lanes = 64.0 * inst->waves;
-    // t: iter {fma, other, valu, lds}, last {..}, fixed {..} -- instructions per wavefront
-    out->flops_per_iteration = lanes * (2.0 * t[0] + t[1]);
-    out->flops_last_pass = lanes * (2.0 * t[4] + t[5]);
-    out->flops_fixed = lanes * (2.0 * t[8] + t[9]);
-    out->f64_insts_per_iteration = t[0] + t[1];
-    out->valu_insts_per_iteration = t[2];
-    out->lds_insts_per_iteration = t[3];
-    out->valu_insts_fixed = t[10] + t[6];
+    const double W = inst->waves;
+    // per section (iteration body, last pass, fixed part) 8 numbers: {fma, other fp64, valu, lds} that EVERY wavefront of the
+    // workgroup runs, then the same four for instructions only some wavefronts run, already summed over those wavefronts
+    auto flops = [&](const double* s) { return 64.0 * (W * (2.0 * s[0] + s[1]) + (2.0 * s[4] + s[5])); };
+    out->flops_per_iteration = flops(t);
+    out->flops_last_pass = flops(t + 8);
+    out->flops_fixed = flops(t + 16);
+    out->f64_insts_per_iteration = t[0] + t[1] + (t[4] + t[5]) / W;  // averaged over the workgroup's wavefronts
+    out->valu_insts_per_iteration = t[2] + t[6] / W;
+    out->lds_insts_per_iteration = t[3] + t[7] / W;
+    out->valu_insts_fixed = t[18] + t[10] + (t[22] + t[14]) / W;
     out->wavefronts = inst->waves;
     out->nslot = nslot;
     out->max_obstacles = inst->max_obs;

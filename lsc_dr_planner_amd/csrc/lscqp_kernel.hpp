@@ -224,6 +224,8 @@ __device__ __forceinline__ bool pivot_ok(FT d) {
 // Position markers for the build's instruction count (lsc_dr_planner_amd/isa_work.py reads the work of one iteration off the
 // machine code: SURVEY.md 8d's fp64-VALU figure): s_nop 13 = top of the iteration body, s_nop 12 = behind the convergence test
 // (where the last, partial pass leaves), s_nop 14 = end of the body.  The compiler itself emits s_nop 0..7 only; ~14 idle cycles each.
+// Nested-dissection instances: regions only SOME wavefronts of the workgroup execute are bracketed by s_nop 8 (wavefront 0 only) /
+// s_nop 9 (wavefront 1 only) / s_nop 10 (wavefronts 0 and 1) ... s_nop 11 (end), so that the count knows who runs what.
 #define LSCQP_MARK(k) asm volatile("s_nop " #k)
 #ifdef LSCQP_PHASE_TIMING
 __device__ unsigned long long lscqp_dbg_cycles[16];
@@ -1542,8 +1544,16 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         asm volatile("" ::: "memory");  // LDS program order between the steps
                     });
                 };
-                if (wv == 0) block_phase(std::integral_constant<int, 0>{});
-                if (wv == 1) block_phase(std::integral_constant<int, 1>{});
+                if (wv == 0) {
+                    LSCQP_MARK(8);
+                    block_phase(std::integral_constant<int, 0>{});
+                    LSCQP_MARK(11);
+                }
+                if (wv == 1) {
+                    LSCQP_MARK(9);
+                    block_phase(std::integral_constant<int, 1>{});
+                    LSCQP_MARK(11);
+                }
                 LSCQP_T(14);  // (development timing: the block phase of the nested dissection)
                 {   // hand-over of wavefront 1's share (single predicated stores; everything else is masked arithmetically)
                     const bool give = (wv == 1) && lf >= NB && lf < NB + NS;
@@ -1563,6 +1573,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     });
                 }
                 if (wv == 0) {  // the separator: dense LDL^T on columns / lanes NB .. NA-1
+                    LSCQP_MARK(8);
                     colw[lf] = A[NB];
                     double d = bcast(A[NB], NB);
                     double invd = fast_rcp(d);
@@ -1606,6 +1617,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         asm volatile("" ::: "memory");
                     });
                     if (lf == 0) flag[0] = (pivot_bad || flag[0] != 0.0) ? 1.0 : 0.0;
+                    LSCQP_MARK(11);
                 }
                 __syncthreads();
                 pivot_bad = (flag[0] != 0.0) || (flag[1] != 0.0);
@@ -1659,15 +1671,18 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 const int srow = sep ? ll_ - NB : 0;
                 // ---- forward through the blocks: L w = b (unit lower) ----
                 if (wv < 2) {
+                    LSCQP_MARK(10);
                     static_for<0, NB>([&](auto Jc) {
                         constexpr int j = decltype(Jc)::value;
                         const double wj = bcast(b, j);
                         b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
                     });
+                    LSCQP_MARK(11);
                 }
                 if (wv == 1 && sep) hand[srow] = b;  // accumulator rows started from 0: their value IS wavefront 1's share
                 __syncthreads();
                 if (wv == 0) {
+                    LSCQP_MARK(8);
                     b += sep ? hand[srow] : 0.0;
                     static_for<NB, NA>([&](auto Jc) {  // forward through the separator
                         constexpr int j = decltype(Jc)::value;
@@ -1681,22 +1696,27 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         const double xj = bcast(b * dinv_own, j);
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);  // (the block rows of wavefront 0 take their separator part here)
                     });
+                    LSCQP_MARK(11);
                 }
                 if (wv == 0 && sep) hand[srow] = b * dinv_own;  // the separator's solution (wavefront 1 reads hand only after the barrier)
                 __syncthreads();
                 if (wv == 1) {  // block rows of wavefront 1: U[i][S] x_S
+                    LSCQP_MARK(9);
                     static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
                         if constexpr (C::nd_touched(1, c)) b = fma(-A[NB + c], hand[c], b);  // (accumulator lanes compute a value nobody uses)
                     });
+                    LSCQP_MARK(11);
                 }
                 if (wv < 2) {
+                    LSCQP_MARK(10);
                     asm volatile("" : "+v"(ll_));
                     static_for<0, NB>([&](auto Jc) {
                         constexpr int j = NB - 1 - decltype(Jc)::value;
                         const double xj = bcast(b * dinv_own, j);
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);
                     });
+                    LSCQP_MARK(11);
                 }
                 return b * dinv_own;  // (final once the lane's own column has been broadcast; 0 for lanes without a row)
             };

@@ -65,21 +65,48 @@ def count(asm_text):
     if not (top < conv < end):
         raise RuntimeError("iteration markers out of order: %r" % mark)
 
+    # Nested-dissection instances bracket the regions only some wavefronts execute: s_nop 8 = wavefront 0 only, 9 = wavefront 1 only,
+    # 10 = wavefronts 0 and 1, s_nop 11 = end.  `share[addr]` = number of wavefronts that run the instruction (None: all of them).
+    share, cur = {}, None
+    for l in asm_text.split("\n"):
+        m = _INS.match(l)
+        if not m:
+            continue
+        op, addr = m.group(1), int(m.group(3), 16)
+        if op == "s_nop":
+            k = re.match(r"^\s+s_nop (\d+)", l)
+            k = int(k.group(1)) if k else -1
+            if k in (8, 9):
+                cur = 1
+            elif k == 10:
+                cur = 2
+            elif k == 11:
+                cur = None
+            continue
+        if cur is not None:
+            share[addr] = cur
+
     def tally(sel):
-        fma = other = valu = lds = 0
+        """per-wavefront instruction counts AVERAGED over the workgroup's wavefronts: an instruction only `k` of the W wavefronts run counts k / W
+        (weights resolved by the caller through `waves`)."""
+        t = {"fma_f64": 0.0, "other_f64": 0.0, "valu": 0.0, "lds": 0.0, "partial_fma_f64": 0.0, "partial_other_f64": 0.0, "partial_valu": 0.0,
+             "partial_lds": 0.0}
         for addr, op, _ in ins:
             if not sel(addr):
                 continue
+            k = share.get(addr)
+            pre = "" if k is None else "partial_"
+            wgt = 1.0 if k is None else float(k)  # partial_*: summed over the wavefronts that run it (1 or 2), not per wavefront
             if op.startswith("v_"):
-                valu += 1
+                t[pre + "valu"] += wgt
                 if _F64_ARITH.match(op):
                     if op.startswith(("v_fma_f64", "v_fmac_f64")):
-                        fma += 1
+                        t[pre + "fma_f64"] += wgt
                     else:
-                        other += 1
+                        t[pre + "other_f64"] += wgt
             elif op.startswith("ds_"):
-                lds += 1
-        return {"fma_f64": fma, "other_f64": other, "valu": valu, "lds": lds}
+                t[pre + "lds"] += wgt
+        return t
 
     body = tally(lambda a: top <= a <= end)
     head = tally(lambda a: top <= a <= conv)  # residual pass + convergence test: what the final, partial pass through the body executes

@@ -53,8 +53,9 @@ def test_swarm_parity(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed, st
         hdr["terminal_segments"] = [oracle.terminal_segments(cls, ag[q:q + 1]) for q in range(N)]
         G = sol.solve_host(hdr, rows, roff, sfcp)
         _check_against_oracle(oracle, cls, G, R)
-        # KKT residuals of the GPU point on the reference's row-for-row model (a few agents per step)
-        for q in range(0, N, max(1, N // 4)):
+        # KKT residuals of the GPU point on the reference's row-for-row model: a few agents per step, EVERY agent for the nz = 84 class
+        # (where the solver's own stationarity test has a documented rounding floor: this is the check that does not)
+        for q in range(0, N, 1 if dim * (3 * M - 2) > 64 else max(1, N // 4)):
             lq = np.ascontiguousarray(b["lsc"][q]); sq = np.ascontiguousarray(b["sfc"][q])
             stat, eqv, iqv = H.kkt_from_primal(oracle, cls, ag[q:q + 1], lq, sq, G["x"][q])
             assert stat <= KKT_TOL and eqv <= KKT_TOL and iqv <= KKT_TOL, (step, q, stat, eqv, iqv)
