@@ -43,7 +43,10 @@ def valu_roofline(sol, n, n_obs, iterations, kernel_ms):
     flops_fixed + iterations x flops_per_iteration + flops_last_pass, where the iterations are the kernel's own count of THIS run
     (lscqp_info.iterations) and the per-iteration figure is read off the selected kernel instance's machine code at build time
     (lscqp_instance_work), over the launch duration measured in this run; against MI355X's 78.6 TFLOP/s fp64 vector peak."""
-    w = sol.instance_work(n, n_obs)
+    try:
+        w = sol.instance_work(n, n_obs)
+    except Exception:  # the run-time-shaped kernel carries no instruction counts
+        return None
     it = np.asarray(iterations, dtype=np.float64)
     flops = float((w["flops_fixed"] + w["flops_last_pass"] + it * w["flops_per_iteration"]).sum())
     rate = flops / (kernel_ms * 1e-3)
