@@ -11,10 +11,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_forest10_closed_loop_is_safe_and_feasible():
+@pytest.mark.parametrize("kernel", ["compiled", "runtime_shaped"])
+def test_forest10_closed_loop_is_safe_and_feasible(kernel, monkeypatch):
+    """kernel = runtime_shaped: the same mission with every QP on csrc/lscqp_generic.hip (LSCQP_FORCE_GENERIC=1) -- 600 QPs of a closed
+    loop whose rows, corridors and goals the device produced itself."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import closed_loop
 
+    if kernel == "runtime_shaped":
+        monkeypatch.setenv("LSCQP_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("LSCQP_FORCE_GENERIC", raising=False)
     log = closed_loop.run(os.path.join(ROOT, "tests", "golden", "forest10_world.json"), steps=60)
     # every QP of 60 replans x 10 agents solves and passes isSolValid: the generated constraints are mutually consistent
     assert log["qp_failed"] == 0 and log["invalid"] == 0 and log["sfc_kept"] == 0, log
