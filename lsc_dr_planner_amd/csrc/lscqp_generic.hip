@@ -9,8 +9,9 @@
 // interior-point iteration, same stopping rules and statuses as lscqp_kernel.hpp (its header comment and DESIGN.md section 2 describe
 // them; the numbered steps below cite it) -- organised for generality instead of issue rate:
 //   * one workgroup of 256 threads per QP, M / dim / end stop / n_obs are run-time values;
-//   * the reduced KKT matrix (nz = dim (3M - 2) or 3 dim M rows, <= 144) lives in LDS as a packed lower triangle and is factorised
-//     there (LDL^T, right-looking, two barriers per column); the substitutions run over LDS as well;
+//   * the reduced KKT matrix (nz = dim (3M - 2) or 3 dim M rows, <= 108) lives in LDS as a packed lower triangle and is factorised
+//     there (LDL^T, right-looking, kept unscaled: one barrier per column); the substitutions run in one wavefront with the right-hand
+//     side in registers and v_readlane broadcasts;
 //   * LSC rows: thread = (group g, control point cp), obstacles o = g, g + G, ... with G = floor(256 / (6M - 3)); row CONSTANTS are
 //     re-read from HBM / L2 in every pass (never staged), row STATE (s, lambda: 16 bytes per row) sits in LDS behind the matrix, sized
 //     per launch from n_obs_max: the capacity is what the CU's 160 KB leave -- about 90 obstacles at M = 10 in 3-D, > 500 at M = 5;
@@ -70,6 +71,22 @@ struct Shape {
     }
 };
 
+// Development aid (-DLSCQP_GEN_TIMING, tools/bench_generic.py --phases): cycles per phase, summed over the workgroups by thread 0.
+#ifdef LSCQP_GEN_TIMING
+__device__ unsigned long long gen_cycles[16];
+#define GEN_T(slot)                                                        \
+    do {                                                                   \
+        __syncthreads();                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        if (tid == 0) atomicAdd(&gen_cycles[slot], now_ - tprev_);         \
+        tprev_ = __builtin_readcyclecounter();                             \
+    } while (0)
+#else
+#define GEN_T(slot) \
+    do {            \
+    } while (0)
+#endif
+
 __device__ __forceinline__ double rcp2(double d) {
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
@@ -112,6 +129,9 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
     const int tid = threadIdx.x;
     const int64_t q = blockIdx.x;
     if (q >= n) return;
+#ifdef LSCQP_GEN_TIMING
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
     const lscqp_header* Hd = hdr + q;
     int flags = 0, it_before = 0;
     if (cls.repair) {
@@ -412,36 +432,31 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
 
     // ---- the reduced matrix, packed lower triangle; x entries a z variable drives --------------------------------------------
     auto tri = [](int i, int j) -> int { return i * (i + 1) / 2 + j; };  // j <= i
+    // (control points are carried as (axis, 6 m + i) pairs: an integer division by the run-time P costs ~40 instructions on this
+    // hardware, and the assembly evaluated a dozen of them per K entry -- 280 k of its 317 k cycles at nz = 90)
     struct Drv {
-        int n, idx[4];
+        int k, cp[4];  // axis, control point index 6 m + i within the axis
         double w[4];
     };
-    auto drive = [&](int zi) -> Drv {
+    auto drive = [&](int k, int a) -> Drv {  // z variable (axis k, index a within the axis)
         Drv D;
-        const int k = zi / NZA, a = zi % NZA;
+        D.k = k;
         const bool zlast = ES && a == 3 * (M - 1);
         const int m = zlast ? M - 1 : a / 3, j = zlast ? 0 : a % 3;
-        const int base = k * P + 6 * m;
-        if (zlast) {
-            D.n = 3;
-            for (int t = 0; t < 3; t++) D.idx[t] = base + 3 + t, D.w[t] = 1.0;
-            D.idx[3] = base, D.w[3] = 0.0;
-        } else {
-            D.n = 1;
-            D.idx[0] = base + 3 + j, D.w[0] = 1.0;
-            for (int t = 0; t < 3; t++) D.idx[1 + t] = base, D.w[1 + t] = 0.0;
-            if (m + 1 < M) {
-                D.n = 4;
-                for (int t = 0; t < 3; t++) D.idx[1 + t] = base + 6 + t, D.w[1 + t] = TBc(t, j);
-            }
+        const int base = 6 * m;
+        const bool nxt = !zlast && (m + 1 < M);
+        D.cp[0] = zlast ? base + 3 : base + 3 + j, D.w[0] = 1.0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            D.cp[1 + t] = zlast ? (t < 2 ? base + 4 + t : base) : (nxt ? base + 6 + t : base);
+            D.w[1 + t] = zlast ? (t < 2 ? 1.0 : 0.0) : (nxt ? TBc(t, j) : 0.0);
         }
         return D;
     };
     const bool comm_on_k = cls.comm_range > 0;
-    // entry (a, b) of K = H + G'WG in x-space; B_ holds the same-axis same-segment 6x6 blocks
-    auto Kentry = [&](int a, int b) -> double {
-        const int ka = a / P, ca = a % P, ma = ca / 6, ia = ca % 6;
-        const int kb = b / P, cb = b % P, mb = cb / 6, ib = cb % 6;
+    // entry ((ka, ca), (kb, cb)) of K = H + G'WG in x-space; B_ holds the same-axis same-segment 6x6 blocks
+    auto Kentry = [&](int ka, int ca, int kb, int cb) -> double {
+        const int ma = ca / 6, ia = ca - 6 * ma, mb = cb / 6, ib = cb - 6 * mb;  // (division by a constant: a multiply)
         double v = 0.0;
         if (ka == kb) {
             if (ma == mb) v += B_[((ka * M + ma) * 6 + ia) * 6 + ib];
@@ -472,6 +487,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
 
     if (status != LSCQP_STATUS_INFEASIBLE)
         for (it = 0; it < cls.max_iter; it++) {
+            GEN_T(0);
             // ============ pass 1: residuals, weights, per-control-point blocks ===========================================
             double sum_sl = 0, sum_pinf = 0, max_rp = 0;
 #pragma unroll
@@ -516,11 +532,15 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             const double mu = sum_sl * inv_m;
             if (tid < CP) {
                 double acc[12];
+#pragma unroll
                 for (int t = 0; t < 12; t++) acc[t] = 0.0;
                 for (int g = 0; g < G; g++)
+#pragma unroll
                     for (int t = 0; t < 12; t++) acc[t] += H_[(g * CP + tid) * 12 + t];
                 const int cp6 = (tid + 3) * 6;
+#pragma unroll
                 for (int t = 0; t < 6; t++) S_[cp6 + t] = acc[t];
+#pragma unroll
                 for (int t = 0; t < 3; t++) LX_[t * CP + tid] = acc[6 + t], LX_[(3 + t) * CP + tid] = acc[9 + t];
             }
             if (tid < 18) S_[tid] = 0.0;  // the initial state carries no LSC rows
@@ -533,6 +553,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             }
             __syncthreads();
 
+            GEN_T(1);
             // ============ cost gradient in z-space, residual norms, convergence ========================================
             double rdn = 0, gls = 0;
             for (int zi = tid; zi < NZ; zi += kT) {
@@ -542,8 +563,10 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 const double* cs = &c_[k * P + 6 * m];
                 double gx[6];  // gradient of the cost w.r.t. this segment's control points (the ones this z drives)
                 double gcost = 0;
+#pragma unroll
                 for (int i = 3; i < 6; i++) {
                     double gq = 0;
+#pragma unroll
                     for (int ip = 0; ip < 6; ip++) gq += KQ(i, ip) * cs[ip];
                     gx[i] = q2s * gq;
                 }
@@ -551,11 +574,13 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 if (zlast) {
                     gcost = gx[3] + gx[4] + gx[5];
                 } else {
-                    gcost = gx[3 + j];
+                    gcost = j == 0 ? gx[3] : (j == 1 ? gx[4] : gx[5]);
                     if (m + 1 < M) {
                         const double* cn = &c_[k * P + 6 * (m + 1)];
+#pragma unroll
                         for (int r = 0; r < 3; r++) {
                             double gq = 0;
+#pragma unroll
                             for (int ip = 0; ip < 6; ip++) gq += KQ(r, ip) * cn[ip];
                             gcost += TBc(r, j) * q2s * gq;
                         }
@@ -622,9 +647,10 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 continue;
             }
 
+            GEN_T(2);
             // ============ assembly: same-axis same-segment blocks, then Hred = T'(H + G'WG)T, packed lower triangle ==========
             for (int e = tid; e < DIM * M * 36; e += kT) {
-                const int k = e / (36 * M), m = (e / 36) % M, i = (e % 36) / 6, ip = e % 6;
+                const int km = e / 36, r36 = e - 36 * km, k = (km >= 2 * M) ? 2 : (km >= M ? 1 : 0), m = km - k * M, i = r36 / 6, ip = r36 - 6 * i;
                 double v = q2s * KQ(i, ip);
                 if (i == 5 && ip == 5 && m >= M - ts) v += wt2;
                 const double* omi = &om_[k * P + 6 * m];
@@ -662,71 +688,134 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 while (i * (i + 1) / 2 > e) i--;
                 while ((i + 1) * (i + 2) / 2 <= e) i++;
                 const int j = e - i * (i + 1) / 2;
-                const Drv Di = drive(i), Dj = drive(j);
+                // Two z variables meet in K only if they drive a common control point (different axes: same segment), neighbouring
+                // segments of one axis (the 6 x 6 blocks through TB), or both reach a c5 / c0 of one axis (communication pairs):
+                // everything else -- 70 % of the triangle at M = 10 -- is a structural zero and skips the 16 K-entry evaluations.
+                const int ki = (i >= 2 * NZA) ? 2 : (i >= NZA ? 1 : 0), ai = i - ki * NZA, kj = (j >= 2 * NZA) ? 2 : (j >= NZA ? 1 : 0), aj = j - kj * NZA;
+                const bool li_ = ES && ai == 3 * (M - 1), lj_ = ES && aj == 3 * (M - 1);
+                const int mi = li_ ? M - 1 : ai / 3, mj = lj_ ? M - 1 : aj / 3, ji = li_ ? 2 : ai % 3, jj = lj_ ? 2 : aj % 3;
+                const int dm = mi > mj ? mi - mj : mj - mi;
+                const bool meet = (ki != kj) ? (dm == 0) : (dm <= 1 || (comm_on_k && ji == 2 && jj == 2));
                 double v = 0.0;
-                for (int a = 0; a < 4; a++)
-                    for (int b = 0; b < 4; b++) {
-                        const double w = Di.w[a] * Dj.w[b];
-                        if (w != 0.0) v += w * Kentry(Di.idx[a], Dj.idx[b]);
-                    }
+                if (meet) {
+                    const Drv Di = drive(ki, ai), Dj = drive(kj, aj);
+                    // (compile-time indices: a private array indexed at run time lives in scratch memory -- a memory round trip per access)
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const double w = Di.w[a] * Dj.w[b];
+                            if (w != 0.0) v += w * Kentry(Di.k, Di.cp[a], Dj.k, Dj.cp[b]);
+                        }
+                }
                 H_[e] = v;
             }
             __syncthreads();
 
+            GEN_T(3);
             // ============ LDL^T in LDS, right-looking: after step j column j holds L[.][j], the diagonal d_j ======================
+            // The factor is kept UNSCALED: after step j column j still holds U[j][i] = d_j L[i][j] (nothing of step j writes column j), so
+            // the step needs no column copy and ONE barrier; the substitutions apply 1 / d_j.  Thread t owns the entries k = t mod 4
+            // (mod 4) of rows t / 4 and t / 4 + 64 for the whole factorisation, and issues its loads four at a time (with a load per
+            // fused multiply-add the update was a chain of LDS round trips: 330 k cycles per factorisation at nz = 90).
             bool pivot_bad = false;
-            for (int j = 0; j < NZ; j++) {
-                const double d = H_[tri(j, j)];
-                if (!(d > 1e-300)) {  // uniform: every thread reads the same entry
-                    pivot_bad = true;
-                    break;
+            {
+                const int rsel = tid >> 2, part = tid & 3;
+                for (int j = 0; j < NZ; j++) {
+                    const double d = H_[tri(j, j)];
+                    if (!(d > 1e-300)) {  // uniform: every thread reads the same entry
+                        pivot_bad = true;
+                        break;
+                    }
+                    const double invd = rcp2(d);
+                    if (tid == 0) dinv_[j] = invd;
+                    for (int i = rsel; i < NZ; i += 64) {
+                        if (i <= j) continue;
+                        const double li = H_[tri(i, j)] * invd;
+                        double* const hrow = &H_[tri(i, 0)];
+                        int k = j + 1 + ((part - (j + 1)) & 3);  // first column > j of this thread's phase
+                        for (; k + 12 <= i; k += 16) {
+                            const double u0 = H_[tri(k, j)], u1 = H_[tri(k + 4, j)], u2 = H_[tri(k + 8, j)], u3 = H_[tri(k + 12, j)];
+                            const double h0 = hrow[k], h1 = hrow[k + 4], h2 = hrow[k + 8], h3 = hrow[k + 12];
+                            hrow[k] = fma(-li, u0, h0), hrow[k + 4] = fma(-li, u1, h1), hrow[k + 8] = fma(-li, u2, h2), hrow[k + 12] = fma(-li, u3, h3);
+                        }
+                        for (; k <= i; k += 4) hrow[k] = fma(-li, H_[tri(k, j)], hrow[k]);
+                    }
+                    __syncthreads();
                 }
-                const double invd = rcp2(d);
-                for (int i = j + 1 + tid; i < NZ; i += kT) {
-                    const double a = H_[tri(i, j)];
-                    col_[i] = a;
-                    H_[tri(i, j)] = a * invd;
-                }
-                if (tid == 0) dinv_[j] = invd;
-                __syncthreads();
-                // trailing update, rows j+1 .. NZ-1: H[i][k] -= L[i][j] * (d L[k][j]);  a row is shared by `tpr` threads
-                const int nrow = NZ - j - 1;
-                const int tpr = nrow > 0 ? (kT / nrow > 0 ? kT / nrow : 1) : 1;
-                for (int w = tid; w < nrow * tpr; w += kT) {
-                    const int i = j + 1 + w / tpr, part = w % tpr;
-                    const double li = H_[tri(i, j)];
-                    for (int k = j + 1 + part; k <= i; k += tpr) H_[tri(i, k)] = fma(-li, col_[k], H_[tri(i, k)]);
-                }
-                __syncthreads();
             }
             if (pivot_bad) {
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
                 restore = status == LSCQP_STATUS_OPTIMAL;
                 break;
             }
-            // solve Hred x = rhs_ in place: L w = b, then (D L') x = w
+            // solve Hred x = rhs_ in place with the unscaled factor U[j][i] = d_j L[i][j] (stored at H_[tri(i, j)], i > j):
+            //   forward   y_j = (b_j - sum_{i<j} U[i][j] y_i) / d_j            (L D y' = b with y = y')
+            //   backward  x_j = y_j - (sum_{i>j} U[j][i] x_i) / d_j
+            // ONE wavefront does it, lane t holding rows t and t + 64 in registers; the value of step j reaches the other lanes through a
+            // v_readlane, not through LDS and a barrier (2 nz barriers per solve before: 70 k cycles at nz = 90).
             auto solve = [&]() {
-                for (int j = 0; j < NZ; j++) {
-                    __syncthreads();
-                    const double wj = rhs_[j];
-                    for (int i = j + 1 + tid; i < NZ; i += kT) rhs_[i] = fma(-H_[tri(i, j)], wj, rhs_[i]);
-                }
                 __syncthreads();
-                for (int i = tid; i < NZ; i += kT) rhs_[i] *= dinv_[i];
-                for (int j = NZ - 1; j >= 0; j--) {
-                    __syncthreads();
-                    const double xj = rhs_[j];
-                    for (int i = tid; i < j; i += kT) rhs_[i] = fma(-H_[tri(j, i)], xj, rhs_[i]);
+                if (tid < 64) {
+                    const int r0 = tid, r1 = tid + 64;
+                    double b0 = r0 < NZ ? rhs_[r0] : 0.0, b1 = r1 < NZ ? rhs_[r1] : 0.0;
+                    const double d0 = r0 < NZ ? dinv_[r0] : 0.0, d1 = r1 < NZ ? dinv_[r1] : 0.0;
+                    auto lane_value = [](double v, int src) -> double {  // (src is uniform: the loop counter)
+                        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+                        return __hiloint2double(hi, lo);
+                    };
+                    // (the factor entries of four steps are loaded before the four dependent broadcast + multiply-add steps run)
+                    const double* const h0r = &H_[tri(r0 < NZ ? r0 : 0, 0)];
+                    const double* const h1r = &H_[tri(r1 < NZ ? r1 : 0, 0)];
+                    for (int j4 = 0; j4 < NZ; j4 += 4) {
+                        double u0[4], u1[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int j = j4 + t;
+                            u0[t] = (r0 > j && r0 < NZ) ? h0r[j] : 0.0;
+                            u1[t] = (r1 > j && r1 < NZ) ? h1r[j] : 0.0;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int j = j4 + t;  // (steps past nz - 1 multiply zeros)
+                            const double yj = (j < 64) ? lane_value(b0 * d0, j) : lane_value(b1 * d1, (j - 64) & 63);
+                            b0 = fma(-u0[t], yj, b0);
+                            b1 = fma(-u1[t], yj, b1);
+                        }
+                    }
+                    // b now holds d_j y_j in its own row; y = b * dinv
+                    const double y0 = b0 * d0, y1 = b1 * d1;
+                    double s0 = 0.0, s1 = 0.0;  // sum_{i>j} U[j][i] x_i of the lane's rows
+                    for (int j4 = ((NZ + 3) & ~3) - 4; j4 >= 0; j4 -= 4) {
+                        double u0[4], u1[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int j = j4 + 3 - t;
+                            u0[t] = (j < NZ && r0 < j) ? H_[tri(j < NZ ? j : 0, r0)] : 0.0;
+                            u1[t] = (j < NZ && r1 < j) ? H_[tri(j < NZ ? j : 0, r1 < NZ ? r1 : 0)] : 0.0;
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int j = j4 + 3 - t;
+                            const double xj = (j < 64) ? lane_value(fma(-d0, s0, y0), j) : lane_value(fma(-d1, s1, y1), (j - 64) & 63);
+                            s0 = fma(u0[t], xj, s0);
+                            s1 = fma(u1[t], xj, s1);
+                        }
+                    }
+                    if (r0 < NZ) rhs_[r0] = fma(-d0, s0, y0);
+                    if (r1 < NZ) rhs_[r1] = fma(-d1, s1, y1);
                 }
                 __syncthreads();
             };
 
+            GEN_T(4);
             // ============ predictor =============================================================================================
             solve();
             for (int zi = tid; zi < NZ; zi += kT) dz_[zi] = rhs_[zi];
             __syncthreads();
             expandT(dz_, dca_, false);
             __syncthreads();
+            GEN_T(5);
             // ============ pass 2: affine step length, mu_aff, corrector right-hand side =========================================
             double rmax = 1.0, sB = 0, dmy = 0;
 #pragma unroll
@@ -793,6 +882,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             sigma = sigma * sigma * sigma;
             const double smu = sigma * mu;
             __syncthreads();
+            GEN_T(6);
             // ============ corrector solve ======================================================================================
             for (int zi = tid; zi < NZ; zi += kT) rhs_[zi] = -gc_[zi] + smu * gatherT(X1, zi) + gatherT(X2, zi);
             __syncthreads();
@@ -801,6 +891,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             __syncthreads();
             expandT(dz_, dc_, false);
             __syncthreads();
+            GEN_T(7);
             // ============ pass 3: directions of the row state, step length ======================================================
             rmax = 0.0;
             double sdl = 0, sdd = 0;
@@ -884,6 +975,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 Rs_[o * CP + lcp] = fma(alpha, D.ds, D.s);
                 Rl_[o * CP + lcp] = fma(alpha, D.dl, D.l);
             }
+            GEN_T(8);
             // ============ update of z and the control points ====================================================================
             if (it == 0) alpha_first = (float)alpha;
             for (int zi = tid; zi < NZ; zi += kT) z_[zi] += alpha * dz_[zi];
@@ -895,6 +987,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 restore = status == LSCQP_STATUS_OPTIMAL;
                 break;
             }
+            GEN_T(9);
         }
     if (status == LSCQP_STATUS_ITER_LIMIT && (near_cnt > 0 || floor_cnt > 0)) {
         status = LSCQP_STATUS_OPTIMAL;
@@ -968,3 +1061,14 @@ extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, in
                        row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out);
     return hipGetLastError();
 }
+
+#ifdef LSCQP_GEN_TIMING
+extern "C" int lscqp_generic_cycles(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lscqp_generic::gen_cycles), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lscqp_generic::gen_cycles), z, sizeof z);
+    }
+    return 0;
+}
+#endif

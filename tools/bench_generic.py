@@ -49,7 +49,30 @@ def run(N, M, dim, n_obs, mode, force):
     return e0.elapsed_time(e1) / 10, float(it.mean()), int(it.max()), int((dst.cpu().numpy() != 0).sum())
 
 
+def phases():
+    """--phases: per-phase cycles of the run-time-shaped kernel (a library built with LSCQP_EXTRA_FLAGS=-DLSCQP_GEN_TIMING, LSCQP_LIB=...)."""
+    import ctypes as C
+
+    L = api.lib()
+    names = ["prologue / loop top", "pass 1", "gradient + tests", "assembly", "LDL^T", "predictor solve + expand", "pass 2", "corrector solve + expand",
+             "pass 3 + step length", "update"]
+    for N, M, dim, n_obs, mode in ((64, 5, 3, 20, api.PLANNER_LSC), (64, 10, 3, 20, api.PLANNER_DLSC)):
+        buf = (C.c_ulonglong * 16)()
+        L.lscqp_generic_cycles(buf, 1)
+        ms, itm, itx, bad = run(N, M, dim, n_obs, mode, True)
+        L.lscqp_generic_cycles(buf, 1)
+        launches = 13.0  # run(): 3 warm + 10 timed launches of the same batch
+        nit = itm * N * launches
+        print("%d x M%d dim %d x %d: %.3f ms per launch, %.2f iterations" % (N, M, dim, n_obs, ms, itm))
+        # GEN_T(k) closes the phase that ENDS at marker k: slot 0 = what precedes pass 1 (prologue on the first pass, else nothing), slot k = phase k-1's successor
+        for k in range(10):
+            print("   %-28s %9.0f cycles per iteration and QP" % (names[k], buf[(k + 1) % 10 if k else 0] / nit if False else buf[k] / nit))
+
+
 if __name__ == "__main__":
+    if "--phases" in sys.argv:
+        phases()
+        sys.exit(0)
     for N, M, dim, n_obs, mode, name in ((64, 5, 3, 20, api.PLANNER_LSC, "lsc"), (1024, 5, 3, 20, api.PLANNER_LSC, "lsc"), (64, 10, 3, 20, api.PLANNER_LSC, "lsc"),
                                          (64, 10, 3, 20, api.PLANNER_DLSC, "dlsc"), (512, 10, 3, 20, api.PLANNER_DLSC, "dlsc"), (64, 10, 2, 9, api.PLANNER_LSC, "lsc"),
                                          (64, 6, 3, 20, api.PLANNER_DLSC, "dlsc"), (64, 9, 3, 20, api.PLANNER_LSC, "lsc")):
