@@ -7,7 +7,7 @@
 //     that leave the chip idle); the kernel is issue/latency bound on fp64 VALU, so everything is organised to minimise the
 //     instruction count of one Mehrotra iteration.  With W > 1: lane -> thread of the workgroup, wave reductions -> wave + LDS.
 //     Reduced systems of up to 64 rows are factorised by every wavefront redundantly (uniform verdict on a failed pivot);
-//     larger ones (M = 10 in 3-D: nz = 84) and M = 10 in 2-D with W >= 2 use a NESTED DISSECTION over two wavefronts (Cfg::ND).
+//     larger ones (M = 8, 9, 10 in 3-D: nz = 66 .. 90) and M = 10 in 2-D with W >= 2 use a NESTED DISSECTION over two wavefronts (Cfg::ND).
 //     FT = float instantiates the mixed-precision form (float32 matrix / factor / substitutions, everything else fp64).
 //   * The equality rows (:318-368, 502-511) are eliminated analytically: per axis the free variables are
 //     z = (c3,c4,c5) of every segment (one scalar for the last segment under the LSC end stop);
@@ -270,40 +270,53 @@ struct Cfg {
     // weights of the two-sided rows in LDS: [interval NX][vel NV][acc NA][comm NC]
     static constexpr int OV = NX, OA = NX + NV, OC = NX + NV + NA, NOM = NX + NV + NA + NC;
     static constexpr int LDH = NZ | 1;
-    // NESTED DISSECTION of the reduced system for classes with more than 64 rows (M = 10 in 3-D: nz = 84).  The (c3, c4)
+    // NESTED DISSECTION of the reduced system for classes with more than 64 rows (M = 8, 9, 10 in 3-D: nz = 66 .. 90).  The (c3, c4)
     // variables of a segment couple only to the neighbouring segments (through the C2 joins) and to the c5 variables; the c5
     // variables of one axis are all coupled (communication-pair rows, src/traj_optimizer.cpp:476-500).  Separator S = the (c3, c4)
     // of the middle segment MS + every c5; it cuts the rest into two independent banded blocks, L = (c3, c4) of segments
-    // 0..MS-1 and R = (c3, c4) of segments MS+1..M-2, which two wavefronts eliminate CONCURRENTLY (each with its share of the
+    // 0..MS-1 and R = (c3, c4) of segments MS+1..MLAST (M-2 under the end stop, else M-1), which two wavefronts eliminate CONCURRENTLY (each with its share of the
     // separator's Schur complement), then one wavefront factorises the separator.  Row length in registers: NB + NS instead of nz.
     static constexpr int MS = (M - 1) / 2;
+    static constexpr int MLAST = ES ? M - 2 : M - 1;   // last segment that owns a (c3, c4) pair
+    static constexpr int NB0 = 2 * DIM * MS;            // block L (wavefront 0): segments 0 .. MS-1, order (m, axis, j)
+    static constexpr int NB1 = 2 * DIM * (MLAST - MS);  // block R (wavefront 1): segments MS+1 .. MLAST
+    static constexpr int NS = 2 * DIM + DIM * M;        // separator: (c3, c4) of segment MS, then c5 of (segment, axis)
+    // Wavefront 0 carries L and the whole separator (rows = columns = NB0 + NS).  Wavefront 1 carries R and, as accumulator rows /
+    // columns, only the separator variables R can reach (NT1: (c3, c4) of segment MS and c5 of segments MS .. M-1), in the same
+    // order with the unreachable ones left out -- that is what lets the end-stop-free 3-D classes (nz = 90, 81, 72) and unequal
+    // blocks fit 64 lanes.
+    static constexpr int NT1 = 2 * DIM + DIM * (M - MS);
+    static constexpr int NR0 = NB0 + NS, NR1 = NB1 + NT1;
+    static constexpr bool ND_FITS = NR0 <= 64 && NR1 <= 64 && MS >= 1 && MLAST > MS;
     // ... and wherever two wavefronts per QP are used and the two blocks come out equal (M = 6, 10): M = 10 in 2-D 56 dense pivots
     // -> 16 + 24 (-7 % on the forest10 replica), M = 6 in 3-D 48 -> 12 + 24
-    static constexpr bool ND = (NZ > 64) || (W >= 2 && ES_ && FB_ == 8 && M >= LSCQP_ND_MIN_M && (2 * DIM * MS == 2 * DIM * (M - 2 - MS)) &&
-                                             (2 * DIM * MS + 2 * DIM + DIM * M <= 64));
-    static constexpr int NB = 2 * DIM * MS;             // block L (wavefront 0): segments 0 .. MS-1, order (m, axis, j)
-    static constexpr int NBR = 2 * DIM * (M - 2 - MS);  // block R (wavefront 1): segments MS+1 .. M-2
-    static constexpr int NS = 2 * DIM + DIM * M;        // separator: (c3, c4) of segment MS, then c5 of (segment, axis)
-    static constexpr int BWB = 4 * DIM - 1;             // half bandwidth inside a block
-    static constexpr int NAR = ND ? NB + NS : NZ;       // entries of a lane's matrix row
-    static_assert(!ND || (ES_ && NB == NBR && NB + NS <= 64 && W >= 2 && FB_ == 8),
-                  "nested dissection: end-stop classes with two equal blocks, two or more wavefronts, fp64");
+    static constexpr bool ND = (NZ > 64) || (W >= 2 && ES_ && FB_ == 8 && M >= LSCQP_ND_MIN_M && NB0 == NB1 && ND_FITS);
+    static constexpr int BWB = 4 * DIM - 1;  // half bandwidth inside a block
+    static constexpr int NAR = ND ? (NR0 > NR1 ? NR0 : NR1) : NZ;  // entries of a lane's matrix row
+    static_assert(!ND || (ND_FITS && W >= 2 && FB_ == 8), "nested dissection: both wavefronts' rows within 64 lanes, two or more wavefronts, fp64");
+    static constexpr int nd_nb(int w) { return w == 0 ? NB0 : NB1; }
+    static constexpr int nd_nr(int w) { return w == 0 ? NR0 : NR1; }
+    // separator variable <-> its position among wavefront 1's accumulators
+    static constexpr int nd_unrank1(int r) { return r < 2 * DIM ? r : r + MS * DIM; }
+    static constexpr int nd_rank1(int sc) { return sc < 2 * DIM ? sc : sc - MS * DIM; }
+    // local column of separator variable sc in wavefront w's rows
+    static constexpr int nd_col(int w, int sc) { return w == 0 ? NB0 + sc : NB1 + nd_rank1(sc); }
     // z index (axis-major: k * NZA + a) of variable (axis k, segment m, j): j = 0, 1, 2 <-> c3, c4, c5; the last segment under the
     // end stop has one variable
     static constexpr int zi_kmj(int k, int m, int j) { return k * NZA + ((ES && m == M - 1) ? 3 * (M - 1) : 3 * m + j); }
-    // nested dissection: local column c of wavefront w (0: L | S, 1: R | S) -> z index
+    // nested dissection: local column c of wavefront w (0: L | S, 1: R | reachable S) -> z index
     static constexpr int nd_zi(int w, int c) {
-        if (c < NB) {
+        if (c < nd_nb(w)) {
             const int seg = c / (2 * DIM), r = c % (2 * DIM);
             return zi_kmj(r / 2, (w == 0 ? 0 : MS + 1) + seg, r % 2);
         }
-        int s = c - NB;
+        int s = w == 0 ? c - NB0 : nd_unrank1(c - NB1);
         if (s < 2 * DIM) return zi_kmj(s / 2, MS, s % 2);
         s -= 2 * DIM;
         return zi_kmj(s % DIM, s / DIM, 2);
     }
     // Separator columns a block can reach (before and after fill-in): (c3, c4) of segment m couple to c5 of segments m-1, m, m+1
-    // only, so block L (segments 0 .. MS-1) never touches c5 of segments > MS and block R (MS+1 .. M-2) never c5 of segments
+    // only, so block L (segments 0 .. MS-1) never touches c5 of segments > MS and block R (MS+1 .. MLAST) never c5 of segments
     // < MS: the block phase and the hand-over skip those columns (21 resp. 24 of 36 at M = 10 in 3-D).
     static constexpr bool nd_touched(int w, int sc) {
         return sc < 2 * DIM || (w == 0 ? sc < 2 * DIM + (MS + 1) * DIM : sc >= 2 * DIM + MS * DIM);
@@ -508,15 +521,15 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             return lv < NZ ? lv : -1;
         } else {
             const int w = lv >> 6, t = lv & 63;
-            const bool own = (w == 0 && t < C::NB + C::NS) || (w == 1 && t < C::NB);
+            const bool own = (w == 0 && t < C::NR0) || (w == 1 && t < C::NB1);
             const int tc = own ? t : 0;
-            // C::nd_zi with run-time arguments
+            // C::nd_zi with run-time arguments (the accumulator lanes of wavefront 1 own no variable)
             int zi;
-            if (tc < C::NB) {
+            if (tc < (w == 0 ? C::NB0 : C::NB1)) {
                 const int seg = tc / (2 * DIM), r = tc % (2 * DIM);
                 zi = C::zi_kmj(r / 2, (w == 0 ? 0 : C::MS + 1) + seg, r % 2);
             } else {
-                int s_ = tc - C::NB;
+                int s_ = tc - C::NB0;
                 const bool mid = s_ < 2 * DIM;
                 const int s2 = mid ? s_ : s_ - 2 * DIM;
                 zi = mid ? C::zi_kmj(s2 / 2, C::MS, s2 % 2) : C::zi_kmj(s2 % DIM, s2 / DIM, 2);
@@ -530,14 +543,14 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             return lv < NZ ? lv : NZ;
         } else {
             const int w = lv >> 6, t = lv & 63;
-            return (w == 0 && t < C::NB + C::NS) ? t : (w == 1 && t < C::NB) ? C::NB + C::NS + t : NZ;
+            return (w == 0 && t < C::NR0) ? t : (w == 1 && t < C::NB1) ? C::NR0 + t : NZ;
         }
     };
     // where a lane parks its factor row while pass 2 runs (the scratch matrix is free then); nested dissection: [NZ + NS + 1][LDP]
     auto park_ptr = [&](int lv) -> FT* {
         if constexpr (C::ND) {
             const int w = lv >> 6, t = lv & 63;
-            return Hs + ((w < 2 && t < C::NB + C::NS) ? w * (C::NB + C::NS) + t : NZ + C::NS) * C::LDP;
+            return Hs + ((w < 2 && t < (w == 0 ? C::NR0 : C::NR1)) ? w * C::NR0 + t : NZ + C::NS) * C::LDP;
         } else {
             return &Hs[(lv < NZ ? lv : NZ) * LDH];
         }
@@ -1354,20 +1367,30 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     __syncthreads();
                     const int wv_ = __builtin_amdgcn_readfirstlane(lvz_ >> 6);
                     const int t_ = lvz_ & 63;
-                    const bool acc = (wv_ == 1) && t_ >= C::NB && t_ < C::NB + C::NS;        // accumulator lane
-                    const bool rowl = (wv_ == 0 && t_ < C::NB + C::NS) || (wv_ == 1 && t_ < C::NB);
-                    const FT* const src = &Hs[(acc ? t_ : (rowl ? ZR.slot : NZ)) * LDH];  // (S lane t of wavefront 0 has slot t)
+                    const bool acc = (wv_ == 1) && t_ >= C::NB1 && t_ < C::NR1;  // accumulator lane
+                    const bool rowl = (wv_ == 0 && t_ < C::NR0) || (wv_ == 1 && t_ < C::NB1);
+                    // (the lane of separator variable s in wavefront 0 is NB0 + s, and that is its slot)
+                    const int sacc = C::NB0 + (acc ? ((t_ - C::NB1) < 2 * DIM ? (t_ - C::NB1) : (t_ - C::NB1) + C::MS * DIM) : 0);
+                    const FT* const src = &Hs[(acc ? sacc : (rowl ? ZR.slot : NZ)) * LDH];
                     if (wv_ == 0) {
                         static_for<0, C::NAR>([&](auto Cc) {
                             constexpr int c = decltype(Cc)::value;
-                            const FT v = src[C::nd_zi(0, c)];
-                            A[c] = rowl ? v : (FT)0;
+                            if constexpr (c < C::NR0) {
+                                const FT v = src[C::nd_zi(0, c)];
+                                A[c] = rowl ? v : (FT)0;
+                            } else {
+                                A[c] = (FT)0;
+                            }
                         });
                     } else {
                         static_for<0, C::NAR>([&](auto Cc) {
                             constexpr int c = decltype(Cc)::value;
-                            const FT v = src[C::nd_zi(1, c)];
-                            A[c] = (rowl || (acc && c < C::NB)) ? v : (FT)0;
+                            if constexpr (c < C::NR1) {
+                                const FT v = src[C::nd_zi(1, c)];
+                                A[c] = (rowl || (acc && c < C::NB1)) ? v : (FT)0;
+                            } else {
+                                A[c] = (FT)0;
+                            }
                         });
                     }
                     __syncthreads();  // the scratch matrix is reused for the hand-overs of the factorisation
@@ -1498,7 +1521,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 //   3. wavefront 0 factorises the NS x NS separator (dense, pivot row over both pipes as in the one-wavefront case).
                 // Pivot rows are read as pivot COLUMNS (symmetry) from a per-wavefront LDS column buffer; the column of the next
                 // pivot is published as soon as it is final.  The branches on the wavefront id are scalar.
-                constexpr int NB = C::NB, NS = C::NS, NA = C::NAR, BWB = C::BWB;
+                constexpr int NB0 = C::NB0, NB1 = C::NB1, NR0 = C::NR0, NR1 = C::NR1, NS = C::NS, BWB = C::BWB;
                 const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
                 int lf = lane & 63;
                 asm volatile("" : "+v"(lf));
@@ -1511,6 +1534,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 // here, and with all of them on it the phase was LDS bound: 34.7 k cycles for 24 pivots.)
                 auto block_phase = [&](auto Wc) {
                     constexpr int w_ = decltype(Wc)::value;
+                    constexpr int NB = C::nd_nb(w_);
                     colw[lf] = A[0];
                     double d = bcast(A[0], 0);
                     double invd = fast_rcp(d);
@@ -1535,7 +1559,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         static_for<0, NS>([&](auto Kc) {
                             constexpr int sc = decltype(Kc)::value;
                             if constexpr (C::nd_touched(w_, sc)) {
-                                constexpr int k = NB + sc;
+                                constexpr int k = C::nd_col(w_, sc);
                                 const double u = (sc & 1) ? cb[k] : bcast(A[k], j);
                                 A[k] = fma(-li, u, A[k]);
                             }
@@ -1556,24 +1580,33 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 }
                 LSCQP_T(14);  // (development timing: the block phase of the nested dissection)
                 {   // hand-over of wavefront 1's share (single predicated stores; everything else is masked arithmetically)
-                    const bool give = (wv == 1) && lf >= NB && lf < NB + NS;
-                    const int srow = (lf >= NB && lf < NB + NS) ? lf - NB : 0;
+                    // Sx[s][c], s and c separator variables wavefront 1 reaches; the other rows / columns are never written
+                    const bool give = (wv == 1) && lf >= NB1 && lf < NR1;
+                    const int r1 = give ? lf - NB1 : 0;
+                    const int srow1 = r1 < 2 * DIM ? r1 : r1 + C::MS * DIM;  // Cfg::nd_unrank1
                     static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
                         if constexpr (C::nd_touched(1, c)) {
-                            if (give) Sx[srow * NS + c] = A[NB + c];
+                            if (give) Sx[srow1 * NS + c] = A[C::nd_col(1, c)];
                         }
                     });
                     if (lf == 0 && wv < 2) flag[wv] = pivot_bad ? 1.0 : 0.0;
                     __syncthreads();
-                    const double take = (wv == 0 && lf >= NB && lf < NB + NS) ? 1.0 : 0.0;
-                    static_for<0, NS>([&](auto Cc) {  // (rows of separator variables wavefront 1 cannot reach hold zeros there)
+                    const bool sep0 = (wv == 0) && lf >= NB0 && lf < NR0;
+                    const int srow0 = sep0 ? lf - NB0 : 0;
+                    const bool take = sep0 && (srow0 < 2 * DIM || srow0 >= 2 * DIM + C::MS * DIM);  // Cfg::nd_touched(1, srow0)
+                    const double* const sxr = Sx + (take ? srow0 : 0) * NS;
+                    static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
-                        if constexpr (C::nd_touched(1, c)) A[NB + c] = fma(take, Sx[srow * NS + c], A[NB + c]);
+                        if constexpr (C::nd_touched(1, c)) {
+                            const double v = sxr[c];
+                            A[NB0 + c] += take ? v : 0.0;
+                        }
                     });
                 }
-                if (wv == 0) {  // the separator: dense LDL^T on columns / lanes NB .. NA-1
+                if (wv == 0) {  // the separator: dense LDL^T on columns / lanes NB0 .. NR0-1
                     LSCQP_MARK(8);
+                    constexpr int NB = NB0, NA = NR0;
                     colw[lf] = A[NB];
                     double d = bcast(A[NB], NB);
                     double invd = fast_rcp(d);
@@ -1662,60 +1695,81 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             // same broadcasts), ONE hand-over of the separator's solution, both wavefronts finish their blocks backward.
             // (generic lambda: instantiated only for the nz > 64 instances; called twice: must not become a real call)
             auto solve_blocked = [&](double b, auto) __attribute__((always_inline)) -> double {
-                constexpr int NB = C::NB, NS = C::NS, NA = C::NAR;
+                constexpr int NB0 = C::NB0, NB1 = C::NB1, NR0 = C::NR0, NR1 = C::NR1, NS = C::NS;
                 const int wv = __builtin_amdgcn_readfirstlane(lane >> 6);
                 int ll_ = lane & 63;
                 asm volatile("" : "+v"(ll_));
-                double* const hand = col_;  // [64] hand-over buffer (the column buffers are idle during the solves)
-                const bool sep = ll_ >= NB && ll_ < NB + NS;
-                const int srow = sep ? ll_ - NB : 0;
-                // ---- forward through the blocks: L w = b (unit lower) ----
-                if (wv < 2) {
-                    LSCQP_MARK(10);
-                    static_for<0, NB>([&](auto Jc) {
+                double* const hand = col_;  // [64] hand-over buffer, indexed by separator variable (the column buffers are idle during the solves)
+                const bool sep0 = ll_ >= NB0 && ll_ < NR0;   // separator lanes of wavefront 0
+                const int srow0 = sep0 ? ll_ - NB0 : 0;
+                const bool acc1 = ll_ >= NB1 && ll_ < NR1;   // accumulator lanes of wavefront 1
+                const int r1 = acc1 ? ll_ - NB1 : 0;
+                const int srow1 = r1 < 2 * DIM ? r1 : r1 + C::MS * DIM;  // Cfg::nd_unrank1
+                auto block_forward = [&](auto Nc) {
+                    static_for<0, decltype(Nc)::value>([&](auto Jc) {
                         constexpr int j = decltype(Jc)::value;
                         const double wj = bcast(b, j);
                         b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
                     });
-                    LSCQP_MARK(11);
-                }
-                if (wv == 1 && sep) hand[srow] = b;  // accumulator rows started from 0: their value IS wavefront 1's share
-                __syncthreads();
-                if (wv == 0) {
-                    LSCQP_MARK(8);
-                    b += sep ? hand[srow] : 0.0;
-                    static_for<NB, NA>([&](auto Jc) {  // forward through the separator
-                        constexpr int j = decltype(Jc)::value;
-                        const double wj = bcast(b, j);
-                        b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
-                    });
-                    // ---- backward: (D L') x = w; row i of the upper factor is A[j > i] of lane i ----
-                    asm volatile("" : "+v"(ll_));
-                    static_for<NB, NA>([&](auto Jc) {
-                        constexpr int j = NA - 1 - (decltype(Jc)::value - NB);
-                        const double xj = bcast(b * dinv_own, j);
-                        b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);  // (the block rows of wavefront 0 take their separator part here)
-                    });
-                    LSCQP_MARK(11);
-                }
-                if (wv == 0 && sep) hand[srow] = b * dinv_own;  // the separator's solution (wavefront 1 reads hand only after the barrier)
-                __syncthreads();
-                if (wv == 1) {  // block rows of wavefront 1: U[i][S] x_S
-                    LSCQP_MARK(9);
-                    static_for<0, NS>([&](auto Cc) {
-                        constexpr int c = decltype(Cc)::value;
-                        if constexpr (C::nd_touched(1, c)) b = fma(-A[NB + c], hand[c], b);  // (accumulator lanes compute a value nobody uses)
-                    });
-                    LSCQP_MARK(11);
-                }
-                if (wv < 2) {
-                    LSCQP_MARK(10);
+                };
+                auto block_backward = [&](auto Nc) {
+                    constexpr int NB = decltype(Nc)::value;
                     asm volatile("" : "+v"(ll_));
                     static_for<0, NB>([&](auto Jc) {
                         constexpr int j = NB - 1 - decltype(Jc)::value;
                         const double xj = bcast(b * dinv_own, j);
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);
                     });
+                };
+                // ---- forward through the blocks: L w = b (unit lower) ----
+                if (wv == 0) {
+                    LSCQP_MARK(8);
+                    block_forward(std::integral_constant<int, NB0>{});
+                    LSCQP_MARK(11);
+                }
+                if (wv == 1) {
+                    LSCQP_MARK(9);
+                    block_forward(std::integral_constant<int, NB1>{});
+                    LSCQP_MARK(11);
+                }
+                if (wv == 1 && acc1) hand[srow1] = b;  // accumulator rows started from 0: their value IS wavefront 1's share
+                __syncthreads();
+                if (wv == 0) {
+                    LSCQP_MARK(8);
+                    {
+                        const bool take = sep0 && (srow0 < 2 * DIM || srow0 >= 2 * DIM + C::MS * DIM);  // Cfg::nd_touched(1, srow0)
+                        const double v = hand[take ? srow0 : 0];
+                        b += take ? v : 0.0;
+                    }
+                    static_for<NB0, NR0>([&](auto Jc) {  // forward through the separator
+                        constexpr int j = decltype(Jc)::value;
+                        const double wj = bcast(b, j);
+                        b = fma(-((ll_ > j) ? A[j] : 0.0), wj, b);
+                    });
+                    // ---- backward: (D L') x = w; row i of the upper factor is A[j > i] of lane i ----
+                    asm volatile("" : "+v"(ll_));
+                    static_for<NB0, NR0>([&](auto Jc) {
+                        constexpr int j = NR0 - 1 - (decltype(Jc)::value - NB0);
+                        const double xj = bcast(b * dinv_own, j);
+                        b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);  // (the block rows of wavefront 0 take their separator part here)
+                    });
+                    LSCQP_MARK(11);
+                }
+                // (same wavefront, LDS in program order: the shares were read above before the buffer is overwritten here)
+                if (wv == 0 && sep0) hand[srow0] = b * dinv_own;  // the separator's solution
+                __syncthreads();
+                if (wv == 1) {  // block rows of wavefront 1: U[i][S] x_S
+                    LSCQP_MARK(9);
+                    static_for<0, NS>([&](auto Cc) {
+                        constexpr int c = decltype(Cc)::value;
+                        if constexpr (C::nd_touched(1, c)) b = fma(-A[C::nd_col(1, c)], hand[c], b);  // (accumulator lanes compute a value nobody uses)
+                    });
+                    block_backward(std::integral_constant<int, NB1>{});
+                    LSCQP_MARK(11);
+                }
+                if (wv == 0) {
+                    LSCQP_MARK(8);
+                    block_backward(std::integral_constant<int, NB0>{});
                     LSCQP_MARK(11);
                 }
                 return b * dinv_own;  // (final once the lane's own column has been broadcast; 0 for lanes without a row)
@@ -1864,7 +1918,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 // dummy row holds whatever the last lane parked)
                 {
                     const FT* const prow = park_ptr(lvz_);
-                    const bool has_row = C::ND ? ((lvz_ >> 6) < 2 && (lvz_ & 63) < C::NB + C::NS) : (W == 1 || zl);
+                    const bool has_row = C::ND ? ((lvz_ >> 6) < 2 && (lvz_ & 63) < ((lvz_ >> 6) == 0 ? C::NR0 : C::NR1)) : (W == 1 || zl);
 #pragma unroll
                     for (int cidx = 0; cidx < C::NAR; cidx++) {
                         const FT v = prow[cidx];
