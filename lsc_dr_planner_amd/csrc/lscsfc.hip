@@ -457,7 +457,7 @@ __device__ __forceinline__ void grow(BoxF& sfc, BoxF& sfc_cand, BoxF& sfc_update
 // Measured and dropped: the corridor's part of the map staged in LDS (the rounds are bound by the CU's LDS pipe and by
 // instruction issue, not by the map reads: slower), integer quick verdicts before the exact comparison (slower).
 #ifdef LSCSFC_DEBUG
-__device__ unsigned long long sfc_dbg[16];
+__device__ unsigned long long sfc_dbg[32];
 #define SFC_DBG(i, v) do { if (threadIdx.x == 0) atomicAdd(&sfc_dbg[i], (unsigned long long)(v)); } while (0)
 #else
 #define SFC_DBG(i, v) do { } while (0)
@@ -466,12 +466,16 @@ __device__ unsigned long long sfc_dbg[16];
 #define LSCSFC_GROUP 4
 #endif
 #ifndef LSCSFC_AHEAD
-#define LSCSFC_AHEAD 63  // boxes of a batch (<= 63: lane j of wavefront 0 assembles box j)
+#define LSCSFC_AHEAD 254  // boxes of a batch's look-ahead (lane j of the first ceil(AHEAD / 64) wavefronts assembles box j; growth counts are bytes: <= 254)
 #endif
 #ifndef LSCSFC_SAMPLED
-#define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing)
+#define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing); <= 63
 #endif
 constexpr int kAhead = LSCSFC_AHEAD;
+constexpr int kSamp = LSCSFC_SAMPLED;           // record slots of a batch: the boxes that have to be sampled
+constexpr int kGenWaves = (kAhead + 63) / 64;   // wavefronts that assemble the look-ahead
+constexpr int kBoxes = kGenWaves * 64;
+static_assert(kAhead >= 2 && kAhead <= 254 && kSamp >= 1 && kSamp <= 63, "look-ahead: growth counts are bytes, the sampled boxes are looked up with one ballot");
 #ifndef LSCSFC_TAB
 #define LSCSFC_TAB 3072
 #endif
@@ -484,17 +488,33 @@ constexpr int kAhead = LSCSFC_AHEAD;
 constexpr int kTab = LSCSFC_TAB;    // entries of the per-(box, axis) tables of a batch
 constexpr int kCell = LSCSFC_CELL;  // largest map extent (cells per axis) with the cell-centre table in LDS
 constexpr int kTodo = LSCSFC_TODO;  // chunks of a batch the filter pass can list
+static_assert(LSCSFC_TODO <= 65536, "a listed item packs the chunk into 16 bits");
 struct Ahead {
-    float lo[kAhead][3];    // minimum corner of box j
-    int n[kAhead][3];
-    int tab[kAhead][3];     // offset of the (box, axis) table
-    float F[6][kAhead + 1]; // face d of the candidate box after c growths of direction d (d < 3: lo[d], else hi[d - 3])
-    int verdict[4];         // of the scan over the records: tests in the batch, first boundary failure, "test box 0 alone", column chunks
-    int axes[kAhead];       // thin axis | fast column axis << 2 | slow column axis << 4
-    int cols[kAhead];       // columns of box j
-    int first[kAhead + 1];  // prefix sums of the boxes' column counts, in wavefronts (64 columns)
+    // the boxes of the batch that have to be sampled, in test order (slot k):
+    float lo[kSamp][3];     // minimum corner
+    int n[kSamp][3];        // sample points per axis
+    int tab[kSamp][3];      // offset of the (box, axis) table
+    int axes[kSamp];        // thin axis | fast column axis << 2 | slow column axis << 4
+    int cols[kSamp];        // columns of the box
+    int first[kSamp + 1];   // prefix sums of the boxes' column counts, in wavefronts (64 columns)
+    int sbox[kSamp];        // which test of the look-ahead the slot is
+    int nsamp;              // slots in use
+    // the look-ahead:
+    float F[6][kAhead + 2]; // face d of the accepted box after c growths of direction d (d < 3: lo[d], else hi[d - 3]); kept across batches
+    int flen[6];            // valid entries of F[d]
+    int gmax[6];            // growths of direction d the world boundary admits (counted from the accepted box)
+    int need[kBoxes];       // per test j: table entries it needs,
+    int ncol[kBoxes];       // its columns (0: nothing to sample),
+    int flag[kBoxes];       // 1: the batch must end in front of it, 4: (j = 0) outside the world boundary; later: its slot, -1 none
+    int seg_start[8];       // segment s of the look-ahead (one inner loop of the reference): its first test,
+    unsigned long long seg_cp[8];  // growths per direction before it,
+    unsigned seg_cands[8];  // its candidate directions,
+    int seg_ncand[8];       // their number,
+    int seg_i[8];           // the index of the last one taken
+    int seg_t0[8];          // and the inner loop's test index of its first test (1: the batch starts behind a pending growth)
+    int verdict[8];         // tests in the batch, "test 0 fails the boundary", "test 0 alone", column chunks, tests of the look-ahead, "it reaches the expansion's end", segments
     int fail;               // first failing test of the batch (kAhead: none)
-    int ntodo;              // chunks the free-space table could not clear (the filter pass of obstacle_in_batch)
+    int ntodo, ntodo2;      // chunks / column segments the free-space table could not clear (the filter pass of obstacle_in_batch)
     int todo[kTodo];
     float ptab[kTab + 4];   // search_point(k) = box_min(k) + iter * res                      (:786-790)
     int vtab[kTab + 4];     // its map index, -1 outside the distance map                      (worldToMap)
@@ -517,8 +537,9 @@ __device__ __forceinline__ float axis_dist(const Ahead& A, int k, bool have, int
     return fabsf(q - p);
 }
 
-// tests the J recorded boxes; returns the index of the first one holding an obstacle, kAhead if none
-__device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double margin) {
+// tests the recorded boxes (slots 0 .. A.nsamp-1); returns the test index of the first one holding an obstacle, kAhead if none
+__device__ int obstacle_in_batch(const MapView& mp, Ahead& A, double margin) {
+    const int J = A.nsamp;
     const double res = mp.res;
     const float delta = (float)(0.5 * res);
     const int lane = threadIdx.x;
@@ -549,51 +570,93 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
     // Filter pass (with the free-space table): every 64-column chunk of the batch is asked ONCE, by one lane, whether the cells its
     // columns run through are provably free -- eight reads of the table instead of 64 x nl samples; what is left over (the chunks next
     // to obstacles: a few per cent of a layer of a large box) is listed and only that is evaluated.  The list's order does not matter:
-    // the verdict is a minimum over the failing boxes.
+    // the verdict is a minimum over the failing boxes.  Columns longer than kSeg samples (the whole-box re-test behind every failure:
+    // 40 - 60 samples along its thin axis) are asked per SEGMENT of kSeg samples: a chunk next to an obstacle is next to it over a few
+    // of its segments only, and a listed segment is ONE group of nearest-cell loads instead of a chain of nl / 4 dependent ones
+    // (measured in a room with a few boxes: 40 of a wavefront's 47 memory round trips per corridor were such chains).
+    constexpr int kSeg = 8;
     const int all_chunks = A.first[J];
-    bool listed = false;
+    bool listed = false, from_back = false;
     int n_rounds = all_chunks;
     if (mp.sat != nullptr && margin <= mp.sat_margin && all_chunks >= 64 && all_chunks <= kTodo) {
-        if (lane == 0) A.ntodo = 0;
-        __syncthreads();
-        for (int c = lane; c < all_chunks; c += kSfcThreads) {
+        if (lane == 0) A.ntodo = 0, A.ntodo2 = 0;
+        int zsh = 0;  // segments per column, rounded up to a power of two (uniform: J <= kSamp slots)
+        for (int t = 0; t < J; t++) {
+            const int nl = A.n[t][A.axes[t] & 3];
+            while (nl > kSeg && (kSeg << zsh) < nl) zsh++;
+        }
+        // is item (chunk c, segment zs; zs < 0: the whole columns) provably free?  `skip`: the columns have no such segment
+        auto item_free = [&](int c, int zs, bool& skip, bool& segmented) -> bool {
             int j = 0;
-            for (int t = 1; t < J; t++) j += (c >= A.first[t]) ? 1 : 0;
+            for (int t = 1; t < J; t++) j += (c >= A.first[t]) ? 1 : 0;  // (J <= kSamp slots)
             const int ax = A.axes[j];
             const int la = ax & 3, ca = (ax >> 2) & 3, cb = (ax >> 4) & 3;
             const int na = A.n[j][ca], nl = A.n[j][la];
             const int c0 = (c - A.first[j]) * 64, cl = A.cols[j] - 1;
             const int c1 = c0 + 63 < cl ? c0 + 63 : cl;
-            const int ib0 = c0 / na, ib1 = c1 / na;
+            // (c0, c1 < 2^22: a float quotient is off by at most one)
+            const float rna = 1.0f / (float)na;
+            int ib0 = (int)((float)c0 * rna), ib1 = (int)((float)c1 * rna);
+            ib0 += (c0 - ib0 * na < 0) ? -1 : ((c0 - ib0 * na >= na) ? 1 : 0);
+            ib1 += (c1 - ib1 * na < 0) ? -1 : ((c1 - ib1 * na >= na) ? 1 : 0);
             const int ia0 = ib0 == ib1 ? c0 - ib0 * na : 0, ia1 = ib0 == ib1 ? c1 - ib1 * na : na - 1;
+            segmented = nl > kSeg;
+            const bool whole = zs < 0 || !segmented;
+            const int zfirst = whole ? 0 : zs * kSeg;
+            skip = zs >= 0 && (segmented ? zfirst >= nl : zs > 0);
+            if (skip) return true;
+            const int zn = whole ? nl : (nl - zfirst < kSeg ? nl - zfirst : kSeg);
             const int ta = A.tab[j][ca], tb = A.tab[j][cb], tl = A.tab[j][la];
             int va0, va1, vb0, vb1, vl0, vl1;
             const int ra = cell_range(A.vtab, ta + ia0, ia1 - ia0 + 1, va0, va1), rb = cell_range(A.vtab, tb + ib0, ib1 - ib0 + 1, vb0, vb1);
-            const int rl = cell_range(A.vtab, tl, nl, vl0, vl1);
-            bool free_ = ra == 2 || rb == 2 || rl == 2;  // (all of the chunk's samples lie beyond the map, far from the origin)
+            const int rl = cell_range(A.vtab, tl + zfirst, zn, vl0, vl1);
+            bool free_ = ra == 2 || rb == 2 || rl == 2;  // (all of the item's samples lie beyond the map, far from the origin)
             if (!free_ && ra == 1 && rb == 1 && rl == 1) {  // (0: a sample outside the map that the exact path has to look at)
                 const int x0 = ca == 0 ? va0 : (cb == 0 ? vb0 : vl0), x1 = ca == 0 ? va1 : (cb == 0 ? vb1 : vl1);
                 const int y0 = ca == 1 ? va0 : (cb == 1 ? vb0 : vl0), y1 = ca == 1 ? va1 : (cb == 1 ? vb1 : vl1);
                 const int z0 = ca == 2 ? va0 : (cb == 2 ? vb0 : vl0), z1 = ca == 2 ? va1 : (cb == 2 ? vb1 : vl1);
                 free_ = cells_free(mp, x0, x1, y0, y1, z0, z1);
             }
-            if (!free_) A.todo[atomicAdd(&A.ntodo, 1)] = c;
+            return free_;
+        };
+        __syncthreads();
+        for (int c = lane; c < all_chunks; c += kSfcThreads) {  // first the chunks, whole columns: listed from the front of A.todo
+            bool skip, segmented;
+            if (!item_free(c, -1, skip, segmented)) A.todo[atomicAdd(&A.ntodo, 1)] = c;  // (all_chunks <= kTodo; chunks < 2^16)
         }
         __syncthreads();
+        SFC_DBG(26, clock64() - tt1_);
         n_rounds = A.ntodo;
         listed = true;
+        if (zsh > 0 && n_rounds > 0) {  // ... then the segments of the chunks that are left: listed from its back, as long as both lists fit
+            const int n1 = n_rounds;
+            for (int it = lane; it < (n1 << zsh); it += kSfcThreads) {
+                const int c = A.todo[it >> zsh], zs = it & ((1 << zsh) - 1);
+                bool skip, segmented;
+                const bool free_ = item_free(c, zs, skip, segmented);
+                if (!skip && !free_) {
+                    const int slot = atomicAdd(&A.ntodo2, 1);
+                    if (n1 + slot < kTodo) A.todo[kTodo - 1 - slot] = c | ((segmented ? zs + 1 : 0) << 16);
+                }
+            }
+            __syncthreads();
+            if (n1 + A.ntodo2 <= kTodo) n_rounds = A.ntodo2, from_back = true;  // (else: the chunks as listed, whole columns)
+        }
+        SFC_DBG(31, clock64() - tt1_);
         SFC_DBG(12, all_chunks); SFC_DBG(13, n_rounds); SFC_DBG(14, 1);
     } else {
         SFC_DBG(15, all_chunks);
     }
     for (int r = lane >> 6; r < n_rounds; r += kSfcThreads / 64) {
         const int stop = *(volatile int*)&A.fail;  // tests behind a failure already found need not be finished
-        const int chunk = __builtin_amdgcn_readfirstlane(listed ? A.todo[r] : r);  // wave-uniform: boxes are padded to whole wavefronts
+        const int item = __builtin_amdgcn_readfirstlane(listed ? A.todo[from_back ? kTodo - 1 - r : r] : r);  // wave-uniform: boxes are padded to whole wavefronts
+        const int chunk = item & 0xffff, zsel = item >> 16;  // (zsel > 0: segment zsel - 1 of the columns only)
         const int idx = chunk * 64 + (lane & 63);
         // the box this chunk belongs to: lane t asks "does box t + 1 start at or before it" (one LDS read per lane instead of a scan)
         const int lt = lane & 63;
-        const int j = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lt + 1 < J && chunk >= A.first[lt + 1 < kAhead ? lt + 1 : kAhead]));
-        if (j > stop) continue;
+        const int j = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lt + 1 < J && chunk >= A.first[lt + 1 < kSamp ? lt + 1 : kSamp]));
+        const int jbox = __builtin_amdgcn_readfirstlane(A.sbox[j]);
+        if (jbox > stop) continue;
         const int ax = __builtin_amdgcn_readfirstlane(A.axes[j]);
         const int la = ax & 3, ca = (ax >> 2) & 3, cb = (ax >> 4) & 3;
         const int col = idx - A.first[j] * 64;
@@ -661,14 +724,17 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, int J, double marg
                 hit = hit || ((double)dist < thr);
             }
         };
-        if (nl <= 2) {
+        SFC_DBG(27, nl <= 2 ? 1 : 0); SFC_DBG(28, (nl > 2 && nl <= 8) ? 1 : 0); SFC_DBG(29, nl > 8 ? 1 : 0); SFC_DBG(30, nl > 8 ? (nl + LSCSFC_GROUP - 1) / LSCSFC_GROUP : 0);
+        if (zsel > 0) {
+            group(std::integral_constant<int, kSeg>{}, (zsel - 1) * kSeg);
+        } else if (nl <= 2) {
             group(std::integral_constant<int, 2>{}, 0);
         } else if (nl <= 8) {
             group(std::integral_constant<int, 8>{}, 0);
         } else {
             for (int z0 = 0; z0 < nl; z0 += LSCSFC_GROUP) group(std::integral_constant<int, LSCSFC_GROUP>{}, z0);
         }
-        if (live && hit) atomicMin(&A.fail, j);
+        if (live && hit) atomicMin(&A.fail, jbox);
     }
     __syncthreads();
     SFC_DBG(8, clock64() - tt1_);
@@ -692,171 +758,363 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
         cands = 0;
         for (int t = 0; t < 6; t++) cands |= (unsigned)cand[t] << (4 * t);
     }
-    auto cand_at = [&](int t) -> int { return (int)((cands >> (4 * t)) & 15u); };
-    // growths per direction (one byte each) after m growths of the loop whose next candidate index is `base`: growth u takes candidate
-    // (base + u) mod ncand -- in closed form, the look-ahead asks for it at up to 62 growths
-    auto growths = [&](int base, int m) -> unsigned long long {
+    // x / n for 0 <= x < 512 and 1 <= n <= 6 as (x * ceil(1024 / n)) >> 10 (exact there; an integer division by a run-time value is ~40 instructions)
+    auto kdiv = [](int n) -> int { return n == 1 ? 1024 : (n == 2 ? 512 : (n == 3 ? 342 : (n == 4 ? 256 : (n == 5 ? 205 : 171)))); };
+    auto mod_of = [](int x, int n, int K) -> int { return x - n * ((x * K) >> 10); };
+    auto cand_of = [](unsigned cs, int t) -> int { return (int)((cs >> (4 * t)) & 15u); };
+    auto erase_of = [](unsigned cs, int t) -> unsigned { return (cs & ((1u << (4 * t)) - 1u)) | ((cs >> (4 * (t + 1))) << (4 * t)); };
+    // growths per direction (one byte each) after m growths of an inner loop with candidates cs[0 .. nc) whose next candidate index is
+    // `base` (in [0, nc]): growth u takes candidate (base + u) mod nc -- in closed form, the look-ahead asks for it at up to 62 growths
+    auto growths_of = [&](unsigned cs, int nc, int K, int base, int m) -> unsigned long long {
+        const int b0 = base >= nc ? base - nc : base;
         unsigned long long cp = 0;
-        for (int sidx = 0; sidx < ncand; sidx++) {
-            int r = (sidx - base) % ncand;  // the first growth that takes candidate sidx
-            if (r < 0) r += ncand;
-            const int cnt = m > r ? (m - 1 - r) / ncand + 1 : 0;
-            cp += (unsigned long long)cnt << (8 * cand_at(sidx));
+#pragma unroll
+        for (int sidx = 0; sidx < 6; sidx++) {
+            int r = sidx - b0;  // the first growth that takes candidate sidx
+            r += r < 0 ? nc : 0;
+            const int cnt = (sidx < nc && m > r) ? (((m - 1 - r) * K) >> 10) + 1 : 0;
+            cp += (unsigned long long)cnt << (8 * cand_of(cs, sidx));
         }
         return cp;
     };
     auto face = [](const BoxF& b, int d) -> float {
         return d == 0 ? b.lo[0] : (d == 1 ? b.lo[1] : (d == 2 ? b.lo[2] : (d == 3 ? b.hi[0] : (d == 4 ? b.hi[1] : b.hi[2]))));
     };
+    // the box whose faces have been grown cp[d] times since the batch's face tables were made
+    auto box_of = [&](unsigned long long cp, BoxF& bx) {
+        for (int k = 0; k < 3; k++) {
+            bx.lo[k] = A.F[k][(int)((cp >> (8 * k)) & 255ull)];
+            bx.hi[k] = A.F[k + 3][(int)((cp >> (8 * (k + 3))) & 255ull)];
+        }
+    };
+    // ... the same box as the accepted one, its candidate grown once more along d and the new layer (what `grow` leaves behind)
+    auto with_pending = [&](unsigned long long cp, int d, BoxF& acc, BoxF& cand, BoxF& upd) {
+        for (int k = 0; k < 3; k++) {
+            const int cl = (int)((cp >> (8 * k)) & 255ull), ch = (int)((cp >> (8 * (k + 3))) & 255ull);
+            acc.lo[k] = A.F[k][cl];
+            acc.hi[k] = A.F[k + 3][ch];
+            cand.lo[k] = upd.lo[k] = acc.lo[k];
+            cand.hi[k] = upd.hi[k] = acc.hi[k];
+            if (d == k) upd.hi[k] = acc.lo[k], cand.lo[k] = upd.lo[k] = A.F[k][cl + 1];
+            if (d == k + 3) upd.lo[k] = acc.hi[k], cand.hi[k] = upd.hi[k] = A.F[k + 3][ch + 1];
+        }
+    };
     const double res = mp.res, rinv = 1.0 / res;
-    BoxF sfc = initial, sfc_cand, sfc_update;
+    // The reference's two nested loops (while candidates are left: re-test the whole box, then grow it round robin until a test fails,
+    // erase the direction that failed) as ONE loop over batches of tests.  State between batches: the accepted box `sfc`, whether a
+    // growth is PENDING (the candidate box is sfc grown once along cand[i] and its new layer is the next box to test; else the next
+    // test is the whole box, the first one of an inner loop), the candidates and the index i of the last one taken.
+    BoxF sfc = initial;
+    bool pend = false;
     int i = -1;
+    unsigned long long shift = 0;  // growths accepted since the face tables were based
+    bool first = true;
+    const int wave = threadIdx.x >> 6, wlane = threadIdx.x & 63;
     while (ncand > 0) {
-        sfc_cand = sfc;
-        sfc_update = sfc;
-        bool failed = false;
-        while (!failed) {
-            // The tests ahead: box j is what the loop condition sees after j passes.  A face of the candidate box only moves when
-            // its own direction is grown, by the reference's float step each time, so the faces after c growths are six short
-            // tables (one lane each); lane j then assembles box j from them and sizes it, and a uniform scan over the <= kAhead
-            // records decides how many tests the batch holds.  (Growing the boxes one after the other in every lane -- dependent
-            // fp64 chains -- cost 1 600 cycles per test, as much as testing them.)
-            const long long tg0_ = clock64();
-            __syncthreads();  // (the previous batch's readers of A are done)
-            if (threadIdx.x < 6) {
-                const int d = threadIdx.x;
-                float x = face(sfc_cand, d);
-                A.F[d][0] = x;
-                for (int c = 1; c <= kAhead; c++) {
-                    x = (float)((double)x + (d < 3 ? -res : res));
-                    A.F[d][c] = x;
-                }
-            }
-            __syncthreads();
-            // (wavefront 0 alone: lane j assembles and sizes box j, a shuffle scan over the lanes places the boxes in the batch's index
-            // space and a ballot finds where the batch ends; the other wavefronts wait at the barrier instead of competing for the SIMDs
-            // and the LDS pipe with sixteen copies of the same scalar work)
-            if (threadIdx.x < 64) {
-                const int j = threadIdx.x;
-                const bool mine = j < kAhead && tables;
-                BoxF u = sfc_update;
-                if (mine && j > 0) {
-                    const unsigned long long cp = growths(i + 1, j - 1);  // what lies before box j: j - 1 growths
-                    const int d = cand_at((i + j) % ncand);             // ... and the growth that makes it
-                    for (int k = 0; k < 3; k++) {
-                        const int cl = (int)((cp >> (8 * k)) & 255ull), ch = (int)((cp >> (8 * (k + 3))) & 255ull);
-                        u.lo[k] = A.F[k][cl];
-                        u.hi[k] = A.F[k + 3][ch];
-                        if (d == k) u.hi[k] = u.lo[k], u.lo[k] = A.F[k][cl + 1];
-                        if (d == k + 3) u.lo[k] = u.hi[k], u.hi[k] = A.F[k + 3][ch + 1];
-                    }
-                }
-                const bool inb = in_boundary(mp, u, 0);
-                int n[3];
-                for (int k = 0; k < 3; k++) n[k] = (int)floor_div((double)(u.hi[k] - u.lo[k]) + 1e-5, res, rinv) + 1;
-                // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
-                bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
-                // a box the map's summary proves free passes like an empty one: no table entries, no columns (lscqp_map_prepare)
-                empty = empty || (mine && inb && surely_free(mp, margin, u.lo[0], u.lo[1], u.lo[2], n[0], n[1], n[2]));
-                // thin axis: the columns run along it (ties: the later axis, so that x stays a column axis)
-                const int la = (n[2] <= n[1] && n[2] <= n[0]) ? 2 : (n[1] <= n[0] ? 1 : 0);
-                const int ca = la == 0 ? 1 : 0, cb = la == 2 ? 1 : 2;
-                const int64_t ncol64 = empty ? 0 : (la == 2 ? (int64_t)n[0] * n[1] : (la == 1 ? (int64_t)n[0] * n[2] : (int64_t)n[1] * n[2]));
-                const bool over = !empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads || ncol64 > (1 << 22));
-                const int ncol = (mine && !over) ? (int)ncol64 : 0;
-                const int need = (mine && !empty) ? n[0] + n[1] + n[2] : 0;
-                const int mychunks = (ncol + 63) >> 6;
-                int pc = mychunks, pu = need;  // inclusive prefix sums over the lanes
-                for (int d = 1; d < kAhead; d <<= 1) {
-                    const int tc = __shfl_up(pc, d), tu = __shfl_up(pu, d);
-                    if (j >= d) pc += tc, pu += tu;
-                }
-                const int ec = pc - mychunks, eu = pu - need;  // what lies before box j
-                // the batch ends at the first box outside the world boundary (that test fails without looking at the map: jstop) or
-                // beyond the batch's limits (jbrk; box 0 beyond them is tested on its own, the sequential way)
-                const unsigned long long mstop = __builtin_amdgcn_ballot_w64(mine && !inb);
-                const unsigned long long mbrk = __builtin_amdgcn_ballot_w64(mine && (over || (int64_t)ec * 64 + ncol > (1 << 22) || eu + need > kTab));
-                const int jstop_ = mstop ? __builtin_ctzll(mstop) : kAhead, jbrk = mbrk ? __builtin_ctzll(mbrk) : kAhead;
-                // ... or behind the LSCSFC_SAMPLED-th box that has to be sampled: tests behind the first failure are wasted work, boxes
-                // the free-space table passes are not
-                const unsigned long long msamp = __builtin_amdgcn_ballot_w64(mine && ncol > 0);
-                const int before = __builtin_popcountll(msamp & ((1ull << j) - 1ull));
-                const unsigned long long mcap = __builtin_amdgcn_ballot_w64(mine && before >= LSCSFC_SAMPLED);
-                const int jcap = mcap ? __builtin_ctzll(mcap) : kAhead;
-                const int jlim = jbrk < jcap ? jbrk : jcap;
-                const int J_ = tables ? (jstop_ < jlim ? jstop_ : jlim) : 0;
-                const bool alone_ = !tables || (jbrk == 0 && jstop_ > 0);
-                if (mine && j < J_) {
-                    for (int k = 0; k < 3; k++) {
-                        A.lo[j][k] = u.lo[k];
-                        A.n[j][k] = empty ? 0 : n[k];  // (no table entries, no columns)
-                    }
-                    A.tab[j][0] = eu, A.tab[j][1] = eu + (empty ? 0 : n[0]), A.tab[j][2] = eu + (empty ? 0 : n[0] + n[1]);
-                    A.axes[j] = la | (ca << 2) | (cb << 4);
-                    A.cols[j] = ncol;
-                    A.first[j + 1] = pc;
-                }
-                if (j == 0) {
-                    A.first[0] = 0, A.fail = kAhead;
-                    A.verdict[0] = J_, A.verdict[1] = tables ? jstop_ : kAhead, A.verdict[2] = alone_ ? 1 : 0;
-                }
-                // chunks of the whole batch: the inclusive sum at its last box
-                const int total_chunks = __shfl(pc, J_ > 0 ? J_ - 1 : 0);
-                if (j == 0) A.verdict[3] = J_ > 0 ? total_chunks : 0;
-            }
-            __syncthreads();
-            int J = A.verdict[0], jstop = A.verdict[1];
-            const bool alone = A.verdict[2] != 0;
-            const int chunks = A.verdict[3];
-            SFC_DBG(9, clock64() - tg0_);
-            SFC_DBG(0, 1); SFC_DBG(1, J); SFC_DBG(2, chunks); SFC_DBG(3, alone ? 1 : 0);
-            const long long t0_ = clock64();
-            int jfail;
-            if (alone) {
-                if (!in_boundary(mp, sfc_update, 0)) {
-                    jfail = 0;
-                } else {
-                    jfail = obstacle_in(mp, sfc_update, margin) ? 0 : kAhead;
-                }
-                J = 1;
-                jstop = kAhead;
+        // The tests ahead: test j is what the loop condition sees after j tests have passed.  A face of the box only moves when its
+        // own direction is grown, by the reference's float step each time, so face d after c growths is a table F[d][c] (a chain of
+        // dependent float steps: kept across batches, shifted by what was accepted and extended at its end).  A test that fails on the
+        // WORLD BOUNDARY is known in advance (pure arithmetic on the face: isSFCInBoundary, :810-817), so the sequence continues behind
+        // it as the reference would: the pending growth is dropped, its direction erased, the whole box re-tested, the remaining
+        // directions grown round robin -- the look-ahead is a list of SEGMENTS (one inner loop each), and only a test that finds an
+        // OBSTACLE (or the batch's limits) ends the batch.  Lane j of the first wavefronts assembles box j from the tables and its
+        // segment's parameters and sizes it; one wavefront then scans the <= kAhead tests, decides how many the batch holds and hands
+        // out the record slots of those that have to be sampled.
+        // (Growing the boxes one after the other in every lane -- dependent fp64 chains -- cost 1 600 cycles per test, as much as
+        // testing them; batches of at most 63 tests that ended at every boundary failure: 8 batches per corridor in a room with a few
+        // boxes, 3 of them ended by the boundary and 2 by the 63.)
+        const long long tg0_ = clock64();
+        const int KA = kAhead;
+        __syncthreads();  // (the previous batch's readers of A are done)
+        for (int d = wave; d < 6; d += kSfcThreads / 64) {  // one wavefront per direction: shift, extend, count
+            int L = 1;
+            if (first) {
+                if (wlane == 0) A.F[d][0] = face(sfc, d);
             } else {
-                jfail = J > 0 ? obstacle_in_batch(mp, A, J, margin) : kAhead;
-            }
-            SFC_DBG(4, clock64() - t0_);
-            const int jf = jfail < jstop ? jfail : jstop;  // first failing test of this batch, kAhead if none was seen
-            const int passes = jf < J ? jf : J;
-            const long long tr0_ = clock64();
-            if (alone) {
-                for (int j = 0; j < passes; j++) {
-                    i++;
-                    if (i >= ncand) i = 0;
-                    grow(sfc, sfc_cand, sfc_update, cand_at(i), res);
+                L = A.flen[d];
+                const int dl = (int)((shift >> (8 * d)) & 255ull);
+                if (dl > 0) {
+                    float mv[(kAhead + 2 + 63) / 64];
+#pragma unroll
+                    for (int q = 0; q < (kAhead + 2 + 63) / 64; q++) {
+                        const int c = wlane + 64 * q;
+                        mv[q] = (c + dl < L) ? A.F[d][c + dl] : 0.0f;
+                    }
+                    __builtin_amdgcn_wave_barrier();  // (one wavefront, LDS in program order: every read above precedes every write below)
+#pragma unroll
+                    for (int q = 0; q < (kAhead + 2 + 63) / 64; q++) {
+                        const int c = wlane + 64 * q;
+                        if (c + dl < L) A.F[d][c] = mv[q];
+                    }
+                    L -= dl;
                 }
-            } else if (passes > 0) {  // the state after `passes` growths, from the face tables
-                const unsigned long long cp = growths(i + 1, passes - 1);
-                i = (i + passes) % ncand;
-                const int d = cand_at(i);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // Extension of the chain x(c + 1) = (float)((double)x(c) + step) to KA + 2 entries, in parallel: while the values stay in
+            // one binade every step adds the same multiple of its ulp, so x(s + m) = x(s) + m (x(s + 1) - x(s)) is a GUESS that each
+            // lane then checks with the reference's own statement -- entry c is accepted iff it equals the step from the guessed entry
+            // c - 1; by induction everything in front of the first mismatch is the chain's value, and the next round starts there (a
+            // handful of rounds: binade crossings near 0 and at 1, 2, 4 ... m).  As a dependent chain: ~85 cycles per entry on one lane.
+            {
+                const double stp = d < 3 ? -res : res;
+                int sl = L - 1;  // last valid entry
+                while (sl < KA + 1) {
+                    const float xs = A.F[d][sl];
+                    const float x1 = (float)((double)xs + stp);
+                    const double dlt = (double)x1 - (double)xs;
+                    int bad = KA + 2;  // first entry that is not confirmed
+#pragma unroll
+                    for (int q = 0; q < (kAhead + 2 + 63) / 64; q++) {
+                        const int m = 1 + wlane + 64 * q, c = sl + m;
+                        const float guess = (float)((double)xs + (double)m * dlt), before = (float)((double)xs + (double)(m - 1) * dlt);
+                        const bool okc = c > KA + 1 || (float)((double)before + stp) == guess;
+                        const unsigned long long mb = __builtin_amdgcn_ballot_w64(!okc);
+                        const int fb = mb ? sl + 1 + 64 * q + (int)__builtin_ctzll(mb) : KA + 2;
+                        bad = fb < bad ? fb : bad;
+                        if (c <= KA + 1 && c < bad) A.F[d][c] = guess;  // (bad only shrinks: an entry behind an earlier mismatch is never written)
+                    }
+                    sl = bad - 1;  // (entry sl + 1 = x1 is always confirmed: progress)
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            L = L < KA + 2 ? KA + 2 : L;
+            __builtin_amdgcn_wave_barrier();
+            // growths of direction d the world boundary admits (the faces move monotonically)
+            const double wb = d < 3 ? (double)mp.world_min(d) + 0.0 - 1e-5 : (double)mp.world_max(d - 3) - 0.0 + 1e-5;
+            int g = 0;
+            for (int q = 0; q < (kAhead + 1 + 63) / 64; q++) {
+                const int c = 1 + wlane + 64 * q;
+                const float x = A.F[d][c < KA + 2 ? c : 0];
+                const bool okc = c <= KA + 1 && (d < 3 ? (double)x > wb : (double)x < wb);
+                g += __builtin_popcountll(__builtin_amdgcn_ballot_w64(okc));
+            }
+            if (wlane == 0) A.gmax[d] = g < 255 ? g : 255, A.flen[d] = L;
+        }
+        if (threadIdx.x == 0) A.nsamp = 0, A.verdict[3] = 0;
+        shift = 0;
+        first = false;
+        __syncthreads();
+        SFC_DBG(21, clock64() - tg0_);
+        // ---- phase A: lane j assembles and sizes box j (the segment list is uniform scalar work, repeated per wavefront)
+        BoxF u = sfc;
+        int n[3] = {0, 0, 0}, la = 0, ca = 1, cb = 2, ncol = 0;
+        if (threadIdx.x < kBoxes) {
+            const int j = threadIdx.x;
+            unsigned long long gm = 0;
+            for (int d = 0; d < 6; d++) gm |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(A.gmax[d]) << (8 * d);
+            // the segments: where the world boundary fails a test, and the state behind it
+            unsigned cs = (unsigned)__builtin_amdgcn_readfirstlane((int)cands);
+            int nc = __builtin_amdgcn_readfirstlane(ncand), is = __builtin_amdgcn_readfirstlane(pend ? i - 1 : i), j0 = 0, sN = 0;
+            int t0 = __builtin_amdgcn_readfirstlane(pend ? 1 : 0);
+            unsigned long long cps = 0;
+            bool done = false;
+            unsigned my_cs = cs;  // lane j: the parameters of the segment test j belongs to
+            int my_nc = nc, my_is = is, my_j0 = 0, my_t0 = t0;
+            unsigned long long my_cp = 0;
+            bool my_end = false;  // test j is the one the boundary fails
+            for (int sg = 0; sg < 7; sg++) {
+                if (j == 0) A.seg_start[sg] = j0, A.seg_cp[sg] = cps, A.seg_cands[sg] = cs, A.seg_ncand[sg] = nc, A.seg_i[sg] = is, A.seg_t0[sg] = t0;
+                const int K = kdiv(nc);
+                int b0 = is + 1;
+                b0 = b0 >= nc ? b0 - nc : b0;
+                int ubest = 1 << 20;  // the first growth of this inner loop whose face leaves the world
+#pragma unroll
+                for (int sidx = 0; sidx < 6; sidx++) {
+                    const int d = cand_of(cs, sidx);
+                    int r = sidx - b0;
+                    r += r < 0 ? nc : 0;
+                    const int g = (int)((gm >> (8 * d)) & 255ull) - (int)((cps >> (8 * d)) & 255ull);  // growths direction d has left
+                    const int uf = r + g * nc;
+                    ubest = (sidx < nc && uf < ubest) ? uf : ubest;
+                }
+                const int jend = j0 + ubest + 1 - t0;  // the test that fails: growth ubest makes the inner loop's test ubest + 1
+                const bool in_seg = j >= j0;            // (later segments overwrite)
+                my_cs = in_seg ? cs : my_cs, my_nc = in_seg ? nc : my_nc, my_is = in_seg ? is : my_is, my_j0 = in_seg ? j0 : my_j0;
+                my_t0 = in_seg ? t0 : my_t0;
+                my_cp = in_seg ? cps : my_cp;
+                my_end = in_seg ? (j == jend) : my_end;
+                if (jend >= KA) break;  // no failure on the boundary within the look-ahead: the segment runs to its end
+                cps += growths_of(cs, nc, K, b0, ubest);  // ubest growths accepted, the pending one dropped,
+                const int ifail = mod_of(is + ubest + 1, nc, K);
+                cs = erase_of(cs, ifail);                 // its direction erased
+                nc--;
+                is = ifail > 0 ? ifail - 1 : nc - 1;
+                j0 = jend + 1;
+                t0 = 0;
+                sN = sg + 1;
+                if (nc == 0) {
+                    done = true;  // ... and with the last direction gone the expansion ends behind test jend
+                    break;
+                }
+            }
+            const int Jtot = done ? j0 : KA;  // tests the look-ahead holds
+            if (j == 0 && done) A.seg_start[sN] = j0, A.seg_cp[sN] = cps, A.seg_cands[sN] = cs, A.seg_ncand[sN] = 0, A.seg_i[sN] = is, A.seg_t0[sN] = 0;
+            if (j == 0) A.verdict[4] = Jtot, A.verdict[5] = done ? 1 : 0, A.verdict[6] = done ? sN : sN + 1;  // (segments that hold tests)
+            SFC_DBG(22, clock64() - tg0_);
+            // box j: test t of its inner loop -- t = 0 the whole box, else the layer of growth t, behind t - 1 accepted ones
+            const bool mine = j < Jtot && tables;
+            const int t = j - my_j0 + my_t0;
+            if (mine) {
+                const int K = kdiv(my_nc);
+                const unsigned long long cp = my_cp + (t >= 1 ? growths_of(my_cs, my_nc, K, my_is + 1, t - 1) : 0ull);
+                const int d = t >= 1 ? cand_of(my_cs, mod_of(my_is + t, my_nc, K)) : -1;
                 for (int k = 0; k < 3; k++) {
                     const int cl = (int)((cp >> (8 * k)) & 255ull), ch = (int)((cp >> (8 * (k + 3))) & 255ull);
-                    sfc.lo[k] = A.F[k][cl];
-                    sfc.hi[k] = A.F[k + 3][ch];
-                    sfc_cand.lo[k] = sfc_update.lo[k] = sfc.lo[k];
-                    sfc_cand.hi[k] = sfc_update.hi[k] = sfc.hi[k];
-                    if (d == k) sfc_update.hi[k] = sfc.lo[k], sfc_cand.lo[k] = sfc_update.lo[k] = A.F[k][cl + 1];
-                    if (d == k + 3) sfc_update.lo[k] = sfc.hi[k], sfc_cand.hi[k] = sfc_update.hi[k] = A.F[k + 3][ch + 1];
+                    u.lo[k] = A.F[k][cl];
+                    u.hi[k] = A.F[k + 3][ch];
+                    if (d == k) u.hi[k] = u.lo[k], u.lo[k] = A.F[k][cl + 1];
+                    if (d == k + 3) u.lo[k] = u.hi[k], u.hi[k] = A.F[k + 3][ch + 1];
                 }
             }
-            SFC_DBG(10, clock64() - tr0_);
-            failed = jf <= J && jf < kAhead;
+            SFC_DBG(23, clock64() - tg0_);
+            const bool inb = in_boundary(mp, u, 0);
+            // (the boundary test of every box must agree with the segment list -- if one ever did not, the batch ends in front of it and
+            // it is test 0 of the next batch, which is decided on its own)
+            const bool mism = mine && j > 0 && (my_end != !inb);
+            for (int k = 0; k < 3; k++) n[k] = (int)floor_div((double)(u.hi[k] - u.lo[k]) + 1e-5, res, rinv) + 1;
+            // an inverted box (a hull clipped to a previous box it does not touch) has no sample points
+            bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
+            // a box the boundary fails is not looked at (the reference's test is `obstacle || !boundary`); a box the map's summary
+            // proves free passes like an empty one: no table entries, no columns (lscqp_map_prepare)
+            empty = empty || !inb || (mine && surely_free(mp, margin, u.lo[0], u.lo[1], u.lo[2], n[0], n[1], n[2]));
+            SFC_DBG(24, clock64() - tg0_);
+            // thin axis: the columns run along it (ties: the later axis, so that x stays a column axis)
+            la = (n[2] <= n[1] && n[2] <= n[0]) ? 2 : (n[1] <= n[0] ? 1 : 0);
+            ca = la == 0 ? 1 : 0, cb = la == 2 ? 1 : 2;
+            const int64_t ncol64 = empty ? 0 : (la == 2 ? (int64_t)n[0] * n[1] : (la == 1 ? (int64_t)n[0] * n[2] : (int64_t)n[1] * n[2]));
+            const bool over = !empty && (n[0] > kSfcThreads || n[1] > kSfcThreads || n[2] > kSfcThreads || ncol64 > (1 << 22));
+            ncol = (mine && !over) ? (int)ncol64 : 0;
+            A.need[j] = (mine && !empty) ? n[0] + n[1] + n[2] : 0;
+            A.ncol[j] = ncol;
+            A.flag[j] = (mine ? 0 : 1) | ((mine && (mism || over)) ? 1 : 0) | ((mine && j == 0 && !inb) ? 4 : 0);
         }
-        if (i < 0) return false;  // initial box outside the world: the reference erases begin() - 1 here (undefined)
-        {  // erase direction i
-            const unsigned below = cands & ((1u << (4 * i)) - 1u);
-            cands = below | ((cands >> (4 * (i + 1))) << (4 * i));
+        __syncthreads();
+        SFC_DBG(25, clock64() - tg0_);
+        // ---- phase B (wavefront 0): lane l scans tests kGenWaves * l ..; the batch ends at once if test 0 is outside the world boundary,
+        // in front of the first box beyond the batch's limits (test 0 beyond them is decided on its own, the sequential way), and behind
+        // the kSamp-th box that has to be sampled: tests behind the first failure are wasted work, boxes the free-space table passes are not
+        if (threadIdx.x < 64) {
+            constexpr int PB = kGenWaves;
+            const int l = threadIdx.x;
+            int ch_[PB], nd_[PB], fl_[PB], nc_[PB];
+            int sc = 0, su = 0, ss = 0;
+#pragma unroll
+            for (int q = 0; q < PB; q++) {
+                const int j = PB * l + q;
+                nc_[q] = A.ncol[j], nd_[q] = A.need[j], fl_[q] = A.flag[j];
+                ch_[q] = (nc_[q] + 63) >> 6;
+                sc += ch_[q], su += nd_[q], ss += nc_[q] > 0 ? 1 : 0;
+            }
+            int pc = sc, pu = su, ps = ss;  // inclusive prefix sums over the lanes
+            for (int d = 1; d < 64; d <<= 1) {
+                const int tc = __shfl_up(pc, d), tu = __shfl_up(pu, d), ts = __shfl_up(ps, d);
+                if (l >= d) pc += tc, pu += tu, ps += ts;
+            }
+            int ec = pc - sc, eu = pu - su, es = ps - ss;  // what lies before the lane's first test
+            int jmine = 1 << 20;
+            bool brk0 = false;
+            int ec_[PB], eu_[PB], es_[PB];
+#pragma unroll
+            for (int q = 0; q < PB; q++) {
+                const int j = PB * l + q;
+                ec_[q] = ec, eu_[q] = eu, es_[q] = es;
+                const bool brk = (fl_[q] & 1) != 0 || (int64_t)ec * 64 + nc_[q] > (1 << 22) || eu + nd_[q] > kTab;
+                const bool stopj = brk || es >= kSamp;
+                jmine = (stopj && j < jmine) ? j : jmine;
+                brk0 = brk0 || (j == 0 && brk);
+                ec += ch_[q], eu += nd_[q], es += nc_[q] > 0 ? 1 : 0;
+            }
+            const unsigned long long mlim = __builtin_amdgcn_ballot_w64(jmine < (1 << 20));
+            const int jlim = mlim ? __builtin_amdgcn_readlane(jmine, __builtin_ctzll(mlim)) : kBoxes;  // (tests >= Jtot carry flag 1)
+            const bool stop0 = (__builtin_amdgcn_readfirstlane(fl_[0]) & 4) != 0;
+            const bool brk_at_0 = __builtin_amdgcn_readfirstlane(brk0 ? 1 : 0) != 0;
+            const int J_ = tables ? (stop0 ? 0 : jlim) : 0;
+            const bool alone_ = !tables || (brk_at_0 && !stop0);
+            int mys = 0, myc = 0;
+#pragma unroll
+            for (int q = 0; q < PB; q++) {
+                const int j = PB * l + q;
+                const bool rec = j < J_ && nc_[q] > 0;
+                if (rec) {
+                    const int k = es_[q];
+                    A.sbox[k] = j, A.first[k] = ec_[q], A.first[k + 1] = ec_[q] + ch_[q], A.tab[k][0] = eu_[q];
+                    mys++, myc += ch_[q];
+                }
+                A.flag[j] = rec ? es_[q] : -1;
+            }
+            if (mys > 0) atomicAdd(&A.nsamp, mys), atomicAdd(&A.verdict[3], myc);
+            if (l == 0) {
+                A.fail = kAhead;
+                A.verdict[0] = J_, A.verdict[1] = (tables && stop0) ? 0 : kAhead, A.verdict[2] = alone_ ? 1 : 0;
+            }
         }
-        ncand--;
-        i = (i > 0) ? i - 1 : ncand - 1;
+        __syncthreads();
+        // ---- phase C: the lanes of the boxes that have to be sampled fill their record slots
+        if (threadIdx.x < kBoxes) {
+            const int k = A.flag[threadIdx.x];
+            if (k >= 0) {
+                for (int m = 0; m < 3; m++) A.lo[k][m] = u.lo[m], A.n[k][m] = n[m];
+                const int eu = A.tab[k][0];
+                A.tab[k][1] = eu + n[0], A.tab[k][2] = eu + n[0] + n[1];
+                A.axes[k] = la | (ca << 2) | (cb << 4);
+                A.cols[k] = ncol;
+            }
+        }
+        __syncthreads();
+        int J = A.verdict[0], jstop = A.verdict[1];
+        const bool alone = A.verdict[2] != 0;
+        const int chunks = A.verdict[3], Jtot = A.verdict[4], nseg = A.verdict[6];
+        const bool done = A.verdict[5] != 0;
+        SFC_DBG(9, clock64() - tg0_);
+        SFC_DBG(0, 1); SFC_DBG(1, J); SFC_DBG(2, chunks); SFC_DBG(3, alone ? 1 : 0);
+        const long long t0_ = clock64();
+        int jfail;
+        if (alone) {  // test 0 on its own, the sequential way
+            BoxF acc, cand, upd;
+            with_pending(0ull, pend ? cand_of(cands, i) : -1, acc, cand, upd);
+            if (!in_boundary(mp, upd, 0)) {
+                jfail = 0;
+            } else {
+                jfail = obstacle_in(mp, upd, margin) ? 0 : kAhead;
+            }
+            J = 1;
+            jstop = kAhead;
+        } else {
+            jfail = (J > 0 && A.nsamp > 0) ? obstacle_in_batch(mp, A, margin) : kAhead;
+        }
+        SFC_DBG(4, clock64() - t0_);
+        const int jf = jfail < jstop ? jfail : jstop;  // the test of this batch that ends it by failing, kAhead if none does
+        const bool failed = jf < kAhead && (jf < J || (jf == 0 && J == 0));
+        // (how batches end: 16 test 0 on the world boundary, 17 obstacle, 18 cut by the batch's limits, 19 tests passed or skipped, 20 the expansion's end)
+        SFC_DBG(16, (failed && jstop <= jfail) ? 1 : 0); SFC_DBG(17, (failed && jfail < jstop) ? 1 : 0);
+        SFC_DBG(18, failed ? 0 : 1); SFC_DBG(19, failed ? jf : J); SFC_DBG(20, (!failed && !alone && done && J == Jtot) ? 1 : 0);
+        const long long tr0_ = clock64();
+        if (!failed && !alone && done && J == Jtot) {  // every test up to the expansion's end was in the batch
+            box_of(A.seg_cp[nseg], sfc);
+            ncand = 0;
+            continue;
+        }
+        // where the batch ends: test jq -- the failing one, or the first one not in the batch (a test that passed on its own: the next)
+        const int jq = failed ? jf : J;
+        int sq = 0;
+        for (int q = 1; q < 7; q++) sq = (q < nseg && jq >= A.seg_start[q]) ? q : sq;
+        const int tq = jq - A.seg_start[sq] + A.seg_t0[sq];  // its test index in its inner loop
+        cands = A.seg_cands[sq], ncand = A.seg_ncand[sq];
+        const int isq = A.seg_i[sq], Kq = kdiv(ncand);
+        // tq - 1 growths of the inner loop accepted before it (tq = 0: it is the whole-box test)
+        const unsigned long long cpq = A.seg_cp[sq] + (tq >= 1 ? growths_of(cands, ncand, Kq, isq + 1, tq - 1) : 0ull);
+        box_of(cpq, sfc);
+        shift = cpq;
+        i = tq >= 1 ? mod_of(isq + tq, ncand, Kq) : isq;
+        pend = tq >= 1;
+        if (failed) {  // the growth under test dropped (tq = 0: the whole-box test itself failed), its direction erased
+            if (i < 0) return false;  // initial box outside the world: the reference erases begin() - 1 here (undefined)
+            cands = erase_of(cands, i);
+            ncand--;
+            i = (i > 0) ? i - 1 : ncand - 1;
+            pend = false;
+        }
+        SFC_DBG(10, clock64() - tr0_);
     }
     const double delta = margin - ((int)(margin / res) * res);  // margin compensation, :868-877
     for (int k = 0; k < 3; k++) {
@@ -1009,8 +1267,8 @@ extern "C" {
 
 #ifdef LSCSFC_DEBUG
 int lscsfc_dbg_read(unsigned long long* out, int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lscsfc::sfc_dbg), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lscsfc::sfc_dbg), z, sizeof z); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lscsfc::sfc_dbg), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(lscsfc::sfc_dbg), z, sizeof z); }
     return 0;
 }
 #endif

@@ -17,6 +17,10 @@
 #ifndef LSCSFC_TP_CELL
 #define LSCSFC_TP_CELL 512
 #endif
+#ifndef LSCSFC_TP_AHEAD
+#define LSCSFC_TP_AHEAD 126  // (two wavefronts assemble the look-ahead; with 254 the tables no longer leave room for four workgroups per CU)
+#endif
+#define LSCSFC_AHEAD LSCSFC_TP_AHEAD
 #define LSCSFC_THREADS LSCSFC_TP_THREADS
 #define LSCSFC_WAVES_PER_EU 4
 #define LSCSFC_TODO LSCSFC_TP_TODO

@@ -20,7 +20,7 @@ plan = api.Plan(sol, wmap, N, min(N - 1, sol.max_obstacles()), ag, constraint_mo
 router = closed_loop.GridRouter(W, wmap.download()[0], wmap.key0)
 starts, desired = np.array(W["starts"], dtype=np.float64), np.array(W["goals"], dtype=np.float64)
 plan.reset(starts); way = starts.copy()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 for k in range(30):
     state = plan.get(api.PLAN_STATE).reshape(N, 9)
     for i in range(N):
