@@ -232,9 +232,10 @@ struct BoxF {
 
 // true: none of the map cells [x0, x1] x [y0, y1] x [z0, z1] (inside the map) can make a test fail (lscqp_map_prepare's table)
 __device__ __forceinline__ bool cells_free(const MapView& mp, int x0, int x1, int y0, int y1, int z0, int z1) {
-    const int64_t sy = mp.dims(0), sz = (int64_t)mp.dims(0) * mp.dims(1);
+    // (32-bit index arithmetic: lscqp_map_prepare refuses maps of more than 2^31 - 1 cells)
+    const uint32_t sy = (uint32_t)mp.dims(0), sz = (uint32_t)mp.dims(0) * (uint32_t)mp.dims(1);
     auto at = [&](int x, int y, int z) -> int64_t {  // prefix sum up to (x, y, z) inclusive; -1 on any axis: empty
-        return (x < 0 || y < 0 || z < 0) ? 0 : (int64_t)mp.sat[x + y * sy + z * sz];
+        return (x < 0 || y < 0 || z < 0) ? 0 : (int64_t)mp.sat[(uint32_t)x + (uint32_t)y * sy + (uint32_t)z * sz];
     };
     const int xa = x0 - 1, ya = y0 - 1, za = z0 - 1;
     const int64_t cnt = at(x1, y1, z1) - at(xa, y1, z1) - at(x1, ya, z1) - at(x1, y1, za) + at(xa, ya, z1) + at(xa, y1, za) + at(x1, ya, za) - at(xa, ya, za);
@@ -466,7 +467,8 @@ __device__ unsigned long long sfc_dbg[32];
 #define LSCSFC_GROUP 4
 #endif
 #ifndef LSCSFC_AHEAD
-#define LSCSFC_AHEAD 254  // boxes of a batch's look-ahead (lane j of the first ceil(AHEAD / 64) wavefronts assembles box j; growth counts are bytes: <= 254)
+#define LSCSFC_AHEAD 126  // tests of a batch's look-ahead (lane j of the first ceil(AHEAD / 64) wavefronts assembles box j; growth counts are bytes: <= 254).
+                          // Measured on the 3-D chain of bench.py (64 agents, a room with 24 boxes): 63 / 126 / 190 / 254 -> 432 / 400 / 404 / 413 us per replan
 #endif
 #ifndef LSCSFC_SAMPLED
 #define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing); <= 63

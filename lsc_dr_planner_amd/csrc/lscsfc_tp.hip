@@ -18,7 +18,7 @@
 #define LSCSFC_TP_CELL 512
 #endif
 #ifndef LSCSFC_TP_AHEAD
-#define LSCSFC_TP_AHEAD 126  // (two wavefronts assemble the look-ahead; with 254 the tables no longer leave room for four workgroups per CU)
+#define LSCSFC_TP_AHEAD 126  // (two wavefronts assemble the look-ahead; with 254 the tables would no longer leave room for four workgroups per CU)
 #endif
 #define LSCSFC_AHEAD LSCSFC_TP_AHEAD
 #define LSCSFC_THREADS LSCSFC_TP_THREADS
