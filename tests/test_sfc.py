@@ -374,3 +374,62 @@ def test_gpu_chain_world_to_trajectory_reproduces_reference_log(api, oracle):
         assert np.allclose(vel, st["v"][:2], rtol=1e-4, atol=2e-6)
         assert np.allclose(acc, st["a"][:2], rtol=3e-4, atol=2e-5)
     gmap.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["latency", "throughput"])
+@pytest.mark.parametrize("world", ["closet", "empty_room", "one_pillar", "long_hall"])
+def test_gpu_corridor_look_ahead_special_paths(api, oracle, world, variant, monkeypatch):
+    """The look-ahead of the corridor kernel continues behind tests the world boundary fails (a list of segments, one inner loop of the
+    reference each) and ends a batch only at an obstacle or at its limits.  Worlds chosen for its corner cases, bit for bit against the
+    oracle, with and without the free-space table:
+      closet      1.2 x 1.0 x 0.8 m, no obstacle: all six directions fail on the boundary inside ONE batch (the expansion ends in it);
+      empty_room  6 x 5 x 3 m, no obstacle: > 126 tests, every failure a boundary failure, face coordinates crossing 0 and binades;
+      one_pillar  the same room with one box: obstacle failures between boundary failures;
+      long_hall   110 m at 0.1 m = 1100 cells along x: beyond the cell-centre table, every test is decided on its own (sequentially)."""
+    import torch
+
+    monkeypatch.setenv("LSCSFC_VARIANT", variant)
+    rng = np.random.default_rng(23)
+    none = np.zeros((0, 6))
+    if world == "closet":
+        wmin, wmax, boxes, n = np.array([-0.6, -0.35, 0.0]), np.array([0.6, 0.65, 0.8]), none, 12
+    elif world == "empty_room":
+        wmin, wmax, boxes, n = np.array([-3.0, -2.2, 0.0]), np.array([3.0, 2.8, 3.0]), none, 24
+    elif world == "one_pillar":
+        wmin, wmax, boxes, n = np.array([-3.0, -2.2, 0.0]), np.array([3.0, 2.8, 3.0]), np.array([[0.6, 0.4, 1.5, 0.5, 0.5, 3.0]]), 32
+    else:
+        wmin, wmax, boxes, n = np.array([-55.0, -1.0, 0.0]), np.array([55.0, 1.0, 1.0]), np.array([[10.0, 0.5, 0.5, 0.4, 0.4, 1.0], [-20.0, -0.5, 0.5, 0.4, 0.4, 1.0]]), 6
+    M = 5
+    starts = np.float32(rng.uniform(wmin + 0.25, wmax - 0.25, (n, 3))).astype(np.float64)
+    radius = np.full(n, 0.15)
+    omap = oracle.Map(boxes, wmin, wmax, 0.1, 1.0)
+    want = np.zeros((n, M), oracle.BOX_DTYPE)
+    st_w = omap.construct_sfc(oracle.SFC_INIT, _pts(starts), radius, want)
+    assert st_w.sum() >= n // 2
+    direction = rng.normal(size=(n, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    P2 = _pts(np.float32(starts + 0.1 * direction).astype(np.float64), np.float32(starts + 0.3 * direction).astype(np.float64),
+              np.float32(starts + 0.2 * direction).astype(np.float64))
+    base = want.copy()
+    base[st_w != 1] = base[np.nonzero(st_w == 1)[0][0]]
+    want2 = base.copy()
+    st_w2 = omap.construct_sfc(oracle.SFC_FROM_HULL, P2, radius, want2)
+    sol = api.Solver(api.make_desc(M=M, dim=3, world_min=wmin, world_max=wmax))
+    dev = torch.device("cuda", 0)
+    d_r = torch.from_numpy(radius).to(dev)
+    for prepared in (0.0, 0.15):
+        gmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+        if prepared > 0:
+            gmap.prepare(prepared)
+        for mode, P, start, exp, exp_st in ((api.SFC_INIT, _pts(starts), np.zeros((n, M), api.BOX_DTYPE), want, st_w), (api.SFC_FROM_HULL, P2, base, want2, st_w2)):
+            d_sfc = torch.from_numpy(start.view(np.float64).reshape(-1).copy()).to(dev)
+            d_st = torch.full((n,), -7, dtype=torch.int32, device=dev)
+            sol.construct_sfc_device(gmap, mode, n, torch.from_numpy(np.ascontiguousarray(P).reshape(-1).copy()).to(dev), d_r, d_sfc, d_st)
+            torch.cuda.synchronize()
+            got, st_g = d_sfc.cpu().numpy().view(api.BOX_DTYPE).reshape(n, M), d_st.cpu().numpy()
+            assert np.array_equal(st_g, exp_st), (world, prepared, mode)
+            ok = exp_st == 1
+            sel = ok if mode == api.SFC_INIT else np.ones(n, bool)
+            assert np.array_equal(got["bmin"][sel], exp["bmin"][sel]) and np.array_equal(got["bmax"][sel], exp["bmax"][sel]), (world, prepared, mode)
+        gmap.close()
