@@ -7,7 +7,7 @@
 // LSC rows (oi, M-1, n) of every obstacle (:140-155; normals shorter than SP_EPSILON_FLOAT skipped), and the goal is
 // (g - w) t* + w (:55).  A one-variable LP needs no solver: every row a_r t + c_r >= 0 is a lower bound on t (a_r > 0),
 // an upper bound (a_r < 0) or a feasibility condition (a_r = 0); t* is the largest lower bound.
-// One lane per agent; the rows are read where the QP's ABI keeps them (packed: n.c >= b, b = d + n.p).
+// One wavefront per agent; the rows are read where the QP's ABI keeps them (packed: n.c >= b, b = d + n.p).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -17,14 +17,18 @@
 
 namespace lscgoal {
 
-constexpr int kThreads = 64;
+constexpr int kThreads = 256;  // four agents per workgroup
 constexpr double kEpsFloat = 1e-5;  // SP_EPSILON_FLOAT (reference include/sp_const.hpp)
 constexpr double kFeasTol = 1e-9;   // slack allowed on a_r = 0 rows and on L <= U (CPLEX's own LP tolerance is 1e-6)
 
+// One WAVEFRONT per agent, a lane per row (round 3; a lane per agent walked its rows one dependent load after the other: 15 us for 20
+// neighbours).  Every row is a bound of its own and the LP's value is a maximum of lower bounds against a minimum of upper ones --
+// order-independent, so the result is the sequential one bit for bit.
 __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
                                                         const lscqp_box* __restrict__ sfc, int32_t* __restrict__ status) {
-    const int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (q >= n) return;
     lscqp_header* H = hdr + q;
     double g[3], w[3], dgw[3];
@@ -36,8 +40,8 @@ __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_
         dist2 += dgw[k] * dgw[k];
     }
     if (sqrt(dist2) < kEpsFloat) {  // :12-14
-        for (int k = 0; k < 3; k++) H->goal[k] = w[k];
-        status[q] = LSCQP_STATUS_OPTIMAL;
+        if (lane < 3) H->goal[lane] = lane == 0 ? w[0] : (lane == 1 ? w[1] : w[2]);
+        if (lane == 0) status[q] = LSCQP_STATUS_OPTIMAL;
         return;
     }
     double lo = 0.0, hi = 1.0 + kEpsFloat;  // variable bounds (:112)
@@ -50,39 +54,52 @@ __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_
         else
             bad = bad || (c < -kFeasTol);
     };
-    if (use_sfc) {  // faces of the last segment's box: +e_k . c - bmin_k >= 0, -e_k . c + bmax_k >= 0
-        const lscqp_box* B = sfc + q * M + (M - 1);
-        for (int k = 0; k < dim; k++) {
-            row(dgw[k], w[k] - B->bmin[k]);
-            row(-dgw[k], B->bmax[k] - w[k]);
-        }
-    }
     const int n_obs = H->n_obs;
     const uint64_t roff = n_obs > 0 ? row_offsets[q] : 0;
-    for (int o = 0; o < n_obs; o++) {
+    const int n_faces = use_sfc ? 2 * dim : 0;
+    for (int r = lane; r < n_faces + n_obs; r += 64) {
+        if (r < n_faces) {  // faces of the last segment's box: +e_k . c - bmin_k >= 0, -e_k . c + bmax_k >= 0
+            const lscqp_box* B = sfc + q * M + (M - 1);
+            const int k = r >> 1;
+            const double dk = k == 0 ? dgw[0] : (k == 1 ? dgw[1] : dgw[2]), wk = k == 0 ? w[0] : (k == 1 ? w[1] : w[2]);
+            if ((r & 1) == 0)
+                row(dk, wk - B->bmin[k]);
+            else
+                row(-dk, B->bmax[k] - wk);
+            continue;
+        }
+        const int o = r - n_faces;
         const size_t ri = roff + ((size_t)o * M + (M - 1)) * 6 + 5;  // getLSC(oi, M-1, n)
-        lscqp_row r;
+        lscqp_row rw;
         if (rows_f32) {
             const lscqp_row_f32 f = reinterpret_cast<const lscqp_row_f32*>(rows)[ri];
-            r = lscqp_row{(double)f.nx, (double)f.ny, (double)f.nz, (double)f.b};
+            rw = lscqp_row{(double)f.nx, (double)f.ny, (double)f.nz, (double)f.b};
         } else {
-            r = rows[ri];
+            rw = rows[ri];
         }
-        if (sqrt(r.nx * r.nx + r.ny * r.ny + r.nz * r.nz) < kEpsFloat) continue;  // :142-144
-        double a = r.nx * dgw[0] + r.ny * dgw[1], c = r.nx * w[0] + r.ny * w[1];
+        if (sqrt(rw.nx * rw.nx + rw.ny * rw.ny + rw.nz * rw.nz) < kEpsFloat) continue;  // :142-144
+        double a = rw.nx * dgw[0] + rw.ny * dgw[1], c = rw.nx * w[0] + rw.ny * w[1];
         if (dim == 3) {
-            a += r.nz * dgw[2];
-            c += r.nz * w[2];
+            a += rw.nz * dgw[2];
+            c += rw.nz * w[2];
         }
-        row(a, c - r.b);
+        row(a, c - rw.b);
     }
+    for (int d = 32; d >= 1; d >>= 1) {  // (no NaN can arise: a != 0 on the paths that divide)
+        lo = fmax(lo, __shfl_xor(lo, d));
+        hi = fmin(hi, __shfl_xor(hi, d));
+    }
+    bad = __builtin_amdgcn_ballot_w64(bad) != 0;
     if (bad || lo > hi + kFeasTol) {  // reference: CPLEX reports infeasible -> throw PlanningReport::QPFAILED (:57-69)
-        status[q] = LSCQP_STATUS_INFEASIBLE;
+        if (lane == 0) status[q] = LSCQP_STATUS_INFEASIBLE;
         return;
     }
     const double t = fmin(lo, hi);
-    for (int k = 0; k < 3; k++) H->goal[k] = dgw[k] * t + w[k];
-    status[q] = LSCQP_STATUS_OPTIMAL;
+    {
+        const double dl = lane == 0 ? dgw[0] : (lane == 1 ? dgw[1] : dgw[2]), wl = lane == 0 ? w[0] : (lane == 1 ? w[1] : w[2]);
+        if (lane < 3) H->goal[lane] = dl * t + wl;
+    }
+    if (lane == 0) status[q] = LSCQP_STATUS_OPTIMAL;
 }
 
 }  // namespace lscgoal
@@ -92,7 +109,8 @@ extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream) {
     if (n == 0) return LSCQP_OK;
-    const unsigned blocks = (unsigned)((n + lscgoal::kThreads - 1) / lscgoal::kThreads);
+    const int64_t per = lscgoal::kThreads / 64;
+    const unsigned blocks = (unsigned)((n + per - 1) / per);
     hipLaunchKernelGGL(lscgoal::goal_kernel, dim3(blocks), dim3(lscgoal::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, rows_f32, n, d_hdr, d_rows,
                        d_row_offsets, d_sfc, d_status);
     const hipError_t e = hipGetLastError();
