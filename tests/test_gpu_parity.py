@@ -554,7 +554,7 @@ def test_log_pipeline_cases_on_the_gpu(api, oracle, torch_cuda):
         assert np.abs(o["x"] - G["x"][q]).max() <= X_TOL
 
 
-@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (7, 3), (10, 2), (10, 3), (5, 2), (8, 2)])
+@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (7, 3), (10, 2), (10, 3), (5, 2), (8, 2), (8, 3), (9, 3)])
 def test_dynamic_limits_bind_on_every_axis_and_in_every_segment(api, oracle, torch_cuda, request, M, dim):
     """A long hop under tight, per-axis different acceleration limits (and, second case, velocity limits): the optimum rides the
     limits on every axis, from the first segments (speeding up) to the last ones (braking) -- rows of src/traj_optimizer.cpp:448-471 far
@@ -600,7 +600,7 @@ def test_dynamic_limits_bind_on_every_axis_and_in_every_segment(api, oracle, tor
     assert ran >= 2
 
 
-@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (7, 3), (10, 2), (10, 3), (5, 2), (8, 2)])
+@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (7, 3), (10, 2), (10, 3), (5, 2), (8, 2), (8, 3), (9, 3)])
 def test_every_row_family_binds_somewhere_along_the_horizon(api, oracle, torch_cuda, request, M, dim):
     """Three more scenarios that make the optimum lean on rows all along the horizon (a strong terminal weight on every segment pulls
     the agent towards a goal it cannot reach): (a) under tight velocity / acceleration limits with the waypoint-range rows
@@ -703,7 +703,8 @@ def test_breakdown_under_one_elimination_order_is_repaired_on_the_other(api, ora
 
 
 @pytest.mark.parametrize("M,dim,n_obs,variant", [(5, 3, 20, ""), (5, 3, 48, ""), (6, 3, 20, ""), (10, 2, 9, ""), (10, 2, 40, ""), (10, 3, 40, ""), (7, 3, 12, ""),
-                                                (8, 2, 12, ""), (5, 3, 10, "dlsc"), (5, 2, 12, "dlsc"), (10, 2, 10, "dlsc"), (5, 3, 20, "rows_f32"),
+                                                (8, 2, 12, ""), (5, 3, 10, "dlsc"), (5, 2, 12, "dlsc"), (10, 2, 10, "dlsc"), (9, 3, 14, ""), (10, 3, 14, "dlsc"), (10, 3, 36, "dlsc"),
+                                                (9, 3, 14, "dlsc"), (8, 3, 14, "dlsc"), (5, 3, 20, "rows_f32"),
                                                 (10, 2, 9, "rows_f32"), (5, 3, 20, "mixed"), (10, 2, 9, "mixed")])
 def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, request, M, dim, n_obs, variant):
     """Index test of the LSC rows: one QP per obstacle slot, whose ONLY non-zero rows sit in that slot (segment oi mod M, all six
@@ -758,7 +759,7 @@ def test_one_binding_lsc_plane_per_obstacle_slot(api, oracle, torch_cuda, reques
     assert ran >= 1
 
 
-@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (10, 2), (10, 3), (7, 3), (5, 2)])
+@pytest.mark.parametrize("M,dim", [(5, 3), (6, 3), (10, 2), (10, 3), (7, 3), (5, 2), (8, 3), (9, 3)])
 def test_one_binding_corridor_face_per_segment_axis_and_side(api, oracle, torch_cuda, request, M, dim):
     """Index test of the corridor rows: one QP per (segment, axis, side) whose corridor is wide open except for that one face, placed
     across the way to the goal (src/traj_optimizer.cpp:372-397)."""
