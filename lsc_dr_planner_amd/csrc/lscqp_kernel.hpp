@@ -227,6 +227,14 @@ __device__ __forceinline__ bool pivot_ok(FT d) {
 // Nested-dissection instances: regions only SOME wavefronts of the workgroup execute are bracketed by s_nop 8 (wavefront 0 only) /
 // s_nop 9 (wavefront 1 only) / s_nop 10 (wavefronts 0 and 1) ... s_nop 11 (end), so that the count knows who runs what.
 #define LSCQP_MARK(k) asm volatile("s_nop " #k)
+// (the brackets of the wavefront-partial regions are fenced: without the fence the scheduler moved an end marker in FRONT of its
+// region's register-only arithmetic, and the count took wavefront 0's separator solve for everybody's)
+#define LSCQP_MARKP(k)                         \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        asm volatile("s_nop " #k);             \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
 #ifdef LSCQP_PHASE_TIMING
 __device__ unsigned long long lscqp_dbg_cycles[16];
 #define LSCQP_T(slot)                                                     \
@@ -285,7 +293,10 @@ struct Cfg {
     // columns, only the separator variables R can reach (NT1: (c3, c4) of segment MS and c5 of segments MS .. M-1), in the same
     // order with the unreachable ones left out -- that is what lets the end-stop-free 3-D classes (nz = 90, 81, 72) and unequal
     // blocks fit 64 lanes.
-    static constexpr int NT1 = 2 * DIM + DIM * (M - MS);
+    // (only where R | S does not fit: M = 10 without the end stop, 30 + 36 lanes.  Everywhere else wavefront 1 keeps one accumulator per
+    // separator variable -- compacting moved its columns to other registers and cost the round-2 instances 1.5 %)
+    static constexpr bool ND_COMPACT = NB1 + NS > 64;
+    static constexpr int NT1 = ND_COMPACT ? 2 * DIM + DIM * (M - MS) : NS;
     static constexpr int NR0 = NB0 + NS, NR1 = NB1 + NT1;
     static constexpr bool ND_FITS = NR0 <= 64 && NR1 <= 64 && MS >= 1 && MLAST > MS;
     // ... and wherever two wavefronts per QP are used and the two blocks come out equal (M = 6, 10): M = 10 in 2-D 56 dense pivots
@@ -297,8 +308,8 @@ struct Cfg {
     static constexpr int nd_nb(int w) { return w == 0 ? NB0 : NB1; }
     static constexpr int nd_nr(int w) { return w == 0 ? NR0 : NR1; }
     // separator variable <-> its position among wavefront 1's accumulators
-    static constexpr int nd_unrank1(int r) { return r < 2 * DIM ? r : r + MS * DIM; }
-    static constexpr int nd_rank1(int sc) { return sc < 2 * DIM ? sc : sc - MS * DIM; }
+    static constexpr int nd_unrank1(int r) { return (!ND_COMPACT || r < 2 * DIM) ? r : r + MS * DIM; }
+    static constexpr int nd_rank1(int sc) { return (!ND_COMPACT || sc < 2 * DIM) ? sc : sc - MS * DIM; }
     // local column of separator variable sc in wavefront w's rows
     static constexpr int nd_col(int w, int sc) { return w == 0 ? NB0 + sc : NB1 + nd_rank1(sc); }
     // z index (axis-major: k * NZA + a) of variable (axis k, segment m, j): j = 0, 1, 2 <-> c3, c4, c5; the last segment under the
@@ -1370,7 +1381,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     const bool acc = (wv_ == 1) && t_ >= C::NB1 && t_ < C::NR1;  // accumulator lane
                     const bool rowl = (wv_ == 0 && t_ < C::NR0) || (wv_ == 1 && t_ < C::NB1);
                     // (the lane of separator variable s in wavefront 0 is NB0 + s, and that is its slot)
-                    const int sacc = C::NB0 + (acc ? ((t_ - C::NB1) < 2 * DIM ? (t_ - C::NB1) : (t_ - C::NB1) + C::MS * DIM) : 0);
+                    const int sacc = C::NB0 + (acc ? ((!C::ND_COMPACT || (t_ - C::NB1) < 2 * DIM) ? (t_ - C::NB1) : (t_ - C::NB1) + C::MS * DIM) : 0);
                     const FT* const src = &Hs[(acc ? sacc : (rowl ? ZR.slot : NZ)) * LDH];
                     if (wv_ == 0) {
                         static_for<0, C::NAR>([&](auto Cc) {
@@ -1569,21 +1580,21 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     });
                 };
                 if (wv == 0) {
-                    LSCQP_MARK(8);
+                    LSCQP_MARKP(8);
                     block_phase(std::integral_constant<int, 0>{});
-                    LSCQP_MARK(11);
+                    LSCQP_MARKP(11);
                 }
                 if (wv == 1) {
-                    LSCQP_MARK(9);
+                    LSCQP_MARKP(9);
                     block_phase(std::integral_constant<int, 1>{});
-                    LSCQP_MARK(11);
+                    LSCQP_MARKP(11);
                 }
                 LSCQP_T(14);  // (development timing: the block phase of the nested dissection)
                 {   // hand-over of wavefront 1's share (single predicated stores; everything else is masked arithmetically)
                     // Sx[s][c], s and c separator variables wavefront 1 reaches; the other rows / columns are never written
                     const bool give = (wv == 1) && lf >= NB1 && lf < NR1;
                     const int r1 = give ? lf - NB1 : 0;
-                    const int srow1 = r1 < 2 * DIM ? r1 : r1 + C::MS * DIM;  // Cfg::nd_unrank1
+                    const int srow1 = (!C::ND_COMPACT || r1 < 2 * DIM) ? r1 : r1 + C::MS * DIM;  // Cfg::nd_unrank1
                     static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
                         if constexpr (C::nd_touched(1, c)) {
@@ -1594,18 +1605,26 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                     __syncthreads();
                     const bool sep0 = (wv == 0) && lf >= NB0 && lf < NR0;
                     const int srow0 = sep0 ? lf - NB0 : 0;
-                    const bool take = sep0 && (srow0 < 2 * DIM || srow0 >= 2 * DIM + C::MS * DIM);  // Cfg::nd_touched(1, srow0)
-                    const double* const sxr = Sx + (take ? srow0 : 0) * NS;
-                    static_for<0, NS>([&](auto Cc) {
-                        constexpr int c = decltype(Cc)::value;
-                        if constexpr (C::nd_touched(1, c)) {
-                            const double v = sxr[c];
-                            A[NB0 + c] += take ? v : 0.0;
-                        }
-                    });
+                    if constexpr (C::ND_COMPACT) {  // (rows of separator variables wavefront 1 cannot reach were not written)
+                        const bool take = sep0 && (srow0 < 2 * DIM || srow0 >= 2 * DIM + C::MS * DIM);  // Cfg::nd_touched(1, srow0)
+                        const double* const sxr = Sx + (take ? srow0 : 0) * NS;
+                        static_for<0, NS>([&](auto Cc) {
+                            constexpr int c = decltype(Cc)::value;
+                            if constexpr (C::nd_touched(1, c)) {
+                                const double v = sxr[c];
+                                A[NB0 + c] += take ? v : 0.0;
+                            }
+                        });
+                    } else {  // (... hold zeros there)
+                        const double take = sep0 ? 1.0 : 0.0;
+                        static_for<0, NS>([&](auto Cc) {
+                            constexpr int c = decltype(Cc)::value;
+                            if constexpr (C::nd_touched(1, c)) A[NB0 + c] = fma(take, Sx[srow0 * NS + c], A[NB0 + c]);
+                        });
+                    }
                 }
                 if (wv == 0) {  // the separator: dense LDL^T on columns / lanes NB0 .. NR0-1
-                    LSCQP_MARK(8);
+                    LSCQP_MARKP(8);
                     constexpr int NB = NB0, NA = NR0;
                     colw[lf] = A[NB];
                     double d = bcast(A[NB], NB);
@@ -1650,7 +1669,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         asm volatile("" ::: "memory");
                     });
                     if (lf == 0) flag[0] = (pivot_bad || flag[0] != 0.0) ? 1.0 : 0.0;
-                    LSCQP_MARK(11);
+                    LSCQP_MARKP(11);
                 }
                 __syncthreads();
                 pivot_bad = (flag[0] != 0.0) || (flag[1] != 0.0);
@@ -1704,7 +1723,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 const int srow0 = sep0 ? ll_ - NB0 : 0;
                 const bool acc1 = ll_ >= NB1 && ll_ < NR1;   // accumulator lanes of wavefront 1
                 const int r1 = acc1 ? ll_ - NB1 : 0;
-                const int srow1 = r1 < 2 * DIM ? r1 : r1 + C::MS * DIM;  // Cfg::nd_unrank1
+                const int srow1 = (!C::ND_COMPACT || r1 < 2 * DIM) ? r1 : r1 + C::MS * DIM;  // Cfg::nd_unrank1
                 auto block_forward = [&](auto Nc) {
                     static_for<0, decltype(Nc)::value>([&](auto Jc) {
                         constexpr int j = decltype(Jc)::value;
@@ -1721,25 +1740,36 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);
                     });
                 };
-                // ---- forward through the blocks: L w = b (unit lower) ----
-                if (wv == 0) {
-                    LSCQP_MARK(8);
-                    block_forward(std::integral_constant<int, NB0>{});
-                    LSCQP_MARK(11);
-                }
-                if (wv == 1) {
-                    LSCQP_MARK(9);
-                    block_forward(std::integral_constant<int, NB1>{});
-                    LSCQP_MARK(11);
+                // ---- forward through the blocks: L w = b (unit lower) ----  (equal blocks: one copy of the code for both wavefronts --
+                // the loop bodies of the M = 10 instances are larger than the instruction cache as it is)
+                if constexpr (NB0 == NB1) {
+                    if (wv < 2) {
+                        LSCQP_MARKP(10);
+                        block_forward(std::integral_constant<int, NB0>{});
+                        LSCQP_MARKP(11);
+                    }
+                } else {
+                    if (wv == 0) {
+                        LSCQP_MARKP(8);
+                        block_forward(std::integral_constant<int, NB0>{});
+                        LSCQP_MARKP(11);
+                    }
+                    if (wv == 1) {
+                        LSCQP_MARKP(9);
+                        block_forward(std::integral_constant<int, NB1>{});
+                        LSCQP_MARKP(11);
+                    }
                 }
                 if (wv == 1 && acc1) hand[srow1] = b;  // accumulator rows started from 0: their value IS wavefront 1's share
                 __syncthreads();
                 if (wv == 0) {
-                    LSCQP_MARK(8);
-                    {
+                    LSCQP_MARKP(8);
+                    if constexpr (C::ND_COMPACT) {
                         const bool take = sep0 && (srow0 < 2 * DIM || srow0 >= 2 * DIM + C::MS * DIM);  // Cfg::nd_touched(1, srow0)
                         const double v = hand[take ? srow0 : 0];
                         b += take ? v : 0.0;
+                    } else {
+                        b += sep0 ? hand[srow0] : 0.0;
                     }
                     static_for<NB0, NR0>([&](auto Jc) {  // forward through the separator
                         constexpr int j = decltype(Jc)::value;
@@ -1753,24 +1783,30 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         const double xj = bcast(b * dinv_own, j);
                         b = fma(-((ll_ < j) ? A[j] : 0.0), xj, b);  // (the block rows of wavefront 0 take their separator part here)
                     });
-                    LSCQP_MARK(11);
+                    LSCQP_MARKP(11);
                 }
                 // (same wavefront, LDS in program order: the shares were read above before the buffer is overwritten here)
                 if (wv == 0 && sep0) hand[srow0] = b * dinv_own;  // the separator's solution
                 __syncthreads();
                 if (wv == 1) {  // block rows of wavefront 1: U[i][S] x_S
-                    LSCQP_MARK(9);
+                    LSCQP_MARKP(9);
                     static_for<0, NS>([&](auto Cc) {
                         constexpr int c = decltype(Cc)::value;
                         if constexpr (C::nd_touched(1, c)) b = fma(-A[C::nd_col(1, c)], hand[c], b);  // (accumulator lanes compute a value nobody uses)
                     });
-                    block_backward(std::integral_constant<int, NB1>{});
-                    LSCQP_MARK(11);
+                    if constexpr (NB0 != NB1) block_backward(std::integral_constant<int, NB1>{});
+                    LSCQP_MARKP(11);
                 }
-                if (wv == 0) {
-                    LSCQP_MARK(8);
+                if constexpr (NB0 == NB1) {
+                    if (wv < 2) {
+                        LSCQP_MARKP(10);
+                        block_backward(std::integral_constant<int, NB0>{});
+                        LSCQP_MARKP(11);
+                    }
+                } else if (wv == 0) {
+                    LSCQP_MARKP(8);
                     block_backward(std::integral_constant<int, NB0>{});
-                    LSCQP_MARK(11);
+                    LSCQP_MARKP(11);
                 }
                 return b * dinv_own;  // (final once the lane's own column has been broadcast; 0 for lanes without a row)
             };

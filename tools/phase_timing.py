@@ -3,7 +3,7 @@ import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "lsc_dr_planner_amd", "csrc")
+SRC = os.environ.get("LSCQP_SRC", os.path.join(ROOT, "lsc_dr_planner_amd", "csrc"))
 OUT = "/tmp/liblscqp_prof.so"
 args = [a for a in sys.argv[1:] if not a.startswith("-")]
 xflags = [a for a in sys.argv[1:] if a.startswith("-D")]
