@@ -919,15 +919,19 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 const int K = kdiv(nc);
                 int b0 = is + 1;
                 b0 = b0 >= nc ? b0 - nc : b0;
+                // (a lane per candidate slot, then six v_readlane: as uniform scalar code the loop over the slots was a chain of ~200
+                // dependent instructions per segment, 6 k cycles per batch where the z directions leave a flat world at once)
+                const int sl = j & 63;
+                const int dsl = cand_of(cs, sl < 6 ? sl : 0);
+                int rsl = sl - b0;  // the first growth that takes candidate sl
+                rsl += rsl < 0 ? nc : 0;
+                const int gsl = (int)((gm >> (8 * dsl)) & 255ull) - (int)((cps >> (8 * dsl)) & 255ull);  // growths its direction has left
+                const int ufl = sl < nc ? rsl + gsl * nc : (1 << 20);
                 int ubest = 1 << 20;  // the first growth of this inner loop whose face leaves the world
 #pragma unroll
                 for (int sidx = 0; sidx < 6; sidx++) {
-                    const int d = cand_of(cs, sidx);
-                    int r = sidx - b0;
-                    r += r < 0 ? nc : 0;
-                    const int g = (int)((gm >> (8 * d)) & 255ull) - (int)((cps >> (8 * d)) & 255ull);  // growths direction d has left
-                    const int uf = r + g * nc;
-                    ubest = (sidx < nc && uf < ubest) ? uf : ubest;
+                    const int uf = __builtin_amdgcn_readlane(ufl, sidx);
+                    ubest = uf < ubest ? uf : ubest;
                 }
                 const int jend = j0 + ubest + 1 - t0;  // the test that fails: growth ubest makes the inner loop's test ubest + 1
                 const bool in_seg = j >= j0;            // (later segments overwrite)
@@ -936,7 +940,14 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 my_cp = in_seg ? cps : my_cp;
                 my_end = in_seg ? (j == jend) : my_end;
                 if (jend >= KA) break;  // no failure on the boundary within the look-ahead: the segment runs to its end
-                cps += growths_of(cs, nc, K, b0, ubest);  // ubest growths accepted, the pending one dropped,
+                {   // ubest growths accepted (the lane's slot: how many of them), the pending one dropped,
+                    const int cnt = (sl < nc && ubest > rsl) ? (((ubest - 1 - rsl) * K) >> 10) + 1 : 0;
+                    const unsigned long long part = (unsigned long long)cnt << (8 * dsl);
+                    const int plo = (int)(unsigned)part, phi = (int)(unsigned)(part >> 32);
+#pragma unroll
+                    for (int sidx = 0; sidx < 6; sidx++)
+                        cps += (unsigned long long)(unsigned)__builtin_amdgcn_readlane(plo, sidx) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(phi, sidx) << 32);
+                }
                 const int ifail = mod_of(is + ubest + 1, nc, K);
                 cs = erase_of(cs, ifail);                 // its direction erased
                 nc--;

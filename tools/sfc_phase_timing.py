@@ -32,4 +32,5 @@ for k in range(30):
     L.lscsfc_dbg_read(buf, 1)
     b = list(buf)
     if k % 5 == 0 or k < 3:
-        print("replan", k, "per agent: batches %.1f boxes %.1f col-chunks %.1f alone %.1f test-cycles %.0f kernel-cycles %.0f (exp calls %.1f)" % tuple(v / N for v in b[:7]), "| fill %.0f rounds-cyc %.0f gen %.0f replay %.0f nrounds %.1f" % tuple(b[i] / N for i in (7, 8, 9, 10, 11)))
+        print("replan", k, "per agent: batches %.1f boxes %.1f col-chunks %.1f alone %.1f test-cycles %.0f kernel-cycles %.0f (exp calls %.1f)" % tuple(v / N for v in b[:7]), "| fill %.0f rounds-cyc %.0f gen %.0f replay %.0f nrounds %.1f" % tuple(b[i] / N for i in (7, 8, 9, 10, 11)),
+              "| filter: chunks %.0f todo %.0f n %.1f nofilter-chunks %.0f | batch ends: boundary %.2f obstacle %.2f limit %.2f passes %.1f end %.2f | gen cumulative: tables %.0f segs %.0f box %.0f free %.0f A-done %.0f | filter-cyc %.0f / both %.0f" % tuple(b[i] / N for i in (12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 31)))
