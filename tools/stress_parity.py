@@ -21,8 +21,11 @@ if "--gen" in sys.argv:
     GEN = int(sys.argv[sys.argv.index("--gen") + 1])
 WARM = "--warm" in sys.argv  # hand the initial trajectory (shifted previous plan) to the solver as primal start
 TIGHT = "--tight" in sys.argv  # lscqp_class_desc.warm_start = LSCQP_WARM_TIGHT
+DLSC = "--dlsc" in sys.argv  # planner mode DLSC (no end stop) instead of LSC
 shapes = [(48, 5, 3, 20, "forest"), (32, 6, 3, 20, "maze"), (16, 10, 2, 9, "forest"), (24, 7, 3, 12, "maze"), (32, 4, 3, 12, "forest"),
           (24, 10, 3, 40, "forest"), (40, 5, 2, 12, "forest"), (24, 8, 2, 12, "maze")]
+if "--nd" in sys.argv:  # the shapes of round 3's nested-dissection instances (M = 8, 9, 10 in 3-D; with --dlsc the end-stop-free classes)
+    shapes = [(24, 10, 3, 14, "forest"), (24, 10, 3, 36, "forest"), (24, 9, 3, 14, "forest"), (24, 9, 3, 40, "maze"), (24, 8, 3, 14, "maze"), (24, 8, 3, 32, "forest")]
 if "--shape" in sys.argv:
     shapes = [shapes[int(sys.argv[sys.argv.index("--shape") + 1])]]
 bad_total = 0
@@ -32,8 +35,9 @@ for (N, M, dim, n_obs, style) in shapes:
     nbad = n_both_bad = 0
     for seed in range(100, 100 + n_seeds):
         sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
-        cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
-        sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, warm_start=api.WARM_TIGHT if TIGHT else api.WARM_DEFAULT))
+        cls = O.make_class(M=M, dim=dim, use_sfc=True, planner_lsc=not DLSC, world_min=sw.world_min, world_max=sw.world_max)
+        sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=api.PLANNER_DLSC if DLSC else api.PLANNER_LSC, world_min=sw.world_min, world_max=sw.world_max,
+                                       warm_start=api.WARM_TIGHT if TIGHT else api.WARM_DEFAULT))
         for step in range(3):
             b = sw.build()
             hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
