@@ -24,7 +24,9 @@ constexpr double kFeasTol = 1e-9;   // slack allowed on a_r = 0 rows and on L <=
 // One WAVEFRONT per agent, a lane per row (round 3; a lane per agent walked its rows one dependent load after the other: 15 us for 20
 // neighbours).  Every row is a bound of its own and the LP's value is a maximum of lower bounds against a minimum of upper ones --
 // order-independent, so the result is the sequential one bit for bit.
-__global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* __restrict__ hdr,
+// fin_dt > 0 (lscqp_plan's chain): the agent's header is finished here as well -- the goal held as a point3d (float32) and
+// terminal_segments from it, what lscplan.hip's finalize_goal_kernel does when the goal LP is off (one graph node less per replan).
+__global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_sfc, int rows_f32, double fin_dt, int64_t n, lscqp_header* __restrict__ hdr,
                                                         const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
                                                         const lscqp_box* __restrict__ sfc, int32_t* __restrict__ status) {
     const int64_t q = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
@@ -39,9 +41,23 @@ __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_
         dgw[k] = g[k] - w[k];
         dist2 += dgw[k] * dgw[k];
     }
+    // what the agent's header is left with: the new goal (the old one if the LP is infeasible) and the status
+    auto finish = [&](double g0, double g1, double g2, int st) {
+        if (fin_dt > 0.0) {  // agent.current_goal_point is a point3d; getTerminalSegments_old (src/traj_optimizer.cpp:530-538) in float32
+#pragma clang fp contract(off)
+            const float f0 = (float)g0, f1 = (float)g1, f2 = (float)g2;
+            g0 = (double)f0, g1 = (double)f1, g2 = (double)f2;
+            const float d0 = f0 - (float)H->p0[0], d1 = f1 - (float)H->p0[1], d2 = f2 - (float)H->p0[2];
+            const float nsq = d0 * d0 + d1 * d1 + d2 * d2;
+            const double ideal_flight_time = sqrt((double)nsq) / H->nominal_velocity;
+            const int ts = (int)((M * fin_dt - ideal_flight_time + 1e-9) / fin_dt);
+            if (lane == 0) H->terminal_segments = ts > 1 ? ts : 1;
+        }
+        if (lane < 3) H->goal[lane] = lane == 0 ? g0 : (lane == 1 ? g1 : g2);
+        if (lane == 0) status[q] = st;
+    };
     if (sqrt(dist2) < kEpsFloat) {  // :12-14
-        if (lane < 3) H->goal[lane] = lane == 0 ? w[0] : (lane == 1 ? w[1] : w[2]);
-        if (lane == 0) status[q] = LSCQP_STATUS_OPTIMAL;
+        finish(w[0], w[1], w[2], LSCQP_STATUS_OPTIMAL);
         return;
     }
     double lo = 0.0, hi = 1.0 + kEpsFloat;  // variable bounds (:112)
@@ -91,29 +107,30 @@ __global__ __launch_bounds__(kThreads) void goal_kernel(int M, int dim, int use_
     }
     bad = __builtin_amdgcn_ballot_w64(bad) != 0;
     if (bad || lo > hi + kFeasTol) {  // reference: CPLEX reports infeasible -> throw PlanningReport::QPFAILED (:57-69)
-        if (lane == 0) status[q] = LSCQP_STATUS_INFEASIBLE;
+        finish(g[0], g[1], g[2], LSCQP_STATUS_INFEASIBLE);
         return;
     }
     const double t = fmin(lo, hi);
-    {
-        const double dl = lane == 0 ? dgw[0] : (lane == 1 ? dgw[1] : dgw[2]), wl = lane == 0 ? w[0] : (lane == 1 ? w[1] : w[2]);
-        if (lane < 3) H->goal[lane] = dl * t + wl;
-    }
-    if (lane == 0) status[q] = LSCQP_STATUS_OPTIMAL;
+    finish(dgw[0] * t + w[0], dgw[1] * t + w[1], dgw[2] * t + w[2], LSCQP_STATUS_OPTIMAL);
 }
 
 }  // namespace lscgoal
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
 
-extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
-                               const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream) {
+extern "C" int lscqp_goal_fin_raw_(int M, int dim, int use_sfc, int rows_f32, double fin_dt, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                   const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream) {
     if (n == 0) return LSCQP_OK;
     const int64_t per = lscgoal::kThreads / 64;
     const unsigned blocks = (unsigned)((n + per - 1) / per);
-    hipLaunchKernelGGL(lscgoal::goal_kernel, dim3(blocks), dim3(lscgoal::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, rows_f32, n, d_hdr, d_rows,
+    hipLaunchKernelGGL(lscgoal::goal_kernel, dim3(blocks), dim3(lscgoal::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, rows_f32, fin_dt, n, d_hdr, d_rows,
                        d_row_offsets, d_sfc, d_status);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;
+}
+
+extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                               const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream) {
+    return lscqp_goal_fin_raw_(M, dim, use_sfc, rows_f32, 0.0, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status, stream);
 }

@@ -28,6 +28,8 @@ extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h);
 extern "C" uint64_t lscqp_handle_generation_(lscqp_handle h);
 extern "C" int lscqp_map_device_(lscqp_map mp);
+extern "C" int lscqp_optimize_goal_fin_device_(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows, const uint64_t* d_row_offsets,
+                                               const lscqp_box* d_sfc, int32_t* d_status_out, double fin_dt, void* stream);
 extern "C" uint64_t lscqp_map_generation_(lscqp_map mp);
 extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                                const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
@@ -65,7 +67,10 @@ __device__ __forceinline__ double const_vel_point(double p, double v, int idx, d
 // becomes "stays where it is".  For the local agents also: header, corridor seed points, and the INITIAL trajectory
 // (initialTrajPlanning :360-423, same three sources but never reset: AgentManager's is_disturbed stays false) in the generator's layout
 // (`own`) and in the solver's (`x_init`).  The initial trajectory is taken before the prediction overwrites the agent's entry of `traj`.
-__global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_replan, const double* __restrict__ state,
+// x_shift != NULL: the agent's entry of `traj` is first made from the previous plans -- lscqp_shift_traj's whole-segment shift
+// (lscgen.hip shift_traj_kernel: segment m := previous segment m + 1, the last one := the previous plan's last point, values rounded to
+// float32, z := z_2d in the plane), one graph node less per replan.
+__global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_replan, const double* __restrict__ x_shift, const double* __restrict__ state,
                                                             const double* __restrict__ waypoint, const double* __restrict__ goal,
                                                             double* traj, const lscqp_agent_param* __restrict__ par,
                                                             double* __restrict__ pos, lscqp_header* __restrict__ hdr,
@@ -78,6 +83,18 @@ __global__ __launch_bounds__(kThreads) void prepare_kernel(Shape s, int first_re
     const bool local = t >= 0 && t < s.n_agents;
     double* tr = traj + g * s.M * 18;
     const int P18 = s.M * 18;
+    if (x_shift != nullptr) {
+        const double* x = x_shift + g * s.dim * s.M * 6;
+        for (int e = lane; e < s.M * 6; e += kThreads) {
+            const int m = e / 6, i = e - 6 * m;
+            const int ms = (m + 1 < s.M) ? m + 1 : s.M - 1, is = (m + 1 < s.M) ? i : 5;
+            double* o = tr + e * 3;
+            o[0] = (double)(float)x[(0 * s.M + ms) * 6 + is];
+            o[1] = (double)(float)x[(1 * s.M + ms) * 6 + is];
+            o[2] = (s.dim == 3) ? (double)(float)x[(2 * s.M + ms) * 6 + is] : (double)(float)s.z_2d;
+        }
+        __syncthreads();  // (one wavefront per agent: its lanes read each other's entries below)
+    }
     if (local) {
         const bool prev = s.initial_traj_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION && !first_replan;
         const bool still = s.initial_traj_mode == LSCQP_TRAJ_FROM_POSITION;
@@ -258,12 +275,10 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     const double fraction = p->d.time_step / s.dt;
     // obstaclePredictionWithPrevSol / initialTrajPlanningPrevSol for every agent of the mission (:273-310, 399-423)
     const bool from_plans = !first_replan && (s.prediction_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION || s.initial_traj_mode == LSCQP_TRAJ_FROM_PREVIOUS_SOLUTION);
-    if (from_plans && fraction >= 1.0 - 1e-9)
-        PLAN_TRY(lscqp_shift_traj_device(h, s.n_total, 1, s.z_2d, x_plan, p->traj, stream));
-    else if (from_plans)
-        PLAN_TRY(lscqp_shift_traj_partial_device(h, s.n_total, fraction, s.z_2d, x_plan, p->traj, stream));
-    hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)s.n_total), dim3(lscplan::kThreads), 0, stream,
-                       s, first_replan ? 1 : 0, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init, p->own);
+    const bool whole_shift = from_plans && fraction >= 1.0 - 1e-9;  // (done by prepare_kernel itself)
+    if (from_plans && !whole_shift) PLAN_TRY(lscqp_shift_traj_partial_device(h, s.n_total, fraction, s.z_2d, x_plan, p->traj, stream));
+    hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)s.n_total), dim3(lscplan::kThreads), 0, stream, s, first_replan ? 1 : 0,
+                       whole_shift ? (const double*)x_plan : (const double*)nullptr, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init, p->own);
     if (p->map)
         PLAN_TRY(lscqp_construct_sfc_device(h, p->map, first_replan ? LSCQP_SFC_INIT : p->d.sfc_mode, s.n_agents, p->points,
                                             p->radius + s.first_agent, sfc, sfc_status, stream));
@@ -272,10 +287,12 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     if (s.n_obs > 0)
         PLAN_TRY(lscqp_generate_constraints_own_(h, p->d.constraint_mode, s.n_agents, s.n_obs, s.first_agent, p->traj, p->own, p->nbr, p->radius,
                                                  p->downwash, goal, rows, s.n_obs, 0, stream));
-    if (p->d.optimize_goal)
-        PLAN_TRY(lscqp_optimize_goal_device(h, s.n_agents, hdr, rows, p->off, p->map ? sfc : nullptr, goal_status, stream));
-    const unsigned nb = (unsigned)((s.n_agents + lscplan::kThreads - 1) / lscplan::kThreads);
-    hipLaunchKernelGGL(lscplan::finalize_goal_kernel, dim3(nb), dim3(lscplan::kThreads), 0, stream, s, hdr);
+    if (p->d.optimize_goal) {  // (the goal LP's kernel finishes the headers itself: one node less)
+        PLAN_TRY(lscqp_optimize_goal_fin_device_(h, s.n_agents, hdr, rows, p->off, p->map ? sfc : nullptr, goal_status, s.dt, stream));
+    } else {
+        const unsigned nb = (unsigned)((s.n_agents + lscplan::kThreads - 1) / lscplan::kThreads);
+        hipLaunchKernelGGL(lscplan::finalize_goal_kernel, dim3(nb), dim3(lscplan::kThreads), 0, stream, s, hdr);
+    }
     PLAN_TRY(lscqp_solve_batch_device_ex(p->hq, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj, status,
                                          info, 1, stream));
     const int64_t ne = s.n_agents * s.nv;

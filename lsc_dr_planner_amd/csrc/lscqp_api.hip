@@ -40,6 +40,8 @@ extern "C" int lscqp_generate_lsc_obstacles_raw_(int M, int dim, double dt, cons
                                                  int64_t first_agent, const double* d_traj, const int32_t* d_ids, const lscqp_obstacle* d_table,
                                                  const double* d_radius, const double* d_goal, const lscqp_header* d_hdr, int rows_f32,
                                                  int32_t n_obs_total, int32_t slot0, const double* d_binv3, lscqp_row* d_rows_out, void* stream);
+extern "C" int lscqp_goal_fin_raw_(int M, int dim, int use_sfc, int rows_f32, double fin_dt, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                   const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
 extern "C" int lscqp_goal_raw_(int M, int dim, int use_sfc, int rows_f32, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status, void* stream);
 extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
@@ -480,8 +482,15 @@ int64_t lscqp_generate_lsc_bytes(lscqp_handle h, int64_t n_agents, int32_t n_obs
            + n_agents * ((int64_t)n_obs * 4 + 24); /* neighbour ids, goal */
 }
 
+// (library-internal, lscplan.hip) the goal LP that also finishes the headers of the chain: goal as a point3d, terminal_segments (fin_dt = the class's dt)
+int lscqp_optimize_goal_fin_device_(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows, const uint64_t* d_row_offsets,
+                                    const lscqp_box* d_sfc, int32_t* d_status_out, double fin_dt, void* stream);
 int lscqp_optimize_goal_device(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows,
                                const uint64_t* d_row_offsets, const lscqp_box* d_sfc, int32_t* d_status_out, void* stream) {
+    return lscqp_optimize_goal_fin_device_(h, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status_out, 0.0, stream);
+}
+int lscqp_optimize_goal_fin_device_(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows, const uint64_t* d_row_offsets,
+                                    const lscqp_box* d_sfc, int32_t* d_status_out, double fin_dt, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -489,7 +498,7 @@ int lscqp_optimize_goal_device(lscqp_handle h, int64_t n, lscqp_header* d_hdr, c
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_goal_raw_(h->desc.M, h->desc.dim, h->desc.use_sfc, h->dev.rows_f32, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status_out, stream);
+    return lscqp_goal_fin_raw_(h->desc.M, h->desc.dim, h->desc.use_sfc, h->dev.rows_f32, fin_dt, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_status_out, stream);
 }
 
 int lscqp_optimize_goal(lscqp_handle h, int64_t n, lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
