@@ -28,6 +28,9 @@ extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" const lscqp_class_desc* lscqp_class_desc_of_(lscqp_handle h);
 extern "C" uint64_t lscqp_handle_generation_(lscqp_handle h);
 extern "C" int lscqp_map_device_(lscqp_map mp);
+extern "C" int lscqp_commit_validate_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const int32_t* d_qp_status,
+                                          const double* d_x_new, const double* d_x_init, double* d_x_plan, double* d_goal, const lscqp_header* d_hdr,
+                                          const lscqp_box* d_sfc, int32_t* d_valid, double* d_state, void* stream);
 extern "C" int lscqp_optimize_goal_fin_device_(lscqp_handle h, int64_t n, lscqp_header* d_hdr, const lscqp_row* d_rows, const uint64_t* d_row_offsets,
                                                const lscqp_box* d_sfc, int32_t* d_status_out, double fin_dt, void* stream);
 extern "C" uint64_t lscqp_map_generation_(lscqp_map mp);
@@ -177,19 +180,6 @@ __global__ __launch_bounds__(kThreads) void finalize_goal_kernel(Shape s, lscqp_
     H->terminal_segments = ts > 1 ? ts : 1;
 }
 
-// failsafe of trajOptimization (:796-797: a failed solve leaves desired_traj = initial_traj), prev_traj = desired_traj (:51),
-// and the goal point the planner carries into the next replan
-__global__ __launch_bounds__(kThreads) void commit_kernel(Shape s, const int32_t* __restrict__ status, const lscqp_header* __restrict__ hdr,
-                                                           const double* __restrict__ x_new, const double* __restrict__ x_init,
-                                                           double* __restrict__ x_plan, double* __restrict__ goal) {
-    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (e >= s.n_agents * s.nv) return;
-    const int64_t q = e / s.nv, j = e - q * s.nv;
-    const bool ok = status[q] == LSCQP_STATUS_OPTIMAL;
-    x_plan[(s.first_agent + q) * s.nv + j] = ok ? x_new[e] : x_init[e];
-    if (j < 3) goal[(s.first_agent + q) * 3 + j] = hdr[q].goal[j];
-}
-
 }  // namespace lscplan
 
 struct lscqp_plan_s {
@@ -295,11 +285,12 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     }
     PLAN_TRY(lscqp_solve_batch_device_ex(p->hq, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj, status,
                                          info, 1, stream));
-    const int64_t ne = s.n_agents * s.nv;
-    hipLaunchKernelGGL(lscplan::commit_kernel, dim3((unsigned)((ne + lscplan::kThreads - 1) / lscplan::kThreads)), dim3(lscplan::kThreads), 0, stream, s,
-                       status, hdr, p->x_new, p->x_init, x_plan, goal);
-    PLAN_TRY(lscqp_validate_step_device(h, s.n_agents, p->d.time_step, s.z_2d, x_plan + s.first_agent * s.nv, hdr, p->map ? sfc : nullptr, valid,
-                                        state_out, stream));
+    {   // commit (failsafe of trajOptimization, prev_traj = desired_traj, the goal point carried over) + isSolValid + doStep: one launch
+        const lscqp_class_desc* cd = lscqp_class_desc_of_(h);
+        if (cd->use_sfc && !p->map) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "the class has corridor rows but the plan has no map");
+        PLAN_TRY(lscqp_commit_validate_raw_(s.M, s.dim, cd->use_sfc, s.dt, s.n_agents, p->d.time_step, s.z_2d, status, p->x_new, p->x_init,
+                                            x_plan + s.first_agent * s.nv, goal + s.first_agent * 3, hdr, p->map ? sfc : nullptr, valid, state_out, stream));
+    }
     if (p->d.safety_samples > 0)  // MultiSyncSimulator::update's safety ratio / excess ratios over the step just planned (:486-577)
         PLAN_TRY(lscqp_safety_metrics_device(h, s.n_agents, s.first_agent, s.n_total, p->d.safety_samples, p->d.record_time_step, s.z_2d, x_plan,
                                              p->radius, p->downwash, hdr, (lscqp_safety*)p->buf[LSCQP_PLAN_BUF_SAFETY], stream));

@@ -41,15 +41,31 @@ __device__ __forceinline__ double bern(const double (&cp)[6], double t) {
 
 // one wavefront per agent: the lanes share the (segment, control point) pairs of the corridor test, lanes 0..2 evaluate one axis of the
 // state each (a lane per agent walked ~60 dependent loads: 19 us for 10 agents in the replan chain)
+// The replan chain (lscplan.hip) hands over its COMMIT as well (qp_status != NULL): desired_traj = the new plan where the QP is OPTIMAL, else
+// the initial trajectory (trajOptimization's failsafe, src/traj_planner.cpp:796-797), stored as the agent's plan for the next replan together
+// with the goal point the planner carries over -- and validated from where it came from, so that nothing is read back (one graph node less).
+struct Commit {
+    const int32_t* qp_status;  // NULL: validate `x` as it is
+    const double* x_new;       // [n][nv]
+    const double* x_init;      // [n][nv]
+    double* x_plan;            // [n][nv] the local agents' block of the mission's plans
+    double* goal;              // [n][3] ... of the goal points
+};
 __global__ __launch_bounds__(kThreads) void validate_step_kernel(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d,
                                                                  const double* __restrict__ x, const lscqp_header* __restrict__ hdr,
                                                                  const lscqp_box* __restrict__ sfc, int32_t* __restrict__ valid,
-                                                                 double* __restrict__ state) {
+                                                                 double* __restrict__ state, Commit cm) {
     const int64_t q = blockIdx.x;
     if (q >= n) return;
     const int lane = threadIdx.x;
     const int P = 6 * M;
     const double* xq = x + q * dim * P;
+    if (cm.qp_status != nullptr) {
+        const int nv = dim * P;
+        xq = (cm.qp_status[q] == LSCQP_STATUS_OPTIMAL ? cm.x_new : cm.x_init) + q * nv;
+        for (int j = lane; j < nv; j += kThreads) cm.x_plan[q * nv + j] = xq[j];
+        if (lane < 3) cm.goal[q * 3 + lane] = hdr[q].goal[lane];
+    }
     auto cp = [&](int k, int m, int i) -> double {  // desired_traj[m][i](k), float32
         return (k < dim) ? (double)(float)xq[k * P + 6 * m + i] : (double)(float)z_2d;
     };
@@ -281,7 +297,19 @@ extern "C" int lscqp_validate_step_raw_(int M, int dim, int use_sfc, double dt, 
                                         void* stream) {
     if (n == 0) return LSCQP_OK;
     hipLaunchKernelGGL(lscpost::validate_step_kernel, dim3((unsigned)n), dim3(lscpost::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, dt, n,
-                       time_step, z_2d, d_x, d_hdr, d_sfc, d_valid, d_state);
+                       time_step, z_2d, d_x, d_hdr, d_sfc, d_valid, d_state, lscpost::Commit{nullptr, nullptr, nullptr, nullptr, nullptr});
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
+
+// (library-internal, lscplan.hip) commit + isSolValid + doStep of the local agents in one launch; d_x_plan / d_goal: the local block
+extern "C" int lscqp_commit_validate_raw_(int M, int dim, int use_sfc, double dt, int64_t n, double time_step, double z_2d, const int32_t* d_qp_status,
+                                          const double* d_x_new, const double* d_x_init, double* d_x_plan, double* d_goal, const lscqp_header* d_hdr,
+                                          const lscqp_box* d_sfc, int32_t* d_valid, double* d_state, void* stream) {
+    if (n == 0) return LSCQP_OK;
+    hipLaunchKernelGGL(lscpost::validate_step_kernel, dim3((unsigned)n), dim3(lscpost::kThreads), 0, (hipStream_t)stream, M, dim, use_sfc, dt, n,
+                       time_step, z_2d, d_x_new, d_hdr, d_sfc, d_valid, d_state, lscpost::Commit{d_qp_status, d_x_new, d_x_init, d_x_plan, d_goal});
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
     return LSCQP_OK;
