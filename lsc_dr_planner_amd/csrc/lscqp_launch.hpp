@@ -31,6 +31,7 @@ using launch_fn = hipError_t (*)(const DevClass*, int64_t, const lscqp_header*, 
     X(8, 2, 0, 12, 1, 0) X(9, 2, 1, 12, 1, 0) X(9, 2, 0, 12, 1, 0) X(6, 2, 1, 12, 1, 0) X(6, 2, 0, 12, 1, 0) X(8, 3, 1, 12, 2, 0)   \
     X(2, 2, 1, 8, 1, 0) X(2, 2, 0, 8, 1, 0) X(3, 2, 1, 8, 1, 0) X(3, 2, 0, 8, 1, 0) X(4, 2, 1, 12, 1, 0) X(4, 2, 0, 12, 1, 0) X(7, 2, 1, 12, 1, 0) X(7, 2, 0, 12, 1, 0) \
     X(5, 3, 1, 8, 4, 0) X(5, 3, 1, 12, 4, 0) X(5, 3, 0, 12, 2, 0) X(5, 3, 0, 8, 4, 0) \
+    X(10, 2, 0, 10, 4, 0) X(10, 2, 0, 5, 2, 0) X(6, 3, 1, 8, 4, 0) X(6, 3, 0, 8, 4, 0) \
     X(10, 3, 0, 7, 2, 0) X(10, 3, 0, 9, 4, 0) X(9, 3, 0, 7, 2, 0) X(9, 3, 0, 8, 4, 0) X(9, 3, 1, 7, 2, 0) X(9, 3, 1, 8, 4, 0) X(8, 3, 0, 7, 2, 0) X(8, 3, 0, 8, 4, 0) \
     X(10, 3, 1, 20, 2, 0) X(10, 2, 1, 20, 2, 0) X(5, 3, 1, 5, 2, 0) X(5, 3, 1, 12, 2, 0) X(6, 3, 1, 7, 2, 0) X(10, 2, 1, 5, 2, 0) X(10, 3, 1, 10, 4, 0) X(10, 2, 1, 10, 4, 0) \
     X(5, 3, 1, 10, 1, 1) X(5, 3, 1, 24, 1, 1) X(6, 3, 1, 20, 1, 1) X(10, 2, 1, 10, 1, 1)
