@@ -590,6 +590,7 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, double margin) {
         }
         // is item (chunk c, segment zs; zs < 0: the whole columns) provably free?  `skip`: the columns have no such segment
         auto item_free = [&](int c, int zs, bool& skip, bool& segmented) -> bool {
+            const long long ti0_ = clock64();
             int j = 0;
             for (int t = 1; t < J; t++) j += (c >= A.first[t]) ? 1 : 0;  // (J <= kSamp slots)
             const int ax = A.axes[j];
@@ -618,11 +619,14 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, double margin) {
                 const int x0 = ca == 0 ? va0 : (cb == 0 ? vb0 : vl0), x1 = ca == 0 ? va1 : (cb == 0 ? vb1 : vl1);
                 const int y0 = ca == 1 ? va0 : (cb == 1 ? vb0 : vl0), y1 = ca == 1 ? va1 : (cb == 1 ? vb1 : vl1);
                 const int z0 = ca == 2 ? va0 : (cb == 2 ? vb0 : vl0), z1 = ca == 2 ? va1 : (cb == 2 ? vb1 : vl1);
+                const long long ti1_ = clock64();
                 free_ = cells_free(mp, x0, x1, y0, y1, z0, z1);
+                SFC_DBG(27, ti1_ - ti0_); SFC_DBG(28, clock64() - ti1_ + (free_ ? 0 : 0)); SFC_DBG(29, 1);
             }
             return free_;
         };
         __syncthreads();
+        SFC_DBG(30, clock64() - tt1_);
         for (int c = lane; c < all_chunks; c += kSfcThreads) {  // first the chunks, whole columns: listed from the front of A.todo
             bool skip, segmented;
             if (!item_free(c, -1, skip, segmented)) A.todo[atomicAdd(&A.ntodo, 1)] = c;  // (all_chunks <= kTodo; chunks < 2^16)
@@ -727,7 +731,6 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, double margin) {
                 hit = hit || ((double)dist < thr);
             }
         };
-        SFC_DBG(27, nl <= 2 ? 1 : 0); SFC_DBG(28, (nl > 2 && nl <= 8) ? 1 : 0); SFC_DBG(29, nl > 8 ? 1 : 0); SFC_DBG(30, nl > 8 ? (nl + LSCSFC_GROUP - 1) / LSCSFC_GROUP : 0);
         if (zsel > 0) {
             group(std::integral_constant<int, kSeg>{}, (zsel - 1) * kSeg);
         } else if (nl <= 2) {
