@@ -472,7 +472,8 @@ __device__ unsigned long long sfc_dbg[32];
                           // Measured on the 3-D chain of bench.py (64 agents, a room with 24 boxes): 63 / 126 / 190 / 254 -> 432 / 400 / 404 / 413 us per replan
 #endif
 #ifndef LSCSFC_SAMPLED
-#define LSCSFC_SAMPLED 12  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing); <= 63
+#define LSCSFC_SAMPLED 10  // ... of which at most this many have to be sampled (boxes the free-space table passes cost nothing); <= 63
+                           // (8 / 10 / 12 / 16 / 24: 3-D chain 396 / 396 / 400 / 439 / 530 us per replan; 4096 agents 0.94 / 0.92 / 0.97 ms with 8 / 10 / 12)
 #endif
 constexpr int kAhead = LSCSFC_AHEAD;
 constexpr int kSamp = LSCSFC_SAMPLED;           // record slots of a batch: the boxes that have to be sampled

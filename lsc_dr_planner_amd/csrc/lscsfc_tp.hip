@@ -18,9 +18,13 @@
 #define LSCSFC_TP_CELL 512
 #endif
 #ifndef LSCSFC_TP_AHEAD
-#define LSCSFC_TP_AHEAD 126  // (two wavefronts assemble the look-ahead; with 254 the tables would no longer leave room for four workgroups per CU)
+#define LSCSFC_TP_AHEAD 62  // (ONE wavefront assembles the look-ahead: here the instructions count, not the chain -- 4096 agents, INIT / FROM_HULL:
+                            // 30 / 46 / 62 / 126 / 254 tests ahead -> 1.00 / 0.99 / 0.97 / 1.01 / 1.08 ms and 1.05 / 1.05 / 1.03 / 1.07 / 1.15 ms)
 #endif
 #define LSCSFC_AHEAD LSCSFC_TP_AHEAD
+#ifdef LSCSFC_TP_SAMPLED
+#define LSCSFC_SAMPLED LSCSFC_TP_SAMPLED
+#endif
 #define LSCSFC_THREADS LSCSFC_TP_THREADS
 #define LSCSFC_WAVES_PER_EU 4
 #define LSCSFC_TODO LSCSFC_TP_TODO
