@@ -243,9 +243,10 @@ int lscqp_diagnose(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lsc
     const size_t total = al(b_hdr) + al(b_rows) + al(b_off) + al(b_sfc) + al(b_x) + al(b_out);
     if (hipMalloc(&dev, total) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipMalloc failed");
     char* p = dev;
+    hipError_t up = hipSuccess;  // the first upload that failed
     auto put = [&](const void* src, size_t b) -> char* {
         char* at = p;
-        if (b) (void)hipMemcpy(at, src, b, hipMemcpyHostToDevice);
+        if (b && up == hipSuccess) up = hipMemcpy(at, src, b, hipMemcpyHostToDevice);
         p += al(b);
         return at;
     };
@@ -257,6 +258,10 @@ int lscqp_diagnose(lscqp_handle h, int64_t n, const lscqp_header* hdr, const lsc
     const lscqp_box* d_sfc = (const lscqp_box*)put(sfc, b_sfc);
     const double* d_x = (const double*)put(x, b_x);
     lscqp_diag* d_out = (lscqp_diag*)p;
+    if (up != hipSuccess) {
+        (void)hipFree(dev);
+        return fail(LSCQP_ERR_HIP, std::string("hipMemcpy (H2D) failed: ") + hipGetErrorString(up));
+    }
     int rc = lscqp_diagnose_device(h, n, d_hdr, d_rows, d_off, b_sfc ? d_sfc : nullptr, d_x, tol, d_out, nullptr);
     if (rc == LSCQP_OK && hipMemcpy(out, d_out, b_out, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(LSCQP_ERR_HIP, "hipMemcpy (D2H) failed");
     (void)hipFree(dev);
