@@ -1023,11 +1023,18 @@ __device__ __forceinline__ bool expand_sfc(const MapView& mp, Ahead& A, bool tab
                 ch_[q] = (nc_[q] + 63) >> 6;
                 sc += ch_[q], su += nd_[q], ss += nc_[q] > 0 ? 1 : 0;
             }
-            int pc = sc, pu = su, ps = ss;  // inclusive prefix sums over the lanes
-            for (int d = 1; d < 64; d <<= 1) {
-                const int tc = __shfl_up(pc, d), tu = __shfl_up(pu, d), ts = __shfl_up(ps, d);
-                if (l >= d) pc += tc, pu += tu, ps += ts;
-            }
+            // inclusive prefix sums over the lanes: DPP row shifts inside the rows of 16 lanes, then the row broadcasts (12 VALU
+            // instructions per sum; as six ds_bpermute steps each: ~600 cycles per sum on the batch's critical path)
+            auto wave_scan = [](int v) -> int {
+                v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+                v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+                v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+                v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+                v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+                v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+                return v;
+            };
+            const int pc = wave_scan(sc), pu = wave_scan(su), ps = wave_scan(ss);
             int ec = pc - sc, eu = pu - su, es = ps - ss;  // what lies before the lane's first test
             int jmine = 1 << 20;
             bool brk0 = false;
