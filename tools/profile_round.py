@@ -165,4 +165,12 @@ if "nonext" not in os.environ.get("PROFILE_SKIP", ""):
                                                                             "rasterise", "select_neighbours", "shift_traj", "goal_kernel", "validate_step"))]
         with open(os.path.join(OUT, tag + "_next_rows_kernel_stats.csv"), "w", newline="") as g:
             csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
+    # the two replan chains of bench.py (replan_chain): which kernel takes what of a replan
+    for mode, name in (([], "c1class"), (["forest10"], "forest10")):
+        dc = os.path.join(OUT, "trace_chain_" + name)
+        run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", dc, "--", sys.executable, os.path.join(ROOT, "tools", "chain_profile.py")] + mode,
+            "%s_chain_%s_trace.log" % (tag, name))
+        for f in glob.glob(os.path.join(dc, "**", "*kernel_stats.csv"), recursive=True):
+            with open(os.path.join(OUT, "%s_chain_%s_kernel_stats.csv" % (tag, name)), "w") as g:
+                g.write(open(f).read())
 print(json.dumps(summary))
