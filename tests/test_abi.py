@@ -150,3 +150,20 @@ def test_instance_work_counters_come_with_the_library(api):
     assert w10["wavefronts"] == 4 and w10["flops_per_iteration"] > 2 * small["flops_per_iteration"] and w10["lds_bytes"] > 100000
     with pytest.raises(api.LscqpError):
         s5.instance_work(64, 500)  # no instance holds 500 obstacles
+
+
+def test_instance_table_covers_every_shape_up_to_m10():
+    """csrc/lscqp_launch.hpp: every (2 <= M <= 10, dim 2 | 3, with / without the end stop) has a compiled fp64 instance -- the run-time-shaped
+    kernel is for M = 11, 12 and for neighbour counts beyond the register slots, not for a planner mode."""
+    from lsc_dr_planner_amd import build
+
+    fp64 = {(M, D, E) for (M, D, E, S, W, X) in build.instances() if X == 0}
+    missing = [(M, D, E) for M in range(2, 11) for D in (2, 3) for E in (0, 1) if (M, D, E) not in fp64]
+    assert not missing, missing
+    # ... and holds at least 40 neighbours per agent in registers at the horizons the reference ships (M = 5, 10)
+    cap = {}
+    for (M, D, E, S, W, X) in build.instances():
+        if X == 0:
+            cap[(M, D, E)] = max(cap.get((M, D, E), 0), S * max(1, 64 * W // (6 * M - 3)))
+    for key in ((5, 3, 1), (5, 3, 0), (10, 2, 1), (10, 2, 0), (10, 3, 1)):
+        assert cap[key] >= 40, (key, cap[key])

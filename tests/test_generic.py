@@ -82,11 +82,16 @@ def test_generic_kernel_on_shapes_with_compiled_instances(api, oracle, torch_cud
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,dim,n_obs", [(5, 3, 64), (6, 3, 64), (10, 2, 64), (10, 3, 64), (9, 3, 30)])
-def test_more_neighbours_than_any_compiled_instance_holds(api, oracle, torch_cuda, M, dim, n_obs):
-    """64 neighbours per agent: beyond the 48 / 40 of the largest compiled instances (every obstacle gets its rows in the reference,
-    src/traj_optimizer.cpp:399-437).  The launch falls through to the run-time-shaped kernel -- OPTIMAL at the oracle's optimum, never
-    CAPACITY."""
+@pytest.mark.parametrize("forced", [False, True], ids=["as_selected", "run_time_shaped_kernel"])
+@pytest.mark.parametrize("M,dim,n_obs", [(5, 3, 64), (5, 3, 100), (6, 3, 64), (10, 2, 64), (10, 3, 64), (9, 3, 30)])
+def test_more_neighbours_than_the_two_wavefront_instances_hold(api, oracle, torch_cuda, monkeypatch, M, dim, n_obs, forced):
+    """64 (100) neighbours per agent: beyond the 48 / 40 of round 2's largest compiled instances (every obstacle gets its rows in the
+    reference, src/traj_optimizer.cpp:399-437).  As selected, the launch goes to a four-wavefront compiled instance where one holds the
+    count (M = 5: 72 / 108, M = 6: 56, M = 9: 40) and falls through to the run-time-shaped kernel otherwise; forced, it is that kernel in
+    every case -- OPTIMAL at the oracle's optimum either way, never CAPACITY."""
+    monkeypatch.delenv("LSCQP_FORCE_GENERIC", raising=False)
+    if forced:
+        monkeypatch.setenv("LSCQP_FORCE_GENERIC", "1")
     sol = api.Solver(api.make_desc(M=M, dim=dim))
     assert sol.max_obstacles() >= n_obs
-    _swarm_vs_oracle(api, oracle, M, dim, n_obs, True, N=80, steps=2, seed=13)
+    _swarm_vs_oracle(api, oracle, M, dim, n_obs, True, N=max(80, n_obs + 8), steps=2, seed=13)
