@@ -433,3 +433,53 @@ def test_gpu_corridor_look_ahead_special_paths(api, oracle, world, variant, monk
             sel = ok if mode == api.SFC_INIT else np.ones(n, bool)
             assert np.array_equal(got["bmin"][sel], exp["bmin"][sel]) and np.array_equal(got["bmax"][sel], exp["bmax"][sel]), (world, prepared, mode)
         gmap.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["latency", "throughput"])
+def test_gpu_corridor_seeded_outside_the_world(api, oracle, variant, monkeypatch):
+    """A replan whose last point / goal lie OUTSIDE the world (a plan that left it): the hull box, clipped to the previous corridor, is
+    INVERTED along that axis (upper face below the world's lower bound).  The reference grows such a box like any other -- no sample
+    points, so every test passes until a boundary says no -- and the layer of the direction that grows back INTO the world fails the
+    boundary on its inner face, which the look-ahead's list of boundary failures does not predict: the batch has to end in front of
+    the disagreement (the safety net of expand_sfc).  Found by tools/sweep_corridors.py (seed 3, agent 197); bit for bit against the oracle."""
+    import torch
+
+    monkeypatch.setenv("LSCSFC_VARIANT", variant)
+    wmin, wmax = np.array([-6.27, -6.0, 0.0]), np.array([6.0, 6.0, 3.31])
+    boxes = np.array([[0.6, 0.4, 1.5, 0.5, 0.5, 3.0], [3.0, -4.0, 1.0, 0.8, 0.8, 0.8]])
+    rng = np.random.default_rng(5)
+    n, M = 24, 5
+    starts = np.float32(np.c_[rng.uniform(-5, 5, n), rng.uniform(-5.9, -5.6, n), rng.uniform(0.5, 2.8, n)]).astype(np.float64)  # along the y = -6 wall
+    out = np.arange(n) % 3 != 2  # two of three agents have left the world through that wall, the others along x / z
+    radius = np.where(np.arange(n) % 2 == 0, 0.25, 0.15)
+    omap = oracle.Map(boxes, wmin, wmax, 0.1, 1.0)
+    base = np.zeros((n, M), oracle.BOX_DTYPE)
+    st0 = omap.construct_sfc(oracle.SFC_INIT, _pts(starts), radius, base)
+    assert (st0 == 1).all()
+    last, goal = starts.copy(), starts.copy()
+    last[:, 1] = np.where(out, wmin[1] - rng.uniform(0.05, 0.3, n), starts[:, 1] + 0.1)
+    goal[:, 1] = np.where(out, wmin[1] - rng.uniform(0.4, 0.8, n), starts[:, 1] + 0.3)
+    last[~out, 0] += 0.2
+    last, goal = np.float32(last).astype(np.float64), np.float32(goal).astype(np.float64)
+    P = _pts(last, goal, last)
+    sol = api.Solver(api.make_desc(M=M, dim=3, world_min=wmin, world_max=wmax))
+    dev = torch.device("cuda", 0)
+    for prepared in (0.0, 0.25):
+        gmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+        if prepared > 0:
+            gmap.prepare(prepared)
+        for mode_o, mode_g in ((oracle.SFC_FROM_POINT, api.SFC_FROM_POINT), (oracle.SFC_FROM_HULL, api.SFC_FROM_HULL)):
+            want = base.copy()
+            st_w = omap.construct_sfc(mode_o, P, radius, want)
+            d_sfc = torch.from_numpy(base.view(np.float64).reshape(-1).copy()).to(dev)
+            d_st = torch.full((n,), -7, dtype=torch.int32, device=dev)
+            sol.construct_sfc_device(gmap, mode_g, n, torch.from_numpy(np.ascontiguousarray(P).reshape(-1).copy()).to(dev), torch.from_numpy(radius).to(dev), d_sfc, d_st)
+            torch.cuda.synchronize()
+            got = d_sfc.cpu().numpy().view(api.BOX_DTYPE).reshape(n, M)
+            assert np.array_equal(d_st.cpu().numpy(), st_w), (prepared, mode_o)
+            assert np.array_equal(got["bmin"], want["bmin"]) and np.array_equal(got["bmax"], want["bmax"]), (prepared, mode_o)
+            inverted = (want["bmax"][:, M - 1] < want["bmin"][:, M - 1]).any(axis=1)
+            if mode_o == oracle.SFC_FROM_POINT and prepared == 0.0:
+                assert inverted.any(), "the premise: some corridor of this test is an inverted box"
+        gmap.close()
