@@ -480,6 +480,7 @@ constexpr int kSamp = LSCSFC_SAMPLED;           // record slots of a batch: the 
 constexpr int kGenWaves = (kAhead + 63) / 64;   // wavefronts that assemble the look-ahead
 constexpr int kBoxes = kGenWaves * 64;
 static_assert(kAhead >= 2 && kAhead <= 254 && kSamp >= 1 && kSamp <= 63, "look-ahead: growth counts are bytes, the sampled boxes are looked up with one ballot");
+static_assert(kBoxes <= kSfcThreads && kSfcThreads % 64 == 0, "a lane per test of the look-ahead");
 #ifndef LSCSFC_TAB
 #define LSCSFC_TAB 3072
 #endif
