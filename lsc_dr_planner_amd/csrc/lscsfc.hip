@@ -12,8 +12,8 @@
 // point.  Here the map is a dense voxel grid in HBM (1 B occupancy + 4 B nearest-cell code per voxel; 288 GB holds
 // kilometre-scale worlds at 0.1 m), its nearest-cell field is built by three separable passes (exact Euclidean, 3 x (2R+1)
 // reads per voxel instead of (2R+1)^3), and one workgroup (16 wavefronts) owns one agent's corridor: the box state is uniform
-// across the group; the next tests of the expansion loop (up to 126, through the failures the world boundary will cause) are known in
-// advance, the up to 12 of them that the map's free-space table cannot pass are evaluated together, a lane per column of sample
+// across the group; the next tests of the expansion loop (up to 126 -- 62 in the throughput build --, through the failures the world boundary will cause) are known in
+// advance, the up to 10 of them that the map's free-space table cannot pass are evaluated together, a lane per column of sample
 // points (obstacle_in_batch below), and the first test that fails decides how far the box has grown.
 //
 // Arithmetic: boxes and points are octomap::point3d (float) in the reference; every statement below keeps float where
