@@ -90,21 +90,23 @@ def to_dev(torch, a, dev):
 
 # BASELINE.json configs at their own shapes (SURVEY.md section 8 size table).  "c1" is the headline (the metric is quoted on it);
 # the others are measured on one GPU in the `configs` section of the JSON line and can be made the timed workload with
-# --config (that is how tools/profile_round.py traces each kernel instance on its own).
+# --config (that is how tools/profile_round.py traces each kernel instance on its own).  `seed`: ONE batch per config -- the `configs`
+# block of the default line, `--config cX` (what the rocprofv3 passes under profiles/ run) and the sharded `--scaling strong` runs all
+# build the swarm from it (weak scaling: + rank), so the profiles are of the very batches the bench line reports.
 CONFIGS = {
-    "c0": dict(agents=10, segments=10, obs=9, dim=2, style="forest", precision="f64", rows="f64",
+    "c0": dict(seed=3020, agents=10, segments=10, obs=9, dim=2, style="forest", precision="f64", rows="f64",
                what="configs[0] forest10 replica: 10 agents x M=10, dim 2 (the reference's own launch shape; CPLEX there)"),
-    "c1": dict(agents=64, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
+    "c1": dict(seed=1000, agents=64, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
                what="configs[1]: 64 agents x M=5 x ~20 LSC half-spaces/seg, fp64"),
-    "c2": dict(agents=512, segments=6, obs=20, dim=3, style="maze", precision="f64", rows="f64",
+    "c2": dict(seed=3518, agents=512, segments=6, obs=20, dim=3, style="maze", precision="f64", rows="f64",
                what="configs[2]: 512 agents dense-maze LSC set, M=6, fp64 (whole batch on one GPU)"),
-    "c3s": dict(agents=128, segments=10, obs=40, dim=3, style="forest", precision="f64", rows="f64",
+    "c3s": dict(seed=3138, agents=128, segments=10, obs=40, dim=3, style="forest", precision="f64", rows="f64",
                 what="configs[3], the per-GPU shard of 8: 128 agents x M=10 x 40 LSC + SFC, fp64 (nz = 84)"),
-    "c3": dict(agents=1024, segments=10, obs=40, dim=3, style="forest", precision="f64", rows="f64",
+    "c3": dict(seed=4034, agents=1024, segments=10, obs=40, dim=3, style="forest", precision="f64", rows="f64",
                what="configs[3] whole: 1024 agents x M=10 x 40 LSC + SFC, fp64, on ONE GPU"),
-    "c4": dict(agents=4096, segments=5, obs=20, dim=3, style="forest", precision="mixed", rows="f32",
+    "c4": dict(seed=7101, agents=4096, segments=5, obs=20, dim=3, style="forest", precision="mixed", rows="f32",
                what="configs[4]: 4096 agents x M=5, fp32 PDIP (float32 factorisation, 16-byte rows) with fp64 residual check"),
-    "c4_f64": dict(agents=4096, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
+    "c4_f64": dict(seed=7101, agents=4096, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
                    what="configs[4] shape in fp64 (32-byte rows): the comparison the mixed-precision instance is judged against"),
 }
 
@@ -138,8 +140,21 @@ def oracle_sample(O, sw, build, M, dim, n_obs_eff, sample, threads=4):
     return R, sel
 
 
-def oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample, budget_s=2.5):
-    """The CPU oracle (a port: CPLEX cannot exist here) on a bounded sample of the batch: QP/s with the best thread count."""
+def usable_cpus():
+    """Host threads this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            avail = max(1, min(avail, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return avail
+
+
+def oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample, budget_s=2.5, single_core=False):
+    """The CPU oracle (a port: CPLEX cannot exist here) on a bounded sample of the batch: QP/s on a FIXED thread count --
+    min(64, usable CPUs, sample size), one QP per thread at a time (OpenMP over agents) -- the same rule for every config."""
     N = len(build["p0"])
     sel = np.arange(min(sample, N))
     cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
@@ -150,28 +165,28 @@ def oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample, budget_s=2.5):
     lsc = np.ascontiguousarray(build["lsc"][sel]).reshape(-1)
     loff = np.arange(len(sel)) * n_obs_eff * M * 6
     sfc_o = np.ascontiguousarray(build["sfc"][sel]).reshape(-1)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    best = None
-    for th in sorted({1, 8, 32, min(64, avail), min(len(sel), avail)}):
-        if th > avail:
-            continue
-        a = time.perf_counter()
-        R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=th)
-        dtm = time.perf_counter() - a
-        if best is None or dtm < best[1]:
-            best = (th, dtm, R)
-        if dtm > budget_s:
-            break
-    cores, _, R = best
+    avail = usable_cpus()
+    cores = max(1, min(64, avail, len(sel)))
+    R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)  # warm (thread pool, caches)
     reps, tcpu = 0, 0.0
     a = time.perf_counter()
     while tcpu < budget_s and reps < 200:
         R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)
         reps += 1
         tcpu = time.perf_counter() - a
-    return dict(value=len(sel) * reps / tcpu, unit="QP/s", cores=cores, kind="port", visible_cpus=avail,
-                sample="first %d QPs of the batch x %d repetitions, oracle/lscqp_oracle.c (dense fp64 PDIP, OpenMP over agents), %.1f s" % (
-                    len(sel), reps, tcpu)), R, sel
+    out = dict(value=len(sel) * reps / tcpu, unit="QP/s", cores=cores, kind="port", visible_cpus=avail,
+               sample="first %d QPs of the batch x %d repetitions, oracle/lscqp_oracle.c (dense fp64 PDIP, OpenMP over agents, %d threads = "
+                      "min(64, usable CPUs, sample)), %.1f s wall" % (len(sel), reps, cores, tcpu))
+    if single_core:
+        k = min(16, len(sel))
+        t1c = 1e30  # single core: the first 16 QPs, best of 5 (a lone 30 ms sample is at the mercy of the host's clock ramp)
+        for _ in range(5):
+            a1 = time.perf_counter()
+            O.solve_batch(cls, ag[:k], lsc, loff[:k], sfc_o, threads=1)
+            t1c = min(t1c, time.perf_counter() - a1)
+        out["single_core_value"] = k / t1c
+        out["sample"] += "; single core: %.1f QP/s" % (k / t1c)
+    return out, R, sel
 
 
 def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_seconds=4.0):
@@ -182,7 +197,7 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     def factory(sw, **kw):
         return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **kw))
 
-    sw, sol64, b, (hdr, rows, off, sfc) = make_batch(api, synth, factory, N, M, dim, n_obs, seed=3000 + N + M, style=cfg["style"], warm_steps=3)
+    sw, sol64, b, (hdr, rows, off, sfc) = make_batch(api, synth, factory, N, M, dim, n_obs, seed=cfg["seed"], style=cfg["style"], warm_steps=3)
     kw = {}
     if cfg.get("warm_start") == "tight":
         kw["warm_start"] = api.WARM_TIGHT
@@ -383,7 +398,7 @@ def single_process_main(args, torch):
     def factory(sw):
         return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **kw))
 
-    sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, factory, n_glob, M, dim, n_obs, seed=1000, style=args.style, warm_steps=3)
+    sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, factory, n_glob, M, dim, n_obs, seed=CONFIGS[args.config]["seed"], style=args.style, warm_steps=3)
     nv, n_obs_eff, per = sol.nv, sw.n_obs, -(-n_glob // G)
     comm = api.Comm(G)
     comm.set_min_agents_per_device(1)  # this run is TOLD how many devices to use; the library's own rule is reported below
@@ -487,12 +502,353 @@ def single_process_main(args, torch):
     comm.close()
 
 
+class Ctx:
+    """What every timed workload of one bench.py process shares: the device, the process group and the reductions over it."""
+
+    def __init__(self, torch, dist, rank, world, dev_index, backend, coll_backend):
+        self.torch, self.dist, self.rank, self.world, self.dev_index = torch, dist, rank, world, dev_index
+        self.dev = torch.device("cuda", dev_index)
+        self.backend, self.coll_backend = backend, coll_backend
+        self.host_collectives = coll_backend.startswith("gloo")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def reduce(self, vals, op):
+        """all-reduce of a few doubles over the ranks (host tensors under gloo, device tensors under RCCL)."""
+        if self.dist is None:
+            return [float(v) for v in vals]
+        d = self.dist
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=("cpu" if self.host_collectives else self.dev))
+        d.all_reduce(t, op={"max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN, "sum": d.ReduceOp.SUM}[op])
+        return [float(v) for v in t.cpu()]
+
+
+def workload_args(base, config, **over):
+    """A copy of the parsed arguments with `config`'s shape filled in (explicit --agents/--segments/... of `base` win only when
+    base.config is that same config)."""
+    a = argparse.Namespace(**vars(base))
+    a.config = config
+    cfg = CONFIGS[config]
+    for k in ("agents", "segments", "obs", "dim", "style", "precision", "rows"):
+        if getattr(a, k, None) is None or base.config != config:
+            setattr(a, k, cfg[k])
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def timed_workload(ctx, a):
+    """ONE timed workload on every rank of the job: build the batch (device resident), `a.warmup` untimed steps, then exactly `a.steps`
+    steps between barrier + synchronize on both sides; max over ranks.  Returns a namespace with everything the line is made of
+    (collective results are identical on every rank) and the device state rank 0 needs for its latency / baseline legs."""
+    from types import SimpleNamespace
+
+    from lsc_dr_planner_amd import api, sharding, synth
+
+    torch, dist, rank, world, dev = ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.dev
+    M, dim, n_obs, N = a.segments, a.dim, a.obs, a.agents
+    cfg_seed = CONFIGS[a.config]["seed"]
+    solver_kw = {}
+    if a.precision == "mixed":
+        solver_kw["precision"] = api.PRECISION_MIXED
+    if a.rows == "f32":
+        solver_kw["row_format"] = api.ROWS_F32
+
+    def warm_factory(sw):  # the warm-up replans are always carried in fp64 on fp64 rows: one batch per config whatever the timed precision
+        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+
+    def all_ranks(fn):
+        """Run the collective-free `fn` on every rank and agree on the outcome: a rank that failed alone would leave the others
+        waiting in the next collective for ever."""
+        err = None
+        try:
+            res = fn()
+        except Exception as ex:  # noqa: BLE001
+            res, err = None, "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        bad, = ctx.reduce([0.0 if err is None else 1.0], "sum")
+        if bad:
+            raise RuntimeError(err or "batch construction failed on %d other rank(s)" % int(bad))
+        return res
+
+    strong = a.scaling == "strong"
+    if strong and (a.pipeline or a.graph):
+        raise SystemExit("bench.py: --scaling strong times the solve + all-gather step; --pipeline / --graph are weak-scaling options")
+    n_glob = N  # agents of the whole job's step: one global batch (strong) or `world` independent swarms of N (weak)
+    if strong:
+        # ONE swarm for the whole job, built identically on every rank (the config's seed; the warm-up replans are carried by the rank's
+        # own GPU, the kernel is deterministic), then cut: rank r owns the contiguous block shard_range(n_glob, world, r) (reference
+        # agent order, src/mission.cpp:140-153).  It is the SAME batch the one-GPU `configs` entry of this config solves whole.
+        sw, sol, build, (hdr, rows, off, sfc) = all_ranks(lambda: make_batch(api, synth, warm_factory, n_glob, M, dim, n_obs, seed=cfg_seed, style=a.style, warm_steps=3))
+        lo, hi = sharding.shard_range(n_glob, world, rank)
+        per = -(-n_glob // world)
+        N = hi - lo
+        if N <= 0:
+            raise SystemExit("bench.py: rank %d owns no agent (%d agents over %d ranks)" % (rank, n_glob, world))
+        whole = SimpleNamespace(hdr=hdr, rows=rows, off=off, sfc=sfc, build=build) if (rank == 0 and world > 1) else None
+        build = slice_build(build, n_glob, lo, hi)
+        hdr, sfc = hdr[lo:hi], sfc.reshape(n_glob, M)[lo:hi]
+        rows = rows.reshape(n_glob, -1)[lo:hi].reshape(-1)
+        off = np.arange(N + 1, dtype=np.uint64) * np.uint64(sw.n_obs * M * 6)
+    else:
+        whole = None
+        sw, sol, build, (hdr, rows, off, sfc) = all_ranks(lambda: make_batch(api, synth, warm_factory, N, M, dim, n_obs, seed=cfg_seed + rank,
+                                                                             style=a.style, warm_steps=3))
+        n_glob = world * N
+    if solver_kw:
+        sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **solver_kw))
+    n_obs_eff = sw.n_obs
+    nv = sol.nv
+    d_hdr, d_off, d_sfc = (to_dev(torch, x, dev) for x in (hdr, off, sfc))
+    d_rows = to_dev(torch, sol.rows_in_format(rows), dev)
+    # TrajOptimizer::solve's initial_traj (the shifted previous plan): the solver's primal start
+    d_xinit = None if a.cold_start else torch.from_numpy(api.x_init_from_swarm(build, dim)).to(dev)
+    n_pad = per if strong else N  # equal blocks for the collective: the last block of a ragged split is padded (never solved)
+    d_x = torch.zeros(n_pad * nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
+    gather = (a.allgather or a.pipeline or strong) and world > 1
+    d_all = torch.zeros(world * n_pad * nv, dtype=torch.float64, device=dev) if gather else None
+    # gloo (test-only backend, ranks sharing a device) carries the all-gather through host memory
+    h_all = torch.zeros(world * n_pad * nv, dtype=torch.float64) if (gather and ctx.host_collectives) else None
+
+    def all_gather_plans():
+        if h_all is None:
+            dist.all_gather_into_tensor(d_all, d_x)
+        else:
+            dist.all_gather_into_tensor(h_all, d_x.cpu())
+            d_all.copy_(h_all)
+
+    d_xwarm = torch.zeros(N * nv, dtype=torch.float64, device=dev)
+    if a.pipeline:
+        # every rank's swarm is independent (weak scaling); global agent id = rank * N + local id.  The rows are
+        # regenerated every step from the CURRENT plans of all agents (replanning from the same state: the previous
+        # plans satisfy the new rows by the supporting-hyperplane argument of SURVEY 8d), so the exchange is load bearing.
+        n_total = world * N
+        d_traj = torch.zeros(n_total * M * 6 * 3, dtype=torch.float64, device=dev)
+        d_nbr = torch.from_numpy((build["nbr"] + rank * N).astype(np.int32)).to(dev)
+        d_rad = torch.full((n_total,), sw.radius, dtype=torch.float64, device=dev)
+        d_dw = torch.full((n_total,), sw.downwash, dtype=torch.float64, device=dev)
+        d_goal = torch.from_numpy(np.ascontiguousarray(build["goal"], dtype=np.float64)).to(dev)
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)  # plans to start from
+        torch.cuda.synchronize()
+
+    def solve_only():
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+
+    def step():
+        if a.pipeline:
+            src = d_x
+            if d_all is not None:
+                all_gather_plans()
+                src = d_all
+            sol.shift_traj_device(world * N, src, d_traj, z_2d=float(build["p0"][0][2]), shift=0)
+            sol.generate_lsc_device(N, n_obs_eff, rank * N, d_traj, d_nbr, d_rad, d_dw, d_goal, d_rows)
+            if d_xinit is not None:
+                d_xwarm.copy_(d_x)  # the plans the rows were generated from are the primal start of the re-solve
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info,
+                         d_x_init=(d_xwarm if (a.pipeline and d_xinit is not None) else d_xinit))
+        if d_all is not None and not a.pipeline:
+            all_gather_plans()
+
+    if a.graph:
+        if world != 1:
+            raise SystemExit("--graph is a single-GPU option")
+        eager_step = step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm up on the capture stream, as graph capture requires
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph, stream=side):
+            eager_step()
+        step = hip_graph.replay  # noqa: F811
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps  # average launch duration on the launch stream
+
+    if d_all is not None and not a.pipeline:
+        # roofline.kernel_ms is the SOLVE kernel's launch duration: time it without the exchange that shares the step's stream
+        ek0, ek1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ek0.record()
+        for _ in range(20):
+            solve_only()
+        ek1.record()
+        torch.cuda.synchronize()
+        kernel_ms = ek0.elapsed_time(ek1) / 20
+    my_elapsed = elapsed
+    elapsed, kernel_ms = ctx.reduce([elapsed, kernel_ms], "max")
+
+    status = d_st.cpu().numpy()
+    info = d_info.cpu().numpy().view(api.INFO_DTYPE)
+    iters = info["iterations"]
+    n_bad = int(ctx.reduce([float((status != 0).sum())], "sum")[0])
+    n_floor = int(ctx.reduce([float(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum())], "sum")[0])
+    it_sum, = ctx.reduce([float(iters.sum())], "sum")
+    it_max, = ctx.reduce([float(iters.max())], "max")
+    n_ranks_seen, n_devices_seen, n_agents_seen = 1, 1, N
+    rank_parity = None
+    step_lat = None
+    if dist is not None:
+        # what actually ran: ranks, DISTINCT devices (by PCI bus id), agents solved per step over all ranks
+        bus = torch.cuda.get_device_properties(ctx.dev_index)
+        dev_id = hash((getattr(bus, "pci_bus_id", ctx.dev_index), getattr(bus, "pci_device_id", 0), getattr(bus, "pci_domain_id", 0), ctx.dev_index)) % (1 << 40)
+        ids = [None] * world
+        dist.all_gather_object(ids, (dev_id, N, my_elapsed))
+        n_ranks_seen, n_devices_seen, n_agents_seen = len(ids), len({i[0] for i in ids}), sum(i[1] for i in ids)
+        if d_all is not None and not a.pipeline:
+            # the exchange must have delivered every owner's block: compare this rank's view with its own block
+            mine = d_all.view(world, n_pad * nv)[rank][: N * nv]
+            if not torch.equal(mine, d_x[: N * nv]):
+                raise SystemExit("bench.py: rank %d: the all-gathered plans do not contain this rank's block" % rank)
+        if not a.no_rank_parity and not a.no_cpu_baseline and a.rows == "f64":
+            # every rank checks its OWN block against the oracle (a bounded sample: the oracle is a dense CPU solver)
+            from oracle import oracle as O
+
+            k = min(N, 16 if M < 10 else 6)
+            Rk, sel = oracle_sample(O, sw, build, M, dim, n_obs_eff, sample=k)
+            xg, og = d_x.cpu().numpy()[: N * nv].reshape(N, nv)[sel], d_obj.cpu().numpy()[sel]
+            ok = (Rk["status"] == 0) & (status[sel] == 0)
+            dxm = float(np.abs(xg - Rk["x"])[ok].max()) if ok.any() else float("inf")
+            dom = float((np.abs(og - Rk["obj"]) / np.maximum(1.0, np.abs(Rk["obj"])))[ok].max()) if ok.any() else float("inf")
+            dxm, dom = ctx.reduce([dxm, dom], "max")
+            rank_parity = {"max_abs_dx": dxm, "max_rel_dobj": dom, "compared_per_rank": int(k), "ranks": world,
+                           "compared": int(ctx.reduce([float(ok.sum())], "sum")[0])}
+        if strong and not a.no_latency:
+            # per-step latency of the sharded step (solve of the block + the all-gather), every rank taking part: max over ranks
+            ls = []
+            for _ in range(260):
+                t_a = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                ls.append(time.perf_counter() - t_a)
+            ls = np.array(ls[10:]) * 1e3
+            p50, p99 = ctx.reduce([float(np.percentile(ls, 50)), float(np.percentile(ls, 99))], "max")
+            step_lat = {"p50": p50, "p99": p99, "calls": int(len(ls)), "what": "solve of the rank's block + all-gather, enqueue -> readable, max over ranks"}
+    one_gpu = None
+    if whole is not None and not a.no_one_gpu_reference:
+        # the SAME global batch solved whole by rank 0's GPU alone (the other ranks wait at the barrier): the one-GPU figure of this very
+        # workload, so that the line carries its own strong-scaling reference
+        w_h, w_o, w_s = (to_dev(torch, x, dev) for x in (whole.hdr, whole.off, whole.sfc))
+        w_r = to_dev(torch, sol.rows_in_format(whole.rows), dev)
+        w_xi = None if a.cold_start else torch.from_numpy(api.x_init_from_swarm(whole.build, dim)).to(dev)
+        w_x, w_ob = torch.zeros(n_glob * nv, dtype=torch.float64, device=dev), torch.zeros(n_glob, dtype=torch.float64, device=dev)
+        w_st, w_in = torch.zeros(n_glob, dtype=torch.int32, device=dev), torch.zeros(n_glob * 32, dtype=torch.uint8, device=dev)
+        reps1 = max(5, min(a.steps, 20))
+        for _ in range(2):
+            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi)
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for _ in range(reps1):
+            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi)
+        torch.cuda.synchronize()
+        t_1 = (time.perf_counter() - t_a) / reps1
+        same = bool(torch.equal(w_x[lo * nv: hi * nv], d_x[: N * nv]))
+        one_gpu = {"qp_per_s": n_glob / t_1, "ms_per_step": t_1 * 1e3, "steps": reps1,
+                   "what": "the whole %d-agent batch on rank 0's GPU alone, no collective (wall clock, synchronised)" % n_glob,
+                   "rank0_block_bit_identical_to_sharded_solve": same}
+        del w_h, w_o, w_s, w_r, w_xi, w_x, w_ob, w_st, w_in
+    ctx.barrier()
+    return SimpleNamespace(a=a, api=api, sw=sw, sol=sol, build=build, hdr=hdr, rows=rows, off=off, sfc=sfc, N=N, M=M, dim=dim, nv=nv, n_obs_eff=n_obs_eff,
+                           n_glob=n_glob, n_pad=n_pad, strong=strong, d_hdr=d_hdr, d_rows=d_rows, d_off=d_off, d_sfc=d_sfc, d_xinit=d_xinit, d_x=d_x,
+                           d_obj=d_obj, d_st=d_st, d_info=d_info, d_all=d_all, elapsed=elapsed, kernel_ms=kernel_ms, status=status, iters=iters,
+                           n_bad=n_bad, n_floor=n_floor, iters_mean=it_sum / max(n_agents_seen, 1), iters_max=int(it_max), n_ranks_seen=n_ranks_seen,
+                           n_devices_seen=n_devices_seen, n_agents_seen=n_agents_seen, rank_parity=rank_parity, step_lat=step_lat, one_gpu=one_gpu,
+                           solve_only=solve_only)
+
+
+def check_ran_as_asked(ctx, a, S):
+    if S.n_ranks_seen != a.gpus or S.n_agents_seen != S.n_glob or (ctx.world > 1 and ctx.backend == "nccl" and S.n_devices_seen != ctx.world):
+        raise SystemExit("bench.py: asked for %d GPUs and %d agents per step; ran %d ranks on %d distinct devices solving %d agents" % (
+            a.gpus, S.n_glob, S.n_ranks_seen, S.n_devices_seen, S.n_agents_seen))
+
+
+def workload_config(ctx, a, S):
+    """The `config` object of a line: names the workload and what ran."""
+    cfg0 = CONFIGS[a.config]
+    gathered = S.d_all is not None
+    c = {
+        "workload": "%s -- %s x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
+                    "%s batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (
+                        cfg0["what"] if (a.agents, S.M, a.obs, S.dim) == (cfg0["agents"], cfg0["segments"], cfg0["obs"], cfg0["dim"]) else "custom shape",
+                        ("ONE batch of %d agents cut into blocks of <= %d per GPU" % (S.n_glob, S.n_pad)) if S.strong else ("%d agents/GPU" % S.N),
+                        S.M, S.n_obs_eff, S.dim, a.style, "fp64" if a.precision == "f64" else "mixed-precision"),
+        "baseline_config": a.config, "batch_seed": CONFIGS[a.config]["seed"], "precision": a.precision, "row_format": a.rows,
+        "collective_backend": ctx.coll_backend, "agents_per_gpu": S.n_pad, "agents_total": S.n_glob, "agents_solved_per_step_all_ranks": S.n_agents_seen,
+        "ranks": S.n_ranks_seen, "distinct_devices": S.n_devices_seen, "launch": "one process per GPU (torch.distributed)" if ctx.world > 1 else "single process",
+        "segments": S.M, "lsc_neighbours": S.n_obs_eff, "dim": S.dim,
+        "rows_per_qp": S.sol.num_inequalities(S.n_obs_eff), "allgather": bool(gathered), "pipeline": bool(a.pipeline), "hip_graph": bool(a.graph),
+        "warm_start": "initial_traj (shifted previous plan) as primal start" if S.d_xinit is not None else "none",
+        "parallelism": ("agents sharded over %d GPU(s), " % ctx.world) +
+                       ("one RCCL all-gather of the plans per step" if gathered else "no data-path collective"),
+    }
+    if S.strong:
+        # north_star: "RCCL all-gather ... only when agent count justifies it" -- the library's stated rule (lscqp_comm_devices_for:
+        # clamp(n / 256, 1, G)) next to what this run was TOLD to use
+        c["devices_by_crossover_rule"] = int(max(1, min(ctx.world, S.n_glob // 256)))
+        c["allgather_bytes_per_rank_per_step"] = int(S.n_pad * S.nv * 8)
+        c["allgather_bytes_received_per_rank_per_step"] = int(ctx.world * S.n_pad * S.nv * 8)
+    if S.one_gpu is not None:
+        c["one_gpu_same_workload"] = S.one_gpu
+    return c
+
+
+def workload_roofline(ctx, a, S):
+    bq = S.sol.algorithmic_bytes(S.n_obs_eff)
+    achieved = bq * S.N / (S.kernel_ms * 1e-3)
+    return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (S.M, S.dim, "float" if a.precision == "mixed" else "double"), "kernel_ms": S.kernel_ms,
+            "algorithmic_bytes_per_qp": bq, "qps_per_launch": S.N}
+
+
+def compact_block(ctx, a, S):
+    """One of the additional workloads of a multi-GPU line: the same quantities as the headline, without the single-GPU legs."""
+    check_ran_as_asked(ctx, a, S)
+    r = workload_roofline(ctx, a, S)
+    c = workload_config(ctx, a, S)
+    out = {"baseline_config": a.config, "scaling": a.scaling, "value": S.n_glob * a.steps / S.elapsed, "unit": "QP/s", "ms_per_step": S.elapsed / a.steps * 1e3,
+           "steps": a.steps, "warmup": a.warmup, "agents_total": S.n_glob, "agents_per_gpu": S.n_pad, "allgather": c["allgather"],
+           "collective_backend": ctx.coll_backend, "distinct_devices": S.n_devices_seen, "workload": c["workload"],
+           "hbm_frac_whole_job": r["algorithmic_bytes_per_qp"] * S.n_glob * a.steps / S.elapsed / (ctx.world * HBM_PEAK),
+           "kernel_ms": S.kernel_ms, "non_optimal": S.n_bad, "floor_accepted": S.n_floor, "iters_mean": S.iters_mean, "iters_max": S.iters_max}
+    for k in ("allgather_bytes_per_rank_per_step", "devices_by_crossover_rule", "one_gpu_same_workload"):
+        if k in c:
+            out[k] = c[k]
+    if S.rank_parity is not None:
+        out["parity_all_ranks"] = S.rank_parity
+    if S.step_lat is not None:
+        out["latency_ms"] = {"sharded_step": S.step_lat}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS), help="BASELINE config that is the timed workload (default c1 = the headline)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="BASELINE config that is the timed workload.  Default: c1 (the headline, configs[1]) on one GPU; with --gpus N > 1 the "
+                         "default is what BASELINE's multi-GPU configs name: c3 (1024 agents x M10 x 40) as ONE batch sharded over the ranks "
+                         "with the RCCL all-gather of the plans every step, followed by the c4-shape, c2 and weak-c1 blocks")
     ap.add_argument("--agents", type=int, default=None, help="agents per GPU per step (overrides the config's)")
     ap.add_argument("--segments", type=int, default=None)
     ap.add_argument("--obs", type=int, default=None)
@@ -509,22 +865,32 @@ def main():
                          "multi-kernel --pipeline step (single GPU only; no *_device entry point synchronises or allocates)")
     ap.add_argument("--cold-start", action="store_true", help="do not hand the initial trajectories to the solver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-size sweep")
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional blocks (one GPU: every BASELINE config at its own shape; "
+                                                            "N > 1: the c4-shape / c2 / weak-c1 workloads after the headline)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the latency loops (their launches would mix into a kernel trace of the timed steps)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): every rank owns --agents agents of its own swarm, no data-path collective.  strong: the "
-                         "config's agents are ONE global batch cut into contiguous blocks of ceil(N/G) (BASELINE configs[2..4]), "
-                         "the plans all-gathered every step")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: every rank owns --agents agents of its own swarm, no data-path collective.  strong: the config's agents are "
+                         "ONE global batch cut into contiguous blocks of ceil(N/G) (BASELINE configs[2..4]), the plans all-gathered every "
+                         "step.  Default: weak with an explicit --config or one GPU; strong for a bare --gpus N > 1")
     ap.add_argument("--single-process", action="store_true",
                     help="drive the --gpus devices from THIS process through lscqp_comm (ncclCommInitAll; one stream per device) "
                          "instead of one process per GPU; implies --scaling strong")
     ap.add_argument("--no-rank-parity", action="store_true", help="multi-rank runs: skip the per-rank oracle check of each rank's own block")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="strong scaling: skip rank 0's solve of the WHOLE batch on its own GPU (config.one_gpu_same_workload)")
     args = ap.parse_args()
-    if args.single_process:
-        args.scaling = "strong"
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    # what a bare `--gpus N` measures (north_star / BASELINE configs[2..4]): N = 1 the configs[1] headline; N > 1 the sharded
+    # configs[3] batch + all-gather as the line's value, then the other multi-GPU configs and the weak-c1 block
+    multi_default = args.gpus > 1 and args.config is None and args.scaling is None and not (args.single_process or args.pipeline or args.graph)
+    if args.config is None:
+        args.config = "c3" if multi_default else ("c2" if args.single_process else "c1")
+    if args.single_process:
+        args.scaling = "strong"
+    if args.scaling is None:
+        args.scaling = "strong" if multi_default else "weak"
     if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ:
         # started bare with --gpus N: launch one rank per GPU ourselves, exactly as the driver would
         raise SystemExit(launch_ranks(args.gpus))
@@ -566,20 +932,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-            try:  # the solve path has no collective; RCCL only carries the barrier, the timing reduction and --allgather
+            try:  # RCCL carries the barrier, the timing reduction and the all-gather of the plans
                 probe = torch.ones(1, device=dev)
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
                 assert int(probe.item()) == world
-            except Exception as e:  # RCCL unusable on this node: the measurement does not depend on it, keep going over gloo
-                sys.stderr.write("bench.py: RCCL probe failed (%s); falling back to gloo for barrier / reductions\n" % e)
+            except Exception as e:  # RCCL unusable on this node: keep going over gloo, and SAY so in the line
+                sys.stderr.write("bench.py: RCCL probe failed (%s); falling back to gloo for barrier / reductions / all-gather\n" % e)
                 try:
                     dist.destroy_process_group()
                 except Exception:
                     pass
                 os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-                coll_backend = "gloo (RCCL probe failed)"
+                coll_backend = "gloo (RCCL probe failed), %d ranks" % dist.get_world_size()
             else:
                 coll_backend = "rccl via torch.distributed nccl backend, %d ranks" % dist.get_world_size()
         else:
@@ -588,237 +954,68 @@ def main():
 
     from lsc_dr_planner_amd import api, synth
 
-    M, dim, n_obs, N = args.segments, args.dim, args.obs, args.agents
-
-    solver_kw = {}
-    if args.precision == "mixed":
-        solver_kw["precision"] = api.PRECISION_MIXED
-    if args.rows == "f32":
-        solver_kw["row_format"] = api.ROWS_F32
-
-    def solver_factory(sw):
-        return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **solver_kw))
-
-    strong = args.scaling == "strong"
-    if strong and (args.pipeline or args.graph):
-        raise SystemExit("bench.py: --scaling strong times the solve + all-gather step; --pipeline / --graph are weak-scaling options")
-    n_glob = N  # agents of the whole job's step: one global batch (strong) or `world` independent swarms of N (weak)
-    if strong:
-        # ONE swarm for the whole job, built identically on every rank (same seed; the warm-up replans are carried by the rank's
-        # own GPU), then cut: rank r owns the contiguous block shard_range(n_glob, world, r) (reference agent order, src/mission.cpp:140-153)
-        from lsc_dr_planner_amd import sharding
-
-        sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, n_glob, M, dim, n_obs, seed=1000, style=args.style, warm_steps=3)
-        lo, hi = sharding.shard_range(n_glob, world, rank)
-        per = -(-n_glob // world)
-        N = hi - lo
-        if N <= 0:
-            raise SystemExit("bench.py: rank %d owns no agent (%d agents over %d ranks)" % (rank, n_glob, world))
-        build = slice_build(build, n_glob, lo, hi)
-        hdr, sfc = hdr[lo:hi], sfc.reshape(n_glob, M)[lo:hi]
-        rows = rows.reshape(n_glob, -1)[lo:hi].reshape(-1)
-        off = np.arange(N + 1, dtype=np.uint64) * np.uint64(sw.n_obs * M * 6)
-    else:
-        sw, sol, build, (hdr, rows, off, sfc) = make_batch(api, synth, solver_factory, N, M, dim, n_obs, seed=1000 + rank,
-                                                           style=args.style, warm_steps=3)
-        n_glob = world * N
-    n_obs_eff = sw.n_obs
-    nv = sol.nv
-    d_hdr, d_off, d_sfc = (to_dev(torch, a, dev) for a in (hdr, off, sfc))
-    d_rows = to_dev(torch, sol.rows_in_format(rows), dev)
-    # TrajOptimizer::solve's initial_traj (the shifted previous plan): the solver's primal start
-    d_xinit = None if args.cold_start else torch.from_numpy(api.x_init_from_swarm(build, dim)).to(dev)
-    n_pad = per if strong else N  # equal blocks for the collective: the last block of a ragged split is padded (never solved)
-    d_x = torch.zeros(n_pad * nv, dtype=torch.float64, device=dev)
-    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
-    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
-    d_info = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
-    gather = (args.allgather or args.pipeline or strong) and world > 1
-    d_all = torch.zeros(world * n_pad * nv, dtype=torch.float64, device=dev) if gather else None
-    # gloo (test-only backend, ranks sharing a device) carries the all-gather through host memory
-    h_all = torch.zeros(world * n_pad * nv, dtype=torch.float64) if (gather and coll_backend.startswith("gloo")) else None
-
-    def all_gather_plans():
-        if h_all is None:
-            dist.all_gather_into_tensor(d_all, d_x)
-        else:
-            dist.all_gather_into_tensor(h_all, d_x.cpu())
-            d_all.copy_(h_all)
-    d_xwarm = torch.zeros(N * nv, dtype=torch.float64, device=dev)
-    if args.pipeline:
-        # every rank's swarm is independent (weak scaling); global agent id = rank * N + local id.  The rows are
-        # regenerated every step from the CURRENT plans of all agents (replanning from the same state: the previous
-        # plans satisfy the new rows by the supporting-hyperplane argument of SURVEY 8d), so the exchange is load bearing.
-        n_total = world * N
-        d_traj = torch.zeros(n_total * M * 6 * 3, dtype=torch.float64, device=dev)
-        d_nbr = torch.from_numpy((build["nbr"] + rank * N).astype(np.int32)).to(dev)
-        d_rad = torch.full((n_total,), sw.radius, dtype=torch.float64, device=dev)
-        d_dw = torch.full((n_total,), sw.downwash, dtype=torch.float64, device=dev)
-        d_goal = torch.from_numpy(np.ascontiguousarray(build["goal"], dtype=np.float64)).to(dev)
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)  # plans to start from
-        torch.cuda.synchronize()
-
-    def step():
-        if args.pipeline:
-            src = d_x
-            if d_all is not None:
-                all_gather_plans()
-                src = d_all
-            sol.shift_traj_device(world * N, src, d_traj, z_2d=float(build["p0"][0][2]), shift=0)
-            sol.generate_lsc_device(N, n_obs_eff, rank * N, d_traj, d_nbr, d_rad, d_dw, d_goal, d_rows)
-            if d_xinit is not None:
-                d_xwarm.copy_(d_x)  # the plans the rows were generated from are the primal start of the re-solve
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info,
-                         d_x_init=(d_xwarm if (args.pipeline and d_xinit is not None) else d_xinit))
-        if d_all is not None and not args.pipeline:
-            all_gather_plans()
-
-    if args.graph:
-        if world != 1:
-            raise SystemExit("--graph is a single-GPU option")
-        eager_step = step
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm up on the capture stream, as graph capture requires
-            for _ in range(3):
-                eager_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        hip_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(hip_graph, stream=side):
-            eager_step()
-        step = hip_graph.replay  # noqa: F811
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration on the launch stream
-    def reduce(vals, op):
-        """all-reduce of a few doubles over the ranks (host tensors under gloo, device tensors under RCCL)."""
-        if dist is None:
-            return [float(v) for v in vals]
-        t = torch.tensor(list(vals), dtype=torch.float64, device=("cpu" if coll_backend.startswith("gloo") else dev))
-        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
-        return [float(v) for v in t.cpu()]
-
-    if d_all is not None and not args.pipeline:
-        # roofline.kernel_ms is the SOLVE kernel's launch duration: time it without the exchange that shares the step's stream
-        ek0, ek1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ek0.record()
-        for _ in range(20):
-            sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
-        ek1.record()
-        torch.cuda.synchronize()
-        kernel_ms = ek0.elapsed_time(ek1) / 20
-    my_elapsed = elapsed
-    elapsed, kernel_ms = reduce([elapsed, kernel_ms], "max")
-
-    status = d_st.cpu().numpy()
-    iters = d_info.cpu().numpy().view(api.INFO_DTYPE)["iterations"]
-    n_bad = int(reduce([float((status != 0).sum())], "sum")[0])
-    n_ranks_seen, n_devices_seen, n_agents_seen = 1, 1, N
-    rank_parity = None
-    step_lat = None
-    if dist is not None:
-        # what actually ran: ranks, DISTINCT devices (by PCI bus id), agents solved per step over all ranks
-        bus = torch.cuda.get_device_properties(dev_index)
-        dev_id = hash((getattr(bus, "pci_bus_id", dev_index), getattr(bus, "pci_device_id", 0), getattr(bus, "pci_domain_id", 0), dev_index)) % (1 << 40)
-        ids = [None] * world
-        dist.all_gather_object(ids, (dev_id, N, my_elapsed))
-        n_ranks_seen, n_devices_seen, n_agents_seen = len(ids), len({i[0] for i in ids}), sum(i[1] for i in ids)
-        if d_all is not None and not args.pipeline:
-            # the exchange must have delivered every owner's block: compare this rank's view with its own block
-            mine = d_all.view(world, n_pad * nv)[rank][: N * nv]
-            if not torch.equal(mine, d_x[: N * nv]):
-                raise SystemExit("bench.py: rank %d: the all-gathered plans do not contain this rank's block" % rank)
-        if not args.no_rank_parity and not args.no_cpu_baseline and args.rows == "f64":
-            # every rank checks its OWN block against the oracle (a bounded sample: the oracle is a dense CPU solver)
-            from oracle import oracle as O
-
-            k = min(N, 16 if M < 10 else 6)
-            Rk, sel = oracle_sample(O, sw, build, M, dim, n_obs_eff, sample=k)
-            xg, og = d_x.cpu().numpy()[: N * nv].reshape(N, nv)[sel], d_obj.cpu().numpy()[sel]
-            ok = (Rk["status"] == 0) & (status[sel] == 0)
-            dxm = float(np.abs(xg - Rk["x"])[ok].max()) if ok.any() else float("inf")
-            dom = float((np.abs(og - Rk["obj"]) / np.maximum(1.0, np.abs(Rk["obj"])))[ok].max()) if ok.any() else float("inf")
-            dxm, dom = reduce([dxm, dom], "max")
-            rank_parity = {"max_abs_dx": dxm, "max_rel_dobj": dom, "compared_per_rank": int(k), "ranks": world,
-                           "compared": int(reduce([float(ok.sum())], "sum")[0])}
-        if strong and not args.no_latency:
-            # per-step latency of the sharded step (solve of the block + the all-gather), every rank taking part: max over ranks
-            ls = []
-            for _ in range(260):
-                a = time.perf_counter()
-                step()
-                torch.cuda.synchronize()
-                ls.append(time.perf_counter() - a)
-            ls = np.array(ls[10:]) * 1e3
-            p50, p99 = reduce([float(np.percentile(ls, 50)), float(np.percentile(ls, 99))], "max")
-            step_lat = {"p50": p50, "p99": p99, "calls": int(len(ls)), "what": "solve of the rank's block + all-gather, enqueue -> readable, max over ranks"}
-
+    ctx = Ctx(torch, dist, rank, world, dev_index, backend, coll_backend)
+    S = timed_workload(ctx, args)
+    # the other workloads of a bare multi-GPU run: every rank takes part, rank 0 keeps the blocks
+    more = []
+    if multi_default and not args.no_extra:
+        for key, scal in (("c4_f64", "strong"), ("c2", "strong"), ("c1", "weak")):
+            a2 = workload_args(args, key, scaling=scal, allgather=False, no_latency=True)
+            try:
+                more.append(compact_block(ctx, a2, timed_workload(ctx, a2)))
+            except Exception as ex:  # (a collective failure takes every rank here; a SystemExit ends the job, as it must)
+                more.append({"baseline_config": key, "scaling": scal, "error": "%s: %s" % (type(ex).__name__, str(ex)[:300])})
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
+    check_ran_as_asked(ctx, args, S)
+
+    sol, N, M, dim, nv, n_obs_eff, n_glob = S.sol, S.N, S.M, S.dim, S.nv, S.n_obs_eff, S.n_glob
+    d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_xinit = S.d_hdr, S.d_rows, S.d_off, S.d_sfc, S.d_x, S.d_obj, S.d_st, S.d_info, S.d_xinit
+    hdr, rows, off, sfc, build, sw, status, iters, kernel_ms, elapsed = S.hdr, S.rows, S.off, S.sfc, S.build, S.sw, S.status, S.iters, S.kernel_ms, S.elapsed
 
     # ---- single-launch latency distribution (enqueue -> results readable), device-resident inputs ----------
     n_lat, n_lath = (60, 60) if args.no_latency else (1050, 250)
     lat = []
     for _ in range(n_lat):  # SURVEY.md 8d: p50 / p99 over >= 1000 timed calls
-        a = time.perf_counter()
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+        t_a = time.perf_counter()
+        S.solve_only()
         torch.cuda.synchronize()
-        lat.append(time.perf_counter() - a)
+        lat.append(time.perf_counter() - t_a)
     lat = np.array(lat[50:]) * 1e3
     # batch-of-1 latency (the unchanged sequential simulator loop, src/multi_sync_simulator.cpp:357-362)
     lat1 = []
     for _ in range(n_lat if not args.no_latency else 0):
-        a = time.perf_counter()
+        t_a = time.perf_counter()
         sol.solve_device(1, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
         torch.cuda.synchronize()
-        lat1.append(time.perf_counter() - a)
+        lat1.append(time.perf_counter() - t_a)
     lat1 = np.array(lat1[50:] or [float('nan')]) * 1e3
     # the host-pointer entry (lscqp_solve_batch: H2D of the inputs, solve, D2H of the results) -- PCIe-inclusive, never `value`
     lath = []
     x0_host = None if d_xinit is None else d_xinit.cpu().numpy().reshape(N, nv)
     for _ in range(n_lath if not args.no_latency else 0):
-        a = time.perf_counter()
+        t_a = time.perf_counter()
         sol.solve_host(hdr, rows, off, sfc, want_info=False, x_init=x0_host)
-        lath.append(time.perf_counter() - a)
+        lath.append(time.perf_counter() - t_a)
     lath = np.array(lath[50:] or [float('nan')]) * 1e3
     # ... and for a single QP: what one TrajOptimizer::solve call of the unchanged sequential planner loop costs end to end
     lath1 = []
     for _ in range(n_lath if not args.no_latency else 0):
-        a = time.perf_counter()
+        t_a = time.perf_counter()
         sol.solve_host(hdr[:1], rows.reshape(N, -1)[0], off[:2], sfc.reshape(N, M)[:1], want_info=False,
                        x_init=None if x0_host is None else x0_host[:1])
-        lath1.append(time.perf_counter() - a)
+        lath1.append(time.perf_counter() - t_a)
     lath1 = np.array(lath1[50:] or [float('nan')]) * 1e3
-    sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+    S.solve_only()
     torch.cuda.synchronize()
 
-    bytes_per_qp = sol.algorithmic_bytes(n_obs_eff)
-    achieved = bytes_per_qp * N / (kernel_ms * 1e-3)
+    roof = workload_roofline(ctx, args, S)
     # HBM-side traffic per launch: PMC counters cannot be read from inside this process, so the value comes from the
     # committed rocprofv3 --pmc passes of THIS command (profiles/<tag>_<config>_pmc.json of the newest tag, numerically
     # sorted; tools/profile_round.py) and is only reported when kernel shape, precision and batch size match; otherwise null.
-    traffic, traffic_src, valu = None, None, None
+    traffic, traffic_src, valu, pm, pf = None, None, None, {}, None
     try:
         pf = newest_profile("*_%s_pmc.json" % args.config)
         pm = json.load(open(pf)) if pf else {}
@@ -839,9 +1036,25 @@ def main():
                         "source": "profiles/%s (rocprofv3 --pmc SQ_*)" % os.path.basename(pf)}
     except Exception:
         pass
-    if n_ranks_seen != args.gpus or n_agents_seen != n_glob or (world > 1 and backend == "nccl" and n_devices_seen != world):
-        raise SystemExit("bench.py: asked for %d GPUs and %d agents per step; ran %d ranks on %d distinct devices solving %d agents" % (
-            args.gpus, n_glob, n_ranks_seen, n_devices_seen, n_agents_seen))
+    roof.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "valu": valu})
+    rv = valu_roofline(sol, N, n_obs_eff, iters, kernel_ms) if args.precision == "f64" else None
+    if rv:  # the roof that binds, inside the object the driver keeps (the full record is `roofline_valu` below)
+        roof["fp64_valu"] = {"achieved_TFLOPs": rv["fp64_flops_per_s"] / 1e12, "peak_TFLOPs": FP64_VECTOR_PEAK / 1e12, "frac": rv["frac_of_78.6e12"],
+                             "flops_per_launch": rv["fp64_flops_per_launch"], "what": "fp64 vector flops of this launch (iterations of this run x "
+                             "machine-code count of the instance) / kernel_ms, against the fp64 vector peak"}
+    latency = {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
+               "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99)),
+               "host_pointers_batch_p50": float(np.percentile(lath, 50)), "host_pointers_batch_p99": float(np.percentile(lath, 99)),
+               "host_pointers_single_qp_p50": float(np.percentile(lath1, 50)), "host_pointers_single_qp_p99": float(np.percentile(lath1, 99)),
+               "samples": {"device_resident": int(len(lat)), "single_qp": int(len(lat1)), "host_pointers": int(len(lath))}}
+    if S.step_lat is not None:
+        latency["sharded_step"] = S.step_lat
+    conf = workload_config(ctx, args, S)
+    # BASELINE's metric is "QP solves/sec + p99 solve latency": the second half travels inside `config` (an object the driver keeps)
+    conf["latency_ms"] = ({"p50": S.step_lat["p50"], "p99": S.step_lat["p99"], "calls": S.step_lat["calls"], "of": "one sharded step: solve of the rank's block + "
+                           "all-gather, enqueue -> readable, max over ranks"} if S.step_lat is not None else
+                          {"p50": latency["batch_p50"], "p99": latency["batch_p99"], "calls": int(len(lat)),
+                           "of": "one %d-QP launch, enqueue -> results readable, device-resident inputs" % N})
     out = {
         "metric": "qp_solves_per_sec",
         "value": n_glob * args.steps / elapsed,
@@ -855,35 +1068,16 @@ def main():
         "vs_baseline": None,
         "dtype": "f64" if args.precision == "f64" else "f64 iterate and residuals, f32 factorisation",
         "data": "synthetic",
-        "config": {
-            "workload": "%s -- %s x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
-                        "%s batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (
-                            cfg0["what"] if (args.agents, M, n_obs, dim) == (cfg0["agents"], cfg0["segments"], cfg0["obs"], cfg0["dim"]) else "custom shape",
-                            ("ONE batch of %d agents cut into blocks of <= %d per GPU" % (n_glob, n_pad)) if strong else ("%d agents/GPU" % N),
-                            M, n_obs_eff, dim, args.style, "fp64" if args.precision == "f64" else "mixed-precision"),
-            "baseline_config": args.config, "precision": args.precision, "row_format": args.rows, "collective_backend": coll_backend,
-            "agents_per_gpu": n_pad, "agents_total": n_glob, "agents_solved_per_step_all_ranks": n_agents_seen,
-            "ranks": n_ranks_seen, "distinct_devices": n_devices_seen, "launch": "one process per GPU (torch.distributed)" if world > 1 else "single process",
-            "segments": M, "lsc_neighbours": n_obs_eff, "dim": dim,
-            "rows_per_qp": sol.num_inequalities(n_obs_eff), "allgather": bool(d_all is not None), "pipeline": bool(args.pipeline), "hip_graph": bool(args.graph),
-            "warm_start": "initial_traj (shifted previous plan) as primal start" if d_xinit is not None else "none",
-            "parallelism": ("agents sharded over %d GPU(s), " % world) +
-                           ("one RCCL all-gather of the plans per step" if d_all is not None else "no data-path collective"),
-        },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (M, dim, "float" if args.precision == "mixed" else "double"), "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_qp": bytes_per_qp, "qps_per_launch": N, "valu": valu,
-        },
-        "roofline_valu": valu_roofline(sol, N, n_obs_eff, iters, kernel_ms) if args.precision == "f64" else None,
-        "latency_ms": {"batch_p50": float(np.percentile(lat, 50)), "batch_p99": float(np.percentile(lat, 99)),
-                       "single_qp_p50": float(np.percentile(lat1, 50)), "single_qp_p99": float(np.percentile(lat1, 99)),
-                       "host_pointers_batch_p50": float(np.percentile(lath, 50)), "host_pointers_batch_p99": float(np.percentile(lath, 99)),
-                       "host_pointers_single_qp_p50": float(np.percentile(lath1, 50)), "host_pointers_single_qp_p99": float(np.percentile(lath1, 99)),
-                       "samples": {"device_resident": int(len(lat)), "single_qp": int(len(lat1)), "host_pointers": int(len(lath))}},
-        "solver": {"non_optimal": n_bad, "iters_mean": float(iters.mean()), "iters_max": int(iters.max())},
+        "config": conf,
+        "roofline": roof,
+        "roofline_valu": rv,
+        "latency_ms": latency,
+        "solver": {"non_optimal": S.n_bad, "floor_accepted": S.n_floor, "iters_mean": S.iters_mean, "iters_max": S.iters_max},
     }
+    if world > 1:
+        out["roofline"]["whole_job"] = {"achieved": roof["algorithmic_bytes_per_qp"] * out["value"] / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",
+                                        "frac": roof["algorithmic_bytes_per_qp"] * out["value"] / (world * HBM_PEAK),
+                                        "what": "QP/s x algorithmic bytes per QP over n_gpus x 8 TB/s (SURVEY.md 8d)"}
     try:  # hardware cross-check of the machine-code count, from the committed PMC pass of this command (labelled as such)
         if out.get("roofline_valu") and pm.get("f64_flops_per_launch_pmc") and pm.get("qps_per_launch") == N:
             out["roofline_valu"]["pmc_cross_check"] = {
@@ -892,64 +1086,22 @@ def main():
                 "note": "valid while the iteration counts of this run equal the profiled run's (same seeds: they do)"}
     except Exception:
         pass
-    if rank_parity is not None:
-        out["parity_all_ranks"] = rank_parity
-    if step_lat is not None:
-        out["latency_ms"]["sharded_step"] = step_lat
-    if strong:
-        # north_star: "RCCL all-gather ... only when agent count justifies it" -- the library's stated rule (lscqp_comm_devices_for:
-        # clamp(n / 256, 1, G)) next to what this run was TOLD to use
-        out["config"]["devices_by_crossover_rule"] = int(max(1, min(world, n_glob // 256)))
-        out["config"]["allgather_bytes_per_rank_per_step"] = int(n_pad * nv * 8)
+    if S.rank_parity is not None:
+        out["parity_all_ranks"] = S.rank_parity
+    if more:
+        out["other_workloads"] = more
 
     # ---- CPU baseline: the oracle port on the same batch, all host cores --------------------------------------
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
 
-        cls = O.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
-        ag = np.zeros(N, O.AGENT_DTYPE)
-        for f in ("p0", "v0", "a0", "goal", "next_waypoint"):
-            ag[f] = build[f]
-        ag["vmax"], ag["amax"], ag["radius"], ag["nominal_velocity"], ag["n_obs"] = 1.0, 2.0, 0.15, 1.0, n_obs_eff
-        lsc = np.ascontiguousarray(build["lsc"]).reshape(-1)
-        loff = np.arange(N) * n_obs_eff * M * 6
-        sfc_o = np.ascontiguousarray(build["sfc"]).reshape(-1)
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        # the box may expose many logical CPUs behind a smaller quota: time a few thread counts, keep the fastest
-        best = None
-        for th in sorted({1, 4, 8, 16, 32, min(64, avail), min(N, avail)}):
-            if th > avail:
-                continue
-            O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=th)  # warm
-            a = time.perf_counter()
-            O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=th)
-            dtm = time.perf_counter() - a
-            if best is None or dtm < best[1]:
-                best = (th, dtm)
-        cores = best[0]
-        reps, tcpu, R = 0, 0.0, None
-        a = time.perf_counter()
-        while tcpu < 3.0 and reps < 200:
-            R = O.solve_batch(cls, ag, lsc, loff, sfc_o, threads=cores)
-            reps += 1
-            tcpu = time.perf_counter() - a
-        t1c = 1e30  # single core: the first 16 QPs, best of 5 (a lone 30 ms sample is at the mercy of the host's clock ramp)
-        for _ in range(5):
-            a1 = time.perf_counter()
-            O.solve_batch(cls, ag[:16], lsc, loff[:16], sfc_o, threads=1)
-            t1c = min(t1c, time.perf_counter() - a1)
-        xg = d_x.cpu().numpy().reshape(N, nv)
-        og = d_obj.cpu().numpy()
-        ok = (R["status"] == 0) & (status == 0)
-        out["cpu_baseline"] = {
-            "value": N * reps / tcpu, "unit": "QP/s", "cores": cores, "kind": "port",
-            "sample": "the same %d-QP batch solved %d times by oracle/lscqp_oracle.c (dense fp64 PDIP, OpenMP over "
-                      "agents, best of several thread counts = %d threads of %d visible CPUs, %.1f s); single core: "
-                      "%.1f QP/s" % (N, reps, cores, avail, tcpu, 16 / t1c),
-            "single_core_value": 16 / t1c,
-            "reference_published": "CPLEX 20.1, 6 threads: 4.58-6.64 ms/QP (151-218 QP/s) at M=10 dim=2 <=9 neighbours "
-                                   "(reference log/summary_LSC_10agents.csv)",
-        }
+        cpu, R, sel = oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample=N if N <= 64 else (64 if M < 10 else 32), budget_s=3.0, single_core=True)
+        cpu["reference_published"] = ("CPLEX 20.1, 6 threads: 4.58-6.64 ms/QP (151-218 QP/s) at M=10 dim=2 <=9 neighbours "
+                                      "(reference log/summary_LSC_10agents.csv)")
+        out["cpu_baseline"] = cpu
+        xg = d_x.cpu().numpy()[: N * nv].reshape(N, nv)[sel]
+        og = d_obj.cpu().numpy()[sel]
+        ok = (R["status"] == 0) & (status[sel] == 0)
         out["parity"] = {
             "max_abs_dx": float(np.abs(xg - R["x"])[ok].max()),
             "max_rel_dobj": float((np.abs(og - R["obj"]) / np.maximum(1.0, np.abs(R["obj"])))[ok].max()),
@@ -991,7 +1143,7 @@ def main():
             t = measure_config(torch, api, synth, dev, "c1", dict(CONFIGS["c1"], what="configs[1] shape forced onto the run-time-shaped kernel"), O=None, lat_seconds=0.5)
             gk["c1_shape_forced"] = {k: t[k] for k in ("kernel_ms", "qp_per_s", "iters_mean", "iters_max", "non_optimal")}
             os.environ.pop("LSCQP_FORCE_GENERIC")
-            t = measure_config(torch, api, synth, dev, "n64", dict(agents=128, segments=5, obs=64, dim=3, style="forest", precision="f64", rows="f64",
+            t = measure_config(torch, api, synth, dev, "n64", dict(agents=128, segments=5, obs=64, dim=3, style="forest", precision="f64", rows="f64", seed=3133,
                                                                   what="128 agents x M=5 x 64 LSC neighbours (beyond every compiled instance)"), O=None, lat_seconds=0.5)
             gk["m5_64_neighbours"] = {k: t[k] for k in ("kernel_ms", "qp_per_s", "iters_mean", "iters_max", "non_optimal", "lsc_neighbours")}
             gk["compiled_instance_at_c1"] = by.get("c1", {}).get("kernel_ms") or out["roofline"]["kernel_ms"]

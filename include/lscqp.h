@@ -318,6 +318,24 @@ int lscqp_solve_batch_sharded_device(lscqp_handle h, lscqp_comm c, const int64_t
                                      const double* const* d_x_init, double* const* d_x_out, double* const* d_obj_out,
                                      int32_t* const* d_status_out, lscqp_info* const* d_info_out, int32_t retry);
 int lscqp_allgather(lscqp_comm c, const double* const* d_send, double* const* d_recv, int64_t count);
+/* The exchange that follows a sharded replan, as a list of collective operations (no device needed: this is the bookkeeping
+ * lscqp_plan_group_step executes over RCCL, exported so that it can be checked for any device count on a host without GPUs).
+ * Device g owns agents [first[g], first[g] + count[g]) of n_total; the blocks must be consecutive in device order and cover the
+ * mission (LSCQP_ERR_INVALID_ARGUMENT otherwise).  Every device holds a buffer of n_total * per doubles in agent order and has
+ * just rewritten its own block.  Equal blocks: ONE in-place all-gather (kind LSCQP_XCHG_ALLGATHER: every device sends `count`
+ * doubles from `offset_of_device[g] = first[g] * per`, block g lands at first[g] * per on every device).  A short or empty last
+ * block: one broadcast per NON-EMPTY owner (kind LSCQP_XCHG_BROADCAST, root = the owner, `offset` / `count` in doubles), empty
+ * owners are skipped by every device alike.  Returns the number of operations in *n_ops (<= n_devices). */
+#define LSCQP_XCHG_ALLGATHER 0
+#define LSCQP_XCHG_BROADCAST 1
+typedef struct lscqp_exchange_op {
+    int32_t kind; /* LSCQP_XCHG_* */
+    int32_t root; /* broadcast: the owner; all-gather: -1 */
+    int64_t offset; /* doubles from the start of the buffer: broadcast: the owner's block; all-gather: 0 (block g at g * count) */
+    int64_t count;  /* doubles: broadcast: the owner's block; all-gather: the (equal) block of every device */
+} lscqp_exchange_op;
+int lscqp_exchange_schedule(int64_t n_total, int32_t n_devices, const int64_t* first, const int64_t* count, int64_t per,
+                            lscqp_exchange_op* ops, int32_t max_ops, int32_t* n_ops);
 
 /* ---- next row of the path: the producer of the LSC rows --------------------------------
  *
@@ -639,7 +657,10 @@ int lscqp_plan_download(lscqp_plan plan, int32_t which, void* host, uint64_t off
 int lscqp_plan_step(lscqp_plan plan, void* stream);
 /* The same through a hipGraph captured at the first call that is not a first replan (that one runs eagerly: it differs, and it
  * warms the kernels' one-time attributes up).  Results are bit-for-bit those of lscqp_plan_step.  The captured launches carry the
- * solver class by value: after lscqp_update on the handle the plan has to be destroyed and created again. */
+ * solver class by value; the plan notices lscqp_update(h) / lscqp_map_prepare(map) by their generation counters, drops the graph and
+ * re-captures at the next call (both step entry points).  An update that changes the SHAPE the plan was sized for -- segments,
+ * dimension, corridor rows on/off, row format, a neighbour capacity below desc.n_obs, dt below desc.time_step -- is refused with
+ * LSCQP_ERR_INVALID_ARGUMENT at the next step: such a plan has to be destroyed and created again. */
 int lscqp_plan_step_graph(lscqp_plan plan, void* stream);
 int64_t lscqp_plan_graph_nodes(lscqp_plan plan); /* nodes of the captured graph, 0 before the capture */
 /* One replan of a mission spread over the devices of a communicator (section 8e): plans[g] was created with device g of `c` current

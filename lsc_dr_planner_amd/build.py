@@ -130,13 +130,20 @@ def _work_table(inst_objs, work_o, jobs=None):
     import isa_work
 
     def one(o):
+        # reporting only (lscqp_instance_work): an instance whose machine code cannot be read (another ROCm layout, markers moved
+        # or duplicated by the compiler) gets NO row -- lscqp_work_table_ then returns 1 and the API answers UNSUPPORTED for it --
+        # and never stops the library from linking
         js = o[:-2] + ".work.json"
-        if not _newer(js, [o, os.path.join(HERE, "isa_work.py")]):
-            return json.load(open(js))
-        with tempfile.TemporaryDirectory() as td:
-            w = isa_work.of_object(o, td)
-        json.dump(w, open(js, "w"))
-        return w
+        try:
+            if not _newer(js, [o, os.path.join(HERE, "isa_work.py")]):
+                return json.load(open(js))
+            with tempfile.TemporaryDirectory() as td:
+                w = isa_work.of_object(o, td)
+            json.dump(w, open(js, "w"))
+            return w
+        except Exception as ex:  # noqa: BLE001
+            sys.stderr.write("build.py: warning: no work counters for %s (%s: %s)\n" % (os.path.basename(o), type(ex).__name__, str(ex)[:200]))
+            return None
 
     with ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
         works = list(ex.map(one, inst_objs))
@@ -144,7 +151,10 @@ def _work_table(inst_objs, work_o, jobs=None):
     with open(src, "w") as f:
         f.write("// generated by lsc_dr_planner_amd/build.py from the instances' machine code (isa_work.py); per wavefront\n")
         f.write("struct Row { int M, D, E, S, W, X; double t[24]; };\nstatic const Row kRows[] = {\n")
+        f.write("    {-1, -1, -1, -1, -1, -1, {0}},\n")  # (keeps the array non-empty when no instance could be read)
         for o, w in zip(inst_objs, works):
+            if w is None:
+                continue
             key = os.path.basename(o)[5:-2].split("_")
             # per section: instructions every wavefront runs (fma, other fp64, valu, lds), then the ones only SOME wavefronts run, summed
             # over those wavefronts (nested-dissection instances)

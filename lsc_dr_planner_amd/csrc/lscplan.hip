@@ -316,11 +316,36 @@ int refresh(lscqp_plan_s* p) {
     const uint64_t hg = lscqp_handle_generation_(p->h), mg = p->map ? lscqp_map_generation_(p->map) : 0;
     if (hg == p->h_gen && mg == p->map_gen) return LSCQP_OK;
     drop_graph(p);
-    if (p->own_hq && hg != p->h_gen) {
-        lscqp_class_desc cd = *lscqp_class_desc_of_(p->h);
-        cd.warm_start = LSCQP_WARM_TIGHT;
-        const int rc = lscqp_update(p->hq, &cd);
-        if (rc != LSCQP_OK) return rc;
+    if (hg != p->h_gen) {
+        // the buffers and the launch shapes of prepare / commit were sized at lscqp_plan_create: an update that changes the SHAPE of the
+        // class (segments, dimension, corridor rows on / off, row format, a kernel capacity below the plan's neighbour slots) cannot be
+        // followed -- refuse the step instead of reading and writing x_new / x_init / rows out of bounds.  Such a plan has to be
+        // destroyed and created again; every other field of the class (weights, dt-independent limits, modes) is followed.
+        const lscqp_class_desc* now = lscqp_class_desc_of_(p->h);
+        const int M = lscqp_num_segments(p->h), nv = lscqp_num_variables(p->h);
+        if (M != p->s.M || nv != p->s.nv || (lscqp_uses_sfc(p->h) != 0) != (p->map != nullptr) || lscqp_max_obstacles(p->h) < p->s.n_obs ||
+            lscqp_row_bytes(p->h) != (int)sizeof(lscqp_row) || !(p->d.time_step <= now->dt * (1 + 1e-9)))
+            return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT,
+                                    "lscqp_update changed the shape of the class (segments / dimension / corridor rows / row format / neighbour "
+                                    "capacity / dt below the plan's time_step) under a live plan: destroy the plan and create it again");
+        p->s.dt = now->dt;
+        lscqp_class_desc cd = *now;
+        if (p->d.tight_warm_start && cd.warm_start != LSCQP_WARM_TIGHT) {
+            cd.warm_start = LSCQP_WARM_TIGHT;
+            if (p->own_hq) {
+                const int rc = lscqp_update(p->hq, &cd);
+                if (rc != LSCQP_OK) return rc;
+            } else {  // h was WARM_TIGHT itself when the plan was made and no longer is: the clone becomes necessary now
+                lscqp_handle hq = nullptr;
+                const int rc = lscqp_create(&cd, &hq);
+                if (rc != LSCQP_OK) return rc;
+                p->hq = hq;
+                p->own_hq = true;
+            }
+        } else if (p->own_hq) {  // h became WARM_TIGHT itself: the clone only has to follow it
+            const int rc = lscqp_update(p->hq, &cd);
+            if (rc != LSCQP_OK) return rc;
+        }
     }
     p->h_gen = hg;
     p->map_gen = mg;

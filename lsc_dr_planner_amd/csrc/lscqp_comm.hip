@@ -202,6 +202,33 @@ int lscqp_shard_range(int64_t n, int32_t n_used, int32_t g, int64_t* first, int6
     return LSCQP_OK;
 }
 
+int lscqp_exchange_schedule(int64_t n_total, int32_t n_devices, const int64_t* first, const int64_t* count, int64_t per,
+                            lscqp_exchange_op* ops, int32_t max_ops, int32_t* n_ops) {
+    if (!first || !count || !ops || !n_ops || n_devices < 1 || n_total < 0 || per < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "bad exchange query");
+    int64_t next = 0;
+    bool equal = true;
+    for (int g = 0; g < n_devices; g++) {
+        if (count[g] < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative block size");
+        if (first[g] != next) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the plans of a group own consecutive blocks of agents in device order");
+        next += count[g];
+        if (count[g] != count[0]) equal = false;
+    }
+    if (next != n_total) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the blocks of the group do not cover the mission (sum of n_agents != n_total)");
+    int k = 0;
+    if (equal) {
+        if (max_ops < 1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "ops array too small");
+        ops[k++] = {LSCQP_XCHG_ALLGATHER, -1, 0, count[0] * per};
+    } else {
+        for (int o = 0; o < n_devices; o++) {
+            if (count[o] == 0) continue;  // an empty block owns nothing (every device skips it alike)
+            if (k >= max_ops) return fail(LSCQP_ERR_INVALID_ARGUMENT, "ops array too small");
+            ops[k++] = {LSCQP_XCHG_BROADCAST, o, first[o] * per, count[o] * per};
+        }
+    }
+    *n_ops = k;
+    return LSCQP_OK;
+}
+
 int lscqp_comm_shard(lscqp_comm c, int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count) {
     if (!c || n_used > c->G || g >= c->G) return fail(LSCQP_ERR_INVALID_ARGUMENT, "bad shard query");
     return lscqp_shard_range(n, n_used, g, first, count);
@@ -389,8 +416,8 @@ int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lsc
 int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_graph) {
     if (!c || !plans) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
     const int G = c->G;
-    int64_t next = 0, n_total = -1;
-    bool equal = true;
+    int64_t n_total = -1;
+    std::vector<int64_t> first(G), count(G);
     for (int g = 0; g < G; g++) {
         if (!plans[g]) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null plan in the group (one plan per device of the communicator)");
         const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[g]);
@@ -398,12 +425,16 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
             return fail(LSCQP_ERR_INVALID_ARGUMENT, "plan g of the group must live on device g of the communicator");
         if (n_total < 0) n_total = d->n_total;
         if (d->n_total != n_total) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the plans of a group describe the same mission: n_total differs");
-        if (d->first_agent != next)
-            return fail(LSCQP_ERR_INVALID_ARGUMENT, "the plans of a group own consecutive blocks of agents in device order");
-        next += d->n_agents;
-        if (d->n_agents != lscqp_plan_desc_of_(plans[0])->n_agents) equal = false;
+        first[g] = d->first_agent;
+        count[g] = d->n_agents;
     }
-    if (next != n_total) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the blocks of the group do not cover the mission (sum of n_agents != n_total)");
+    // the exchange as a list of operations in AGENTS (per = 1; scaled by each buffer's doubles per agent below)
+    std::vector<lscqp_exchange_op> ops(G);
+    int32_t n_ops = 0;
+    {
+        const int rc = lscqp_exchange_schedule(n_total, G, first.data(), count.data(), 1, ops.data(), G, &n_ops);
+        if (rc != LSCQP_OK) return rc;
+    }
     DeviceGuard dg;
     std::lock_guard<std::mutex> lk(c->mu);
     for (int g = 0; g < G; g++) {
@@ -430,15 +461,13 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
             uint64_t bytes = 0;
             double* const base = (double*)lscqp_plan_buffer(plans[g], kExchanged[b], &bytes);
             const size_t per = (size_t)(bytes / sizeof(double) / (uint64_t)n_total);  // doubles per agent
-            if (equal) {
-                const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[g]);
-                r = c->rccl.AllGather(base + (size_t)d->first_agent * per, base, (size_t)d->n_agents * per, ncclDouble, c->comms[g], c->stream[g]);
-            } else {
-                for (int o = 0; o < G && r == ncclSuccess; o++) {
-                    const lscqp_plan_desc* d = lscqp_plan_desc_of_(plans[o]);
-                    if (d->n_agents == 0) continue;  // an empty block owns nothing (every rank skips it alike)
-                    double* const blk = base + (size_t)d->first_agent * per;
-                    r = c->rccl.Broadcast(blk, blk, (size_t)d->n_agents * per, ncclDouble, o, c->comms[g], c->stream[g]);
+            for (int k = 0; k < n_ops && r == ncclSuccess; k++) {
+                const lscqp_exchange_op& op = ops[k];
+                if (op.kind == LSCQP_XCHG_ALLGATHER) {  // in place: device g's own block is where the all-gather puts it
+                    r = c->rccl.AllGather(base + (size_t)first[g] * per, base, (size_t)op.count * per, ncclDouble, c->comms[g], c->stream[g]);
+                } else {
+                    double* const blk = base + (size_t)op.offset * per;
+                    r = c->rccl.Broadcast(blk, blk, (size_t)op.count * per, ncclDouble, op.root, c->comms[g], c->stream[g]);
                 }
             }
         }

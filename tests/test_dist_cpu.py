@@ -105,3 +105,58 @@ def test_two_rank_gloo_exchange_of_plan_buffers(tmp_path):
     assert np.array_equal(b0, b1)
     want = np.concatenate([np.arange(n_total * per, dtype=np.float64) + 1000.0 * per for per in (120, 9, 3)])
     assert np.array_equal(b0, want)
+
+
+def _apply_exchange(bufs, ops, first, per):
+    """What RCCL does with the operations of lscqp_exchange_schedule, on host arrays (one per device)."""
+    from lsc_dr_planner_amd import api
+
+    G = len(bufs)
+    for op in ops:
+        if op["kind"] == api.XCHG_ALLGATHER:  # in place: device g sends `count` doubles from its own block, block o lands at o * count
+            sent = [bufs[g][first[g] * per: first[g] * per + op["count"]].copy() for g in range(G)]
+            for g in range(G):
+                for o in range(G):
+                    bufs[g][o * op["count"]: (o + 1) * op["count"]] = sent[o]
+        else:
+            src = bufs[op["root"]][op["offset"]: op["offset"] + op["count"]].copy()
+            for g in range(G):
+                bufs[g][op["offset"]: op["offset"] + op["count"]] = src
+
+
+def test_exchange_schedule_delivers_every_owners_block_for_any_device_count(api):
+    """The bookkeeping of the sharded replan's exchange (lscqp_plan_group_step / the bench's all-gather) for G in {2, 3, 4, 8} devices and
+    agent counts that split evenly, raggedly, and leave devices EMPTY -- without a device: lscqp_shard_range cuts the mission,
+    lscqp_exchange_schedule turns the blocks into collectives, the collectives are played on host arrays: afterwards every device
+    holds every owner's block, nothing out of bounds, an empty owner never roots a broadcast."""
+    rng = np.random.default_rng(3)
+    for G in (1, 2, 3, 4, 8):
+        for n in sorted({1, 2, G - 1, G, G + 1, 9, 10, 64, 512, 1000, 1024, 4096} - {0}):
+            for per in (1, 3, 90):
+                blocks = [api.shard_range(n, G, g) for g in range(G)]
+                first, count = [b[0] for b in blocks], [b[1] for b in blocks]
+                assert first[0] == 0 and sum(count) == n and all(first[g + 1] == first[g] + count[g] for g in range(G - 1))
+                assert max(count) == -(-n // G)  # contiguous blocks of ceil(N / G), SURVEY.md section 8e
+                ops = api.exchange_schedule(n, first, count, per)
+                truth = rng.standard_normal(n * per)
+                bufs = []
+                for g in range(G):  # device g holds stale data everywhere but in its own, freshly written block
+                    b = rng.standard_normal(n * per)
+                    b[first[g] * per: (first[g] + count[g]) * per] = truth[first[g] * per: (first[g] + count[g]) * per]
+                    bufs.append(b)
+                equal = len(set(count)) == 1
+                if equal:
+                    assert len(ops) == 1 and ops[0]["kind"] == api.XCHG_ALLGATHER and ops[0]["count"] == count[0] * per
+                else:
+                    assert all(o["kind"] == api.XCHG_BROADCAST for o in ops) and [int(o["root"]) for o in ops] == [g for g in range(G) if count[g] > 0]
+                    for o in ops:
+                        assert o["offset"] == first[o["root"]] * per and o["count"] == count[o["root"]] * per and o["offset"] + o["count"] <= n * per
+                _apply_exchange(bufs, ops, first, per)
+                for g in range(G):
+                    assert np.array_equal(bufs[g], truth), (G, n, per, g)
+    # blocks that do not tile the mission are refused
+    import pytest
+
+    for first, count in (([0, 5], [4, 5]), ([0, 4], [4, 5]), ([1, 5], [4, 5])):
+        with pytest.raises(api.LscqpError):
+            api.exchange_schedule(10, first, count, 1)

