@@ -485,7 +485,7 @@ int lscqp_validate_step_device(lscqp_handle h, int64_t n, double time_step, doub
  * (ellipsoidalDistance, include/util.hpp:155-159, radius-weighted downwash :505-507) and the positive parts of
  * (v_k - max_vel_k) / max_vel_k, (a_k - max_acc_k) / max_acc_k (:560-572).  States are Trajectory::getStateAt of the
  * float32 control points.  The mission-wide figures are the min / max of these per-agent records (over ranks: one
- * MIN / MAX all-reduce).  Obstacle safety ratios (:530-557) need the obstacle models, which are out of scope.
+ * MIN / MAX all-reduce).  The obstacle safety ratio (:527-557) is lscqp_safety_obstacles_device below.
  *   d_x_all [n_total][dim*M*(n+1)]  every agent's current plan (x_out of the solve, all-gathered)
  *   d_radius, d_downwash [n_total]   d_hdr [n_agents] (max_vel / max_acc)   d_out [n_agents] */
 typedef struct lscqp_safety {
@@ -498,6 +498,25 @@ typedef struct lscqp_safety {
 int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_samples,
                                 double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
                                 const double* d_downwash, const lscqp_header* d_hdr, lscqp_safety* d_out, void* stream);
+/* The OBSTACLE leg of the same loop (src/multi_sync_simulator.cpp:527-557): per local agent the minimum, over the samples of its plan
+ * and over the obstacles of the mission, of ellipsoidalDistance(agent position, obstacle position, downwash) / (r_i + r_o) with the
+ * mixed downwash (r_o dw_o + r_i dw_i) / (r_i + r_o) (:538-540, include/util.hpp:155-159).  The obstacle table is the one the
+ * constraint generator takes (lscqp_obstacle: position, radius, downwash are read); positions are the obstacle generator's CURRENT
+ * ones, the same for every sample (:534 -- only the agents move along future_time), narrowed to float32 like point3d.  Entries with
+ * type == LSCQP_OBSTACLE_REAL are skipped (:531-532: "real" obstacles are tracked robots, not simulated ones).  safety_ratio_obs is
+ * +inf and closest_obstacle -1 when nothing was compared (SP_INFINITY in the reference).  MIN over ranks gives the mission's figure.
+ *   d_x_all [n_total][dim*M*(n+1)], d_radius / d_downwash [n_total] (only the local agents' entries are read), d_obstacles [n_obstacles],
+ *   d_out [n_agents] */
+#define LSCQP_OBSTACLE_REAL 2
+typedef struct lscqp_safety_obs {
+    double safety_ratio_obs;  /* min over samples and obstacles */
+    int32_t closest_obstacle; /* index into d_obstacles attaining it (first sample, then smallest index: the reference's strict <) */
+    int32_t sample;
+} lscqp_safety_obs;
+int lscqp_safety_obstacles_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_samples,
+                                  double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
+                                  const double* d_downwash, int32_t n_obstacles, const lscqp_obstacle* d_obstacles,
+                                  lscqp_safety_obs* d_out, void* stream);
 
 /* ---- next row of the path: the producer of the SFC boxes -----------------------------------
  *

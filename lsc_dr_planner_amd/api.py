@@ -32,6 +32,8 @@ ROWS_F64, ROWS_F32 = 0, 1
 BOX_DTYPE = np.dtype([("bmin", "f8", 3), ("bmax", "f8", 3)])
 SAFETY_DTYPE = np.dtype([("safety_ratio", "f8"), ("closest_agent", "i4"), ("sample", "i4"), ("vel_excess_ratio", "f8", 3),
                          ("acc_excess_ratio", "f8", 3)])
+SAFETY_OBS_DTYPE = np.dtype([("safety_ratio_obs", "f8"), ("closest_obstacle", "i4"), ("sample", "i4")])  # lscqp_safety_obs
+OBSTACLE_REAL = 2
 OBSTACLE_DTYPE = np.dtype([("position", "f8", 3), ("velocity", "f8", 3), ("radius", "f8"), ("downwash", "f8"), ("max_acc", "f8"),
                            ("type", "i4"), ("reserved", "i4")])  # lscqp_obstacle
 
@@ -168,6 +170,8 @@ def lib():
         L.lscqp_optimize_goal.argtypes = [vp, C.c_int64] + [vp] * 5
         L.lscqp_safety_metrics_device.restype = C.c_int
         L.lscqp_safety_metrics_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double] + [vp] * 6
+        L.lscqp_safety_obstacles_device.restype = C.c_int
+        L.lscqp_safety_obstacles_device.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.lscqp_map_create.restype = C.c_int
         L.lscqp_map_create.argtypes = [vp, C.c_int64, vp, vp, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
         L.lscqp_map_create_from_csv.restype = C.c_int
@@ -228,7 +232,7 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_shift_traj_partial_device", "lscqp_generate_constraints_device_ex",
                     "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
-                    "lscqp_map_download", "lscqp_map_prepare", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device",
+                    "lscqp_map_download", "lscqp_map_prepare", "lscqp_construct_sfc_device", "lscqp_construct_sfc", "lscqp_safety_metrics_device", "lscqp_safety_obstacles_device",
                     "lscqp_plan_create", "lscqp_plan_destroy", "lscqp_plan_reset", "lscqp_plan_buffer", "lscqp_plan_upload", "lscqp_plan_download",
                     "lscqp_plan_step", "lscqp_plan_step_graph", "lscqp_plan_graph_nodes", "lscqp_plan_group_step",
                     "lscqp_instance_work", "lscqp_diagnose", "lscqp_diagnose_device", "lscqp_dump_instance", "lscqp_row_family_name",
@@ -727,6 +731,19 @@ class Solver:
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         rc = lib().lscqp_safety_metrics_device(self._h, n_agents, first_agent, n_total, int(n_samples), float(record_time_step), float(z_2d),
                                                p(d_x_all), p(d_radius), p(d_downwash), p(d_hdr), p(d_out), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def safety_obstacles_device(self, n_agents, first_agent, n_total, n_samples, record_time_step, d_x_all, d_radius, d_downwash, n_obstacles,
+                                d_obstacles, d_out, z_2d=1.0, stream=None):
+        """MultiSyncSimulator::update's obstacle safety ratio per local agent (SAFETY_OBS_DTYPE records in d_out; d_obstacles: OBSTACLE_DTYPE)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)  # noqa: E731
+        rc = lib().lscqp_safety_obstacles_device(self._h, n_agents, first_agent, n_total, int(n_samples), float(record_time_step), float(z_2d),
+                                                 p(d_x_all), p(d_radius), p(d_downwash), int(n_obstacles), p(d_obstacles), p(d_out),
+                                                 C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

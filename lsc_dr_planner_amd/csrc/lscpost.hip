@@ -276,9 +276,67 @@ __global__ __launch_bounds__(kSafT) void safety_metrics_kernel(int M, int dim, d
     }
 }
 
+// The obstacle leg of the same loop (src/multi_sync_simulator.cpp:527-557).  A mission has a handful of obstacles (mission.on) against
+// up to thousands of agents: one lane per agent, every lane walks the samples of its own plan and the obstacle table (uniform
+// addresses: scalar loads).  IEEE division and square root (few pairs: the agent-agent kernel's fast
+// reciprocals buy nothing here), so the figures are bit-for-bit the double arithmetic of the reference's expression.
+constexpr int kObsT = 256;
+__global__ __launch_bounds__(kObsT) void safety_obstacles_kernel(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int n_samples,
+                                                                 double record_time_step, double z_2d, const double* __restrict__ x_all,
+                                                                 const double* __restrict__ radius, const double* __restrict__ downwash,
+                                                                 int n_obstacles, const lscqp_obstacle* __restrict__ obs,
+                                                                 lscqp_safety_obs* __restrict__ out) {
+    const int64_t a = (int64_t)blockIdx.x * kObsT + threadIdx.x;
+    if (a >= n_agents) return;
+    const int64_t gi = first_agent + a;
+    const int nv = dim * 6 * M;
+    const double ri = radius[gi], dri = ri * downwash[gi];
+    double best = INFINITY;
+    int bo = -1, bs = -1;
+    for (int s = 0; s < n_samples; s++) {
+        float pi[3];
+        position_at(M, dim, dt, s * record_time_step, z_2d, x_all + gi * nv, pi);
+        for (int o = 0; o < n_obstacles; o++) {
+            if (obs[o].type == LSCQP_OBSTACLE_REAL) continue;  // :531-532
+            const double ro = obs[o].radius;
+            const double dwn = (ro * obs[o].downwash + dri) / (ri + ro);  // :538-540
+            const float dx = pi[0] - (float)obs[o].position[0], dy = pi[1] - (float)obs[o].position[1];
+            const float dz = (float)((double)(pi[2] - (float)obs[o].position[2]) / dwn);
+            float nsq;
+            {
+#pragma clang fp contract(off)
+                nsq = dx * dx + dy * dy + dz * dz;
+            }
+            const double ratio = sqrt((double)nsq) / (ri + ro);
+            if (ratio < best) {  // the reference's strict <: first (sample, obstacle) attaining the minimum
+                best = ratio;
+                bo = o;
+                bs = s;
+            }
+        }
+    }
+    lscqp_safety_obs R;
+    R.safety_ratio_obs = best;
+    R.closest_obstacle = bo;
+    R.sample = bs;
+    out[a] = R;
+}
+
 }  // namespace lscpost
 
 extern "C" int lscqp_set_error_(int code, const char* msg);
+
+extern "C" int lscqp_safety_obstacles_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int n_samples, double record_time_step,
+                                           double z_2d, const double* d_x_all, const double* d_radius, const double* d_downwash, int n_obstacles,
+                                           const lscqp_obstacle* d_obstacles, lscqp_safety_obs* d_out, void* stream) {
+    if (n_agents == 0) return LSCQP_OK;
+    const unsigned blocks = (unsigned)((n_agents + lscpost::kObsT - 1) / lscpost::kObsT);
+    hipLaunchKernelGGL(lscpost::safety_obstacles_kernel, dim3(blocks), dim3(lscpost::kObsT), 0, (hipStream_t)stream, M, dim, dt, n_agents, first_agent,
+                       n_samples, record_time_step, z_2d, d_x_all, d_radius, d_downwash, n_obstacles, d_obstacles, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lscqp_set_error_(LSCQP_ERR_HIP, (std::string("HIP launch failed: ") + hipGetErrorString(e)).c_str());
+    return LSCQP_OK;
+}
 
 extern "C" int lscqp_safety_metrics_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int64_t n_total, int n_samples,
                                          double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,

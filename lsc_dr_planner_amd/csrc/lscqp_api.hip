@@ -566,6 +566,26 @@ int lscqp_safety_metrics_device(lscqp_handle h, int64_t n_agents, int64_t first_
                                      d_x_all, d_radius, d_downwash, d_hdr, d_out, stream);
 }
 
+extern "C" int lscqp_safety_obstacles_raw_(int M, int dim, double dt, int64_t n_agents, int64_t first_agent, int n_samples, double record_time_step,
+                                           double z_2d, const double* d_x_all, const double* d_radius, const double* d_downwash, int n_obstacles,
+                                           const lscqp_obstacle* d_obstacles, lscqp_safety_obs* d_out, void* stream);
+
+int lscqp_safety_obstacles_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_samples,
+                                  double record_time_step, double z_2d, const double* d_x_all, const double* d_radius,
+                                  const double* d_downwash, int32_t n_obstacles, const lscqp_obstacle* d_obstacles,
+                                  lscqp_safety_obs* d_out, void* stream) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_agents < 0 || first_agent < 0 || n_samples < 0 || n_obstacles < 0 || n_total < first_agent + n_agents)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "inconsistent sizes");
+    if (n_agents == 0) return LSCQP_OK;
+    if (!d_x_all || !d_radius || !d_downwash || !d_out || (n_obstacles > 0 && !d_obstacles)) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    return lscqp_safety_obstacles_raw_(h->desc.M, h->desc.dim, h->desc.dt, n_agents, first_agent, n_samples, record_time_step, z_2d, d_x_all,
+                                       d_radius, d_downwash, n_obstacles, d_obstacles, d_out, stream);
+}
+
 int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map mp, int32_t mode, int64_t n, const double* d_points, const double* d_radius,
                                lscqp_box* d_sfc, int32_t* d_status_out, void* stream) {
     if (!h || !mp) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");

@@ -91,3 +91,44 @@ void orc_safety_metrics(const orc_class* c, int n_agents, int first, int n_total
         for (int k = 0; k < 3; k++) o[3 + k] = vex[k], o[6 + k] = aex[k];
     }
 }
+
+/*
+ * The OBSTACLE leg of the same loop (reference src/multi_sync_simulator.cpp:527-557): per agent the minimum over samples and
+ * over the non-"real" obstacles of ellipsoidalDistance(agent position at t_s, obstacle position, mixed downwash) /
+ * (r_i + r_o), with downwash = (r_o * dw_o + r_i * dw_i) / (r_i + r_o) (:538-540).  The obstacle positions are those of
+ * obstacle_generator.getObstacle(oi) -- the generator's CURRENT state, the same for every sample of the step (:534; only the
+ * agents move along future_time) -- held as point3d, i.e. float32.  obs: [n_obs][5] = x, y, z, radius, downwash; skip[o] != 0
+ * marks a "real" obstacle (:531-532).  out: [n_agents][3] = ratio (+inf if nothing was compared), obstacle index, sample of the
+ * first strict minimum in (sample, obstacle) order.
+ */
+void orc_safety_obstacles(const orc_class* c, int n_agents, int first, int n_samples, double step, double z_2d, const double* x_all,
+                          const double* radius, const double* downwash, int n_obs, const double* obs, const int* skip, double* out) {
+    const int nv = c->dim * c->M * 6;
+    for (int a = 0; a < n_agents; a++) {
+        const int gi = first + a;
+        double best = INFINITY, bo = -1, bs = -1;
+        double xf[3 * 6 * 16];
+        for (int i = 0; i < nv; i++) xf[i] = (double)(float)x_all[(size_t)gi * nv + i];
+        for (int s = 0; s < n_samples; s++) {
+            const double t = s * step;
+            double pi[3] = {0, 0, 0}, vi[3] = {0, 0, 0}, ai[3] = {0, 0, 0};
+            orc_state_at(c, xf, t, pi, vi, ai);
+            if (c->dim == 2) pi[2] = z_2d;
+            for (int o = 0; o < n_obs; o++) {
+                if (skip && skip[o]) continue;
+                const double* ob = &obs[(size_t)o * 5];
+                const double dwn = (ob[3] * ob[4] + radius[gi] * downwash[gi]) / (radius[gi] + ob[3]);
+                const float dx = (float)pi[0] - (float)ob[0], dy = (float)pi[1] - (float)ob[1];
+                const float dz = (float)((double)((float)pi[2] - (float)ob[2]) / dwn);
+                const float nsq = dx * dx + dy * dy + dz * dz;
+                const double ratio = sqrt((double)nsq) / (radius[gi] + ob[3]);
+                if (ratio < best) {
+                    best = ratio;
+                    bo = o;
+                    bs = s;
+                }
+            }
+        }
+        out[(size_t)a * 3] = best, out[(size_t)a * 3 + 1] = bo, out[(size_t)a * 3 + 2] = bs;
+    }
+}

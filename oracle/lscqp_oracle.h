@@ -159,6 +159,8 @@ int orc_validate_step(const orc_class* c, const orc_agent* ag, const orc_box* sf
                       double* state9);
 void orc_safety_metrics(const orc_class* c, int n_agents, int first, int n_total, int n_samples, double step, double z_2d,
                         const double* x_all, const double* radius, const double* downwash, const orc_agent* ag, double* out);
+void orc_safety_obstacles(const orc_class* c, int n_agents, int first, int n_samples, double step, double z_2d, const double* x_all,
+                          const double* radius, const double* downwash, int n_obs, const double* obs, const int* skip, double* out);
 
 #ifdef __cplusplus
 }

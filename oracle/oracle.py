@@ -132,6 +132,7 @@ def lib():
         _lib.orc_validate_step.argtypes = [C.POINTER(OrcClass), C.c_void_p, C.c_void_p, dp, C.c_double, C.c_double, dp]
         _lib.orc_safety_metrics.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp,
                                             C.c_void_p, dp]
+        _lib.orc_safety_obstacles.argtypes = [C.POINTER(OrcClass), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_int, dp, ip, dp]
         _lib.orc_map_create.restype = C.c_void_p
         _lib.orc_map_create.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double]
         _lib.orc_map_destroy.argtypes = [C.c_void_p]
@@ -433,6 +434,21 @@ def safety_metrics(cls, agents, x_all, radius, downwash, n_samples, step, first=
     out = np.zeros((ag.shape[0], 9))
     lib().orc_safety_metrics(C.byref(cls), ag.shape[0], first, n_total, int(n_samples), float(step), float(z_2d), _dp(xx), _dp(r), _dp(dw),
                              _vp(ag), _dp(out))
+    return out
+
+
+def safety_obstacles(cls, n_agents, x_all, radius, downwash, obstacles, n_samples, step, first=0, z_2d=1.0, skip=None):
+    """The obstacle leg of MultiSyncSimulator::update's safety figures (reference src/multi_sync_simulator.cpp:527-557): obstacles
+    (n_obs, 5) = x, y, z, radius, downwash; skip (n_obs,) != 0 marks "real" obstacles.  Returns (n_agents, 3): ratio, obstacle, sample."""
+    xx = np.ascontiguousarray(x_all, dtype=np.float64)
+    n_total = xx.shape[0]
+    r = np.ascontiguousarray(np.broadcast_to(radius, (n_total,)), dtype=np.float64)
+    dw = np.ascontiguousarray(np.broadcast_to(downwash, (n_total,)), dtype=np.float64)
+    ob = np.ascontiguousarray(obstacles, dtype=np.float64).reshape(-1, 5)
+    sk = np.ascontiguousarray(np.zeros(len(ob)) if skip is None else skip, dtype=np.int32)
+    out = np.zeros((int(n_agents), 3))
+    lib().orc_safety_obstacles(C.byref(cls), int(n_agents), int(first), int(n_samples), float(step), float(z_2d), _dp(xx), _dp(r), _dp(dw),
+                               len(ob), _dp(ob), sk.ctypes.data_as(C.POINTER(C.c_int)), _dp(out))
     return out
 
 

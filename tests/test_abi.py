@@ -110,7 +110,11 @@ def test_next_row_entry_points_validate_and_accept_empty_batches(api):
     assert L.lscqp_shift_traj_device(h, 0, 1, 1.0, p, p, None) == api.OK
     assert L.lscqp_safety_metrics_device(h, 0, 0, 0, 1, 0.1, 1.0, p, p, p, p, p, None) == api.OK
     assert L.lscqp_validate_step_device(h, 0, 0.2, 1.0, p, p, p, p, p, None) == api.OK
+    assert L.lscqp_safety_obstacles_device(h, 0, 0, 0, 1, 0.1, 1.0, p, p, p, 3, p, p, None) == api.OK
     # bad arguments
+    assert L.lscqp_safety_obstacles_device(h, 4, 2, 5, 1, 0.1, 1.0, p, p, p, 3, p, p, None) == api.ERR_INVALID_ARGUMENT  # 2 + 4 > 5
+    assert L.lscqp_safety_obstacles_device(h, 1, 0, 1, 1, 0.1, 1.0, p, p, p, 3, None, p, None) == api.ERR_INVALID_ARGUMENT  # obstacles announced, no table
+    assert L.lscqp_safety_obstacles_device(None, 1, 0, 1, 1, 0.1, 1.0, p, p, p, 0, None, p, None) == api.ERR_INVALID_ARGUMENT
     assert L.lscqp_generate_constraints_device(h, 7, 4, 8, 0, p, p, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT
     assert b"mode" in L.lscqp_last_error()
     assert L.lscqp_generate_constraints_device(None, api.GEN_LSC, 4, 8, 0, p, p, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT
@@ -125,6 +129,7 @@ def test_next_row_entry_points_validate_and_accept_empty_batches(api):
     if not torch.cuda.is_available():
         for rc in (L.lscqp_generate_constraints_device(h, api.GEN_CLSC, 4, 8, 0, p, p, p, p, p, p, None),
                    L.lscqp_safety_metrics_device(h, 1, 0, 1, 1, 0.1, 1.0, p, p, p, p, p, None),
+                   L.lscqp_safety_obstacles_device(h, 1, 0, 1, 1, 0.1, 1.0, p, p, p, 0, None, p, None),
                    L.lscqp_validate_step_device(h, 1, 0.2, 1.0, p, p, p, p, p, None),
                    L.lscqp_shift_traj_device(h, 1, 1, 1.0, p, p, None)):
             assert rc == api.ERR_NO_DEVICE and b"no CPU fallback" in L.lscqp_last_error()
