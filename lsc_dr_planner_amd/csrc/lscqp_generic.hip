@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
         return v;
     };
 
-    double res_p = 0, res_d = 0, res_gap = 0, snap_p = 0, snap_d = 0, snap_gap = 0;
+    double res_p = 0, res_d = 0, res_gap = 0, snap_p = 0, snap_d = 0, snap_gap = 0, obj_abs = 0;
     bool restore = false;
     int it = 0, near_cnt = 0, floor_cnt = 0;
     float rp_ref = 3.0e38f;
@@ -608,10 +608,15 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 rp_ref = (float)max_rp;
             }
             if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {
-                res_gap = (sum_sl + sum_pinf) / (1.0 + fabs(objective(false)));
+                obj_abs = fabs(objective(false));
+                res_gap = (sum_sl + sum_pinf) / (1.0 + obj_abs);
                 if (res_gap <= tol || (res_gap <= 10.0 * tol && rdn <= 1e-7 * gls)) {
-                    for (int zi = tid; zi < NZ; zi += kT) zs_[zi] = z_[zi];
-                    snap_p = max_rp, snap_d = res_d, snap_gap = res_gap;
+                    // the BEST remembered point, not the latest (lscqp_kernel.hpp: gap target first, then the smaller stationarity)
+                    const bool at_target = res_gap <= tol, had_target = snap_gap <= tol;
+                    if (floor_cnt == 0 || (at_target && !had_target) || (at_target == had_target && res_d < snap_d)) {
+                        for (int zi = tid; zi < NZ; zi += kT) zs_[zi] = z_[zi];
+                        snap_p = max_rp, snap_d = res_d, snap_gap = res_gap;
+                    }
                 }
                 if (res_gap <= tol) {
                     floor_cnt++;
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             const double mu_aff = ((1.0 - a_aff) * sum_sl + a_aff * a_aff * sB) * inv_m;
             double sigma = fmax(mu_aff, 0.0) / mu;
             sigma = sigma * sigma * sigma;
-            const double smu = sigma * mu;
+            const double smu = fmax(sigma * mu, LSCQP_SMU_FLOOR * tol * (1.0 + obj_abs) * inv_m);  // (lscqp_kernel.hpp: never aim below the gap target)
             __syncthreads();
             GEN_T(6);
             // ============ corrector solve ======================================================================================
@@ -1002,7 +1007,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
         expandT(z_, c_, true);
         __syncthreads();
         res_p = snap_p, res_d = snap_d, res_gap = snap_gap;
-        flags |= LSCQP_INFO_FLOOR_ACCEPTED;
+        if (!(snap_d <= 1e-8 && snap_gap <= tol && snap_p <= 1e-9)) flags |= LSCQP_INFO_FLOOR_ACCEPTED;  // (lscqp_kernel.hpp: the stated deviation only)
     }
     if (recentred || net_done) flags |= LSCQP_INFO_RECENTRED;
     __syncthreads();

@@ -1,8 +1,10 @@
-"""Audit of the ONE stated deviation from north_star's 1e-8 bar: an instance may be accepted with its own scaled
-stationarity residual at the rounding floor (<= 1e-6 instead of 1e-8) when the iteration breaks down after the primal and gap tests
-were met -- lscqp_info.flags & LSCQP_INFO_FLOOR_ACCEPTED.  The claim is that such points still meet 1e-8 on the objective and on the
-KKT residuals of the reference's row-for-row model.  Here EVERY floor-accepted instance of BASELINE configs[3] (1024 x M10 x 40, the
-config that produces them: about 1 % of its instances) and of the configs[4] shape is checked against the oracle, not a sample."""
+"""Audit of what USED to be the one stated deviation from north_star's 1e-8 bar: an instance accepted with its own scaled stationarity
+residual at the rounding floor (<= 1e-6 instead of 1e-8) when the iteration breaks down after the primal and gap tests were met --
+lscqp_info.flags & LSCQP_INFO_FLOOR_ACCEPTED.  Round 3: 11 of the 1024 instances of BASELINE configs[3] (none elsewhere).  Round 4
+(the corrector never aims below the gap target; the best remembered point is the one returned): NO instance of
+configs[3], configs[2] or the configs[4] shape carries the flag, warm-started or from the default start -- every instance meets
+1e-9 m / 1e-8 / tol on the solver's own residuals.  Should one ever carry it again, it is still held to the 1e-8 bar on the reference's
+row-for-row model against the oracle."""
 import os
 import sys
 
@@ -27,7 +29,7 @@ def _bench_batch(api, key):
         return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
 
     # the very batch bench.py's `configs` section measures (same seed, same three warm-up replans)
-    sw, sol, b, (hdr, rows, off, sfc) = bench.make_batch(api, synth, factory, N, M, dim, n_obs, seed=3000 + N + M, style=cfg["style"], warm_steps=3)
+    sw, sol, b, (hdr, rows, off, sfc) = bench.make_batch(api, synth, factory, N, M, dim, n_obs, seed=cfg["seed"], style=cfg["style"], warm_steps=3)
     return sw, sol, b, hdr, rows, off, sfc, M, dim
 
 
@@ -47,6 +49,8 @@ def test_every_floor_accepted_instance_meets_the_bar_on_the_reference_model(api,
         # every instance that is NOT flagged met the strict test (1e-8) on the solver's own residual
         strict = np.setdiff1d(np.arange(N), fl)
         assert (G["info"]["res_dual"][strict] <= 1e-8).all()
+        assert len(fl) == 0, "%s / %s start: %d instance(s) flagged LSCQP_INFO_FLOOR_ACCEPTED: %s (res_dual %s)" % (
+            key, start, len(fl), fl.tolist(), G["info"]["res_dual"][fl].tolist())
         if len(fl) == 0:
             continue
         R = oracle.solve_batch(cls, ag[fl], lsc, loff[fl], np.ascontiguousarray(sfc_o.reshape(N, M)[fl]).reshape(-1), threads=16)

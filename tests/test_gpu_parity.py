@@ -454,8 +454,9 @@ def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(
     o = oracle.solve(cls, ag, lsc, sfc)
     assert o["status"] == 0
     assert abs(o["obj"] - d_obj.item()) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - d_x.cpu().numpy()).max() <= 1e-6
-    # accepted by the fallback rule: the point is the remembered one and says so
-    assert (info["flags"] & api.INFO_FLOOR_ACCEPTED) and info["res_primal"] <= 1e-9 and info["res_dual"] <= 1e-6
+    # a point returned by the fallback rule is the remembered one and says so; since round 4 (centring target never below the gap
+    # target, best remembered point) the instance may as well end as an ordinary OPTIMAL one: then it meets the strict 1e-8
+    assert info["res_primal"] <= 1e-9 and info["res_dual"] <= (1e-6 if (info["flags"] & api.INFO_FLOOR_ACCEPTED) else 1e-8)
 
 
 def test_log_replay_known_answers_on_the_gpu(api, oracle, torch_cuda):
