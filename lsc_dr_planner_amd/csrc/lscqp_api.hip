@@ -97,6 +97,8 @@ const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t 
     const Inst* best = nullptr;
     // testing knob: LSCQP_FORCE_GENERIC=1 sends every fp64 launch to the run-time-shaped kernel (lscqp_generic.hip), also for shapes
     // that have compiled instances -- so that kernel is tested on the shapes every fixture exists for
+    // (both knobs are read at every launch ON PURPOSE: the tests and bench.py flip them between launches of one process.  getenv is
+    // safe against concurrent getenv; a process that calls setenv while another thread solves is outside what the knobs are for.)
     const char* fg = getenv("LSCQP_FORCE_GENERIC");
     if (fg && fg[0] == '1' && !mixed) return nullptr;
     const bool small = n <= 2 * (int64_t)n_cu;

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "lscqp_kernel.hpp"  // DevClass, KQ, TBc, fast_rcp (shared with the compiled instances)
 #include "lscqp_launch.hpp"
 
@@ -1007,6 +1009,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
         expandT(z_, c_, true);
         __syncthreads();
         res_p = snap_p, res_d = snap_d, res_gap = snap_gap;
+        flags |= LSCQP_INFO_REMEMBERED;
         if (!(snap_d <= 1e-8 && snap_gap <= tol && snap_p <= 1e-9)) flags |= LSCQP_INFO_FLOOR_ACCEPTED;  // (lscqp_kernel.hpp: the stated deviation only)
     }
     if (recentred || net_done) flags |= LSCQP_INFO_RECENTRED;
@@ -1052,14 +1055,14 @@ extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, in
                                            int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
     if (!lscqp_generic_supports(M, dim, es) || cls->n_obs_max > lscqp_generic_max_obstacles(M, dim, es)) return hipErrorInvalidValue;
     const size_t lds = lscqp_generic_lds_bytes(M, dim, es, cls->n_obs_max);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // (zero-initialised; two host threads may launch for the first time at once: setting it twice is harmless)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lscqp_generic::pdip_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)lscqp::kMaxLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(lscqp_generic::pdip_generic_kernel, dim3((unsigned)n), dim3(lscqp_generic::kT), lds, stream, *cls, M, dim, es, n, hdr, rows,

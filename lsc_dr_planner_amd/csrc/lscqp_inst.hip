@@ -1,6 +1,8 @@
 // One kernel instance per translation unit so the instances compile in parallel.
 // Built with -DLSCQP_M=<M> -DLSCQP_DIM=<dim> -DLSCQP_ES=<0|1> -DLSCQP_NSLOT=<slots> -DLSCQP_W=<wavefronts per QP>
 // -DLSCQP_MIXED=<0|1>; exports lscqp_launch_<M>_<dim>_<ES>_<NSLOT>_<W>_<MIXED>.
+#include <atomic>
+
 #include "lscqp_kernel.hpp"
 #include "lscqp_launch.hpp"
 
@@ -29,13 +31,13 @@ extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscq
     if (cls->n_obs_max > C::MAX_OBS) return hipErrorInvalidValue;
     // raise the dynamic-LDS cap (160 KiB per CU on gfx950) once PER DEVICE: the attribute belongs to the device's copy of the
     // kernel, and one process may drive several GPUs (lscqp_comm_*)
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // (zero-initialised; two host threads may launch for the first time at once: setting it twice is harmless)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(C::T), lds, stream, *cls, n, hdr, rows, row_offsets, sfc, x_init, x_out,

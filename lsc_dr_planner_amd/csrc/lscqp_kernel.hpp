@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
     float gap_mark = 3.0e38f;  // jam test: the gap when it last improved tenfold, iterations since, done once
     int jam_since = 0;
     bool recentred = false;
+    int shift_level = 0;  // 0: no diagonal shift; 1, 2: the factorisation lost a pivot and the matrix carries 1e-14 / 1e-12 max|K| on its diagonal
     const double tol = cls.tol;
     const bool comm_on_k = cls.comm_range > 0;
     // (row of the scratch matrix a lane assembles into: non-z lanes share one dummy row, index NZ, that is never read)
@@ -1301,6 +1302,23 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             LSCQP_STOP(3)
 
             // ============ assemble own row of Hred = T'(H + G'WG)T ==========================================
+            // A non-positive pivot is rounding, not the matrix (Hred is SPD): once lambda / s of the active rows spans ~1e15 -- a row that
+            // a long step left 1e3 below the average product does that at mu = 1e-12 already -- the factorisation's noise, eps max|K|,
+            // reaches the smallest eigenvalues of Hred (~0.1: cond 3e6).  Round 3 ended such an instance (NUMERIC unless a point had
+            // been remembered); now the iteration is REPEATED (see below the factorisation) with a diagonal shift of 1e-14, then
+            // 1e-12, times the largest weight that went into the matrix, kept for the rest of the solve: residuals and stopping tests
+            // are exact whatever the direction, so a shifted direction can cost an iteration, never accuracy.
+            // (tools/floor_probe.py, seed 228: an M = 10 instance 17x from its gap target with a stationarity of 7e-11 lost a pivot.)
+            double diag_shift = 0.0;
+            if (shift_level > 0) {  // uniform over the QP's lanes; rare
+                LSCQP_PHASE_LANE(lvr_);
+                double big = 0.0;
+                for (int e = lvr_; e < 6 * P; e += T) big = fmax(big, fabs(S_[e]));
+                for (int e = lvr_; e < C::NOM; e += T) big = fmax(big, om_[e]);
+                big = block_max(big);
+                diag_shift = (shift_level == 1 ? 1e-14 : 1e-12) * fmax(big, 1.0);
+                LSCQP_TR(11, (double)shift_level);
+            }
             {
                 LSCQP_Z_ROLES();
                 double q2 = q2s;  // opaque as well: q2*KQ(i,j) would otherwise be hoisted as 21 VGPR pairs
@@ -1411,7 +1429,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                         const double old = (double)*t;
                         if (use) *t = (FT)(near ? (old - w) : -w);
                     }
-                    hrow[zi] += (FT)dsum;  // dsum == 0 for lanes that are not c5 variables (zi = 0 for lanes without a variable)
+                    hrow[zi] += (FT)(dsum + diag_shift);  // dsum == 0 for lanes that are not c5 variables (zi = 0 for lanes without a variable: the dummy row)
                 }
                 // W > 1 with nz <= 64: the system fits wavefront 0, whose lanes assembled it; EVERY wavefront loads the same rows
                 // (lane & 63) and factorises the same matrix redundantly.  The verdict on a failed pivot is then identical in all
@@ -1473,7 +1491,6 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 }
             }
             LSCQP_T(3);
-            LSCQP_STOP(4)
 
             // ============ LDL^T in registers: lane i holds row i ===============================================
             bool pivot_bad = false;
@@ -1722,6 +1739,19 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 __syncthreads();
                 pivot_bad = (flag[0] != 0.0) || (flag[1] != 0.0);
                 __syncthreads();  // the flags sit in the scratch matrix, which the next phase overwrites
+            }
+            LSCQP_STOP(4)
+            if (pivot_bad && shift_level < 2) {  // uniform over the QP's lanes: repeat this iteration with a (larger) diagonal shift
+                shift_level++;
+                flags |= LSCQP_INFO_SHIFTED;
+                LSCQP_TR(6, 2.0);
+                // the scratch rows must be all-zero outside the assembly pattern again (nested dissection reused them for its hand-overs)
+                LSCQP_PHASE_LANE(lvr_);
+                FT* const hz = &Hs[lane_slot(lvr_) * LDH];
+#pragma unroll
+                for (int cidx = 0; cidx < NZ; cidx++) hz[cidx] = (FT)0;
+                LSCQP_BLOCK_SYNC();
+                continue;
             }
             auto numeric_exit = [&]() {
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;
@@ -2180,6 +2210,7 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
         // A remembered point that meets the three strict tests (1e-9 m, 1e-8, tol) lacks only the second confirmation of
         // LSCQP_NEAR_CONFIRM -- whose purpose, letting the iteration polish on, is moot once the iteration has ended -- and is an
         // ordinary OPTIMAL result.
+        flags |= LSCQP_INFO_REMEMBERED;
         if (!(snap_d <= 1e-8 && snap_gap <= tol && snap_p <= 1e-9)) flags |= LSCQP_INFO_FLOOR_ACCEPTED;
     }
     if (recentred || net_done) flags |= LSCQP_INFO_RECENTRED;

@@ -659,7 +659,9 @@ __device__ int obstacle_in_batch(const MapView& mp, Ahead& A, double margin) {
     for (int r = lane >> 6; r < n_rounds; r += kSfcThreads / 64) {
         const int stop = *(volatile int*)&A.fail;  // tests behind a failure already found need not be finished
         const int item = __builtin_amdgcn_readfirstlane(listed ? A.todo[from_back ? kTodo - 1 - r : r] : r);  // wave-uniform: boxes are padded to whole wavefronts
-        const int chunk = item & 0xffff, zsel = item >> 16;  // (zsel > 0: segment zsel - 1 of the columns only)
+        // (a LISTED item packs the chunk into 16 bits -- the list is only built when all_chunks <= kTodo <= 65536 -- with the segment
+        // selector above it; an unlisted round IS the chunk, whatever its size: nothing to unpack, nothing to truncate)
+        const int chunk = listed ? (item & 0xffff) : item, zsel = listed ? (item >> 16) : 0;  // (zsel > 0: segment zsel - 1 of the columns only)
         const int idx = chunk * 64 + (lane & 63);
         // the box this chunk belongs to: lane t asks "does box t + 1 start at or before it" (one LDS read per lane instead of a scan)
         const int lt = lane & 63;

@@ -388,10 +388,19 @@ def test_plan_chain_in_three_dimensions_with_static_goals(api, oracle, torch_cud
                 o = oracle.solve(cls, ag, lsc, box)
                 assert o["status"] == 0, (k, q)
                 assert abs(o["obj"] - obj[q]) <= 1e-8 * max(1.0, abs(o["obj"])), (k, q, o["obj"], obj[q])
-                # (a point accepted by the fallback rule -- flagged; the objective bar holds, its stationarity is 1e-7 instead of 1e-8
-                # relative -- may sit some 1e-5 m along a flat direction: BVC cells leave the z axis of a blocked agent almost free)
-                floor = bool(info["flags"][q] & api.INFO_FLOOR_ACCEPTED)
-                assert np.abs(o["x"] - x[q]).max() <= (5e-5 if floor else 2e-6), (k, q, floor)
+                # (a REMEMBERED point -- flagged: the iteration broke down and the best point it had seen is returned; the objective bar
+                # holds and its stationarity is within 1e-8, or 1e-7 with FLOOR_ACCEPTED -- may sit some 1e-5 m along a flat direction:
+                # BVC cells leave the z axis of a blocked agent almost free)
+                floor = bool(info["flags"][q] & (api.INFO_FLOOR_ACCEPTED | api.INFO_REMEMBERED))
+                dxq = np.abs(o["x"] - x[q]).max()
+                if dxq > 2e-6 and not floor:
+                    # an ordinary OPTIMAL result further than 2e-6 m from the oracle's point must itself be a KKT point of the reference's
+                    # row-for-row model at the 1e-8 bar (then the two points are two ends of a flat valley: same objective to 1e-8,
+                    # asserted above -- not a solver error)
+                    stat, eqv, iqv = H.kkt_from_primal(oracle, cls, ag, lsc, box, x[q])
+                    assert stat <= 1e-8 and eqv <= 1e-8 and iqv <= 1e-8, (k, q, dxq, stat, eqv, iqv)
+                    floor = True
+                assert dxq <= (5e-5 if floor else 2e-6), (k, q, floor)
     assert failed == 0, failed
     assert worst_ratio >= 1.0 - 5e-6, worst_ratio
     state = plan.get(api.PLAN_STATE).reshape(N, 9)

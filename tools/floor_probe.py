@@ -19,7 +19,7 @@ xflags = [a for a in sys.argv[1:] if a.startswith("-D")]
 import bench  # noqa: E402
 
 cfg = bench.CONFIGS[key]
-N, M, D, NOBS = cfg["agents"], cfg["segments"], cfg["dim"], cfg["obs"]
+N, M, D, NOBS = int(os.environ.get("PROBE_N", cfg["agents"])), cfg["segments"], cfg["dim"], cfg["obs"]
 NSLOT, W = {(10, 3): (10, 4), (5, 3): (10, 1), (6, 3): (7, 2), (10, 2): (5, 2)}[(M, D)]
 if os.environ.get("PROBE_NSLOT"):
     NSLOT, W = int(os.environ["PROBE_NSLOT"]), int(os.environ["PROBE_W"])
@@ -47,7 +47,20 @@ def factory(sw):
     return api.Solver(api.make_desc(M=M, dim=D, world_min=sw.world_min, world_max=sw.world_max))
 
 
-sw, sol, b, (hdr, rows, off, sfc) = bench.make_batch(api, synth, factory, N, M, D, NOBS, seed=cfg["seed"], style=cfg["style"], warm_steps=3)
+if os.environ.get("PROBE_SWARM"):
+    # PROBE_SWARM=seed,steps : synth.Swarm(N, seed=seed) of the config's shape advanced `steps` replans (failed QPs keep their start), as the
+    # parity tests build their batches; PROBE_N overrides the agent count
+    seed_, steps_ = [int(v) for v in os.environ["PROBE_SWARM"].split(",")]
+    sw = synth.Swarm(N, M=M, dim=D, n_obs=NOBS, seed=seed_, style=cfg["style"])
+    sol = factory(sw)
+    for _ in range(steps_):
+        b = sw.build()
+        hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+        sw.advance(sol.solve_host(hdr, rows, off, sfc)["x"])
+    b = sw.build()
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+else:
+    sw, sol, b, (hdr, rows, off, sfc) = bench.make_batch(api, synth, factory, N, M, D, NOBS, seed=cfg["seed"], style=cfg["style"], warm_steps=3)
 dev = torch.device("cuda", 0)
 t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (hdr, rows, off, sfc)]
 dx = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
@@ -84,13 +97,14 @@ info = dinfo.cpu().numpy().view(api.INFO_DTYPE)
 st = dst.cpu().numpy()
 fl = np.where((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0)[0]
 print("config %s: %d instances, status histogram %s, floor accepted %d: %s" % (key, N, np.bincount(st).tolist(), len(fl), fl.tolist()))
-print("iterations: mean %.3f max %d; refined iterations (slot 11): %d in %d instances" % (
+print("iterations: mean %.3f max %d; iterations with a shifted refactorisation (slot 11): %d in %d instances" % (
     info["iterations"].mean(), info["iterations"].max(), int((tr[:, :, 11] > 0).sum()), int(((tr[:, :, 11] > 0).sum(axis=1) > 0).sum())))
-show = fl if len(fl) else np.argsort(-info["iterations"])[:3]
+bad = np.where(st != 0)[0]
+show = bad if len(bad) else (fl if len(fl) else np.argsort(-info["iterations"])[:3])
 names = {0: "", 1: "OPTIMAL", 2: "PIVOT", 3: "STALL", 4: "INFEAS"}
 for q in show[:int(os.environ.get("PROBE_SHOW", "12"))]:
     print("--- instance %d: iterations %d, res_dual %.2e gap %.2e" % (q, info["iterations"][q], info["res_dual"][q], info["gap"][q]))
     for it in range(min(int(info["iterations"][q]) + 1, 64)):
         r = tr[q, it]
         print("   it %2d  rp %.1e  rd %.2e  gap* %.2e  mu %.1e  alpha %.4f sigma %.1e  gls %.1e wmax %.1e lmax %.1e |dz| %.1e %s%s" % (
-            it, r[0], r[1], r[2], r[3], r[4], r[5], r[7], r[8], r[9], r[10], names.get(int(r[6]), "?"), " refined" if r[11] else ""))
+            it, r[0], r[1], r[2], r[3], r[4], r[5], r[7], r[8], r[9], r[10], names.get(int(r[6]), "?"), " SHIFTED" if r[11] else ""))
