@@ -229,6 +229,15 @@ __device__ __forceinline__ bool pivot_ok(FT d) {
 // (where the last, partial pass leaves), s_nop 14 = end of the body.  The compiler itself emits s_nop 0..7 only; ~14 idle cycles each.
 // Nested-dissection instances: regions only SOME wavefronts of the workgroup execute are bracketed by s_nop 8 (wavefront 0 only) /
 // s_nop 9 (wavefront 1 only) / s_nop 10 (wavefronts 0 and 1) ... s_nop 11 (end), so that the count knows who runs what.
+// (-DLSCQP_NO_MARKERS builds the kernel without them -- an A/B library, LSCQP_AB=nomark; measured cost of carrying them: DESIGN.md section 4)
+#ifdef LSCQP_NO_MARKERS
+#define LSCQP_MARK(k) \
+    do {              \
+    } while (0)
+#define LSCQP_MARKP(k) \
+    do {               \
+    } while (0)
+#else
 #define LSCQP_MARK(k) asm volatile("s_nop " #k)
 // (the brackets of the wavefront-partial regions are fenced: without the fence the scheduler moved an end marker in FRONT of its
 // region's register-only arithmetic, and the count took wavefront 0's separator solve for everybody's)
@@ -238,6 +247,7 @@ __device__ __forceinline__ bool pivot_ok(FT d) {
         asm volatile("s_nop " #k);             \
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
+#endif
 // Development aid: -DLSCQP_TRACE records, per iteration of the first LSCQP_TRACE_Q instances of a launch, the quantities the stopping
 // tests look at (tools/floor_probe.py reads them back): [q][it][0..7] = max|r_p|, stationarity / scale, gap figure, mu, step length,
 // sigma, exit code of the iteration (0 none, 1 optimal, 2 pivot breakdown, 3 stalled step, 4 infeasible), stationarity scale, then
