@@ -485,6 +485,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
     float gap_mark = 3.0e38f;
     int jam_since = 0;
     bool recentred = false;
+    int shift_level = 0;  // (lscqp_kernel.hpp: a lost pivot repeats the iteration with 1e-14 / 1e-12 max|K| on the diagonal)
     const double tol = cls.tol;
 
     if (status != LSCQP_STATUS_INFEASIBLE)
@@ -655,6 +656,14 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             }
 
             GEN_T(2);
+            double diag_shift = 0.0;
+            if (shift_level > 0) {  // uniform; rare
+                double big = 0.0;
+                for (int e = tid; e < 6 * P; e += kT) big = fmax(big, fabs(S_[e]));
+                for (int e = tid; e < S.NOM; e += kT) big = fmax(big, om_[e]);
+                big = block_max(big);
+                diag_shift = (shift_level == 1 ? 1e-14 : 1e-12) * fmax(big, 1.0);
+            }
             // ============ assembly: same-axis same-segment blocks, then Hred = T'(H + G'WG)T, packed lower triangle ==========
             for (int e = tid; e < DIM * M * 36; e += kT) {
                 const int km = e / 36, r36 = e - 36 * km, k = (km >= 2 * M) ? 2 : (km >= M ? 1 : 0), m = km - k * M, i = r36 / 6, ip = r36 - 6 * i;
@@ -715,7 +724,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                             if (w != 0.0) v += w * Kentry(Di.k, Di.cp[a], Dj.k, Dj.cp[b]);
                         }
                 }
-                H_[e] = v;
+                H_[e] = (i == j) ? v + diag_shift : v;
             }
             __syncthreads();
 
@@ -750,6 +759,12 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                     }
                     __syncthreads();
                 }
+            }
+            if (pivot_bad && shift_level < 2) {  // repeat this iteration with a (larger) diagonal shift: rounding lost the pivot, not the matrix
+                shift_level++;
+                flags |= LSCQP_INFO_SHIFTED;
+                __syncthreads();
+                continue;
             }
             if (pivot_bad) {
                 status = (near_cnt > 0 || floor_cnt > 0) ? LSCQP_STATUS_OPTIMAL : LSCQP_STATUS_NUMERIC;

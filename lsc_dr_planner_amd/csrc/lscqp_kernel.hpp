@@ -1751,7 +1751,9 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
                 __syncthreads();  // the flags sit in the scratch matrix, which the next phase overwrites
             }
             LSCQP_STOP(4)
-            if (pivot_bad && shift_level < 2) {  // uniform over the QP's lanes: repeat this iteration with a (larger) diagonal shift
+            // (not in the mixed-precision instances: a float32 factorisation that loses a pivot hands the instance to the fp64 second
+            // pass, which is what that pass exists for -- retrying in float32 first cost configs[4]-mixed 0.71 -> 0.89 ms)
+            if (pivot_bad && shift_level < 2 && !MIXED) {  // uniform over the QP's lanes: repeat this iteration with a (larger) diagonal shift
                 shift_level++;
                 flags |= LSCQP_INFO_SHIFTED;
                 LSCQP_TR(6, 2.0);
