@@ -215,19 +215,31 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     dst = torch.zeros(N, dtype=torch.int32, device=dev)
     dinfo = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
 
-    def call():
-        sol.solve_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi)
+    d_order = [None]
 
-    for _ in range(3):
-        call()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    def call():
+        sol.solve_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi, d_order=d_order[0])
+
+    def timed(k):
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
+
+    ms_as_given = timed(max(5, reps // 2))
+    # the work order a planner has: the agents whose previous QP took the most iterations first (lscqp_order_by_work_device on the info
+    # records of the previous solve -- lscqp_plan carries it from replan to replan).  Here the previous solve is of the SAME batch: the hint
+    # is perfect; tools/lpt_probe.py shows the same figures with a hint that is off by one iteration on half of the instances.
+    order_buf = torch.zeros(N, dtype=torch.int32, device=dev)
+    sol.order_by_work_device(N, dinfo, order_buf)
+    d_order[0] = order_buf
+    ms = timed(reps)
     # >= 1000 calls where that fits a bounded time (the slowest config, 1024 x M=10, needs ~10 s for them)
     p50, p99, nlat = percentile_latency(torch, call, max_seconds=min(14.0, max(lat_seconds, 1.15e-3 * ms * 1100)))
     info = dinfo.cpu().numpy().view(api.INFO_DTYPE)
@@ -236,6 +248,8 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     out = {"config": key, "what": cfg["what"], "agents": N, "segments": M, "dim": dim, "lsc_neighbours": sw.n_obs, "style": cfg["style"],
            "precision": cfg["precision"], "rows": cfg["rows"], "rows_per_qp": sol.num_inequalities(sw.n_obs),
            "kernel_ms": ms, "qp_per_s": N / (ms * 1e-3), "latency_ms": {"p50": p50, "p99": p99, "calls": nlat},
+           "work_order": "longest first: lscqp_order_by_work_device on the previous solve's iteration counts (same batch: a perfect hint)",
+           "kernel_ms_as_given": ms_as_given, "qp_per_s_as_given": N / (ms_as_given * 1e-3),
            "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
            "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()),
            "roofline_valu": valu_roofline(sol, N, sw.n_obs, info["iterations"], ms) if cfg["precision"] == "f64" else None,
@@ -635,8 +649,10 @@ def timed_workload(ctx, a):
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)  # plans to start from
         torch.cuda.synchronize()
 
+    d_order = [None]  # work order of the launch: set after the warm-up steps from their iteration counts (see below)
+
     def solve_only():
-        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+        sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit, d_order=d_order[0])
 
     def step():
         if a.pipeline:
@@ -649,7 +665,7 @@ def timed_workload(ctx, a):
             if d_xinit is not None:
                 d_xwarm.copy_(d_x)  # the plans the rows were generated from are the primal start of the re-solve
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info,
-                         d_x_init=(d_xwarm if (a.pipeline and d_xinit is not None) else d_xinit))
+                         d_x_init=(d_xwarm if (a.pipeline and d_xinit is not None) else d_xinit), d_order=d_order[0])
         if d_all is not None and not a.pipeline:
             all_gather_plans()
 
@@ -672,6 +688,15 @@ def timed_workload(ctx, a):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    if a.warmup > 0 and not a.graph and not a.no_work_order:
+        # the work order a planner has from the previous replan (lscqp_plan carries it by itself): longest previous solve first.  It
+        # matters only where a launch runs more than one round of workgroups (configs[3], the configs[4] shape); results are bit-identical.
+        order_buf = torch.zeros(N, dtype=torch.int32, device=dev)
+        sol.order_by_work_device(N, d_info, order_buf)
+        d_order[0] = order_buf
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
     ctx.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -754,26 +779,30 @@ def timed_workload(ctx, a):
         w_x, w_ob = torch.zeros(n_glob * nv, dtype=torch.float64, device=dev), torch.zeros(n_glob, dtype=torch.float64, device=dev)
         w_st, w_in = torch.zeros(n_glob, dtype=torch.int32, device=dev), torch.zeros(n_glob * 32, dtype=torch.uint8, device=dev)
         reps1 = max(5, min(a.steps, 20))
-        for _ in range(2):
-            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi)
+        w_ord = None
+        for i_ in range(3):
+            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi, d_order=w_ord)
+            if i_ == 0 and d_order[0] is not None:  # the same work order rule as the sharded steps
+                w_ord = torch.zeros(n_glob, dtype=torch.int32, device=dev)
+                sol.order_by_work_device(n_glob, w_in, w_ord)
         torch.cuda.synchronize()
         t_a = time.perf_counter()
         for _ in range(reps1):
-            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi)
+            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi, d_order=w_ord)
         torch.cuda.synchronize()
         t_1 = (time.perf_counter() - t_a) / reps1
         same = bool(torch.equal(w_x[lo * nv: hi * nv], d_x[: N * nv]))
         one_gpu = {"qp_per_s": n_glob / t_1, "ms_per_step": t_1 * 1e3, "steps": reps1,
                    "what": "the whole %d-agent batch on rank 0's GPU alone, no collective (wall clock, synchronised)" % n_glob,
                    "rank0_block_bit_identical_to_sharded_solve": same}
-        del w_h, w_o, w_s, w_r, w_xi, w_x, w_ob, w_st, w_in
+        del w_h, w_o, w_s, w_r, w_xi, w_x, w_ob, w_st, w_in, w_ord
     ctx.barrier()
     return SimpleNamespace(a=a, api=api, sw=sw, sol=sol, build=build, hdr=hdr, rows=rows, off=off, sfc=sfc, N=N, M=M, dim=dim, nv=nv, n_obs_eff=n_obs_eff,
                            n_glob=n_glob, n_pad=n_pad, strong=strong, d_hdr=d_hdr, d_rows=d_rows, d_off=d_off, d_sfc=d_sfc, d_xinit=d_xinit, d_x=d_x,
                            d_obj=d_obj, d_st=d_st, d_info=d_info, d_all=d_all, elapsed=elapsed, kernel_ms=kernel_ms, status=status, iters=iters,
                            n_bad=n_bad, n_floor=n_floor, iters_mean=it_sum / max(n_agents_seen, 1), iters_max=int(it_max), n_ranks_seen=n_ranks_seen,
                            n_devices_seen=n_devices_seen, n_agents_seen=n_agents_seen, rank_parity=rank_parity, step_lat=step_lat, one_gpu=one_gpu,
-                           solve_only=solve_only)
+                           solve_only=solve_only, ordered=d_order[0] is not None)
 
 
 def check_ran_as_asked(ctx, a, S):
@@ -798,6 +827,7 @@ def workload_config(ctx, a, S):
         "segments": S.M, "lsc_neighbours": S.n_obs_eff, "dim": S.dim,
         "rows_per_qp": S.sol.num_inequalities(S.n_obs_eff), "allgather": bool(gathered), "pipeline": bool(a.pipeline), "hip_graph": bool(a.graph),
         "warm_start": "initial_traj (shifted previous plan) as primal start" if S.d_xinit is not None else "none",
+        "work_order": ("longest previous solve first (lscqp_order_by_work_device on the warm-up steps' iteration counts)" if S.ordered else "as given"),
         "parallelism": ("agents sharded over %d GPU(s), " % ctx.world) +
                        ("one RCCL all-gather of the plans per step" if gathered else "no data-path collective"),
     }
@@ -877,6 +907,8 @@ def main():
                     help="drive the --gpus devices from THIS process through lscqp_comm (ncclCommInitAll; one stream per device) "
                          "instead of one process per GPU; implies --scaling strong")
     ap.add_argument("--no-rank-parity", action="store_true", help="multi-rank runs: skip the per-rank oracle check of each rank's own block")
+    ap.add_argument("--no-work-order", action="store_true",
+                    help="launch the instances in the order given instead of longest-previous-solve first (lscqp_order_by_work_device)")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
                     help="strong scaling: skip rank 0's solve of the WHOLE batch on its own GPU (config.one_gpu_same_workload)")
     args = ap.parse_args()

@@ -278,6 +278,22 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
                              const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
                              lscqp_info* d_info_out, void* stream);
 
+/* Work order of a launch (round 4).  A launch with more instances than the chip holds at once is run by PERSISTENT workgroups that take
+ * instance after instance from a queue (list scheduling; nothing to ask for, lscqp_solve_batch_device[_ex] do it by themselves).  The
+ * launch then lasts sum / slots + (what is still running when the queue is empty): starting the LONGEST instances first shortens that
+ * tail -- 1024 x M10 x 40 on one MI355X: 1.14 ms in the given order with one instance per workgroup, see DESIGN.md section 4 for the
+ * figures with the queue and with the order.  The iteration count of the previous replan's solve of the same agent is the hint a
+ * planner has (lscqp_plan carries it from replan to replan by itself):
+ *   lscqp_order_by_work_device   d_order_out[n] := the instances sorted by d_info_prev[i].iterations, most first, ties in index order
+ *   lscqp_solve_batch_device_ordered   lscqp_solve_batch_device_ex with the k-th slot of the launch solving instance d_order[k]
+ *                                (a permutation of 0 .. n-1; NULL = identity).  Results land at the instance's own index, bit for bit
+ *                                what any other order gives. */
+int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t* d_order_out, void* stream);
+int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                     const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out,
+                                     double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry,
+                                     const int32_t* d_order, void* stream);
+
 /* ---- multi-GPU: the agent batch over the GPUs of one node, from ONE host process ----------------
  *
  * The reference's host is a single process (one ROS node); within a replan step its N QPs are independent

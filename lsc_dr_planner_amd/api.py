@@ -113,6 +113,10 @@ def lib():
         L.lscqp_solve_batch_device.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 10
         L.lscqp_solve_batch_device_ex.restype = C.c_int
         L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
+        L.lscqp_solve_batch_device_ordered.restype = C.c_int
+        L.lscqp_solve_batch_device_ordered.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp, vp]
+        L.lscqp_order_by_work_device.restype = C.c_int
+        L.lscqp_order_by_work_device.argtypes = [C.c_int64, vp, vp, vp]
         L.lscqp_solve_batch_stream.restype = C.c_int
         L.lscqp_solve_batch_stream.argtypes = [vp, C.c_int64] + [vp] * 10
         for f in ("lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles"):
@@ -225,7 +229,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device",
                     "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
@@ -673,9 +677,10 @@ class Solver:
 
     # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
     def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None,
-                     d_x_init=None, retry=False):
+                     d_x_init=None, retry=False, d_order=None):
         """All arguments are torch CUDA tensors (any dtype; only data_ptr() is used) or None.
-        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream.  retry: lscqp_solve_batch_device_ex's second pass."""
+        Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream.  retry: lscqp_solve_batch_device_ex's second pass.
+        d_order: int32 permutation of 0 .. n-1 (lscqp_solve_batch_device_ordered: the k-th slot of the launch solves instance d_order[k])."""
         import torch
 
         s = stream if stream is not None else torch.cuda.current_stream()
@@ -683,8 +688,18 @@ class Solver:
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
 
-        rc = lib().lscqp_solve_batch_device_ex(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
-                                               p(d_obj), p(d_status), p(d_info), int(retry), C.c_void_p(s.cuda_stream))
+        rc = lib().lscqp_solve_batch_device_ordered(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
+                                                    p(d_obj), p(d_status), p(d_info), int(retry), p(d_order), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    @staticmethod
+    def order_by_work_device(n, d_info_prev, d_order_out, stream=None):
+        """lscqp_order_by_work_device: d_order_out (int32[n]) := instances by the iterations of their previous solve, most first."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_order_by_work_device(int(n), C.c_void_p(d_info_prev.data_ptr()), C.c_void_p(d_order_out.data_ptr()), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

@@ -41,6 +41,7 @@ extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int
 
 namespace lscplan {
 
+constexpr size_t kOrderMin = 512;  // agents from which a plan carries the work order of its QP launch from replan to replan
 constexpr int kThreads = 64;
 static_assert(kThreads == 64, "prepare_kernel hands data between the lanes of ONE wavefront (initial trajectory read before the prediction overwrites it)");
 
@@ -199,6 +200,7 @@ struct lscqp_plan_s {
     double *radius = nullptr, *downwash = nullptr, *traj = nullptr, *pos = nullptr, *points = nullptr, *x_init = nullptr, *x_new = nullptr, *own = nullptr;
     int32_t* nbr = nullptr;
     uint64_t* off = nullptr;
+    int32_t* order = nullptr;  // work order of the next solve (n_agents >= kOrderMin only)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr;
@@ -283,8 +285,16 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
         const unsigned nb = (unsigned)((s.n_agents + lscplan::kThreads - 1) / lscplan::kThreads);
         hipLaunchKernelGGL(lscplan::finalize_goal_kernel, dim3(nb), dim3(lscplan::kThreads), 0, stream, s, hdr);
     }
-    PLAN_TRY(lscqp_solve_batch_device_ex(p->hq, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj, status,
-                                         info, 1, stream));
+    // Work order of the solve (include/lscqp.h): from the second replan on, the agents whose previous QP took the most iterations go
+    // first -- the info records of the previous replan are still in place here.  Only where a launch can have a tail: more agents than
+    // a few rounds of workgroups (below that every QP starts at once).
+    const int32_t* order = nullptr;
+    if (p->order && !first_replan) {
+        PLAN_TRY(lscqp_order_by_work_device(s.n_agents, info, p->order, stream));
+        order = p->order;
+    }
+    PLAN_TRY(lscqp_solve_batch_device_ordered(p->hq, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj,
+                                              status, info, 1, order, stream));
     {   // commit (failsafe of trajOptimization, prev_traj = desired_traj, the goal point carried over) + isSolValid + doStep: one launch
         const lscqp_class_desc* cd = lscqp_class_desc_of_(h);
         if (cd->use_sfc && !p->map) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "the class has corridor rows but the plan has no map");
@@ -454,7 +464,7 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc_pub<lscqp_safety>(p, LSCQP_PLAN_BUF_SAFETY, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
         ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
         ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->own, n * P * 3)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
-        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1));
+        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1)) && (n >= lscplan::kOrderMin ? ok(dalloc(p, &p->order, n)) : true);
     if (rc == LSCQP_OK && desc->closed_loop) {
         p->buf[LSCQP_PLAN_BUF_NEXT_STATE] = (double*)p->buf[LSCQP_PLAN_BUF_STATE] + desc->first_agent * 9;
         p->bytes[LSCQP_PLAN_BUF_NEXT_STATE] = n * 9 * sizeof(double);

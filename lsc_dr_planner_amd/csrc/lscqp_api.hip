@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -150,6 +152,76 @@ int cu_count() {  // of the CURRENT device (one process may drive several: lscqp
     }
     return n_cu[dev];
 }
+// Work-queue counters of the persistent launches (lscqp_kernel.hpp: lscqp_pdip_kernel): a ring of zeroable ints per device, one taken per
+// launch and cleared on the launch's own stream right before it (a memset node when the stream is being captured into a graph -- the ring
+// exists by then: the plan's first replan runs eagerly).  4096 slots: a launch would have to be overtaken by 4096 later ones to share a
+// counter with one of them.
+constexpr unsigned kQueueRing = 4096;
+int* next_queue_counter(hipStream_t stream) {
+    static int* ring[64] = {};
+    static std::mutex mu;
+    static std::atomic<unsigned> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    int* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ring[dev]) {
+            if (hipMalloc(&ring[dev], sizeof(int) * kQueueRing) != hipSuccess) {
+                ring[dev] = nullptr;
+                return nullptr;  // (the launch then runs one instance per workgroup, as before)
+            }
+        }
+        base = ring[dev];
+    }
+    int* const slot = base + (next.fetch_add(1, std::memory_order_relaxed) % kQueueRing);
+    if (hipMemsetAsync(slot, 0, sizeof(int), stream) != hipSuccess) return nullptr;
+    return slot;
+}
+
+// lscqp_order_by_work_device: a stable counting sort of the instances by the iterations their previous solve took, most first.  One
+// workgroup; thread t owns the contiguous range [t c, (t + 1) c) of the instances, so equal keys keep their order and the result is
+// the same from run to run (the order only decides WHEN an instance is solved, never its result).
+constexpr int kOrdT = 128, kOrdK = 64;  // (33 KB of LDS for the per-thread histograms)
+__global__ __launch_bounds__(kOrdT) void order_by_work_kernel(int64_t n, const lscqp_info* __restrict__ info, int32_t* __restrict__ order) {
+    __shared__ int hist[kOrdK][kOrdT + 1];
+    __shared__ int colsum[kOrdK];
+    const int t = threadIdx.x;
+    const int64_t c = (n + kOrdT - 1) / kOrdT, lo = (int64_t)t * c, hi = lo + c < n ? lo + c : n;
+    for (int k = 0; k < kOrdK; k++) hist[k][t] = 0;
+    for (int64_t i = lo; i < hi; i++) {
+        int key = info[i].iterations;
+        key = key < 0 ? 0 : (key >= kOrdK ? kOrdK - 1 : key);
+        hist[kOrdK - 1 - key][t]++;  // row 0 = the most iterations
+    }
+    __syncthreads();
+    if (t < kOrdK) {  // exclusive prefix over the threads of one key
+        int run = 0;
+        for (int u = 0; u < kOrdT; u++) {
+            const int v = hist[t][u];
+            hist[t][u] = run;
+            run += v;
+        }
+        colsum[t] = run;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < kOrdK; k++) {
+            const int v = colsum[k];
+            colsum[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    for (int64_t i = lo; i < hi; i++) {
+        int key = info[i].iterations;
+        key = key < 0 ? 0 : (key >= kOrdK ? kOrdK - 1 : key);
+        const int r = kOrdK - 1 - key;
+        order[colsum[r] + hist[r][t]++] = (int32_t)i;
+    }
+}
+
 bool shape_exists(int M, int dim, int es, int mixed) {
     for (const Inst& i : kInst)
         if (i.M == M && i.dim == dim && i.es == es && i.mixed == mixed) return true;
@@ -648,10 +720,31 @@ int64_t lscqp_algorithmic_bytes(lscqp_handle h, int32_t n_obs) {
     return (int64_t)(h->dev.rows_f32 ? 16 : 32) * n_obs * h->P + 48 * h->desc.M + 256 + 8 * h->nv + 16;
 }
 
+int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t* d_order_out, void* stream) {
+    if (n < 0 || n > 0x7fffffff) return fail(LSCQP_ERR_INVALID_ARGUMENT, "0 <= n < 2^31 required");
+    if (n == 0) return LSCQP_OK;
+    if (!d_info_prev || !d_order_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    hipLaunchKernelGGL(order_by_work_kernel, dim3(1), dim3(kOrdT), 0, (hipStream_t)stream, n, d_info_prev, d_order_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (order_by_work): ") + hipGetErrorString(e));
+    return LSCQP_OK;
+}
+
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                                 const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
                                 lscqp_info* d_info_out, int32_t retry, void* stream) {
+    return lscqp_solve_batch_device_ordered(h, n, n_obs_max, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
+                                            d_info_out, retry, nullptr, stream);
+}
+
+int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                                     const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                                     const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                                     lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -670,6 +763,12 @@ int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, co
     const Inst* inst64 = mixed ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : inst;
     lscqp::DevClass cls = h->dev;
     cls.n_obs_max = n_obs_max;
+    cls.order = d_order;
+    // a launch of more instances than the device has CUs MAY exceed what the chip holds at once: it gets a zeroed work-queue counter and
+    // the instance's launcher decides (lscqp_inst.hip: persistent workgroups over the queue, or one instance per workgroup)
+    static const bool no_queue = getenv("LSCQP_NO_QUEUE") != nullptr;  // (development: tools/lpt_probe.py tells the queue and the order apart)
+    const bool queued = !no_queue && n > (int64_t)cu_count();
+    auto with_queue = [&](lscqp::DevClass& c) { c.queue = queued ? next_queue_counter((hipStream_t)stream) : nullptr; };
     hipError_t e = hipSuccess;
     if (!inst || !inst64) {
         // no compiled instance serves this launch (shape without one, or more obstacles than its register slots hold): the
@@ -696,10 +795,12 @@ int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, co
         const Inst* other = other_order_instance(inst64, n_obs_max);
         if (!other) return LSCQP_OK;
         cls.repair = 1;
+        with_queue(cls);
         e = other->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (other-order pass): ") + hipGetErrorString(e));
         return LSCQP_OK;
     }
+    with_queue(cls);
     e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
     // Second pass over the batch, same stream, no host round trip: a workgroup whose instance is already OPTIMAL (or was
@@ -713,6 +814,7 @@ int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, co
     const Inst* alt = retry == 2 ? other_order_instance(inst64, n_obs_max) : nullptr;
     if (mixed || (retry && (d_x_init || alt))) {
         cls.repair = 1;
+        with_queue(cls);
         e = (alt ? alt : inst64)->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
                                      d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));

@@ -129,8 +129,8 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
     double* const Rs_ = smem + S.o_rs;
     double* const Rl_ = smem + S.o_rl;
     const int tid = threadIdx.x;
-    const int64_t q = blockIdx.x;
-    if (q >= n) return;
+    if ((int64_t)blockIdx.x >= n) return;
+    const int64_t q = cls.order ? (int64_t)cls.order[blockIdx.x] : (int64_t)blockIdx.x;  // (lscqp_kernel.hpp: work order of the launch; no queue here)
 #ifdef LSCQP_GEN_TIMING
     unsigned long long tprev_ = __builtin_readcyclecounter();
 #endif

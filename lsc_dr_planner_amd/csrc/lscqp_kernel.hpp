@@ -48,6 +48,13 @@ struct DevClass {
     int repair;     // second pass over a batch: only instances whose status_out is neither OPTIMAL nor CAPACITY are solved
     double warm_mu0, warm_s0;  // centring of an instance that comes with an initial trajectory (lscqp_class_desc.warm_start)
     double warm_net;           // > 0: first-step length below which such an instance returns to the (1e-3, 0.03) centring
+    // Work distribution of a launch (round 4).  order: the k-th workgroup-slot of the launch solves instance order[k] (NULL: k) -- a
+    // permutation of 0 .. n-1, longest expected work first (lscqp_order_by_work_device).  queue: a zeroed counter; when set, the launch
+    // is PERSISTENT: gridDim.x workgroups (what the chip holds at once) take their first instance from blockIdx.x and every further
+    // one from gridDim.x + atomicAdd(queue, 1) -- true list scheduling instead of the hardware's dispatch order (NULL: one instance
+    // per workgroup, grid = n).
+    const int32_t* order;
+    int* queue;
 };
 
 // Q_base * dt^5 for n = 5, phi = 3 (integers)
@@ -394,18 +401,15 @@ struct Cfg {
 #ifndef LSCQP_KERNEL_ATTR
 #define LSCQP_KERNEL_ATTR
 #endif
+// ONE instance, solved by the calling workgroup (the body of the kernel below).
 template <int M, int DIM, bool ES, int NSLOT, int W = 1, class FT = double>
-__global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
-                                                        const lscqp_row* __restrict__ rows,
-                                                        const uint64_t* __restrict__ row_offsets,
-                                                        const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init,
-                                                        double* __restrict__ x_out,
-                                                        double* __restrict__ obj_out, int32_t* __restrict__ status_out,
-                                                        lscqp_info* __restrict__ info_out) {
+__device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_t q, double* const smem, const lscqp_header* __restrict__ hdr,
+                                               const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
+                                               const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init, double* __restrict__ x_out,
+                                               double* __restrict__ obj_out, int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out) {
     using C = Cfg<M, DIM, ES, NSLOT, W, (int)sizeof(FT)>;
     constexpr bool MIXED = !std::is_same<FT, double>::value;
     constexpr int P = C::P, CP = C::CP, NZA = C::NZA, NZ = C::NZ, NX = C::NX, G = C::G, LDH = C::LDH, T = C::T;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double* const c_ = smem + C::o_c;
     double* const dca_ = smem + C::o_dca;
     double* const dc_ = smem + C::o_dc;
@@ -496,8 +500,6 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
         cross3(v, b, c, op_max, op_max, op_max);
         return v;
     };
-    const int64_t q = blockIdx.x;
-    if (q >= n) return;
     // The header (256 B) and the instance's corridor boxes (48 B per segment) are fetched ONCE, one 8-byte load per lane, and parked in
     // the pivot-column buffer (idle until the first factorisation); the prologue reads them from there.  Read field by field from
     // global memory they were a string of dependent scalar / vector loads: 9.6 k + 11.9 k cycles of a 4096-QP launch's prologue per QP
@@ -2242,6 +2244,56 @@ __global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(De
             info_out[q].res_primal = res_p;
             info_out[q].res_dual = res_d;
             info_out[q].gap = res_gap;
+        }
+    }
+}
+
+// The kernel: one workgroup of W wavefronts per instance AT A TIME.  grid = n and one instance per workgroup when the launch fits the
+// chip at once; otherwise, in the PERSIST instances (cls.queue set), grid = the workgroups the chip holds and each of them keeps taking
+// instances from the queue until it is empty -- list scheduling by construction.  Measured why (tools/lpt_probe.py, 1024 x M10 x 40 on
+// one MI355X, one workgroup per CU): with grid = n the launch lasted 1.07 - 1.21 ms in the given and in random orders -- MORE than list
+// scheduling's worst case, sum / 256 + longest = 0.57 + 0.39 ms: the hardware does not hand a free CU the next workgroup of the grid
+// in general -- and 0.83 ms with the instances sorted longest first.
+// PERSIST is a per-instance choice (lscqp_inst.hip): the loop keeps every kernel argument live across the whole body for the next
+// instance (ten pointers and the class, most of them dead after the prologue of the one-instance form), which pushes the
+// register-tight one-wavefront instances into scratch (<5,3,true,10,1>: 0 -> 176 B per lane; reading the arguments back from the kernarg
+// segment per instance made it 632 B) -- those keep one instance per workgroup and take only the ORDER of the launch.
+template <int M, int DIM, bool ES, int NSLOT, int W = 1, class FT = double, bool PERSIST = false>
+__global__ __launch_bounds__(64 * W) LSCQP_KERNEL_ATTR void lscqp_pdip_kernel(DevClass cls, int64_t n, const lscqp_header* __restrict__ hdr,
+                                                        const lscqp_row* __restrict__ rows,
+                                                        const uint64_t* __restrict__ row_offsets,
+                                                        const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init,
+                                                        double* __restrict__ x_out,
+                                                        double* __restrict__ obj_out, int32_t* __restrict__ status_out,
+                                                        lscqp_info* __restrict__ info_out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if constexpr (!PERSIST) {
+        const int64_t k = blockIdx.x;
+        if (k >= n) return;
+        const int64_t q = cls.order ? (int64_t)cls.order[k] : k;
+        lscqp_pdip_one<M, DIM, ES, NSLOT, W, FT>(cls, q, smem, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out);
+    } else {
+        int64_t k = blockIdx.x;
+#pragma unroll 1
+        for (;;) {
+            if (k >= n) return;
+            const int64_t q = cls.order ? (int64_t)cls.order[k] : k;
+            lscqp_pdip_one<M, DIM, ES, NSLOT, W, FT>(cls, q, smem, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out);
+            if (!cls.queue) return;  // (uniform: a kernel argument)
+            // next instance: one atomic per workgroup, handed to its lanes through LDS (the instance just finished no longer needs it)
+            __syncthreads();
+            if (threadIdx.x == 0) *reinterpret_cast<volatile long long*>(smem) = (long long)gridDim.x + (long long)atomicAdd(cls.queue, 1);
+            if constexpr (W == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
+            } else {
+                __syncthreads();
+            }
+            k = *reinterpret_cast<volatile long long*>(smem);
+            if constexpr (W == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                __syncthreads();
+            }
         }
     }
 }

@@ -860,3 +860,58 @@ def test_tight_warm_start_mode_reaches_the_same_optimum(api, oracle, torch_cuda,
             it_tight += B["info"]["iterations"].sum()
         sw.advance(B["x"])
     assert M != 5 or it_tight < 0.8 * it_base, (it_tight, it_base)
+
+
+@pytest.mark.gpu
+def test_work_order_and_work_queue_change_when_an_instance_is_solved_never_its_result(api, oracle, torch_cuda):
+    """Round 4: a launch with more instances than the chip holds runs persistent workgroups over a queue, and the caller may name the order
+    (lscqp_solve_batch_device_ordered; lscqp_order_by_work_device sorts by the previous solve's iterations, most first, stable).  Both only
+    decide WHEN an instance is solved: 1200 x M10 x 12 QPs (more than four rounds of one workgroup per CU) give bit for bit the same plans,
+    objectives, statuses and iteration counts in one launch as given, in the sorted order, in a random order, and solved in chunks that fit
+    the chip (one instance per workgroup, no queue); a sample agrees with the oracle."""
+    torch = torch_cuda
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim, n_obs = 1200, 10, 3, 12
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=41)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    b = sw.build()
+    hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_hdr, d_rows, d_off, d_sfc = up(hdr), up(rows), up(off), up(sfc)
+
+    def solve(d_order=None, chunks=None):
+        d_x = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
+        d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+        d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        d_info = torch.zeros(N * api.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        if chunks is None:
+            sol.solve_device(N, sw.n_obs, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_order=d_order)
+        else:
+            R2, S2 = rows.reshape(N, -1), sfc.reshape(N, M)
+            for lo in range(0, N, chunks):
+                hi = min(N, lo + chunks)
+                o = np.arange(hi - lo + 1, dtype=np.uint64) * np.uint64(R2.shape[1])
+                sol.solve_device(hi - lo, sw.n_obs, up(hdr[lo:hi]), up(R2[lo:hi]), up(o), up(S2[lo:hi]), d_x[lo * sol.nv:], d_obj[lo:], d_st[lo:],
+                                 d_info[lo * api.INFO_DTYPE.itemsize:])
+        torch.cuda.synchronize()
+        return d_x.cpu().numpy(), d_obj.cpu().numpy(), d_st.cpu().numpy(), d_info.cpu().numpy().view(api.INFO_DTYPE).copy(), d_info
+
+    x0, o0, s0, i0, d_info0 = solve()
+    assert (s0 == 0).all(), np.bincount(s0)
+    d_order = torch.zeros(N, dtype=torch.int32, device=dev)
+    sol.order_by_work_device(N, d_info0, d_order)
+    torch.cuda.synchronize()
+    order = d_order.cpu().numpy()
+    assert np.array_equal(order, np.argsort(-i0["iterations"], kind="stable").astype(np.int32)) and i0["iterations"].max() > i0["iterations"].min()
+    rnd = np.random.default_rng(3).permutation(N).astype(np.int32)
+    for name, res in (("sorted", solve(d_order)), ("random", solve(torch.from_numpy(rnd).to(dev))), ("chunks of 200", solve(chunks=200))):
+        x, o, s, i, _ = res
+        assert np.array_equal(x, x0) and np.array_equal(o, o0) and np.array_equal(s, s0) and np.array_equal(i["iterations"], i0["iterations"]), name
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=sw.world_min, world_max=sw.world_max)
+    ag, lsc, loff, sfc_o = H.swarm_oracle_inputs(oracle, sw, b)
+    sel = np.r_[order[:6], order[-6:]]  # the longest and the shortest solves
+    R = oracle.solve_batch(cls, ag[sel], lsc, loff[sel], np.ascontiguousarray(sfc_o.reshape(N, M)[sel]).reshape(-1), threads=12)
+    assert (R["status"] == 0).all()
+    assert np.abs(x0.reshape(N, -1)[sel] - R["x"]).max() <= 1e-6 and (np.abs(o0[sel] - R["obj"]) / np.maximum(1, np.abs(R["obj"]))).max() <= OBJ_TOL

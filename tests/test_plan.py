@@ -709,3 +709,33 @@ def test_update_that_changes_the_shape_under_a_live_plan_is_refused(api, torch_c
     assert np.array_equal(p.get(api.PLAN_PLAN), q.get(api.PLAN_PLAN)) and (p.get(api.PLAN_STATUS) == 0).all()
     p.close()
     q.close()
+
+
+@pytest.mark.gpu
+def test_large_plan_carries_its_work_order_and_graph_equals_eager(api, torch_cuda):
+    """A plan of 600 agents (>= 512: DESIGN.md section 4) sorts its QP launch by the previous replan's iteration counts
+    (lscqp_order_by_work_device, one more node of the chain) -- the order decides when an agent's QP runs, never its result: two plans of
+    the same mission, one stepped eagerly and one through its captured graph, stay bit-identical over six replans; every QP solves."""
+    N, M = 600, 5
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(6), indexing="ij"), -1).reshape(-1, 3)[:N].astype(np.float64)
+    starts = g * 1.25 + np.array([-5.5, -5.5, 1.0])
+    goals = starts + np.array([0.5, 0.25, 0.0])
+    wmin, wmax = [-8.0, -8.0, 0.0], [8.0, 8.0, 9.0]
+    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, use_sfc=False, world_min=wmin, world_max=wmax))
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = 0.15, 2.0, 1.0, 2.0, 1.0
+    kw = dict(constraint_mode=api.GEN_LSC, optimize_goal=False, closed_loop=True)
+    pe, pg = api.Plan(sol, None, N, 12, ag, **kw), api.Plan(sol, None, N, 12, ag, **kw)
+    for p in (pe, pg):
+        p.reset(starts, goals)
+        p.put(api.PLAN_WAYPOINT, goals)
+    for k in range(6):
+        pe.step(graph=False)
+        pg.step(graph=True)
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(pe.get(api.PLAN_PLAN), pg.get(api.PLAN_PLAN)) and np.array_equal(pe.get(api.PLAN_OBJECTIVE), pg.get(api.PLAN_OBJECTIVE)), k
+        assert (pe.get(api.PLAN_STATUS) == 0).all(), (k, np.bincount(pe.get(api.PLAN_STATUS)))
+    it = pe.get(api.PLAN_INFO)["iterations"]
+    assert it.max() >= 2 and pg.graph_nodes() >= 6
+    pe.close()
+    pg.close()

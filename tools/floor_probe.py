@@ -73,7 +73,7 @@ class DevClass(C.Structure):
     _fields_ = [("dt", C.c_double), ("w_c", C.c_double), ("w_t", C.c_double), ("comm_range", C.c_double), ("world_min", C.c_double * 3),
                 ("world_max", C.c_double * 3), ("q2s", C.c_double), ("dQ", C.c_double * 36), ("tol", C.c_double), ("max_iter", C.c_int),
                 ("use_sfc", C.c_int), ("n_obs_max", C.c_int), ("rows_f32", C.c_int), ("rsfc", C.c_int), ("repair", C.c_int),
-                ("warm_mu0", C.c_double), ("warm_s0", C.c_double), ("warm_net", C.c_double)]
+                ("warm_mu0", C.c_double), ("warm_s0", C.c_double), ("warm_net", C.c_double), ("order", C.c_void_p), ("queue", C.c_void_p)]
 
 
 cls = DevClass()

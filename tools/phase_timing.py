@@ -44,7 +44,7 @@ class DevClass(C.Structure):
     _fields_ = [("dt", C.c_double), ("w_c", C.c_double), ("w_t", C.c_double), ("comm_range", C.c_double), ("world_min", C.c_double * 3),
                 ("world_max", C.c_double * 3), ("q2s", C.c_double), ("dQ", C.c_double * 36), ("tol", C.c_double), ("max_iter", C.c_int),
                 ("use_sfc", C.c_int), ("n_obs_max", C.c_int), ("rows_f32", C.c_int), ("rsfc", C.c_int), ("repair", C.c_int),
-                ("warm_mu0", C.c_double), ("warm_s0", C.c_double), ("warm_net", C.c_double)]
+                ("warm_mu0", C.c_double), ("warm_s0", C.c_double), ("warm_net", C.c_double), ("order", C.c_void_p), ("queue", C.c_void_p)]
 kq = [720,-1800,1200,0,0,-120,-1800,4800,-3600,0,600,0,1200,-3600,3600,-1200,0,0,0,0,-1200,3600,-3600,1200,0,600,0,-3600,4800,-1800,-120,0,0,1200,-1800,720]
 cls = DevClass(); cls.dt = 0.2; cls.w_c = 0.01; cls.w_t = 1.0; cls.comm_range = 3.0
 for k in range(3): cls.world_min[k] = sw.world_min[k]; cls.world_max[k] = sw.world_max[k]
