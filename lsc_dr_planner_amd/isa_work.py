@@ -32,7 +32,8 @@ def disassemble(obj_path, workdir):
 
 
 def count(asm_text):
-    """-> dict for the (single) lscqp_pdip_kernel of the object: per-lane counts inside / outside the iteration loop."""
+    """-> dict for the FIRST lscqp_pdip_kernel of the object (the one-instance-per-workgroup form; an instance with a persistent form
+    carries that second, same body): per-lane counts inside / outside the iteration loop."""
     start, ins = None, []
     for l in asm_text.split("\n"):
         s = _SYM.match(l)
@@ -57,7 +58,7 @@ def count(asm_text):
     mark = {}
     for l in asm_text.split("\n"):
         m = re.match(r"^\s+s_nop (12|13|14)\s*//\s*([0-9A-Fa-f]+):", l)
-        if m:
+        if m and ins[0][0] <= int(m.group(2), 16) <= ins[-1][0]:  # (an instance may carry two forms of the kernel: the first one counts)
             mark.setdefault(int(m.group(1)), []).append(int(m.group(2), 16))
     if sorted(mark) != [12, 13, 14] or any(len(v) != 1 for v in mark.values()):
         raise RuntimeError("iteration markers not found exactly once each: %r" % mark)
@@ -73,6 +74,8 @@ def count(asm_text):
         if not m:
             continue
         op, addr = m.group(1), int(m.group(3), 16)
+        if not (ins[0][0] <= addr <= ins[-1][0]):
+            continue
         if op == "s_nop":
             k = re.match(r"^\s+s_nop (\d+)", l)
             k = int(k.group(1)) if k else -1

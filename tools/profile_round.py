@@ -53,6 +53,12 @@ def profile_config(c):
     from bench import CONFIGS
 
     N = CONFIGS[c]["agents"]
+
+    def timed_shape(name, grid, wg):
+        """a launch over the whole batch: one workgroup per instance (grid = N workgroups), or the persistent form of the kernel (its last
+        template argument is `true`; the grid is then what the chip holds)"""
+        return grid == N * wg or name.replace(" ", "").split(">(")[0].endswith(",true")
+
     res = {"config": c, "what": CONFIGS[c]["what"], "command": " ".join(["python", "bench.py"] + bench_cmd(c)[2:])}
     # 1. kernel trace
     d = os.path.join(OUT, "trace_" + c)
@@ -70,7 +76,7 @@ def profile_config(c):
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
-            if "lscqp_pdip_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N * int(r["Workgroup_Size_X"]):
+            if "lscqp_pdip_kernel" in r["Kernel_Name"] and timed_shape(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])):
                 per.setdefault(r["Kernel_Name"], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         res["timed_launches"] = {}
         for k, v in per.items():
@@ -85,7 +91,7 @@ def profile_config(c):
         acc, disp = {}, {}
         for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "lscqp_pdip_kernel" not in r["Kernel_Name"] or int(r["Grid_Size"]) != N * int(r["Workgroup_Size"]):
+                if "lscqp_pdip_kernel" not in r["Kernel_Name"] or not timed_shape(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"])):
                     continue
                 kn = r["Kernel_Name"]
                 acc.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
