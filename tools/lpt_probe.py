@@ -17,7 +17,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from lsc_dr_planner_amd import api, synth  # noqa: E402
 
-for key in sys.argv[1:] or ["c3", "c4_f64", "c2"]:
+for key in [a for a in sys.argv[1:] if not a.startswith("-")] or ([] if "--chain" in sys.argv else ["c3", "c4_f64", "c2"]):
     cfg = bench.CONFIGS[key]
     N, M, D, NOBS = cfg["agents"], cfg["segments"], cfg["dim"], cfg["obs"]
 
@@ -62,3 +62,55 @@ for key in sys.argv[1:] or ["c3", "c4_f64", "c2"]:
         res[name] = ms
     print("%s (%d QPs, iterations mean %.2f max %d, queue %s): " % (key, N, it.mean(), it.max(), "off" if os.environ.get("LSCQP_NO_QUEUE") else "on") +
           " | ".join("%s %.4f ms" % kv for kv in res.items()))
+
+
+def chain_hint_quality(N=256, replans=40):
+    """How good is the hint in a real closed loop?  bench.py's 3-D replan chain (CLSC rows, corridors, goal LP, QP; agents on a sphere swapping
+    sides) with N agents: per replan the iteration count of every agent's QP; reported: the rank correlation between consecutive replans and
+    how many of the slowest 10 % of a replan were among the slowest 25 % of the previous one (what the first round of a sorted launch holds)."""
+    rng = np.random.default_rng(7)
+    radii = (10.0, 10.0, 4.0)
+    i = np.arange(N) + 0.5
+    phi, th = np.arccos(1 - 2 * i / N), np.pi * (1 + 5 ** 0.5) * i
+    starts = np.round((np.c_[np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)] * list(radii) + [0, 0, radii[2] + 1.0]) * 4) / 4
+    goals = np.c_[-starts[:, 0], -starts[:, 1], 2 * (radii[2] + 1.0) - starts[:, 2]]
+    boxes = []
+    while len(boxes) < 24:
+        c = np.r_[rng.uniform(-0.7 * radii[0], 0.7 * radii[0], 2), rng.uniform(1.5, 2 * radii[2] + 0.5)]
+        if np.abs(starts - c).max(axis=1).min() > 1.2:
+            boxes.append([c[0], c[1], c[2], 0.8, 0.8, 0.8])
+    wmin, wmax = [-radii[0] - 2.0, -radii[1] - 2.0, 0.0], [radii[0] + 2.0, radii[1] + 2.0, 2 * radii[2] + 2.0]
+    sol = api.Solver(api.make_desc(M=5, dim=3, dt=0.2, world_min=wmin, world_max=wmax))
+    wmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = 0.15, 2.0, 1.0, 2.0, 1.0
+    plan = api.Plan(sol, wmap, N, 20, ag, constraint_mode=api.GEN_CLSC, sfc_mode=api.SFC_FROM_HULL, optimize_goal=True, closed_loop=True)
+    plan.reset(starts)
+    its = []
+    for k in range(replans + 1):
+        pos = plan.get(api.PLAN_STATE).reshape(N, 9)[:, :3]
+        d = goals - pos
+        dist = np.linalg.norm(d, axis=1, keepdims=True)
+        plan.put(api.PLAN_WAYPOINT, np.float32(pos + d / np.maximum(dist, 1e-9) * np.minimum(dist, 0.75)).astype(np.float64))
+        plan.step(graph=True)
+        torch.cuda.synchronize()
+        if k >= 1:
+            its.append(plan.get(api.PLAN_INFO)["iterations"].copy())
+    its = np.array(its)
+    from scipy.stats import spearmanr
+
+    rho = [spearmanr(its[k - 1], its[k]).correlation for k in range(1, len(its)) if its[k].std() > 0 and its[k - 1].std() > 0]
+    hit = []
+    for k in range(1, len(its)):
+        slow = np.argsort(-its[k], kind="stable")[: max(1, N // 10)]
+        first_round = set(np.argsort(-its[k - 1], kind="stable")[: N // 4].tolist())
+        hit.append(np.mean([q in first_round for q in slow]))
+    print("closed loop, %d agents x %d replans: iterations mean %.2f max %d; rank correlation between consecutive replans %.2f (median); "
+          "of the slowest 10 %% of a replan %.0f %% were among the slowest 25 %% of the previous one" % (
+              N, len(its), its.mean(), its.max(), float(np.median(rho)), 100 * float(np.mean(hit))))
+    plan.close()
+    wmap.close()
+
+
+if "--chain" in sys.argv:
+    chain_hint_quality()
