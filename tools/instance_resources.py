@@ -2,7 +2,7 @@
 (llvm-readelf --notes of the unbundled gfx950 code object).  Run after a build: a kernel change that makes a headline instance spill shows here."""
 import glob,os,subprocess,re,sys,tempfile
 LL="/opt/rocm/lib/llvm/bin"
-objs=sorted(glob.glob('/root/repo/lsc_dr_planner_amd/csrc/_obj/inst_*.o'))
+objs=sorted(glob.glob("/root/repo/lsc_dr_planner_amd/csrc/_obj%s/inst_*.o" % (("_" + os.environ["LSCQP_AB"]) if os.environ.get("LSCQP_AB") else "")))
 out=[]
 for o in objs:
     with tempfile.TemporaryDirectory() as td:
