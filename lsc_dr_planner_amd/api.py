@@ -115,6 +115,10 @@ def lib():
         L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
         L.lscqp_solve_batch_device_ordered.restype = C.c_int
         L.lscqp_solve_batch_device_ordered.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp, vp]
+        L.lscqp_order_by_cost_device.restype = C.c_int
+        L.lscqp_order_by_cost_device.argtypes = [C.c_int64, vp, vp, vp]
+        L.lscqp_construct_sfc_device_ordered.restype = C.c_int
+        L.lscqp_construct_sfc_device_ordered.argtypes = [vp, vp, C.c_int32, C.c_int64] + [vp] * 7
         L.lscqp_order_by_work_device.restype = C.c_int
         L.lscqp_order_by_work_device.argtypes = [C.c_int64, vp, vp, vp]
         L.lscqp_solve_batch_stream.restype = C.c_int
@@ -229,7 +233,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
                     "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
@@ -694,6 +698,16 @@ class Solver:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     @staticmethod
+    def order_by_cost_device(n, d_cost_prev, d_order_out, stream=None):
+        """lscqp_order_by_cost_device: d_order_out (int32[n]) := agents by the cost (uint32) of their previous corridor, most expensive first."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = lib().lscqp_order_by_cost_device(int(n), C.c_void_p(d_cost_prev.data_ptr()), C.c_void_p(d_order_out.data_ptr()), C.c_void_p(s.cuda_stream))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    @staticmethod
     def order_by_work_device(n, d_info_prev, d_order_out, stream=None):
         """lscqp_order_by_work_device: d_order_out (int32[n]) := instances by the iterations of their previous solve, most first."""
         import torch
@@ -762,14 +776,15 @@ class Solver:
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
-    def construct_sfc_device(self, world_map, mode, n, d_points, d_radius, d_sfc, d_status, stream=None):
-        """Corridor update of n agents on the device (SFC_INIT / SFC_FROM_HULL / SFC_FROM_POINT, see include/lscqp.h)."""
+    def construct_sfc_device(self, world_map, mode, n, d_points, d_radius, d_sfc, d_status, stream=None, d_order=None, d_cost=None):
+        """Corridor update of n agents on the device (SFC_INIT / SFC_FROM_HULL / SFC_FROM_POINT, see include/lscqp.h).  d_order: int32
+        permutation (workgroup k builds agent d_order[k]'s corridor); d_cost: uint32[n], every agent's cost of this launch."""
         import torch
 
         s = stream if stream is not None else torch.cuda.current_stream()
-        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        rc = lib().lscqp_construct_sfc_device(self._h, world_map._h, int(mode), n, p(d_points), p(d_radius), p(d_sfc), p(d_status),
-                                              C.c_void_p(s.cuda_stream))
+        p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)  # noqa: E731
+        rc = lib().lscqp_construct_sfc_device_ordered(self._h, world_map._h, int(mode), n, p(d_points), p(d_radius), p(d_sfc), p(d_status),
+                                                      p(d_order), p(d_cost), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

@@ -201,6 +201,8 @@ struct lscqp_plan_s {
     int32_t* nbr = nullptr;
     uint64_t* off = nullptr;
     int32_t* order = nullptr;  // work order of the next solve (n_agents >= kOrderMin only)
+    int32_t* sfc_order = nullptr;  // ... and of the next corridor launch, from the costs recorded by this one
+    uint32_t* sfc_cost = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr;
@@ -271,9 +273,16 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
     if (from_plans && !whole_shift) PLAN_TRY(lscqp_shift_traj_partial_device(h, s.n_total, fraction, s.z_2d, x_plan, p->traj, stream));
     hipLaunchKernelGGL(lscplan::prepare_kernel, dim3((unsigned)s.n_total), dim3(lscplan::kThreads), 0, stream, s, first_replan ? 1 : 0,
                        whole_shift ? (const double*)x_plan : (const double*)nullptr, state, waypoint, goal, p->traj, p->par, p->pos, hdr, p->points, p->x_init, p->own);
-    if (p->map)
-        PLAN_TRY(lscqp_construct_sfc_device(h, p->map, first_replan ? LSCQP_SFC_INIT : p->d.sfc_mode, s.n_agents, p->points,
-                                            p->radius + s.first_agent, sfc, sfc_status, stream));
+    if (p->map) {
+        // (large plans: most expensive corridor of the previous replan first, the costs of this one recorded for the next)
+        const int32_t* sfc_order = nullptr;
+        if (p->sfc_order && !first_replan) {
+            PLAN_TRY(lscqp_order_by_cost_device(s.n_agents, p->sfc_cost, p->sfc_order, stream));
+            sfc_order = p->sfc_order;
+        }
+        PLAN_TRY(lscqp_construct_sfc_device_ordered(h, p->map, first_replan ? LSCQP_SFC_INIT : p->d.sfc_mode, s.n_agents, p->points,
+                                                    p->radius + s.first_agent, sfc, sfc_status, sfc_order, p->sfc_cost, stream));
+    }
     PLAN_TRY(lscqp_select_neighbours_device(h, s.n_agents, s.first_agent, s.n_total, s.n_obs, lscqp_class_desc_of_(h)->communication_range, p->pos, p->nbr, count,
                                             stream));
     if (s.n_obs > 0)
@@ -464,7 +473,7 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc_pub<lscqp_safety>(p, LSCQP_PLAN_BUF_SAFETY, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
         ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
         ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->own, n * P * 3)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
-        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1)) && (n >= lscplan::kOrderMin ? ok(dalloc(p, &p->order, n)) : true);
+        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1)) && (n >= lscplan::kOrderMin ? (ok(dalloc(p, &p->order, n)) && (map ? (ok(dalloc(p, &p->sfc_order, n)) && ok(dalloc(p, &p->sfc_cost, n))) : true)) : true);
     if (rc == LSCQP_OK && desc->closed_loop) {
         p->buf[LSCQP_PLAN_BUF_NEXT_STATE] = (double*)p->buf[LSCQP_PLAN_BUF_STATE] + desc->first_agent * 9;
         p->bytes[LSCQP_PLAN_BUF_NEXT_STATE] = n * 9 * sizeof(double);

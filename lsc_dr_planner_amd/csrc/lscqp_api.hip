@@ -660,8 +660,77 @@ int lscqp_safety_obstacles_device(lscqp_handle h, int64_t n_agents, int64_t firs
                                        d_radius, d_downwash, n_obstacles, d_obstacles, d_out, stream);
 }
 
+extern "C" int lscqp_construct_sfc_raw_ex_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius, lscqp_box* d_sfc,
+                                           int32_t* d_status_out, const int32_t* d_order, uint32_t* d_cost_out, void* stream);
+
 int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map mp, int32_t mode, int64_t n, const double* d_points, const double* d_radius,
                                lscqp_box* d_sfc, int32_t* d_status_out, void* stream) {
+    return lscqp_construct_sfc_device_ordered(h, mp, mode, n, d_points, d_radius, d_sfc, d_status_out, nullptr, nullptr, stream);
+}
+
+// lscqp_order_by_cost_device: the same stable counting sort as lscqp_order_by_work_device on 32-bit costs, scaled to 64 bins by the
+// largest of them (one workgroup; two passes over the costs)
+__global__ __launch_bounds__(kOrdT) void order_by_cost_kernel(int64_t n, const uint32_t* __restrict__ cost, int32_t* __restrict__ order) {
+    __shared__ int hist[kOrdK][kOrdT + 1];
+    __shared__ int colsum[kOrdK];
+    __shared__ unsigned int cmax[kOrdT];
+    const int t = threadIdx.x;
+    const int64_t c = (n + kOrdT - 1) / kOrdT, lo = (int64_t)t * c, hi = lo + c < n ? lo + c : n;
+    unsigned int m = 0;
+    for (int64_t i = lo; i < hi; i++) m = cost[i] > m ? cost[i] : m;
+    cmax[t] = m;
+    for (int k = 0; k < kOrdK; k++) hist[k][t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        unsigned int mm = 1;
+        for (int u = 0; u < kOrdT; u++) mm = cmax[u] > mm ? cmax[u] : mm;
+        cmax[0] = mm;
+    }
+    __syncthreads();
+    const unsigned long long top = cmax[0];
+    auto row_of = [&](uint32_t v) -> int { return kOrdK - 1 - (int)(((unsigned long long)v * (kOrdK - 1)) / top); };  // row 0 = the most expensive
+    for (int64_t i = lo; i < hi; i++) hist[row_of(cost[i])][t]++;
+    __syncthreads();
+    if (t < kOrdK) {
+        int run = 0;
+        for (int u = 0; u < kOrdT; u++) {
+            const int v = hist[t][u];
+            hist[t][u] = run;
+            run += v;
+        }
+        colsum[t] = run;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < kOrdK; k++) {
+            const int v = colsum[k];
+            colsum[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    for (int64_t i = lo; i < hi; i++) {
+        const int r = row_of(cost[i]);
+        order[colsum[r] + hist[r][t]++] = (int32_t)i;
+    }
+}
+
+int lscqp_order_by_cost_device(int64_t n, const uint32_t* d_cost_prev, int32_t* d_order_out, void* stream) {
+    if (n < 0 || n > 0x7fffffff) return fail(LSCQP_ERR_INVALID_ARGUMENT, "0 <= n < 2^31 required");
+    if (n == 0) return LSCQP_OK;
+    if (!d_cost_prev || !d_order_out) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null buffer");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    hipLaunchKernelGGL(order_by_cost_kernel, dim3(1), dim3(kOrdT), 0, (hipStream_t)stream, n, d_cost_prev, d_order_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (order_by_cost): ") + hipGetErrorString(e));
+    return LSCQP_OK;
+}
+
+int lscqp_construct_sfc_device_ordered(lscqp_handle h, lscqp_map mp, int32_t mode, int64_t n, const double* d_points, const double* d_radius,
+                                       lscqp_box* d_sfc, int32_t* d_status_out, const int32_t* d_order, uint32_t* d_cost_out, void* stream) {
     if (!h || !mp) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
     if (mode != LSCQP_SFC_INIT && mode != LSCQP_SFC_FROM_HULL && mode != LSCQP_SFC_FROM_POINT)
         return fail(LSCQP_ERR_INVALID_ARGUMENT, "mode must be LSCQP_SFC_INIT, LSCQP_SFC_FROM_HULL or LSCQP_SFC_FROM_POINT");
@@ -672,7 +741,7 @@ int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map mp, int32_t mode, int64
     int ndev = 0;
     const hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
-    return lscqp_construct_sfc_raw_(mp, mode, h->desc.M, n, d_points, d_radius, d_sfc, d_status_out, stream);
+    return lscqp_construct_sfc_raw_ex_(mp, mode, h->desc.M, n, d_points, d_radius, d_sfc, d_status_out, d_order, d_cost_out, stream);
 }
 
 int lscqp_select_neighbours_device(lscqp_handle h, int64_t n_agents, int64_t first_agent, int64_t n_total, int32_t n_obs,

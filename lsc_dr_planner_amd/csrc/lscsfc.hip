@@ -69,6 +69,11 @@ struct MapView {
     const int32_t* nearest;
     const int32_t* sat;  // (NULL: lscqp_map_prepare was not called)
     double sat_margin;
+    // work distribution of a launch (set per launch; lscqp_construct_sfc_device_ordered): the k-th workgroup builds the corridor of agent
+    // order[k] (NULL: k), and every workgroup leaves the cycles it took (>> 4) in cost[agent] (NULL: nothing) -- the hint for the order
+    // of the NEXT replan's launch: corridors along a wall cost three times the ones in open space, and a launch ends with its last one
+    const int32_t* order;
+    uint32_t* cost;
     __host__ __device__ __forceinline__ float world_min(int k) const { return k == 0 ? wmin0 : (k == 1 ? wmin1 : wmin2); }
     __host__ __device__ __forceinline__ float world_max(int k) const { return k == 0 ? wmax0 : (k == 1 ? wmax1 : wmax2); }
     __host__ __device__ __forceinline__ int key0(int k) const { return k == 0 ? key00 : (k == 1 ? key01 : key02); }
@@ -1185,8 +1190,9 @@ __device__ void clip_to_prev(const BoxF& prev, BoxF& ini, double res) {  // :677
 __global__ __launch_bounds__(kSfcThreads) LSCSFC_KERNEL_ATTR void construct_sfc_kernel(MapView mp, int mode, int M, int64_t n, const double* __restrict__ pts,
                                                            const double* __restrict__ radius, lscqp_box* __restrict__ sfc,
                                                            int32_t* __restrict__ status) {
-    const int64_t a = blockIdx.x;
-    if (a >= n) return;
+    if ((int64_t)blockIdx.x >= n) return;
+    const int64_t a = mp.order ? (int64_t)mp.order[blockIdx.x] : (int64_t)blockIdx.x;
+    const long long t_begin_ = clock64();
     const double res = mp.res;
     const double margin = radius[a];
     float P[3][3];
@@ -1254,6 +1260,10 @@ __global__ __launch_bounds__(kSfcThreads) LSCSFC_KERNEL_ATTR void construct_sfc_
                 (c < 3 ? S[m].bmin[c] : S[m].bmax[c - 3]) = val;
             }
         if (threadIdx.x == 0) status[a] = ok ? 1 : 0;
+        if (threadIdx.x == 0 && mp.cost) {
+            const unsigned long long dtc = (unsigned long long)(clock64() - t_begin_) >> 4;
+            mp.cost[a] = dtc > 0xffffffffull ? 0xffffffffu : (uint32_t)dtc;
+        }
         return;
     }
     // sfcs[m] = sfcs[m + 1] for m < M - 1, then the new (or the kept) last box.  Every lane moves whole elements; the
@@ -1273,6 +1283,10 @@ __global__ __launch_bounds__(kSfcThreads) LSCSFC_KERNEL_ATTR void construct_sfc_
         (c < 3 ? S[M - 1].bmin[c] : S[M - 1].bmax[c - 3]) = val;
     }
     if (threadIdx.x == 0) status[a] = ok ? 1 : 0;
+    if (threadIdx.x == 0 && mp.cost) {
+        const unsigned long long dtc = (unsigned long long)(clock64() - t_begin_) >> 4;
+        mp.cost[a] = dtc > 0xffffffffull ? 0xffffffffu : (uint32_t)dtc;
+    }
 }
 
 }  // namespace lscsfc
@@ -1467,9 +1481,17 @@ int lscqp_map_download(lscqp_map mp, uint8_t* occ, int32_t* nearest) {
     return LSCQP_OK;
 }
 
+int lscqp_construct_sfc_raw_ex_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius, lscqp_box* d_sfc,
+                                int32_t* d_status_out, const int32_t* d_order, uint32_t* d_cost_out, void* stream);
 int lscqp_construct_sfc_raw_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius, lscqp_box* d_sfc,
                              int32_t* d_status_out, void* stream) {
+    return lscqp_construct_sfc_raw_ex_(mp, mode, M, n, d_points, d_radius, d_sfc, d_status_out, nullptr, nullptr, stream);
+}
+int lscqp_construct_sfc_raw_ex_(lscqp_map mp, int mode, int M, int64_t n, const double* d_points, const double* d_radius, lscqp_box* d_sfc,
+                                int32_t* d_status_out, const int32_t* d_order, uint32_t* d_cost_out, void* stream) {
     lscsfc::MapView v;
+    v.order = d_order;
+    v.cost = d_cost_out;
     v.res = mp->res;
     v.wmin0 = mp->world_min[0], v.wmin1 = mp->world_min[1], v.wmin2 = mp->world_min[2];
     v.wmax0 = mp->world_max[0], v.wmax1 = mp->world_max[1], v.wmax2 = mp->world_max[2];

@@ -721,11 +721,14 @@ def test_large_plan_carries_its_work_order_and_graph_equals_eager(api, torch_cud
     starts = g * 1.25 + np.array([-5.5, -5.5, 1.0])
     goals = starts + np.array([0.5, 0.25, 0.0])
     wmin, wmax = [-8.0, -8.0, 0.0], [8.0, 8.0, 9.0]
-    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, use_sfc=False, world_min=wmin, world_max=wmax))
+    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, use_sfc=True, world_min=wmin, world_max=wmax))
+    # (a few pillars between the lattice's columns: the corridor launch is sorted by the previous replan's recorded costs as well)
+    boxes = [[-4.9 + 2.5 * i, -4.9 + 2.5 * j, 4.0, 0.3, 0.3, 8.0] for i in range(4) for j in range(4)]
+    wmap = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
     ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
     ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = 0.15, 2.0, 1.0, 2.0, 1.0
-    kw = dict(constraint_mode=api.GEN_LSC, optimize_goal=False, closed_loop=True)
-    pe, pg = api.Plan(sol, None, N, 12, ag, **kw), api.Plan(sol, None, N, 12, ag, **kw)
+    kw = dict(constraint_mode=api.GEN_LSC, sfc_mode=api.SFC_FROM_POINT, optimize_goal=False, closed_loop=True)
+    pe, pg = api.Plan(sol, wmap, N, 12, ag, **kw), api.Plan(sol, wmap, N, 12, ag, **kw)
     for p in (pe, pg):
         p.reset(starts, goals)
         p.put(api.PLAN_WAYPOINT, goals)
@@ -736,6 +739,7 @@ def test_large_plan_carries_its_work_order_and_graph_equals_eager(api, torch_cud
         assert np.array_equal(pe.get(api.PLAN_PLAN), pg.get(api.PLAN_PLAN)) and np.array_equal(pe.get(api.PLAN_OBJECTIVE), pg.get(api.PLAN_OBJECTIVE)), k
         assert (pe.get(api.PLAN_STATUS) == 0).all(), (k, np.bincount(pe.get(api.PLAN_STATUS)))
     it = pe.get(api.PLAN_INFO)["iterations"]
-    assert it.max() >= 2 and pg.graph_nodes() >= 6
+    assert it.max() >= 2 and pg.graph_nodes() >= 8
     pe.close()
     pg.close()
+    wmap.close()

@@ -483,3 +483,55 @@ def test_gpu_corridor_seeded_outside_the_world(api, oracle, variant, monkeypatch
             if mode_o == oracle.SFC_FROM_POINT and prepared == 0.0:
                 assert inverted.any(), "the premise: some corridor of this test is an inverted box"
         gmap.close()
+
+
+@pytest.mark.gpu
+def test_corridor_work_order_changes_when_a_corridor_is_built_never_the_corridor(api, torch_cuda):
+    """Round 4: lscqp_construct_sfc_device_ordered builds agent d_order[k]'s corridor in workgroup k and records every agent's cost;
+    lscqp_order_by_cost_device sorts by those costs, most expensive first.  1500 agents in a room with pillars (more than the chip takes
+    at once, so the throughput build runs): INIT and FROM_HULL give bit for bit the same boxes and statuses as given, in the sorted order and
+    in a random order; the recorded costs are positive and the order is a permutation that is non-increasing in the 64 cost bins."""
+    torch = torch_cuda
+    rng = np.random.default_rng(9)
+    N, M = 1500, 5
+    wmin, wmax = np.array([-12.0, -12.0, 0.0]), np.array([12.0, 12.0, 6.0])
+    boxes = np.concatenate([rng.uniform(wmin + 1, wmax - 1, (160, 3)), rng.choice([0.4, 0.6, 1.0], (160, 3))], axis=1)
+    wm = api.WorldMap(boxes, wmin, wmax, 0.1, 1.0)
+    wm.prepare(0.15)
+    sol = api.Solver(api.make_desc(M=M, dim=3, world_min=wmin, world_max=wmax))
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    starts = np.float32(rng.uniform(wmin + 0.5, wmax - 0.5, (N, 3))).astype(np.float64)
+    P = np.repeat(starts[:, None, :], 3, axis=1)
+    rad = np.full(N, 0.15)
+    d_sfc = torch.zeros(N * M * 6, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(N, dtype=torch.int32, device=dev)
+    d_cost = torch.zeros(N, dtype=torch.int32, device=dev)  # (uint32 on the device)
+    sol.construct_sfc_device(wm, api.SFC_INIT, N, up(P.reshape(-1)), up(rad), d_sfc, d_st, d_cost=d_cost)
+    torch.cuda.synchronize()
+    base, st0 = d_sfc.clone(), d_st.clone()
+    feasible = st0.cpu().numpy() == 1
+    assert feasible.sum() > N // 2
+    cost = d_cost.cpu().numpy().view(np.uint32)
+    assert (cost > 0).all()
+    d_order = torch.zeros(N, dtype=torch.int32, device=dev)
+    sol.order_by_cost_device(N, d_cost, d_order)
+    torch.cuda.synchronize()
+    order = d_order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(N))
+    bins = (cost[order].astype(np.uint64) * 63) // max(int(cost.max()), 1)
+    assert (np.diff(bins.astype(np.int64)) <= 0).all() and bins[0] == 63
+    step = rng.normal(size=(N, 3))
+    step /= np.linalg.norm(step, axis=1, keepdims=True)
+    P2 = np.float32(np.stack([starts + 0.3 * step, starts + 0.5 * step, starts + 0.5 * step], axis=1)).astype(np.float64)
+    ref = {}
+    for mode, pts in ((api.SFC_INIT, P), (api.SFC_FROM_HULL, P2)):
+        for name, od in (("as given", None), ("sorted", d_order), ("random", up(rng.permutation(N).astype(np.int32)))):
+            work, st = base.clone(), torch.zeros(N, dtype=torch.int32, device=dev)
+            sol.construct_sfc_device(wm, mode, N, up(pts.reshape(-1)), up(rad), work, st, d_order=od)
+            torch.cuda.synchronize()
+            if name == "as given":
+                ref[mode] = (work, st)
+            else:
+                assert torch.equal(work, ref[mode][0]) and torch.equal(st, ref[mode][1]), (mode, name)
+    wm.close()

@@ -166,3 +166,21 @@ assert torch.equal(base_t, base), "the free-space table changed a corridor"
 ms = timed(upd, reps=20) - ms_copy
 print(json.dumps({"kernel": "construct_sfc FROM_HULL with the free-space table", "agents": N, "kernel_ms": ms, "agents_per_s": N / ms * 1e3,
                   "new_boxes": int((d_st.cpu().numpy() == 1).sum())}))
+# ... and in the work order a plan carries from replan to replan (round 4): the corridors that cost the most in the previous launch first
+d_cost = torch.zeros(N, dtype=torch.int32, device=dev)
+d_ord = torch.zeros(N, dtype=torch.int32, device=dev)
+d_sfc.copy_(base)
+sol.construct_sfc_device(wm, api.SFC_FROM_HULL, N, d_P2, d_r, d_sfc, d_st, d_cost=d_cost)
+ref_boxes = d_sfc.clone()
+sol.order_by_cost_device(N, d_cost, d_ord)
+
+
+def upd_ordered():
+    d_sfc.copy_(base)
+    sol.construct_sfc_device(wm, api.SFC_FROM_HULL, N, d_P2, d_r, d_sfc, d_st, d_order=d_ord, d_cost=d_cost)
+
+
+ms_o = timed(upd_ordered, reps=20) - ms_copy
+assert torch.equal(d_sfc, ref_boxes), "the work order changed a corridor"
+print(json.dumps({"kernel": "construct_sfc FROM_HULL with the free-space table, most expensive previous corridor first (lscqp_order_by_cost_device)",
+                  "agents": N, "kernel_ms": ms_o, "agents_per_s": N / ms_o * 1e3, "as_given_ms": ms}))

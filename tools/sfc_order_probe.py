@@ -1,4 +1,4 @@
-"""Development aid: does the corridor launch (construct_sfc FROM_HULL, 4096 agents, tools/bench_next_rows.py's world) have a tail like the QP
+"""Development aid (the experiment BEFORE lscqp_construct_sfc_device_ordered existed; tests/test_sfc.py covers the entry point): does the corridor launch (construct_sfc FROM_HULL, 4096 agents, tools/bench_next_rows.py's world) have a tail like the QP
 launch had?  Per-agent cost = the duration of a one-agent launch; then the whole launch is timed with the agents as given, most expensive
 first, cheapest first and in a random order (inputs permuted on the host; the boxes must not change)."""
 import os
