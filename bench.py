@@ -34,6 +34,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
+ORDER_MIN = 512  # agents from which a launch is sorted by the previous solve's iteration counts (lscqp_plan's kOrderMin)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK = 78.6e12  # flop/s, MI355X fp64 vector (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 
@@ -218,6 +219,8 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     d_order = [None]
 
     def call():
+        if d_order[0] is not None:  # what a replan does: sort by the previous solve's counts (they are in dinfo), then solve in that order
+            sol.order_by_work_device(N, dinfo, d_order[0])
         sol.solve_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi, d_order=d_order[0])
 
     def timed(k):
@@ -236,10 +239,13 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     # the work order a planner has: the agents whose previous QP took the most iterations first (lscqp_order_by_work_device on the info
     # records of the previous solve -- lscqp_plan carries it from replan to replan).  Here the previous solve is of the SAME batch: the hint
     # is perfect; tools/lpt_probe.py shows the same figures with a hint that is off by one iteration on half of the instances.
-    order_buf = torch.zeros(N, dtype=torch.int32, device=dev)
-    sol.order_by_work_device(N, dinfo, order_buf)
-    d_order[0] = order_buf
-    ms = timed(reps)
+    # Only where a launch can have a tail (more instances than the chip starts at once; lscqp_plan's threshold): the sort is part of
+    # every timed call, as it is part of every replan.
+    if N > ORDER_MIN:
+        d_order[0] = torch.zeros(N, dtype=torch.int32, device=dev)
+        ms = timed(reps)
+    else:
+        ms = ms_as_given
     # >= 1000 calls where that fits a bounded time (the slowest config, 1024 x M=10, needs ~10 s for them)
     p50, p99, nlat = percentile_latency(torch, call, max_seconds=min(14.0, max(lat_seconds, 1.15e-3 * ms * 1100)))
     info = dinfo.cpu().numpy().view(api.INFO_DTYPE)
@@ -248,7 +254,8 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     out = {"config": key, "what": cfg["what"], "agents": N, "segments": M, "dim": dim, "lsc_neighbours": sw.n_obs, "style": cfg["style"],
            "precision": cfg["precision"], "rows": cfg["rows"], "rows_per_qp": sol.num_inequalities(sw.n_obs),
            "kernel_ms": ms, "qp_per_s": N / (ms * 1e-3), "latency_ms": {"p50": p50, "p99": p99, "calls": nlat},
-           "work_order": "longest first: lscqp_order_by_work_device on the previous solve's iteration counts (same batch: a perfect hint)",
+           "work_order": ("longest first: lscqp_order_by_work_device on the previous solve's iteration counts, inside every timed call (same batch: "
+                          "a perfect hint)") if N > ORDER_MIN else "as given (the launch starts every instance at once)",
            "kernel_ms_as_given": ms_as_given, "qp_per_s_as_given": N / (ms_as_given * 1e-3),
            "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
            "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()),
@@ -655,6 +662,8 @@ def timed_workload(ctx, a):
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit, d_order=d_order[0])
 
     def step():
+        if d_order[0] is not None:  # (what a replan does: the previous step's iteration counts are in d_info)
+            sol.order_by_work_device(N, d_info, d_order[0])
         if a.pipeline:
             src = d_x
             if d_all is not None:
@@ -688,12 +697,11 @@ def timed_workload(ctx, a):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if a.warmup > 0 and not a.graph and not a.no_work_order:
-        # the work order a planner has from the previous replan (lscqp_plan carries it by itself): longest previous solve first.  It
-        # matters only where a launch runs more than one round of workgroups (configs[3], the configs[4] shape); results are bit-identical.
-        order_buf = torch.zeros(N, dtype=torch.int32, device=dev)
-        sol.order_by_work_device(N, d_info, order_buf)
-        d_order[0] = order_buf
+    if a.warmup > 0 and not a.graph and not a.no_work_order and N > ORDER_MIN:
+        # the work order a planner has from the previous replan (lscqp_plan carries it by itself): longest previous solve first, re-sorted
+        # inside every step.  Only where a launch runs more than one round of workgroups (configs[3], the configs[4] shape): results are
+        # bit-identical, smaller launches start every instance at once anyway.
+        d_order[0] = torch.zeros(N, dtype=torch.int32, device=dev)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -779,16 +787,20 @@ def timed_workload(ctx, a):
         w_x, w_ob = torch.zeros(n_glob * nv, dtype=torch.float64, device=dev), torch.zeros(n_glob, dtype=torch.float64, device=dev)
         w_st, w_in = torch.zeros(n_glob, dtype=torch.int32, device=dev), torch.zeros(n_glob * 32, dtype=torch.uint8, device=dev)
         reps1 = max(5, min(a.steps, 20))
-        w_ord = None
-        for i_ in range(3):
-            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi, d_order=w_ord)
-            if i_ == 0 and d_order[0] is not None:  # the same work order rule as the sharded steps
-                w_ord = torch.zeros(n_glob, dtype=torch.int32, device=dev)
+        w_ord = torch.zeros(n_glob, dtype=torch.int32, device=dev) if (n_glob > ORDER_MIN and not a.no_work_order) else None
+
+        def whole():  # the same rule as the sharded steps: sorted by the previous solve's counts where the launch can have a tail
+            if w_ord is not None:
                 sol.order_by_work_device(n_glob, w_in, w_ord)
+            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi, d_order=w_ord)
+
+        sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi)
+        for i_ in range(2):
+            whole()
         torch.cuda.synchronize()
         t_a = time.perf_counter()
         for _ in range(reps1):
-            sol.solve_device(n_glob, n_obs_eff, w_h, w_r, w_o, w_s, w_x, w_ob, w_st, w_in, d_x_init=w_xi, d_order=w_ord)
+            whole()
         torch.cuda.synchronize()
         t_1 = (time.perf_counter() - t_a) / reps1
         same = bool(torch.equal(w_x[lo * nv: hi * nv], d_x[: N * nv]))
@@ -827,7 +839,8 @@ def workload_config(ctx, a, S):
         "segments": S.M, "lsc_neighbours": S.n_obs_eff, "dim": S.dim,
         "rows_per_qp": S.sol.num_inequalities(S.n_obs_eff), "allgather": bool(gathered), "pipeline": bool(a.pipeline), "hip_graph": bool(a.graph),
         "warm_start": "initial_traj (shifted previous plan) as primal start" if S.d_xinit is not None else "none",
-        "work_order": ("longest previous solve first (lscqp_order_by_work_device on the warm-up steps' iteration counts)" if S.ordered else "as given"),
+        "work_order": ("longest previous solve first (lscqp_order_by_work_device on the previous step's iteration counts, inside every step)"
+                       if S.ordered else "as given (the launch starts every instance at once)"),
         "parallelism": ("agents sharded over %d GPU(s), " % ctx.world) +
                        ("one RCCL all-gather of the plans per step" if gathered else "no data-path collective"),
     }

@@ -592,7 +592,7 @@ int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map map, int32_t mode, int6
                                const double* d_radius, lscqp_box* d_sfc, int32_t* d_status_out, void* stream);
 /* The same with a work order (round 4): workgroup k of the launch builds the corridor of agent d_order[k] (a permutation of 0 .. n-1;
  * NULL = identity) and every agent's cost -- the cycles its workgroup took, >> 4 -- is left in d_cost_out[agent] (NULL: not recorded).
- * lscqp_order_by_cost_device sorts by the costs of the PREVIOUS replan, most expensive first (stable; 64 bins scaled to the largest):
+ * lscqp_order_by_cost_device sorts by the costs of the PREVIOUS replan, most expensive first (stable; 16 levels scaled to the largest):
  * a corridor along a wall costs three times one in open space and a launch ends with its last workgroup -- 4096 agents 0.98 -> 0.83 ms.
  * Same boxes bit for bit in any order; lscqp_plan (>= 512 agents) carries costs and order from replan to replan by itself. */
 int lscqp_order_by_cost_device(int64_t n, const uint32_t* d_cost_prev, int32_t* d_order_out, void* stream);
