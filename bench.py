@@ -34,7 +34,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-ORDER_MIN = 512  # agents from which a launch is sorted by the previous solve's iteration counts (lscqp_plan's kOrderMin)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK = 78.6e12  # flop/s, MI355X fp64 vector (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
 
@@ -239,9 +238,9 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     # the work order a planner has: the agents whose previous QP took the most iterations first (lscqp_order_by_work_device on the info
     # records of the previous solve -- lscqp_plan carries it from replan to replan).  Here the previous solve is of the SAME batch: the hint
     # is perfect; tools/lpt_probe.py shows the same figures with a hint that is off by one iteration on half of the instances.
-    # Only where a launch can have a tail (more instances than the chip starts at once; lscqp_plan's threshold): the sort is part of
+    # Only where a launch can have a tail (more instances than lscqp_launch_capacity; lscqp_plan's rule): the sort is part of
     # every timed call, as it is part of every replan.
-    if N > ORDER_MIN:
+    if N > sol.launch_capacity(N, sw.n_obs):
         d_order[0] = torch.zeros(N, dtype=torch.int32, device=dev)
         ms = timed(reps)
     else:
@@ -255,7 +254,7 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
            "precision": cfg["precision"], "rows": cfg["rows"], "rows_per_qp": sol.num_inequalities(sw.n_obs),
            "kernel_ms": ms, "qp_per_s": N / (ms * 1e-3), "latency_ms": {"p50": p50, "p99": p99, "calls": nlat},
            "work_order": ("longest first: lscqp_order_by_work_device on the previous solve's iteration counts, inside every timed call (same batch: "
-                          "a perfect hint)") if N > ORDER_MIN else "as given (the launch starts every instance at once)",
+                          "a perfect hint)") if d_order[0] is not None else "as given (the launch starts every instance at once)",
            "kernel_ms_as_given": ms_as_given, "qp_per_s_as_given": N / (ms_as_given * 1e-3),
            "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
            "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()),
@@ -697,7 +696,7 @@ def timed_workload(ctx, a):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if a.warmup > 0 and not a.graph and not a.no_work_order and N > ORDER_MIN:
+    if a.warmup > 0 and not a.graph and not a.no_work_order and N > sol.launch_capacity(N, n_obs_eff):
         # the work order a planner has from the previous replan (lscqp_plan carries it by itself): longest previous solve first, re-sorted
         # inside every step.  Only where a launch runs more than one round of workgroups (configs[3], the configs[4] shape): results are
         # bit-identical, smaller launches start every instance at once anyway.
@@ -787,7 +786,7 @@ def timed_workload(ctx, a):
         w_x, w_ob = torch.zeros(n_glob * nv, dtype=torch.float64, device=dev), torch.zeros(n_glob, dtype=torch.float64, device=dev)
         w_st, w_in = torch.zeros(n_glob, dtype=torch.int32, device=dev), torch.zeros(n_glob * 32, dtype=torch.uint8, device=dev)
         reps1 = max(5, min(a.steps, 20))
-        w_ord = torch.zeros(n_glob, dtype=torch.int32, device=dev) if (n_glob > ORDER_MIN and not a.no_work_order) else None
+        w_ord = torch.zeros(n_glob, dtype=torch.int32, device=dev) if (n_glob > sol.launch_capacity(n_glob, n_obs_eff) and not a.no_work_order) else None
 
         def whole():  # the same rule as the sharded steps: sorted by the previous solve's counts where the launch can have a tail
             if w_ord is not None:

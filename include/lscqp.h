@@ -283,11 +283,14 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
  * launch then lasts sum / slots + (what is still running when the queue is empty): starting the LONGEST instances first shortens that
  * tail -- 1024 x M10 x 40 on one MI355X: 1.14 ms in the given order with one instance per workgroup, see DESIGN.md section 4 for the
  * figures with the queue and with the order.  The iteration count of the previous replan's solve of the same agent is the hint a
- * planner has (lscqp_plan carries it from replan to replan by itself):
+ * planner has (lscqp_plan carries it from replan to replan by itself when its QP launch exceeds lscqp_launch_capacity):
  *   lscqp_order_by_work_device   d_order_out[n] := the instances sorted by d_info_prev[i].iterations, most first, ties in index order
  *   lscqp_solve_batch_device_ordered   lscqp_solve_batch_device_ex with the k-th slot of the launch solving instance d_order[k]
  *                                (a permutation of 0 .. n-1; NULL = identity).  Results land at the instance's own index, bit for bit
  *                                what any other order gives. */
+/* instances of a launch of n the device works on at once (CUs x workgroups per CU of the kernel instance the launch selects); a launch of
+ * more runs in rounds and has a tail -- that is where the order pays.  -1 without a device. */
+int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max);
 int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t* d_order_out, void* stream);
 int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
                                      const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out,
@@ -594,7 +597,7 @@ int lscqp_construct_sfc_device(lscqp_handle h, lscqp_map map, int32_t mode, int6
  * NULL = identity) and every agent's cost -- the cycles its workgroup took, >> 4 -- is left in d_cost_out[agent] (NULL: not recorded).
  * lscqp_order_by_cost_device sorts by the costs of the PREVIOUS replan, most expensive first (stable; 16 levels scaled to the largest):
  * a corridor along a wall costs three times one in open space and a launch ends with its last workgroup -- 4096 agents 0.98 -> 0.83 ms.
- * Same boxes bit for bit in any order; lscqp_plan (>= 512 agents) carries costs and order from replan to replan by itself. */
+ * Same boxes bit for bit in any order; lscqp_plan carries costs and order from replan to replan by itself where its launches exceed the chip. */
 int lscqp_order_by_cost_device(int64_t n, const uint32_t* d_cost_prev, int32_t* d_order_out, void* stream);
 int lscqp_construct_sfc_device_ordered(lscqp_handle h, lscqp_map map, int32_t mode, int64_t n, const double* d_points,
                                        const double* d_radius, lscqp_box* d_sfc, int32_t* d_status_out, const int32_t* d_order,

@@ -115,6 +115,8 @@ def lib():
         L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
         L.lscqp_solve_batch_device_ordered.restype = C.c_int
         L.lscqp_solve_batch_device_ordered.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp, vp]
+        L.lscqp_launch_capacity.restype = C.c_int64
+        L.lscqp_launch_capacity.argtypes = [vp, C.c_int64, C.c_int32]
         L.lscqp_order_by_cost_device.restype = C.c_int
         L.lscqp_order_by_cost_device.argtypes = [C.c_int64, vp, vp, vp]
         L.lscqp_construct_sfc_device_ordered.restype = C.c_int
@@ -233,7 +235,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_launch_capacity", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
                     "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
@@ -696,6 +698,10 @@ class Solver:
                                                     p(d_obj), p(d_status), p(d_info), int(retry), p(d_order), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def launch_capacity(self, n, n_obs_max):
+        """lscqp_launch_capacity: instances of a launch of n the device works on at once (-1 without a device)."""
+        return int(lib().lscqp_launch_capacity(self._h, int(n), int(n_obs_max)))
 
     @staticmethod
     def order_by_cost_device(n, d_cost_prev, d_order_out, stream=None):

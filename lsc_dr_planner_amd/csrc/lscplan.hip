@@ -41,7 +41,10 @@ extern "C" int lscqp_generate_constraints_own_(lscqp_handle h, int32_t mode, int
 
 namespace lscplan {
 
-constexpr size_t kOrderMin = 512;  // agents from which a plan carries the work order of its QP launch from replan to replan
+// A plan carries the work order of its QP launch from replan to replan when the launch exceeds what the chip works on at once
+// (lscqp_launch_capacity: 256 instances of the M = 10 class, 1024 of M = 5), and that of its corridor launch from this many agents on
+// (the throughput build of the corridor kernel keeps four agents per CU)
+constexpr size_t kSfcOrderMin = 1024;
 constexpr int kThreads = 64;
 static_assert(kThreads == 64, "prepare_kernel hands data between the lanes of ONE wavefront (initial trajectory read before the prediction overwrites it)");
 
@@ -200,7 +203,7 @@ struct lscqp_plan_s {
     double *radius = nullptr, *downwash = nullptr, *traj = nullptr, *pos = nullptr, *points = nullptr, *x_init = nullptr, *x_new = nullptr, *own = nullptr;
     int32_t* nbr = nullptr;
     uint64_t* off = nullptr;
-    int32_t* order = nullptr;  // work order of the next solve (n_agents >= kOrderMin only)
+    int32_t* order = nullptr;  // work order of the next solve (only where the launch exceeds lscqp_launch_capacity)
     int32_t* sfc_order = nullptr;  // ... and of the next corridor launch, from the costs recorded by this one
     uint32_t* sfc_cost = nullptr;
     hipGraph_t graph = nullptr;
@@ -473,7 +476,8 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         ok(dalloc_pub<lscqp_info>(p, LSCQP_PLAN_BUF_INFO, n)) && ok(dalloc_pub<lscqp_safety>(p, LSCQP_PLAN_BUF_SAFETY, n)) && ok(dalloc(p, &p->par, nt)) && ok(dalloc(p, &p->radius, nt)) &&
         ok(dalloc(p, &p->downwash, nt)) && ok(dalloc(p, &p->traj, nt * P * 3)) && ok(dalloc(p, &p->pos, nt * 3)) &&
         ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->own, n * P * 3)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
-        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1)) && (n >= lscplan::kOrderMin ? (ok(dalloc(p, &p->order, n)) && (map ? (ok(dalloc(p, &p->sfc_order, n)) && ok(dalloc(p, &p->sfc_cost, n))) : true)) : true);
+        ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1)) && ((int64_t)n > lscqp_launch_capacity(h, (int64_t)n, desc->n_obs) ? ok(dalloc(p, &p->order, n)) : true) &&
+        ((map && n > lscplan::kSfcOrderMin) ? (ok(dalloc(p, &p->sfc_order, n)) && ok(dalloc(p, &p->sfc_cost, n))) : true);
     if (rc == LSCQP_OK && desc->closed_loop) {
         p->buf[LSCQP_PLAN_BUF_NEXT_STATE] = (double*)p->buf[LSCQP_PLAN_BUF_STATE] + desc->first_agent * 9;
         p->bytes[LSCQP_PLAN_BUF_NEXT_STATE] = n * 9 * sizeof(double);

@@ -411,6 +411,20 @@ int lscqp_max_obstacles(lscqp_handle h) {
     return best;
 }
 int lscqp_uses_sfc(lscqp_handle h) { return h ? (h->desc.use_sfc ? 1 : 0) : -1; }
+// How many instances of a launch of n the device works on at once: every instance keeps one wavefront per SIMD (more than 256 registers
+// per lane), so a CU holds 4 / W workgroups of W wavefronts, or fewer if their LDS does not fit.  A launch of more than this many
+// instances runs in rounds and has a tail: that is where the work order pays (lscqp_order_by_work_device).
+int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max) {
+    if (!h || n < 0 || n_obs_max < 0) return -1;
+    const int n_cu = cu_count();
+    if (n_cu <= 0) return -1;
+    const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
+    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
+    if (!inst) return (int64_t)n_cu;  // (the run-time-shaped kernel: one 256-thread workgroup per CU at the LDS sizes it runs with)
+    const int by_lds = (int)(lscqp::kMaxLdsBytes / inst->lds), by_simd = 4 / inst->waves;
+    const int per_cu = by_lds < by_simd ? by_lds : by_simd;
+    return (int64_t)n_cu * (per_cu < 1 ? 1 : per_cu);
+}
 
 // Work counters of the kernel instance a launch would select (include/lscqp.h): the per-wavefront instruction counts come from the
 // table the build reads off each instance's machine code (lsc_dr_planner_amd/isa_work.py -> lscqp_work_table_, generated TU).

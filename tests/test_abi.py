@@ -112,6 +112,7 @@ def test_next_row_entry_points_validate_and_accept_empty_batches(api):
     assert L.lscqp_validate_step_device(h, 0, 0.2, 1.0, p, p, p, p, p, None) == api.OK
     assert L.lscqp_safety_obstacles_device(h, 0, 0, 0, 1, 0.1, 1.0, p, p, p, 3, p, p, None) == api.OK
     assert L.lscqp_order_by_work_device(0, p, p, None) == api.OK
+    assert L.lscqp_launch_capacity(None, 1, 0) == -1 and L.lscqp_launch_capacity(h, -1, 0) == -1
     assert L.lscqp_order_by_cost_device(0, p, p, None) == api.OK and L.lscqp_order_by_cost_device(3, p, None, None) == api.ERR_INVALID_ARGUMENT
     assert L.lscqp_construct_sfc_device_ordered(h, None, api.SFC_INIT, 1, p, p, p, p, p, p, None) == api.ERR_INVALID_ARGUMENT
     assert L.lscqp_order_by_work_device(4, None, p, None) == api.ERR_INVALID_ARGUMENT and L.lscqp_order_by_work_device(-1, p, p, None) == api.ERR_INVALID_ARGUMENT
