@@ -152,29 +152,44 @@ int cu_count() {  // of the CURRENT device (one process may drive several: lscqp
     }
     return n_cu[dev];
 }
-// Work-queue counters of the persistent launches (lscqp_kernel.hpp: lscqp_pdip_kernel): a ring of zeroable ints per device, one taken per
-// launch and cleared on the launch's own stream right before it (a memset node when the stream is being captured into a graph -- the ring
-// exists by then: the plan's first replan runs eagerly).  4096 slots: a launch would have to be overtaken by 4096 later ones to share a
-// counter with one of them.
-constexpr unsigned kQueueRing = 4096;
+// Work-queue counters of the persistent launches (lscqp_kernel.hpp: lscqp_pdip_kernel): zeroable ints per device, one per launch, cleared
+// on the launch's own stream right before it.  Two launches must never share a counter while both run (instances would be skipped), so:
+//   * an EAGER launch takes the next of kQueueEager rotating slots -- it would have to be overtaken by that many later launches, still
+//     running, to meet one of them;
+//   * a launch being CAPTURED into a graph (hipStreamIsCapturing) gets a slot of its own for good: the graph replays for as long as its
+//     owner likes, concurrently with anything, and the memset node travels with it.  kQueueCaptured such slots per device and process;
+//     when they are used up -- or when the ring does not exist yet: hipMalloc is not allowed inside a capture; lscqp_plan runs its first
+//     replan eagerly -- the launch simply keeps one instance per workgroup (NULL).
+constexpr unsigned kQueueEager = 4096, kQueueCaptured = 4096;
 int* next_queue_counter(hipStream_t stream) {
     static int* ring[64] = {};
     static std::mutex mu;
-    static std::atomic<unsigned> next{0};
+    static std::atomic<unsigned> next_eager{0};
+    static std::atomic<unsigned> next_captured[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     int* base = nullptr;
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!ring[dev]) {
-            if (hipMalloc(&ring[dev], sizeof(int) * kQueueRing) != hipSuccess) {
+            if (capturing) return nullptr;
+            if (hipMalloc(&ring[dev], sizeof(int) * (kQueueEager + kQueueCaptured)) != hipSuccess) {
                 ring[dev] = nullptr;
                 return nullptr;  // (the launch then runs one instance per workgroup, as before)
             }
         }
         base = ring[dev];
     }
-    int* const slot = base + (next.fetch_add(1, std::memory_order_relaxed) % kQueueRing);
+    int* slot;
+    if (capturing) {
+        const unsigned k = next_captured[dev].fetch_add(1, std::memory_order_relaxed);
+        if (k >= kQueueCaptured) return nullptr;
+        slot = base + kQueueEager + k;
+    } else {
+        slot = base + (next_eager.fetch_add(1, std::memory_order_relaxed) % kQueueEager);
+    }
     if (hipMemsetAsync(slot, 0, sizeof(int), stream) != hipSuccess) return nullptr;
     return slot;
 }

@@ -745,3 +745,35 @@ def test_large_plan_carries_its_work_order_and_graph_equals_eager(api, torch_cud
     pe.close()
     pg.close()
     wmap.close()
+
+
+@pytest.mark.gpu
+def test_persistent_qp_launch_inside_a_captured_graph(api, torch_cuda):
+    """300 agents of the M = 10 class: more QPs than the chip works on at once (256: one workgroup per CU), so the plan's QP launch runs
+    persistent workgroups over a work queue whose counter is cleared by a memset node of the captured graph, in the order of the previous
+    replan's iteration counts.  Graph and eager stay bit-identical over five replans, and a third plan stepped through its own graph at the
+    same time (its launches own other counters) does not disturb them."""
+    N, M = 300, 10
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:N].astype(np.float64)
+    starts = g * 1.5 + np.array([-6.75, -6.75, 1.0])
+    goals = starts + np.array([0.75, 0.5, 0.25])
+    wmin, wmax = [-9.0, -9.0, 0.0], [9.0, 9.0, 6.0]
+    sol = api.Solver(api.make_desc(M=M, dim=3, dt=0.2, comm_range=0.0, use_sfc=False, world_min=wmin, world_max=wmax))
+    assert 0 < sol.launch_capacity(N, 10) < N
+    ag = np.zeros(N, api.AGENT_PARAM_DTYPE)
+    ag["radius"], ag["downwash"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = 0.15, 2.0, 1.0, 2.0, 1.0
+    kw = dict(constraint_mode=api.GEN_LSC, optimize_goal=False, closed_loop=True)
+    pe, pg, pc = (api.Plan(sol, None, N, 10, ag, **kw) for _ in range(3))
+    for p in (pe, pg, pc):
+        p.reset(starts, goals)
+        p.put(api.PLAN_WAYPOINT, goals)
+    side = torch_cuda.cuda.Stream()
+    for k in range(5):
+        pe.step(graph=False)
+        pg.step(graph=True)
+        pc.step(stream=side, graph=True)  # a second graph of the same handle, replayed concurrently on another stream
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(pe.get(api.PLAN_PLAN), pg.get(api.PLAN_PLAN)) and np.array_equal(pe.get(api.PLAN_PLAN), pc.get(api.PLAN_PLAN)), k
+        assert (pe.get(api.PLAN_STATUS) == 0).all(), (k, np.bincount(pe.get(api.PLAN_STATUS)))
+    for p in (pe, pg, pc):
+        p.close()
