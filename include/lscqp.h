@@ -188,6 +188,12 @@ typedef struct lscqp_box {
                                        1e-8, tol) -- it lacks only the second confirmation an iteration that goes on would give */
 #define LSCQP_INFO_SHIFTED 16       /* a factorisation lost a pivot to rounding and was repeated with a diagonal shift of
                                        1e-14 (1e-12) max|K|; residuals and stopping tests are exact whatever the direction */
+#define LSCQP_INFO_RESCUED 32       /* solved by the RESCUE pass: the instance had run into the iteration limit (a limit cycle of the
+                                       predictor-corrector iteration: one cold DLSC instance in ~30 000 of the stress sweeps) or broken
+                                       down numerically, and was re-solved on the run-time-shaped kernel with the corrector's
+                                       second-order term weighted by the affine step length where that step is blocked (< 0.3) in
+                                       the feasible phase.  Run by the host-pointer entries for batches that still hold such an
+                                       instance after their other passes, and by retry == 2 of the device entries. */
 typedef struct lscqp_info {
     int32_t iterations;
     int32_t flags;     /* LSCQP_INFO_* */
@@ -265,8 +271,10 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
  * no host round trip, ~3 us when there is nothing to repair.  retry == 2: the second pass runs on the compiled instance that
  * eliminates the reduced system in the OTHER order (natural vs nested dissection; M = 10 in 2-D has both), also for batches
  * without a start trajectory -- a factorisation that breaks down in one order usually survives in the other; that instance costs
- * ~35 us to launch even with nothing to repair, so it is not what retry == 1 does.  The host-pointer entries run it by themselves,
- * and only for batches that still hold a non-OPTIMAL instance after the first call.
+ * ~35 us to launch even with nothing to repair, so it is not what retry == 1 does.  retry == 2 also ends with the RESCUE pass
+ * (LSCQP_INFO_RESCUED: instances still at the iteration limit / a numerical breakdown, on the run-time-shaped kernel with a weighted
+ * corrector).  The host-pointer entries run both by themselves, and only for batches that still hold such an instance after the
+ * first call.
  * In LSCQP_PRECISION_MIXED the fp64 second pass always runs. */
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,

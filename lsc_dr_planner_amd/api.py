@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LSCQP_LIB") or os.path.join(_HERE, "liblscqp.so")  # 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC, STATUS_CAPACITY = 0, 1, 2, 3, 4
 PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
 WARM_DEFAULT, WARM_TIGHT = 0, 1  # lscqp_class_desc.warm_start
-INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED, INFO_REMEMBERED, INFO_SHIFTED = 1, 2, 4, 8, 16  # lscqp_info.flags
+INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED, INFO_REMEMBERED, INFO_SHIFTED, INFO_RESCUED = 1, 2, 4, 8, 16, 32  # lscqp_info.flags
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC, PLANNER_RSFC = 0, 1, 2, 3
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
 SFC_INIT, SFC_FROM_HULL, SFC_FROM_POINT = 0, 1, 2  # lscqp_construct_sfc_device modes

@@ -873,6 +873,13 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
             return fail(LSCQP_ERR_UNSUPPORTED, buf);
         }
         if (retry == -2) return LSCQP_OK;  // (no other elimination order to try)
+        if (retry == -3) {  // (internal) only the rescue pass
+            cls.repair = 2;
+            e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out,
+                                     d_info_out, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (rescue pass): ") + hipGetErrorString(e));
+            return LSCQP_OK;
+        }
         e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
                                  d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (run-time-shaped kernel): ") + hipGetErrorString(e));
@@ -882,8 +889,27 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      d_info_out, (hipStream_t)stream);
             if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (run-time-shaped kernel, second pass): ") + hipGetErrorString(e));
         }
+        if (retry == 2) {
+            cls.repair = 2;
+            e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out,
+                                     d_info_out, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (rescue pass): ") + hipGetErrorString(e));
+        }
         return LSCQP_OK;
     }
+    // RESCUE pass (retry == -3: only it; retry == 2: after the other passes): what is still at the iteration limit or broke down
+    // numerically goes through the run-time-shaped kernel once more with cls.repair = 2 (lscqp_generic.hip: weighted corrector)
+    auto rescue = [&]() -> int {
+        if (n_obs_max > lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) return LSCQP_OK;  // (the kernel cannot hold the batch: nothing to try)
+        lscqp::DevClass rc_ = cls;
+        rc_.repair = 2;
+        rc_.queue = nullptr;
+        const hipError_t er = lscqp_launch_generic(&rc_, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out,
+                                                   d_status_out, d_info_out, (hipStream_t)stream);
+        if (er != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (rescue pass): ") + hipGetErrorString(er));
+        return LSCQP_OK;
+    };
+    if (retry == -3) return rescue();
     if (retry == -2) {  // (internal) only the repair pass, on the other-order instance: the statuses of a first pass are in d_status_out
         const Inst* other = other_order_instance(inst64, n_obs_max);
         if (!other) return LSCQP_OK;
@@ -912,6 +938,7 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));
     }
+    if (retry == 2) return rescue();
     return LSCQP_OK;
 }
 
@@ -1001,6 +1028,16 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
         const Inst* first = any ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : nullptr;
         if (first && other_order_instance(first, n_obs_max)) {
             rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, st);
+            if (rc != LSCQP_OK) return rc;
+            LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+            LSCQP_CK(hipStreamSynchronize(st));
+        }
+        // ... and what is STILL at the iteration limit or broke down numerically gets the rescue pass (run-time-shaped kernel, weighted
+        // corrector: LSCQP_INFO_RESCUED); again only batches with such an instance pay for it
+        bool lim = false;
+        for (int64_t q = 0; q < n && !lim; q++) lim = st_h[q] == LSCQP_STATUS_ITER_LIMIT || st_h[q] == LSCQP_STATUS_NUMERIC;
+        if (lim && n_obs_max <= lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) {
+            rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -3, st);
             if (rc != LSCQP_OK) return rc;
             LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));

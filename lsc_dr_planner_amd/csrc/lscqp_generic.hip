@@ -25,6 +25,9 @@
 
 #include <atomic>
 
+#ifndef LSCQP_SOC_GATE
+#define LSCQP_SOC_GATE 0.3  // rescue pass: affine step length below which the corrector's second-order term is weighted with it
+#endif
 #include "lscqp_kernel.hpp"  // DevClass, KQ, TBc, fast_rcp (shared with the compiled instances)
 #include "lscqp_launch.hpp"
 
@@ -136,10 +139,14 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
 #endif
     const lscqp_header* Hd = hdr + q;
     int flags = 0, it_before = 0;
+    // cls.repair == 2: the RESCUE pass (lscqp_api.hip) -- only instances that ran into the iteration limit or broke down numerically,
+    // re-solved from the default start with the corrector's second-order term weighted (see pass 2)
+    const bool rescue = cls.repair == 2;
     if (cls.repair) {
         const int st0 = status_out[q];
         if (st0 == LSCQP_STATUS_OPTIMAL || st0 == LSCQP_STATUS_CAPACITY) return;
-        flags |= LSCQP_INFO_REPAIRED;
+        if (rescue && st0 != LSCQP_STATUS_ITER_LIMIT && st0 != LSCQP_STATUS_NUMERIC) return;
+        flags |= LSCQP_INFO_REPAIRED | (rescue ? LSCQP_INFO_RESCUED : 0);
         if (info_out) it_before = info_out[q].iterations;
     }
     const int n_obs = Hd->n_obs;
@@ -840,6 +847,23 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             GEN_T(5);
             // ============ pass 2: affine step length, mu_aff, corrector right-hand side =========================================
             double rmax = 1.0, sB = 0, dmy = 0;
+            // WEIGHT OF THE SECOND-ORDER TERM, rescue pass only (end of round 4).  Mehrotra's corrector carries ds_a dl_a, the error a FULL
+            // affine step would leave.  When the affine step is blocked early (alpha_aff < LSCQP_SOC_GATE) that estimate is far too large
+            // and the corrected direction can be worse than none: a DLSC instance (M = 10, 3-D, 23 neighbours, cold start;
+            // tests/golden/limit_cycle_dlsc.npz, found by tools/stress_parity.py --dlsc --seed0 400) CYCLES with period four -- alpha
+            // 0.89 / 0.46 / 0.16 / 0.84, sigma 1e-3 / 0.97 / 0.61 / 0.97, mu going UP sixfold on the blocked steps, gap 6e-6 .. 6e-5 --
+            // to the iteration limit, before and after its one re-centring, on every kernel and in the numpy prototype alike.  With the
+            // term weighted by alpha_aff in those iterations (what Colombo & Gondzio's weighted correctors reduce to without a line
+            // search) it converges in 11.  The weight is applied only once the primal residual is below 1e-6 m: before that a short
+            // affine step is the infeasible start's, not bad centring, and the weighted iteration stalls there (an M = 7 instance of
+            // tests/test_gpu_parity.py went INFEASIBLE; tools/proto_corrector.py: the feasible-phase gate changes no iteration count
+            // on the bench shapes).  In the compiled instances the same sweep costs the 64-QP headline 3 % (measured, A/B) for a
+            // one-in-30 000 event, so it lives here, behind the rescue pass, and the first pass is bit-identical to what it was.
+            const double soc_gate = rescue ? LSCQP_SOC_GATE : 0.0;
+            double som = 1.0;  // weight of ds_a dl_a in the corrector (uniform over the workgroup)
+#pragma nounroll
+            for (int rep2 = 0;; rep2++) {
+            rmax = 1.0, sB = 0;
 #pragma unroll
             for (int u = 0; u < kR2; u++) {
                 const int r = tid + kT * u;
@@ -853,7 +877,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 sB += t_on[u] ? (pl + ph) : 0.0;
                 if (r < S.NOM) {
                     rv1_[r] = t_on[u] ? isl - ish : 0.0;
-                    rv2_[r] = t_on[u] ? (-pl - t_ll[u] * rpl) * isl - (-ph - t_lh[u] * rph) * ish : 0.0;
+                    rv2_[r] = t_on[u] ? (-som * pl - t_ll[u] * rpl) * isl - (-som * ph - t_lh[u] * rph) * ish : 0.0;
                 }
             }
             {
@@ -870,7 +894,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                     rmax = fmax(rmax, (l > 0.0) ? fmax(-t, 1.0 + t) : 1.0);
                     const double pa = -ds * l * (1.0 + t);
                     sB += pa;
-                    const double t2 = (-pa - l * rp) * is;
+                    const double t2 = (-som * pa - l * rp) * is;
                     b10 += is * R.nx, b11 += is * R.ny, b12 += is * R.nz;
                     b20 += t2 * R.nx, b21 += t2 * R.ny, b22 += t2 * R.nz;
                 }
@@ -893,6 +917,10 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 }
             }
             block_reduce3(rmax, sB, dmy, true, false, false);
+            if (rep2 == 1 || !(rmax * soc_gate > 1.0 && max_rp <= 1e-6)) break;  // uniform; the repetition rewrites rv2_ / LX_ and reproduces rmax, sB
+            som = rcp2(rmax);
+            __syncthreads();
+            }
             for (int e = tid; e < NX; e += kT) {
                 const int k = e / P, cp = e % P;
                 X1[e] = gather_rows(rv1_, e) + (cp >= 3 ? LX_[k * CP + cp - 3] : 0.0);
@@ -927,8 +955,8 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 const double tl = (dya + rpl) * isl, th = (rph - dya) * ish;
                 const double pl = -(dya + rpl) * t_ll[u] * (1.0 + tl), ph = -(rph - dya) * t_lh[u] * (1.0 + th);
                 const double dsl = dyc + rpl, dsh = rph - dyc;
-                const double dll = (smu - pl) * isl - t_ll[u] - t_ll[u] * isl * dsl;
-                const double dlh = (smu - ph) * ish - t_lh[u] - t_lh[u] * ish * dsh;
+                const double dll = (smu - som * pl) * isl - t_ll[u] - t_ll[u] * isl * dsl;
+                const double dlh = (smu - som * ph) * ish - t_lh[u] - t_lh[u] * ish * dsh;
                 const double ill = rcp2(on ? t_ll[u] : 1.0), ilh = rcp2(on ? t_lh[u] : 1.0);
                 const double rr = fmax(fmax(-dsl * isl, -dsh * ish), fmax(-dll * ill, -dlh * ilh));
                 rmax = fmax(rmax, on ? rr : 0.0);
@@ -956,7 +984,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 const double pa = -dsa * D.l * (1.0 + dsa * is);
                 const double ds = (R.nx * dx3 + R.ny * dy3 + R.nz * dz3) + rp;
                 const bool act = D.l > 0.0;
-                D.dl = act ? ((smu - pa) * is - D.l - D.l * is * ds) : 0.0;
+                D.dl = act ? ((smu - som * pa) * is - D.l - D.l * is * ds) : 0.0;
                 D.ds = act ? ds : 0.0;
                 return D;
             };

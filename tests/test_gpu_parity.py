@@ -409,6 +409,62 @@ def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_c
     assert d_st.item() == 0 and abs(d_obj.item() - o["obj"]) <= OBJ_TOL * max(1.0, abs(o["obj"]))
 
 
+def test_limit_cycle_of_the_iteration_is_ended_by_the_rescue_pass(api, oracle, torch_cuda):
+    """tests/golden/limit_cycle_dlsc.json: a DLSC instance (M = 10, 3-D, 23 neighbours) on which the predictor-corrector iteration runs
+    into a limit cycle from the default start -- period four, gap 6e-6 .. 6e-5, the re-centring does not break it -- and ends at the
+    iteration limit on the compiled instances and on the run-time-shaped kernel alike.  The host-pointer entry (what the shim calls) and
+    retry = 2 of the device entry re-solve such an instance in the rescue pass (run-time-shaped kernel, the corrector's second-order
+    term weighted by the blocked affine step length): the optimum is the oracle's, lscqp_info says LSCQP_INFO_RESCUED."""
+    torch = torch_cuda
+    g = H.load_golden("limit_cycle_dlsc")
+    M, dim, n_obs = g["M"], g["dim"], g["n_obs"]
+    sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=api.PLANNER_DLSC, world_min=g["world_min"], world_max=g["world_max"]))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, planner_lsc=False, world_min=g["world_min"], world_max=g["world_max"])
+    hdr = np.zeros(1, api.HEADER_DTYPE)
+    for f, v in g["hdr"].items():
+        hdr[f][0] = v
+    hdr["n_obs"][0] = n_obs
+    R = np.array(g["rows"])
+    rows = np.zeros(len(R), api.ROW_DTYPE)
+    rows["nx"], rows["ny"], rows["nz"], rows["b"] = R[:, 0], R[:, 1], R[:, 2], R[:, 3]
+    sfc = np.zeros(M, api.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = g["sfc_min"], g["sfc_max"]
+    off = np.array([0, len(R)], dtype=np.uint64)
+    ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
+    lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+    lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)
+    lsc["d"] = R[:, 3].reshape(n_obs, M, 6)
+    o = oracle.solve(cls, ag, lsc, sfc)
+    assert o["status"] == 0
+
+    def agrees(obj, x):
+        return abs(o["obj"] - obj) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - x).max() <= X_TOL
+
+    G = sol.solve_host(hdr, rows, off, sfc)
+    assert G["status"][0] == 0 and agrees(G["obj"][0], G["x"][0])
+    # (the flag is what makes this fixture a test of the rescue pass: should a later first pass solve the instance, look for a new one)
+    assert G["info"]["flags"][0] & api.INFO_RESCUED and G["info"]["flags"][0] & api.INFO_REPAIRED
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_x = torch.zeros(sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_st = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    d_info = torch.zeros(api.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    args = (1, n_obs, up(hdr), up(rows), up(off), up(sfc), d_x, d_obj, d_st)
+    sol.solve_device(*args, d_info=d_info)  # one pass: the honest verdict, never a wrong optimum
+    torch.cuda.synchronize()
+    assert d_st.item() == api.STATUS_ITER_LIMIT
+    sol.solve_device(*args, d_info=d_info, retry=2)
+    torch.cuda.synchronize()
+    assert d_st.item() == 0 and agrees(d_obj.item(), d_x.cpu().numpy())
+    assert d_info.cpu().numpy().view(api.INFO_DTYPE)["flags"][0] & api.INFO_RESCUED
+    # an infeasible instance is none of the rescue pass's business: same verdict, no flag
+    sfc2 = sfc.copy()  # (a corridor five metres from the start state: the acceleration limits keep the first free control points near it)
+    sfc2["bmin"], sfc2["bmax"] = hdr["p0"][0] + 5.0, hdr["p0"][0] + 6.0
+    G2 = sol.solve_host(hdr, rows, off, sfc2)
+    assert G2["status"][0] == api.STATUS_INFEASIBLE and not (G2["info"]["flags"][0] & api.INFO_RESCUED)
+
+
 def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(api, oracle, torch_cuda):
     """tests/golden/pivot_breakdown_w2.json: an M = 6 dense-maze instance whose factorisation breaks down after the acceptance tests
     were met at the rounding floor.  In the two-wavefront instance only wavefront 0 holds the system and sees the failed pivot;

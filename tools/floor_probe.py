@@ -19,7 +19,7 @@ xflags = [a for a in sys.argv[1:] if a.startswith("-D")]
 import bench  # noqa: E402
 
 cfg = bench.CONFIGS[key]
-N, M, D, NOBS = int(os.environ.get("PROBE_N", cfg["agents"])), cfg["segments"], cfg["dim"], cfg["obs"]
+N, M, D, NOBS = int(os.environ.get("PROBE_N", 1 if os.environ.get("PROBE_NPZ") else cfg["agents"])), cfg["segments"], cfg["dim"], cfg["obs"]
 NSLOT, W = {(10, 3): (10, 4), (5, 3): (10, 1), (6, 3): (7, 2), (10, 2): (5, 2)}[(M, D)]
 if os.environ.get("PROBE_NSLOT"):
     NSLOT, W = int(os.environ["PROBE_NSLOT"]), int(os.environ["PROBE_W"])
@@ -29,7 +29,9 @@ extern "C" int lscqp_trace_read(double* out, int nq) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lscqp::lscqp_dbg_trace), sizeof(double) * 64 * 12 * nq);
 }
 '''
-tu = '#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES 1\n#define LSCQP_NSLOT %d\n#define LSCQP_W %d\n#define LSCQP_MIXED 0\n#include "lscqp_inst.hip"\n' % (M, D, NSLOT, W) + drv
+ES = int(os.environ.get("PROBE_ES", "1"))  # 0: the end-stop-free class (DLSC / BVC / RSFC planner modes)
+tu = ('#define LSCQP_M %d\n#define LSCQP_DIM %d\n#define LSCQP_ES %d\n#define LSCQP_NSLOT %d\n#define LSCQP_W %d\n#define LSCQP_MIXED 0\n#include "lscqp_inst.hip"\n'
+      % (M, D, ES, NSLOT, W)) + drv
 open("/tmp/trace_tu.hip", "w").write(tu)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-mllvm",
                        "-disable-promote-alloca-to-vector", "-DLSCQP_TRACE", "-DLSCQP_TRACE_Q=%d" % N, "-I", SRC, "/tmp/trace_tu.hip", "-o", OUT] + xflags,
@@ -47,7 +49,19 @@ def factory(sw):
     return api.Solver(api.make_desc(M=M, dim=D, world_min=sw.world_min, world_max=sw.world_max))
 
 
-if os.environ.get("PROBE_SWARM"):
+if os.environ.get("PROBE_NPZ"):
+    # PROBE_NPZ=file : ONE dumped instance (hdr[1], rows[], sfc[1, M], world_min, world_max in the ABI's dtypes), cold start
+    class _W:  # what the rest of the script reads off a swarm
+        pass
+    dmp = np.load(os.environ["PROBE_NPZ"])
+    sw = _W()
+    sw.world_min, sw.world_max, sw.n_obs = dmp["world_min"], dmp["world_max"], int(dmp["hdr"]["n_obs"][0])
+    N, b = 1, None
+    sol = api.Solver(api.make_desc(M=M, dim=D, planner_mode=api.PLANNER_LSC if ES else api.PLANNER_DLSC, world_min=sw.world_min, world_max=sw.world_max))
+    hdr, rows, sfc = dmp["hdr"], dmp["rows"], dmp["sfc"]
+    off = np.array([0, len(rows)], dtype=np.uint64)
+    os.environ["WARM"] = "0"
+elif os.environ.get("PROBE_SWARM"):
     # PROBE_SWARM=seed,steps : synth.Swarm(N, seed=seed) of the config's shape advanced `steps` replans (failed QPs keep their start), as the
     # parity tests build their batches; PROBE_N overrides the agent count
     seed_, steps_ = [int(v) for v in os.environ["PROBE_SWARM"].split(",")]
@@ -84,7 +98,7 @@ cls.q2s = 2 * 0.01 * 0.2 ** -5
 cls.tol, cls.max_iter, cls.use_sfc, cls.n_obs_max = 1e-10, 60, 1, sw.n_obs
 cls.warm_mu0, cls.warm_s0, cls.warm_net = 1e-3, 0.03, 0.0
 d_xi = torch.from_numpy(api.x_init_from_swarm(b, D)).to(dev) if os.environ.get("WARM", "1") != "0" else None
-fn = getattr(L, "lscqp_launch_%d_%d_1_%d_%d_0" % (M, D, NSLOT, W))
+fn = getattr(L, "lscqp_launch_%d_%d_%d_%d_%d_0" % (M, D, ES, NSLOT, W))
 fn.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
 rc = fn(C.byref(cls), N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), d_xi.data_ptr() if d_xi is not None else None,
         dx.data_ptr(), dob.data_ptr(), dst.data_ptr(), dinfo.data_ptr(), None)

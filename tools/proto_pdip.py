@@ -32,6 +32,7 @@ def build_T(M, end_stop):
 
 
 FINISH_LOG = []
+JAM_COLD = True  # the kernel counts jams from the default start too (round 2)
 PIVOT_FLOOR = 0.0
 JACOBI = True
 
@@ -68,7 +69,7 @@ def solve32(fac, b):
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
           tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None, sigma_pow=3.0,
-          dual_start=None, nbr_ids=None, state_out=None, split_steps=False):
+          dual_start=None, nbr_ids=None, state_out=None, split_steps=False, corr_weight=None, second_jam=None, trace=None):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -235,6 +236,8 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         hdr["goal"][k] ** 2 for k in range(dim))
     status, it, near_cnt, rp_ref = 2, 0, 0, 3.0e38
     gap_mark, jam_since, recentred, floor_seen = 3.0e38, 0, False, False
+    safe_mode = False
+    aa_prev = 1.0
     for it in range(max_iter):
         rp = Gz @ z - hz - s
         grad = Kfull @ z + gfull
@@ -323,7 +326,20 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             rp_ref = float(np.float32(np.abs(rp).max()))
         # jammed warm start (same rule as the kernel): residuals converged, the gap below 1e-4 but without a tenfold improvement
         # within six such iterations and never at its target -> the row state is re-centred once at the current point
-        if warm and not recentred and np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-6 * gls:
+        if second_jam is not None and recentred and not safe_mode and np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-6 * gls:
+            gap_rel = (mu * mrows + pinf) / (1 + abs(objz + objc))
+            if tol < gap_rel <= 1e-4:
+                if gap_rel <= 0.1 * gap_mark:
+                    gap_mark, jam_since = gap_rel, 0
+                else:
+                    jam_since += 1
+            if jam_since >= second_jam[0] and not floor_seen:
+                safe_mode = True
+                if len(second_jam) > 2 and second_jam[2]:
+                    s = np.maximum(Gz @ z - hz, 0.03)
+                    lam = 1e-3 / s
+                    continue
+        if (warm or JAM_COLD) and not recentred and np.abs(rp).max() <= 1e-9 and np.abs(rd).max() <= 1e-6 * gls:
             gap_rel = (mu * mrows + pinf) / (1 + abs(objz + objc))
             if tol < gap_rel <= 1e-4:
                 if gap_rel <= 0.1 * gap_mark:
@@ -334,6 +350,7 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
                 s = np.maximum(Gz @ z - hz, 0.03)
                 lam = 1e-3 / s
                 recentred, rp_ref, near_cnt = True, 3.0e38, 0
+                jam_since, gap_mark = 0, 3.0e38
                 continue
             floor_seen = floor_seen or gap_rel <= tol
         w = lam / s
@@ -372,10 +389,31 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         if neg.any(): aa = min(aa, (-lam[neg] / dla[neg]).min())
         mu_aff = (s + aa * dsa) @ (lam + aa * dla) / mrows
         sigma = (mu_aff / mu) ** sigma_pow
-        q = (sigma * mu - dsa * dla) / s - w * rp
+        # experiment (round 4): weight of Mehrotra's second-order term.  None: 1 (the kernel's); 'aff' / 'aff2': alpha_aff / alpha_aff^2
+        # (the term estimates the error of a FULL affine step); safe mode (second_jam, below): 0 and sigma >= second_jam[1]
+        if corr_weight is None:
+            om = 1.0
+        elif corr_weight == "aff":
+            om = aa
+        elif corr_weight == "aff2":
+            om = aa * aa
+        elif str(corr_weight).startswith("lag"):  # 'lag0.3': the PREVIOUS iteration's alpha_aff, where that was below the threshold
+            om = aa_prev if aa_prev < float(corr_weight[3:]) else 1.0
+        elif str(corr_weight).startswith("fgate"):  # 'fgate0.3,1e-6': as gate, once the primal residual is below the second number
+            thr_, rpmax_ = [float(v) for v in corr_weight[5:].split(",")]
+            om = aa if (aa < thr_ and np.abs(rp).max() <= rpmax_) else 1.0
+        elif str(corr_weight).startswith("gate"):  # 'gate0.3': alpha_aff below the threshold, else 1
+            om = aa if aa < float(corr_weight[4:]) else 1.0
+        else:
+            om = float(corr_weight)
+        if safe_mode:
+            om, sigma = 0.0, max(sigma, second_jam[1])
+        aa_prev = aa
+        soc = om * dsa * dla
+        q = (sigma * mu - soc) / s - w * rp
         dz = lin(q)
         ds = Gz @ dz + rp
-        dl = (sigma * mu - dsa * dla) / s - lam - w * ds
+        dl = (sigma * mu - soc) / s - lam - w * ds
         a = 1e300
         neg = ds < 0
         if neg.any(): a = min(a, (-s[neg] / ds[neg]).min())
@@ -418,6 +456,8 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             a = a_std if (_bt == 0 and a_std < a) else 0.7 * a
         if it == 0:
             a_first = a
+        if trace is not None:
+            trace.append((it, mu, a, sigma, aa))
         if verbose:  # which row stopped the step: the smallest ratio among -s/ds (primal) and -lam/dl (dual)
             rs = np.where(ds < 0, -s / np.where(ds < 0, ds, -1.0), np.inf); rl = np.where(dl < 0, -lam / np.where(dl < 0, dl, -1.0), np.inf)
             i_s, i_l = int(rs.argmin()), int(rl.argmin())

@@ -1,5 +1,5 @@
 """Development aid: randomized parity sweep of the HIP solver against the CPU oracle over seeds / shapes / styles.
-    python tools/stress_parity.py [n_seeds]
+    python tools/stress_parity.py [n_seeds] [--seed0 S] [--warm] [--tight] [--dlsc] [--nd] [--gen 0|1|2] [--shape i]
 Prints one line per configuration and every instance that is non-optimal or outside the parity tolerances."""
 import os
 import sys
@@ -16,6 +16,7 @@ from lsc_dr_planner_amd import api, synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
+SEED0 = int(sys.argv[sys.argv.index("--seed0") + 1]) if "--seed0" in sys.argv else 100  # first seed of the sweep
 GEN = None  # --gen 0|1|2: the rows come from the device generator (generateLSC / generateCLSC / generateBVC), not from synth
 if "--gen" in sys.argv:
     GEN = int(sys.argv[sys.argv.index("--gen") + 1])
@@ -33,7 +34,7 @@ for (N, M, dim, n_obs, style) in shapes:
     worst_dx = worst_do = 0.0
     iters = []
     nbad = n_both_bad = 0
-    for seed in range(100, 100 + n_seeds):
+    for seed in range(SEED0, SEED0 + n_seeds):
         sw = synth.Swarm(N, M=M, dim=dim, n_obs=n_obs, seed=seed, style=style)
         cls = O.make_class(M=M, dim=dim, use_sfc=True, planner_lsc=not DLSC, world_min=sw.world_min, world_max=sw.world_max)
         sol = api.Solver(api.make_desc(M=M, dim=dim, planner_mode=api.PLANNER_DLSC if DLSC else api.PLANNER_LSC, world_min=sw.world_min, world_max=sw.world_max,
