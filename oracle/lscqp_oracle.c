@@ -429,8 +429,12 @@ static void qr_of_transpose(int neq, int nv, const double* A, double* Q, double*
 /* ------------------------------------------------------------------------------------------------
  * Generic dense Mehrotra predictor-corrector:  min 1/2 z'Hz + g'z  s.t.  Gz <= h
  * ---------------------------------------------------------------------------------------------- */
+/* weighted != 0 (second attempt of orc_solve only, round 4): in iterations whose affine step is blocked below 0.3 while the primal residual
+ * has closed, Mehrotra's second-order term ds_a dl_a -- the error of a FULL affine step -- is weighted with that step length; the plain
+ * iteration can run into a limit cycle there (the same finding as in the HIP kernel: NOTES.md section 11, "A limit cycle ...").  The first
+ * attempt is the iteration every golden vector was pinned with, unchanged. */
 static int pdip_dense(int nz, int m, const double* H, const double* g, const double* G, const double* h,
-                      const double* z0, double tol, int max_iter, double* z, double* lam, int* iters_out) {
+                      const double* z0, double tol, int max_iter, double* z, double* lam, int* iters_out, int weighted) {
     double* s = (double*)malloc(sizeof(double) * m);
     double* w = (double*)malloc(sizeof(double) * m);
     double* rp = (double*)malloc(sizeof(double) * m);
@@ -536,6 +540,8 @@ static int pdip_dense(int nz, int m, const double* H, const double* g, const dou
         mu_aff = m > 0 ? mu_aff / m : 0.0;
         double sigma = mu > 0 ? pow(mu_aff / mu, 3.0) : 0.0;
         /* corrector: rc = s*lam - sigma*mu + dsa*dla */
+        if (weighted && alpha_aff < 0.3 && rpn <= 1e-6 * hscale)
+            for (int i = 0; i < m; i++) dsa[i] *= alpha_aff; /* (dsa is only used in the product from here on) */
         for (int i = 0; i < m; i++) t[i] = (s[i] * lam[i] - sigma * mu + dsa[i] * dla[i]) / s[i] - w[i] * rp[i];
         for (int j = 0; j < nz; j++) rhs[j] = -rd[j];
         for (int i = 0; i < m; i++) {
@@ -733,7 +739,12 @@ int orc_solve(const orc_class* c, const orc_agent* a, const orc_lsc* lsc, const 
     double* z = (double*)malloc(sizeof(double) * nz);
     double* lall = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
     int it = 0;
-    int status = pdip_dense(nz, m, Hz, gz, Gz, hz, z0, tol, max_iter, z, lall, &it);
+    int status = pdip_dense(nz, m, Hz, gz, Gz, hz, z0, tol, max_iter, z, lall, &it, 0);
+    if (status == 2 || status == 3) { /* iteration limit / breakdown: once more with the weighted corrector (see pdip_dense) */
+        int it2 = 0;
+        status = pdip_dense(nz, m, Hz, gz, Gz, hz, z0, tol, max_iter, z, lall, &it2, 1);
+        it += it2;
+    }
     for (int i = 0; i < nv; i++) {
         double s = xp[i];
         for (int j = 0; j < nz; j++) s += NMAT(i, j) * z[j];
