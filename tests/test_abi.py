@@ -178,3 +178,19 @@ def test_instance_table_covers_every_shape_up_to_m10():
             cap[(M, D, E)] = max(cap.get((M, D, E), 0), S * max(1, 64 * W // (6 * M - 3)))
     for key in ((5, 3, 1), (5, 3, 0), (10, 2, 1), (10, 2, 0), (10, 3, 1)):
         assert cap[key] >= 40, (key, cap[key])
+
+
+def test_python_constants_are_the_headers(api):
+    """Statuses, return codes and lscqp_info flags used by the tests and bench.py (api.py) are include/lscqp.h's, name for name."""
+    import os
+    import re
+
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "lscqp.h")).read()
+    hdr = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(LSCQP_(?:STATUS|ERR|INFO)_[A-Z0-9_]+|LSCQP_OK)\s*=?\s+(\d+)\b", txt)}
+    hdr.update({m.group(1): int(m.group(2)) for m in re.finditer(r"\b(LSCQP_(?:STATUS|ERR)_[A-Z0-9_]+|LSCQP_OK) = (\d+)", txt)})
+    seen = 0
+    for name, val in vars(api).items():
+        if re.fullmatch(r"(STATUS|ERR|INFO)_[A-Z0-9_]+|OK", name) and isinstance(val, int):
+            assert hdr.get("LSCQP_" + name) == val, (name, val, hdr.get("LSCQP_" + name))
+            seen += 1
+    assert seen >= 16 and hdr["LSCQP_INFO_RESCUED"] == 32
