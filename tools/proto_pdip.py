@@ -32,6 +32,7 @@ def build_T(M, end_stop):
 
 
 FINISH_LOG = []
+EXTRA_SOLVES = 0
 JAM_COLD = True  # the kernel counts jams from the default start too (round 2)
 PIVOT_FLOOR = 0.0
 JACOBI = True
@@ -69,7 +70,7 @@ def solve32(fac, b):
 
 def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_max, hdr, rows, sfc, ts,
           tol=1e-10, max_iter=60, verbose=False, fp32=None, gondzio=0, gondzio_from=0, mu0_s0=None, early_recentre=None, finish=None, sigma_pow=3.0,
-          dual_start=None, nbr_ids=None, state_out=None, split_steps=False, corr_weight=None, second_jam=None, trace=None):
+          dual_start=None, nbr_ids=None, state_out=None, split_steps=False, corr_weight=None, second_jam=None, trace=None, start=None, sig_rule=None, clip=None, presolve=False, probe=None, gpar=(1.08, 0.08, 0.1, 10.0, 1.01, 0.9), tau_pow=1.0, tau_gate=1e-4, return_problem=False):
     """hdr: dict p0,v0,a0,goal,next_waypoint,vmax,amax,radius. rows: (n_obs, M, 6, 4) packed (nx,ny,nz,b).
     sfc: (M, 2, 3) or None. Returns x (dim*P), obj, status, iters."""
     P = 6 * M
@@ -88,6 +89,16 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         rows[..., 3] -= rows[..., :3] @ org
     T, nzA = build_T(M, end_stop)
     nz = dim * nzA
+    if presolve and end_stop and rows is not None:
+        # experiment (round 5): under the end stop c3 = c4 = c5 of the last segment are ONE point; a neighbour's three rows on it share the
+        # segment's normal, so only the one with the largest right-hand side can bind: the other two are dominated (dropped like zero rows)
+        for oi in range(rows.shape[0]):
+            r3 = rows[oi, M - 1, 3:6]
+            if np.abs(r3[:, :3] - r3[0, :3]).max() < 1e-12:
+                keep = int(np.argmax(r3[:, 3]))
+                for i in range(3):
+                    if i != keep:
+                        rows[oi, M - 1, 3 + i, :3] = 0.0
     Q2 = 2 * w_c * q_base(dt)
     # fixed part
     cfix = np.zeros((dim, P))
@@ -187,6 +198,8 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     if np.any(np.concatenate([r[2] - r[1] for r in rowsA]) < 0):
         return None, np.nan, 1, 0
 
+    if return_problem:
+        return dict(K=Kfull, g=gfull, G=Gz, h=hz, keys=keys, T=T, cfix=cfix, nzA=nzA, K0=K0, org=org)
     # ---- PDIP ("G z - h = s >= 0") ----------------------------------------------------------------
     z = np.zeros(nz)
     for k in range(dim):  # start: every free control point at c2 of the first segment
@@ -212,6 +225,36 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
     s = np.maximum(Gz @ z - hz, 0.0)
     s = np.maximum(s, s0)
     lam = mu0 / s  # centred start: every product s*lam = mu0
+    if start is not None and warm:
+        # experiment (round 5): honest slacks for rows that start close to their bound.  start = (s_floor, lam_cap): s = max(r, s_floor),
+        # lam = min(mu0 / s, lam_cap) -- the multiplier the inflated start would have given, on the slack the row really has
+        r_ = Gz @ z - hz
+        s = np.maximum(r_, start[0])
+        lam = np.minimum(mu0 / s, start[1])
+    if probe is not None and warm:
+        # experiment (round 5): PROBE start.  The unconstrained Newton step dz_u = -H^-1 grad(z0) (H is the class's constant matrix: its
+        # inverse can be tabulated per `ts`) says which rows the cost pushes the plan through: r + G dz_u < 0.  Those rows start with their
+        # honest slack and a multiplier sized to stop the motion: lam = min(cap, -(r + G dz_u) / (g' H^-1 g) / (number of such rows)^pw)
+        kind, cap, pw, sfl = probe
+        r_ = Gz @ z - hz
+        grad0 = Kfull @ z + gfull
+        Hi = np.linalg.inv(Kfull)
+        dzu = -Hi @ grad0
+        pred = r_ + Gz @ dzu
+        hitrows = np.where(pred < 0)[0]
+        LAST_START["probe_rows"] = len(hitrows)
+        if len(hitrows):
+            gHg = np.einsum("ij,jk,ik->i", Gz[hitrows], Hi, Gz[hitrows])
+            if kind == "each":
+                lam_p = -pred[hitrows] / np.maximum(gHg, 1e-12) / len(hitrows) ** pw
+            elif kind == "nnls":
+                from scipy.optimize import nnls
+                A_ = Gz[hitrows]
+                # min || A H^-1 A' lam + pred ||  (the multipliers that bring the violated rows back to zero slack), lam >= 0
+                lam_p, _ = nnls(A_ @ Hi @ A_.T + 1e-9 * np.eye(len(hitrows)), -pred[hitrows])
+            lam_p = np.minimum(lam_p, cap)
+            s[hitrows] = np.maximum(r_[hitrows], sfl)
+            lam[hitrows] = np.maximum(lam[hitrows], lam_p)
     if dual_start is not None:
         # experiment: DUAL warm start.  dual_start = (prev, rule): prev maps a row key of the PREVIOUS replan's QP to its final (s, lam);
         # the row (fam, k, m, i) of this replan was row (fam, k, m + 1, i) then (the plan moved on by one segment), the new last
@@ -388,7 +431,17 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         neg = dla < 0
         if neg.any(): aa = min(aa, (-lam[neg] / dla[neg]).min())
         mu_aff = (s + aa * dsa) @ (lam + aa * dla) / mrows
+        if sig_rule is not None and sig_rule[0] == "split":
+            # experiment (round 5): the affine step's primal and dual lengths taken separately for the centring estimate only
+            aap = aad = 1.0
+            neg = dsa < 0
+            if neg.any(): aap = min(aap, (-s[neg] / dsa[neg]).min())
+            neg = dla < 0
+            if neg.any(): aad = min(aad, (-lam[neg] / dla[neg]).min())
+            mu_aff = (s + aap * dsa) @ (lam + aad * dla) / mrows
         sigma = (mu_aff / mu) ** sigma_pow
+        if sig_rule is not None and sig_rule[0] == "cap":
+            sigma = min(sigma, sig_rule[1])
         # experiment (round 4): weight of Mehrotra's second-order term.  None: 1 (the kernel's); 'aff' / 'aff2': alpha_aff / alpha_aff^2
         # (the term estimates the error of a FULL affine step); safe mode (second_jam, below): 0 and sigma >= second_jam[1]
         if corr_weight is None:
@@ -425,13 +478,15 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
         # beyond the current step, pull the outlying complementarity products of the trial point back into [0.1, 10] x target
         for _g in range(gondzio if it >= gondzio_from else 0):
             a_cur = min(1.0, 0.9995 * a) if a < 1e299 else 1.0
-            if a_cur >= 0.9:
+            if a_cur >= gpar[5]:
                 break
-            a_t = min(1.0, 1.08 * a_cur + 0.08)
+            global EXTRA_SOLVES
+            EXTRA_SOLVES += 1
+            a_t = min(1.0, gpar[0] * a_cur + gpar[1])
             v = (s + a_t * ds) * (lam + a_t * dl)
             mu_t = sigma * mu
-            t = np.clip(v, 0.1 * mu_t, 10 * mu_t) - v
-            t = np.maximum(t, -10 * mu_t)
+            t = np.clip(v, gpar[2] * mu_t, gpar[3] * mu_t) - v
+            t = np.maximum(t, -gpar[3] * mu_t)
             dzc = lin(t / s) + 0 * dz  # K dz = G'(t/s) - (-grad) ... the corrector solves with rhs = G'(t/s) only
             dzc = dzc - lin(np.zeros(mrows))  # remove the -grad part that lin() adds
             dsc = Gz @ dzc
@@ -442,11 +497,11 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             if neg.any(): a2 = min(a2, (-s[neg] / ds2[neg]).min())
             neg = dl2 < 0
             if neg.any(): a2 = min(a2, (-lam[neg] / dl2[neg]).min())
-            if min(1.0, 0.9995 * a2) >= 1.01 * a_cur:
+            if min(1.0, 0.9995 * a2) >= gpar[4] * a_cur:
                 dz, ds, dl, a = dz2, ds2, dl2, a2
             else:
                 break
-        tau = max(0.9995, 1.0 - mu) if sigma < 1e-4 else 0.9995  # adaptive fraction to the boundary (kernel: same rule)
+        tau = max(0.9995, 1.0 - mu ** tau_pow) if sigma < tau_gate else 0.9995  # adaptive fraction to the boundary (kernel: same rule; tau_pow = 1)
         a_std = min(1.0, 0.9995 * a)
         a = min(1.0, tau * a)
         for _bt in range(10):  # centrality safeguard: every product stays >= 1e-4 mu(a)  (kernel: same rule)
@@ -463,6 +518,21 @@ def solve(M, dim, dt, w_c, w_t, comm_range, end_stop, use_sfc, world_min, world_
             i_s, i_l = int(rs.argmin()), int(rl.argmin())
             print("   alpha %.4f sigma %.2e | primal block row %d ratio %.3f (s %.2e lam %.2e) | dual block row %d ratio %.3f (s %.2e lam %.2e) | rows %d"
                   % (a, sigma, i_s, rs[i_s], s[i_s], lam[i_s], i_l, rl[i_l], s[i_l], lam[i_l], mrows))
+        if clip is not None and np.abs(rp).max() <= clip[2]:
+            # experiment (round 5): PER-ROW step lengths.  z takes the step a_z = the common step unless that is short: then the rows that block
+            # are clipped on their own at the fraction-to-the-boundary (they pick up a residual the next Newton step removes)
+            #   clip = (which, a_min, rp_max): which in 'd' (multipliers only), 'p' (slacks only), 'pd'
+            az = 1.0
+            if 'p' not in clip[0]:
+                az = min(az, tau * a_pr)
+            if 'd' not in clip[0]:
+                az = min(az, tau * a_du)
+            if a < clip[1]:
+                fl = 1.0 - tau
+                z = z + az * dz
+                s = np.maximum(s + az * ds, fl * s)
+                lam = np.maximum(lam + az * dl, fl * lam)
+                continue
         if split_steps:
             # experiment: separate primal and dual step lengths (as Ipopt takes them): (z, s) move by a_p, lam by a_d
             tau_ = tau
