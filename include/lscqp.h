@@ -102,8 +102,22 @@ typedef struct lscqp_class_desc {
     int32_t precision; /* LSCQP_PRECISION_* below */
     double tol;        /* relative duality-gap tolerance, 0 = default 1e-10 */
     int32_t warm_start; /* LSCQP_WARM_* below: how an instance that comes with an initial trajectory is centred */
-    int32_t reserved_;
+    int32_t active_set; /* LSCQP_ACTIVE_SET_* below: the dual active-set phase in front of the interior-point kernel (0 = default: on) */
 } lscqp_class_desc;
+
+/* The dual active-set phase (round 5).  The QP's Hessian is a constant of the class -- jerk cost and terminal pull never depend on the
+ * neighbours -- and a plan's optimum holds few of its rows (none at all for 61 of the 64 QPs of BASELINE configs[1]): a first launch
+ * over the batch starts every instance at its unconstrained minimiser (three vectors of a per-class table, no factorisation) and adds
+ * the violated rows one at a time (Goldfarb-Idnani; csrc/lscqp_das.hip).  What it finishes is marked LSCQP_INFO_ACTIVE_SET and meets
+ * the same bar as an interior-point result (1e-9 m on every row, 1e-9 scaled stationarity, multipliers >= 0, exact complementarity);
+ * what it does not finish inside its budget (active rows, steps) -- or cannot judge: infeasible row systems, dependent active rows,
+ * capacity -- is solved by the interior-point kernel behind it in the same call, on the same stream, exactly as without the phase.
+ *   LSCQP_ACTIVE_SET_DEFAULT  on
+ *   LSCQP_ACTIVE_SET_OFF      the interior-point kernel alone (rounds 1-4; also: environment LSCQP_ACTIVE_SET=0 for a whole process)
+ *   LSCQP_ACTIVE_SET_ONLY     the phase alone: instances it leaves are returned LSCQP_STATUS_ITER_LIMIT (development / tests) */
+#define LSCQP_ACTIVE_SET_DEFAULT 0
+#define LSCQP_ACTIVE_SET_OFF 1
+#define LSCQP_ACTIVE_SET_ONLY 2
 
 /* Centring of warm-started instances (x_init given).  Every complementarity product starts at mu0 with the slacks floored at s0.
  *   LSCQP_WARM_DEFAULT  (mu0, s0) = (1e-3, 3 cm): safe whatever the quality of the initial trajectory; the shortest TAIL, which is
@@ -194,6 +208,12 @@ typedef struct lscqp_box {
                                        second-order term weighted by the affine step length where that step is blocked (< 0.3) in
                                        the feasible phase.  Run by the host-pointer entries for batches that still hold such an
                                        instance after their other passes, and by retry == 2 of the device entries. */
+#define LSCQP_INFO_ACTIVE_SET 64    /* solved by the DUAL ACTIVE SET phase (round 5, csrc/lscqp_das.hip) that runs in front of the interior-point
+                                       kernel: Goldfarb-Idnani from the unconstrained minimiser on the class's tabulated inverse.
+                                       `iterations` then counts its steps (rows added + rows dropped; 0 = the unconstrained minimiser
+                                       violates no row), res_primal is the largest violation over EVERY row at the returned point
+                                       (<= 1e-9 m), res_dual the reduced stationarity residual on the interior-point kernel's scale
+                                       (verified <= 1e-9), gap is 0: complementarity is exact.  See lscqp_class_desc.active_set. */
 typedef struct lscqp_info {
     int32_t iterations;
     int32_t flags;     /* LSCQP_INFO_* */

@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("LSCQP_LIB") or os.path.join(_HERE, "liblscqp.so")  # 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_ITER_LIMIT, STATUS_NUMERIC, STATUS_CAPACITY = 0, 1, 2, 3, 4
 PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
 WARM_DEFAULT, WARM_TIGHT = 0, 1  # lscqp_class_desc.warm_start
-INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED, INFO_REMEMBERED, INFO_SHIFTED, INFO_RESCUED = 1, 2, 4, 8, 16, 32  # lscqp_info.flags
+INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED, INFO_REMEMBERED, INFO_SHIFTED, INFO_RESCUED, INFO_ACTIVE_SET = 1, 2, 4, 8, 16, 32, 64  # lscqp_info.flags
+ACTIVE_SET_DEFAULT, ACTIVE_SET_OFF, ACTIVE_SET_ONLY = 0, 1, 2  # lscqp_class_desc.active_set
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC, PLANNER_RSFC = 0, 1, 2, 3
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
 SFC_INIT, SFC_FROM_HULL, SFC_FROM_POINT = 0, 1, 2  # lscqp_construct_sfc_device modes
@@ -60,7 +61,7 @@ class ClassDesc(C.Structure):
         ("planner_mode", C.c_int32), ("use_sfc", C.c_int32), ("row_format", C.c_int32),
         ("dt", C.c_double), ("control_input_weight", C.c_double), ("terminal_weight", C.c_double),
         ("communication_range", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3),
-        ("max_iter", C.c_int32), ("precision", C.c_int32), ("tol", C.c_double), ("warm_start", C.c_int32), ("reserved_", C.c_int32),
+        ("max_iter", C.c_int32), ("precision", C.c_int32), ("tol", C.c_double), ("warm_start", C.c_int32), ("active_set", C.c_int32),
     ]
 
 
@@ -251,9 +252,10 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
 
 def make_desc(M=5, dim=3, dt=0.2, w_c=0.01, w_t=1.0, comm_range=3.0, planner_mode=PLANNER_LSC, use_sfc=True,
               world_min=(-5, -5, 0), world_max=(5, 5, 2.5), n=5, phi=3, phi_n=1, max_iter=0, tol=0.0, row_format=ROWS_F64,
-              precision=PRECISION_F64, warm_start=0):
+              precision=PRECISION_F64, warm_start=0, active_set=0):
     d = ClassDesc()
     d.warm_start = warm_start
+    d.active_set = active_set
     d.row_format = row_format
     d.precision = precision
     d.M, d.n, d.phi, d.phi_n, d.dim = M, n, phi, phi_n, dim

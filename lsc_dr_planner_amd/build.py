@@ -100,6 +100,11 @@ def build(force=False, verbose=False, jobs=None):
     gen_src = os.path.join(CSRC, "lscqp_generic.hip")
     if force or _newer(gen_o, hdrs + [gen_src]):
         tasks.append([HIPCC] + FLAGS + ["-c", gen_src, "-o", gen_o])
+    das_o = os.path.join(OBJ, "lscqp_das.o")
+    objs.append(das_o)
+    das_src = os.path.join(CSRC, "lscqp_das.hip")
+    if force or _newer(das_o, hdrs + [das_src]):
+        tasks.append([HIPCC] + FLAGS + ["-c", das_src, "-o", das_o])
     diag_o = os.path.join(OBJ, "lscqp_diag.o")
     objs.append(diag_o)
     diag_src = os.path.join(CSRC, "lscqp_diag.hip")

@@ -32,6 +32,13 @@ extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, in
                                            const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
                                            int32_t* status_out, lscqp_info* info_out, hipStream_t stream);
 
+// the dual active-set phase (lscqp_das.hip)
+extern "C" size_t lscqp_das_build_tables(int M, int es, double dt, double w_c, double w_t, double* out);
+extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int stage_rows);
+extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
+                                       int stage_rows, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
+                                       const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out, int32_t* status_out,
+                                       lscqp_info* info_out, hipStream_t stream);
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
@@ -294,10 +301,23 @@ const double kQInt[36] = {720, -1800, 1200, 0,     0,     -120, -1800, 4800, -36
 
 }  // namespace
 
+// Tables of the dual active-set phase: one host copy per class generation, one device copy per device that has solved with the handle
+// (a communicator drives several devices through one handle).  Shared by the copies lscqp_update makes of the handle.
+struct DasTables {
+    std::mutex mu;
+    std::vector<double> host;
+    uint64_t gen = 0;
+    double* dev[64] = {};
+    size_t dev_n[64] = {};
+    uint64_t dev_gen[64] = {};
+    std::vector<void*> garbage;  // buffers replaced by an update that changed the shape: freed with the handle (a captured graph may still hold them)
+};
+
 struct lscqp_solver {
     lscqp_class_desc desc;
     lscqp::DevClass dev;
     int nv, P, es;
+    DasTables* das = nullptr;
     // staging of the host-pointer entry points: device buffer + pinned mirror + private stream per concurrent call
     // (one H2D and one D2H per host-pointer solve instead of eight small copies; lscqp_staging.hpp)
     lscqp::StagePool* pool = nullptr;
@@ -363,6 +383,8 @@ static int derive(lscqp_solver* s, const lscqp_class_desc* d) {
     c.rows_f32 = d->row_format == LSCQP_ROWS_F32;
     c.repair = 0;
     c.rsfc = d->planner_mode == LSCQP_PLANNER_RSFC;
+    if (d->active_set != LSCQP_ACTIVE_SET_DEFAULT && d->active_set != LSCQP_ACTIVE_SET_OFF && d->active_set != LSCQP_ACTIVE_SET_ONLY)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "active_set must be LSCQP_ACTIVE_SET_DEFAULT, _OFF or _ONLY");
     if (d->warm_start != LSCQP_WARM_DEFAULT && d->warm_start != LSCQP_WARM_TIGHT)
         return fail(LSCQP_ERR_INVALID_ARGUMENT, "warm_start must be LSCQP_WARM_DEFAULT or LSCQP_WARM_TIGHT");
     // (the build-time knobs LSCQP_WARM_MU0 / LSCQP_WARM_S0 of the kernel header are the default mode's values)
@@ -377,6 +399,60 @@ extern "C" uint64_t lscqp_handle_generation_(lscqp_handle h) { return h->generat
 // (library-internal, lscqp_comm.hip) does a batch of this shape have a second chance on the instance with the other elimination order?
 extern "C" int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max);
 
+// (re)build the host copy of the active-set tables after derive(); the device copies are refreshed lazily by das_device_table
+static void das_refresh(lscqp_solver* s) {
+    if (!s->das) return;
+    std::lock_guard<std::mutex> lk(s->das->mu);
+    const size_t nd = lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, nullptr);
+    s->das->host.assign(nd, 0.0);
+    if (s->desc.control_input_weight > 0 && s->desc.terminal_weight >= 0 &&
+        lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, s->das->host.data()) == nd) {
+        // ok
+    } else {
+        s->das->host.clear();  // (a class whose reduced Hessian is not positive definite has no active-set phase)
+    }
+    s->das->gen++;
+    // devices that already hold a copy are refreshed NOW (create / update are host synchronisation points; a later launch may sit inside a
+    // stream capture, where nothing can be copied -- it would silently run without the phase and differ in the last bits from the eager run)
+    DasTables& D = *s->das;
+    for (int d = 0; d < 64; d++) {
+        if (!D.dev[d]) continue;
+        if (D.host.empty() || D.dev_n[d] != D.host.size()) {
+            D.garbage.push_back(D.dev[d]);
+            D.dev[d] = nullptr;
+            continue;
+        }
+        if (hipMemcpy(D.dev[d], D.host.data(), sizeof(double) * D.host.size(), hipMemcpyHostToDevice) == hipSuccess) D.dev_gen[d] = D.gen;
+    }
+}
+// the tables on the CURRENT device; nullptr: not available right now (no tables, allocation failed, or the first use on this device falls
+// inside a stream capture, where hipMalloc / hipMemcpy are not allowed) -- the launch then runs without the phase
+static const double* das_device_table(lscqp_solver* s, hipStream_t stream) {
+    if (!s->das) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(s->das->mu);
+    DasTables& D = *s->das;
+    if (D.host.empty()) return nullptr;
+    if (D.dev[dev] && D.dev_gen[dev] == D.gen) return D.dev[dev];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
+    if (D.dev[dev] && D.dev_n[dev] != D.host.size()) {
+        D.garbage.push_back(D.dev[dev]);
+        D.dev[dev] = nullptr;
+    }
+    if (!D.dev[dev]) {
+        if (hipMalloc(&D.dev[dev], sizeof(double) * D.host.size()) != hipSuccess) {
+            D.dev[dev] = nullptr;
+            return nullptr;
+        }
+        D.dev_n[dev] = D.host.size();
+    }
+    if (hipMemcpy(D.dev[dev], D.host.data(), sizeof(double) * D.host.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    D.dev_gen[dev] = D.gen;
+    return D.dev[dev];
+}
+
 static inline size_t row_bytes(lscqp_handle h) { return h->dev.rows_f32 ? sizeof(lscqp_row_f32) : sizeof(lscqp_row); }
 
 extern "C" {
@@ -390,6 +466,12 @@ int lscqp_create(const lscqp_class_desc* desc, lscqp_handle* out) {
         return rc;
     }
     s->pool = new lscqp::StagePool();
+    s->das = new DasTables();
+    das_refresh(s);
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) (void)das_device_table(s, nullptr);  // (a host without a device still creates handles: lscqp_dump_instance)
+    }
     *out = s;
     return LSCQP_OK;
 }
@@ -400,13 +482,24 @@ int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
     int rc = derive(&tmp, desc);
     if (rc != LSCQP_OK) return rc;
     tmp.generation = h->generation + 1;
-    *h = tmp;  // (the staging pool pointer travels with the copy)
+    *h = tmp;  // (the staging pool pointer and the active-set tables travel with the copy)
+    das_refresh(h);
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) (void)das_device_table(h, nullptr);
+    }
     return LSCQP_OK;
 }
 
 int lscqp_destroy(lscqp_handle h) {
     if (!h) return LSCQP_OK;
     delete h->pool;
+    if (h->das) {
+        for (int d = 0; d < 64; d++)
+            if (h->das->dev[d]) (void)hipFree(h->das->dev[d]);
+        for (void* g : h->das->garbage) (void)hipFree(g);
+        delete h->das;
+    }
     delete h;
     return LSCQP_OK;
 }
@@ -863,6 +956,47 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
     const bool queued = !no_queue && n > (int64_t)cu_count();
     auto with_queue = [&](lscqp::DevClass& c) { c.queue = queued ? next_queue_counter((hipStream_t)stream) : nullptr; };
     hipError_t e = hipSuccess;
+    // ---- the DUAL ACTIVE SET phase (lscqp_das.hip) in front of the first interior-point pass ----------------------------------------
+    // One launch over the batch; what it finishes is OPTIMAL (LSCQP_INFO_ACTIVE_SET), everything else is marked for the interior-point
+    // kernel, whose first pass then runs with cls.repair = 3 (skip what is OPTIMAL, nothing was "repaired").  Launch shape: a batch that
+    // leaves the chip idle gets four wavefronts per QP, the whole budget of active rows and the class's table in LDS (latency); a batch
+    // that fills it gets one wavefront per QP and a small LDS footprint (occupancy is what hides the row reads), and the few instances
+    // with more active rows than that fall to the interior-point kernel.
+    bool das_ran = false;
+    if (retry >= 0 && h->desc.active_set != LSCQP_ACTIVE_SET_OFF) {
+        static const bool das_env_off = [] { const char* v = getenv("LSCQP_ACTIVE_SET"); return v && v[0] == '0'; }();
+        const char* dyn = getenv("LSCQP_ACTIVE_SET_NOW");  // (tests / A-B inside one process: read at every launch like the other knobs)
+        const bool off = (dyn ? dyn[0] == '0' : das_env_off) && h->desc.active_set != LSCQP_ACTIVE_SET_ONLY;
+        const double* d_tab = off ? nullptr : das_device_table(h, (hipStream_t)stream);
+        int cap = 0;
+        if (!inst || !inst64) cap = (mixed || n_obs_max > lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) ? -1 : n_obs_max;
+        else cap = std::min(inst->max_obs, inst64->max_obs);
+        if (d_tab && cap >= 0) {
+            const bool small = n <= 2 * (int64_t)cu_count();
+            auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+            int threads = env_int("LSCQP_DAS_THREADS", small ? 256 : 64);
+            int kmax = env_int("LSCQP_DAS_KMAX", small ? 32 : 8);
+            int steps = env_int("LSCQP_DAS_STEPS", small ? 96 : 24);
+            int cacheC = env_int("LSCQP_DAS_CACHE", small ? 1 : 0);
+            int stage = env_int("LSCQP_DAS_STAGE", small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
+            const int Mx = h->desc.M, dx = h->desc.dim;
+            // what does not fit the CU's LDS is given up in this order: staged rows, the table copy, active rows
+            if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) stage = 0;
+            if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) cacheC = 0;
+            while (kmax > 4 && lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) kmax -= 4;
+            if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) <= lscqp::kMaxLdsBytes) {
+                e = lscqp_launch_das(&cls, Mx, dx, h->es, cap, threads, kmax, steps, cacheC, stage, d_tab, n, d_hdr, d_rows, d_row_offsets, d_sfc,
+                                     d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
+                if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (dual active-set phase): ") + hipGetErrorString(e));
+                das_ran = true;
+            }
+        }
+        if (h->desc.active_set == LSCQP_ACTIVE_SET_ONLY) {
+            if (!das_ran) return fail(LSCQP_ERR_UNSUPPORTED, "LSCQP_ACTIVE_SET_ONLY: the active-set phase could not run (no tables on this device, or capacity)");
+            return LSCQP_OK;
+        }
+    }
+    const int first_repair = das_ran ? 3 : 0;
     if (!inst || !inst64) {
         // no compiled instance serves this launch (shape without one, or more obstacles than its register slots hold): the
         // run-time-shaped kernel, fp64.  Same statuses, same second pass.
@@ -880,6 +1014,7 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
             if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (rescue pass): ") + hipGetErrorString(e));
             return LSCQP_OK;
         }
+        cls.repair = first_repair;
         e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
                                  d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (run-time-shaped kernel): ") + hipGetErrorString(e));
@@ -919,6 +1054,7 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (other-order pass): ") + hipGetErrorString(e));
         return LSCQP_OK;
     }
+    cls.repair = first_repair;
     with_queue(cls);
     e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));

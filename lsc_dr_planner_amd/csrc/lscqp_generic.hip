@@ -146,8 +146,10 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
         const int st0 = status_out[q];
         if (st0 == LSCQP_STATUS_OPTIMAL || st0 == LSCQP_STATUS_CAPACITY) return;
         if (rescue && st0 != LSCQP_STATUS_ITER_LIMIT && st0 != LSCQP_STATUS_NUMERIC) return;
-        flags |= LSCQP_INFO_REPAIRED | (rescue ? LSCQP_INFO_RESCUED : 0);
-        if (info_out) it_before = info_out[q].iterations;
+        if (cls.repair != 3) {  // (3: the FIRST interior-point pass, behind the dual active-set phase of lscqp_das.hip)
+            flags |= LSCQP_INFO_REPAIRED | (rescue ? LSCQP_INFO_RESCUED : 0);
+            if (info_out) it_before = info_out[q].iterations;
+        }
     }
     const int n_obs = Hd->n_obs;
     if (n_obs > cls.n_obs_max) {  // refused, never truncated (see lscqp_kernel.hpp): the launch sized the row state for n_obs_max

@@ -46,6 +46,7 @@ struct DevClass {
     int rows_f32;   // lscqp_class_desc.row_format == LSCQP_ROWS_F32
     int rsfc;       // LSCQP_PLANNER_RSFC: z bounds of segment 0 are +-100, not the world box (src/traj_optimizer.cpp:255-258)
     int repair;     // second pass over a batch: only instances whose status_out is neither OPTIMAL nor CAPACITY are solved
+                    // (3: the first interior-point pass behind the dual active-set phase: same skip, no REPAIRED flag)
     double warm_mu0, warm_s0;  // centring of an instance that comes with an initial trajectory (lscqp_class_desc.warm_start)
     double warm_net;           // > 0: first-step length below which such an instance returns to the (1e-3, 0.03) centring
     // Work distribution of a launch (round 4).  order: the k-th workgroup-slot of the launch solves instance order[k] (NULL: k) -- a
@@ -505,6 +506,10 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
     // global memory they were a string of dependent scalar / vector loads: 9.6 k + 11.9 k cycles of a 4096-QP launch's prologue per QP
     // (header + control points, two-sided row set-up; tools/phase_timing.py) against 3.5 k + 5.2 k now.  `H` below points into LDS.
     double* const org_ = goal_ + 4;
+    if (cls.repair) {  // (uniform) what an earlier pass -- or the dual active-set phase in front of this kernel -- finished is skipped before anything is fetched
+        const int st_early = status_out[q];
+        if (st_early == LSCQP_STATUS_OPTIMAL || st_early == LSCQP_STATUS_CAPACITY) return;
+    }
     {
         const double* hsrc = reinterpret_cast<const double*>(hdr + q);
         const double* ssrc = reinterpret_cast<const double*>(sfc) + q * 6 * M;
@@ -518,8 +523,10 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
     if (cls.repair) {        // uniform over the workgroup
         const int st0 = status_out[q];
         if (st0 == LSCQP_STATUS_OPTIMAL || st0 == LSCQP_STATUS_CAPACITY) return;
-        flags |= LSCQP_INFO_REPAIRED;
-        if (info_out) it_before = info_out[q].iterations;
+        if (cls.repair != 3) {  // (3: the FIRST interior-point pass, behind the dual active-set phase of lscqp_das.hip -- nothing was repaired)
+            flags |= LSCQP_INFO_REPAIRED;
+            if (info_out) it_before = info_out[q].iterations;
+        }
     }
     // An instance with more obstacles than this kernel instance has row slots for is REFUSED, never truncated: dropping LSC
     // rows silently would void the collision-avoidance guarantee the rows exist for (reference: every obstacle gets its rows,

@@ -33,6 +33,7 @@ def _bench_batch(api, key):
     return sw, sol, b, hdr, rows, off, sfc, M, dim
 
 
+@pytest.mark.pdip_only
 @pytest.mark.gpu
 @pytest.mark.parametrize("key", ["c3", "c4_f64", "c2"])
 def test_every_floor_accepted_instance_meets_the_bar_on_the_reference_model(api, oracle, torch_cuda, key):

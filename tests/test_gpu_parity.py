@@ -300,6 +300,7 @@ def _compiled_instances():
     return [i[:5] for i in inst if i[5] == 0]  # (the mixed-precision instances have their own tests)
 
 
+@pytest.mark.pdip_only
 @pytest.mark.parametrize("M,dim,es,nslot,waves", _compiled_instances())
 def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_cuda, request, M, dim, es, nslot, waves):
     """Every kernel instance, at its full obstacle capacity: bitwise repeatable and equal to the oracle.
@@ -333,6 +334,7 @@ def test_every_compiled_instance_is_deterministic_and_exact(api, oracle, torch_c
         sw.advance(runs[0]["x"])
 
 
+@pytest.mark.pdip_only
 @pytest.mark.parametrize("N,M,dim,n_obs,style,seed", [(48, 5, 3, 20, "forest", 21), (16, 10, 2, 9, "forest", 22), (24, 10, 3, 40, "forest", 23)])
 def test_initial_trajectory_as_primal_start(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed):
     """x_init (TrajOptimizer::solve's initial_traj, the shifted previous plan) only moves the starting point of the
@@ -361,6 +363,7 @@ def test_initial_trajectory_as_primal_start(api, oracle, torch_cuda, N, M, dim, 
     assert it_warm <= it_cold
 
 
+@pytest.mark.pdip_only
 def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_cuda):
     """An instance from the 64-agent closed loop (tests/golden/warm_start_jam.json) whose iteration, started from the shifted
     previous plan, stalls with the gap near 6e-7 unless the row state is re-centred: both entry points return the optimum (the
@@ -409,6 +412,7 @@ def test_jammed_warm_start_is_solved_from_the_default_start(api, oracle, torch_c
     assert d_st.item() == 0 and abs(d_obj.item() - o["obj"]) <= OBJ_TOL * max(1.0, abs(o["obj"]))
 
 
+@pytest.mark.pdip_only
 def test_limit_cycle_of_the_iteration_is_ended_by_the_rescue_pass(api, oracle, torch_cuda):
     """tests/golden/limit_cycle_dlsc.json: a DLSC instance (M = 10, 3-D, 23 neighbours) on which the predictor-corrector iteration runs
     into a limit cycle from the default start -- period four, gap 6e-6 .. 6e-5, the re-centring does not break it -- and ends at the
@@ -465,6 +469,7 @@ def test_limit_cycle_of_the_iteration_is_ended_by_the_rescue_pass(api, oracle, t
     assert G2["status"][0] == api.STATUS_INFEASIBLE and not (G2["info"]["flags"][0] & api.INFO_RESCUED)
 
 
+@pytest.mark.pdip_only
 def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(api, oracle, torch_cuda):
     """tests/golden/pivot_breakdown_w2.json: an M = 6 dense-maze instance whose factorisation breaks down after the acceptance tests
     were met at the rounding floor.  In the two-wavefront instance only wavefront 0 holds the system and sees the failed pivot;
@@ -716,6 +721,7 @@ def test_every_row_family_binds_somewhere_along_the_horizon(api, oracle, torch_c
     assert ran >= 2
 
 
+@pytest.mark.pdip_only
 def test_breakdown_under_one_elimination_order_is_repaired_on_the_other(api, oracle, torch_cuda):
     """tests/golden/nd_breakdown_m10d2.json (tools/make_golden_nd_breakdown.py): a feasible M = 10, 2-D instance from the sweep far outside
     the reference's parameters on which the nested-dissection instance ends NUMERIC at iteration 11 (a pivot of the late-iteration matrix
@@ -871,6 +877,7 @@ def test_one_binding_corridor_face_per_segment_axis_and_side(api, oracle, torch_
     assert ran >= 2
 
 
+@pytest.mark.pdip_only
 def test_feasible_instance_whose_residual_pauses_around_the_tenth_iteration(api, oracle, torch_cuda):
     """tools/stress_parity.py, shape (24 x M10 x 40 neighbours, forest), seed 114, first batch from hover: instance 14 holds its primal
     residual at 5e-4 m for four iterations around the tenth and converges afterwards.  The single-check stall rule of round 1 (and a
@@ -890,6 +897,7 @@ def test_feasible_instance_whose_residual_pauses_around_the_tenth_iteration(api,
     _check_against_oracle(oracle, cls, G, R)
 
 
+@pytest.mark.pdip_only
 @pytest.mark.parametrize("N,M,dim,n_obs,style,seed", [(48, 5, 3, 20, "forest", 21), (16, 10, 2, 9, "forest", 22), (24, 10, 3, 40, "forest", 23), (32, 6, 3, 20, "maze", 24)])
 def test_tight_warm_start_mode_reaches_the_same_optimum(api, oracle, torch_cuda, N, M, dim, n_obs, style, seed):
     """lscqp_class_desc.warm_start = LSCQP_WARM_TIGHT (an option for throughput batches): every complementarity product starts at 1e-7 with
@@ -918,6 +926,7 @@ def test_tight_warm_start_mode_reaches_the_same_optimum(api, oracle, torch_cuda,
     assert M != 5 or it_tight < 0.8 * it_base, (it_tight, it_base)
 
 
+@pytest.mark.pdip_only
 @pytest.mark.gpu
 def test_work_order_and_work_queue_change_when_an_instance_is_solved_never_its_result(api, oracle, torch_cuda):
     """Round 4: a launch with more instances than the chip holds runs persistent workgroups over a queue, and the caller may name the order

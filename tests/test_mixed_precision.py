@@ -50,6 +50,7 @@ def _solve_all(api, oracle, sw, M, dim, precision, steps, check_oracle=True, x_w
     (48, 6, 3, 20, "maze", 3, 3),     # dense maze: float32 breakdowns happen, the fp64 second pass repairs them
     (10, 10, 2, 9, "forest", 2, 3),   # forest10 replica
 ])
+@pytest.mark.pdip_only
 def test_mixed_precision_matches_the_oracle(api, oracle, N, M, dim, n_obs, style, seed, steps):
     from lsc_dr_planner_amd import synth
 
@@ -57,6 +58,7 @@ def test_mixed_precision_matches_the_oracle(api, oracle, N, M, dim, n_obs, style
     _solve_all(api, oracle, sw, M, dim, api.PRECISION_MIXED, steps)
 
 
+@pytest.mark.pdip_only
 def test_configs4_full_size_4096_agents(api, oracle):
     """BASELINE configs[4] at its own size: 4096 agents x M = 5 x 20 neighbours, float32 rows AND float32 factorisation, against
     the fp64 mode on the same batch (every instance) and the oracle (a bounded sample)."""
@@ -106,6 +108,7 @@ def test_configs4_full_size_4096_agents(api, oracle):
     del torch
 
 
+@pytest.mark.pdip_only
 def test_second_pass_flags_and_iteration_accounting(api, oracle):
     """Dense-maze class in mixed precision: whatever the float32 factorisation could not finish comes back OPTIMAL from the
     fp64 second pass with LSCQP_INFO_REPAIRED set and both passes' iterations counted; untouched instances carry no flag."""
@@ -176,6 +179,7 @@ def test_capacity_is_a_status_not_a_truncation(api, oracle):
     assert e.value.code == api.ERR_UNSUPPORTED
 
 
+@pytest.mark.pdip_only
 def test_device_retry_solves_a_jammed_warm_start(api, oracle):
     """tests/golden/warm_start_jam.json through the DEVICE entry with retry and too few iterations for the warm start to finish
     (max_iter = 12: it needs 21 with the in-kernel re-centring): the second pass solves it from the default start on the

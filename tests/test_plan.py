@@ -711,6 +711,7 @@ def test_update_that_changes_the_shape_under_a_live_plan_is_refused(api, torch_c
     q.close()
 
 
+@pytest.mark.pdip_only
 @pytest.mark.gpu
 def test_large_plan_carries_its_work_order_and_graph_equals_eager(api, torch_cuda):
     """A plan of 1200 agents -- more than the chip works on at once (lscqp_launch_capacity: 1024 QPs of this class; the corridor kernel's
