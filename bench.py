@@ -48,6 +48,8 @@ def valu_roofline(sol, n, n_obs, iterations, kernel_ms):
     except Exception:  # the run-time-shaped kernel carries no instruction counts
         return None
     it = np.asarray(iterations, dtype=np.float64)
+    if it.size == 0:
+        return None
     flops = float((w["flops_fixed"] + w["flops_last_pass"] + it * w["flops_per_iteration"]).sum())
     rate = flops / (kernel_ms * 1e-3)
     # the launch lasts as long as its slowest instance: that wavefront's own issue rate (VALU instructions per second of the launch)
@@ -124,6 +126,42 @@ def percentile_latency(torch, call, max_calls=1050, max_seconds=6.0, skip=50):
             break
     lat = np.array(lat[skip:]) * 1e3
     return float(np.percentile(lat, 50)), float(np.percentile(lat, 99)), int(len(lat))
+
+
+def path_stats(api, info, status):
+    """Which of the two kernels finished how many instances of a launch (round 5: the dual active-set phase runs in front of the
+    interior-point kernel; lscqp_info.iterations counts active-set STEPS for the former and interior-point ITERATIONS for the latter)."""
+    by_as = (info["flags"] & api.INFO_ACTIVE_SET) != 0
+    ip = ~by_as & (status == 0)
+    it = info["iterations"]
+    return {"active_set_solved": int(by_as.sum()), "active_set_steps_mean": float(it[by_as].mean()) if by_as.any() else 0.0,
+            "active_set_steps_max": int(it[by_as].max()) if by_as.any() else 0,
+            "interior_point_solved": int(ip.sum()), "interior_point_iters_mean": float(it[ip].mean()) if ip.any() else 0.0,
+            "interior_point_iters_max": int(it[ip].max()) if ip.any() else 0}
+
+
+def active_set_kernel_ms(torch, api, desc_kwargs, n, n_obs, tensors, reps=20):
+    """Average duration of ONE launch of the dual active-set kernel (lscqp_das::das_kernel) on the given device-resident batch: the phase
+    alone (LSCQP_ACTIVE_SET_ONLY), `reps` launches back to back between two HIP events on the launch stream.  None if the phase is off."""
+    if os.environ.get("LSCQP_ACTIVE_SET", "1")[:1] == "0" or os.environ.get("LSCQP_ACTIVE_SET_NOW", "1")[:1] == "0":
+        return None
+    sol = api.Solver(api.make_desc(active_set=api.ACTIVE_SET_ONLY, **desc_kwargs))
+    dh, dr, do, ds, dxi = tensors
+    dx = torch.zeros(n * sol.nv, dtype=torch.float64, device=dh.device)
+    dob = torch.zeros(n, dtype=torch.float64, device=dh.device)
+    dst = torch.zeros(n, dtype=torch.int32, device=dh.device)
+    dinfo = torch.zeros(n * 32, dtype=torch.uint8, device=dh.device)
+    for _ in range(3):
+        sol.solve_device(n, n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        sol.solve_device(n, n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi)
+    e1.record()
+    torch.cuda.synchronize()
+    sol.close()
+    return e0.elapsed_time(e1) / reps
 
 
 def oracle_sample(O, sw, build, M, dim, n_obs_eff, sample, threads=4):
@@ -257,8 +295,11 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
                           "a perfect hint)") if d_order[0] is not None else "as given (the launch starts every instance at once)",
            "kernel_ms_as_given": ms_as_given, "qp_per_s_as_given": N / (ms_as_given * 1e-3),
            "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
-           "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()),
-           "roofline_valu": valu_roofline(sol, N, sw.n_obs, info["iterations"], ms) if cfg["precision"] == "f64" else None,
+           "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()), "paths": path_stats(api, info, st),
+           "active_set_kernel_ms": active_set_kernel_ms(torch, api, dict(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max,
+                                                                       **{k_: v_ for k_, v_ in kw.items() if k_ == "row_format"}), N, sw.n_obs, (dh, dr, do, ds, dxi)),
+           "roofline_valu": (valu_roofline(sol, N, sw.n_obs, info["iterations"][((info["flags"] & api.INFO_ACTIVE_SET) == 0) & (st == 0)], ms)
+                             if cfg["precision"] == "f64" else None),
            "non_optimal": int((st != 0).sum()), "second_pass": int(((info["flags"] & api.INFO_REPAIRED) != 0).sum()),
            "floor_accepted": int(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum())}
     if O is not None:
@@ -733,6 +774,15 @@ def timed_workload(ctx, a):
     status = d_st.cpu().numpy()
     info = d_info.cpu().numpy().view(api.INFO_DTYPE)
     iters = info["iterations"]
+    paths = path_stats(api, info, status)  # (this rank's block)
+    paths = {k: (ctx.reduce([float(v)], "max" if k.endswith("_max") else "sum")[0]) for k, v in paths.items()}
+    for k in ("active_set_steps_mean", "interior_point_iters_mean"):  # (sums of per-rank means -> mean over ranks: blocks are equal up to one agent)
+        paths[k] = paths[k] / max(ctx.world, 1)
+    das_ms = active_set_kernel_ms(torch, api, dict(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max,
+                                                   **{k_: v_ for k_, v_ in solver_kw.items() if k_ == "row_format"}), N, n_obs_eff,
+                                  (d_hdr, d_rows, d_off, d_sfc, d_xinit))
+    if das_ms is not None:
+        das_ms, = ctx.reduce([das_ms], "max")
     n_bad = int(ctx.reduce([float((status != 0).sum())], "sum")[0])
     n_floor = int(ctx.reduce([float(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum())], "sum")[0])
     it_sum, = ctx.reduce([float(iters.sum())], "sum")
@@ -813,7 +863,7 @@ def timed_workload(ctx, a):
                            d_obj=d_obj, d_st=d_st, d_info=d_info, d_all=d_all, elapsed=elapsed, kernel_ms=kernel_ms, status=status, iters=iters,
                            n_bad=n_bad, n_floor=n_floor, iters_mean=it_sum / max(n_agents_seen, 1), iters_max=int(it_max), n_ranks_seen=n_ranks_seen,
                            n_devices_seen=n_devices_seen, n_agents_seen=n_agents_seen, rank_parity=rank_parity, step_lat=step_lat, one_gpu=one_gpu,
-                           solve_only=solve_only, ordered=d_order[0] is not None)
+                           solve_only=solve_only, ordered=d_order[0] is not None, paths=paths, das_ms=das_ms)
 
 
 def check_ran_as_asked(ctx, a, S):
@@ -828,7 +878,7 @@ def workload_config(ctx, a, S):
     gathered = S.d_all is not None
     c = {
         "workload": "%s -- %s x M=%d segments x %d LSC neighbours (dim=%d, %s swarm after 3 warm-up replans), "
-                    "%s batched PDIP, one workgroup per QP (two wavefronts when the batch leaves SIMDs idle, else one)" % (
+                    "%s: dual active-set phase (one workgroup per QP) with the batched PDIP behind it for what it leaves" % (
                         cfg0["what"] if (a.agents, S.M, a.obs, S.dim) == (cfg0["agents"], cfg0["segments"], cfg0["obs"], cfg0["dim"]) else "custom shape",
                         ("ONE batch of %d agents cut into blocks of <= %d per GPU" % (S.n_glob, S.n_pad)) if S.strong else ("%d agents/GPU" % S.N),
                         S.M, S.n_obs_eff, S.dim, a.style, "fp64" if a.precision == "f64" else "mixed-precision"),
@@ -855,10 +905,20 @@ def workload_config(ctx, a, S):
 
 
 def workload_roofline(ctx, a, S):
+    """The dominant kernel of the step.  Round 5: the dual active-set kernel (lscqp_das::das_kernel) finishes most -- on BASELINE's batches
+    all -- instances and is where the step's time goes; `kernel_ms` is ITS average launch duration (the phase alone, 20 launches back to
+    back between HIP events on the launch stream), `step_gpu_ms` the whole solve call's (phase + the interior-point pass behind it,
+    events around the timed steps).  With the phase switched off (LSCQP_ACTIVE_SET=0) the kernel is the interior-point instance, as in
+    rounds 1-4."""
     bq = S.sol.algorithmic_bytes(S.n_obs_eff)
-    achieved = bq * S.N / (S.kernel_ms * 1e-3)
+    pd = "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (S.M, S.dim, "float" if a.precision == "mixed" else "double")
+    if S.das_ms is not None and S.paths["active_set_solved"] >= 0.5 * S.n_agents_seen:
+        kms, kname = S.das_ms, "lscqp_das::das_kernel<%d,%s>" % (4 if S.N <= 512 else 1, "true" if a.rows == "f32" else "false")
+    else:
+        kms, kname = S.kernel_ms, pd
+    achieved = bq * S.N / (kms * 1e-3)
     return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
-            "kernel": "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (S.M, S.dim, "float" if a.precision == "mixed" else "double"), "kernel_ms": S.kernel_ms,
+            "kernel": kname, "kernel_ms": kms, "step_gpu_ms": S.kernel_ms, "behind_it": pd,
             "algorithmic_bytes_per_qp": bq, "qps_per_launch": S.N}
 
 
@@ -871,7 +931,8 @@ def compact_block(ctx, a, S):
            "steps": a.steps, "warmup": a.warmup, "agents_total": S.n_glob, "agents_per_gpu": S.n_pad, "allgather": c["allgather"],
            "collective_backend": ctx.coll_backend, "distinct_devices": S.n_devices_seen, "workload": c["workload"],
            "hbm_frac_whole_job": r["algorithmic_bytes_per_qp"] * S.n_glob * a.steps / S.elapsed / (ctx.world * HBM_PEAK),
-           "kernel_ms": S.kernel_ms, "non_optimal": S.n_bad, "floor_accepted": S.n_floor, "iters_mean": S.iters_mean, "iters_max": S.iters_max}
+           "kernel_ms": S.kernel_ms, "active_set_kernel_ms": S.das_ms, "non_optimal": S.n_bad, "floor_accepted": S.n_floor, "iters_mean": S.iters_mean,
+           "iters_max": S.iters_max, "paths": S.paths}
     for k in ("allgather_bytes_per_rank_per_step", "devices_by_crossover_rule", "one_gpu_same_workload"):
         if k in c:
             out[k] = c[k]
@@ -1065,8 +1126,9 @@ def main():
         pm = json.load(open(pf)) if pf else {}
         kname = (pm.get("kernel") or "").replace(" ", "")
         want_t = "float" if args.precision == "mixed" else "double"
-        if (pm.get("qps_per_launch") == N and ("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) in kname and want_t in kname
-                and pm.get("lsc_neighbours") == n_obs_eff):
+        is_das = "das_kernel" in kname and "das_kernel" in roof["kernel"] and pm.get("segments", M) == M and pm.get("dim", dim) == dim
+        is_pdip = ("lscqp_pdip_kernel<%d,%d,true" % (M, dim)) in kname and want_t in kname and "pdip" in roof["kernel"]
+        if pm.get("qps_per_launch") == N and (is_das or is_pdip) and pm.get("lsc_neighbours") == n_obs_eff:
             traffic = pm["traffic_bytes_per_launch"]
             traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)" % os.path.basename(pf)
             sq = pm.get("sq") or {}
@@ -1081,7 +1143,9 @@ def main():
     except Exception:
         pass
     roof.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "valu": valu})
-    rv = valu_roofline(sol, N, n_obs_eff, iters, kernel_ms) if args.precision == "f64" else None
+    info_h = d_info.cpu().numpy().view(api.INFO_DTYPE)
+    rv = (valu_roofline(sol, N, n_obs_eff, iters[((info_h["flags"] & api.INFO_ACTIVE_SET) == 0) & (status == 0)], kernel_ms)
+          if args.precision == "f64" else None)
     if rv:  # the roof that binds, inside the object the driver keeps (the full record is `roofline_valu` below)
         roof["fp64_valu"] = {"achieved_TFLOPs": rv["fp64_flops_per_s"] / 1e12, "peak_TFLOPs": FP64_VECTOR_PEAK / 1e12, "frac": rv["frac_of_78.6e12"],
                              "flops_per_launch": rv["fp64_flops_per_launch"], "what": "fp64 vector flops of this launch (iterations of this run x "
@@ -1116,7 +1180,9 @@ def main():
         "roofline": roof,
         "roofline_valu": rv,
         "latency_ms": latency,
-        "solver": {"non_optimal": S.n_bad, "floor_accepted": S.n_floor, "iters_mean": S.iters_mean, "iters_max": S.iters_max},
+        "solver": {"non_optimal": S.n_bad, "floor_accepted": S.n_floor, "iters_mean": S.iters_mean, "iters_max": S.iters_max, "paths": S.paths,
+                   "what": "iters_*: lscqp_info.iterations over the batch = active-set steps for instances the dual active-set phase finished "
+                           "(LSCQP_INFO_ACTIVE_SET), interior-point iterations for the others; `paths` tells them apart"},
     }
     if world > 1:
         out["roofline"]["whole_job"] = {"achieved": roof["algorithmic_bytes_per_qp"] * out["value"] / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",

@@ -956,6 +956,7 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
     const bool queued = !no_queue && n > (int64_t)cu_count();
     auto with_queue = [&](lscqp::DevClass& c) { c.queue = queued ? next_queue_counter((hipStream_t)stream) : nullptr; };
     hipError_t e = hipSuccess;
+    if (retry < 0 && h->desc.active_set == LSCQP_ACTIVE_SET_ONLY) return LSCQP_OK;  // (the host-pointer entries' extra passes are interior-point passes)
     // ---- the DUAL ACTIVE SET phase (lscqp_das.hip) in front of the first interior-point pass ----------------------------------------
     // One launch over the batch; what it finishes is OPTIMAL (LSCQP_INFO_ACTIVE_SET), everything else is marked for the interior-point
     // kernel, whose first pass then runs with cls.repair = 3 (skip what is OPTIMAL, nothing was "repaired").  Launch shape: a batch that

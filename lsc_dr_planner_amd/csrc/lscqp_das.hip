@@ -53,26 +53,31 @@ constexpr int kMaxK = 32;           // active rows the phase can hold (lanes of 
 
 // ---- tables, per number of terminal segments ts = 1 .. M:  [U1 (P) | U2 (P) | G1 (P) | C (P x P, symmetric)] --------------------------
 __host__ __device__ inline size_t table_stride(int M) { return (size_t)(3 + 6 * M) * (size_t)(6 * M); }
+__host__ __device__ inline int num_pairs(int M, int dim) { return dim * (6 * M + 5 * M + 4 * M + M * (M - 1) / 2); }
 
-struct Layout {  // LDS carve of one QP, in doubles
-    int P, NX, kmax;
-    int o_hdr, o_sfc, o_c, o_cu, o_dc, o_wp, o_lo, o_hi, o_g, o_W, o_L, o_u, o_r, o_v, o_y, o_linv, o_arhs, o_acoef, o_red, o_sc, o_C, o_int, o_rows, n_stage, total;
+// LDS carve of one QP, in doubles.
+struct Layout {
+    int P, NX, kmax, NPAIR;
+    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_pix, o_W, o_S, o_L, o_u, o_r, o_v, o_y, o_linv, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_C, o_rows, n_stage, total;
     __host__ __device__ static Layout make(int M, int dim, int kmax, int cacheC, int stage_rows = 0) {
         Layout s;
-        s.P = 6 * M, s.NX = dim * s.P, s.kmax = kmax;
+        s.P = 6 * M, s.NX = dim * s.P, s.kmax = kmax, s.NPAIR = num_pairs(M, dim);
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
         s.o_hdr = take(32);
         s.o_sfc = take(6 * M);
-        s.o_c = take(s.NX), s.o_cu = take(s.NX), s.o_dc = take(s.NX), s.o_wp = take(s.NX), s.o_lo = take(s.NX), s.o_hi = take(s.NX), s.o_g = take(3 * s.NX);
-        s.o_W = take(kmax * s.NX);
+        s.o_c = take(3 * s.P), s.o_cu = take(s.NX), s.o_lam = take(s.NX);  // (c_: a third, zero axis in 2-D: row evaluation without a branch on dim)
+        s.o_plo = take(s.NPAIR), s.o_phi = take(s.NPAIR), s.o_pix = take((s.NPAIR + 1) / 2);  // two-sided rows: bounds, packed stencil
+        s.o_W = take((kmax + 1) * s.NX);      // w_j = C a_j of the active rows; slot k (the next free one) holds the candidate's
+        s.o_S = take(kmax * (kmax + 1));      // the Gram matrix S = A'C A itself (its factor is rebuilt from it when a row leaves)
         s.o_L = take(kmax * (kmax + 1));
-        s.o_u = take(kmax), s.o_r = take(kmax), s.o_v = take(kmax), s.o_y = take(kmax), s.o_linv = take(kmax), s.o_arhs = take(kmax + 1);
+        s.o_u = take(kmax + 1), s.o_r = take(kmax + 1), s.o_v = take(kmax + 1), s.o_y = take(kmax + 1), s.o_linv = take(kmax + 1), s.o_arhs = take(kmax + 1);
         s.o_acoef = take(3 * (kmax + 1));
-        s.o_red = take(32);
-        s.o_sc = take(16);  // org[3], goal[3], vmax dt/n [3], amax dt^2/(n(n-1)) [3]
+        s.o_aint = take(2 * (kmax + 1) + 2);  // ints: per active row {id, entry0, entry1, entry2} (+ the candidate); entry = axis << 16 | control point
+        s.o_red = take(2 * 16);               // cross-wavefront reductions, double buffered
+        s.o_ctl = take(8);
+        s.o_wb = take(8);  // world box of the class (a kernel argument indexed with a run-time axis would be fetched through vector memory)
         s.o_C = take(cacheC ? s.P * s.P : 0);
-        s.o_int = take(4 * (kmax + 1) + 16);  // ints: per active row {id, idx0, idx1, idx2} (+ the candidate), control words
         s.n_stage = stage_rows;  // LSC rows of the instance kept in LDS after the first pass (SoA nx | ny | nz | b), 0: re-read from L2
         s.o_rows = take(4 * stage_rows);
         s.total = o;
@@ -80,8 +85,7 @@ struct Layout {  // LDS carve of one QP, in doubles
     }
 };
 
-// Wave reductions on the DPP network (lscqp_kernel.hpp: four row_shr steps, two row broadcasts, one v_readlane pair -- ~150 cycles per
-// value against ~600 for a ds_bpermute butterfly on fp64).
+// Wave reductions on the DPP network (lscqp_kernel.hpp: ~150 cycles per fp64 value against ~600 for a ds_bpermute butterfly).
 __device__ __forceinline__ double wave_max(double v) { return lscqp::wave_max(v); }
 __device__ __forceinline__ double wave_min(double v) { return -lscqp::wave_max(-v); }
 __device__ __forceinline__ double wave_sum(double v) { return lscqp::wave_sum(v); }
@@ -95,13 +99,19 @@ __device__ __forceinline__ void wave_argmin(double& v, int& id) {  // lexicograp
 // integer division by a run-time value costs ~40
 __device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a + 0.5f) * inv_b); }
 
-// LDS hand-overs between the lanes of ONE wavefront (the small factor): LDS operations of a wavefront execute in order, the fence keeps
-// the compiler from moving them across
+// LDS hand-overs.  Inside ONE wavefront: its LDS operations execute in order, the fences keep the compiler from moving them.  Across the
+// workgroup: s_barrier behind a wait on the LDS counter only -- a __syncthreads() would also wait for every global load in flight, and the
+// rows of the first pass are meant to stay in flight across the barriers of the prologue.
 #define LSCQP_DAS_WAVE_SYNC()                                   \
     do {                                                        \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
         __builtin_amdgcn_wave_barrier();                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+#define LSCQP_DAS_BARRIER()                                                           \
+    do {                                                                              \
+        if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
     } while (0)
 
 // Development aid: per-phase cycle totals, compiled in only with -DLSCQP_DAS_TIMING (tools/das_timing.py)
@@ -119,39 +129,71 @@ __device__ unsigned long long das_cycles[16];
     } while (0)
 #endif
 
-// One row of the model as (<= 3 control-point entries, right-hand side): a'c >= h.
+// One row of the model as (<= 3 entries, right-hand side): a'c >= h.  An entry names (axis, control point) as axis << 16 | cp.
 struct Row {
-    int idx[3];
+    int ent[3];
     double coef[3];
     double rhs;
 };
+__device__ __forceinline__ int ent_axis(int e) { return e >> 16; }
+__device__ __forceinline__ int ent_cp(int e) { return e & 0xffff; }
 
-__global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, int es, int cap, int kmax, int max_steps, int cacheC, int stage_rows,
-                                                  const double* __restrict__ tab, int64_t n, const lscqp_header* __restrict__ hdr,
-                                                  const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
-                                                  const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init, double* __restrict__ x_out,
-                                                  double* __restrict__ obj_out, int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out) {
+// a' C b for two rows: C couples control points of the same axis only
+__device__ __forceinline__ double cdot(const int* ea, const double* ca, const int* eb, const double* cb, const double* __restrict__ Cm, int P) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (ca[i] != 0.0 && cb[j] != 0.0 && ent_axis(ea[i]) == ent_axis(eb[j])) s += ca[i] * cb[j] * Cm[(size_t)ent_cp(ea[i]) * P + ent_cp(eb[j])];
+        }
+    }
+    return s;
+}
+// (C a)[axis kx, control point cp]
+__device__ __forceinline__ double ccol(const int* ea, const double* ca, int kx, int cp, const double* __restrict__ Cm, int P) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        if (ca[i] != 0.0 && ent_axis(ea[i]) == kx) s += ca[i] * Cm[(size_t)ent_cp(ea[i]) * P + cp];
+    return s;
+}
+
+#ifndef LSCQP_DAS_KU1
+#define LSCQP_DAS_KU1 2
+#endif
+#ifndef LSCQP_DAS_WPE1
+#define LSCQP_DAS_WPE1 3
+#endif
+template <int NW, bool F32>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_kernel(DevClass cls, int M, int dim, int es, int cap, int kmax, int max_steps, int cacheC, int stage_rows,
+                                                      const double* __restrict__ tab, int64_t n, const lscqp_header* __restrict__ hdr,
+                                                      const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
+                                                      const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init, double* __restrict__ x_out,
+                                                      double* __restrict__ obj_out, int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int T = 64 * NW;
+    constexpr int kU = (NW == 1) ? LSCQP_DAS_KU1 : 4;  // LSC rows in flight per thread (the one-wavefront form trades them for a third / fourth wavefront per SIMD)
     const int64_t k0 = blockIdx.x;
     if (k0 >= n) return;
     const int64_t q = cls.order ? (int64_t)cls.order[k0] : k0;
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wv = tid >> 6, NW = T >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef LSCQP_DAS_TIMING
     unsigned long long tprev_ = __builtin_readcyclecounter();
 #endif
     const Layout L = Layout::make(M, dim, kmax, cacheC, stage_rows);
-    const int P = L.P, NX = L.NX;
+    const int P = L.P, NX = L.NX, NPAIR = L.NPAIR;
     double* const H_ = smem + L.o_hdr;
     double* const sfc_ = smem + L.o_sfc;
     double* const c_ = smem + L.o_c;
     double* const cu_ = smem + L.o_cu;
-    double* const dc_ = smem + L.o_dc;
-    double* const wp_ = smem + L.o_wp;
-    double* const lo_ = smem + L.o_lo;
-    double* const hi_ = smem + L.o_hi;
-    double* const g_ = smem + L.o_g;
-    double* const W_ = smem + L.o_W;
-    double* const Lm_ = smem + L.o_L;  // [kmax][kmax + 1] lower Cholesky factor of S = A'W
+    double* const lam_ = smem + L.o_lam;
+    double* const plo_ = smem + L.o_plo;
+    double* const phi_ = smem + L.o_phi;
+    int* const pix_ = reinterpret_cast<int*>(smem + L.o_pix);  // packed stencil of a two-sided row: type << 24 | first entry index (in 0 .. NX-1) << 12 | second
+    double* const W_ = smem + L.o_W;   // [kmax + 1][NX]
+    double* const Sm_ = smem + L.o_S;  // [kmax][kmax + 1] S = A'C A (lower triangle used)
+    double* const Lm_ = smem + L.o_L;  // [kmax][kmax + 1] lower Cholesky factor of S
     double* const u_ = smem + L.o_u;
     double* const r_ = smem + L.o_r;
     double* const v_ = smem + L.o_v;
@@ -159,15 +201,17 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
     double* const linv_ = smem + L.o_linv;
     double* const arhs_ = smem + L.o_arhs;    // [kmax + 1]: slot kmax = the candidate row
     double* const acoef_ = smem + L.o_acoef;  // [kmax + 1][3]
-    double* const red_ = smem + L.o_red;
+    int* const aint_ = reinterpret_cast<int*>(smem + L.o_aint);  // [kmax + 1][4]: id, entry0, entry1, entry2
+    double* const red_ = smem + L.o_red;      // [2][16]
+    double* const ctl_ = smem + L.o_ctl;      // step decision of wavefront 0: t, kind, leaving row, accumulated multiplier of the candidate
+    double* const wb_ = smem + L.o_wb;        // world_min[3], world_max[3]
     double* const Cc_ = smem + L.o_C;
-    int* const aint_ = reinterpret_cast<int*>(smem + L.o_int);  // [kmax + 1][4]: id, idx0, idx1, idx2
-    int* const ctl_ = aint_ + 4 * (kmax + 1);                   // control words shared by the workgroup
-    double* const Sx_ = smem + L.o_rows;                        // staged LSC rows: [nx | ny | nz | b] x stage_rows
+    double* const Sx_ = smem + L.o_rows;      // staged LSC rows: [nx | ny | nz | b] x stage_rows
     double* const Sy_ = Sx_ + stage_rows;
     double* const Sz_ = Sy_ + stage_rows;
     double* const Sb_ = Sz_ + stage_rows;
     const int LDL = kmax + 1;
+    int par = 0;  // which half of red_ the next cross-wavefront reduction uses (double buffered: one barrier per reduction)
 
     // ---- header, corridor boxes (and the instance's row offset: one memory round trip for all three) -------------------------------
     const uint64_t roff = row_offsets ? row_offsets[q] : 0;
@@ -175,6 +219,10 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
         const double* hsrc = reinterpret_cast<const double*>(hdr + q);
         const double* ssrc = reinterpret_cast<const double*>(sfc) + q * 6 * M;
         for (int e = tid; e < 32 + (cls.use_sfc ? 6 * M : 0); e += T) (e < 32 ? H_[e] : sfc_[e - 32]) = e < 32 ? hsrc[e] : ssrc[e - 32];
+        if (tid < 6) {  // (selects, not an indexed kernel argument)
+            const double w = tid == 0 ? cls.world_min[0] : tid == 1 ? cls.world_min[1] : tid == 2 ? cls.world_min[2] : tid == 3 ? cls.world_max[0] : tid == 4 ? cls.world_max[1] : cls.world_max[2];
+            wb_[tid] = w;
+        }
     }
     __syncthreads();
     DAS_T(0);  // header, boxes, row offset
@@ -183,7 +231,7 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
     const int n_obs = Hd->n_obs;
     // Handing an instance over: the interior-point kernel behind this phase solves whatever is not OPTIMAL (cls.repair == 3 there).
     auto hand_over = [&](int steps) {
-        for (int e = tid; e < NX; e += T) x_out[q * NX + e] = x_init ? x_init[q * NX + e] : Hd->p0[e / P];
+        for (int e = tid; e < NX; e += T) x_out[q * NX + e] = x_init ? x_init[q * NX + e] : Hd->p0[fdiv(e, 1.0f / (float)P)];
         if (tid == 0) {
             obj_out[q] = 0.0;
             status_out[q] = LSCQP_STATUS_ITER_LIMIT;
@@ -200,23 +248,12 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
         return;
     }
     const double dt = cls.dt;
-    // per-axis scalars live in LDS: indexed with a run-time axis, a register array would be materialised in scratch memory (and a kernel
-    // with a private segment costs tens of microseconds to launch)
-    double* const org = smem + L.o_sc;
-    double* const goal = org + 3;
-    double* const Vk = org + 6;
-    double* const Ak = org + 9;
-    if (tid < 3) {
-        org[tid] = Hd->p0[tid];
-        goal[tid] = Hd->goal[tid] - Hd->p0[tid];
-        Vk[tid] = Hd->vmax[tid] * dt * 0.2;
-        Ak[tid] = Hd->amax[tid] * dt * dt * 0.05;
-    }
-    __syncthreads();
+    const double org0 = Hd->p0[0], org1 = Hd->p0[1], org2 = Hd->p0[2];
+    const double* const org = Hd->p0;  // (LDS: indexed with a run-time axis; a register array would be materialised in scratch memory)
     int ts = Hd->terminal_segments;
     if (ts <= 0) {  // src/traj_optimizer.cpp:530-538 in fp64 (as lscqp_kernel.hpp)
-        const double d2 = goal[0] * goal[0] + goal[1] * goal[1] + goal[2] * goal[2];
-        ts = (int)((M * dt - sqrt(d2) / Hd->nominal_velocity + 1e-9) / dt);
+        const double g0 = Hd->goal[0] - org0, g1 = Hd->goal[1] - org1, g2 = Hd->goal[2] - org2;
+        ts = (int)((M * dt - sqrt(g0 * g0 + g1 * g1 + g2 * g2) / Hd->nominal_velocity + 1e-9) / dt);
         if (ts < 1) ts = 1;
     }
     if (ts > M) ts = M;
@@ -226,441 +263,533 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
     const bool comm_on = cls.comm_range > 0;
     const double rho_pair = 0.5 * cls.comm_range - Hd->radius;  // :484
     const double rho_wp = 0.5 * cls.comm_range - 1e-5;          // :495
-
-    // ---- merged intervals (world box, corridor, communication rows on c[m][5]: as lscqp_kernel.hpp), unconstrained optimum --------
-    bool empty = false;
-    for (int e = tid; e < NX; e += T) {
-        const int k = e / P, cp = e % P, m = cp / 6;
-        const double ok_ = org[k];
-        double lo = cls.world_min[k] - ok_, hi = cls.world_max[k] - ok_;  // :252-253,260-265
-        if (cls.rsfc && k == 2 && m == 0) {                               // :255-258
-            lo = -100.0 - ok_;
-            hi = 100.0 - ok_;
-        }
-        if (cls.use_sfc) {  // :372-397
-            lo = fmax(lo, sfcl[m].bmin[k] - ok_);
-            hi = fmin(hi, sfcl[m].bmax[k] - ok_);
-        }
-        if (comm_on && cp % 6 == 5) {  // pairs (m, mi = 0) :482-487 and waypoint rows :494-497
-            const double wpk = Hd->next_waypoint[k] - ok_;
-            lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
-            hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
-        }
-        lo_[e] = lo;
-        hi_[e] = hi;
-        if (cp >= 3 && lo > hi) empty = true;
-        const double c1 = Hd->v0[k] * dt * 0.2;
-        const double c2 = Hd->a0[k] * dt * dt * 0.05 + 2.0 * c1;
-        const double fixv = (cp == 1) ? c1 : (cp == 2) ? c2 : 0.0;
-        const double cv = fixv - c1 * U1[cp] - c2 * U2[cp] + wt2 * goal[k] * G1[cp];
-        c_[e] = cv;
-        cu_[e] = cv;
-    }
-    if (tid == 0) ctl_[0] = 0;
-    __syncthreads();
-    if (empty) ctl_[0] = 1;  // (benign race: every writer stores 1)
-    __syncthreads();
-    if (ctl_[0]) {  // an empty interval: INFEASIBLE is the interior-point kernel's verdict to give
-        hand_over(0);
-        return;
-    }
-
-    DAS_T(1);  // intervals, unconstrained optimum (table vectors)
-    // ---- row ids ------------------------------------------------------------------------------------------------------------------
     const int nL = n_obs * P;
     const int NCP = M * (M - 1) / 2;
-    const int oB = nL, oV = oB + 2 * NX, oA = oV + 2 * dim * 5 * M, oC = oA + 2 * dim * 4 * M, nAll = oC + (comm_on ? 2 * dim * NCP : 0);
     const float iP = 1.0f / (float)P, i5M = 1.0f / (float)(5 * M), i4M = 1.0f / (float)(4 * M), iNCP = 1.0f / (float)(NCP > 0 ? NCP : 1);
     const bool staged = stage_rows > 0 && nL <= stage_rows;  // (uniform)
-    bool rows_in_lds = false;                                // set after the first pass
-    auto load_row = [&](int j, double& nx, double& ny, double& nz, double& b) -> bool {  // LSC row j of this instance, translated; false: dropped
-        if (rows_in_lds) {  // (uniform) staged by the first pass: dropped rows hold (0, 0, 0 | -1)
-            nx = Sx_[j], ny = Sy_[j], nz = Sz_[j], b = Sb_[j];
-            return b != -1.0 || nx != 0.0 || ny != 0.0 || nz != 0.0;
-        }
-        double x, y, z, w;
-        if (cls.rows_f32) {
+    bool rows_in_lds = false;                                // set by the first pass
+
+    // ---- memory first: the table vectors of this thread's control points and its first LSC rows are requested before anything is computed --
+    // (the row format is a template parameter and the index is clamped instead of guarded: a branch around a load makes the compiler wait
+    // for every load right behind it -- the loads of a thread have to be in flight TOGETHER)
+    auto fetch_row = [&](int j, double& x, double& y, double& z, double& w) {  // raw row j of this instance
+        if constexpr (F32) {
             const float4 f = reinterpret_cast<const float4*>(rows)[roff + (uint64_t)j];
             x = f.x, y = f.y, z = f.z, w = f.w;
         } else {
             const double4 d = *reinterpret_cast<const double4*>(&rows[roff + (uint64_t)j]);
             x = d.x, y = d.y, z = d.z, w = d.w;
         }
-        nx = x, ny = y, nz = (dim == 3) ? z : 0.0;
-        b = w - (x * org[0] + y * org[1] + (dim == 3 ? z * org[2] : 0.0));
-        return !(sqrt(x * x + y * y + z * z) < 1e-5) && (j - P * fdiv(j, iP)) >= 3;  // dropped like the reference does (:409-411, :404-406)
     };
-    // the row with id `rid` as entries (uniform over the workgroup); false: the row does not exist
-    auto decode = [&](int rid, Row& R) -> bool {
-        R.idx[0] = R.idx[1] = R.idx[2] = 0;
+    constexpr int NE = 4;  // control-point entries per thread the prologue handles in registers (NX <= 4 T for every shape: 216 at M = 12 in 3-D)
+    double tu1[NE], tu2[NE], tg1[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        const int e = tid + i * T;
+        if (e < NX) {
+            const int cp = e - P * fdiv(e, iP);
+            tu1[i] = U1[cp], tu2[i] = U2[cp], tg1[i] = G1[cp];
+        }
+    }
+    double px[kU], py[kU], pz[kU], pw[kU];  // the first rows of this thread, raw
+#pragma unroll
+    for (int u = 0; u < kU; u++) px[u] = py[u] = pz[u] = 0.0, pw[u] = -1.0;
+    if (nL > 0) {
+#pragma unroll
+        for (int u = 0; u < kU; u++) {
+            const int j = tid + u * T;
+            fetch_row(j < nL ? j : 0, px[u], py[u], pz[u], pw[u]);
+        }
+    }
+
+    // ---- the two-sided rows, one table for all four families (ids nL + 2 r + side; side 0: stencil - lo >= 0, side 1: hi - stencil >= 0) ----
+    //   r in [0, NX)                    interval of one control point: world box, corridor, communication rows on c[m][5]  (:252-265, 372-397, 482-497)
+    //   then dim * 5M velocity rows     c[i+1] - c[i],            |.| <= vmax dt / n          (:448-453)
+    //   then dim * 4M acceleration rows c[i+2] - 2 c[i+1] + c[i], |.| <= amax dt^2 / (n (n-1)) (:462-471)
+    //   then dim * NCP pairs (uu, up)   c[uu][5] - c[up+1][0],    |.| <= rho                   (:482-487 with mi = up + 1 >= 1)
+    // type 0: no row; 1: interval; 2: velocity; 3: acceleration; 4: pair.  Entry indices are positions in c_ (axis * P + control point).
+    const int oV = NX, oA = oV + dim * 5 * M, oC = oA + dim * 4 * M;
+    bool empty = false;
+    for (int r = tid; r < NPAIR; r += T) {
+        int type = 0, e0 = 0, e1 = 0;
+        double lo = -1.0, hi = 1.0;
+        if (r < oV) {
+            const int k = fdiv(r, iP), cp = r - k * P, m = cp / 6;
+            const double ok_ = org[k];
+            lo = wb_[k] - ok_, hi = wb_[3 + k] - ok_;  // :252-253,260-265
+            if (cls.rsfc && k == 2 && m == 0) {                         // :255-258
+                lo = -100.0 - ok_;
+                hi = 100.0 - ok_;
+            }
+            if (cls.use_sfc) {  // :372-397
+                lo = fmax(lo, sfcl[m].bmin[k] - ok_);
+                hi = fmin(hi, sfcl[m].bmax[k] - ok_);
+            }
+            if (comm_on && cp % 6 == 5) {  // pairs (m, mi = 0) :482-487 and waypoint rows :494-497
+                const double wpk = Hd->next_waypoint[k] - ok_;
+                lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
+                hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
+            }
+            type = cp >= 3 ? 1 : 0;
+            e0 = r;
+            if (type && lo > hi) empty = true;
+        } else if (r < oA) {
+            const int s = r - oV, k = fdiv(s, i5M), rr = s - k * 5 * M, m = rr / 5, i = rr % 5;
+            type = (m == 0 && i < 2) ? 0 : 2;
+            e0 = k * P + 6 * m + i;
+            hi = Hd->vmax[k] * dt * 0.2, lo = -hi;
+        } else if (r < oC) {
+            const int s = r - oA, k = fdiv(s, i4M), rr = s - k * 4 * M, m = rr / 4, i = rr % 4;
+            type = (m == 0 && i < 1) ? 0 : 3;
+            e0 = k * P + 6 * m + i;
+            hi = Hd->amax[k] * dt * dt * 0.05, lo = -hi;
+        } else {
+            const int s = r - oC, k = fdiv(s, iNCP), ci = s - k * NCP;
+            int uu = 1;
+            while (uu * (uu + 1) / 2 <= ci) uu++;
+            const int up = ci - uu * (uu - 1) / 2;
+            type = comm_on ? 4 : 0;
+            e0 = k * P + 6 * (up + 1), e1 = k * P + 6 * uu + 5;
+            hi = rho_pair, lo = -rho_pair;
+        }
+        plo_[r] = lo, phi_[r] = hi;
+        pix_[r] = (type << 24) | (e0 << 12) | e1;
+    }
+    // ---- unconstrained optimum: c_u[k] = cfix[k] - c1_k U1 - c2_k U2 + 2 w_t goal_k G1 ---------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        const int e = tid + i * T;
+        if (e < NX) {
+            const int k = fdiv(e, iP), cp = e - k * P;
+            const double c1 = Hd->v0[k] * dt * 0.2;
+            const double c2 = Hd->a0[k] * dt * dt * 0.05 + 2.0 * c1;
+            const double fixv = (cp == 1) ? c1 : (cp == 2) ? c2 : 0.0;
+            const double cv = fixv - c1 * tu1[i] - c2 * tu2[i] + wt2 * (Hd->goal[k] - org[k]) * tg1[i];
+            c_[e] = cv;
+            cu_[e] = cv;
+        }
+    }
+    if (dim == 2)
+        for (int e = tid; e < P; e += T) c_[2 * P + e] = 0.0;
+    if (tid == 0) ctl_[4] = 0.0;
+    LSCQP_DAS_BARRIER();
+    if (empty) ctl_[4] = 1.0;  // (benign race: every writer stores 1)
+    LSCQP_DAS_BARRIER();
+    if (ctl_[4] != 0.0) {  // an empty interval: INFEASIBLE is the interior-point kernel's verdict to give
+        hand_over(0);
+        return;
+    }
+    DAS_T(1);  // tables, two-sided rows, unconstrained optimum
+
+    // ---- rows by id ---------------------------------------------------------------------------------------------------------------------
+    // LSC row j, translated to the agent's position; false: the reference drops it (:404-406: first three control points, :409-411: zero normal)
+    auto translate = [&](int j, double x, double y, double z, double w, double& nx, double& ny, double& nz, double& b) -> bool {
+        nx = x, ny = y, nz = (dim == 3) ? z : 0.0;
+        b = w - (x * org0 + y * org1 + (dim == 3 ? z * org2 : 0.0));
+        return !(x * x + y * y + z * z < 1e-10) && (j - P * fdiv(j, iP)) >= 3;
+    };
+    auto load_row = [&](int j, double& nx, double& ny, double& nz, double& b) -> bool {  // (single rows: the candidate's)
+        if (rows_in_lds) {  // (uniform) staged by the first pass: dropped rows hold (0, 0, 0 | -1)
+            nx = Sx_[j], ny = Sy_[j], nz = Sz_[j], b = Sb_[j];
+            return b != -1.0 || nx != 0.0 || ny != 0.0 || nz != 0.0;
+        }
+        double x, y, z, w;
+        fetch_row(j, x, y, z, w);
+        return translate(j, x, y, z, w, nx, ny, nz, b);
+    };
+    // stencil of a two-sided row on a vector in c_ layout
+    auto pair_val = [&](int pk, const double* vec) -> double {
+        const int type = pk >> 24, e0 = (pk >> 12) & 0xfff, e1 = pk & 0xfff;
+        return type == 1 ? vec[e0] : type == 2 ? (vec[e0 + 1] - vec[e0]) : type == 3 ? (vec[e0 + 2] - 2.0 * vec[e0 + 1] + vec[e0]) : (vec[e1] - vec[e0]);
+    };
+    auto ent_of = [&](int e) -> int {  // position in c_ -> axis << 16 | control point
+        const int k = fdiv(e, iP);
+        return (k << 16) | (e - k * P);
+    };
+    // the row with id `rid` as entries (uniform over the workgroup)
+    auto decode = [&](int rid, Row& R) {
+        R.ent[0] = R.ent[1] = R.ent[2] = 0;
         R.coef[0] = R.coef[1] = R.coef[2] = 0.0;
         if (rid < nL) {
             const int cp = rid - P * fdiv(rid, iP);
             double nx, ny, nz, b;
-            const bool ok = load_row(rid, nx, ny, nz, b);
-            R.idx[0] = cp, R.idx[1] = P + cp, R.idx[2] = (dim == 3 ? 2 * P : 0) + cp;
+            (void)load_row(rid, nx, ny, nz, b);
+            R.ent[0] = cp, R.ent[1] = (1 << 16) | cp, R.ent[2] = (2 << 16) | cp;
             R.coef[0] = nx, R.coef[1] = ny, R.coef[2] = (dim == 3) ? nz : 0.0;
             R.rhs = b;
-            return ok;
+            return;
         }
-        if (rid < oV) {
-            const int s = rid - oB, e = s >> 1;
-            R.idx[0] = e;
-            R.coef[0] = (s & 1) ? -1.0 : 1.0;
-            R.rhs = (s & 1) ? -hi_[e] : lo_[e];
-            return (e - P * fdiv(e, iP)) >= 3;
-        }
-        if (rid < oA) {
-            const int s = rid - oV, r = s >> 1, k = fdiv(r, i5M), rr = r - k * 5 * M, m = rr / 5, i = rr % 5, e = k * P + 6 * m + i;
-            const double sg = (s & 1) ? -1.0 : 1.0;
-            R.idx[0] = e + 1, R.idx[1] = e;
-            R.coef[0] = sg, R.coef[1] = -sg;
-            R.rhs = -Vk[k];
-            return !(m == 0 && i < 2);
-        }
-        if (rid < oC) {
-            const int s = rid - oA, r = s >> 1, k = fdiv(r, i4M), rr = r - k * 4 * M, m = rr / 4, i = rr % 4, e = k * P + 6 * m + i;
-            const double sg = (s & 1) ? -1.0 : 1.0;
-            R.idx[0] = e + 2, R.idx[1] = e + 1, R.idx[2] = e;
-            R.coef[0] = sg, R.coef[1] = -2.0 * sg, R.coef[2] = sg;
-            R.rhs = -Ak[k];
-            return !(m == 0 && i < 1);
-        }
-        {
-            const int s = rid - oC, r = s >> 1, k = fdiv(r, iNCP), ci = r - k * NCP;
-            int uu = 1;
-            while (uu * (uu + 1) / 2 <= ci) uu++;
-            const int up = ci - uu * (uu - 1) / 2;
-            const double sg = (s & 1) ? -1.0 : 1.0;
-            R.idx[0] = k * P + 6 * uu + 5, R.idx[1] = k * P + 6 * (up + 1);
-            R.coef[0] = sg, R.coef[1] = -sg;
-            R.rhs = -rho_pair;
-            return true;
+        const int s = rid - nL, r = s >> 1, pk = pix_[r];
+        const int type = pk >> 24, e0 = (pk >> 12) & 0xfff, e1 = pk & 0xfff;
+        const double sg = (s & 1) ? -1.0 : 1.0;
+        R.rhs = (s & 1) ? -phi_[r] : plo_[r];
+        if (type == 1) {
+            R.ent[0] = ent_of(e0), R.coef[0] = sg;
+        } else if (type == 2) {
+            R.ent[0] = ent_of(e0 + 1), R.ent[1] = ent_of(e0), R.coef[0] = sg, R.coef[1] = -sg;
+        } else if (type == 3) {
+            R.ent[0] = ent_of(e0 + 2), R.ent[1] = ent_of(e0 + 1), R.ent[2] = ent_of(e0), R.coef[0] = sg, R.coef[1] = -2.0 * sg, R.coef[2] = sg;
+        } else {
+            R.ent[0] = ent_of(e1), R.ent[1] = ent_of(e0), R.coef[0] = sg, R.coef[1] = -sg;
         }
     };
-    auto row_dot = [&](const int* idx, const double* coef, const double* vec) -> double {
-        return coef[0] * vec[idx[0]] + coef[1] * vec[idx[1]] + coef[2] * vec[idx[2]];
+    auto row_dot = [&](const int* ent, const double* coef, const double* vec) -> double {  // a'vec for a vector in c_ layout
+        return coef[0] * vec[ent_axis(ent[0]) * P + ent_cp(ent[0])] + coef[1] * vec[ent_axis(ent[1]) * P + ent_cp(ent[1])] +
+               coef[2] * vec[ent_axis(ent[2]) * P + ent_cp(ent[2])];
     };
 
     // ---- one pass over every row: the most violated one (normalised slack, lowest id on ties) and the largest raw violation ---------
-    // The FIRST pass reads the LSC rows from HBM (four in flight per thread) and, in the staged form (small batches: LDS to spare), leaves
-    // them translated in LDS; later passes read them from there, or from L2.
-    auto pass = [&](double& best, int& bid, double& worst_raw) {
-        double bv = 1e300, wr = 1e300;
+    // The FIRST pass consumes the rows requested in the prologue (HBM), asks for the rest four at a time and, in the staged form (small
+    // batches: LDS to spare), leaves them translated in LDS; later passes read them from there, or from L2.
+    bool first_pass = true;  // (uniform)
+    // Rows are judged by their RAW slack (metres, the interior-point kernel's bar), which is also what picks the candidate.  Straight-line code:
+    // a dropped row, or a slot behind the instance's last row, is the harmless row (0, 0, 0 | -1) -- slack +1 -- instead of a branch.
+    auto pass = [&](double& best, int& bid) {
+        double bv = 1e300;
         int bi = 0x7fffffff;
-        auto see = [&](double slack, double inrm, int id) {
-            const double v = slack * inrm;
-            if (v < bv) bv = v, bi = id;  // (ids ascend within a thread: the first minimum is the lowest id)
-            wr = fmin(wr, slack);
+        auto see = [&](double slack, int id) {
+            const bool lt = slack < bv;  // (ids ascend within a thread: the first minimum is the lowest id)
+            bv = lt ? slack : bv;
+            bi = lt ? id : bi;
         };
-        constexpr int U = 4;
-        for (int j0 = tid; j0 < nL; j0 += U * T) {
-            double rx[U], ry[U], rz[U], rb[U];
-            bool ok[U];
+        auto eval = [&](int j0, const double* rx, const double* ry, const double* rz, const double* rb) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int j = j0 + u * T;
-                ok[u] = (j < nL) ? load_row(j, rx[u], ry[u], rz[u], rb[u]) : false;
-                if (j >= nL) rx[u] = ry[u] = rz[u] = 0.0, rb[u] = -1.0;
+            for (int u = 0; u < kU; u++) {
+                const int j = j0 + u * T, jc = j < nL ? j : 0;
+                const int cp = jc - P * fdiv(jc, iP);
+                see(rx[u] * c_[cp] + ry[u] * c_[P + cp] + rz[u] * c_[2 * P + cp] - rb[u], j);
             }
+        };
+        // raw -> translated, dropped rows and slots past the end neutralised
+        auto prep = [&](int j0, const double* x, const double* y, const double* z, const double* w, double* rx, double* ry, double* rz, double* rb) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
+            for (int u = 0; u < kU; u++) {
+                const int j = j0 + u * T, jc = j < nL ? j : 0;
+                const bool ok = translate(jc, x[u], y[u], z[u], w[u], rx[u], ry[u], rz[u], rb[u]) && j < nL;
+                rx[u] = ok ? rx[u] : 0.0, ry[u] = ok ? ry[u] : 0.0, rz[u] = ok ? rz[u] : 0.0, rb[u] = ok ? rb[u] : -1.0;
+            }
+        };
+        auto stage = [&](int j0, const double* rx, const double* ry, const double* rz, const double* rb) {
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
                 const int j = j0 + u * T;
-                if (j < nL) {
-                    if (staged && !rows_in_lds) {
-                        Sx_[j] = ok[u] ? rx[u] : 0.0, Sy_[j] = ok[u] ? ry[u] : 0.0, Sz_[j] = ok[u] ? rz[u] : 0.0, Sb_[j] = ok[u] ? rb[u] : -1.0;
-                    }
-                    if (ok[u]) {
-                        const int cp = j - P * fdiv(j, iP);
-                        const double s = rx[u] * c_[cp] + ry[u] * c_[P + cp] + (dim == 3 ? rz[u] * c_[2 * P + cp] : 0.0) - rb[u];
-                        const double n2 = rx[u] * rx[u] + ry[u] * ry[u] + rz[u] * rz[u];
-                        see(s, n2 > 1e-20 ? rsqrt(n2) : 1.0, j);
-                    }
+                if (j < nL) Sx_[j] = rx[u], Sy_[j] = ry[u], Sz_[j] = rz[u], Sb_[j] = rb[u];
+            }
+        };
+        double rx[kU], ry[kU], rz[kU], rb[kU];
+        if (first_pass) {
+            // the prologue's rows, then the rest from memory
+            prep(tid, px, py, pz, pw, rx, ry, rz, rb);
+            if (staged) stage(tid, rx, ry, rz, rb);
+            eval(tid, rx, ry, rz, rb);
+            for (int j0 = tid + kU * T; j0 < nL; j0 += kU * T) {
+                double x[kU], y[kU], z[kU], w[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) fetch_row(j0 + u * T < nL ? j0 + u * T : 0, x[u], y[u], z[u], w[u]);
+                prep(j0, x, y, z, w, rx, ry, rz, rb);
+                if (staged) stage(j0, rx, ry, rz, rb);
+                eval(j0, rx, ry, rz, rb);
+            }
+        } else if (rows_in_lds) {
+            for (int j0 = tid; j0 < nL; j0 += kU * T) {
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const int j = j0 + u * T, jc = j < nL ? j : 0;
+                    rx[u] = Sx_[jc], ry[u] = Sy_[jc], rz[u] = Sz_[jc], rb[u] = (j < nL) ? Sb_[jc] : 1e300;  // (a slot past the end: slack -> -inf guard below)
+                    if (!(j < nL)) rx[u] = ry[u] = rz[u] = 0.0, rb[u] = -1.0;
                 }
+                eval(j0, rx, ry, rz, rb);
+            }
+        } else {
+            for (int j0 = tid; j0 < nL; j0 += kU * T) {
+                double x[kU], y[kU], z[kU], w[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) fetch_row(j0 + u * T < nL ? j0 + u * T : 0, x[u], y[u], z[u], w[u]);
+                prep(j0, x, y, z, w, rx, ry, rz, rb);
+                eval(j0, rx, ry, rz, rb);
             }
         }
-        // intervals
-        for (int e = tid; e < NX; e += T) {
-            if ((e - P * fdiv(e, iP)) >= 3) {
-                const double cv = c_[e];
-                see(cv - lo_[e], 1.0, oB + 2 * e);
-                see(hi_[e] - cv, 1.0, oB + 2 * e + 1);
-            }
+        const bool was_first = first_pass;
+        first_pass = false;
+        DAS_T(8);
+        for (int r0 = tid; r0 < NPAIR; r0 += 2 * T) {  // two at a time: their LDS round trips overlap
+            const int r1 = r0 + T, r1c = r1 < NPAIR ? r1 : r0;
+            const int pk0 = pix_[r0], pk1 = pix_[r1c];
+            const double lo0 = plo_[r0], hi0 = phi_[r0], lo1 = plo_[r1c], hi1 = phi_[r1c];
+            const double d0 = pair_val(pk0, c_), d1 = pair_val(pk1, c_);
+            const bool on0 = (pk0 >> 24) != 0, on1 = (pk1 >> 24) != 0 && r1 < NPAIR;
+            see(on0 ? d0 - lo0 : 1.0, nL + 2 * r0);
+            see(on0 ? hi0 - d0 : 1.0, nL + 2 * r0 + 1);
+            see(on1 ? d1 - lo1 : 1.0, nL + 2 * r1);
+            see(on1 ? hi1 - d1 : 1.0, nL + 2 * r1 + 1);
         }
-        // velocity: c[i+1] - c[i], |.| <= vmax dt / n   (:448-453)
-        for (int r = tid; r < dim * 5 * M; r += T) {
-            const int k = fdiv(r, i5M), rr = r - k * 5 * M, m = rr / 5, i = rr % 5;
-            if (!(m == 0 && i < 2)) {
-                const int e = k * P + 6 * m + i;
-                const double d = c_[e + 1] - c_[e];
-                see(d + Vk[k], 0.70710678118654752, oV + 2 * r);
-                see(Vk[k] - d, 0.70710678118654752, oV + 2 * r + 1);
-            }
-        }
-        // acceleration: c[i+2] - 2 c[i+1] + c[i]   (:462-471)
-        for (int r = tid; r < dim * 4 * M; r += T) {
-            const int k = fdiv(r, i4M), rr = r - k * 4 * M, m = rr / 4, i = rr % 4;
-            if (!(m == 0 && i < 1)) {
-                const int e = k * P + 6 * m + i;
-                const double d = c_[e + 2] - 2.0 * c_[e + 1] + c_[e];
-                see(d + Ak[k], 0.40824829046386302, oA + 2 * r);
-                see(Ak[k] - d, 0.40824829046386302, oA + 2 * r + 1);
-            }
-        }
-        // communication pairs (uu, up < uu): c[uu][5] - c[up+1][0]   (:482-487 with mi = up + 1 >= 1)
-        if (comm_on) {
-            for (int r = tid; r < dim * NCP; r += T) {
-                const int k = fdiv(r, iNCP), ci = r - k * NCP;
-                int uu = 1;
-                while (uu * (uu + 1) / 2 <= ci) uu++;
-                const int up = ci - uu * (uu - 1) / 2;
-                const double d = c_[k * P + 6 * uu + 5] - c_[k * P + 6 * (up + 1)];
-                see(d + rho_pair, 0.70710678118654752, oC + 2 * r);
-                see(rho_pair - d, 0.70710678118654752, oC + 2 * r + 1);
-            }
-        }
+        DAS_T(9);
         wave_argmin(bv, bi);
-        wr = wave_min(wr);
-        if (NW > 1) {
-            __syncthreads();  // (red_ may still be read from the previous reduction)
+        if constexpr (NW > 1) {
+            double* const rb_ = red_ + 16 * par;
+            par ^= 1;
             if (lane == 0) {
-                red_[wv] = bv;
-                red_[8 + wv] = wr;
-                reinterpret_cast<int*>(red_ + 16)[wv] = bi;
+                rb_[wv] = bv;
+                reinterpret_cast<int*>(rb_ + 8)[wv] = bi;
             }
-            __syncthreads();
-            bv = red_[0], wr = red_[8], bi = reinterpret_cast<int*>(red_ + 16)[0];
+            LSCQP_DAS_BARRIER();
+            bv = rb_[0], bi = reinterpret_cast<int*>(rb_ + 8)[0];
+#pragma unroll
             for (int w = 1; w < NW; w++) {
-                const double ov = red_[w];
-                const int oi = reinterpret_cast<int*>(red_ + 16)[w];
+                const double ov = rb_[w];
+                const int oi = reinterpret_cast<int*>(rb_ + 8)[w];
                 if (ov < bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
-                wr = fmin(wr, red_[8 + w]);
             }
-        } else if (staged && !rows_in_lds) {
-            __syncthreads();  // the staged rows are read by other lanes from now on
+        } else if (staged && was_first) {
+            LSCQP_DAS_BARRIER();  // the staged rows are read by other lanes from now on
         }
         if (staged) rows_in_lds = true;
-        best = bv, bid = bi, worst_raw = wr;
-    };
-    auto block_max = [&](double v) -> double {
-        v = wave_max(v);
-        if (NW > 1) {
-            __syncthreads();
-            if (lane == 0) red_[wv] = v;
-            __syncthreads();
-            v = red_[0];
-            for (int w = 1; w < NW; w++) v = fmax(v, red_[w]);
-        }
-        return v;
-    };
-    auto block_sum = [&](double v) -> double {  // fixed order: reproducible
-        v = wave_sum(v);
-        if (NW > 1) {
-            __syncthreads();
-            if (lane == 0) red_[wv] = v;
-            __syncthreads();
-            v = red_[0];
-            for (int w = 1; w < NW; w++) v += red_[w];
-        }
-        return v;
+        best = bv, bid = bi;
     };
 
-    // ---- the small factor: S = A'W (k x k, SPD), S = Lm Lm', rows owned by the lanes of wavefront 0 ------------------------------------
-    // from scratch (after a row left the set): S_ij = a_i . W_j
+    // ---- the small factor: S = A'C A (k x k, SPD), S = Lm Lm', rows owned by the lanes of wavefront 0 -------------------------------------
+    const double* Cm = Cg;  // column cp = Cm + cp * P (symmetric); the LDS copy once a step needs it
+    // from scratch (after a row left the set), out of the stored Gram matrix
     auto factor_scratch = [&](int k) -> bool {  // wavefront 0 only; returns false on a lost pivot (dependent rows)
         bool ok = true;
         if (wv == 0) {
             const int i = lane;
             double sdiag = 1.0;
             if (i < k) {
-                for (int j = 0; j <= i; j++) Lm_[i * LDL + j] = row_dot(&aint_[4 * i + 1], &acoef_[3 * i], W_ + (size_t)j * NX);
-                sdiag = Lm_[i * LDL + i];
+                for (int j = 0; j <= i; j++) Lm_[i * LDL + j] = Sm_[i * LDL + j];
+                sdiag = Sm_[i * LDL + i];
             }
             LSCQP_DAS_WAVE_SYNC();
             for (int j = 0; j < k; j++) {
-                const double d = Lm_[j * LDL + j];
-                if (!(d > 1e-13 * __shfl(sdiag, j, 64))) ok = false;
-                const double dj = sqrt(fmax(d, 1e-300));
-                const double idj = 1.0 / dj;
-                const double lij = (i > j && i < k) ? Lm_[i * LDL + j] * idj : 0.0;
+                const int js = __builtin_amdgcn_readfirstlane(j);
+                const double d = Lm_[js * LDL + js];
+                if (!(d > 1e-13 * lscqp::bcast(sdiag, js))) ok = false;
+                const double idj = rsqrt(fmax(d, 1e-300));
+                const double dj = d * idj;
+                const double lij = (i > js && i < k) ? Lm_[i * LDL + js] * idj : 0.0;
                 LSCQP_DAS_WAVE_SYNC();  // every lane has read the pivot before its owner overwrites it
-                if (i == j) Lm_[j * LDL + j] = dj, linv_[j] = idj;
-                if (i > j && i < k) Lm_[i * LDL + j] = lij;
+                if (i == js) Lm_[js * LDL + js] = dj, linv_[js] = idj;
+                if (i > js && i < k) Lm_[i * LDL + js] = lij;
                 LSCQP_DAS_WAVE_SYNC();
                 // trailing update of the own row: S_ic -= L_ij L_cj, c = j+1 .. i
-                if (i > j && i < k) {
-                    for (int cidx = j + 1; cidx <= i; cidx++) Lm_[i * LDL + cidx] -= lij * Lm_[cidx * LDL + j];
+                if (i > js && i < k) {
+#pragma unroll 4
+                    for (int cidx = js + 1; cidx <= i; cidx++) Lm_[i * LDL + cidx] -= lij * Lm_[cidx * LDL + js];
                 }
                 LSCQP_DAS_WAVE_SYNC();
             }
         }
         return ok;
     };
-    // r = S^-1 v through the factor (wavefront 0; v_ in, y_ = Lm^-1 v and r_ out; lane j owns component j, the pivot component of a step
-    // reaches the others with v_readlane).  With `ratio`: the dual step bound t1 = min over r_j > 0 of u_j / r_j and its row (lowest j on
-    // ties) land in red_[24], red_[25] -- one division per lane instead of k per thread.
-    auto solve_factor = [&](int k, bool ratio) {
-        if (wv == 0) {
-            double vi = (lane < k) ? v_[lane] : 0.0;
-            for (int j = 0; j < k; j++) {  // forward: Lm y = v
-                const int js = __builtin_amdgcn_readfirstlane(j);
-                const double yj = lscqp::bcast(vi, js) * linv_[js];
-                if (lane == js) y_[js] = yj;
-                if (lane > js && lane < k) vi -= Lm_[lane * LDL + js] * yj;
+    // r = S^-1 v through the factor (wavefront 0; lane j holds v_j on entry and r_j on return; y = Lm^-1 v is left in y_, r in r_).  The
+    // substitution is a chain of dependent steps (broadcast of the pivot component, one multiply, one FMA); the factor's entries are
+    // requested a window of eight columns ahead so that no LDS round trip sits inside the chain.
+    auto solve_factor = [&](int k, double vi) -> double {
+        const bool mine = lane < k;
+        const int ll = mine ? lane : 0;
+        const double li_own = mine ? linv_[ll] : 0.0;
+        vi = mine ? vi : 0.0;
+        for (int j0 = 0; j0 < k; j0 += 8) {  // forward: Lm y = v
+            double Lr[8];
+#pragma unroll
+            for (int t_ = 0; t_ < 8; t_++) Lr[t_] = (j0 + t_ < k) ? Lm_[ll * LDL + j0 + t_] : 0.0;
+#pragma unroll
+            for (int t_ = 0; t_ < 8; t_++) {
+                const int js = __builtin_amdgcn_readfirstlane(j0 + t_);
+                if (js < k) {
+                    const double yj = lscqp::bcast(vi * li_own, js);
+                    vi = (lane == js) ? yj : vi;  // (lane j keeps y_j in place of v_j: the backward sweep starts from it)
+                    if (lane > js && mine) vi -= Lr[t_] * yj;
+                }
             }
-            LSCQP_DAS_WAVE_SYNC();
-            double yi = (lane < k) ? y_[lane] : 0.0;
-            double ri = 0.0;
-            for (int j = k - 1; j >= 0; j--) {  // backward: Lm' r = y
-                const int js = __builtin_amdgcn_readfirstlane(j);
-                const double rj = lscqp::bcast(yi, js) * linv_[js];
-                if (lane == js) r_[js] = rj, ri = rj;
-                if (lane < js) yi -= Lm_[js * LDL + lane] * rj;
+        }
+        if (mine) y_[lane] = vi;
+        double yi = vi, ri = 0.0;
+        for (int j1 = k - 1; j1 >= 0; j1 -= 8) {  // backward: Lm' r = y
+            double Lc[8];
+#pragma unroll
+            for (int t_ = 0; t_ < 8; t_++) Lc[t_] = (j1 - t_ >= 0) ? Lm_[(j1 - t_) * LDL + ll] : 0.0;
+#pragma unroll
+            for (int t_ = 0; t_ < 8; t_++) {
+                const int js = __builtin_amdgcn_readfirstlane(j1 - t_);
+                if (js >= 0) {
+                    const double rj = lscqp::bcast(yi * li_own, js);
+                    ri = (lane == js) ? rj : ri;
+                    if (lane < js) yi -= Lc[t_] * rj;
+                }
             }
-            if (ratio) {
-                double tr = (lane < k && ri > 0.0) ? u_[lane] / ri : 1e300;
-                int tl = lane;
-                wave_argmin(tr, tl);
-                if (lane == 0) red_[24] = tr, red_[25] = (double)(tr < 1e299 ? tl : -1);
-            }
+        }
+        if (mine) r_[lane] = ri;
+        return ri;
+    };
+    // c_[e] = base[e] (or c_[e]) + sum_j wts[j] W_j[e] over the active rows
+    auto add_columns = [&](int k, const double* wts, const double* base) {
+        for (int e = tid; e < NX; e += T) {
+            double a = base ? base[e] : c_[e];
+            for (int j = 0; j < k; j++) a += wts[j] * W_[(size_t)j * NX + e];
+            c_[e] = a;
         }
     };
 
-    // ---- verification: reduced stationarity  T'(Hx c + fx - A'u), scaled as lscqp_info.res_dual (uniform result) -----------------------
-    // g_[0 .. NX): Hx c + fx - A'u;  g_[NX ..): Hx c + fx;  g_[2 NX ..): Hx cfix + fx
+    // ---- verification + objective, one reduction: reduced stationarity T'(Hx c + fx - A'u) scaled as lscqp_info.res_dual; objective exactly
+    // as cplex.getObjValue() reports it (as lscqp_kernel.hpp).  Every z thread evaluates the <= 4 control-point rows of Hx it needs itself.
     const int NZA = 3 * (M - 1) + (es ? 1 : 3);
-    auto verify = [&](int k) -> double {
-        __syncthreads();
-        for (int e = tid; e < NX; e += T) {
-            const int kx = e / P, cp = e % P, m = cp / 6, i = cp % 6;
-            const double* cc = &c_[kx * P + 6 * m];
-            double hx = 0.0;
+    auto finish = [&](int k, double& res_d, double& obj) {
+        if (k > 0) {  // A'u, per control point
+            for (int e = tid; e < NX; e += T) lam_[e] = 0.0;
+            LSCQP_DAS_BARRIER();
+            if (tid == 0) {
+                for (int j = 0; j < k; j++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) hx += q2s * KQ(i, j) * cc[j];
-            const bool term = (i == 5 && m >= M - ts);
-            const double fx = term ? -wt2 * goal[kx] : 0.0;
-            if (term) hx += wt2 * cc[5];
-            double h0 = fx;
-            if (m == 0) {
-                const double c1 = Hd->v0[kx] * dt * 0.2;
-                const double c2 = Hd->a0[kx] * dt * dt * 0.05 + 2.0 * c1;
-                h0 += q2s * (KQ(i, 1) * c1 + KQ(i, 2) * c2);
+                    for (int t_ = 0; t_ < 3; t_++) {
+                        const int en = aint_[4 * j + 1 + t_];
+                        lam_[ent_axis(en) * P + ent_cp(en)] += u_[j] * acoef_[3 * j + t_];
+                    }
             }
-            double lam = 0.0;
-            for (int j = 0; j < k; j++) {
-#pragma unroll
-                for (int t_ = 0; t_ < 3; t_++)
-                    if (aint_[4 * j + 1 + t_] == e) lam += u_[j] * acoef_[3 * j + t_];
-            }
-            g_[e] = hx + fx - lam;
-            g_[NX + e] = hx + fx;
-            g_[2 * NX + e] = h0;
+            LSCQP_DAS_BARRIER();
         }
-        __syncthreads();
         double rd = 0.0, gs = 0.0;
         for (int zi = tid; zi < dim * NZA; zi += T) {
-            const int kx = zi / NZA, a = zi % NZA;
+            const int kx = zi / NZA, a = zi - kx * NZA;
             const bool last = es && a == 3 * (M - 1);
             const int m = last ? M - 1 : a / 3, j = last ? 0 : a % 3;
-#pragma unroll
-            for (int w = 0; w < 3; w++) {
-                const double* gg = g_ + w * NX + kx * P;
-                double comp = last ? (gg[6 * m + 3] + gg[6 * m + 4] + gg[6 * m + 5]) : gg[6 * m + 3 + j];
-                if (m + 1 < M) {  // (c0, c1, c2) of the next segment = TB (c3, c4, c5) of this one, TB = [[0,0,1],[0,-1,2],[1,-4,4]]
-                    const double* gn = gg + 6 * (m + 1);
-                    comp += (j == 0) ? gn[2] : (j == 1) ? (-gn[1] - 4.0 * gn[2]) : (gn[0] + 2.0 * gn[1] + 4.0 * gn[2]);
+            const double c1 = Hd->v0[kx] * dt * 0.2;
+            const double c2 = Hd->a0[kx] * dt * dt * 0.05 + 2.0 * c1;
+            const double gk = Hd->goal[kx] - org[kx];
+            // the six rows of Hx of one segment on this axis: g = Hx c + fx, g0 = Hx cfix + fx, lm = A'u (constant indices: registers)
+            auto seg = [&](int mm, double* g, double* g0, double* lm) {
+                const double* cc = &c_[kx * P + 6 * mm];
+                const double v0 = cc[0], v1 = cc[1], v2 = cc[2], v3 = cc[3], v4 = cc[4], v5 = cc[5];
+                lscqp::static_for<0, 6>([&](auto Ic) {
+                    constexpr int i = decltype(Ic)::value;
+                    g[i] = q2s * (KQ(i, 0) * v0 + KQ(i, 1) * v1 + KQ(i, 2) * v2 + KQ(i, 3) * v3 + KQ(i, 4) * v4 + KQ(i, 5) * v5);
+                    g0[i] = (mm == 0) ? q2s * (KQ(i, 1) * c1 + KQ(i, 2) * c2) : 0.0;
+                    lm[i] = (k > 0) ? lam_[kx * P + 6 * mm + i] : 0.0;
+                });
+                if (mm >= M - ts) {
+                    g[5] += wt2 * (v5 - gk);
+                    g0[5] += -wt2 * gk;
                 }
-                if (w == 0) rd = fmax(rd, fabs(comp));
-                else gs = fmax(gs, fabs(comp));
+            };
+            double g[6], g0[6], lm[6];
+            seg(m, g, g0, lm);
+            double cf, cg, c0;  // T' of: full residual, gradient, gradient at the fixed part
+            if (last) {
+                cf = (g[3] - lm[3]) + (g[4] - lm[4]) + (g[5] - lm[5]), cg = g[3] + g[4] + g[5], c0 = g0[3] + g0[4] + g0[5];
+            } else {
+                const double gs_ = j == 0 ? g[3] : j == 1 ? g[4] : g[5], ls_ = j == 0 ? lm[3] : j == 1 ? lm[4] : lm[5], g0s = j == 0 ? g0[3] : j == 1 ? g0[4] : g0[5];
+                cf = gs_ - ls_, cg = gs_, c0 = g0s;
             }
+            if (m + 1 < M) {  // (c0, c1, c2) of the next segment = TB (c3, c4, c5) of this one, TB = [[0,0,1],[0,-1,2],[1,-4,4]]
+                seg(m + 1, g, g0, lm);
+                const double w0 = (j == 2) ? 1.0 : 0.0, w1 = (j == 1) ? -1.0 : (j == 2) ? 2.0 : 0.0, w2 = (j == 0) ? 1.0 : (j == 1) ? -4.0 : 4.0;
+                cf += w0 * (g[0] - lm[0]) + w1 * (g[1] - lm[1]) + w2 * (g[2] - lm[2]);
+                cg += w0 * g[0] + w1 * g[1] + w2 * g[2];
+                c0 += w0 * g0[0] + w1 * g0[1] + w2 * g0[2];
+            }
+            rd = fmax(rd, fabs(cf));
+            gs = fmax(gs, fmax(fabs(cg), fabs(c0)));
         }
-        // (one reduction for both: the two maxima packed side by side)
+        double part = 0.0;
+        for (int lv = tid; lv < dim * M; lv += T) {
+            const int kx = lv / M, m = lv - kx * M;
+            const double* cc = &c_[kx * P + 6 * m];
+            const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
+            const double j1 = (cc[4] - cc[1]) - 3.0 * (cc[3] - cc[2]);
+            const double j2 = (cc[5] - cc[2]) - 3.0 * (cc[4] - cc[3]);
+            const double quad = 0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
+            double pp = 0.5 * q2s * 3600.0 * quad;
+            const double ok_ = org[kx];
+            double corr = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                double r = 0;
+#pragma unroll
+                for (int ip = 0; ip < 6; ip++) r += cls.dQ[i * 6 + ip] * (cc[ip] + ok_);
+                corr += r * (cc[i] + ok_);
+            }
+            pp += cls.w_c * corr;
+            const double dgoal = cc[5] - (Hd->goal[kx] - ok_);
+            pp += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
+            part += pp;
+        }
         rd = wave_max(rd);
         gs = wave_max(gs);
-        if (NW > 1) {
-            __syncthreads();
-            if (lane == 0) red_[wv] = rd, red_[8 + wv] = gs;
-            __syncthreads();
-            rd = red_[0], gs = red_[8];
-            for (int w = 1; w < NW; w++) rd = fmax(rd, red_[w]), gs = fmax(gs, red_[8 + w]);
+        part = wave_sum(part);
+        if constexpr (NW > 1) {
+            double* const rb_ = red_ + 16 * par;
+            par ^= 1;
+            if (lane == 0) rb_[wv] = rd, rb_[4 + wv] = gs, rb_[8 + wv] = part;
+            LSCQP_DAS_BARRIER();
+            rd = rb_[0], gs = rb_[4], part = rb_[8];
+#pragma unroll
+            for (int w = 1; w < NW; w++) rd = fmax(rd, rb_[w]), gs = fmax(gs, rb_[4 + w]), part += rb_[8 + w];  // (fixed order: reproducible)
         }
-        return rd / fmax(1.0, gs);
+        res_d = rd / fmax(1.0, gs);
+        obj = part;
     };
 
     // ---- the loop ---------------------------------------------------------------------------------------------------------------------
     int k = 0, steps = 0;
     bool polished = false, solved = false, haveC = false;
-    double res_p = 0.0, res_d = 0.0;
-    const double* Cm = Cg;  // column cp = Cm + cp * P (symmetric); the LDS copy once a step needs it
+    double res_p = 0.0, res_d = 0.0, obj = 0.0;
     for (;;) {
-        __syncthreads();  // c_ final
-        double best, worst;
+        double best;
         int bid;
-        pass(best, bid, worst);
+        pass(best, bid);
         DAS_T(steps == 0 ? 2 : 3);  // first pass / later passes
         if (!(best < -kTolP)) {
-            res_p = fmax(0.0, -worst);
-            res_d = verify(k);
-            DAS_T(4);  // verification
+            res_p = fmax(0.0, -best);
+            finish(k, res_d, obj);
+            DAS_T(4);  // verification + objective
             if (res_d <= kTolD) {
                 solved = true;
                 break;
             }
             if (polished || k == 0) break;  // (never seen on the bench's classes; the interior-point kernel then solves the instance)
             // POLISH (a stationarity residual above the bar: rounding accumulated over many steps): the point rebuilt from its
-            // multipliers, c = c_u + W u -- stationary up to the table's rounding -- and one refinement of the multipliers that puts the
-            // active rows back at zero slack:  rho = h_A - A c,  du = S^-1 rho,  u += du,  c += W du.  Then every row is looked at again.
-            __syncthreads();
-            for (int e = tid; e < NX; e += T) {
-                double a = cu_[e];
-                for (int j = 0; j < k; j++) a += u_[j] * W_[(size_t)j * NX + e];
-                c_[e] = a;
+            // multipliers, c = c_u + sum u_j C a_j -- stationary up to the table's rounding -- and one refinement of the multipliers that
+            // puts the active rows back at zero slack:  rho = h_A - A c,  du = S^-1 rho,  u += du,  c += sum du_j C a_j.  Then every row
+            // is looked at again.
+            LSCQP_DAS_BARRIER();
+            add_columns(k, u_, cu_);
+            LSCQP_DAS_BARRIER();
+            if (wv == 0) {
+                const double rho = (lane < k) ? arhs_[lane] - row_dot(&aint_[4 * lane + 1], &acoef_[3 * lane], c_) : 0.0;
+                const double du = solve_factor(k, rho);
+                if (lane < k) u_[lane] += du;
             }
-            __syncthreads();
-            if (tid < k) v_[tid] = arhs_[tid] - row_dot(&aint_[4 * tid + 1], &acoef_[3 * tid], c_);
-            __syncthreads();
-            solve_factor(k, false);
-            __syncthreads();
-            if (tid < k) u_[tid] += r_[tid];
-            for (int e = tid; e < NX; e += T) {
-                double a = c_[e];
-                for (int j = 0; j < k; j++) a += r_[j] * W_[(size_t)j * NX + e];
-                c_[e] = a;
-            }
+            LSCQP_DAS_BARRIER();
+            add_columns(k, r_, nullptr);
+            LSCQP_DAS_BARRIER();
             polished = true;
             continue;
         }
         polished = false;
         if (k >= kmax) break;  // more active rows than this launch holds: the interior-point kernel's
-        if (cacheC && !haveC) {  // the table of this instance's ts in LDS from the first step on (every step reads up to three of its columns)
+        if (cacheC && !haveC) {  // the table of this instance's ts in LDS from the first step on (every step reads a few of its columns)
             for (int e = tid; e < P * P; e += T) Cc_[e] = Cg[e];
             haveC = true;
             Cm = Cc_;
-            __syncthreads();
+            LSCQP_DAS_BARRIER();  // (every thread reads columns other threads copied)
         }
         // ---- the candidate row p = bid, slot kmax of the descriptors ----
         Row Rp;
-        (void)decode(bid, Rp);
+        decode(bid, Rp);
         if (tid == 0) {
             aint_[4 * kmax] = bid;
-            for (int t = 0; t < 3; t++) aint_[4 * kmax + 1 + t] = Rp.idx[t], acoef_[3 * kmax + t] = Rp.coef[t];
+            for (int t = 0; t < 3; t++) aint_[4 * kmax + 1 + t] = Rp.ent[t], acoef_[3 * kmax + t] = Rp.coef[t];
             arhs_[kmax] = Rp.rhs;
+            ctl_[3] = 0.0;  // the candidate's multiplier so far
         }
-        // w_p = C a_p
+        // w_p = C a_p into slot k of W (every thread its control points); wavefront 0 needs only a_p'C a_p of it, which it computes itself
         for (int e = tid; e < NX; e += T) {
             const int kx = fdiv(e, iP), cp = e - kx * P;
-            double a = 0.0;
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                const int ix = Rp.idx[t], ik = fdiv(ix, iP);
-                if (Rp.coef[t] != 0.0 && ik == kx) a += Rp.coef[t] * Cm[(size_t)(ix - ik * P) * P + cp];
-            }
-            wp_[e] = a;
+            W_[(size_t)k * NX + e] = ccol(Rp.ent, Rp.coef, kx, cp, Cm, P);
         }
-        __syncthreads();
+        LSCQP_DAS_BARRIER();
         DAS_T(5);  // candidate: decode, table copy, w_p
-        const double spp = row_dot(Rp.idx, Rp.coef, wp_);
-        double up = 0.0;
+        const double spp = row_dot(Rp.ent, Rp.coef, W_ + (size_t)k * NX);
         bool stop = false;
         for (;;) {  // partial steps until p has joined the set
             steps++;
@@ -668,78 +797,96 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
                 stop = true;
                 break;
             }
-            // v = A'w_p, r = S^-1 v, dc = w_p - W r
-            if (k > 0) {
-                if (tid < k) v_[tid] = row_dot(&aint_[4 * tid + 1], &acoef_[3 * tid], wp_);
-                __syncthreads();
-                solve_factor(k, true);
-                __syncthreads();
+            // Wavefront 0 decides the step: v = A'w_p, r = S^-1 v, curvature a_p'w_p - v'r, dual bound t1, primal length t2.
+            if (wv == 0) {
+                const double vj = (lane < k) ? row_dot(&aint_[4 * lane + 1], &acoef_[3 * lane], W_ + (size_t)k * NX) : 0.0;
+                const double ri = solve_factor(k, vj);
+                const double vr = wave_sum((lane < k) ? vj * ri : 0.0);
+                const double yy = wave_sum((lane < k) ? y_[lane] * y_[lane] : 0.0);
+                const double curv = spp - vr;
+                const double sp = row_dot(Rp.ent, Rp.coef, c_) - Rp.rhs;
+                const double t2 = (curv > 1e-12 * spp) ? -sp / curv : 1e300;
+                double t1 = (lane < k && ri > 0.0) ? u_[lane] / ri : 1e300;
+                int l = lane;
+                wave_argmin(t1, l);
+                const double t = fmin(t1, t2);
+                int kind;  // 0: no step exists (hand over); 1: p joins; 2: row l leaves; 3: p joins but is dependent after all (hand over)
+                if (!(t < 1e299)) kind = 0;
+                else if (t2 <= t1) kind = (spp - yy > 1e-13 * spp) ? 1 : 3;
+                else kind = 2;
+                if (kind == 1 || kind == 2) {
+                    if (lane < k) u_[lane] = fmax(0.0, u_[lane] - t * ri);
+                    if (kind == 1) {  // one more row of the Gram matrix (v, spp) and of its factor (y, sqrt(spp - y'y))
+                        const double dl = sqrt(spp - yy);
+                        if (lane < k) Lm_[k * LDL + lane] = y_[lane], Sm_[k * LDL + lane] = vj;
+                        if (lane == 0) Lm_[k * LDL + k] = dl, linv_[k] = 1.0 / dl, Sm_[k * LDL + k] = spp, u_[k] = ctl_[3] + t;
+                    }
+                }
+                if (lane == 0) {
+                    ctl_[0] = t;
+                    ctl_[1] = (double)kind;
+                    ctl_[2] = (double)l;
+                    ctl_[3] += t;
+                    ctl_[5] = (t2 < 1e299) ? 1.0 : 0.0;  // a primal step is taken
+                }
             }
-            for (int e = tid; e < NX; e += T) {
-                double a = wp_[e];
-                for (int j = 0; j < k; j++) a -= r_[j] * W_[(size_t)j * NX + e];
-                dc_[e] = a;
-            }
-            __syncthreads();
-            const double curv = row_dot(Rp.idx, Rp.coef, dc_);
-            const double sp = row_dot(Rp.idx, Rp.coef, c_) - Rp.rhs;
-            const double t2 = (curv > 1e-12 * spp) ? -sp / curv : 1e300;
-            // t1 = min over the active rows with r_j > 0 of u_j / r_j (lowest j on ties): computed by wavefront 0 with the solve
-            const double t1 = (k > 0) ? red_[24] : 1e300;
-            const int l = (k > 0) ? (int)red_[25] : -1;
-            const double t = fmin(t1, t2);
-            if (!(t < 1e299)) {  // no step at all: the rows admit no point (INFEASIBLE is the interior-point kernel's verdict to give)
+            LSCQP_DAS_BARRIER();
+            const double t = ctl_[0];
+            const int kind = (int)ctl_[1], l = (int)ctl_[2];
+            if (kind == 0 || kind == 3) {
                 stop = true;
                 break;
             }
-            __syncthreads();  // everybody has read c_, u_, r_
-            if (t2 < 1e299) {
-                for (int e = tid; e < NX; e += T) c_[e] += t * dc_[e];
-            }
-            if (tid < k) u_[tid] = fmax(0.0, u_[tid] - t * r_[tid]);
-            up += t;
-            if (t2 <= t1) {
-                // p joins: W, descriptor, multiplier, one more row of the factor (y = Lm^-1 v is in y_)
-                double yy = 0.0;
-                for (int j = 0; j < k; j++) yy += y_[j] * y_[j];
-                const double dnew = spp - yy;
-                if (!(dnew > 1e-13 * spp)) {  // dependent on the active rows after all (rounding): leave it
-                    stop = true;
-                    break;
+            // c += t (w_p - sum r_j w_j)   (r_ holds this step's r); a leaving row closes the gap in W on the way (the candidate moves down too)
+            for (int e = tid; e < NX; e += T) {
+                if (ctl_[5] != 0.0) {
+                    double a = W_[(size_t)k * NX + e];
+                    for (int j = 0; j < k; j++) a -= r_[j] * W_[(size_t)j * NX + e];
+                    c_[e] += t * a;
                 }
-                for (int e = tid; e < NX; e += T) W_[(size_t)k * NX + e] = wp_[e];
+                if (kind == 2)
+                    for (int j = l; j < k; j++) W_[(size_t)j * NX + e] = W_[(size_t)(j + 1) * NX + e];
+            }
+            if (kind == 1) {
                 if (tid == 0) {
                     for (int t_ = 0; t_ < 4; t_++) aint_[4 * k + t_] = aint_[4 * kmax + t_];
                     for (int t_ = 0; t_ < 3; t_++) acoef_[3 * k + t_] = acoef_[3 * kmax + t_];
                     arhs_[k] = arhs_[kmax];
-                    u_[k] = up;
-                    const double dl = sqrt(dnew);
-                    for (int j = 0; j < k; j++) Lm_[k * LDL + j] = y_[j];
-                    Lm_[k * LDL + k] = dl;
-                    linv_[k] = 1.0 / dl;
                 }
                 k++;
+                LSCQP_DAS_BARRIER();
                 break;
             }
-            // row l leaves: close the gap in W, descriptors, multipliers; factor from scratch
-            __syncthreads();
-            for (int e = tid; e < NX; e += T) {
-                for (int j = l; j + 1 < k; j++) W_[(size_t)j * NX + e] = W_[(size_t)(j + 1) * NX + e];
-            }
-            if (tid == 0) {
-                for (int j = l; j + 1 < k; j++) {
-                    for (int t_ = 0; t_ < 4; t_++) aint_[4 * j + t_] = aint_[4 * (j + 1) + t_];
-                    for (int t_ = 0; t_ < 3; t_++) acoef_[3 * j + t_] = acoef_[3 * (j + 1) + t_];
-                    arhs_[j] = arhs_[j + 1];
-                    u_[j] = u_[j + 1];
+            // row l leaves: close the gap in descriptors, multipliers and the Gram matrix (wavefront 0), then its factor from scratch
+            if (wv == 0) {
+                if (lane == 0) {
+                    for (int j = l; j + 1 < k; j++) {
+                        for (int t_ = 0; t_ < 4; t_++) aint_[4 * j + t_] = aint_[4 * (j + 1) + t_];
+                        for (int t_ = 0; t_ < 3; t_++) acoef_[3 * j + t_] = acoef_[3 * (j + 1) + t_];
+                        arhs_[j] = arhs_[j + 1];
+                        u_[j] = u_[j + 1];
+                    }
                 }
+                // lane i = row i of the new matrix: entry (i, j) comes from (i + [i >= l], j + [j >= l])
+                const int i = lane, si = i + (i >= l ? 1 : 0);
+                LSCQP_DAS_WAVE_SYNC();
+                if (i < k - 1) {
+                    for (int j = 0; j <= i; j++) {
+                        const int sj = j + (j >= l ? 1 : 0);
+                        const double sv = Sm_[si * LDL + sj];
+                        Lm_[i * LDL + j] = sv;  // parked in the factor's storage: rows are rewritten in place only after every lane has read
+                    }
+                }
+                LSCQP_DAS_WAVE_SYNC();
+                if (i < k - 1)
+                    for (int j = 0; j <= i; j++) Sm_[i * LDL + j] = Lm_[i * LDL + j];
+                LSCQP_DAS_WAVE_SYNC();
             }
             k--;
-            __syncthreads();
             const bool okf = factor_scratch(k);
-            if (wv == 0 && lane == 0) ctl_[1] = okf ? 0 : 1;
-            __syncthreads();
-            if (ctl_[1]) {
+            if (wv == 0 && lane == 0) ctl_[6] = okf ? 0.0 : 1.0;
+            LSCQP_DAS_BARRIER();
+            if (ctl_[6] != 0.0) {
                 stop = true;
                 break;
             }
@@ -747,38 +894,13 @@ __global__ __launch_bounds__(256) void das_kernel(DevClass cls, int M, int dim, 
         DAS_T(6);  // the partial steps of the candidate
         if (stop) break;
     }
-    __syncthreads();
     if (!solved) {
         hand_over(steps);
         return;
     }
 
-    // ---- epilogue: objective exactly as cplex.getObjValue() reports it (as lscqp_kernel.hpp), control points in the world frame ------------
-    double part = 0.0;
-    for (int lv = tid; lv < dim * M; lv += T) {
-        const int kx = lv / M, m = lv % M;
-        const double* cc = &c_[kx * P + 6 * m];
-        const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
-        const double j1 = (cc[4] - cc[1]) - 3.0 * (cc[3] - cc[2]);
-        const double j2 = (cc[5] - cc[2]) - 3.0 * (cc[4] - cc[3]);
-        const double quad = 0.2 * (j0 * j0 + j2 * j2) + (2.0 / 15.0) * j1 * j1 + 0.2 * (j0 * j1 + j1 * j2) + (1.0 / 15.0) * j0 * j2;
-        double pp = 0.5 * q2s * 3600.0 * quad;
-        const double ok_ = org[kx];
-        double corr = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double r = 0;
-#pragma unroll
-            for (int ip = 0; ip < 6; ip++) r += cls.dQ[i * 6 + ip] * (cc[ip] + ok_);
-            corr += r * (cc[i] + ok_);
-        }
-        pp += cls.w_c * corr;
-        const double dgoal = cc[5] - goal[kx];
-        pp += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
-        part += pp;
-    }
-    const double obj = block_sum(part);
-    for (int e = tid; e < NX; e += T) x_out[q * NX + e] = c_[e] + org[e / P];
+    // ---- epilogue: control points in the world frame ---------------------------------------------------------------------------------
+    for (int e = tid; e < NX; e += T) x_out[q * NX + e] = c_[e] + org[fdiv(e, iP)];
     if (tid == 0) {
         obj_out[q] = obj;
         status_out[q] = LSCQP_STATUS_OPTIMAL;
@@ -913,13 +1035,22 @@ extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int di
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lscqp_das::das_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)lscqp::kMaxLdsBytes);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(lscqp_das::das_kernel<1, false>), reinterpret_cast<const void*>(lscqp_das::das_kernel<2, false>),
+                              reinterpret_cast<const void*>(lscqp_das::das_kernel<4, false>), reinterpret_cast<const void*>(lscqp_das::das_kernel<1, true>),
+                              reinterpret_cast<const void*>(lscqp_das::das_kernel<2, true>), reinterpret_cast<const void*>(lscqp_das::das_kernel<4, true>)}) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lscqp::kMaxLdsBytes);
+            if (e != hipSuccess) return e;
+        }
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lscqp_das::das_kernel, dim3((unsigned)n), dim3((unsigned)threads), lds, stream, *cls, M, dim, es, cap, kmax, max_steps, cacheC, stage_rows, d_tab, n,
-                       hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out);
+#define LSCQP_DAS_LAUNCH(NW_, F_)                                                                                                                              \
+    hipLaunchKernelGGL((lscqp_das::das_kernel<NW_, F_>), dim3((unsigned)n), dim3(64 * NW_), lds, stream, *cls, M, dim, es, cap, kmax, max_steps, cacheC, stage_rows, \
+                       d_tab, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out)
+    const bool f32 = cls->rows_f32 != 0;
+    if (threads == 64) { if (f32) LSCQP_DAS_LAUNCH(1, true); else LSCQP_DAS_LAUNCH(1, false); }
+    else if (threads == 128) { if (f32) LSCQP_DAS_LAUNCH(2, true); else LSCQP_DAS_LAUNCH(2, false); }
+    else { if (f32) LSCQP_DAS_LAUNCH(4, true); else LSCQP_DAS_LAUNCH(4, false); }
+#undef LSCQP_DAS_LAUNCH
     return hipGetLastError();
 }

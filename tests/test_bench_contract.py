@@ -30,7 +30,13 @@ def test_bench_prints_one_contract_line():
     assert b["parity"]["max_rel_dobj"] <= 1e-8 and b["parity"]["max_abs_dx"] <= 1e-6
     # BASELINE's metric has two halves: the p99 latency and the roof that binds travel inside objects the driver keeps
     assert b["config"]["latency_ms"]["p99"] >= b["config"]["latency_ms"]["p50"] > 0 and b["config"]["latency_ms"]["calls"] >= 1000
-    assert 0 < r["fp64_valu"]["frac"] < 1 and b["config"]["baseline_config"] == "c1" and b["config"]["batch_seed"] == 1000
+    # round 5: which kernel finished what (the dual active-set phase in front, the interior-point kernel behind it); the fp64 vector roofline is
+    # the interior-point kernel's and is only there when that kernel solved something
+    pth = b["solver"]["paths"]
+    assert pth["active_set_solved"] + pth["interior_point_solved"] == 64 and pth["active_set_solved"] > 0
+    assert ("das_kernel" in r["kernel"]) == (pth["active_set_solved"] >= 32) and r["kernel_ms"] > 0 and r["step_gpu_ms"] >= 0.5 * r["kernel_ms"]
+    assert ("fp64_valu" in r) == (pth["interior_point_solved"] > 0) and (pth["interior_point_solved"] == 0 or 0 < r["fp64_valu"]["frac"] < 1)
+    assert b["config"]["baseline_config"] == "c1" and b["config"]["batch_seed"] == 1000
     # value is whole-job throughput of the timed steps
     assert abs(b["value"] - 64 * 1e3 / b["ms_per_step"]) <= 1e-6 * b["value"]
 

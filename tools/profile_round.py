@@ -65,9 +65,10 @@ def profile_config(c):
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--"] + bench_cmd(c), "%s_%s_trace.log" % (tag, c))
     bj = last_json(os.path.join(OUT, "%s_%s_trace.log" % (tag, c)))
     res["bench_under_rocprof"] = bj and {k: bj.get(k) for k in ("value", "ms_per_step", "roofline", "roofline_valu", "solver", "config")}
+    res["phase"] = "off" if os.environ.get("LSCQP_ACTIVE_SET", "1")[:1] == "0" else "dual active-set phase + interior point behind it"
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
-        keep = [rows[0]] + [r for r in rows[1:] if "lscqp_pdip_kernel" in r[0]]
+        keep = [rows[0]] + [r for r in rows[1:] if "lscqp_pdip_kernel" in r[0] or "das_kernel" in r[0]]
         with open(os.path.join(OUT, "%s_%s_kernel_stats.csv" % (tag, c)), "w", newline="") as g:
             csv.writer(g, quoting=csv.QUOTE_ALL).writerows(keep)
         res["kernel_stats"] = [dict(zip(rows[0], r)) for r in keep[1:]]
@@ -76,7 +77,7 @@ def profile_config(c):
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
-            if "lscqp_pdip_kernel" in r["Kernel_Name"] and timed_shape(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])):
+            if ("lscqp_pdip_kernel" in r["Kernel_Name"] or "das_kernel" in r["Kernel_Name"]) and timed_shape(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])):
                 per.setdefault(r["Kernel_Name"], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         res["timed_launches"] = {}
         for k, v in per.items():
@@ -91,7 +92,7 @@ def profile_config(c):
         acc, disp = {}, {}
         for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if "lscqp_pdip_kernel" not in r["Kernel_Name"] or not timed_shape(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"])):
+                if ("lscqp_pdip_kernel" not in r["Kernel_Name"] and "das_kernel" not in r["Kernel_Name"]) or not timed_shape(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"])):
                     continue
                 kn = r["Kernel_Name"]
                 acc.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -107,9 +108,10 @@ def profile_config(c):
     ic, _ = pmc(["SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQC_ICACHE_MISSES_DUPLICATE"], "icache")
     ic2, _ = pmc(["SQC_TC_INST_REQ", "SQ_IFETCH", "SQ_WAIT_ANY", "SQ_WAVES"], "ifetch")
     fl, _ = pmc(["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_WAVES"], "f64")
-    kernels = sorted(disp)  # mixed precision: the float instance and the fp64 second pass
-    main = next((k for k in kernels if "float" in k), kernels[0] if kernels else None)
+    kernels = sorted(disp)  # the dual active-set kernel, the interior-point instance behind it (mixed precision: the float instance and the fp64 second pass)
+    main = next((k for k in kernels if "das_kernel" in k), next((k for k in kernels if "float" in k), kernels[0] if kernels else None))
     res.update({"kernels": kernels, "kernel": main, "qps_per_launch": N, "lsc_neighbours": bj and bj["config"]["lsc_neighbours"],
+                "segments": bj and bj["config"]["segments"], "dim": bj and bj["config"]["dim"],
                 "dispatch": disp.get(main), "dispatch_all": disp, "sq": sq.get(main), "sq_all": sq,
                 "icache": dict(ic.get(main) or {}, **(ic2.get(main) or {})), "f64_insts": fl.get(main),
                 "FETCH_SIZE_KB_raw": {k: v.get("FETCH_SIZE") for k, v in fetch.items()},
@@ -135,11 +137,23 @@ def profile_config(c):
         raw_w = 1024.0 * sum(v.get("WRITE_SIZE", 0.0) for v in write.values())
         nv = bj["config"]["dim"] * bj["config"]["segments"] * 6
         in_bytes = alg - N * (8 * nv + 16)
-        # every input byte is read exactly once (rows at 32 or 16 B/lane stride, headers, boxes, offsets, initial trajectories):
-        # if the raw counter already equals that volume the factor is 1, otherwise the guide's 2
-        cal = 1.0 if in_bytes and abs(raw_f - in_bytes) <= 0.15 * in_bytes else 2.0
-        res["fetch_calibration"] = {"factor": cal, "known_input_bytes": in_bytes, "raw_fetch_bytes": raw_f}
-        res["traffic_bytes_per_launch"] = cal * raw_f + raw_w
+        # Every input byte is read once per launch by the kernel that dominates (the dual active-set kernel reads rows, header, boxes,
+        # offset; the interior-point pass behind it reads only statuses).  The guide's correction -- contiguous 16 B/lane streaming reads
+        # are tallied at half their size on gfx950 -- concerns the ROW stream only (dwordx4 loads); headers, boxes, tables and instruction
+        # fetch are counted as they are.  So the raw counter is compared with the two volumes it can stand for and corrected by exactly
+        # the rows' missing half when it matches the second; a counter that matches neither is reported RAW with that said (never "x 2").
+        row_b = 16 if (bj["config"].get("row_format") == "f32") else 32
+        rows_bytes = N * bj["config"]["lsc_neighbours"] * bj["config"]["segments"] * 6 * row_b
+        full, half = in_bytes, in_bytes - 0.5 * rows_bytes
+        if in_bytes and abs(raw_f - full) <= 0.15 * full:
+            corr, how = raw_f, "as counted (matches the input volume)"
+        elif in_bytes and abs(raw_f - half) <= 0.15 * half:
+            corr, how = raw_f + 0.5 * rows_bytes, "row stream tallied at half its size: + rows / 2"
+        else:
+            corr, how = raw_f, "uncalibrated: the raw counter matches neither the input volume nor the volume with the row stream at half; reported raw"
+        res["fetch_calibration"] = {"how": how, "known_input_bytes": in_bytes, "row_stream_bytes": rows_bytes, "raw_fetch_bytes": raw_f,
+                                    "instruction_bytes_from_L2": res["icache"].get("inst_bytes_from_L2_per_launch")}
+        res["traffic_bytes_per_launch"] = corr + raw_w
         if main in res.get("timed_launches", {}):
             t = sum(v["avg_ns"] for v in res["timed_launches"].values()) * 1e-9
             res["roofline_from_trace"] = {"step_time_s": t, "achieved_GBps": alg / t / 1e9, "frac_of_8TBps": alg / t / 8.0e12}
