@@ -293,8 +293,10 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
  * without a start trajectory -- a factorisation that breaks down in one order usually survives in the other; that instance costs
  * ~35 us to launch even with nothing to repair, so it is not what retry == 1 does.  retry == 2 also ends with the RESCUE pass
  * (LSCQP_INFO_RESCUED: instances still at the iteration limit / a numerical breakdown, on the run-time-shaped kernel with a weighted
- * corrector).  The host-pointer entries run both by themselves, and only for batches that still hold such an instance after the
- * first call.
+ * corrector).  retry == 3: the second pass from the default start AND the rescue pass, without the other-order pass -- two launches that
+ * return at once for every instance already OPTIMAL (each tests the status before it fetches anything); what lscqp_plan's chain enqueues
+ * in every replan (the reference tries a failed QP again on the spot, src/traj_planner.cpp:763-766).  Other values: LSCQP_ERR_INVALID_ARGUMENT.
+ * The host-pointer entries run both by themselves, and only for batches that still hold such an instance after the first call.
  * In LSCQP_PRECISION_MIXED the fp64 second pass always runs. */
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,

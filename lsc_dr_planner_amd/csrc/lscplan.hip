@@ -305,8 +305,10 @@ int enqueue(lscqp_plan_s* p, bool first_replan, hipStream_t stream) {
         PLAN_TRY(lscqp_order_by_work_device(s.n_agents, info, p->order, stream));
         order = p->order;
     }
+    // retry = 3: the reference tries a failed QP again on the spot (src/traj_planner.cpp:763-766) -- here a second pass from the default start and
+    // the RESCUE pass behind it are always enqueued (each returns per instance on OPTIMAL: two near-empty launches when nothing failed)
     PLAN_TRY(lscqp_solve_batch_device_ordered(p->hq, s.n_agents, s.n_obs, hdr, rows, p->off, p->map ? sfc : nullptr, p->x_init, p->x_new, obj,
-                                              status, info, 1, order, stream));
+                                              status, info, 3, order, stream));
     {   // commit (failsafe of trajOptimization, prev_traj = desired_traj, the goal point carried over) + isSolValid + doStep: one launch
         const lscqp_class_desc* cd = lscqp_class_desc_of_(h);
         if (cd->use_sfc && !p->map) return lscqp_set_error_(LSCQP_ERR_INVALID_ARGUMENT, "the class has corridor rows but the plan has no map");

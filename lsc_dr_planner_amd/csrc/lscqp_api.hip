@@ -919,6 +919,10 @@ int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t
     return LSCQP_OK;
 }
 
+int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                       const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out, double* d_obj_out,
+                                       int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream);
+
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                                 const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
@@ -931,7 +935,19 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                                      const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
                                      lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream) {
+    if (retry < 0 || retry > 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "retry must be 0, 1, 2 or 3");
+    return lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out,
+                                              retry, d_order, stream);
+}
+
+// The worker behind the public device entries.  retry also takes the library's own pass codes: -2 = only the repair pass on the instance of
+// the other elimination order, -3 = only the rescue pass (the host-pointer entries and lscqp_comm.hip run them after looking at the statuses).
+int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
+                                       const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
+                                       const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
+                                       lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (retry < -3 || retry > 3 || retry == -1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "invalid pass code");
     if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
     if (!d_hdr || !d_x_out || !d_obj_out || !d_status_out || (n_obs_max > 0 && (!d_rows || !d_row_offsets)) ||
@@ -1025,7 +1041,7 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      d_info_out, (hipStream_t)stream);
             if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (run-time-shaped kernel, second pass): ") + hipGetErrorString(e));
         }
-        if (retry == 2) {
+        if (retry == 2 || retry == 3) {
             cls.repair = 2;
             e = lscqp_launch_generic(&cls, h->desc.M, h->desc.dim, h->es, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out,
                                      d_info_out, (hipStream_t)stream);
@@ -1075,7 +1091,7 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));
     }
-    if (retry == 2) return rescue();
+    if (retry == 2 || retry == 3) return rescue();
     return LSCQP_OK;
 }
 
@@ -1164,7 +1180,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
         for (int64_t q = 0; q < n && !any; q++) any = st_h[q] != LSCQP_STATUS_OPTIMAL && st_h[q] != LSCQP_STATUS_CAPACITY;
         const Inst* first = any ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : nullptr;
         if (first && other_order_instance(first, n_obs_max)) {
-            rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, st);
+            rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, nullptr, st);
             if (rc != LSCQP_OK) return rc;
             LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));
@@ -1174,7 +1190,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
         bool lim = false;
         for (int64_t q = 0; q < n && !lim; q++) lim = st_h[q] == LSCQP_STATUS_ITER_LIMIT || st_h[q] == LSCQP_STATUS_NUMERIC;
         if (lim && n_obs_max <= lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) {
-            rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -3, st);
+            rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -3, nullptr, st);
             if (rc != LSCQP_OK) return rc;
             LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));

@@ -27,6 +27,9 @@
 extern "C" int lscqp_set_error_(int code, const char* msg);
 extern "C" const lscqp_plan_desc* lscqp_plan_desc_of_(lscqp_plan p);  // lscplan.hip
 extern "C" int lscqp_plan_device_(lscqp_plan p);
+extern "C" int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                                  const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out, double* d_obj_out,
+                                                  int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream);
 extern "C" int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max);
 
 namespace {
@@ -384,10 +387,10 @@ int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lsc
                 const uint64_t r0 = n_obs_max > 0 ? row_offsets[S.first] : 0, r1 = n_obs_max > 0 ? row_offsets[S.first + S.cnt] : 0;
                 const size_t b_rows = al(rb * (size_t)(r1 - r0)), b_off = al(sizeof(uint64_t) * (S.cnt + 1));
                 const size_t o_rows = b_hdr, o_off = o_rows + b_rows, o_sfc = o_off + b_off;
-                rc = lscqp_solve_batch_device_ex(h, S.cnt, n_obs_max, (const lscqp_header*)db, (const lscqp_row*)(db + o_rows),
+                rc = lscqp_solve_batch_device_internal_(h, S.cnt, n_obs_max, (const lscqp_header*)db, (const lscqp_row*)(db + o_rows),
                                                  (const uint64_t*)(db + o_off), use_sfc ? (const lscqp_box*)(db + o_sfc) : nullptr, nullptr,
                                                  (double*)(db + S.o_x), (double*)(db + S.o_obj), (int32_t*)(db + S.o_st),
-                                                 (lscqp_info*)(db + S.o_info), -2, c->stream[g]);
+                                                 (lscqp_info*)(db + S.o_info), -2, nullptr, c->stream[g]);
                 if (rc == LSCQP_OK && hipMemcpyAsync(hb2 + S.b_in, db + S.b_in, S.b_out, hipMemcpyDeviceToHost, c->stream[g]) != hipSuccess)
                     rc = fail(LSCQP_ERR_HIP, "hipMemcpyAsync (D2H) failed");
                 if (rc == LSCQP_OK && (e = hipStreamSynchronize(c->stream[g])) != hipSuccess)

@@ -448,6 +448,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_k
         double bv = 1e300;
         int bi = 0x7fffffff;
         auto see = [&](double slack, int id) {
+            // (a NaN slack -- NaN in a row, in the header, in the point -- must never read as "satisfied": it becomes the most violated row
+            // there is; the step for it finds no length and the instance goes to the interior-point kernel, which answers NUMERIC)
+            slack = (slack == slack) ? slack : -1e308;
             const bool lt = slack < bv;  // (ids ascend within a thread: the first minimum is the lowest id)
             bv = lt ? slack : bv;
             bi = lt ? id : bi;
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_k
 #pragma unroll
             for (int w = 1; w < NW; w++) rd = fmax(rd, rb_[w]), gs = fmax(gs, rb_[4 + w]), part += rb_[8 + w];  // (fixed order: reproducible)
         }
-        res_d = rd / fmax(1.0, gs);
+        res_d = (part == part && fabs(part) < 1e300) ? rd / fmax(1.0, gs) : 1e300;  // (a non-finite objective is not a pass)
         obj = part;
     };
 

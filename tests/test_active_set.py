@@ -207,3 +207,24 @@ def test_the_phase_is_repeatable_bit_for_bit(api, oracle, torch_cuda, solver_pat
                 assert np.array_equal(r["x"], runs[0]["x"]) and np.array_equal(r["obj"], runs[0]["obj"])
                 assert np.array_equal(r["info"]["iterations"], runs[0]["info"]["iterations"]) and np.array_equal(r["status"], runs[0]["status"])
             sw.advance(runs[0]["x"])
+
+
+@pytest.mark.gpu
+def test_nan_in_the_inputs_is_never_an_optimal_plan(api, oracle, torch_cuda, solver_path):
+    """Garbage in: a NaN in an instance's header or in one of its rows must not come back LSCQP_STATUS_OPTIMAL (comparisons with NaN are
+    false: a row whose slack is NaN would otherwise read as satisfied).  The neighbours in the batch are solved as usual."""
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim = 12, 5, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=8, seed=9)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    b = sw.build()
+    hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+    hdr, rows = hdr.copy(), rows.copy()
+    hdr["v0"][3][1] = np.nan                       # instance 3: its state
+    rows["b"][int(roff[7]) + 2 * M * 6 + 17] = np.nan  # instance 7: one row of its third neighbour
+    hdr["goal"][9][0] = np.inf                     # instance 9: its goal
+    G = sol.solve_host(hdr, rows, roff, sfcp)
+    bad = np.array([3, 7, 9])
+    assert (G["status"][bad] != 0).all(), G["status"]
+    assert (np.delete(G["status"], bad) == 0).all() and np.isfinite(np.delete(G["x"], bad, axis=0)).all()

@@ -4,7 +4,7 @@ factorisation cannot finish are re-solved by the fp64 kernel inside the same cal
 
   objective     |obj_gpu - obj_oracle| <= 1e-8 * max(1, |obj|)
   control points max |dx| <= 1e-6 m
-  solver's own fp64 residuals: primal <= 1e-9 m, scaled stationarity <= 1e-8 (1e-6 only with LSCQP_INFO_FLOOR_ACCEPTED)
+  solver's own fp64 residuals: primal <= 1e-9 m, scaled stationarity <= 1e-8 (round 5: no floor acceptance in mixed precision any more: such instances go to the fp64 second pass)
 
 plus the status / flag contract of the second pass, and the capacity status that replaced the silent row truncation.
 """
@@ -33,7 +33,7 @@ def _solve_all(api, oracle, sw, M, dim, precision, steps, check_oracle=True, x_w
         assert G["info"]["res_primal"].max() <= 1e-9
         strict = (G["info"]["flags"] & api.INFO_FLOOR_ACCEPTED) == 0
         assert G["info"]["res_dual"][strict].max(initial=0.0) <= 1e-8
-        assert G["info"]["res_dual"].max() <= 1e-6
+        assert G["info"]["res_dual"].max() <= 1e-8 and ((G["info"]["flags"] & api.INFO_FLOOR_ACCEPTED) == 0).all()
         if check_oracle:
             R = oracle.solve_batch(cls, ag, lsc, off, sfc, threads=8)
             assert (R["status"] == 0).all()
@@ -86,7 +86,7 @@ def test_configs4_full_size_4096_agents(api, oracle):
         dx = np.abs(G64["x"] - GMX["x"]).max()
         do = (np.abs(G64["obj"] - GMX["obj"]) / np.maximum(1.0, np.abs(G64["obj"]))).max()
         assert dx <= X_TOL and do <= OBJ_TOL, (step, dx, do)
-        assert GMX["info"]["res_primal"].max() <= 1e-9 and GMX["info"]["res_dual"].max() <= 1e-6
+        assert GMX["info"]["res_primal"].max() <= 1e-9 and GMX["info"]["res_dual"].max() <= 1e-8
         # iterations: with cond(Hred) ~ 2e5 a float32 solve carries a relative residual of ~1e-2, i.e. the dual residual shrinks
         # ~100x per iteration instead of quadratically: about two more iterations than fp64 on this class (measured 5.1 vs 3.1)
         assert GMX["info"]["iterations"].mean() <= G64["info"]["iterations"].mean() + 3.0

@@ -30,6 +30,7 @@ if "--nd" in sys.argv:  # the shapes of round 3's nested-dissection instances (M
 if "--shape" in sys.argv:
     shapes = [shapes[int(sys.argv[sys.argv.index("--shape") + 1])]]
 bad_total = tol_total = 0
+n_kkt_ok = 0
 for (N, M, dim, n_obs, style) in shapes:
     worst_dx = worst_do = 0.0
     iters = []
@@ -75,6 +76,16 @@ for (N, M, dim, n_obs, style) in shapes:
                         (" | against the oracle at tol 1e-14: dx %.2e" % dx_tight[q]) if (dx_tight is not None and both[q]) else ""))
                     if dx_tight is not None and both[q] and dx_tight[q] <= 1e-6:
                         n_oracle_tol += 1
+                    if G["status"][q] == 0 and R["status"][q] != 0:
+                        # the GPU returned a plan where the oracle gave up: is it a KKT point of the reference's row-for-row model?
+                        lq = np.ascontiguousarray(lsc.reshape(N, -1)[q]); sq = np.ascontiguousarray(sfco.reshape(N, -1)[q])
+                        try:
+                            stat, eqv, iqv = H.kkt_from_primal(O, cls, ag[q:q + 1], lq, sq, G["x"][q])
+                            n_kkt_ok += int(max(stat, eqv, iqv) <= 1e-8)
+                            print("      ... the GPU point on the reference's model: stationarity %.1e, equality violation %.1e, inequality violation %.1e (flags %d)" % (
+                                stat, eqv, iqv, G["info"]["flags"][q]))
+                        except Exception as ex:  # noqa: BLE001
+                            print("      ... KKT check failed:", type(ex).__name__, str(ex)[:120])
             if both.any():
                 worst_dx = max(worst_dx, dx[both].max())
                 worst_do = max(worst_do, do[both].max())
@@ -85,4 +96,5 @@ for (N, M, dim, n_obs, style) in shapes:
     tol_total += n_oracle_tol
     print("%-28s seeds %d: mismatches %d (%d within 1e-6 m of the oracle at tol 1e-14), max dx %.2e, max rel dobj %.2e, iterations mean %.2f max %d, non-optimal on both sides %d" % (
         str((N, M, dim, n_obs, style)), n_seeds, nbad, n_oracle_tol, worst_dx, worst_do, it.mean(), it.max(), n_both_bad))
+print("GPU-optimal / oracle-failed instances that are KKT points of the reference's model to 1e-8:", n_kkt_ok)
 print("TOTAL mismatches", bad_total, "of which within 1e-6 m of the oracle converged to 1e-14 (the default-tolerance oracle's x was the loose one):", tol_total)
