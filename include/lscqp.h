@@ -321,6 +321,9 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
 /* instances of a launch of n the device works on at once (CUs x workgroups per CU of the kernel instance the launch selects); a launch of
  * more runs in rounds and has a tail -- that is where the order pays.  -1 without a device. */
 int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max);
+/* instances ONE device works on at once in the FIRST kernel of a solve of this class: the dual active-set phase's resident workgroups when
+ * the phase is on, lscqp_launch_capacity otherwise.  -1 without a device. */
+int64_t lscqp_device_fill(lscqp_handle h, int64_t n, int32_t n_obs_max);
 int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t* d_order_out, void* stream);
 int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
                                      const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out,
@@ -341,6 +344,11 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
  *                            device (0.108 vs 0.136 ms at M = 5), so spreading a small batch buys nothing and only adds the
  *                            exchange; north_star: "only when agent count justifies it".  lscqp_comm_set_min_agents_per_device
  *                            moves the threshold (1 = always use every device).
+ *   lscqp_comm_devices_for_class   the rule lscqp_solve_batch_sharded applies (round 5), with the class in hand: clamp(n / fill, 1, G),
+ *                            fill = lscqp_device_fill(h, n, n_obs_max) = the instances ONE device works on at once in the first
+ *                            kernel of a solve (the dual active-set phase's resident workgroups, or lscqp_launch_capacity without
+ *                            the phase): a second device is used only where one would need a second round.  A threshold set with
+ *                            lscqp_comm_set_min_agents_per_device overrides it.
  *   lscqp_comm_shard         the block [first, first + count) of device g when n agents are spread over n_used devices
  *   lscqp_solve_batch_sharded        HOST pointers for the whole batch (same arguments as lscqp_solve_batch): every block is staged
  *                            to its device, solved there (with the retry pass) and fetched back, all devices concurrently, each
@@ -362,6 +370,7 @@ void* lscqp_comm_stream(lscqp_comm c, int32_t g); /* hipStream_t of device g */
 const char* lscqp_comm_backend(lscqp_comm c);
 int lscqp_comm_set_min_agents_per_device(lscqp_comm c, int64_t n);
 int32_t lscqp_comm_devices_for(lscqp_comm c, int64_t n);
+int32_t lscqp_comm_devices_for_class(lscqp_comm c, lscqp_handle h, int64_t n, int32_t n_obs_max);
 int lscqp_comm_shard(lscqp_comm c, int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count);
 /* the same partition rule without a communicator (no device needed): block g of n agents over n_used devices */
 int lscqp_shard_range(int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count);

@@ -145,6 +145,10 @@ def lib():
         L.lscqp_comm_set_min_agents_per_device.argtypes = [vp, C.c_int64]
         L.lscqp_comm_devices_for.restype = C.c_int32
         L.lscqp_comm_devices_for.argtypes = [vp, C.c_int64]
+        L.lscqp_comm_devices_for_class.restype = C.c_int32
+        L.lscqp_comm_devices_for_class.argtypes = [vp, vp, C.c_int64, C.c_int32]
+        L.lscqp_device_fill.restype = C.c_int64
+        L.lscqp_device_fill.argtypes = [vp, C.c_int64, C.c_int32]
         L.lscqp_comm_shard.restype = C.c_int
         L.lscqp_comm_shard.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, vp, vp]
         L.lscqp_shard_range.restype = C.c_int
@@ -239,7 +243,7 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_launch_capacity", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
                     "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
-                    "lscqp_comm_devices_for", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
+                    "lscqp_comm_devices_for", "lscqp_comm_devices_for_class", "lscqp_device_fill", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_shift_traj_partial_device", "lscqp_generate_constraints_device_ex",
                     "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
@@ -496,6 +500,9 @@ class Comm:
     def devices_for(self, n):
         return lib().lscqp_comm_devices_for(self._h, int(n))
 
+    def devices_for_class(self, solver, n, n_obs_max):
+        return lib().lscqp_comm_devices_for_class(self._h, solver._h, int(n), int(n_obs_max))
+
     def stream(self, g):
         return lib().lscqp_comm_stream(self._h, g)
 
@@ -700,6 +707,10 @@ class Solver:
                                                     p(d_obj), p(d_status), p(d_info), int(retry), p(d_order), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def device_fill(self, n, n_obs_max):
+        """lscqp_device_fill: instances one device works on at once in the first kernel of a solve of this class."""
+        return lib().lscqp_device_fill(self._h, int(n), int(n_obs_max))
 
     def launch_capacity(self, n, n_obs_max):
         """lscqp_launch_capacity: instances of a launch of n the device works on at once (-1 without a device)."""

@@ -534,6 +534,21 @@ int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max) {
     return (int64_t)n_cu * (per_cu < 1 ? 1 : per_cu);
 }
 
+// Instances ONE device works on at once in the first kernel of a solve of this class (include/lscqp.h): with the dual active-set phase on,
+// the phase's one-wavefront form at the occupancy the runtime reports for its LDS footprint; otherwise lscqp_launch_capacity.
+extern "C" int lscqp_das_blocks_per_cu(int M, int dim, int kmax, int rows_f32);
+int64_t lscqp_device_fill(lscqp_handle h, int64_t n, int32_t n_obs_max) {
+    if (!h || n < 0 || n_obs_max < 0) return -1;
+    const int n_cu = cu_count();
+    if (n_cu <= 0) return -1;
+    static const bool das_env_off = [] { const char* v = getenv("LSCQP_ACTIVE_SET"); return v && v[0] == '0'; }();
+    if (h->desc.active_set != LSCQP_ACTIVE_SET_OFF && !das_env_off && h->das && !h->das->host.empty()) {
+        const int per_cu = lscqp_das_blocks_per_cu(h->desc.M, h->desc.dim, 8, h->dev.rows_f32);
+        if (per_cu > 0) return (int64_t)n_cu * per_cu;
+    }
+    return lscqp_launch_capacity(h, n, n_obs_max);
+}
+
 // Work counters of the kernel instance a launch would select (include/lscqp.h): the per-wavefront instruction counts come from the
 // table the build reads off each instance's machine code (lsc_dr_planner_amd/isa_work.py -> lscqp_work_table_, generated TU).
 extern "C" int lscqp_work_table_(int M, int D, int E, int S, int W, int X, double* out24);

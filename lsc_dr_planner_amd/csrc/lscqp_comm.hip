@@ -92,6 +92,7 @@ struct lscqp_comm_s {
     std::vector<ncclComm_t> comms;
     std::string backend;
     int64_t min_agents_per_device = 256;  // see lscqp_comm_devices_for
+    bool min_agents_set = false;          // the caller named the threshold: it overrides the class's own (lscqp_comm_devices_for_class)
     std::mutex mu;                        // one sharded call at a time per communicator (RCCL groups must not interleave)
 };
 
@@ -182,12 +183,30 @@ const char* lscqp_comm_backend(lscqp_comm c) { return c ? c->backend.c_str() : "
 int lscqp_comm_set_min_agents_per_device(lscqp_comm c, int64_t n) {
     if (!c || n < 1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null communicator or n < 1");
     c->min_agents_per_device = n;
+    c->min_agents_set = true;
     return LSCQP_OK;
 }
 
 int32_t lscqp_comm_devices_for(lscqp_comm c, int64_t n) {
     if (!c) return -1;
     int64_t g = n / c->min_agents_per_device;
+    if (g < 1) g = 1;
+    if (g > c->G) g = c->G;
+    return (int32_t)g;
+}
+
+// The spreading rule with the class in hand (round 5): a device is given work only where ONE device would need more than one round of
+// workgroups for the batch -- lscqp_device_fill(h) instances are in flight on a device at once (3072 with the dual active-set phase at
+// M = 5, one launch of which lasts ~50 us for 4096 QPs: far below the cost of an exchange over xGMI) -- clamp(n / fill, 1, G).  A threshold
+// the caller set with lscqp_comm_set_min_agents_per_device overrides it.
+int32_t lscqp_comm_devices_for_class(lscqp_comm c, lscqp_handle h, int64_t n, int32_t n_obs_max) {
+    if (!c) return -1;
+    if (c->min_agents_set || !h) return lscqp_comm_devices_for(c, n);
+    DeviceGuard dg;
+    (void)hipSetDevice(c->dev[0]);
+    const int64_t fill = lscqp_device_fill(h, n, n_obs_max);
+    if (fill <= 0) return lscqp_comm_devices_for(c, n);
+    int64_t g = n / fill;
     if (g < 1) g = 1;
     if (g > c->G) g = c->G;
     return (int32_t)g;
@@ -312,7 +331,7 @@ int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lsc
     const int use_sfc = lscqp_uses_sfc(h);
     if (use_sfc && !sfc) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null sfc buffer");
     const size_t rb = (size_t)lscqp_row_bytes(h);
-    const int G = lscqp_comm_devices_for(c, n);
+    const int G = lscqp_comm_devices_for_class(c, h, n, n_obs_max);
     if (n_devices_used) *n_devices_used = G;
     DeviceGuard dg;
     std::lock_guard<std::mutex> lk(c->mu);

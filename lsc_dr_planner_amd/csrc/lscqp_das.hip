@@ -1024,6 +1024,16 @@ extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int 
     return sizeof(double) * (size_t)lscqp_das::Layout::make(M, dim, kmax, cacheC, stage_rows).total;
 }
 
+// workgroups of the one-wavefront form a CU holds at once (registers and the LDS footprint of a launch with `kmax` active rows, no table
+// copy, no staged rows), as the runtime computes it; 0 without a device
+extern "C" int lscqp_das_blocks_per_cu(int M, int dim, int kmax, int rows_f32) {
+    int nb = 0;
+    const size_t lds = lscqp_das_lds_bytes(M, dim, kmax, 0, 0);
+    const hipError_t e = rows_f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lscqp_das::das_kernel<1, true>, 64, lds)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lscqp_das::das_kernel<1, false>, 64, lds);
+    return e == hipSuccess ? nb : 0;
+}
+
 // Launch of the phase over a batch.  threads: 64, 128 or 256 per QP; kmax <= 32 active rows; stage_rows: LSC rows per instance kept in LDS
 // after the first pass (0: re-read from L2 in every pass; an instance with more rows than that re-reads them too); cap: the obstacle capacity of the kernel
 // instance that runs behind the phase (an instance beyond it is left to that kernel's LSCQP_STATUS_CAPACITY).

@@ -7,6 +7,7 @@
 #include <goal_optimizer.hpp>
 #include <traj_optimizer.hpp>
 #include <result_csv.hpp>
+#include <fstream>
 #include <iostream>
 #include <memory>
 #include <vector>
@@ -297,6 +298,32 @@ static int scenario_csv(const char* path) {
     }
     SimulationResultCsv w2(std::cout, 2);
     w2.writeStep(1.0, 0.2, 0.1, trajs, {0.001, 0.002});
+    // a mission with two obstacles (mission.on = 2): the agents' columns end in "," and the obstacle columns follow (:603-610, :638-652)
+    SimulationResultCsv w3(std::cout, 2, 2);
+    w3.writeHeader();
+    w3.writeStep(1.0, 0.2, 0.1, trajs, {0.001, 0.002}, [](size_t oi, double ft) {
+        ObstacleSample o;
+        o.px = 3.0 + (double)oi + 0.5 * ft, o.py = -1.0, o.pz = 1.0, o.size = 0.15 * (double)(oi + 1);
+        return o;
+    });
+    return 0;
+}
+
+// the mission summary: fields from a text file (one token per field, the reference's order) -> description + row on stdout, then the
+// append rule on a scratch file (description only into a new or empty file)
+static int scenario_summary(const char* path, const char* scratch) {
+    std::ifstream f(path);
+    if (!f) return 2;
+    SimulationSummary s;
+    f >> s.start_time >> s.total_flight_time >> s.total_flight_distance >> s.safety_ratio_agent >> s.safety_ratio_obs >> s.vel_excess_ratio >>
+        s.acc_excess_ratio >> s.mapf_time_average >> s.mapf_time_min >> s.mapf_time_max >> s.planning_time_average >> s.planning_time_min >>
+        s.planning_time_max >> s.initial_traj_planning_time >> s.obstacle_prediction_time >> s.goal_planning_time >> s.lsc_generation_time >>
+        s.sfc_generation_time >> s.traj_optimization_time >> s.mission_file_name >> s.world_file_name >> s.planner_mode >> s.goal_mode >> s.mapf_mode >>
+        s.communication_range >> s.world_dimension >> s.M >> s.dt;
+    if (!f) return 2;
+    SimulationSummaryCsv::writeDescription(std::cout);
+    SimulationSummaryCsv::writeRow(std::cout, s);
+    if (!SimulationSummaryCsv::append(scratch, s) || !SimulationSummaryCsv::append(scratch, s)) return 3;
     return 0;
 }
 
@@ -541,6 +568,7 @@ int main(int argc, char** argv) {
     if (s == "subsegment") return scenario_subsegment();
     if (s == "dynamic_obstacle") return scenario_dynamic_obstacle();
     if (s == "csv" && argc > 2) return scenario_csv(argv[2]);
+    if (s == "summary" && argc > 3) return scenario_summary(argv[2], argv[3]);
     if (s == "sfc" && argc > 2) return scenario_sfc(argv[2]);
     fprintf(stderr, "usage: shim_test host|kat|pair|infeasible|goal\n");
     return 2;

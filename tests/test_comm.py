@@ -38,7 +38,13 @@ def test_sharded_solve_equals_the_single_device_solve(api, oracle):
     N, M, dim = 300, 5, 3
     sw = synth.Swarm(N, M=M, dim=dim, n_obs=12, seed=9)
     sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
-    comm.set_min_agents_per_device(32)  # so that a multi-GPU box really spreads this batch
+    # round 5: the rule lscqp_solve_batch_sharded applies knows the class -- a second device only where ONE device would need a second round
+    # of workgroups in the first kernel of the solve (lscqp_device_fill: thousands of QPs with the dual active-set phase)
+    fill = sol.device_fill(N, 12)
+    assert fill >= 256 and comm.devices_for_class(sol, 64, 12) == 1 and comm.devices_for_class(sol, fill - 1, 12) == 1
+    assert comm.devices_for_class(sol, 40 * fill, 12) == min(comm.size, 40)
+    comm.set_min_agents_per_device(32)  # so that a multi-GPU box really spreads this batch (a threshold the caller names overrides the class's)
+    assert comm.devices_for_class(sol, 300, 12) == comm.devices_for(300) == min(comm.size, 300 // 32)
     for step in range(2):
         b = sw.build()
         hdr, rows, off, sfc = api.batch_from_swarm(b, sw.n_obs, M)

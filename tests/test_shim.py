@@ -133,7 +133,40 @@ def test_result_csv_writer_reproduces_reference_log_lines(shim_exe, tmp_path):
     want4 = [0, 1, 1, 2, 0.5, 0.5, 0, -0.25, 0, 0, 0, 0.001, 1, 1, 2, 2, 0.5, 0.5, 0, -0.25, 0, 0, 0, 0.002]
     assert np.abs(np.array(f4) - want4).max() < 1e-4  # float32 second differences leave 1e-5 m/s^2 of rounding noise
     f5 = lines[5].split(",")
-    assert f5[1] == "1.1" and abs(float(f5[2]) - 1.05) < 1e-6 and abs(float(f5[4]) - 0.475) < 1e-6 and len(lines) == 6
+    assert f5[1] == "1.1" and abs(float(f5[2]) - 1.05) < 1e-6 and abs(float(f5[4]) - 0.475) < 1e-6 and len(lines) == 9  # (+ the header and two rows of the obstacle-column scenario)
+
+
+def test_result_csv_with_obstacle_columns(shim_exe, tmp_path):
+    """mission.on != 0 (reference src/multi_sync_simulator.cpp:603-610, 638-652): every agent's block ends in ",", then "obs_id,t,px,py,pz,size"
+    per obstacle; the header names them once.  Two agents, two obstacles, two sample times through writeStep."""
+    p = tmp_path / "states.txt"
+    p.write_text("1 0\n")
+    out = subprocess.run([shim_exe, "csv", str(p)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    hdr, r0, r1 = lines[-3:]
+    assert hdr == ",".join(["id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time"] * 2 + ["obs_id,t,px,py,pz,size"] * 2)
+    f0, f1 = r0.split(","), r1.split(",")
+    assert len(f0) == len(f1) == 2 * 12 + 2 * 6 == len(hdr.split(","))
+    assert f0[24:] == ["0", "1", "3", "-1", "1", "0.15", "1", "1", "4", "-1", "1", "0.3"]
+    assert f1[24:] == ["0", "1.1", "3.05", "-1", "1", "0.15", "1", "1.1", "4.05", "-1", "1", "0.3"]
+    assert f0[:2] == ["0", "1"] and f1[12:14] == ["1", "1.1"]
+
+
+def test_summary_csv_writer_reproduces_reference_summary_lines(shim_exe, tmp_path):
+    """SimulationSummaryCsv against the reference's own log/summary_LSC_10agents.csv: its fields fed back through the writer give the
+    description line and both mission rows character for character (column names included: traj_optimization_time, safety_ratio_agent,
+    safety_ratio_obs, the excess ratios; reference src/multi_sync_simulator.cpp:658-709), and the append rule writes the description
+    once."""
+    g = H.load_golden("summary_log_lines")
+    for k, want in enumerate(g["raw_lines"][1:]):
+        src = tmp_path / ("fields%d.txt" % k)
+        src.write_text("\n".join(want.split(",")) + "\n")
+        scratch = tmp_path / ("summary%d.csv" % k)
+        out = subprocess.run([shim_exe, "summary", str(src), str(scratch)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.splitlines() == [g["raw_lines"][0], want]
+        assert scratch.read_text().splitlines() == [g["raw_lines"][0], want, want]
 
 
 @pytest.mark.gpu
