@@ -278,7 +278,8 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     # is perfect; tools/lpt_probe.py shows the same figures with a hint that is off by one iteration on half of the instances.
     # Only where a launch can have a tail (more instances than lscqp_launch_capacity; lscqp_plan's rule): the sort is part of
     # every timed call, as it is part of every replan.
-    if N > sol.launch_capacity(N, sw.n_obs):
+    phase_on = os.environ.get("LSCQP_ACTIVE_SET", "1")[:1] != "0" and os.environ.get("LSCQP_ACTIVE_SET_NOW", "1")[:1] != "0"
+    if N > sol.launch_capacity(N, sw.n_obs) and not phase_on:  # (round 5: with the dual active-set phase in front there is no iteration tail to sort)
         d_order[0] = torch.zeros(N, dtype=torch.int32, device=dev)
         ms = timed(reps)
     else:
@@ -737,7 +738,8 @@ def timed_workload(ctx, a):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if a.warmup > 0 and not a.graph and not a.no_work_order and N > sol.launch_capacity(N, n_obs_eff):
+    phase_on = os.environ.get("LSCQP_ACTIVE_SET", "1")[:1] != "0" and os.environ.get("LSCQP_ACTIVE_SET_NOW", "1")[:1] != "0"
+    if a.warmup > 0 and not a.graph and not a.no_work_order and not phase_on and N > sol.launch_capacity(N, n_obs_eff):
         # the work order a planner has from the previous replan (lscqp_plan carries it by itself): longest previous solve first, re-sorted
         # inside every step.  Only where a launch runs more than one round of workgroups (configs[3], the configs[4] shape): results are
         # bit-identical, smaller launches start every instance at once anyway.
@@ -913,7 +915,8 @@ def workload_roofline(ctx, a, S):
     bq = S.sol.algorithmic_bytes(S.n_obs_eff)
     pd = "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (S.M, S.dim, "float" if a.precision == "mixed" else "double")
     if S.das_ms is not None and S.paths["active_set_solved"] >= 0.5 * S.n_agents_seen:
-        kms, kname = S.das_ms, "lscqp_das::das_kernel<%d,%s>" % (4 if S.N <= 512 else 1, "true" if a.rows == "f32" else "false")
+        n_cu = ctx.torch.cuda.get_device_properties(ctx.dev_index).multi_processor_count
+        kms, kname = S.das_ms, "lscqp_das::das_kernel<%d,%s>" % (4 if S.N <= 8 * n_cu else 1, "true" if a.rows == "f32" else "false")
     else:
         kms, kname = S.kernel_ms, pd
     achieved = bq * S.N / (kms * 1e-3)

@@ -36,7 +36,7 @@ extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, in
 extern "C" size_t lscqp_das_build_tables(int M, int es, double dt, double w_c, double w_t, double* out);
 extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int stage_rows);
 extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
-                                       int stage_rows, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
+                                       int stage_rows, int screen, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
                                        const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out, int32_t* status_out,
                                        lscqp_info* info_out, hipStream_t stream);
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
@@ -1004,20 +1004,26 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
         if (!inst || !inst64) cap = (mixed || n_obs_max > lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) ? -1 : n_obs_max;
         else cap = std::min(inst->max_obs, inst64->max_obs);
         if (d_tab && cap >= 0) {
-            const bool small = n <= 2 * (int64_t)cu_count();
+            // Launch shape (measured, profiles/r05_das_launch_shapes.txt): up to two QPs per CU the launch is about latency -- four
+            // wavefronts per QP, the whole budget of active rows, the class's table and the instance's rows in LDS; up to eight per CU
+            // the launch still lasts as long as its slowest QP (1024 x M10 x 40: 0.28 ms with one wavefront per QP, 0.19 ms with four) but
+            // LDS is what limits the resident workgroups -- four wavefronts, a small footprint; beyond that one wavefront per QP.
+            const int64_t ncu = cu_count();
+            const bool small = n <= 2 * ncu, medium = n <= 8 * ncu;
             auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-            int threads = env_int("LSCQP_DAS_THREADS", small ? 256 : 64);
+            int threads = env_int("LSCQP_DAS_THREADS", medium ? 256 : 64);
             int kmax = env_int("LSCQP_DAS_KMAX", small ? 32 : 8);
             int steps = env_int("LSCQP_DAS_STEPS", small ? 96 : 24);
             int cacheC = env_int("LSCQP_DAS_CACHE", small ? 1 : 0);
             int stage = env_int("LSCQP_DAS_STAGE", small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
+            const int screen = env_int("LSCQP_DAS_SCREEN", 0);  // the lean form in front: built and measured, no gain (the phase is bound by instruction issue, not occupancy)
             const int Mx = h->desc.M, dx = h->desc.dim;
             // what does not fit the CU's LDS is given up in this order: staged rows, the table copy, active rows
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) stage = 0;
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) cacheC = 0;
             while (kmax > 4 && lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) kmax -= 4;
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) <= lscqp::kMaxLdsBytes) {
-                e = lscqp_launch_das(&cls, Mx, dx, h->es, cap, threads, kmax, steps, cacheC, stage, d_tab, n, d_hdr, d_rows, d_row_offsets, d_sfc,
+                e = lscqp_launch_das(&cls, Mx, dx, h->es, cap, threads, kmax, steps, cacheC, stage, screen, d_tab, n, d_hdr, d_rows, d_row_offsets, d_sfc,
                                      d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (dual active-set phase): ") + hipGetErrorString(e));
                 das_ran = true;

@@ -165,15 +165,22 @@ __device__ __forceinline__ double ccol(const int* ea, const double* ca, int kx, 
 #ifndef LSCQP_DAS_WPE1
 #define LSCQP_DAS_WPE1 3
 #endif
-template <int NW, bool F32>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_kernel(DevClass cls, int M, int dim, int es, int cap, int kmax, int max_steps, int cacheC, int stage_rows,
+// SCREEN: the lean form for batches that fill the chip -- unconstrained minimiser, ONE pass over the rows, verification; an instance with a
+// violated row is left (LSCQP_STATUS_ITER_LIMIT) to the full form, which runs behind it over the same batch and skips what is OPTIMAL
+// (`behind` != 0).  Without the step loop the kernel needs half the registers: twice the wavefronts per SIMD for the phase that streams
+// the rows from HBM.
+#ifndef LSCQP_DAS_WPES
+#define LSCQP_DAS_WPES 4
+#endif
+template <int NW, bool F32, bool SCREEN = false>
+__global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_kernel(DevClass cls, int M, int dim, int es, int cap, int kmax, int max_steps, int cacheC, int stage_rows, int behind,
                                                       const double* __restrict__ tab, int64_t n, const lscqp_header* __restrict__ hdr,
                                                       const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
                                                       const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init, double* __restrict__ x_out,
                                                       double* __restrict__ obj_out, int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int T = 64 * NW;
-    constexpr int kU = (NW == 1) ? LSCQP_DAS_KU1 : 4;  // LSC rows in flight per thread (the one-wavefront form trades them for a third / fourth wavefront per SIMD)
+    constexpr int kU = SCREEN ? 4 : (NW == 1) ? LSCQP_DAS_KU1 : 4;  // LSC rows in flight per thread (the one-wavefront full form trades them for a third wavefront per SIMD)
     const int64_t k0 = blockIdx.x;
     if (k0 >= n) return;
     const int64_t q = cls.order ? (int64_t)cls.order[k0] : k0;
@@ -213,6 +220,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_k
     const int LDL = kmax + 1;
     int par = 0;  // which half of red_ the next cross-wavefront reduction uses (double buffered: one barrier per reduction)
 
+    if (!SCREEN && behind) {  // (uniform) behind the lean form: what it finished is skipped before anything is fetched
+        if (status_out[q] == LSCQP_STATUS_OPTIMAL) return;
+    }
     // ---- header, corridor boxes (and the instance's row offset: one memory round trip for all three) -------------------------------
     const uint64_t roff = row_offsets ? row_offsets[q] : 0;
     {
@@ -769,6 +779,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? LSCQP_DAS_WPE1 : 1)) void das_k
             continue;
         }
         polished = false;
+        if constexpr (SCREEN) break;  // (a violated row: the full form's)
         if (k >= kmax) break;  // more active rows than this launch holds: the interior-point kernel's
         if (cacheC && !haveC) {  // the table of this instance's ts in LDS from the first step on (every step reads a few of its columns)
             for (int e = tid; e < P * P; e += T) Cc_[e] = Cg[e];
@@ -1035,12 +1046,14 @@ extern "C" int lscqp_das_blocks_per_cu(int M, int dim, int kmax, int rows_f32) {
 }
 
 // Launch of the phase over a batch.  threads: 64, 128 or 256 per QP; kmax <= 32 active rows; stage_rows: LSC rows per instance kept in LDS
-// after the first pass (0: re-read from L2 in every pass; an instance with more rows than that re-reads them too); cap: the obstacle capacity of the kernel
-// instance that runs behind the phase (an instance beyond it is left to that kernel's LSCQP_STATUS_CAPACITY).
+// after the first pass (0: re-read from L2 in every pass; an instance with more rows than that re-reads them too); cap: the obstacle
+// capacity of the kernel instance that runs behind the phase (an instance beyond it is left to that kernel's LSCQP_STATUS_CAPACITY).
+// screen != 0: the lean one-wavefront form first (unconstrained minimiser + one pass + verification at twice the occupancy), then the
+// full form over what it left -- for batches that fill the chip, where most instances hold no active row at all.
 extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
-                                       int stage_rows, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
-                                       const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out, int32_t* status_out,
-                                       lscqp_info* info_out, hipStream_t stream) {
+                                       int stage_rows, int screen, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
+                                       const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
+                                       int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
     if (kmax < 1 || kmax > lscqp_das::kMaxK || (threads != 64 && threads != 128 && threads != 256)) return hipErrorInvalidValue;
     const size_t lds = lscqp_das_lds_bytes(M, dim, kmax, cacheC, stage_rows);
     if (lds > lscqp::kMaxLdsBytes) return hipErrorInvalidValue;
@@ -1050,17 +1063,30 @@ extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int di
     if (!attr_set[dev].load(std::memory_order_acquire)) {
         for (const void* f : {reinterpret_cast<const void*>(lscqp_das::das_kernel<1, false>), reinterpret_cast<const void*>(lscqp_das::das_kernel<2, false>),
                               reinterpret_cast<const void*>(lscqp_das::das_kernel<4, false>), reinterpret_cast<const void*>(lscqp_das::das_kernel<1, true>),
-                              reinterpret_cast<const void*>(lscqp_das::das_kernel<2, true>), reinterpret_cast<const void*>(lscqp_das::das_kernel<4, true>)}) {
+                              reinterpret_cast<const void*>(lscqp_das::das_kernel<2, true>), reinterpret_cast<const void*>(lscqp_das::das_kernel<4, true>),
+                              reinterpret_cast<const void*>(lscqp_das::das_kernel<1, false, true>), reinterpret_cast<const void*>(lscqp_das::das_kernel<1, true, true>)}) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lscqp::kMaxLdsBytes);
             if (e != hipSuccess) return e;
         }
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (n <= 0) return hipSuccess;
+    const bool f32 = cls->rows_f32 != 0;
+    int behind = 0;
+    if (screen) {
+        const size_t lds_s = lscqp_das_lds_bytes(M, dim, 1, 0, 0);  // (no active rows, no table copy, no staged rows)
+#define LSCQP_DAS_SCREEN(F_)                                                                                                                                  \
+    hipLaunchKernelGGL((lscqp_das::das_kernel<1, F_, true>), dim3((unsigned)n), dim3(64), lds_s, stream, *cls, M, dim, es, cap, 1, 0, 0, 0, 0, d_tab, n, hdr, rows, \
+                       row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out)
+        if (f32) LSCQP_DAS_SCREEN(true); else LSCQP_DAS_SCREEN(false);
+#undef LSCQP_DAS_SCREEN
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        behind = 1;
+    }
 #define LSCQP_DAS_LAUNCH(NW_, F_)                                                                                                                              \
     hipLaunchKernelGGL((lscqp_das::das_kernel<NW_, F_>), dim3((unsigned)n), dim3(64 * NW_), lds, stream, *cls, M, dim, es, cap, kmax, max_steps, cacheC, stage_rows, \
-                       d_tab, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out)
-    const bool f32 = cls->rows_f32 != 0;
+                       behind, d_tab, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out)
     if (threads == 64) { if (f32) LSCQP_DAS_LAUNCH(1, true); else LSCQP_DAS_LAUNCH(1, false); }
     else if (threads == 128) { if (f32) LSCQP_DAS_LAUNCH(2, true); else LSCQP_DAS_LAUNCH(2, false); }
     else { if (f32) LSCQP_DAS_LAUNCH(4, true); else LSCQP_DAS_LAUNCH(4, false); }

@@ -59,7 +59,8 @@ def test_bench_line_covers_every_baseline_config_at_its_own_shape():
         assert c["non_optimal"] == 0 and c["latency_ms"]["calls"] >= 1 and c["qp_per_s"] > 0 and c["hbm_frac"] > 0
         assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port"
         # both launch orders are in the line; the sorted one only where a launch runs more than one round of workgroups
-        assert c["kernel_ms_as_given"] > 0 and ("longest first" in c["work_order"]) == (k in ("c3", "c4_f64", "c4"))
+        # (round 5: with the dual active-set phase in front a launch has no iteration tail to sort: every config runs as given)
+        assert c["kernel_ms_as_given"] > 0 and "longest first" not in c["work_order"] and c["paths"]["active_set_solved"] > 0
         if c["rows"] == "f64":
             assert c["parity_vs_oracle"]["max_abs_dx"] <= 1e-6 and c["parity_vs_oracle"]["max_rel_dobj"] <= 1e-8
     assert by["c4"]["precision"] == "mixed" and by["c4"]["rows"] == "f32" and by["c3"]["lsc_neighbours"] == 40
