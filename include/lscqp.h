@@ -317,7 +317,9 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
  *   lscqp_order_by_work_device   d_order_out[n] := the instances sorted by d_info_prev[i].iterations, most first, ties in index order
  *   lscqp_solve_batch_device_ordered   lscqp_solve_batch_device_ex with the k-th slot of the launch solving instance d_order[k]
  *                                (a permutation of 0 .. n-1; NULL = identity).  Results land at the instance's own index, bit for bit
- *                                what any other order gives. */
+ *                                what any other order gives.  The permutation is trusted; with the environment variable
+ *                                LSCQP_CHECK_ORDER=1 every call verifies it on the device first (an allocation and a synchronisation:
+ *                                a debugging aid) and returns LSCQP_ERR_INVALID_ARGUMENT for a stale or short order buffer. */
 /* instances of a launch of n the device works on at once (CUs x workgroups per CU of the kernel instance the launch selects); a launch of
  * more runs in rounds and has a tail -- that is where the order pays.  -1 without a device. */
 int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max);

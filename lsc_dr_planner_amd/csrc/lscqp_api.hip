@@ -81,6 +81,7 @@ namespace {
 struct Inst {
     int M, dim, es, max_obs, waves, mixed;
     int nd;     // nested-dissection elimination order (lscqp_kernel.hpp Cfg::ND); 0: the natural order
+    int persist;  // the instance has a persistent form (lscqp_inst.hip: LSCQP_PERSIST): only its launches can use a work-queue counter
     int heavy;  // an instance whose state no longer fits the register file: more than 12 LSC slots per lane (376 - 1432 B/lane of
                 // scratch measured for <6,3,.,20,1>, <5,3,.,24,1>, <10,2,.,24,1>: 2.3x slower per QP than the two-wavefront
                 // instance of the shape at every batch size, M = 6, 512 .. 2048 QPs) or a long matrix row (M >= 7: 108 - 192 B/lane;
@@ -91,7 +92,7 @@ struct Inst {
 constexpr int max_obs_of(int M, int nslot, int w) { return nslot * ((64 * w / (6 * M - 3)) > 0 ? (64 * w / (6 * M - 3)) : 1); }
 const Inst kInst[] = {
 #define LSCQP_ROW(M, D, E, S, W, X) \
-    {M, D, E, max_obs_of(M, S, W), W, X, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::ND ? 1 : 0, (S > 12 || (W == 1 && M >= 7)) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
+    {M, D, E, max_obs_of(M, S, W), W, X, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::ND ? 1 : 0, (W >= 2 && S <= 10 && E != 0 && M != 9 && !X) ? 1 : 0, (S > 12 || (W == 1 && M >= 7)) ? 1 : 0, lscqp::Cfg<M, D, (E != 0), S, W, (X ? 4 : 8)>::lds_bytes(), lscqp_launch_##M##_##D##_##E##_##S##_##W##_##X},
     LSCQP_INSTANCES(LSCQP_ROW)
 #undef LSCQP_ROW
 };
@@ -285,6 +286,27 @@ __global__ __launch_bounds__(kOrdT) void order_by_cost_kernel(int64_t n, const u
     // (16 levels: a tile of 64 costs then has at most 16 distinct keys to peel -- with 64 levels the sort took 30 us for 4096 agents, and
     // the order only has to put the expensive quarter first)
     order_by_key(n, [&](int64_t i) -> int { return 15 - (int)(((unsigned long long)cost[i] * 15) / top); }, order);
+}
+
+// Debug aid (environment LSCQP_CHECK_ORDER=1): is d_order a permutation of 0 .. n-1?  A stale or short order buffer would make two workgroups
+// write the same instance and leave another untouched; the check costs an allocation and a synchronisation, hence the knob.
+__global__ void check_order_kernel(int64_t n, const int32_t* __restrict__ order, int* __restrict__ seen, int* __restrict__ bad) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t q = order[k];
+    if (q < 0 || q >= n) atomicAdd(bad, 1);
+    else if (atomicAdd(&seen[q], 1) != 0) atomicAdd(bad, 1);
+}
+int order_is_permutation(int64_t n, const int32_t* d_order, hipStream_t stream) {  // 1 yes, 0 no, -1 could not check
+    int* buf = nullptr;
+    if (hipMalloc(&buf, sizeof(int) * (size_t)(n + 1)) != hipSuccess) return -1;
+    int bad = -1;
+    if (hipMemsetAsync(buf, 0, sizeof(int) * (size_t)(n + 1), stream) == hipSuccess) {
+        hipLaunchKernelGGL(check_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, d_order, buf, buf + n);
+        if (hipMemcpyAsync(&bad, buf + n, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) bad = -1;
+    }
+    (void)hipFree(buf);
+    return bad < 0 ? -1 : (bad == 0 ? 1 : 0);
 }
 
 bool shape_exists(int M, int dim, int es, int mixed) {
@@ -975,6 +997,11 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             return fail(LSCQP_ERR_NO_DEVICE, std::string("no HIP device: lscqp has no CPU fallback (hipGetDeviceCount: ") +
                                                  hipGetErrorString(de) + ", " + std::to_string(ndev) + " devices)");
     }
+    if (d_order) {
+        const char* chk = getenv("LSCQP_CHECK_ORDER");
+        if (chk && chk[0] == '1' && order_is_permutation(n, d_order, (hipStream_t)stream) == 0)
+            return fail(LSCQP_ERR_INVALID_ARGUMENT, "d_order is not a permutation of 0 .. n-1 (LSCQP_CHECK_ORDER)");
+    }
     const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
     const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, cu_count());
     const Inst* inst64 = mixed ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : inst;
@@ -985,7 +1012,12 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     // the instance's launcher decides (lscqp_inst.hip: persistent workgroups over the queue, or one instance per workgroup)
     static const bool no_queue = getenv("LSCQP_NO_QUEUE") != nullptr;  // (development: tools/lpt_probe.py tells the queue and the order apart)
     const bool queued = !no_queue && n > (int64_t)cu_count();
-    auto with_queue = [&](lscqp::DevClass& c) { c.queue = queued ? next_queue_counter((hipStream_t)stream) : nullptr; };
+    // (a counter -- a memset on the stream, a slot of the ring -- only for a launch that can use it: the instance has a persistent form, and
+    // the pass is not the near-empty one behind the dual active-set phase, where almost every workgroup returns at once)
+    bool das_in_front = false;
+    auto with_queue = [&](lscqp::DevClass& c, const Inst* i) {
+        c.queue = (queued && i && i->persist && !das_in_front) ? next_queue_counter((hipStream_t)stream) : nullptr;
+    };
     hipError_t e = hipSuccess;
     if (retry < 0 && h->desc.active_set == LSCQP_ACTIVE_SET_ONLY) return LSCQP_OK;  // (the host-pointer entries' extra passes are interior-point passes)
     // ---- the DUAL ACTIVE SET phase (lscqp_das.hip) in front of the first interior-point pass ----------------------------------------
@@ -1087,13 +1119,15 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
         const Inst* other = other_order_instance(inst64, n_obs_max);
         if (!other) return LSCQP_OK;
         cls.repair = 1;
-        with_queue(cls);
+        with_queue(cls, other);
         e = other->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, nullptr, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (other-order pass): ") + hipGetErrorString(e));
         return LSCQP_OK;
     }
     cls.repair = first_repair;
-    with_queue(cls);
+    das_in_front = das_ran;
+    with_queue(cls, inst);
+    das_in_front = false;
     e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
     // Second pass over the batch, same stream, no host round trip: a workgroup whose instance is already OPTIMAL (or was
@@ -1107,7 +1141,7 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     const Inst* alt = retry == 2 ? other_order_instance(inst64, n_obs_max) : nullptr;
     if (mixed || (retry && (d_x_init || alt))) {
         cls.repair = 1;
-        with_queue(cls);
+        with_queue(cls, alt ? alt : inst64);
         e = (alt ? alt : inst64)->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
                                      d_info_out, (hipStream_t)stream);
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));

@@ -228,3 +228,34 @@ def test_nan_in_the_inputs_is_never_an_optimal_plan(api, oracle, torch_cuda, sol
     bad = np.array([3, 7, 9])
     assert (G["status"][bad] != 0).all(), G["status"]
     assert (np.delete(G["status"], bad) == 0).all() and np.isfinite(np.delete(G["x"], bad, axis=0)).all()
+
+
+@pytest.mark.gpu
+def test_a_stale_work_order_is_refused_when_asked_to_check(api, oracle, torch_cuda, solver_path, monkeypatch):
+    """lscqp_solve_batch_device_ordered trusts d_order to be a permutation of 0 .. n-1; LSCQP_CHECK_ORDER=1 (a debugging aid: it allocates and
+    synchronises) verifies it on the device and refuses a duplicate or out-of-range entry instead of leaving an instance unsolved."""
+    if solver_path != "active_set":
+        pytest.skip("one path")
+    torch = torch_cuda
+    from lsc_dr_planner_amd import synth
+
+    N, M, dim = 40, 5, 3
+    sw = synth.Swarm(N, M=M, dim=dim, n_obs=8, seed=4)
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max))
+    b = sw.build()
+    hdr, rows, roff, sfcp = api.batch_from_swarm(b, sw.n_obs, M)
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)  # noqa: E731
+    d_x = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
+    d_obj = torch.zeros(N, dtype=torch.float64, device=dev)
+    d_st = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    args = (N, sw.n_obs, up(hdr), up(rows), up(roff), up(sfcp), d_x, d_obj, d_st, None)
+    monkeypatch.setenv("LSCQP_CHECK_ORDER", "1")
+    good = torch.from_numpy(np.random.default_rng(0).permutation(N).astype(np.int32)).to(dev)
+    sol.solve_device(*args, d_order=good)
+    torch.cuda.synchronize()
+    assert (d_st.cpu().numpy() == 0).all()
+    for bad in (np.r_[np.arange(N - 1), 0], np.r_[np.arange(N - 1), N]):
+        with pytest.raises(api.LscqpError) as e:
+            sol.solve_device(*args, d_order=torch.from_numpy(bad.astype(np.int32)).to(dev))
+        assert e.value.code == api.ERR_INVALID_ARGUMENT and "permutation" in str(e.value)
