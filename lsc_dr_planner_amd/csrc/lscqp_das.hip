@@ -69,7 +69,7 @@ struct Layout {
         s.o_c = take(3 * s.P), s.o_cu = take(s.NX), s.o_lam = take(s.NX);  // (c_: a third, zero axis in 2-D: row evaluation without a branch on dim)
         s.o_plo = take(s.NPAIR), s.o_phi = take(s.NPAIR), s.o_pix = take((s.NPAIR + 1) / 2);  // two-sided rows: bounds, packed stencil
         s.o_W = take((kmax + 1) * s.NX);      // w_j = C a_j of the active rows; slot k (the next free one) holds the candidate's
-        s.o_S = take(kmax * (kmax + 1));      // the Gram matrix S = A'C A itself (its factor is rebuilt from it when a row leaves)
+        s.o_S = take(kmax * (kmax + 1));      // scratch of the factor's downdate when a row leaves
         s.o_L = take(kmax * (kmax + 1));
         s.o_u = take(kmax + 1), s.o_r = take(kmax + 1), s.o_v = take(kmax + 1), s.o_y = take(kmax + 1), s.o_linv = take(kmax + 1), s.o_arhs = take(kmax + 1);
         s.o_acoef = take(3 * (kmax + 1));
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     double* const phi_ = smem + L.o_phi;
     int* const pix_ = reinterpret_cast<int*>(smem + L.o_pix);  // packed stencil of a two-sided row: type << 24 | first entry index (in 0 .. NX-1) << 12 | second
     double* const W_ = smem + L.o_W;   // [kmax + 1][NX]
-    double* const Sm_ = smem + L.o_S;  // [kmax][kmax + 1] S = A'C A (lower triangle used)
+    double* const Sm_ = smem + L.o_S;  // [kmax][kmax + 1] scratch of the factor's downdate
     double* const Lm_ = smem + L.o_L;  // [kmax][kmax + 1] lower Cholesky factor of S
     double* const u_ = smem + L.o_u;
     double* const r_ = smem + L.o_r;
@@ -562,35 +562,37 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
 
     // ---- the small factor: S = A'C A (k x k, SPD), S = Lm Lm', rows owned by the lanes of wavefront 0 -------------------------------------
     const double* Cm = Cg;  // column cp = Cm + cp * P (symmetric); the LDS copy once a step needs it
-    // from scratch (after a row left the set), out of the stored Gram matrix
-    auto factor_scratch = [&](int k) -> bool {  // wavefront 0 only; returns false on a lost pivot (dependent rows)
+    // A row leaves the set: row / column l of S = Lm Lm' goes.  Deleting row l of Lm leaves a lower Hessenberg matrix from that row on;
+    // Givens rotations of the column pairs (j, j + 1), j = l .. k - 2, restore the triangle (the standard downdate of Goldfarb-Idnani
+    // implementations: O(k^2), backward stable, no square-root chain per column as a factorisation from scratch has).  Lane i = row i;
+    // every lane touches its own row only, the rotation's (c, s) come from lane j by v_readlane.  Wavefront 0 only; false on a vanishing pivot.
+    auto factor_remove = [&](int k, int l) -> bool {
         bool ok = true;
         if (wv == 0) {
             const int i = lane;
-            double sdiag = 1.0;
-            if (i < k) {
-                for (int j = 0; j <= i; j++) Lm_[i * LDL + j] = Sm_[i * LDL + j];
-                sdiag = Sm_[i * LDL + i];
+            // rows l + 1 .. k - 1 move up by one (through the scratch area: every lane reads before any lane writes)
+            if (i >= l && i < k - 1)
+                for (int c = 0; c < k; c++) Sm_[i * LDL + c] = (c <= i + 1) ? Lm_[(i + 1) * LDL + c] : 0.0;
+            LSCQP_DAS_WAVE_SYNC();
+            if (i >= l && i < k - 1)
+                for (int c = 0; c < k; c++) Lm_[i * LDL + c] = Sm_[i * LDL + c];
+            LSCQP_DAS_WAVE_SYNC();
+            for (int j = l; j < k - 1; j++) {
+                const int js = __builtin_amdgcn_readfirstlane(j);
+                const bool mine = i >= js && i < k - 1;
+                const double x = mine ? Lm_[i * LDL + js] : 0.0, y = mine ? Lm_[i * LDL + js + 1] : 0.0;
+                const double a = lscqp::bcast(x, js), b = lscqp::bcast(y, js);
+                const double r2 = a * a + b * b;
+                if (!(r2 > 1e-280)) ok = false;
+                const double ir = rsqrt(fmax(r2, 1e-300));
+                const double cc = a * ir, ss = b * ir;
+                if (mine) {
+                    Lm_[i * LDL + js] = cc * x + ss * y;
+                    Lm_[i * LDL + js + 1] = cc * y - ss * x;
+                }
+                if (i == js) linv_[js] = ir;  // 1 / (the new diagonal entry r2 * ir)
             }
             LSCQP_DAS_WAVE_SYNC();
-            for (int j = 0; j < k; j++) {
-                const int js = __builtin_amdgcn_readfirstlane(j);
-                const double d = Lm_[js * LDL + js];
-                if (!(d > 1e-13 * lscqp::bcast(sdiag, js))) ok = false;
-                const double idj = rsqrt(fmax(d, 1e-300));
-                const double dj = d * idj;
-                const double lij = (i > js && i < k) ? Lm_[i * LDL + js] * idj : 0.0;
-                LSCQP_DAS_WAVE_SYNC();  // every lane has read the pivot before its owner overwrites it
-                if (i == js) Lm_[js * LDL + js] = dj, linv_[js] = idj;
-                if (i > js && i < k) Lm_[i * LDL + js] = lij;
-                LSCQP_DAS_WAVE_SYNC();
-                // trailing update of the own row: S_ic -= L_ij L_cj, c = j+1 .. i
-                if (i > js && i < k) {
-#pragma unroll 4
-                    for (int cidx = js + 1; cidx <= i; cidx++) Lm_[i * LDL + cidx] -= lij * Lm_[cidx * LDL + js];
-                }
-                LSCQP_DAS_WAVE_SYNC();
-            }
         }
         return ok;
     };
@@ -830,10 +832,10 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 else kind = 2;
                 if (kind == 1 || kind == 2) {
                     if (lane < k) u_[lane] = fmax(0.0, u_[lane] - t * ri);
-                    if (kind == 1) {  // one more row of the Gram matrix (v, spp) and of its factor (y, sqrt(spp - y'y))
+                    if (kind == 1) {  // one more row of the factor: (y, sqrt(spp - y'y))
                         const double dl = sqrt(spp - yy);
-                        if (lane < k) Lm_[k * LDL + lane] = y_[lane], Sm_[k * LDL + lane] = vj;
-                        if (lane == 0) Lm_[k * LDL + k] = dl, linv_[k] = 1.0 / dl, Sm_[k * LDL + k] = spp, u_[k] = ctl_[3] + t;
+                        if (lane < k) Lm_[k * LDL + lane] = y_[lane];
+                        if (lane == 0) Lm_[k * LDL + k] = dl, linv_[k] = 1.0 / dl, u_[k] = ctl_[3] + t;
                     }
                 }
                 if (lane == 0) {
@@ -871,33 +873,17 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 LSCQP_DAS_BARRIER();
                 break;
             }
-            // row l leaves: close the gap in descriptors, multipliers and the Gram matrix (wavefront 0), then its factor from scratch
-            if (wv == 0) {
-                if (lane == 0) {
-                    for (int j = l; j + 1 < k; j++) {
-                        for (int t_ = 0; t_ < 4; t_++) aint_[4 * j + t_] = aint_[4 * (j + 1) + t_];
-                        for (int t_ = 0; t_ < 3; t_++) acoef_[3 * j + t_] = acoef_[3 * (j + 1) + t_];
-                        arhs_[j] = arhs_[j + 1];
-                        u_[j] = u_[j + 1];
-                    }
+            // row l leaves: close the gap in descriptors and multipliers, downdate the factor (wavefront 0)
+            if (wv == 0 && lane == 0) {
+                for (int j = l; j + 1 < k; j++) {
+                    for (int t_ = 0; t_ < 4; t_++) aint_[4 * j + t_] = aint_[4 * (j + 1) + t_];
+                    for (int t_ = 0; t_ < 3; t_++) acoef_[3 * j + t_] = acoef_[3 * (j + 1) + t_];
+                    arhs_[j] = arhs_[j + 1];
+                    u_[j] = u_[j + 1];
                 }
-                // lane i = row i of the new matrix: entry (i, j) comes from (i + [i >= l], j + [j >= l])
-                const int i = lane, si = i + (i >= l ? 1 : 0);
-                LSCQP_DAS_WAVE_SYNC();
-                if (i < k - 1) {
-                    for (int j = 0; j <= i; j++) {
-                        const int sj = j + (j >= l ? 1 : 0);
-                        const double sv = Sm_[si * LDL + sj];
-                        Lm_[i * LDL + j] = sv;  // parked in the factor's storage: rows are rewritten in place only after every lane has read
-                    }
-                }
-                LSCQP_DAS_WAVE_SYNC();
-                if (i < k - 1)
-                    for (int j = 0; j <= i; j++) Sm_[i * LDL + j] = Lm_[i * LDL + j];
-                LSCQP_DAS_WAVE_SYNC();
             }
+            const bool okf = factor_remove(k, l);
             k--;
-            const bool okf = factor_scratch(k);
             if (wv == 0 && lane == 0) ctl_[6] = okf ? 0.0 : 1.0;
             LSCQP_DAS_BARRIER();
             if (ctl_[6] != 0.0) {
