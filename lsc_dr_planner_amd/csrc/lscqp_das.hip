@@ -58,7 +58,7 @@ __host__ __device__ inline int num_pairs(int M, int dim) { return dim * (6 * M +
 // LDS carve of one QP, in doubles.
 struct Layout {
     int P, NX, kmax, NPAIR;
-    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_pix, o_W, o_S, o_L, o_u, o_r, o_v, o_y, o_linv, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_C, o_rows, n_stage, total;
+    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_pix, o_W, o_L, o_u, o_r, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_C, o_rows, n_stage, total;
     __host__ __device__ static Layout make(int M, int dim, int kmax, int cacheC, int stage_rows = 0) {
         Layout s;
         s.P = 6 * M, s.NX = dim * s.P, s.kmax = kmax, s.NPAIR = num_pairs(M, dim);
@@ -69,9 +69,8 @@ struct Layout {
         s.o_c = take(3 * s.P), s.o_cu = take(s.NX), s.o_lam = take(s.NX);  // (c_: a third, zero axis in 2-D: row evaluation without a branch on dim)
         s.o_plo = take(s.NPAIR), s.o_phi = take(s.NPAIR), s.o_pix = take((s.NPAIR + 1) / 2);  // two-sided rows: bounds, packed stencil
         s.o_W = take((kmax + 1) * s.NX);      // w_j = C a_j of the active rows; slot k (the next free one) holds the candidate's
-        s.o_S = take(kmax * (kmax + 1));      // scratch of the factor's downdate when a row leaves
         s.o_L = take(kmax * (kmax + 1));
-        s.o_u = take(kmax + 1), s.o_r = take(kmax + 1), s.o_v = take(kmax + 1), s.o_y = take(kmax + 1), s.o_linv = take(kmax + 1), s.o_arhs = take(kmax + 1);
+        s.o_u = take(kmax + 1), s.o_r = take(kmax + 4), s.o_arhs = take(kmax + 1);
         s.o_acoef = take(3 * (kmax + 1));
         s.o_aint = take(2 * (kmax + 1) + 2);  // ints: per active row {id, entry0, entry1, entry2} (+ the candidate); entry = axis << 16 | control point
         s.o_red = take(2 * 16);               // cross-wavefront reductions, double buffered
@@ -89,10 +88,22 @@ struct Layout {
 __device__ __forceinline__ double wave_max(double v) { return lscqp::wave_max(v); }
 __device__ __forceinline__ double wave_min(double v) { return -lscqp::wave_max(-v); }
 __device__ __forceinline__ double wave_sum(double v) { return lscqp::wave_sum(v); }
-__device__ __forceinline__ void wave_argmin(double& v, int& id) {  // lexicographic (value, id): every lane ends with the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_i32(int v) {
+    return min(v, __builtin_amdgcn_update_dpp(2147483647, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {  // (the scan of lscqp::wave_reduce1 on one register per value instead of two)
+    v = dpp_min_i32<0x111, 0xf>(v);
+    v = dpp_min_i32<0x112, 0xf>(v);
+    v = dpp_min_i32<0x114, 0xf>(v);
+    v = dpp_min_i32<0x118, 0xf>(v);
+    v = dpp_min_i32<0x142, 0xa>(v);
+    v = dpp_min_i32<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ void wave_argmin(double& v, int& id) {  // lexicographic (value, id), ids >= 0: every lane ends with the result
     const double vm = wave_min(v);
-    const double cand = (v == vm) ? (double)id : 2147483647.0;  // (ids are < 2^31: exact in fp64)
-    id = (int)wave_min(cand);
+    id = wave_min_i32((v == vm) ? id : 2147483647);
     v = vm;
 }
 // a / b for small non-negative integers (a < 2^20, b <= 2^10) through one fp32 multiplication: exact, and a handful of instructions where an
@@ -119,9 +130,11 @@ __device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a
 __device__ unsigned long long das_cycles[16];
 #define DAS_T(slot)                                                        \
     do {                                                                   \
+        if ((LSCQP_DAS_TIMING >> (slot)) & 1) {                                \
         const unsigned long long now_ = __builtin_readcyclecounter();      \
         if (tid == 0) atomicAdd(&das_cycles[slot], now_ - tprev_);          \
         tprev_ = now_;                                                     \
+        }                                                                  \
     } while (0)
 #else
 #define DAS_T(slot) \
@@ -199,13 +212,9 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     double* const phi_ = smem + L.o_phi;
     int* const pix_ = reinterpret_cast<int*>(smem + L.o_pix);  // packed stencil of a two-sided row: type << 24 | first entry index (in 0 .. NX-1) << 12 | second
     double* const W_ = smem + L.o_W;   // [kmax + 1][NX]
-    double* const Sm_ = smem + L.o_S;  // [kmax][kmax + 1] scratch of the factor's downdate
-    double* const Lm_ = smem + L.o_L;  // [kmax][kmax + 1] lower Cholesky factor of S
+    double* const Jm_ = smem + L.o_L;  // [kmax][kmax + 1] J = L^-1, S = A'C A = L L' over the active rows
     double* const u_ = smem + L.o_u;
     double* const r_ = smem + L.o_r;
-    double* const v_ = smem + L.o_v;
-    double* const y_ = smem + L.o_y;
-    double* const linv_ = smem + L.o_linv;
     double* const arhs_ = smem + L.o_arhs;    // [kmax + 1]: slot kmax = the candidate row
     double* const acoef_ = smem + L.o_acoef;  // [kmax + 1][3]
     int* const aint_ = reinterpret_cast<int*>(smem + L.o_aint);  // [kmax + 1][4]: id, entry0, entry1, entry2
@@ -562,79 +571,68 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
 
     // ---- the small factor: S = A'C A (k x k, SPD), S = Lm Lm', rows owned by the lanes of wavefront 0 -------------------------------------
     const double* Cm = Cg;  // column cp = Cm + cp * P (symmetric); the LDS copy once a step needs it
-    // A row leaves the set: row / column l of S = Lm Lm' goes.  Deleting row l of Lm leaves a lower Hessenberg matrix from that row on;
-    // Givens rotations of the column pairs (j, j + 1), j = l .. k - 2, restore the triangle (the standard downdate of Goldfarb-Idnani
-    // implementations: O(k^2), backward stable, no square-root chain per column as a factorisation from scratch has).  Lane i = row i;
-    // every lane touches its own row only, the rotation's (c, s) come from lane j by v_readlane.  Wavefront 0 only; false on a vanishing pivot.
-    auto factor_remove = [&](int k, int l) -> bool {
+    // The small system S = A'C A of the active rows is carried as J = L^-1, the INVERSE of its Cholesky factor (lower triangular, zeros kept
+    // above the diagonal): S^-1 = J'J, so r = S^-1 v is two matrix-vector products without a dependent chain (a substitution through L is
+    // 2k dependent broadcast-multiply-subtract steps), a joining row appends the row (-r' , 1) / sqrt(a_p'w_p - v'r) -- r is this step's --
+    // and a leaving row costs k - l rotations of row pairs.  Lane i of wavefront 0 = row i (products) / column i (rotations).
+    //
+    // Row l leaves: rotations of the rows (l, l + 1), (l + 1, l + 2), ... push column l's content into the last row, which is dropped with
+    // the column (Goldfarb-Idnani's downdate on J).  In place: the lane of column c writes column c - [c > l] of row j after every lane
+    // has read rows j and j + 1 (LDS operations of one wavefront execute in order).  false on a vanishing pivot.
+    auto factor_remove = [&](int k_, int l_) -> bool {
         bool ok = true;
         if (wv == 0) {
-            const int i = lane;
-            // rows l + 1 .. k - 1 move up by one (through the scratch area: every lane reads before any lane writes)
-            if (i >= l && i < k - 1)
-                for (int c = 0; c < k; c++) Sm_[i * LDL + c] = (c <= i + 1) ? Lm_[(i + 1) * LDL + c] : 0.0;
-            LSCQP_DAS_WAVE_SYNC();
-            if (i >= l && i < k - 1)
-                for (int c = 0; c < k; c++) Lm_[i * LDL + c] = Sm_[i * LDL + c];
-            LSCQP_DAS_WAVE_SYNC();
+            const int k = __builtin_amdgcn_readfirstlane(k_), l = __builtin_amdgcn_readfirstlane(l_);
+            const bool mine = lane < k;
+            const int c = mine ? lane : 0;
+            const int cn = c - (c > l ? 1 : 0);
+            double carry = Jm_[l * LDL + c];
+            double a = Jm_[l * LDL + l];
             for (int j = l; j < k - 1; j++) {
-                const int js = __builtin_amdgcn_readfirstlane(j);
-                const bool mine = i >= js && i < k - 1;
-                const double x = mine ? Lm_[i * LDL + js] : 0.0, y = mine ? Lm_[i * LDL + js + 1] : 0.0;
-                const double a = lscqp::bcast(x, js), b = lscqp::bcast(y, js);
+                const double x = Jm_[(j + 1) * LDL + c];
+                const double b = Jm_[(j + 1) * LDL + l];
                 const double r2 = a * a + b * b;
                 if (!(r2 > 1e-280)) ok = false;
                 const double ir = rsqrt(fmax(r2, 1e-300));
-                const double cc = a * ir, ss = b * ir;
-                if (mine) {
-                    Lm_[i * LDL + js] = cc * x + ss * y;
-                    Lm_[i * LDL + js + 1] = cc * y - ss * x;
-                }
-                if (i == js) linv_[js] = ir;  // 1 / (the new diagonal entry r2 * ir)
+                const double ca = a * ir, sb = b * ir;
+                const double fin = ca * x - sb * carry;  // the new row j: nothing left in column l, a positive diagonal
+                carry = ca * carry + sb * x;
+                a = r2 * ir;
+                if (mine && lane != l) Jm_[j * LDL + cn] = fin;
             }
+            if (mine) Jm_[(k - 1) * LDL + lane] = 0.0, Jm_[lane * LDL + k - 1] = 0.0;  // (J is zero outside its k x k block: solve_factor reads windows)
             LSCQP_DAS_WAVE_SYNC();
         }
         return ok;
     };
-    // r = S^-1 v through the factor (wavefront 0; lane j holds v_j on entry and r_j on return; y = Lm^-1 v is left in y_, r in r_).  The
-    // substitution is a chain of dependent steps (broadcast of the pivot component, one multiply, one FMA); the factor's entries are
-    // requested a window of eight columns ahead so that no LDS round trip sits inside the chain.
-    auto solve_factor = [&](int k, double vi) -> double {
+    // r = S^-1 v = J'(J v) (wavefront 0; lane j holds v_j on entry and r_j on return, also left in r_; yy = v'S^-1 v = |J v|^2 if asked for).
+    // The factor's entries are requested a window of eight columns ahead so that no LDS round trip sits between the multiply-adds; the
+    // loads carry no condition (J is zero outside its block, the index is clamped into the array): a test around a load makes the compiler
+    // wait for each one in turn.
+    auto solve_factor = [&](int k_, double vi, double* yy) -> double {
+        const int k = __builtin_amdgcn_readfirstlane(k_);
         const bool mine = lane < k;
-        const int ll = mine ? lane : 0;
-        const double li_own = mine ? linv_[ll] : 0.0;
+        const int ll = min(lane, kmax - 1);
         vi = mine ? vi : 0.0;
-        for (int j0 = 0; j0 < k; j0 += 8) {  // forward: Lm y = v
-            double Lr[8];
+        double yi = 0.0, ri = 0.0;
+        for (int j0 = 0; j0 < k; j0 += 8) {  // y = J v (row ll of J)
+            double Jr[8];
 #pragma unroll
-            for (int t_ = 0; t_ < 8; t_++) Lr[t_] = (j0 + t_ < k) ? Lm_[ll * LDL + j0 + t_] : 0.0;
+            for (int t_ = 0; t_ < 8; t_++) Jr[t_] = Jm_[ll * LDL + min(j0 + t_, kmax)];  // (column kmax: always zero)
 #pragma unroll
-            for (int t_ = 0; t_ < 8; t_++) {
-                const int js = __builtin_amdgcn_readfirstlane(j0 + t_);
-                if (js < k) {
-                    const double yj = lscqp::bcast(vi * li_own, js);
-                    vi = (lane == js) ? yj : vi;  // (lane j keeps y_j in place of v_j: the backward sweep starts from it)
-                    if (lane > js && mine) vi -= Lr[t_] * yj;
-                }
-            }
+            for (int t_ = 0; t_ < 8; t_++) yi += Jr[t_] * lscqp::bcast(vi, j0 + t_);  // (k <= 32: the lane index stays below 64; lanes >= k hold 0)
         }
-        if (mine) y_[lane] = vi;
-        double yi = vi, ri = 0.0;
-        for (int j1 = k - 1; j1 >= 0; j1 -= 8) {  // backward: Lm' r = y
-            double Lc[8];
+        yi = mine ? yi : 0.0;
+        if (yy) *yy = wave_sum(yi * yi);
+        for (int j0 = 0; j0 < k; j0 += 8) {  // r = J'y (column ll of J)
+            double Jc[8];
 #pragma unroll
-            for (int t_ = 0; t_ < 8; t_++) Lc[t_] = (j1 - t_ >= 0) ? Lm_[(j1 - t_) * LDL + ll] : 0.0;
+            for (int t_ = 0; t_ < 8; t_++) Jc[t_] = Jm_[min(j0 + t_, kmax - 1) * LDL + ll];  // (a clamped row meets y = 0)
 #pragma unroll
-            for (int t_ = 0; t_ < 8; t_++) {
-                const int js = __builtin_amdgcn_readfirstlane(j1 - t_);
-                if (js >= 0) {
-                    const double rj = lscqp::bcast(yi * li_own, js);
-                    ri = (lane == js) ? rj : ri;
-                    if (lane < js) yi -= Lc[t_] * rj;
-                }
-            }
+            for (int t_ = 0; t_ < 8; t_++) ri += Jc[t_] * lscqp::bcast(yi, j0 + t_);
         }
-        if (mine) r_[lane] = ri;
+        ri = mine ? ri : 0.0;
+        if (lane < kmax + 4) r_[lane] = ri;  // (zeros behind the active rows: the update of c reads a window of four without a test)
         return ri;
     };
     // c_[e] = base[e] (or c_[e]) + sum_j wts[j] W_j[e] over the active rows
@@ -746,7 +744,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
 
     // ---- the loop ---------------------------------------------------------------------------------------------------------------------
     int k = 0, steps = 0;
-    bool polished = false, solved = false, haveC = false;
+    bool polished = false, solved = false, haveC = false, haveJ = false;
     double res_p = 0.0, res_d = 0.0, obj = 0.0;
     for (;;) {
         double best;
@@ -771,7 +769,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             LSCQP_DAS_BARRIER();
             if (wv == 0) {
                 const double rho = (lane < k) ? arhs_[lane] - row_dot(&aint_[4 * lane + 1], &acoef_[3 * lane], c_) : 0.0;
-                const double du = solve_factor(k, rho);
+                const double du = solve_factor(k, rho, nullptr);
                 if (lane < k) u_[lane] += du;
             }
             LSCQP_DAS_BARRIER();
@@ -783,6 +781,10 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         polished = false;
         if constexpr (SCREEN) break;  // (a violated row: the full form's)
         if (k >= kmax) break;  // more active rows than this launch holds: the interior-point kernel's
+        if (!haveJ) {  // (before the first step; the barrier behind w_p orders it against wavefront 0's use)
+            for (int e = tid; e < kmax * LDL; e += T) Jm_[e] = 0.0;
+            haveJ = true;
+        }
         if (cacheC && !haveC) {  // the table of this instance's ts in LDS from the first step on (every step reads a few of its columns)
             for (int e = tid; e < P * P; e += T) Cc_[e] = Cg[e];
             haveC = true;
@@ -816,26 +818,28 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             // Wavefront 0 decides the step: v = A'w_p, r = S^-1 v, curvature a_p'w_p - v'r, dual bound t1, primal length t2.
             if (wv == 0) {
                 const double vj = (lane < k) ? row_dot(&aint_[4 * lane + 1], &acoef_[3 * lane], W_ + (size_t)k * NX) : 0.0;
-                const double ri = solve_factor(k, vj);
-                const double vr = wave_sum((lane < k) ? vj * ri : 0.0);
-                const double yy = wave_sum((lane < k) ? y_[lane] * y_[lane] : 0.0);
-                const double curv = spp - vr;
+                DAS_T(13);
+                double yy;
+                const double ri = solve_factor(k, vj, &yy);
+                DAS_T(14);
+                const double curv = spp - yy;  // a_p'w_p - v'S^-1 v
                 const double sp = row_dot(Rp.ent, Rp.coef, c_) - Rp.rhs;
                 const double t2 = (curv > 1e-12 * spp) ? -sp / curv : 1e300;
                 double t1 = (lane < k && ri > 0.0) ? u_[lane] / ri : 1e300;
                 int l = lane;
                 wave_argmin(t1, l);
                 const double t = fmin(t1, t2);
-                int kind;  // 0: no step exists (hand over); 1: p joins; 2: row l leaves; 3: p joins but is dependent after all (hand over)
+                int kind;  // 0: no step exists (hand over); 1: p joins; 2: row l leaves
                 if (!(t < 1e299)) kind = 0;
-                else if (t2 <= t1) kind = (spp - yy > 1e-13 * spp) ? 1 : 3;
+                else if (t2 <= t1) kind = 1;
                 else kind = 2;
+                DAS_T(15);
                 if (kind == 1 || kind == 2) {
                     if (lane < k) u_[lane] = fmax(0.0, u_[lane] - t * ri);
-                    if (kind == 1) {  // one more row of the factor: (y, sqrt(spp - y'y))
-                        const double dl = sqrt(spp - yy);
-                        if (lane < k) Lm_[k * LDL + lane] = y_[lane];
-                        if (lane == 0) Lm_[k * LDL + k] = dl, linv_[k] = 1.0 / dl, u_[k] = ctl_[3] + t;
+                    if (kind == 1) {  // one more row of J: (-r', 1) / sqrt(curv); the column above its diagonal entry is zero
+                        const double idl = rsqrt(curv);
+                        if (lane < k) Jm_[k * LDL + lane] = -ri * idl, Jm_[lane * LDL + k] = 0.0;
+                        if (lane == 0) Jm_[k * LDL + k] = idl, u_[k] = ctl_[3] + t;
                     }
                 }
                 if (lane == 0) {
@@ -846,23 +850,40 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                     ctl_[5] = (t2 < 1e299) ? 1.0 : 0.0;  // a primal step is taken
                 }
             }
+            DAS_T(10);  // the step's decision (wavefront 0)
             LSCQP_DAS_BARRIER();
             const double t = ctl_[0];
-            const int kind = (int)ctl_[1], l = (int)ctl_[2];
+            const int kind = __builtin_amdgcn_readfirstlane((int)ctl_[1]), l = __builtin_amdgcn_readfirstlane((int)ctl_[2]);  // (uniform: scalar loop bounds)
             if (kind == 0 || kind == 3) {
                 stop = true;
                 break;
             }
             // c += t (w_p - sum r_j w_j)   (r_ holds this step's r); a leaving row closes the gap in W on the way (the candidate moves down too)
+            const int ks = __builtin_amdgcn_readfirstlane(k);  // (uniform by construction; said so: scalar loop bounds)
+            const bool primal = __builtin_amdgcn_readfirstlane((int)ctl_[5]) != 0;
             for (int e = tid; e < NX; e += T) {
-                if (ctl_[5] != 0.0) {
-                    double a = W_[(size_t)k * NX + e];
-                    for (int j = 0; j < k; j++) a -= r_[j] * W_[(size_t)j * NX + e];
+                if (primal) {
+                    double a = W_[(size_t)ks * NX + e];
+                    for (int j0 = 0; j0 < ks; j0 += 4) {
+                        double wj[4], rj[4];
+#pragma unroll
+                        for (int t_ = 0; t_ < 4; t_++)  // (past the end: the candidate's column with r_'s zero)
+                            wj[t_] = W_[(size_t)min(j0 + t_, ks) * NX + e], rj[t_] = r_[j0 + t_];
+#pragma unroll
+                        for (int t_ = 0; t_ < 4; t_++) a -= rj[t_] * wj[t_];
+                    }
                     c_[e] += t * a;
                 }
-                if (kind == 2)
-                    for (int j = l; j < k; j++) W_[(size_t)j * NX + e] = W_[(size_t)(j + 1) * NX + e];
+                if (kind == 2) {  // (every thread its own elements: the copies of one element are ordered, those of different elements independent)
+                    double nxt = W_[(size_t)(l + 1) * NX + e];
+                    for (int j = l; j < ks; j++) {
+                        const double cur = nxt;
+                        nxt = W_[(size_t)min(j + 2, ks) * NX + e];
+                        W_[(size_t)j * NX + e] = cur;
+                    }
+                }
             }
+            DAS_T(11);  // the step itself: c, W
             if (kind == 1) {
                 if (tid == 0) {
                     for (int t_ = 0; t_ < 4; t_++) aint_[4 * k + t_] = aint_[4 * kmax + t_];
@@ -873,19 +894,32 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 LSCQP_DAS_BARRIER();
                 break;
             }
-            // row l leaves: close the gap in descriptors and multipliers, downdate the factor (wavefront 0)
-            if (wv == 0 && lane == 0) {
-                for (int j = l; j + 1 < k; j++) {
-                    for (int t_ = 0; t_ < 4; t_++) aint_[4 * j + t_] = aint_[4 * (j + 1) + t_];
-                    for (int t_ = 0; t_ < 3; t_++) acoef_[3 * j + t_] = acoef_[3 * (j + 1) + t_];
-                    arhs_[j] = arhs_[j + 1];
-                    u_[j] = u_[j + 1];
+            // row l leaves: close the gap in descriptors and multipliers (lane j takes slot j + 1's: every lane reads before any lane writes),
+            // downdate the factor (wavefront 0)
+            if (wv == 0) {
+                const bool mv = lane >= l && lane + 1 < k;
+                const int from = mv ? lane + 1 : 0;
+                int ai[4];
+                double ac[3];
+#pragma unroll
+                for (int t_ = 0; t_ < 4; t_++) ai[t_] = aint_[4 * from + t_];
+#pragma unroll
+                for (int t_ = 0; t_ < 3; t_++) ac[t_] = acoef_[3 * from + t_];
+                const double ah = arhs_[from], uu = u_[from];
+                LSCQP_DAS_WAVE_SYNC();
+                if (mv) {
+#pragma unroll
+                    for (int t_ = 0; t_ < 4; t_++) aint_[4 * lane + t_] = ai[t_];
+#pragma unroll
+                    for (int t_ = 0; t_ < 3; t_++) acoef_[3 * lane + t_] = ac[t_];
+                    arhs_[lane] = ah, u_[lane] = uu;
                 }
             }
             const bool okf = factor_remove(k, l);
             k--;
             if (wv == 0 && lane == 0) ctl_[6] = okf ? 0.0 : 1.0;
             LSCQP_DAS_BARRIER();
+            DAS_T(12);  // a leaving row: descriptors, factor
             if (ctl_[6] != 0.0) {
                 stop = true;
                 break;

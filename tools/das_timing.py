@@ -24,14 +24,15 @@ if "--build-only" in sys.argv:
     print(OUT)
     sys.exit(0)
 
-os.environ["LSCQP_LIB"] = OUT
+os.environ["LSCQP_LIB"] = os.environ.get("DAS_TIMING_LIB", OUT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
 from lsc_dr_planner_amd import api, synth  # noqa: E402
 
 L = api.lib()
-NAMES = ["header/boxes/offset", "intervals + c_u", "first pass: reduction", "later passes: reduction", "verification", "candidate (decode, table, w_p)", "partial steps", "epilogue", "passes: LSC rows", "passes: two-sided rows"]
+NAMES = ["header/boxes/offset", "intervals + c_u", "first pass: reduction", "later passes: reduction", "verification", "candidate (decode, table, w_p)", "partial steps", "epilogue", "passes: LSC rows", "passes: two-sided rows",
+         "step: decision (wavefront 0)", "step: c and W", "step: a leaving row", "decision: v = A'w_p", "decision: r = S^-1 v", "decision: sums, lengths, argmin"]
 dev = torch.device("cuda", 0)
 for key in [a for a in sys.argv[1:] if not a.startswith("-")] or ["c1", "c0", "c2", "c3s", "c4_f64"]:
     cfg = bench.CONFIGS[key]
@@ -58,7 +59,7 @@ for key in [a for a in sys.argv[1:] if not a.startswith("-")] or ["c1", "c0", "c
     torch.cuda.synchronize()
     L.lscqp_das_cycles(cyc, 0)
     info = d_info.cpu().numpy().view(api.INFO_DTYPE)
-    c = np.array(list(cyc)[:10], dtype=float) / reps / N
+    c = np.array(list(cyc)[:16], dtype=float) / reps / N
     print("%s: %d QPs, steps mean %.2f max %d, %.1f us per call | cycles per QP (thread 0 of each workgroup, mean over the batch): total %.0f" % (
         key, N, info["iterations"].mean(), info["iterations"].max(), e0.elapsed_time(e1) / reps * 1e3, c.sum()))
     for n_, v in zip(NAMES, c):

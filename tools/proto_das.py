@@ -41,6 +41,9 @@ def tables(M, es, dt, w_c, w_t):
     return out, T
 
 
+PRICING = os.environ.get("PROTO_PRICING", "euclid")  # experiment: 'cnorm' = slack / sqrt(a'C a) (the dual ascent each row offers from rest)
+
+
 def das(M, dim, dt, w_c, w_t, comm_range, es, use_sfc, wmin, wmax, hdr, rows, sfc, ts, tab, kmax=32, max_steps=96, verbose=False):
     P = 6 * M
     NX = dim * P
@@ -119,6 +122,16 @@ def das(M, dim, dt, w_c, w_t, comm_range, es, use_sfc, wmin, wmax, hdr, rows, sf
             return [(k, int(cpj[rid]), Rn[rid, k]) for k in range(dim)], Rb[rid]
         ent, h, _, _ = srows[rid - nL]
         return ent, h
+
+    if PRICING == "cnorm":
+        dC = np.diag(C)
+        inrm = 1.0 / np.sqrt(np.maximum((Rn[:, :dim] ** 2).sum(axis=1) * dC[cpj], 1e-300))
+        for r_ in range(len(srows)):
+            s_ = 0.0
+            for k in range(dim):
+                a_ = SA[r_, k * P:(k + 1) * P]
+                s_ += a_ @ C @ a_
+            Sn[r_] = 1.0 / np.sqrt(max(s_, 1e-300))
 
     def most_violated(c):
         cf = c.reshape(-1)
