@@ -58,7 +58,7 @@ __host__ __device__ inline int num_pairs(int M, int dim) { return dim * (6 * M +
 // LDS carve of one QP, in doubles.
 struct Layout {
     int P, NX, kmax, NPAIR;
-    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_pix, o_W, o_L, o_u, o_r, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_C, o_rows, n_stage, total;
+    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_pix, o_W, o_L, o_u, o_r, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_C, o_rows, o_tl, n_stage, total;
     __host__ __device__ static Layout make(int M, int dim, int kmax, int cacheC, int stage_rows = 0) {
         Layout s;
         s.P = 6 * M, s.NX = dim * s.P, s.kmax = kmax, s.NPAIR = num_pairs(M, dim);
@@ -73,12 +73,15 @@ struct Layout {
         s.o_u = take(kmax + 1), s.o_r = take(kmax + 4), s.o_arhs = take(kmax + 1);
         s.o_acoef = take(3 * (kmax + 1));
         s.o_aint = take(2 * (kmax + 1) + 2);  // ints: per active row {id, entry0, entry1, entry2} (+ the candidate); entry = axis << 16 | control point
-        s.o_red = take(2 * 16);               // cross-wavefront reductions, double buffered
+        s.o_red = take(2 * 24);               // cross-wavefront reductions, double buffered
         s.o_ctl = take(8);
         s.o_wb = take(8);  // world box of the class (a kernel argument indexed with a run-time axis would be fetched through vector memory)
         s.o_C = take(cacheC ? s.P * s.P : 0);
         s.n_stage = stage_rows;  // LSC rows of the instance kept in LDS after the first pass (SoA nx | ny | nz | b), 0: re-read from L2
         s.o_rows = take(4 * stage_rows);
+#ifdef LSCQP_DAS_TIMING
+        s.o_tl = take(16);
+#endif
         s.total = o;
         return s;
     }
@@ -128,17 +131,38 @@ __device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a
 // Development aid: per-phase cycle totals, compiled in only with -DLSCQP_DAS_TIMING (tools/das_timing.py)
 #ifdef LSCQP_DAS_TIMING
 __device__ unsigned long long das_cycles[16];
+// (thread 0 accumulates in LDS and adds to the global totals once, at the end: an atomic behind every probe would be waited for by the next
+// wait on vector memory -- a round trip of microseconds booked on whatever phase comes next)
+#define DAS_T_DECL()                                                                                                                  \
+    unsigned long long* const das_tl_ = reinterpret_cast<unsigned long long*>(smem + Layout::make(M, dim, kmax, cacheC, stage_rows).o_tl); \
+    if (threadIdx.x == 0)                                                                                                             \
+        for (int i_ = 0; i_ < 16; i_++) das_tl_[i_] = 0;                                                                              \
+    unsigned long long tprev_ = __builtin_readcyclecounter()
 #define DAS_T(slot)                                                        \
     do {                                                                   \
-        if ((LSCQP_DAS_TIMING >> (slot)) & 1) {                                \
-        const unsigned long long now_ = __builtin_readcyclecounter();      \
-        if (tid == 0) atomicAdd(&das_cycles[slot], now_ - tprev_);          \
-        tprev_ = now_;                                                     \
+        if ((LSCQP_DAS_TIMING >> (slot)) & 1) {                            \
+            const unsigned long long now_ = __builtin_readcyclecounter();  \
+            if (tid == 0) das_tl_[slot] += now_ - tprev_;                  \
+            tprev_ = now_;                                                 \
         }                                                                  \
     } while (0)
+#ifndef LSCQP_DAS_TIMING_MIN_STEPS
+#define LSCQP_DAS_TIMING_MIN_STEPS 0  /* only instances with at least that many steps are booked */
+#endif
+#define DAS_T_FLUSH()                                                                  \
+    do {                                                                               \
+        if (tid == 0 && steps >= LSCQP_DAS_TIMING_MIN_STEPS)                           \
+            for (int i_ = 0; i_ < 16; i_++) atomicAdd(&das_cycles[i_], das_tl_[i_]);   \
+    } while (0)
 #else
+#define DAS_T_DECL() \
+    do {             \
+    } while (0)
 #define DAS_T(slot) \
     do {            \
+    } while (0)
+#define DAS_T_FLUSH() \
+    do {              \
     } while (0)
 #endif
 
@@ -198,9 +222,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     if (k0 >= n) return;
     const int64_t q = cls.order ? (int64_t)cls.order[k0] : k0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef LSCQP_DAS_TIMING
-    unsigned long long tprev_ = __builtin_readcyclecounter();
-#endif
+    DAS_T_DECL();
     const Layout L = Layout::make(M, dim, kmax, cacheC, stage_rows);
     const int P = L.P, NX = L.NX, NPAIR = L.NPAIR;
     double* const H_ = smem + L.o_hdr;
@@ -417,9 +439,16 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         return translate(j, x, y, z, w, nx, ny, nz, b);
     };
     // stencil of a two-sided row on a vector in c_ layout
+    // (every family as the three-point stencil v[i0] + a1 v[i1] + a2 v[e0] with loads that carry no test: a branch per family makes the
+    // compiler wait for each family's loads in turn; the products with -1, -2, 1, 0 are exact, the value is the plain expression's)
     auto pair_val = [&](int pk, const double* vec) -> double {
         const int type = pk >> 24, e0 = (pk >> 12) & 0xfff, e1 = pk & 0xfff;
-        return type == 1 ? vec[e0] : type == 2 ? (vec[e0 + 1] - vec[e0]) : type == 3 ? (vec[e0 + 2] - 2.0 * vec[e0 + 1] + vec[e0]) : (vec[e1] - vec[e0]);
+        const int i0 = (type == 4) ? e1 : e0 + max(type - 1, 0);  // 1: c[e0]   2: c[e0+1] - c[e0]   3: c[e0+2] - 2 c[e0+1] + c[e0]   4: c[e1] - c[e0]
+        const int i1 = (type == 3) ? e0 + 1 : e0;
+        const double a1 = (type <= 1) ? 0.0 : (type == 3) ? -2.0 : -1.0;
+        const double a2 = (type == 3) ? 1.0 : 0.0;
+        const double v0 = vec[i0], v1 = vec[i1], v2 = vec[e0];
+        return (v0 + a1 * v1) + a2 * v2;
     };
     auto ent_of = [&](int e) -> int {  // position in c_ -> axis << 16 | control point
         const int k = fdiv(e, iP);
@@ -463,9 +492,9 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     bool first_pass = true;  // (uniform)
     // Rows are judged by their RAW slack (metres, the interior-point kernel's bar), which is also what picks the candidate.  Straight-line code:
     // a dropped row, or a slot behind the instance's last row, is the harmless row (0, 0, 0 | -1) -- slack +1 -- instead of a branch.
-    auto pass = [&](double& best, int& bid) {
-        double bv = 1e300;
-        int bi = 0x7fffffff;
+    auto pass_local = [&](double& bv, int& bi) {
+        bv = 1e300;
+        bi = 0x7fffffff;
         auto see = [&](double slack, int id) {
             // (a NaN slack -- NaN in a row, in the header, in the point -- must never read as "satisfied": it becomes the most violated row
             // there is; the step for it finds no length and the instance goes to the interior-point kernel, which answers NUMERIC)
@@ -531,7 +560,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 eval(j0, rx, ry, rz, rb);
             }
         }
-        const bool was_first = first_pass;
         first_pass = false;
         DAS_T(8);
         for (int r0 = tid; r0 < NPAIR; r0 += 2 * T) {  // two at a time: their LDS round trips overlap
@@ -546,22 +574,32 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             see(on1 ? hi1 - d1 : 1.0, nL + 2 * r1 + 1);
         }
         DAS_T(9);
+    };
+    // the workgroup's (slack, id) minimum out of the wavefronts' (buffer rb_: values at [0, 4), ids as ints at [4, 6))
+    auto pass_combine = [&](const double* rb_, double& bv, int& bi) {
+        bv = rb_[0], bi = reinterpret_cast<const int*>(rb_ + 4)[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            const double ov = rb_[w];
+            const int oi = reinterpret_cast<const int*>(rb_ + 4)[w];
+            if (ov < bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
+        }
+    };
+    auto pass = [&](double& best, int& bid) {
+        const bool was_first = first_pass;
+        double bv;
+        int bi;
+        pass_local(bv, bi);
         wave_argmin(bv, bi);
         if constexpr (NW > 1) {
-            double* const rb_ = red_ + 16 * par;
+            double* const rb_ = red_ + 24 * par;
             par ^= 1;
             if (lane == 0) {
                 rb_[wv] = bv;
-                reinterpret_cast<int*>(rb_ + 8)[wv] = bi;
+                reinterpret_cast<int*>(rb_ + 4)[wv] = bi;
             }
             LSCQP_DAS_BARRIER();
-            bv = rb_[0], bi = reinterpret_cast<int*>(rb_ + 8)[0];
-#pragma unroll
-            for (int w = 1; w < NW; w++) {
-                const double ov = rb_[w];
-                const int oi = reinterpret_cast<int*>(rb_ + 8)[w];
-                if (ov < bv || (ov == bv && oi < bi)) bv = ov, bi = oi;
-            }
+            pass_combine(rb_, bv, bi);
         } else if (staged && was_first) {
             LSCQP_DAS_BARRIER();  // the staged rows are read by other lanes from now on
         }
@@ -647,7 +685,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     // ---- verification + objective, one reduction: reduced stationarity T'(Hx c + fx - A'u) scaled as lscqp_info.res_dual; objective exactly
     // as cplex.getObjValue() reports it (as lscqp_kernel.hpp).  Every z thread evaluates the <= 4 control-point rows of Hx it needs itself.
     const int NZA = 3 * (M - 1) + (es ? 1 : 3);
-    auto finish = [&](int k, double& res_d, double& obj) {
+    auto finish_local = [&](int k, double& rd, double& gs, double& part) {
         if (k > 0) {  // A'u, per control point
             for (int e = tid; e < NX; e += T) lam_[e] = 0.0;
             LSCQP_DAS_BARRIER();
@@ -661,7 +699,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             }
             LSCQP_DAS_BARRIER();
         }
-        double rd = 0.0, gs = 0.0;
+        rd = 0.0, gs = 0.0;
         for (int zi = tid; zi < dim * NZA; zi += T) {
             const int kx = zi / NZA, a = zi - kx * NZA;
             const bool last = es && a == 3 * (M - 1);
@@ -703,8 +741,10 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             rd = fmax(rd, fabs(cf));
             gs = fmax(gs, fmax(fabs(cg), fabs(c0)));
         }
-        double part = 0.0;
-        for (int lv = tid; lv < dim * M; lv += T) {
+        part = 0.0;
+        // (the objective's threads sit in the second wavefront when there is one: its arithmetic runs beside the stationarity rows' instead of behind them)
+        for (int lv = tid - (NW > 1 ? 64 : 0); lv < dim * M; lv += T) {
+            if (lv < 0) continue;
             const int kx = lv / M, m = lv - kx * M;
             const double* cc = &c_[kx * P + 6 * m];
             const double j0 = (cc[3] - cc[0]) - 3.0 * (cc[2] - cc[1]);
@@ -726,20 +766,29 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             pp += (m >= M - ts) ? cls.w_t * dgoal * dgoal : 0.0;
             part += pp;
         }
-        rd = wave_max(rd);
-        gs = wave_max(gs);
-        part = wave_sum(part);
-        if constexpr (NW > 1) {
-            double* const rb_ = red_ + 16 * par;
-            par ^= 1;
-            if (lane == 0) rb_[wv] = rd, rb_[4 + wv] = gs, rb_[8 + wv] = part;
-            LSCQP_DAS_BARRIER();
-            rd = rb_[0], gs = rb_[4], part = rb_[8];
+    };
+    // (buffer rb_: the wavefronts' stationarity maxima at [8, 12), gradient scales at [12, 16), objective parts at [16, 20))
+    auto finish_combine = [&](const double* rb_, double& rd, double& gs, double& part) {
+        rd = rb_[8], gs = rb_[12], part = rb_[16];
 #pragma unroll
-            for (int w = 1; w < NW; w++) rd = fmax(rd, rb_[w]), gs = fmax(gs, rb_[4 + w]), part += rb_[8 + w];  // (fixed order: reproducible)
-        }
+        for (int w = 1; w < NW; w++) rd = fmax(rd, rb_[8 + w]), gs = fmax(gs, rb_[12 + w]), part += rb_[16 + w];  // (fixed order: reproducible)
+    };
+    auto finish_verdict = [&](double rd, double gs, double part, double& res_d, double& obj) {
         res_d = (part == part && fabs(part) < 1e300) ? rd / fmax(1.0, gs) : 1e300;  // (a non-finite objective is not a pass)
         obj = part;
+    };
+    auto finish = [&](int k, double& res_d, double& obj) {
+        double rd, gs, part;
+        finish_local(k, rd, gs, part);
+        lscqp::wave_reduce3<lscqp::OpMax, lscqp::OpMax, lscqp::OpSum>(rd, gs, part);
+        if constexpr (NW > 1) {
+            double* const rb_ = red_ + 24 * par;
+            par ^= 1;
+            if (lane == 0) rb_[8 + wv] = rd, rb_[12 + wv] = gs, rb_[16 + wv] = part;
+            LSCQP_DAS_BARRIER();
+            finish_combine(rb_, rd, gs, part);
+        }
+        finish_verdict(rd, gs, part, res_d, obj);
     };
 
     // ---- the loop ---------------------------------------------------------------------------------------------------------------------
@@ -930,6 +979,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     }
     if (!solved) {
         hand_over(steps);
+        DAS_T_FLUSH();
         return;
     }
 
@@ -947,6 +997,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         }
     }
     DAS_T(7);  // epilogue
+    DAS_T_FLUSH();
 }
 
 }  // namespace lscqp_das

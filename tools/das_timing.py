@@ -59,7 +59,9 @@ for key in [a for a in sys.argv[1:] if not a.startswith("-")] or ["c1", "c0", "c
     torch.cuda.synchronize()
     L.lscqp_das_cycles(cyc, 0)
     info = d_info.cpu().numpy().view(api.INFO_DTYPE)
-    c = np.array(list(cyc)[:16], dtype=float) / reps / N
+    nbook = int(os.environ.get("DAS_TIMING_MIN_STEPS", "0"))
+    Nb = max(1, int((info["iterations"] >= nbook).sum()))  # (DAS_TIMING_DIV: a build with LSCQP_DAS_TIMING_MIN_STEPS books those instances only)
+    c = np.array(list(cyc)[:16], dtype=float) / reps / Nb
     print("%s: %d QPs, steps mean %.2f max %d, %.1f us per call | cycles per QP (thread 0 of each workgroup, mean over the batch): total %.0f" % (
         key, N, info["iterations"].mean(), info["iterations"].max(), e0.elapsed_time(e1) / reps * 1e3, c.sum()))
     for n_, v in zip(NAMES, c):
