@@ -916,7 +916,8 @@ def workload_roofline(ctx, a, S):
     pd = "lscqp_pdip_kernel<%d,%d,true,NSLOT,W,%s>" % (S.M, S.dim, "float" if a.precision == "mixed" else "double")
     if S.das_ms is not None and S.paths["active_set_solved"] >= 0.5 * S.n_agents_seen:
         n_cu = ctx.torch.cuda.get_device_properties(ctx.dev_index).multi_processor_count
-        kms, kname = S.das_ms, "lscqp_das::das_kernel<%d,%s>" % (4 if S.N <= 8 * n_cu else 1, "true" if a.rows == "f32" else "false")
+        kms, kname = S.das_ms, "lscqp_das::das_kernel<%d,%s,false,%s>" % (4 if S.N <= 8 * n_cu else 1, "true" if a.rows == "f32" else "false",
+                                                                                  "false" if S.N <= 2 * n_cu else "true")  # (wavefronts, row format, lean form, first look peeled)
     else:
         kms, kname = S.kernel_ms, pd
     achieved = bq * S.N / (kms * 1e-3)

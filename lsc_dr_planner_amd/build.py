@@ -104,7 +104,10 @@ def build(force=False, verbose=False, jobs=None):
     objs.append(das_o)
     das_src = os.path.join(CSRC, "lscqp_das.hip")
     if force or _newer(das_o, hdrs + [das_src]):
-        tasks.append([HIPCC] + FLAGS + ["-c", das_src, "-o", das_o])
+        # -ffp-contract=on: a multiply-add is fused where the SOURCE writes a * b + c in one expression and nowhere else.  The default (fast) lets
+        # the backend fuse across statements as the surrounding code happens to allow -- the kernel's instantiations (row formats, wavefronts
+        # per QP, launch forms) then differ in the last bit, and the phase's results are required to be identical across all of them
+        tasks.append([HIPCC] + FLAGS + ["-ffp-contract=on", "-c", das_src, "-o", das_o])
     diag_o = os.path.join(OBJ, "lscqp_diag.o")
     objs.append(diag_o)
     diag_src = os.path.join(CSRC, "lscqp_diag.hip")

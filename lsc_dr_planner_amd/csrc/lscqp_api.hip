@@ -153,9 +153,10 @@ int cu_count() {  // of the CURRENT device (one process may drive several: lscqp
     static bool known[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!known[dev]) {
-        hipDeviceProp_t prop;
-        n_cu[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    if (!known[dev]) {  // (a failed query is not remembered: the launch policies would then treat every batch as one that fills the chip, for the whole process)
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 0;
+        n_cu[dev] = v;
         known[dev] = true;
     }
     return n_cu[dev];
@@ -426,10 +427,10 @@ static void das_refresh(lscqp_solver* s) {
     if (!s->das) return;
     std::lock_guard<std::mutex> lk(s->das->mu);
     const size_t nd = lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, nullptr);
-    s->das->host.assign(nd, 0.0);
+    s->das->host.assign(nd + 36, 0.0);  // (the tables, then the class's 36 coefficient-rounding terms of the objective: the kernel reads them from here)
     if (s->desc.control_input_weight > 0 && s->desc.terminal_weight >= 0 &&
         lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, s->das->host.data()) == nd) {
-        // ok
+        for (int i = 0; i < 36; i++) s->das->host[nd + i] = s->dev.dQ[i];
     } else {
         s->das->host.clear();  // (a class whose reduced Hessian is not positive definite has no active-set phase)
     }
@@ -1040,7 +1041,7 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             // wavefronts per QP, the whole budget of active rows, the class's table and the instance's rows in LDS; up to eight per CU
             // the launch still lasts as long as its slowest QP (1024 x M10 x 40: 0.28 ms with one wavefront per QP, 0.19 ms with four) but
             // LDS is what limits the resident workgroups -- four wavefronts, a small footprint; beyond that one wavefront per QP.
-            const int64_t ncu = cu_count();
+            const int64_t ncu = cu_count() > 0 ? cu_count() : 256;
             const bool small = n <= 2 * ncu, medium = n <= 8 * ncu;
             auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
             int threads = env_int("LSCQP_DAS_THREADS", medium ? 256 : 64);
@@ -1048,7 +1049,9 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             int steps = env_int("LSCQP_DAS_STEPS", small ? 96 : 24);
             int cacheC = env_int("LSCQP_DAS_CACHE", small ? 1 : 0);
             int stage = env_int("LSCQP_DAS_STAGE", small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
-            const int screen = env_int("LSCQP_DAS_SCREEN", 0);  // the lean form in front: built and measured, no gain (the phase is bound by instruction issue, not occupancy)
+            // form: bit 0 the lean form in front (built and measured, no gain: the phase is bound by instruction issue, not occupancy); bit 1 the
+            // first look inside the loop of steps (one copy of that code: batches of at most two workgroups per CU; lscqp_das.hip, PEEL)
+            const int screen = (env_int("LSCQP_DAS_SCREEN", 0) ? 1 : 0) | (env_int("LSCQP_DAS_LOOP", small ? 1 : 0) ? 2 : 0);
             const int Mx = h->desc.M, dx = h->desc.dim;
             // what does not fit the CU's LDS is given up in this order: staged rows, the table copy, active rows
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) stage = 0;

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "lsc_dr_planner_amd", "csrc")
 OUT = os.path.join(ROOT, "lsc_dr_planner_amd", "liblscqp_dastime.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-mllvm", "-disable-promote-alloca-to-vector", "-ffp-contract=on"]
 
 if "--build-only" in sys.argv:
     o = "/tmp/lscqp_das_timing.o"
