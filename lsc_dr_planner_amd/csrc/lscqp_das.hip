@@ -176,24 +176,29 @@ struct Row {
 __device__ __forceinline__ int ent_axis(int e) { return e >> 16; }
 __device__ __forceinline__ int ent_cp(int e) { return e & 0xffff; }
 
-// a' C b for two rows: C couples control points of the same axis only
+// C couples control points of the same axis only.
+// (C a)[axis kx, control point cp]
+__device__ __forceinline__ double ccol(const int* ea, const double* ca, int kx, int cp, const double* __restrict__ Cm, int P) {
+    // (loads without a test -- an unused entry is (axis 0, control point 0) with coefficient 0 -- so that the three are in flight together)
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double v = Cm[(size_t)ent_cp(ea[i]) * P + cp];
+        s += ((ent_axis(ea[i]) == kx) ? ca[i] : 0.0) * v;
+    }
+    return s;
+}
+// a'C b for two rows
 __device__ __forceinline__ double cdot(const int* ea, const double* ca, const int* eb, const double* cb, const double* __restrict__ Cm, int P) {
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            if (ca[i] != 0.0 && cb[j] != 0.0 && ent_axis(ea[i]) == ent_axis(eb[j])) s += ca[i] * cb[j] * Cm[(size_t)ent_cp(ea[i]) * P + ent_cp(eb[j])];
+            const double v = Cm[(size_t)ent_cp(ea[i]) * P + ent_cp(eb[j])];
+            s += ((ent_axis(ea[i]) == ent_axis(eb[j])) ? ca[i] * cb[j] : 0.0) * v;
         }
     }
-    return s;
-}
-// (C a)[axis kx, control point cp]
-__device__ __forceinline__ double ccol(const int* ea, const double* ca, int kx, int cp, const double* __restrict__ Cm, int P) {
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-        if (ca[i] != 0.0 && ent_axis(ea[i]) == kx) s += ca[i] * Cm[(size_t)ent_cp(ea[i]) * P + cp];
     return s;
 }
 
@@ -873,8 +878,9 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         polished = false;
         if constexpr (SCREEN) break;  // (a violated row: the full form's)
         if (k >= kmax) break;  // more active rows than this launch holds: the interior-point kernel's
-        if (!haveJ) {  // (before the first step; the barrier behind w_p orders it against wavefront 0's use)
-            for (int e = tid; e < kmax * LDL; e += T) Jm_[e] = 0.0;
+        if (!haveJ) {  // (before the first step; by wavefront 0, the only one that touches J: in order with its own use)
+            if (wv == 0)
+                for (int e = lane; e < kmax * LDL; e += 64) Jm_[e] = 0.0;
             haveJ = true;
         }
         if (cacheC && !haveC) {  // the table of this instance's ts in LDS from the first step on (every step reads a few of its columns)
@@ -892,24 +898,31 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             arhs_[kmax] = Rp.rhs;
             ctl_[3] = 0.0;  // the candidate's multiplier so far
         }
-        // w_p = C a_p into slot k of W (every thread its control points); wavefront 0 needs only a_p'C a_p of it, which it computes itself
-        for (int e = tid; e < NX; e += T) {
-            const int kx = fdiv(e, iP), cp = e - kx * P;
-            W_[(size_t)k * NX + e] = ccol(Rp.ent, Rp.coef, kx, cp, Cm, P);
-        }
-        LSCQP_DAS_BARRIER();
-        DAS_T(5);  // candidate: decode, table copy, w_p
-        const double spp = row_dot(Rp.ent, Rp.coef, W_ + (size_t)k * NX);
-        bool stop = false;
+        // w_p = C a_p goes into slot k of W.  Wavefront 0's decision of the first partial step does not read it -- a_p'C a_p comes straight from
+        // the table, v_j = a_j'C a_p = a_p'w_j from the columns the active rows already have -- so the OTHER wavefronts compute w_p while
+        // wavefront 0 decides, and one barrier serves both (one wavefront per QP: first w_p, then the decision).
+        auto compute_wp = [&](int first_thread, int n_threads) {
+            for (int e = tid - first_thread; e < NX; e += n_threads) {
+                if (e < 0) continue;
+                const int kx = fdiv(e, iP), cp = e - kx * P;
+                W_[(size_t)k * NX + e] = ccol(Rp.ent, Rp.coef, kx, cp, Cm, P);
+            }
+        };
+        if constexpr (NW == 1) compute_wp(0, T);
+        DAS_T(5);  // candidate: decode, table copy (one wavefront: w_p)
+        double spp = 0.0;  // a_p'C a_p (wavefront 0)
+        bool stop = false, first_step = true;
         for (;;) {  // partial steps until p has joined the set
             steps++;
             if (steps > max_steps) {
                 stop = true;
                 break;
             }
+            if (NW > 1 && first_step && wv != 0) compute_wp(64, T - 64);
             // Wavefront 0 decides the step: v = A'w_p, r = S^-1 v, curvature a_p'w_p - v'r, dual bound t1, primal length t2.
             if (wv == 0) {
-                const double vj = (lane < k) ? row_dot(&aint_[4 * lane + 1], &acoef_[3 * lane], W_ + (size_t)k * NX) : 0.0;
+                if (first_step) spp = cdot(Rp.ent, Rp.coef, Rp.ent, Rp.coef, Cm, P);
+                const double vj = (lane < k) ? row_dot(Rp.ent, Rp.coef, W_ + (size_t)lane * NX) : 0.0;
                 DAS_T(13);
                 double yy;
                 const double ri = solve_factor(k, vj, &yy);
@@ -942,6 +955,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                     ctl_[5] = (t2 < 1e299) ? 1.0 : 0.0;  // a primal step is taken
                 }
             }
+            first_step = false;
             DAS_T(10);  // the step's decision (wavefront 0)
             LSCQP_DAS_BARRIER();
             const double t = ctl_[0];
