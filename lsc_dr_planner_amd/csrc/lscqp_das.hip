@@ -351,6 +351,21 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         }
     }
 
+    // The small-batch form asks for the class's table NOW as well (an instance with a step would otherwise wait a memory round trip for it at
+    // its first step -- and in a batch of 64 that one instance is the launch's time); a quiet instance never waits for these loads.
+    constexpr int kCPre = (NW == 4 && !PEEL && !SCREEN) ? 6 : 0;  // table entries per thread held in registers (6 x 256 >= 36 M^2 up to M = 6)
+    double cpre[kCPre > 0 ? kCPre : 1];
+    const bool c_prefetched = kCPre > 0 && cacheC && P * P <= kCPre * T;  // (uniform)
+    if constexpr (kCPre > 0) {
+        if (c_prefetched) {
+#pragma unroll
+            for (int i = 0; i < kCPre; i++) {
+                const int e = tid + i * T;
+                cpre[i] = Cg[e < P * P ? e : 0];
+            }
+        }
+    }
+
     // ---- the two-sided rows, one table for all four families (ids nL + 2 r + side; side 0: stencil - lo >= 0, side 1: hi - stencil >= 0) ----
     //   r in [0, NX)                    interval of one control point: world box, corridor, communication rows on c[m][5]  (:252-265, 372-397, 482-497)
     //   then dim * 5M velocity rows     c[i+1] - c[i],            |.| <= vmax dt / n          (:448-453)
@@ -884,7 +899,19 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             haveJ = true;
         }
         if (cacheC && !haveC) {  // the table of this instance's ts in LDS from the first step on (every step reads a few of its columns)
-            for (int e = tid; e < P * P; e += T) Cc_[e] = Cg[e];
+            bool copied = false;
+            if constexpr (kCPre > 0) {
+                if (c_prefetched) {
+#pragma unroll
+                    for (int i = 0; i < kCPre; i++) {
+                        const int e = tid + i * T;
+                        if (e < P * P) Cc_[e] = cpre[i];
+                    }
+                    copied = true;
+                }
+            }
+            if (!copied)
+                for (int e = tid; e < P * P; e += T) Cc_[e] = Cg[e];
             haveC = true;
             Cm = Cc_;
             LSCQP_DAS_BARRIER();  // (every thread reads columns other threads copied)
