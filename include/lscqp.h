@@ -392,7 +392,17 @@ int lscqp_allgather(lscqp_comm c, const double* const* d_send, double* const* d_
  * just rewritten its own block.  Equal blocks: ONE in-place all-gather (kind LSCQP_XCHG_ALLGATHER: every device sends `count`
  * doubles from `offset_of_device[g] = first[g] * per`, block g lands at first[g] * per on every device).  A short or empty last
  * block: one broadcast per NON-EMPTY owner (kind LSCQP_XCHG_BROADCAST, root = the owner, `offset` / `count` in doubles), empty
- * owners are skipped by every device alike.  Returns the number of operations in *n_ops (<= n_devices). */
+ * owners are skipped by every device alike.  Returns the number of operations in *n_ops (<= n_devices).
+ *
+ * lscqp_exchange_schedule_padded: the same with `pad_agents` agents of room BEHIND the mission in every device's buffer.  The blocks
+ * lscqp_shard_range cuts -- ceil(n_total / G) agents each, a shorter one, then empty ones -- start at multiples of the block size, so a
+ * ragged mission is ONE in-place all-gather of the full block size as well (device g sends from g * B * per; what a short or empty
+ * block sends beyond its agents lands behind the mission, in the padding) whenever G * B - n_total <= pad_agents; otherwise, and for
+ * blocks of any other shape, the broadcasts above.  The three buffers lscqp_plan_group_step exchanges (LSCQP_PLAN_BUF_PLAN, _STATE,
+ * _GOAL) are allocated with LSCQP_PLAN_EXCHANGE_PAD agents of such room (G * B - n_total < G <= 64 always): a group of plans cut by
+ * lscqp_shard_range exchanges with one all-gather per buffer whatever the agent count.  lscqp_plan_buffer keeps reporting the
+ * mission's own bytes. */
+#define LSCQP_PLAN_EXCHANGE_PAD 64
 #define LSCQP_XCHG_ALLGATHER 0
 #define LSCQP_XCHG_BROADCAST 1
 typedef struct lscqp_exchange_op {
@@ -403,6 +413,8 @@ typedef struct lscqp_exchange_op {
 } lscqp_exchange_op;
 int lscqp_exchange_schedule(int64_t n_total, int32_t n_devices, const int64_t* first, const int64_t* count, int64_t per,
                             lscqp_exchange_op* ops, int32_t max_ops, int32_t* n_ops);
+int lscqp_exchange_schedule_padded(int64_t n_total, int32_t n_devices, const int64_t* first, const int64_t* count, int64_t per, int64_t pad_agents,
+                                   lscqp_exchange_op* ops, int32_t max_ops, int32_t* n_ops);
 
 /* ---- next row of the path: the producer of the LSC rows --------------------------------
  *

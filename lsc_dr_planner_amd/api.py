@@ -155,6 +155,8 @@ def lib():
         L.lscqp_shard_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, vp, vp]
         L.lscqp_exchange_schedule.restype = C.c_int
         L.lscqp_exchange_schedule.argtypes = [C.c_int64, C.c_int32, vp, vp, C.c_int64, vp, C.c_int32, vp]
+        L.lscqp_exchange_schedule_padded.restype = C.c_int
+        L.lscqp_exchange_schedule_padded.argtypes = [C.c_int64, C.c_int32, vp, vp, C.c_int64, C.c_int64, vp, C.c_int32, vp]
         L.lscqp_comm_synchronize.restype = C.c_int
         L.lscqp_comm_synchronize.argtypes = [vp]
         L.lscqp_solve_batch_sharded.restype = C.c_int
@@ -243,7 +245,7 @@ EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_launch_capacity", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
                     "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
-                    "lscqp_comm_devices_for", "lscqp_comm_devices_for_class", "lscqp_device_fill", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
+                    "lscqp_comm_devices_for", "lscqp_comm_devices_for_class", "lscqp_device_fill", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_exchange_schedule_padded", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
                     "lscqp_shift_traj_device", "lscqp_shift_traj_partial_device", "lscqp_generate_constraints_device_ex",
                     "lscqp_generate_lsc_obstacles_device", "lscqp_generate_lsc_bytes", "lscqp_optimize_goal_device", "lscqp_optimize_goal", "lscqp_validate_step_device", "lscqp_map_create", "lscqp_map_create_from_csv", "lscqp_map_destroy", "lscqp_map_info",
@@ -457,13 +459,20 @@ XCHG_ALLGATHER, XCHG_BROADCAST = 0, 1
 EXCHANGE_OP_DTYPE = np.dtype([("kind", "<i4"), ("root", "<i4"), ("offset", "<i8"), ("count", "<i8")])
 
 
-def exchange_schedule(n_total, first, count, per=1):
-    """lscqp_exchange_schedule: the collective operations of the exchange that follows a sharded replan (what lscqp_plan_group_step
-    runs over RCCL), for blocks [first[g], first[g] + count[g]) of n_total agents, `per` doubles per agent.  No device needed."""
+PLAN_EXCHANGE_PAD = 64  # LSCQP_PLAN_EXCHANGE_PAD
+
+
+def exchange_schedule(n_total, first, count, per=1, pad_agents=None):
+    """lscqp_exchange_schedule[_padded]: the collective operations of the exchange that follows a sharded replan (what lscqp_plan_group_step
+    runs over RCCL), for blocks [first[g], first[g] + count[g]) of n_total agents, `per` doubles per agent; pad_agents: agents of room
+    behind the mission in every device's buffer (None: the unpadded entry).  No device needed."""
     first, count = np.ascontiguousarray(first, dtype=np.int64), np.ascontiguousarray(count, dtype=np.int64)
     ops = np.zeros(max(len(first), 1), EXCHANGE_OP_DTYPE)
     n = C.c_int32()
-    rc = lib().lscqp_exchange_schedule(int(n_total), len(first), first.ctypes.data, count.ctypes.data, int(per), ops.ctypes.data, len(ops), C.byref(n))
+    if pad_agents is not None:
+        rc = lib().lscqp_exchange_schedule_padded(int(n_total), len(first), first.ctypes.data, count.ctypes.data, int(per), int(pad_agents), ops.ctypes.data, len(ops), C.byref(n))
+    else:
+        rc = lib().lscqp_exchange_schedule(int(n_total), len(first), first.ctypes.data, count.ctypes.data, int(per), ops.ctypes.data, len(ops), C.byref(n))
     if rc != OK:
         raise LscqpError(rc, lib().lscqp_last_error().decode())
     return ops[: n.value]

@@ -468,8 +468,11 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
     const size_t n = (size_t)desc->n_agents, nt = (size_t)desc->n_total, P = (size_t)M * 6, no = (size_t)desc->n_obs;
     int rc = LSCQP_OK;
     auto ok = [&](int r) { return rc == LSCQP_OK && (rc = r) == LSCQP_OK; };
-    ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_STATE, nt * 9)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_WAYPOINT, n * 3)) &&
-        ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_PLAN, nt * nv)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_GOAL, nt * 3)) &&
+    // (the three buffers a group exchanges carry room for LSCQP_PLAN_EXCHANGE_PAD agents behind the mission: a ragged split is then one
+    // in-place all-gather of full blocks as well, include/lscqp.h; the public size stays the mission's)
+    const size_t ntp = nt + LSCQP_PLAN_EXCHANGE_PAD;
+    ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_STATE, ntp * 9)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_WAYPOINT, n * 3)) &&
+        ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_PLAN, ntp * nv)) && ok(dalloc_pub<double>(p, LSCQP_PLAN_BUF_GOAL, ntp * 3)) &&
         ok(dalloc_pub<lscqp_header>(p, LSCQP_PLAN_BUF_HEADER, n)) && ok(dalloc_pub<lscqp_row>(p, LSCQP_PLAN_BUF_ROWS, n * no * P)) &&
         ok(dalloc_pub<lscqp_box>(p, LSCQP_PLAN_BUF_SFC, n * M)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_STATUS, n)) &&
         ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_GOAL_STATUS, n)) && ok(dalloc_pub<int32_t>(p, LSCQP_PLAN_BUF_SFC_STATUS, n)) &&
@@ -480,6 +483,11 @@ int lscqp_plan_create(lscqp_handle h, lscqp_map map, const lscqp_plan_desc* desc
         ok(dalloc(p, &p->points, n * 9)) && ok(dalloc(p, &p->own, n * P * 3)) && ok(dalloc(p, &p->x_init, n * nv)) && ok(dalloc(p, &p->x_new, n * nv)) &&
         ok(dalloc(p, &p->nbr, n * no)) && ok(dalloc(p, &p->off, n + 1)) && ((int64_t)n > lscqp_launch_capacity(h, (int64_t)n, desc->n_obs) ? ok(dalloc(p, &p->order, n)) : true) &&
         ((map && n > lscplan::kSfcOrderMin) ? (ok(dalloc(p, &p->sfc_order, n)) && ok(dalloc(p, &p->sfc_cost, n))) : true);
+    if (rc == LSCQP_OK) {
+        p->bytes[LSCQP_PLAN_BUF_STATE] = nt * 9 * sizeof(double);
+        p->bytes[LSCQP_PLAN_BUF_PLAN] = nt * nv * sizeof(double);
+        p->bytes[LSCQP_PLAN_BUF_GOAL] = nt * 3 * sizeof(double);
+    }
     if (rc == LSCQP_OK && desc->closed_loop) {
         p->buf[LSCQP_PLAN_BUF_NEXT_STATE] = (double*)p->buf[LSCQP_PLAN_BUF_STATE] + desc->first_agent * 9;
         p->bytes[LSCQP_PLAN_BUF_NEXT_STATE] = n * 9 * sizeof(double);

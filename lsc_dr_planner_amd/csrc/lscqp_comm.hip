@@ -226,7 +226,12 @@ int lscqp_shard_range(int64_t n, int32_t n_used, int32_t g, int64_t* first, int6
 
 int lscqp_exchange_schedule(int64_t n_total, int32_t n_devices, const int64_t* first, const int64_t* count, int64_t per,
                             lscqp_exchange_op* ops, int32_t max_ops, int32_t* n_ops) {
-    if (!first || !count || !ops || !n_ops || n_devices < 1 || n_total < 0 || per < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "bad exchange query");
+    return lscqp_exchange_schedule_padded(n_total, n_devices, first, count, per, 0, ops, max_ops, n_ops);
+}
+
+int lscqp_exchange_schedule_padded(int64_t n_total, int32_t n_devices, const int64_t* first, const int64_t* count, int64_t per, int64_t pad_agents,
+                                   lscqp_exchange_op* ops, int32_t max_ops, int32_t* n_ops) {
+    if (!first || !count || !ops || !n_ops || n_devices < 1 || n_total < 0 || per < 0 || pad_agents < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "bad exchange query");
     int64_t next = 0;
     bool equal = true;
     for (int g = 0; g < n_devices; g++) {
@@ -236,8 +241,19 @@ int lscqp_exchange_schedule(int64_t n_total, int32_t n_devices, const int64_t* f
         if (count[g] != count[0]) equal = false;
     }
     if (next != n_total) return fail(LSCQP_ERR_INVALID_ARGUMENT, "the blocks of the group do not cover the mission (sum of n_agents != n_total)");
+    // the blocks of lscqp_shard_range -- B = ceil(n / G) agents at multiples of B, one shorter, the rest empty -- with room behind the mission
+    // for what the short and the empty ones send beyond their agents
+    bool ceil_split = !equal && count[0] > 0;
+    if (ceil_split) {
+        const int64_t B = count[0];
+        for (int g = 0; g < n_devices && ceil_split; g++) {
+            const int64_t at = std::min<int64_t>((int64_t)g * B, n_total), want = std::min<int64_t>(B, n_total - at);
+            if (first[g] != at || count[g] != want) ceil_split = false;
+        }
+        if ((int64_t)n_devices * B - n_total > pad_agents) ceil_split = false;
+    }
     int k = 0;
-    if (equal) {
+    if (equal || ceil_split) {
         if (max_ops < 1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "ops array too small");
         ops[k++] = {LSCQP_XCHG_ALLGATHER, -1, 0, count[0] * per};
     } else {
@@ -454,7 +470,7 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
     std::vector<lscqp_exchange_op> ops(G);
     int32_t n_ops = 0;
     {
-        const int rc = lscqp_exchange_schedule(n_total, G, first.data(), count.data(), 1, ops.data(), G, &n_ops);
+        const int rc = lscqp_exchange_schedule_padded(n_total, G, first.data(), count.data(), 1, LSCQP_PLAN_EXCHANGE_PAD, ops.data(), G, &n_ops);
         if (rc != LSCQP_OK) return rc;
     }
     DeviceGuard dg;
@@ -485,8 +501,9 @@ int lscqp_plan_group_step(lscqp_comm c, const lscqp_plan* plans, int32_t use_gra
             const size_t per = (size_t)(bytes / sizeof(double) / (uint64_t)n_total);  // doubles per agent
             for (int k = 0; k < n_ops && r == ncclSuccess; k++) {
                 const lscqp_exchange_op& op = ops[k];
-                if (op.kind == LSCQP_XCHG_ALLGATHER) {  // in place: device g's own block is where the all-gather puts it
-                    r = c->rccl.AllGather(base + (size_t)first[g] * per, base, (size_t)op.count * per, ncclDouble, c->comms[g], c->stream[g]);
+                if (op.kind == LSCQP_XCHG_ALLGATHER) {  // in place: device g's own block is where the all-gather puts it -- g blocks of op.count
+                    // agents into the buffer (= first[g] for every block that holds agents; an EMPTY block of a ragged mission sends from the padding)
+                    r = c->rccl.AllGather(base + (size_t)g * (size_t)op.count * per, base, (size_t)op.count * per, ncclDouble, c->comms[g], c->stream[g]);
                 } else {
                     double* const blk = base + (size_t)op.offset * per;
                     r = c->rccl.Broadcast(blk, blk, (size_t)op.count * per, ncclDouble, op.root, c->comms[g], c->stream[g]);

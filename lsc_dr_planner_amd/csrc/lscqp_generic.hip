@@ -495,6 +495,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
     int jam_since = 0;
     bool recentred = false;
     int shift_level = 0;  // (lscqp_kernel.hpp: a lost pivot repeats the iteration with 1e-14 / 1e-12 max|K| on the diagonal)
+    bool repeated = false;  // (lscqp_kernel.hpp: a repeated iteration takes the point's tests and counters once, and is counted once)
     const double tol = cls.tol;
 
     if (status != LSCQP_STATUS_INFEASIBLE)
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
             gls = fmax(1.0, gls);
             res_p = max_rp;
             res_d = rdn / gls;
-            if ((it & 3) == 2) {  // infeasibility: a primal residual that stalls, or runaway multipliers (see lscqp_kernel.hpp)
+            if (!repeated && (it & 3) == 2) {  // infeasibility: a primal residual that stalls, or runaway multipliers (see lscqp_kernel.hpp)
                 stalled = (it >= 10 && max_rp > 1e-4 && max_rp > 0.7 * (double)rp_ref) ? stalled + 1 : 0;
                 if (stalled >= 2 || (it >= 10 && max_rp > 1e-5 && sum_pinf > 1e6)) {
                     status = LSCQP_STATUS_INFEASIBLE;
@@ -619,7 +620,9 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 }
                 rp_ref = (float)max_rp;
             }
-            if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {
+            if (repeated) {
+                // (nothing: see `repeated`)
+            } else if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {
                 obj_abs = fabs(objective(false));
                 res_gap = (sum_sl + sum_pinf) / (1.0 + obj_abs);
                 if (res_gap <= tol || (res_gap <= 10.0 * tol && rdn <= 1e-7 * gls)) {
@@ -652,6 +655,7 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 }
             } else
                 res_gap = sum_sl + sum_pinf;
+            repeated = false;
             const bool net = cls.warm_net > 0 && x_init != nullptr && it == 1 && !net_done && (double)alpha_first < cls.warm_net;
             if (net || (!recentred && jam_since >= 6 && floor_cnt == 0)) {
                 double cnt_ = 0;
@@ -773,6 +777,8 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
                 shift_level++;
                 flags |= LSCQP_INFO_SHIFTED;
                 __syncthreads();
+                repeated = true;
+                it--;  // (the loop's increment makes it this iteration again)
                 continue;
             }
             if (pivot_bad) {

@@ -1057,6 +1057,8 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
     int jam_since = 0;
     bool recentred = false;
     int shift_level = 0;  // 0: no diagonal shift; 1, 2: the factorisation lost a pivot and the matrix carries 1e-14 / 1e-12 max|K| on its diagonal
+    bool repeated = false;  // this pass of the loop repeats an iteration at the SAME point (a lost pivot, now with a diagonal shift): the point's
+                            // tests and counters were taken the first time and are not taken again, and the iteration is not counted twice
     const double tol = cls.tol;
     const bool comm_on_k = cls.comm_range > 0;
     // (row of the scratch matrix a lane assembles into: non-z lanes share one dummy row, index NZ, that is never read)
@@ -1213,7 +1215,7 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
             // Marginally infeasible instances creep down to ~1e-3 m before they stall while their multipliers run away
             // (sum lambda |r_p| passes 1e6 within a few more iterations): the stall test therefore goes down to 1e-4 m, and a
             // runaway multiplier-weighted residual ends the instance as well.
-            if ((it & 3) == 2) {
+            if (!repeated && (it & 3) == 2) {
                 // (round 2: the stall has to show at two checks in a row -- a feasible instance started far below its multipliers'
                 // scale crept for ten iterations and then converged; see mu_scale above)
                 // (no shortcut for a flat residual either: a feasible M = 10, 40-neighbour instance sat at 5e-4 m for four iterations
@@ -1234,7 +1236,9 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
             // A point that meets the primal and gap tests while its stationarity is still above 1e-8 (cond(Hred) ~ 1e7 at
             // M = 10 in 3-D leaves a rounding floor of ~2e-8) is remembered as well (floor_cnt): if the iteration later
             // stalls or breaks down numerically, the result is accepted rather than reported as a failure.
-            if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {  // uniform over the QP's lanes
+            if (repeated) {
+                // (nothing: see `repeated`)
+            } else if (max_rp <= 1e-9 && rdn <= 1e-6 * gls) {  // uniform over the QP's lanes
                 LSCQP_PHASE_LANE(lvo_);
                 obj_abs = fabs(objective(false, lvo_));
                 res_gap = (sum_sl + sum_pinf) / (1.0 + obj_abs);
@@ -1304,6 +1308,7 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
             // boxed in by slacks of 3 mm) and the iteration would crawl; such an instance goes back to the round-1 centring after that
             // one iteration.  (tools/proto_pdip.py `early_recentre`: on 60 instances dumped from the forest10 closed loop 10.6 -> 6.1
             // iterations with it, two instances +2; without it single instances take 18-23.)
+            repeated = false;
             const bool net = cls.warm_net > 0 && x_init != nullptr && it == 1 && !net_done && (double)alpha_first < cls.warm_net;
             if (net || (!recentred && jam_since >= 6 && floor_cnt == 0)) {  // uniform over the QP's lanes
                 double cnt_ = 0;
@@ -1772,6 +1777,8 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
 #pragma unroll
                 for (int cidx = 0; cidx < NZ; cidx++) hz[cidx] = (FT)0;
                 LSCQP_BLOCK_SYNC();
+                repeated = true;
+                it--;  // (the loop's increment makes it this iteration again)
                 continue;
             }
             auto numeric_exit = [&]() {

@@ -113,8 +113,9 @@ def _apply_exchange(bufs, ops, first, per):
 
     G = len(bufs)
     for op in ops:
-        if op["kind"] == api.XCHG_ALLGATHER:  # in place: device g sends `count` doubles from its own block, block o lands at o * count
-            sent = [bufs[g][first[g] * per: first[g] * per + op["count"]].copy() for g in range(G)]
+        if op["kind"] == api.XCHG_ALLGATHER:  # in place: device g sends `count` doubles from g * count (its own block), block o lands at o * count
+            sent = [bufs[g][g * op["count"]: (g + 1) * op["count"]].copy() for g in range(G)]
+            assert all(len(s) == op["count"] for s in sent), "an all-gather block reaches beyond a device's buffer"
             for g in range(G):
                 for o in range(G):
                     bufs[g][o * op["count"]: (o + 1) * op["count"]] = sent[o]
@@ -160,3 +161,39 @@ def test_exchange_schedule_delivers_every_owners_block_for_any_device_count(api)
     for first, count in (([0, 5], [4, 5]), ([0, 4], [4, 5]), ([1, 5], [4, 5])):
         with pytest.raises(api.LscqpError):
             api.exchange_schedule(10, first, count, 1)
+
+
+def test_a_ragged_mission_is_one_allgather_when_the_buffers_carry_padding(api):
+    """lscqp_exchange_schedule_padded: with LSCQP_PLAN_EXCHANGE_PAD agents of room behind the mission (what lscqp_plan_create allocates for the
+    buffers a group exchanges) the blocks lscqp_shard_range cuts are ONE in-place all-gather for EVERY agent count -- short and empty
+    blocks send from and into the padding; played on host arrays the mission part of every device's buffer ends up complete, and nothing
+    is touched beyond the padding.  Without enough padding, or for blocks of another shape, the broadcasts."""
+    rng = np.random.default_rng(5)
+    pad = api.PLAN_EXCHANGE_PAD
+    for G in (1, 2, 3, 4, 8):
+        for n in sorted({1, 2, G - 1, G, G + 1, 9, 10, 63, 64, 65, 512, 1000, 1023, 4096} - {0}):
+            for per in (1, 9, 90):
+                blocks = [api.shard_range(n, G, g) for g in range(G)]
+                first, count = [b[0] for b in blocks], [b[1] for b in blocks]
+                ops = api.exchange_schedule(n, first, count, per, pad_agents=pad)
+                B = -(-n // G)
+                assert len(ops) == 1 and ops[0]["kind"] == api.XCHG_ALLGATHER and ops[0]["count"] == B * per, (G, n, ops)
+                assert G * B - n <= pad
+                truth = rng.standard_normal(n * per)
+                bufs = []
+                for g in range(G):
+                    b = rng.standard_normal((n + pad) * per)
+                    b[first[g] * per: (first[g] + count[g]) * per] = truth[first[g] * per: (first[g] + count[g]) * per]
+                    bufs.append(b)
+                _apply_exchange(bufs, ops, first, per)
+                for g in range(G):
+                    assert np.array_equal(bufs[g][: n * per], truth), (G, n, per, g)
+    # not enough room behind the mission: the broadcasts of the unpadded entry
+    first, count = zip(*[api.shard_range(9, 8, g) for g in range(8)])  # 2,2,2,2,1,0,0,0: 8 * 2 - 9 = 7 agents of padding needed
+    assert len(api.exchange_schedule(9, first, count, 3, pad_agents=7)) == 1
+    ops = api.exchange_schedule(9, first, count, 3, pad_agents=6)
+    assert len(ops) == 5 and all(o["kind"] == api.XCHG_BROADCAST for o in ops)
+    # blocks of another shape (not what lscqp_shard_range cuts): broadcasts whatever the padding
+    ops = api.exchange_schedule(10, [0, 3, 7], [3, 4, 3], 2, pad_agents=pad)
+    assert len(ops) == 3 and all(o["kind"] == api.XCHG_BROADCAST for o in ops)
+

@@ -470,6 +470,42 @@ def test_limit_cycle_of_the_iteration_is_ended_by_the_rescue_pass(api, oracle, t
 
 
 @pytest.mark.pdip_only
+def test_an_iteration_repeated_with_a_diagonal_shift_is_counted_once(api, oracle, torch_cuda):
+    """tests/golden/shifted_pivot.json (tools/make_golden_shifted.py): a cold M = 10, 3-D, 40-neighbour instance whose interior-point solve
+    loses a pivot of a late iteration's matrix -- rounding, not the matrix -- and repeats that iteration with a diagonal shift
+    (LSCQP_INFO_SHIFTED).  The repeat happens at the SAME point: its stopping tests and counters (confirmations at the rounding floor, the
+    jam and stall counters) were taken the first time and must not be taken again, and lscqp_info.iterations counts the iteration once --
+    the number the fixture recorded (one point counted twice could have met the two-confirmation acceptance alone).  The
+    optimum is the oracle's; the run-time-shaped kernel, which carries the same logic, agrees."""
+    g = H.load_golden("shifted_pivot")
+    M, dim, n_obs = g["M"], g["dim"], g["n_obs"]
+    sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=g["world_min"], world_max=g["world_max"], active_set=api.ACTIVE_SET_OFF))
+    cls = oracle.make_class(M=M, dim=dim, use_sfc=True, world_min=g["world_min"], world_max=g["world_max"])
+    hdr = np.zeros(1, api.HEADER_DTYPE)
+    for f, v in g["hdr"].items():
+        hdr[f][0] = v
+    hdr["n_obs"][0] = n_obs
+    R = np.array(g["rows"])
+    rows = np.zeros(len(R), api.ROW_DTYPE)
+    rows["nx"], rows["ny"], rows["nz"], rows["b"] = R[:, 0], R[:, 1], R[:, 2], R[:, 3]
+    sfc = np.zeros(M, api.BOX_DTYPE)
+    sfc["bmin"], sfc["bmax"] = g["sfc_min"], g["sfc_max"]
+    off = np.array([0, len(R)], dtype=np.uint64)
+    ag = oracle.make_agent(n_obs=n_obs, **{k: v for k, v in g["hdr"].items()})
+    lsc = np.zeros((n_obs, M, 6), oracle.LSC_DTYPE)
+    lsc["nrm"] = R[:, :3].reshape(n_obs, M, 6, 3)
+    lsc["d"] = R[:, 3].reshape(n_obs, M, 6)
+    o = oracle.solve(cls, ag, lsc, sfc)
+    assert o["status"] == 0
+    G = sol.solve_host(hdr, rows, off, sfc)
+    assert G["status"][0] == 0
+    assert abs(o["obj"] - G["obj"][0]) <= OBJ_TOL * max(1.0, abs(o["obj"])) and np.abs(o["x"] - G["x"][0]).max() <= X_TOL
+    # (the flag is what makes this fixture a test of the repeated iteration: should a later kernel keep the pivot, look for a new instance)
+    assert G["info"]["flags"][0] & api.INFO_SHIFTED
+    assert G["info"]["iterations"][0] == g["iterations"], (G["info"]["iterations"][0], g["iterations"])
+
+
+@pytest.mark.pdip_only
 def test_pivot_breakdown_in_a_multi_wavefront_instance_ends_the_whole_workgroup(api, oracle, torch_cuda):
     """tests/golden/pivot_breakdown_w2.json: an M = 6 dense-maze instance whose factorisation breaks down after the acceptance tests
     were met at the rounding floor.  In the two-wavefront instance only wavefront 0 holds the system and sees the failed pivot;
