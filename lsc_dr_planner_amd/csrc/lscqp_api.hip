@@ -1045,10 +1045,12 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             const bool small = n <= 2 * ncu, medium = n <= 8 * ncu;
             auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
             int threads = env_int("LSCQP_DAS_THREADS", medium ? 256 : 64);
-            // (16 active rows, not the 32 the kernel could hold: the footprint decides how many workgroups a CU holds at once and whether the
-            // instance's rows fit in LDS beside the rest -- 512 x M6: 43.0 -> 33.9 us, 128 x M10 x 40: 92.2 -> 84.4, 64 x M5: 12.9 -> 12.4 -- and no
-            // feasible instance of a 6 000-instance sweep of the harder swarms needs more than 12, profiles/r05_kmax_sweep.txt)
-            int kmax = env_int("LSCQP_DAS_KMAX", small ? 16 : 8);
+            // (20 active rows, not the 32 the kernel could hold: the footprint decides how many workgroups a CU holds at once and whether the
+            // instance's rows fit in LDS beside the rest -- 512 x M6: 43.0 -> 33.9 us, 128 x M10 x 40: 92.2 -> 84.3, 64 x M5: 12.9 -> 12.5; 24 would
+            // already cost the M = 10 class its staged rows.  No feasible instance of a 6 000-instance sweep of the harder swarms needs more than
+            // 12; ONE of the ~50 000 of the stress sweep needs 17-20, and at 16 it went to the interior-point kernel, which accepted it at its
+            // rounding floor (stationarity 1.9e-7): profiles/r05_kmax_sweep.txt, NOTES.md section 13)
+            int kmax = env_int("LSCQP_DAS_KMAX", small ? 20 : 8);
             int steps = env_int("LSCQP_DAS_STEPS", small ? 96 : 24);
             int cacheC = env_int("LSCQP_DAS_CACHE", small ? 1 : 0);
             int stage = env_int("LSCQP_DAS_STAGE", small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
