@@ -947,7 +947,22 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             }
             if (NW > 1 && first_step && wv != 0) compute_wp(64, T - 64);
             // Wavefront 0 decides the step: v = A'w_p, r = S^-1 v, curvature a_p'w_p - v'r, dual bound t1, primal length t2.
-            if (wv == 0) {
+            if (wv == 0 && __builtin_amdgcn_readfirstlane(k) == 0) {
+                // the FIRST active row (most stepping instances of a plan never hold a second): nothing to solve, no row can leave -- the general
+                // decision below with k = 0, minus its two reductions and its solve; the same values to the bit
+                if (first_step) spp = cdot(Rp.ent, Rp.coef, Rp.ent, Rp.coef, Cm, P);
+                const double sp = row_dot(Rp.ent, Rp.coef, c_) - Rp.rhs;
+                const double t = (spp > 1e-12 * spp) ? -sp / spp : 1e300;
+                const int kind = (t < 1e299) ? 1 : 0;
+                if (lane == 0) {
+                    if (kind == 1) Jm_[0] = rsqrt(spp), u_[0] = ctl_[3] + t;
+                    ctl_[0] = t;
+                    ctl_[1] = (double)kind;
+                    ctl_[2] = 0.0;
+                    ctl_[3] += t;
+                    ctl_[5] = (t < 1e299) ? 1.0 : 0.0;
+                }
+            } else if (wv == 0) {
                 if (first_step) spp = cdot(Rp.ent, Rp.coef, Rp.ent, Rp.coef, Cm, P);
                 const double vj = (lane < k) ? row_dot(Rp.ent, Rp.coef, W_ + (size_t)lane * NX) : 0.0;
                 DAS_T(13);
