@@ -34,6 +34,7 @@ extern "C" hipError_t lscqp_launch_generic(const lscqp::DevClass* cls, int M, in
 
 // the dual active-set phase (lscqp_das.hip)
 extern "C" size_t lscqp_das_build_tables(int M, int es, double dt, double w_c, double w_t, double* out);
+extern "C" size_t lscqp_das_build_pairs(int M, int dim, int comm_on, int32_t* out);
 extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int stage_rows);
 extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
                                        int stage_rows, int screen, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
@@ -427,10 +428,15 @@ static void das_refresh(lscqp_solver* s) {
     if (!s->das) return;
     std::lock_guard<std::mutex> lk(s->das->mu);
     const size_t nd = lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, nullptr);
-    s->das->host.assign(nd + 36, 0.0);  // (the tables, then the class's 36 coefficient-rounding terms of the objective: the kernel reads them from here)
+    // (the tables, then the class's 36 coefficient-rounding terms of the objective, then its two-sided rows as far as they are the class's: the
+    // kernel reads all three from here)
+    const size_t npair = lscqp_das_build_pairs(s->desc.M, s->desc.dim, s->desc.communication_range > 0, nullptr);
+    s->das->host.assign(nd + 36 + npair, 0.0);
     if (s->desc.control_input_weight > 0 && s->desc.terminal_weight >= 0 &&
         lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, s->das->host.data()) == nd) {
         for (int i = 0; i < 36; i++) s->das->host[nd + i] = s->dev.dQ[i];
+        static_assert(sizeof(double) == 2 * sizeof(int32_t), "two ints per table slot");
+        lscqp_das_build_pairs(s->desc.M, s->desc.dim, s->desc.communication_range > 0, reinterpret_cast<int32_t*>(s->das->host.data() + nd + 36));
     } else {
         s->das->host.clear();  // (a class whose reduced Hessian is not positive definite has no active-set phase)
     }

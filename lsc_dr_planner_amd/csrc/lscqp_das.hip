@@ -263,6 +263,13 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     }
     // ---- header, corridor boxes (and the instance's row offset: one memory round trip for all three) -------------------------------
     const uint64_t roff = row_offsets ? row_offsets[q] : 0;
+    // the class's two-sided rows (lscqp_das_build_pairs, behind the tables and the 36 rounding terms): the first four of this thread are asked
+    // for NOW -- they depend on nothing the header holds
+    constexpr int kPB = 4;
+    const int2* const pairs_g = reinterpret_cast<const int2*>(tab + (size_t)M * table_stride(M) + 36);
+    int2 pwr[kPB];
+#pragma unroll
+    for (int u = 0; u < kPB; u++) pwr[u] = pairs_g[min(tid + u * T, NPAIR - 1)];
     {
         const double* hsrc = reinterpret_cast<const double*>(hdr + q);
         const double* ssrc = reinterpret_cast<const double*>(sfc) + q * 6 * M;
@@ -313,8 +320,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     const double rho_pair = 0.5 * cls.comm_range - Hd->radius;  // :484
     const double rho_wp = 0.5 * cls.comm_range - 1e-5;          // :495
     const int nL = n_obs * P;
-    const int NCP = M * (M - 1) / 2;
-    const float iP = 1.0f / (float)P, i5M = 1.0f / (float)(5 * M), i4M = 1.0f / (float)(4 * M), iNCP = 1.0f / (float)(NCP > 0 ? NCP : 1);
+    const float iP = 1.0f / (float)P;
     const bool staged = stage_rows > 0 && nL <= stage_rows;  // (uniform)
     bool rows_in_lds = false;                                // set by the first pass
 
@@ -372,52 +378,44 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     //   then dim * 4M acceleration rows c[i+2] - 2 c[i+1] + c[i], |.| <= amax dt^2 / (n (n-1)) (:462-471)
     //   then dim * NCP pairs (uu, up)   c[uu][5] - c[up+1][0],    |.| <= rho                   (:482-487 with mi = up + 1 >= 1)
     // type 0: no row; 1: interval; 2: velocity; 3: acceleration; 4: pair.  Entry indices are positions in c_ (axis * P + control point).
-    const int oV = NX, oA = oV + dim * 5 * M, oC = oA + dim * 4 * M;
     bool empty = false;
-    for (int r = tid; r < NPAIR; r += T) {
-        int type = 0, e0 = 0, e1 = 0;
-        double lo = -1.0, hi = 1.0;
-        if (r < oV) {
-            const int k = fdiv(r, iP), cp = r - k * P, m = cp / 6;
-            const double ok_ = org[k];
-            lo = wb_[k] - ok_, hi = wb_[3 + k] - ok_;  // :252-253,260-265
-            if (cls.rsfc && k == 2 && m == 0) {                         // :255-258
+    const double hv_c = dt * 0.2, ha_c = dt * dt * 0.05;
+    for (int r0 = tid; r0 < NPAIR; r0 += kPB * T) {
+        if (r0 != tid) {
+#pragma unroll
+            for (int u = 0; u < kPB; u++) pwr[u] = pairs_g[min(r0 + u * T, NPAIR - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < kPB; u++) {
+            if ((r0 - tid) + u * T >= NPAIR) break;  // (uniform: no thread of the workgroup has a row in this slot)
+            const int r = r0 + u * T;
+            const int w0 = pwr[u].x, w1 = pwr[u].y;
+            const int fam = w1 & 3, k = (w1 >> 2) & 3, m = (w1 >> 4) & 15;
+            const bool last = (w1 >> 8) & 1, rs = (w1 >> 9) & 1;
+            // every load of every family, without a test (one branch per family made the compiler wait for each family's loads in turn)
+            const double ok_ = org[k], wlo = wb_[k], whi = wb_[3 + k], wpk = Hd->next_waypoint[k] - ok_;
+            const double hv = Hd->vmax[k] * hv_c, ha = Hd->amax[k] * ha_c;
+            double lo = wlo - ok_, hi = whi - ok_;  // :252-253,260-265
+            if (cls.rsfc && rs) {                  // :255-258
                 lo = -100.0 - ok_;
                 hi = 100.0 - ok_;
             }
-            if (cls.use_sfc) {  // :372-397
+            if (cls.use_sfc) {  // (uniform) :372-397
                 lo = fmax(lo, sfcl[m].bmin[k] - ok_);
                 hi = fmin(hi, sfcl[m].bmax[k] - ok_);
             }
-            if (comm_on && cp % 6 == 5) {  // pairs (m, mi = 0) :482-487 and waypoint rows :494-497
-                const double wpk = Hd->next_waypoint[k] - ok_;
-                lo = fmax(lo, fmax(-rho_pair, wpk - rho_wp));
-                hi = fmin(hi, fmin(rho_pair, wpk + rho_wp));
+            const double clo = fmax(lo, fmax(-rho_pair, wpk - rho_wp)), chi = fmin(hi, fmin(rho_pair, wpk + rho_wp));  // pairs (m, mi = 0) :482-487, waypoint rows :494-497
+            lo = (comm_on && last) ? clo : lo;
+            hi = (comm_on && last) ? chi : hi;
+            const double hs = fam == 1 ? hv : fam == 2 ? ha : rho_pair;  // :448-453, :462-471, :482-487
+            lo = fam == 0 ? lo : -hs;
+            hi = fam == 0 ? hi : hs;
+            if (r < NPAIR) {
+                if (fam == 0 && (w0 >> 24) != 0 && lo > hi) empty = true;
+                plo_[r] = lo, phi_[r] = hi;
+                pix_[r] = w0;
             }
-            type = cp >= 3 ? 1 : 0;
-            e0 = r;
-            if (type && lo > hi) empty = true;
-        } else if (r < oA) {
-            const int s = r - oV, k = fdiv(s, i5M), rr = s - k * 5 * M, m = rr / 5, i = rr % 5;
-            type = (m == 0 && i < 2) ? 0 : 2;
-            e0 = k * P + 6 * m + i;
-            hi = Hd->vmax[k] * dt * 0.2, lo = -hi;
-        } else if (r < oC) {
-            const int s = r - oA, k = fdiv(s, i4M), rr = s - k * 4 * M, m = rr / 4, i = rr % 4;
-            type = (m == 0 && i < 1) ? 0 : 3;
-            e0 = k * P + 6 * m + i;
-            hi = Hd->amax[k] * dt * dt * 0.05, lo = -hi;
-        } else {
-            const int s = r - oC, k = fdiv(s, iNCP), ci = s - k * NCP;
-            int uu = 1;
-            while (uu * (uu + 1) / 2 <= ci) uu++;
-            const int up = ci - uu * (uu - 1) / 2;
-            type = comm_on ? 4 : 0;
-            e0 = k * P + 6 * (up + 1), e1 = k * P + 6 * uu + 5;
-            hi = rho_pair, lo = -rho_pair;
         }
-        plo_[r] = lo, phi_[r] = hi;
-        pix_[r] = (type << 24) | (e0 << 12) | e1;
     }
     // ---- unconstrained optimum: c_u[k] = cfix[k] - c1_k U1 - c2_k U2 + 2 w_t goal_k G1 ---------------------------------------------------
 #pragma unroll
@@ -1093,6 +1091,49 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
 
 // The tables of a class: for ts = 1 .. M  [U1 | U2 | G1 | C], C = T (T'Hx T)^-1 T' in extended precision (cond(T'Hx T) ~ 2e5 .. 3e6).
 // Returns the number of doubles written (M * table_stride(M)); out may be NULL to ask for the size.
+// The two-sided rows of a class, as far as they do not depend on the instance (the order and the ids of the kernel's table: intervals, velocity
+// rows, acceleration rows, communication pairs): per row two ints -- the packed stencil the kernel keeps in LDS (type << 24 | e0 << 12 | e1)
+// and what its bounds depend on (family | axis << 2 | segment << 4 | last control point of its segment << 8 | axis 2 of segment 0 << 9).
+// The kernel reads them from behind the tables and the objective's rounding term instead of deriving them thread by thread with one
+// branch per family.  Returns the number of rows (num_pairs); out == NULL: only that.
+extern "C" size_t lscqp_das_build_pairs(int M, int dim, int comm_on, int32_t* out) {
+    const int P = 6 * M, NX = dim * P, NCP = M * (M - 1) / 2;
+    const int oV = NX, oA = oV + dim * 5 * M, oC = oA + dim * 4 * M, NPAIR = lscqp_das::num_pairs(M, dim);
+    if (!out) return (size_t)NPAIR;
+    for (int r = 0; r < NPAIR; r++) {
+        int type = 0, e0 = 0, e1 = 0, fam = 0, k = 0, m = 0, last = 0;
+        if (r < oV) {
+            k = r / P;
+            const int cp = r - k * P;
+            m = cp / 6, last = cp % 6 == 5;
+            type = cp >= 3 ? 1 : 0, e0 = r, fam = 0;
+        } else if (r < oA) {
+            const int s = r - oV;
+            k = s / (5 * M);
+            const int rr = s - k * 5 * M, i = rr % 5;
+            m = rr / 5;
+            type = (m == 0 && i < 2) ? 0 : 2, e0 = k * P + 6 * m + i, fam = 1;
+        } else if (r < oC) {
+            const int s = r - oA;
+            k = s / (4 * M);
+            const int rr = s - k * 4 * M, i = rr % 4;
+            m = rr / 4;
+            type = (m == 0 && i < 1) ? 0 : 3, e0 = k * P + 6 * m + i, fam = 2;
+        } else {
+            const int s = r - oC;
+            k = s / NCP;
+            const int ci = s - k * NCP;
+            int uu = 1;
+            while (uu * (uu + 1) / 2 <= ci) uu++;
+            const int up = ci - uu * (uu - 1) / 2;
+            type = comm_on ? 4 : 0, e0 = k * P + 6 * (up + 1), e1 = k * P + 6 * uu + 5, fam = 3, m = 0;
+        }
+        out[2 * r] = (type << 24) | (e0 << 12) | e1;
+        out[2 * r + 1] = fam | (k << 2) | (m << 4) | (last << 8) | ((fam == 0 && k == 2 && m == 0) ? 1 << 9 : 0);
+    }
+    return (size_t)NPAIR;
+}
+
 extern "C" size_t lscqp_das_build_tables(int M, int es, double dt, double w_c, double w_t, double* out) {
     const int P = 6 * M, NZA = 3 * (M - 1) + (es ? 1 : 3);
     const size_t stride = lscqp_das::table_stride(M);

@@ -67,6 +67,41 @@ def test_tables_equal_an_independent_construction(api, M, es, dt, w_c, w_t):
         assert np.allclose(tb[2 * P:3 * P], sum(Cm[:, 6 * m + 5] for m in range(M - ts, M)), rtol=0, atol=1e-13 * np.abs(Cm).max())
 
 
+@pytest.mark.parametrize("M,dim,comm", [(5, 3, 1), (10, 2, 1), (6, 3, 0), (12, 3, 1), (2, 2, 1)])
+def test_two_sided_rows_of_a_class_equal_an_independent_construction(api, M, dim, comm):
+    """lscqp_das_build_pairs: what the kernel's two-sided rows are as far as they are the CLASS's (stencil type and entries; family, axis,
+    segment for the bounds) -- built here from the reference's own loops (src/traj_optimizer.cpp: control-point intervals :252-265 /
+    :372-397, velocity rows :448-453, acceleration rows :462-471, communication pairs :482-487), row by row."""
+    L = api.lib()
+    L.lscqp_das_build_pairs.restype = C.c_size_t
+    L.lscqp_das_build_pairs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    P = 6 * M
+    n = L.lscqp_das_build_pairs(M, dim, comm, None)
+    want = []
+    for k in range(dim):  # one interval per control point and axis; the initial state's three control points carry no row
+        for cp in range(P):
+            want.append((1 if cp >= 3 else 0, k * P + cp, 0, 0, k, cp // 6, int(cp % 6 == 5)))
+    for k in range(dim):  # velocity: c[i+1] - c[i], i = 0..4 of every segment; the first two of segment 0 are fixed by the initial state
+        for m in range(M):
+            for i in range(5):
+                want.append((0 if (m == 0 and i < 2) else 2, k * P + 6 * m + i, 0, 1, k, m, 0))
+    for k in range(dim):  # acceleration: c[i+2] - 2 c[i+1] + c[i], i = 0..3
+        for m in range(M):
+            for i in range(4):
+                want.append((0 if (m == 0 and i < 1) else 3, k * P + 6 * m + i, 0, 2, k, m, 0))
+    for k in range(dim):  # communication range between the last control point of segment uu and the first of segment up + 1 (up < uu)
+        for uu in range(1, M):
+            for up in range(uu):
+                want.append((4 if comm else 0, k * P + 6 * (up + 1), k * P + 6 * uu + 5, 3, k, 0, 0))
+    assert n == len(want)
+    out = np.zeros(2 * n, np.int32)
+    assert L.lscqp_das_build_pairs(M, dim, comm, out.ctypes.data) == n
+    for r, (typ, e0, e1, fam, k, m, last) in enumerate(want):
+        w0, w1 = int(out[2 * r]), int(out[2 * r + 1])
+        assert (w0 >> 24, (w0 >> 12) & 0xfff, w0 & 0xfff) == (typ, e0, e1), (r, w0)
+        assert (w1 & 3, (w1 >> 2) & 3, (w1 >> 4) & 15, (w1 >> 8) & 1, (w1 >> 9) & 1) == (fam, k, m, last, int(fam == 0 and k == 2 and m == 0)), (r, w1)
+
+
 def test_active_set_field_is_validated(api):
     with pytest.raises(api.LscqpError) as e:
         api.Solver(api.make_desc(M=5, dim=3, active_set=7))
