@@ -14,13 +14,14 @@
 //                             One symmetric P x P table per number of terminal segments, the same for every axis, built on the host
 //                             in extended precision when the class is created (lscqp_das_build_tables) -- 7 KB at M = 5.
 //     unconstrained optimum   c_u[k] = cfix[k] - c1_k U1 - c2_k U2 + 2 w_t goal_k G1      (three table vectors: no factorisation)
-//     one step for row p      w_p = C a_p;   r = S^-1 A'w_p  (S = A'W, the active rows' small Gram matrix, Cholesky in LDS);
+//     one step for row p      w_p = C a_p;   r = S^-1 A'w_p  (S = A'W over the active rows, carried as J = L^-1 of its Cholesky factor:
+//                             S^-1 = J'J, two products per step, a row appended when one joins, rotations when one leaves);
 //                             dc = w_p - W r;   t = min( min_{r_j > 0} u_j / r_j ,  -slack_p / a_p'dc );   c += t dc,  u -= t r,  u_p += t
 //                             t = the second: p joins the active set;  t = the first: row j leaves it and the step is repeated.
 //
-// The work per QP is one pass over the rows per step (the rows are read where they lie -- HBM the first time, L2 afterwards; nothing
-// is staged) plus a handful of short vector operations: the phase is bound by memory latency and, for large batches, by HBM bandwidth
-// -- the roofline north_star names.  What it returns is a KKT point of the reference's model: primal violation <= 1e-9 m on EVERY row
+// The work per QP is one pass over the rows per step (read from HBM the first time; afterwards from LDS in the small-batch form, from
+// L2 otherwise) plus a handful of short vector operations: small batches are bound by the chain of memory round trips of their slowest
+// instance, large ones by instruction issue at 0.27 of the HBM roof (NOTES.md sections 12-13).  What it returns is a KKT point of the reference's model: primal violation <= 1e-9 m on EVERY row
 // (the last pass), multipliers >= 0, exact complementarity, and the reduced stationarity residual verified against the same scale the
 // interior-point kernel uses (<= 1e-9) -- after a final "polish" that rebuilds the point from its multipliers and refines them once.
 // An instance the phase does not finish (more active rows than its budget, more steps than its budget, a dependent active set, an
@@ -30,7 +31,8 @@
 //
 // Organisation: one workgroup (64 .. 256 threads) per QP, M / dim / end stop / n_obs are run-time values (one kernel for every class);
 // row ids:  [LSC rows o*P + cp | interval lo/hi per (axis, cp) | velocity lo/hi | acceleration lo/hi | communication pairs lo/hi],
-// selection = the most violated row (slack / |a|), lowest id on ties: results are reproducible bit for bit from run to run.
+// selection = the most violated row (raw slack), lowest id on ties: results are reproducible bit for bit from run to run and across
+// the kernel's forms (wavefronts per QP, row format, first look peeled or not; built with -ffp-contract=on for that).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
