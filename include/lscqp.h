@@ -113,7 +113,8 @@ typedef struct lscqp_class_desc {
  * what it does not finish inside its budget (active rows, steps) -- or cannot judge: infeasible row systems, dependent active rows,
  * capacity -- is solved by the interior-point kernel behind it in the same call, on the same stream, exactly as without the phase.
  *   LSCQP_ACTIVE_SET_DEFAULT  on
- *   LSCQP_ACTIVE_SET_OFF      the interior-point kernel alone (rounds 1-4; also: environment LSCQP_ACTIVE_SET=0 for a whole process)
+ *   LSCQP_ACTIVE_SET_OFF      the interior-point kernel alone (rounds 1-4; also: LSCQP_ACTIVE_SET=0 in the environment when the handle is
+ *                             CREATED -- the library reads its environment in lscqp_create and nowhere else)
  *   LSCQP_ACTIVE_SET_ONLY     the phase alone: instances it leaves are returned LSCQP_STATUS_ITER_LIMIT (development / tests) */
 #define LSCQP_ACTIVE_SET_DEFAULT 0
 #define LSCQP_ACTIVE_SET_OFF 1
@@ -229,8 +230,18 @@ typedef struct lscqp_solver* lscqp_handle;
  * uploads class constants to the device. */
 int lscqp_create(const lscqp_class_desc* desc, lscqp_handle* out);
 
-/* Replaces TrajOptimizer::updateParam (src/traj_optimizer.cpp:158-160): re-derive class constants. */
+/* Replaces TrajOptimizer::updateParam (src/traj_optimizer.cpp:158-160): re-derive class constants.  Launches already enqueued (or captured
+ * in a graph) keep the constants they were enqueued with: the class travels by value in kernel arguments, and the active-set tables of a
+ * device are immutable once a launch may have seen them -- an update that changes them (dt, weights, M, planner mode, communication range
+ * on/off) gives every device that holds a copy a FRESH buffer and retires the old one; the reference's own updates (slack_mode flips,
+ * src/traj_planner.cpp:155,160,187,214) change none of these and touch nothing on the device.  Not a device synchronisation point. */
 int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc);
+
+/* The class's active-set tables on the CURRENT device, now.  lscqp_create loads them on the device that is current then; any other device's
+ * first solve loads them lazily -- which a launch inside a stream capture cannot do (hipMalloc / hipMemcpy are not allowed there): such a
+ * launch returns LSCQP_ERR_HIP and names this function, instead of silently running without the phase.  lscqp_comm_prepare does it for every
+ * device of a communicator. */
+int lscqp_prepare_device(lscqp_handle h);
 
 int lscqp_destroy(lscqp_handle h);
 
@@ -317,14 +328,15 @@ int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const
  *   lscqp_order_by_work_device   d_order_out[n] := the instances sorted by d_info_prev[i].iterations, most first, ties in index order
  *   lscqp_solve_batch_device_ordered   lscqp_solve_batch_device_ex with the k-th slot of the launch solving instance d_order[k]
  *                                (a permutation of 0 .. n-1; NULL = identity).  Results land at the instance's own index, bit for bit
- *                                what any other order gives.  The permutation is trusted; with the environment variable
- *                                LSCQP_CHECK_ORDER=1 every call verifies it on the device first (an allocation and a synchronisation:
+ *                                what any other order gives.  The permutation is trusted; a handle created with LSCQP_CHECK_ORDER=1
+ *                                in the environment verifies it on the device in every call first (an allocation and a synchronisation:
  *                                a debugging aid) and returns LSCQP_ERR_INVALID_ARGUMENT for a stale or short order buffer. */
 /* instances of a launch of n the device works on at once (CUs x workgroups per CU of the kernel instance the launch selects); a launch of
  * more runs in rounds and has a tail -- that is where the order pays.  -1 without a device. */
 int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max);
-/* instances ONE device works on at once in the FIRST kernel of a solve of this class: the dual active-set phase's resident workgroups when
- * the phase is on, lscqp_launch_capacity otherwise.  -1 without a device. */
+/* instances ONE device works on at once in the kernel that carries a solve of this class: the dual active-set phase's resident workgroups
+ * when the phase is on AND finishing what it is given; lscqp_launch_capacity (the interior-point instance's) when the phase is off or the
+ * handle's last host-pointer call had to run the interior-point passes behind it.  -1 without a device. */
 int64_t lscqp_device_fill(lscqp_handle h, int64_t n, int32_t n_obs_max);
 int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t* d_order_out, void* stream);
 int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
@@ -349,8 +361,13 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
  *   lscqp_comm_devices_for_class   the rule lscqp_solve_batch_sharded applies (round 5), with the class in hand: clamp(n / fill, 1, G),
  *                            fill = lscqp_device_fill(h, n, n_obs_max) = the instances ONE device works on at once in the first
  *                            kernel of a solve (the dual active-set phase's resident workgroups, or lscqp_launch_capacity without
- *                            the phase): a second device is used only where one would need a second round.  A threshold set with
- *                            lscqp_comm_set_min_agents_per_device overrides it.
+ *                            the phase, or while the phase keeps leaving work to the slower kernel): a second device is used only
+ *                            where one would need a second round.  A threshold set with lscqp_comm_set_min_agents_per_device
+ *                            overrides it.  THE rule of the library: lscqp_solve_batch_sharded applies it, and a caller of
+ *                            lscqp_solve_batch_sharded_device (who cuts the blocks himself) asks it here; lscqp_comm_devices_for is
+ *                            its class-free fallback for callers without a handle.
+ *   lscqp_comm_prepare       the class's active-set tables on every device of the communicator, now (a device's first solve loads
+ *                            them lazily otherwise -- which a launch inside a stream capture cannot do: it fails, loudly)
  *   lscqp_comm_shard         the block [first, first + count) of device g when n agents are spread over n_used devices
  *   lscqp_solve_batch_sharded        HOST pointers for the whole batch (same arguments as lscqp_solve_batch): every block is staged
  *                            to its device, solved there (with the retry pass) and fetched back, all devices concurrently, each
@@ -373,6 +390,7 @@ const char* lscqp_comm_backend(lscqp_comm c);
 int lscqp_comm_set_min_agents_per_device(lscqp_comm c, int64_t n);
 int32_t lscqp_comm_devices_for(lscqp_comm c, int64_t n);
 int32_t lscqp_comm_devices_for_class(lscqp_comm c, lscqp_handle h, int64_t n, int32_t n_obs_max);
+int lscqp_comm_prepare(lscqp_comm c, lscqp_handle h);
 int lscqp_comm_shard(lscqp_comm c, int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count);
 /* the same partition rule without a communicator (no device needed): block g of n agents over n_used devices */
 int lscqp_shard_range(int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count);

@@ -243,7 +243,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
                     "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_launch_capacity", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
-                    "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
+                    "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_prepare_device", "lscqp_comm_prepare", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_devices_for_class", "lscqp_device_fill", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_exchange_schedule_padded", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
                     "lscqp_solve_batch_sharded_device", "lscqp_allgather", "lscqp_generate_lsc_device", "lscqp_select_neighbours_device", "lscqp_generate_constraints_device",
@@ -439,6 +439,8 @@ class Plan:
         return torch.as_tensor(_View(), device="cuda")
 
     def step(self, stream=None, graph=False):
+        if getattr(self, "_solver", None) is not None:
+            self._solver._sync_knobs()
         sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
         self._check((lib().lscqp_plan_step_graph if graph else lib().lscqp_plan_step)(self._p, sp))
 
@@ -510,7 +512,14 @@ class Comm:
         return lib().lscqp_comm_devices_for(self._h, int(n))
 
     def devices_for_class(self, solver, n, n_obs_max):
+        solver._sync_knobs()
         return lib().lscqp_comm_devices_for_class(self._h, solver._h, int(n), int(n_obs_max))
+
+    def prepare(self, solver):
+        """lscqp_comm_prepare: the solver's active-set tables on every device of the communicator."""
+        rc = lib().lscqp_comm_prepare(self._h, solver._h)
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     def stream(self, g):
         return lib().lscqp_comm_stream(self._h, g)
@@ -541,15 +550,70 @@ class Comm:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
 
+# The library reads its environment when a handle is CREATED and never afterwards (csrc/lscqp_api.hip: Knobs).  The test suite and bench.py
+# flip these switches between launches of one process, on live handles: this wrapper (test and bench plumbing, not the product) notices a change
+# of the process environment and tells the handle to re-read it through the library-internal lscqp_debug_reload_knobs_.
+_KNOB_ENV = ("LSCQP_FORCE_GENERIC", "LSCQP_WAVES", "LSCQP_ACTIVE_SET", "LSCQP_ACTIVE_SET_NOW", "LSCQP_CHECK_ORDER", "LSCQP_NO_QUEUE", "LSCQP_DEFER_BEHIND")
+
+
+def _knob_env():
+    g = os.environ.get
+    return tuple(g(k) for k in _KNOB_ENV)
+
+
 class Solver:
     def __init__(self, desc):
         self.desc = desc
         self._h = C.c_void_p()
+        self._knob_seen = _knob_env()
         rc = lib().lscqp_create(C.byref(desc), C.byref(self._h))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
         self.nv = lib().lscqp_num_variables(self._h)
         self.M, self.dim, self.P = desc.M, desc.dim, desc.M * 6
+
+    def _sync_knobs(self):
+        now = _knob_env()
+        if now != self._knob_seen:
+            self._knob_seen = now
+            lib().lscqp_debug_reload_knobs_(self._h)
+
+    def set_knob(self, name, value):
+        """lscqp_debug_set_knob_ (library-internal): one of the handle's development switches by name, e.g. the launch-shape overrides of
+        the dual active-set phase (das_threads, das_kmax, das_steps, das_cache, das_stage, das_screen, das_loop; -1 = the policy's value)."""
+        rc = lib().lscqp_debug_set_knob_(self._h, name.encode(), int(value))
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def prepare_device(self):
+        rc = lib().lscqp_prepare_device(self._h)
+        if rc != OK:
+            raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+    def bind_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None, d_x_init=None, retry=False,
+                    d_order=None):
+        """solve_device with every argument converted ONCE: returns a zero-argument callable that enqueues the same
+        lscqp_solve_batch_device_ordered call on the same stream each time it is called (a timed loop then pays for the C entry, not for
+        building eleven ctypes pointers per step).  The tensors must stay alive and in place."""
+        import torch
+
+        self._sync_knobs()
+        s = stream if stream is not None else torch.cuda.current_stream()
+
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        fn = lib().lscqp_solve_batch_device_ordered
+        args = (self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x), p(d_obj), p(d_status), p(d_info), int(retry),
+                p(d_order), C.c_void_p(s.cuda_stream))
+        keep = (d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info, d_x_init, d_order, s)
+
+        def call(_fn=fn, _args=args, _keep=keep):
+            rc = _fn(*_args)
+            if rc != OK:
+                raise LscqpError(rc, lib().lscqp_last_error().decode())
+
+        return call
 
     def rows_in_format(self, rows):
         """Packed rows (ROW_DTYPE or ROW_F32_DTYPE) in the handle's storage format; fp64 rows are rounded to float32 for
@@ -586,6 +650,7 @@ class Solver:
 
     def instance_work(self, n, n_obs_max):
         """lscqp_instance_work: work counters (from the machine code) of the kernel instance a launch of n QPs would select."""
+        self._sync_knobs()
         w = Work()
         rc = lib().lscqp_instance_work(self._h, int(n), int(n_obs_max), C.byref(w))
         if rc != OK:
@@ -601,6 +666,7 @@ class Solver:
     # ---- host-pointer call (numpy) --------------------------------------------------------------------
     def solve_host(self, hdr, rows=None, row_offsets=None, sfc=None, want_info=True, x_init=None):
         """x_init: (n, nv) initial trajectories (TrajOptimizer::solve's initial_traj) as the primal start, or None."""
+        self._sync_knobs()
         n = len(hdr)
         hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE)
         x = np.zeros((n, self.nv))
@@ -626,6 +692,7 @@ class Solver:
 
     def solve_sharded(self, comm, hdr, rows=None, row_offsets=None, sfc=None, want_info=True, x_init=None):
         """lscqp_solve_batch_sharded: the host-pointer call over the devices of `comm`; returns solve_host's dict + devices_used."""
+        self._sync_knobs()
         n = len(hdr)
         hdr = np.ascontiguousarray(hdr, dtype=HEADER_DTYPE)
         x = np.zeros((n, self.nv))
@@ -687,6 +754,7 @@ class Solver:
     def solve_sharded_device(self, comm, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, d_x_init=None, retry=False):
         """lscqp_solve_batch_sharded_device: lists of per-device torch CUDA tensors (entry g lives on device g of `comm`), n[g] agents on
         device g; asynchronous on the communicator's streams (comm.synchronize() waits)."""
+        self._sync_knobs()
         G = comm.size
         vp = C.c_void_p * G
 
@@ -707,6 +775,8 @@ class Solver:
         d_order: int32 permutation of 0 .. n-1 (lscqp_solve_batch_device_ordered: the k-th slot of the launch solves instance d_order[k])."""
         import torch
 
+        self._sync_knobs()
+
         s = stream if stream is not None else torch.cuda.current_stream()
 
         def p(t):
@@ -719,10 +789,12 @@ class Solver:
 
     def device_fill(self, n, n_obs_max):
         """lscqp_device_fill: instances one device works on at once in the first kernel of a solve of this class."""
+        self._sync_knobs()
         return lib().lscqp_device_fill(self._h, int(n), int(n_obs_max))
 
     def launch_capacity(self, n, n_obs_max):
         """lscqp_launch_capacity: instances of a launch of n the device works on at once (-1 without a device)."""
+        self._sync_knobs()
         return int(lib().lscqp_launch_capacity(self._h, int(n), int(n_obs_max)))
 
     @staticmethod

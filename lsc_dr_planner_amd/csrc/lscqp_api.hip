@@ -79,6 +79,33 @@ int fail(int code, const std::string& msg) {
 extern "C" int lscqp_set_error_(int code, const char* msg) { return fail(code, msg); }
 namespace {
 
+// Development / test switches of a handle.  They are read from the environment ONCE, when the handle is created (load_knobs), and live in
+// the handle from then on: nothing a solve call can reach calls getenv (a deployed process does not change algorithm because its
+// environment changed under it).  The test suite flips them on a live handle through the library-internal lscqp_debug_reload_knobs_ /
+// lscqp_debug_set_knob_ (api.py); the launch-shape overrides of the dual active-set phase (das_*) exist only through that setter.
+struct Knobs {
+    int force_generic = 0;   // LSCQP_FORCE_GENERIC=1: every fp64 launch on the run-time-shaped kernel (lscqp_generic.hip)
+    int pin_waves = 0;       // LSCQP_WAVES=1|2|4: pins the wavefront count of the interior-point instance (every compiled instance is reachable by the tests)
+    int active_set_off = 0;  // LSCQP_ACTIVE_SET=0 / LSCQP_ACTIVE_SET_NOW=0: rounds 1-4's solver (not for LSCQP_ACTIVE_SET_ONLY handles)
+    int check_order = 0;     // LSCQP_CHECK_ORDER=1: d_order is verified to be a permutation (allocates and synchronises)
+    int no_queue = 0;        // LSCQP_NO_QUEUE: no persistent workgroups (tools/lpt_probe.py)
+    int defer_behind = 1;    // host-pointer entries: the interior-point pass behind the phase only when the phase left something (0: always enqueued)
+    int das_threads = -1, das_kmax = -1, das_steps = -1, das_cache = -1, das_stage = -1, das_screen = -1, das_loop = -1;  // -1: the launch policy's value
+};
+void load_knobs(Knobs& k) {
+    auto on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+    k.force_generic = on("LSCQP_FORCE_GENERIC");
+    const char* pin = getenv("LSCQP_WAVES");
+    k.pin_waves = (pin && (pin[0] == '1' || pin[0] == '2' || pin[0] == '4') && pin[1] == 0) ? pin[0] - '0' : 0;
+    const char* as = getenv("LSCQP_ACTIVE_SET");
+    const char* now = getenv("LSCQP_ACTIVE_SET_NOW");
+    k.active_set_off = now ? now[0] == '0' : (as && as[0] == '0');
+    k.check_order = on("LSCQP_CHECK_ORDER");
+    k.no_queue = getenv("LSCQP_NO_QUEUE") != nullptr;
+    const char* db = getenv("LSCQP_DEFER_BEHIND");
+    k.defer_behind = db ? db[0] != '0' : 1;
+}
+
 struct Inst {
     int M, dim, es, max_obs, waves, mixed;
     int nd;     // nested-dissection elimination order (lscqp_kernel.hpp Cfg::ND); 0: the natural order
@@ -104,18 +131,13 @@ const Inst kInst[] = {
 // the fewest wavefronts per QP, which is what fills the chip (4 QPs per CU) -- unless the instance's LDS footprint admits
 // only one workgroup per CU anyway (the nz = 84 class): then more wavefronts are free.  Within a wave count: smallest
 // capacity.
-const Inst* find_instance(int M, int dim, int es, int mixed, int n_obs, int64_t n, int n_cu) {
+const Inst* find_instance(const Knobs& kn, int M, int dim, int es, int mixed, int n_obs, int64_t n, int n_cu) {
     const Inst* best = nullptr;
-    // testing knob: LSCQP_FORCE_GENERIC=1 sends every fp64 launch to the run-time-shaped kernel (lscqp_generic.hip), also for shapes
-    // that have compiled instances -- so that kernel is tested on the shapes every fixture exists for
-    // (both knobs are read at every launch ON PURPOSE: the tests and bench.py flip them between launches of one process.  getenv is
-    // safe against concurrent getenv; a process that calls setenv while another thread solves is outside what the knobs are for.)
-    const char* fg = getenv("LSCQP_FORCE_GENERIC");
-    if (fg && fg[0] == '1' && !mixed) return nullptr;
+    // (test switches of the handle: force_generic sends every fp64 launch to the run-time-shaped kernel, also for shapes that have compiled
+    // instances -- so that kernel is tested on the shapes every fixture exists for; pin_waves pins the wavefront count)
+    if (kn.force_generic && !mixed) return nullptr;
     const bool small = n <= 2 * (int64_t)n_cu;
-    // testing knob: LSCQP_WAVES=1|2 pins the wavefront count (every compiled instance has to be reachable by the tests)
-    const char* pin = getenv("LSCQP_WAVES");
-    const int pin_w = (pin && (pin[0] == '1' || pin[0] == '2' || pin[0] == '4') && pin[1] == 0) ? pin[0] - '0' : 0;
+    const int pin_w = kn.pin_waves;
     for (const Inst& i : kInst) {
         if (!(i.M == M && i.dim == dim && i.es == es && i.mixed == mixed && i.max_obs >= n_obs)) continue;
         if (pin_w && i.waves != pin_w && !mixed) continue;
@@ -327,6 +349,12 @@ const double kQInt[36] = {720, -1800, 1200, 0,     0,     -120, -1800, 4800, -36
 
 // Tables of the dual active-set phase: one host copy per class generation, one device copy per device that has solved with the handle
 // (a communicator drives several devices through one handle).  Shared by the copies lscqp_update makes of the handle.
+// A device buffer is IMMUTABLE once a launch may have seen it: an update that changes the tables gives every device a FRESH buffer and
+// retires the old one (a kernel of an earlier asynchronous solve, or a captured graph replaying on a non-blocking stream, may still be
+// reading it -- until round 5 the copy was made in place).  An update that leaves the tables as they are (the planner's mode flips:
+// reference src/traj_planner.cpp:155,160,187,214 change slack_mode only) touches nothing on the device.  Retired buffers are freed
+// with the handle; should more than kMaxRetired accumulate (a caller that keeps changing dt or the weights), the devices are
+// synchronised once and the list is emptied.
 struct DasTables {
     std::mutex mu;
     std::vector<double> host;
@@ -334,7 +362,12 @@ struct DasTables {
     double* dev[64] = {};
     size_t dev_n[64] = {};
     uint64_t dev_gen[64] = {};
-    std::vector<void*> garbage;  // buffers replaced by an update that changed the shape: freed with the handle (a captured graph may still hold them)
+    struct Retired {
+        void* p;
+        int dev;
+    };
+    std::vector<Retired> garbage;
+    static constexpr size_t kMaxRetired = 256;
 };
 
 struct lscqp_solver {
@@ -345,6 +378,8 @@ struct lscqp_solver {
     // staging of the host-pointer entry points: device buffer + pinned mirror + private stream per concurrent call
     // (one H2D and one D2H per host-pointer solve instead of eight small copies; lscqp_staging.hpp)
     lscqp::StagePool* pool = nullptr;
+    Knobs knobs;              // read from the environment at lscqp_create, never afterwards (lscqp_debug_reload_knobs_ for the tests)
+    std::atomic<int>* behind_needed = nullptr;  // host-pointer entries: did the last call's phase leave work for the interior-point kernel?
     uint64_t generation = 0;  // bumped by lscqp_update: holders of state derived from the class (a captured plan graph) re-derive it
 };
 
@@ -423,40 +458,71 @@ extern "C" uint64_t lscqp_handle_generation_(lscqp_handle h) { return h->generat
 // (library-internal, lscqp_comm.hip) does a batch of this shape have a second chance on the instance with the other elimination order?
 extern "C" int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max);
 
-// (re)build the host copy of the active-set tables after derive(); the device copies are refreshed lazily by das_device_table
+// one device's copy of the current tables, in a buffer no launch has seen yet (mu held; the caller restores the current device).
+// false: allocation or copy failed -- the device then has no tables and its launches run without the phase (or fail loudly, das_device_table)
+static bool das_upload(DasTables& D, int d) {
+    if (D.dev[d]) {
+        D.garbage.push_back({D.dev[d], d});
+        D.dev[d] = nullptr;
+    }
+    if (D.host.empty()) return false;
+    if (hipSetDevice(d) != hipSuccess) return false;
+    double* p = nullptr;
+    if (hipMalloc(&p, sizeof(double) * D.host.size()) != hipSuccess) return false;
+    // (a blocking copy into memory nothing else knows about: no launch can race with it)
+    if (hipMemcpy(p, D.host.data(), sizeof(double) * D.host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p);
+        return false;
+    }
+    D.dev[d] = p;
+    D.dev_n[d] = D.host.size();
+    D.dev_gen[d] = D.gen;
+    return true;
+}
+// (re)build the host copy of the active-set tables after derive() and give every device that holds a copy the new generation
 static void das_refresh(lscqp_solver* s) {
     if (!s->das) return;
     std::lock_guard<std::mutex> lk(s->das->mu);
+    DasTables& D = *s->das;
     const size_t nd = lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, nullptr);
     // (the tables, then the class's 36 coefficient-rounding terms of the objective, then its two-sided rows as far as they are the class's: the
     // kernel reads all three from here)
     const size_t npair = lscqp_das_build_pairs(s->desc.M, s->desc.dim, s->desc.communication_range > 0, nullptr);
-    s->das->host.assign(nd + 36 + npair, 0.0);
+    std::vector<double> fresh(nd + 36 + npair, 0.0);
     if (s->desc.control_input_weight > 0 && s->desc.terminal_weight >= 0 &&
-        lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, s->das->host.data()) == nd) {
-        for (int i = 0; i < 36; i++) s->das->host[nd + i] = s->dev.dQ[i];
+        lscqp_das_build_tables(s->desc.M, s->es, s->desc.dt, s->desc.control_input_weight, s->desc.terminal_weight, fresh.data()) == nd) {
+        for (int i = 0; i < 36; i++) fresh[nd + i] = s->dev.dQ[i];
         static_assert(sizeof(double) == 2 * sizeof(int32_t), "two ints per table slot");
-        lscqp_das_build_pairs(s->desc.M, s->desc.dim, s->desc.communication_range > 0, reinterpret_cast<int32_t*>(s->das->host.data() + nd + 36));
+        lscqp_das_build_pairs(s->desc.M, s->desc.dim, s->desc.communication_range > 0, reinterpret_cast<int32_t*>(fresh.data() + nd + 36));
     } else {
-        s->das->host.clear();  // (a class whose reduced Hessian is not positive definite has no active-set phase)
+        fresh.clear();  // (a class whose reduced Hessian is not positive definite has no active-set phase)
     }
-    s->das->gen++;
-    // devices that already hold a copy are refreshed NOW (create / update are host synchronisation points; a later launch may sit inside a
-    // stream capture, where nothing can be copied -- it would silently run without the phase and differ in the last bits from the eager run)
-    DasTables& D = *s->das;
-    for (int d = 0; d < 64; d++) {
-        if (!D.dev[d]) continue;
-        if (D.host.empty() || D.dev_n[d] != D.host.size()) {
-            D.garbage.push_back(D.dev[d]);
-            D.dev[d] = nullptr;
-            continue;
+    if (D.gen != 0 && fresh.size() == D.host.size() && (fresh.empty() || memcmp(fresh.data(), D.host.data(), sizeof(double) * fresh.size()) == 0))
+        return;  // the update left the tables as they are: the device copies stay, bit for bit, and nothing in flight is disturbed
+    D.host.swap(fresh);
+    D.gen++;
+    // devices that already hold a copy get the new generation NOW (create / update are host synchronisation points; a later launch may sit
+    // inside a stream capture, where nothing can be allocated or copied), each in a fresh buffer
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < 64; d++)
+        if (D.dev[d]) (void)das_upload(D, d);
+    if (D.garbage.size() > DasTables::kMaxRetired) {  // (see the struct: bounded, at the price of one synchronisation per kMaxRetired changes)
+        for (const DasTables::Retired& g : D.garbage) {
+            if (hipSetDevice(g.dev) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(g.p);
+            }
         }
-        if (hipMemcpy(D.dev[d], D.host.data(), sizeof(double) * D.host.size(), hipMemcpyHostToDevice) == hipSuccess) D.dev_gen[d] = D.gen;
+        D.garbage.clear();
     }
+    if (have_cur) (void)hipSetDevice(cur);
 }
-// the tables on the CURRENT device; nullptr: not available right now (no tables, allocation failed, or the first use on this device falls
-// inside a stream capture, where hipMalloc / hipMemcpy are not allowed) -- the launch then runs without the phase
-static const double* das_device_table(lscqp_solver* s, hipStream_t stream) {
+// the tables on the CURRENT device.  *err (when given) says why there are none: 0 the class has no tables (no phase, by construction),
+// 1 allocation / copy failed, 2 the first use on this device falls inside a stream capture, where hipMalloc / hipMemcpy are not allowed --
+// the caller decides (lscqp_prepare_device before capturing avoids it)
+static const double* das_device_table(lscqp_solver* s, hipStream_t stream, int* err = nullptr) {
+    if (err) *err = 0;
     if (!s->das) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -464,21 +530,20 @@ static const double* das_device_table(lscqp_solver* s, hipStream_t stream) {
     DasTables& D = *s->das;
     if (D.host.empty()) return nullptr;
     if (D.dev[dev] && D.dev_gen[dev] == D.gen) return D.dev[dev];
+    // (this stream capturing -- or, for the NULL stream, another stream of the process capturing in global mode, which the query reports as an
+    // error: hipMalloc / a blocking hipMemcpy would invalidate that capture)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
-    if (D.dev[dev] && D.dev_n[dev] != D.host.size()) {
-        D.garbage.push_back(D.dev[dev]);
-        D.dev[dev] = nullptr;
+    const hipError_t qe = hipStreamIsCapturing(stream, &cap);
+    if (qe != hipSuccess) (void)hipGetLastError();
+    const bool capturing = qe != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (capturing) {
+        if (err) *err = 2;
+        return nullptr;
     }
-    if (!D.dev[dev]) {
-        if (hipMalloc(&D.dev[dev], sizeof(double) * D.host.size()) != hipSuccess) {
-            D.dev[dev] = nullptr;
-            return nullptr;
-        }
-        D.dev_n[dev] = D.host.size();
+    if (!das_upload(D, dev)) {
+        if (err) *err = 1;
+        return nullptr;
     }
-    if (hipMemcpy(D.dev[dev], D.host.data(), sizeof(double) * D.host.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    D.dev_gen[dev] = D.gen;
     return D.dev[dev];
 }
 
@@ -496,12 +561,50 @@ int lscqp_create(const lscqp_class_desc* desc, lscqp_handle* out) {
     }
     s->pool = new lscqp::StagePool();
     s->das = new DasTables();
+    s->behind_needed = new std::atomic<int>(0);
+    load_knobs(s->knobs);  // the ONLY place the product reads its environment
     das_refresh(s);
     {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) (void)das_device_table(s, nullptr);  // (a host without a device still creates handles: lscqp_dump_instance)
     }
     *out = s;
+    return LSCQP_OK;
+}
+
+// The class's active-set tables on the CURRENT device, now: what the first solve on a device would otherwise do lazily -- and cannot do
+// inside a stream capture.  lscqp_create does it for the device that is current then, lscqp_comm_create for every device of the communicator.
+int lscqp_prepare_device(lscqp_handle h) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    int why = 0;
+    if (!das_device_table(h, nullptr, &why) && why != 0)
+        return fail(LSCQP_ERR_HIP, why == 2 ? "lscqp_prepare_device inside a stream capture" : "active-set tables: device allocation or copy failed");
+    return LSCQP_OK;
+}
+
+// (library-internal, tests and development tools) re-read the handle's switches from the environment / set one by name; -1 restores a
+// launch-shape override to the policy's value
+int lscqp_debug_reload_knobs_(lscqp_handle h) {
+    if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    Knobs k = h->knobs;
+    load_knobs(k);
+    h->knobs = k;
+    return LSCQP_OK;
+}
+int lscqp_debug_set_knob_(lscqp_handle h, const char* name, int value) {
+    if (!h || !name) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    const std::string n(name);
+    Knobs& k = h->knobs;
+    int* slot = n == "force_generic" ? &k.force_generic : n == "pin_waves" ? &k.pin_waves : n == "active_set_off" ? &k.active_set_off
+              : n == "check_order" ? &k.check_order : n == "no_queue" ? &k.no_queue : n == "defer_behind" ? &k.defer_behind
+              : n == "das_threads" ? &k.das_threads : n == "das_kmax" ? &k.das_kmax : n == "das_steps" ? &k.das_steps
+              : n == "das_cache" ? &k.das_cache : n == "das_stage" ? &k.das_stage : n == "das_screen" ? &k.das_screen
+              : n == "das_loop" ? &k.das_loop : nullptr;
+    if (!slot) return fail(LSCQP_ERR_INVALID_ARGUMENT, "unknown knob: " + n);
+    *slot = value;
     return LSCQP_OK;
 }
 
@@ -523,10 +626,11 @@ int lscqp_update(lscqp_handle h, const lscqp_class_desc* desc) {
 int lscqp_destroy(lscqp_handle h) {
     if (!h) return LSCQP_OK;
     delete h->pool;
+    delete h->behind_needed;
     if (h->das) {
         for (int d = 0; d < 64; d++)
             if (h->das->dev[d]) (void)hipFree(h->das->dev[d]);
-        for (void* g : h->das->garbage) (void)hipFree(g);
+        for (const DasTables::Retired& g : h->das->garbage) (void)hipFree(g.p);
         delete h->das;
     }
     delete h;
@@ -556,7 +660,7 @@ int64_t lscqp_launch_capacity(lscqp_handle h, int64_t n, int32_t n_obs_max) {
     const int n_cu = cu_count();
     if (n_cu <= 0) return -1;
     const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
-    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
+    const Inst* inst = find_instance(h->knobs, h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
     if (!inst) return (int64_t)n_cu;  // (the run-time-shaped kernel: one 256-thread workgroup per CU at the LDS sizes it runs with)
     const int by_lds = (int)(lscqp::kMaxLdsBytes / inst->lds), by_simd = 4 / inst->waves;
     const int per_cu = by_lds < by_simd ? by_lds : by_simd;
@@ -570,8 +674,10 @@ int64_t lscqp_device_fill(lscqp_handle h, int64_t n, int32_t n_obs_max) {
     if (!h || n < 0 || n_obs_max < 0) return -1;
     const int n_cu = cu_count();
     if (n_cu <= 0) return -1;
-    static const bool das_env_off = [] { const char* v = getenv("LSCQP_ACTIVE_SET"); return v && v[0] == '0'; }();
-    if (h->desc.active_set != LSCQP_ACTIVE_SET_OFF && !das_env_off && h->das && !h->das->host.empty()) {
+    // (the phase's fill only while the phase finishes what it is given: when the handle's last host-pointer call had to run the interior-point
+    // passes behind it -- a hard stretch of the mission, mixed precision on a loaded swarm -- the slower kernel is the one that fills the device)
+    const bool ip_busy = h->behind_needed && h->behind_needed->load(std::memory_order_relaxed) != 0;
+    if (!ip_busy && h->desc.active_set != LSCQP_ACTIVE_SET_OFF && !(h->knobs.active_set_off && h->desc.active_set != LSCQP_ACTIVE_SET_ONLY) && h->das && !h->das->host.empty()) {
         const int per_cu = lscqp_das_blocks_per_cu(h->desc.M, h->desc.dim, 8, h->dev.rows_f32);
         if (per_cu > 0) return (int64_t)n_cu * per_cu;
     }
@@ -587,7 +693,7 @@ int lscqp_instance_work(lscqp_handle h, int64_t n, int32_t n_obs_max, lscqp_work
     const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
     int n_cu = cu_count();
     if (n_cu <= 0) n_cu = 256;  // (no device in this process: MI355X's CU count decides the small-batch policy)
-    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
+    const Inst* inst = find_instance(h->knobs, h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, n_cu);
     if (!inst) return fail(LSCQP_ERR_UNSUPPORTED, "no compiled kernel instance for this launch (the run-time-shaped kernel carries no instruction counts)");
     const int G = 64 * inst->waves / (6 * inst->M - 3) > 0 ? 64 * inst->waves / (6 * inst->M - 3) : 1;
     const int nslot = inst->max_obs / G;
@@ -965,7 +1071,7 @@ int lscqp_order_by_work_device(int64_t n, const lscqp_info* d_info_prev, int32_t
 
 int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
                                        const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out, double* d_obj_out,
-                                       int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream);
+                                       int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream, int* deferred);
 
 int lscqp_solve_batch_device_ex(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                 const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
@@ -981,16 +1087,26 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream) {
     if (retry < 0 || retry > 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "retry must be 0, 1, 2 or 3");
     return lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out,
-                                              retry, d_order, stream);
+                                              retry, d_order, stream, nullptr);
 }
 
 // The worker behind the public device entries.  retry also takes the library's own pass codes: -2 = only the repair pass on the instance of
-// the other elimination order, -3 = only the rescue pass (the host-pointer entries and lscqp_comm.hip run them after looking at the statuses).
+// the other elimination order, -3 = only the rescue pass (the host-pointer entries and lscqp_comm.hip run them after looking at the statuses),
+// -10 - r = the interior-point passes of a call with retry = r whose dual active-set phase has ALREADY run (see `deferred`).
+// deferred != NULL (the host-pointer entries): when the dual active-set phase runs, the call returns right behind it with *deferred = 1 and
+// the interior-point passes are NOT enqueued -- the caller reads the statuses with the results and enqueues them (pass code -10 - retry)
+// only if the phase left an instance: on the bench's batches it never does, and a near-empty launch costs 2 - 4 us of every call.
 int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,
                                        const lscqp_row* d_rows, const uint64_t* d_row_offsets, const lscqp_box* d_sfc,
                                        const double* d_x_init, double* d_x_out, double* d_obj_out, int32_t* d_status_out,
-                                       lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream) {
+                                       lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream, int* deferred) {
     if (!h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null handle");
+    if (deferred) *deferred = 0;
+    bool behind_only = false;  // the phase of this call ran in an earlier invocation
+    if (retry <= -10 && retry >= -13) {
+        behind_only = true;
+        retry = -10 - retry;
+    }
     if (retry < -3 || retry > 3 || retry == -1) return fail(LSCQP_ERR_INVALID_ARGUMENT, "invalid pass code");
     if (n < 0 || n_obs_max < 0) return fail(LSCQP_ERR_INVALID_ARGUMENT, "negative size");
     if (n == 0) return LSCQP_OK;
@@ -1004,21 +1120,18 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             return fail(LSCQP_ERR_NO_DEVICE, std::string("no HIP device: lscqp has no CPU fallback (hipGetDeviceCount: ") +
                                                  hipGetErrorString(de) + ", " + std::to_string(ndev) + " devices)");
     }
-    if (d_order) {
-        const char* chk = getenv("LSCQP_CHECK_ORDER");
-        if (chk && chk[0] == '1' && order_is_permutation(n, d_order, (hipStream_t)stream) == 0)
-            return fail(LSCQP_ERR_INVALID_ARGUMENT, "d_order is not a permutation of 0 .. n-1 (LSCQP_CHECK_ORDER)");
-    }
+    const Knobs& kn = h->knobs;
+    if (d_order && kn.check_order && order_is_permutation(n, d_order, (hipStream_t)stream) == 0)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "d_order is not a permutation of 0 .. n-1 (LSCQP_CHECK_ORDER)");
     const int mixed = h->desc.precision == LSCQP_PRECISION_MIXED ? 1 : 0;
-    const Inst* inst = find_instance(h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, cu_count());
-    const Inst* inst64 = mixed ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : inst;
+    const Inst* inst = find_instance(h->knobs, h->desc.M, h->desc.dim, h->es, mixed, n_obs_max, n, cu_count());
+    const Inst* inst64 = mixed ? find_instance(h->knobs, h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : inst;
     lscqp::DevClass cls = h->dev;
     cls.n_obs_max = n_obs_max;
     cls.order = d_order;
     // a launch of more instances than the device has CUs MAY exceed what the chip holds at once: it gets a zeroed work-queue counter and
     // the instance's launcher decides (lscqp_inst.hip: persistent workgroups over the queue, or one instance per workgroup)
-    static const bool no_queue = getenv("LSCQP_NO_QUEUE") != nullptr;  // (development: tools/lpt_probe.py tells the queue and the order apart)
-    const bool queued = !no_queue && n > (int64_t)cu_count();
+    const bool queued = !kn.no_queue && n > (int64_t)cu_count();  // (no_queue: tools/lpt_probe.py tells the queue and the order apart)
     // (a counter -- a memset on the stream, a slot of the ring -- only for a launch that can use it: the instance has a persistent form, and
     // the pass is not the near-empty one behind the dual active-set phase, where almost every workgroup returns at once)
     bool das_in_front = false;
@@ -1033,12 +1146,17 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     // leaves the chip idle gets four wavefronts per QP, the whole budget of active rows and the class's table in LDS (latency); a batch
     // that fills it gets one wavefront per QP and a small LDS footprint (occupancy is what hides the row reads), and the few instances
     // with more active rows than that fall to the interior-point kernel.
-    bool das_ran = false;
-    if (retry >= 0 && h->desc.active_set != LSCQP_ACTIVE_SET_OFF) {
-        static const bool das_env_off = [] { const char* v = getenv("LSCQP_ACTIVE_SET"); return v && v[0] == '0'; }();
-        const char* dyn = getenv("LSCQP_ACTIVE_SET_NOW");  // (tests / A-B inside one process: read at every launch like the other knobs)
-        const bool off = (dyn ? dyn[0] == '0' : das_env_off) && h->desc.active_set != LSCQP_ACTIVE_SET_ONLY;
-        const double* d_tab = off ? nullptr : das_device_table(h, (hipStream_t)stream);
+    bool das_ran = behind_only;
+    if (retry >= 0 && !behind_only && h->desc.active_set != LSCQP_ACTIVE_SET_OFF) {
+        const bool off = kn.active_set_off && h->desc.active_set != LSCQP_ACTIVE_SET_ONLY;
+        int why = 0;
+        const double* d_tab = off ? nullptr : das_device_table(h, (hipStream_t)stream, &why);
+        // (no tables on this device and none can be made right now: running without the phase would differ from an eager run in the last
+        // bits -- silently, for the whole lifetime of a captured graph.  Say so instead.)
+        if (!off && !d_tab && why == 2)
+            return fail(LSCQP_ERR_HIP, "the class's active-set tables are not on this device and the launch sits inside a stream capture: call "
+                                       "lscqp_prepare_device(handle) on this device before capturing");
+        if (!off && !d_tab && why == 1) return fail(LSCQP_ERR_HIP, "active-set tables: device allocation or copy failed");
         int cap = 0;
         if (!inst || !inst64) cap = (mixed || n_obs_max > lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) ? -1 : n_obs_max;
         else cap = std::min(inst->max_obs, inst64->max_obs);
@@ -1049,20 +1167,20 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             // LDS is what limits the resident workgroups -- four wavefronts, a small footprint; beyond that one wavefront per QP.
             const int64_t ncu = cu_count() > 0 ? cu_count() : 256;
             const bool small = n <= 2 * ncu, medium = n <= 8 * ncu;
-            auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-            int threads = env_int("LSCQP_DAS_THREADS", medium ? 256 : 64);
+            auto knob = [](int v, int dflt) { return v >= 0 ? v : dflt; };  // (overrides: lscqp_debug_set_knob_, tests and sweeps only)
+            int threads = knob(kn.das_threads, medium ? 256 : 64);
             // (20 active rows, not the 32 the kernel could hold: the footprint decides how many workgroups a CU holds at once and whether the
             // instance's rows fit in LDS beside the rest -- 512 x M6: 43.0 -> 33.9 us, 128 x M10 x 40: 92.2 -> 84.3, 64 x M5: 12.9 -> 12.5; 24 would
             // already cost the M = 10 class its staged rows.  No feasible instance of a 6 000-instance sweep of the harder swarms needs more than
             // 12; ONE of the ~50 000 of the stress sweep needs 17-20, and at 16 it went to the interior-point kernel, which accepted it at its
             // rounding floor (stationarity 1.9e-7): profiles/r05_kmax_sweep.txt, NOTES.md section 13)
-            int kmax = env_int("LSCQP_DAS_KMAX", small ? 20 : 8);
-            int steps = env_int("LSCQP_DAS_STEPS", small ? 96 : 24);
-            int cacheC = env_int("LSCQP_DAS_CACHE", small ? 1 : 0);
-            int stage = env_int("LSCQP_DAS_STAGE", small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
+            int kmax = knob(kn.das_kmax, small ? 20 : 8);
+            int steps = knob(kn.das_steps, small ? 96 : 24);
+            int cacheC = knob(kn.das_cache, small ? 1 : 0);
+            int stage = knob(kn.das_stage, small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
             // form: bit 0 the lean form in front (built and measured, no gain: the phase is bound by instruction issue, not occupancy); bit 1 the
             // first look inside the loop of steps (one copy of that code: batches of at most two workgroups per CU; lscqp_das.hip, PEEL)
-            const int screen = (env_int("LSCQP_DAS_SCREEN", 0) ? 1 : 0) | (env_int("LSCQP_DAS_LOOP", small ? 1 : 0) ? 2 : 0);
+            const int screen = (knob(kn.das_screen, 0) ? 1 : 0) | (knob(kn.das_loop, small ? 1 : 0) ? 2 : 0);
             const int Mx = h->desc.M, dx = h->desc.dim;
             // what does not fit the CU's LDS is given up in this order: staged rows, the table copy, active rows
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) stage = 0;
@@ -1077,6 +1195,10 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
         }
         if (h->desc.active_set == LSCQP_ACTIVE_SET_ONLY) {
             if (!das_ran) return fail(LSCQP_ERR_UNSUPPORTED, "LSCQP_ACTIVE_SET_ONLY: the active-set phase could not run (no tables on this device, or capacity)");
+            return LSCQP_OK;
+        }
+        if (das_ran && deferred) {  // the caller looks at the statuses first
+            *deferred = 1;
             return LSCQP_OK;
         }
     }
@@ -1238,18 +1360,45 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, st));
     // (retry = 1: instances a warm start did not bring to OPTIMAL are solved once more from the default start by a second pass
     // on the device, before the results are copied back)
-    int rc = lscqp_solve_batch_device_ex(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, 1, st);
+    // The interior-point passes behind the dual active-set phase are enqueued with the phase only when the handle's previous host-pointer call
+    // needed them (a swarm in a hard stretch keeps needing them: no second round trip then); otherwise the statuses are read with the results
+    // and the passes follow only if the phase left an instance -- on quiet batches it never does, and the launch of a kernel that finds nothing
+    // to do is 2 - 4 us of a 20 us call.
+    int deferred = 0;
+    const bool speculate = h->knobs.defer_behind && h->behind_needed && h->behind_needed->load(std::memory_order_relaxed) == 0;
+    int rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, 1, nullptr, st,
+                                                speculate ? &deferred : nullptr);
     if (rc != LSCQP_OK) return rc;
     LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
     LSCQP_CK(hipStreamSynchronize(st));
+    {
+        const int32_t* st_h = (const int32_t*)(hbase + o_st);
+        bool left = false;  // did the phase hand an instance over?  (its mark: ITER_LIMIT with no iterations; anything not OPTIMAL counts)
+        if (deferred) {
+            for (int64_t q = 0; q < n && !left; q++) left = st_h[q] != LSCQP_STATUS_OPTIMAL;
+            if (left) {
+                rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, -11, nullptr, st, nullptr);
+                if (rc != LSCQP_OK) return rc;
+                LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+                LSCQP_CK(hipStreamSynchronize(st));
+            }
+            if (h->behind_needed) h->behind_needed->store(left ? 1 : 0, std::memory_order_relaxed);
+        } else if (h->behind_needed && h->knobs.defer_behind && d_info) {
+            // (the passes ran with the phase: keep doing that while the phase keeps leaving work -- lscqp_info tells who finished an instance)
+            const lscqp_info* in_h = (const lscqp_info*)(hbase + o_info);
+            bool any_ip = false;
+            for (int64_t q = 0; q < n && !any_ip; q++) any_ip = !(in_h[q].flags & LSCQP_INFO_ACTIVE_SET);
+            h->behind_needed->store(any_ip ? 1 : 0, std::memory_order_relaxed);
+        }
+    }
     {   // instances that are still not OPTIMAL get one more pass where the shape has an instance with the other elimination order
         // (a factorisation that breaks down in one order usually survives in the other); only batches with such instances pay for it
         const int32_t* st_h = (const int32_t*)(hbase + o_st);
         bool any = false;
         for (int64_t q = 0; q < n && !any; q++) any = st_h[q] != LSCQP_STATUS_OPTIMAL && st_h[q] != LSCQP_STATUS_CAPACITY;
-        const Inst* first = any ? find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : nullptr;
+        const Inst* first = any ? find_instance(h->knobs, h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count()) : nullptr;
         if (first && other_order_instance(first, n_obs_max)) {
-            rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, nullptr, st);
+            rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, nullptr, st, nullptr);
             if (rc != LSCQP_OK) return rc;
             LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));
@@ -1259,7 +1408,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
         bool lim = false;
         for (int64_t q = 0; q < n && !lim; q++) lim = st_h[q] == LSCQP_STATUS_ITER_LIMIT || st_h[q] == LSCQP_STATUS_NUMERIC;
         if (lim && n_obs_max <= lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) {
-            rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -3, nullptr, st);
+            rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -3, nullptr, st, nullptr);
             if (rc != LSCQP_OK) return rc;
             LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));
@@ -1274,7 +1423,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
 }
 
 int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max) {
-    const Inst* first = find_instance(h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count());
+    const Inst* first = find_instance(h->knobs, h->desc.M, h->desc.dim, h->es, 0, n_obs_max, n, cu_count());
     return (first && other_order_instance(first, n_obs_max)) ? 1 : 0;
 }
 

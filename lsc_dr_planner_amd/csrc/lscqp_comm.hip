@@ -29,7 +29,7 @@ extern "C" const lscqp_plan_desc* lscqp_plan_desc_of_(lscqp_plan p);  // lscplan
 extern "C" int lscqp_plan_device_(lscqp_plan p);
 extern "C" int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
                                                   const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out, double* d_obj_out,
-                                                  int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream);
+                                                  int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order, void* stream, int* deferred);
 extern "C" int lscqp_has_other_order_(lscqp_handle h, int64_t n, int32_t n_obs_max);
 
 namespace {
@@ -210,6 +210,19 @@ int32_t lscqp_comm_devices_for_class(lscqp_comm c, lscqp_handle h, int64_t n, in
     if (g < 1) g = 1;
     if (g > c->G) g = c->G;
     return (int32_t)g;
+}
+
+// The class's active-set tables on every device of the communicator, now (lscqp_prepare_device per device): a device's first solve would
+// otherwise load them lazily -- which a launch inside a stream capture cannot do (it fails loudly instead of running without the phase).
+int lscqp_comm_prepare(lscqp_comm c, lscqp_handle h) {
+    if (!c || !h) return fail(LSCQP_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard dg;
+    for (int g = 0; g < c->G; g++) {
+        if (hipSetDevice(c->dev[g]) != hipSuccess) return fail(LSCQP_ERR_HIP, "hipSetDevice failed");
+        const int rc = lscqp_prepare_device(h);
+        if (rc != LSCQP_OK) return rc;
+    }
+    return LSCQP_OK;
 }
 
 int lscqp_shard_range(int64_t n, int32_t n_used, int32_t g, int64_t* first, int64_t* count) {
@@ -425,7 +438,7 @@ int lscqp_solve_batch_sharded(lscqp_handle h, lscqp_comm c, int64_t n, const lsc
                 rc = lscqp_solve_batch_device_internal_(h, S.cnt, n_obs_max, (const lscqp_header*)db, (const lscqp_row*)(db + o_rows),
                                                  (const uint64_t*)(db + o_off), use_sfc ? (const lscqp_box*)(db + o_sfc) : nullptr, nullptr,
                                                  (double*)(db + S.o_x), (double*)(db + S.o_obj), (int32_t*)(db + S.o_st),
-                                                 (lscqp_info*)(db + S.o_info), -2, nullptr, c->stream[g]);
+                                                 (lscqp_info*)(db + S.o_info), -2, nullptr, c->stream[g], nullptr);
                 if (rc == LSCQP_OK && hipMemcpyAsync(hb2 + S.b_in, db + S.b_in, S.b_out, hipMemcpyDeviceToHost, c->stream[g]) != hipSuccess)
                     rc = fail(LSCQP_ERR_HIP, "hipMemcpyAsync (D2H) failed");
                 if (rc == LSCQP_OK && (e = hipStreamSynchronize(c->stream[g])) != hipSuccess)

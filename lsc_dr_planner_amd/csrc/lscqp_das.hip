@@ -882,9 +882,16 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             if (wv == 0) {
                 const double rho = (lane < k) ? arhs_[lane] - row_dot(&aint_[4 * lane + 1], &acoef_[3 * lane], c_) : 0.0;
                 const double du = solve_factor(k, rho, nullptr);
-                if (lane < k) u_[lane] += du;
+                // multipliers >= 0 is the one KKT condition the passes do not look at again: a refined multiplier below zero by more than
+                // rounding is not this phase's to return -- the interior-point kernel solves the instance; rounding-size negatives are zero
+                const double un = (lane < k) ? u_[lane] + du : 0.0;
+                const double umax = wave_max(fabs(un));
+                const double neg = wave_max((lane < k && un < -1e-12 * umax) ? 1.0 : 0.0);
+                if (lane < k) u_[lane] = fmax(un, 0.0);
+                if (lane == 0) ctl_[7] = neg;
             }
             LSCQP_DAS_BARRIER();
+            if (ctl_[7] != 0.0) break;  // (uniform; not solved: handed over below)
             add_columns(k, r_, nullptr);
             LSCQP_DAS_BARRIER();
             polished = true;

@@ -13,6 +13,7 @@
 #include <functional>
 #include <ostream>
 #include <string>
+#include <stdexcept>
 #include <vector>
 
 #include "sp_const.hpp"
@@ -36,8 +37,12 @@ public:
     }
 
     // one sample time: the agents' states and their last total planning time (:616-636), then the obstacles (:638-652)
+    // (a writer constructed with obstacle columns needs a sample per obstacle: std::invalid_argument otherwise -- the columns of a row
+    // cannot be left out, and reading past a short vector is not an option)
     void writeRow(double t, const std::vector<State>& states, const std::vector<double>& planning_time,
                   const std::vector<ObstacleSample>& obstacles = {}) {
+        if (states.size() < qn_ || planning_time.size() < qn_ || obstacles.size() < on_)
+            throw std::invalid_argument("SimulationResultCsv::writeRow: fewer states / planning times / obstacle samples than the header's columns");
         for (size_t qi = 0; qi < qn_; qi++) {
             const State& s = states[qi];
             os_ << qi << "," << t << "," << s.position.x() << "," << s.position.y() << "," << s.position.z() << "," << s.velocity.x() << ","
@@ -52,7 +57,10 @@ public:
 
     // one planned step starting at simulation time t: samples future_time = 0, record_time_step, ... < time_step of every
     // agent's current trajectory (AgentManager::getFutureState = desired_traj.getStateAt), :612-653
-    // obstacle_at(oi, future_time): what ObstacleGenerator::getObstacle(oi) holds at that sample (the caller's obstacle model)
+    // obstacle_at(oi, future_time): what ObstacleGenerator::getObstacle(oi) holds at that sample (the caller's obstacle model).  NOTE the
+    // reference logs obstacle_generator.getObstacle(oi) UNCHANGED for every future_time of one step (:638-652 sit inside the sample loop
+    // but the generator is only advanced once per step, :279): a callback that reproduces the reference's file returns the step's sample
+    // whatever future_time is; one that advances the obstacle writes a finer -- different -- log.
     void writeStep(double t, double time_step, double record_time_step, const std::vector<traj_t>& trajs,
                    const std::vector<double>& planning_time, const std::function<ObstacleSample(size_t, double)>& obstacle_at = nullptr) {
         double future_time = 0;

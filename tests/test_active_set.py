@@ -178,7 +178,8 @@ def test_budget_exhausted_instances_are_solved_by_the_interior_point_kernel(api,
     x0 = api.x_init_from_swarm(b, dim)
     full = sol.solve_host(hdr, rows, roff, sfcp, x_init=x0)
     assert (full["status"] == 0).all() and ((full["info"]["flags"] & api.INFO_ACTIVE_SET) != 0).all() and full["info"]["iterations"].max() >= 1
-    monkeypatch.setenv("LSCQP_DAS_STEPS", "0")
+    sol.set_knob("das_steps", 0)  # (library-internal switch of the handle: the launch's step budget)
+    only.set_knob("das_steps", 0)
     G = sol.solve_host(hdr, rows, roff, sfcp, x_init=x0)
     O1 = only.solve_host(hdr, rows, roff, sfcp, x_init=x0)
     by_phase = (G["info"]["flags"] & api.INFO_ACTIVE_SET) != 0
