@@ -39,7 +39,7 @@ extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int 
 extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
                                        int stage_rows, int screen, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
                                        const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out, int32_t* status_out,
-                                       lscqp_info* info_out, hipStream_t stream);
+                                       lscqp_info* info_out, int32_t* active_io, int hint_mode, hipStream_t stream);
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
@@ -1090,6 +1090,10 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                               retry, d_order, stream, nullptr);
 }
 
+// lscqp_solve_batch_device_hinted hands its two extra arguments to the worker through this (the worker's signature is shared with lscqp_comm.hip)
+static thread_local int32_t* g_active_io = nullptr;
+static thread_local int g_hint_mode = 0;
+
 // The worker behind the public device entries.  retry also takes the library's own pass codes: -2 = only the repair pass on the instance of
 // the other elimination order, -3 = only the rescue pass (the host-pointer entries and lscqp_comm.hip run them after looking at the statuses),
 // -10 - r = the interior-point passes of a call with retry = r whose dual active-set phase has ALREADY run (see `deferred`).
@@ -1174,8 +1178,15 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             // already cost the M = 10 class its staged rows.  No feasible instance of a 6 000-instance sweep of the harder swarms needs more than
             // 12; ONE of the ~50 000 of the stress sweep needs 17-20, and at 16 it went to the interior-point kernel, which accepted it at its
             // rounding floor (stationarity 1.9e-7): profiles/r05_kmax_sweep.txt, NOTES.md section 13)
-            int kmax = knob(kn.das_kmax, small ? 20 : 8);
-            int steps = knob(kn.das_steps, small ? 96 : 24);
+            // round 6 (tools/loaded_probe.py, swarms 8 - 30 replans into their exchange): a batch that leaves most CUs idle (n <= CUs) gets every
+            // active row the kernel can hold -- the forest10 class mid-exchange holds > 20 rows at one agent's optimum for several replans, and
+            // handing that ONE instance over cost the call 0.16 ms of phase + 0.34 ms of interior point against 0.34 ms without the phase; the
+            // step budget of the other small batches is halved: a feasible instance of the loaded sweeps needs <= 50 steps (<= 33 beyond 64 agents),
+            // an instance that keeps adding and dropping beyond that is, on those sweeps, one whose rows admit no point -- the kernel behind
+            // says so in 14 iterations, and every step spent here before that is added to the call
+            const bool tiny = n <= ncu;
+            int kmax = knob(kn.das_kmax, tiny ? 32 : small ? 20 : 8);
+            int steps = knob(kn.das_steps, tiny ? 96 : small ? 48 : 24);
             int cacheC = knob(kn.das_cache, small ? 1 : 0);
             int stage = knob(kn.das_stage, small ? 1 : 0) ? n_obs_max * 6 * h->desc.M : 0;
             // form: bit 0 the lean form in front (built and measured, no gain: the phase is bound by instruction issue, not occupancy); bit 1 the
@@ -1185,10 +1196,18 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             // what does not fit the CU's LDS is given up in this order: staged rows, the table copy, active rows
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) stage = 0;
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) cacheC = 0;
+            if (tiny && kn.das_kmax < 0 && kmax > 20 && lscqp_das_lds_bytes(Mx, dx, kmax, knob(kn.das_cache, 1), knob(kn.das_stage, 1) ? n_obs_max * 6 * Mx : 0) > lscqp::kMaxLdsBytes) {
+                // (the larger budget never at the price of the staged rows or the table copy: 128 x M10 x 40 runs 8 % slower without them)
+                kmax = 20;
+                cacheC = knob(kn.das_cache, 1);
+                stage = knob(kn.das_stage, 1) ? n_obs_max * 6 * Mx : 0;
+                if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) stage = 0;
+                if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) cacheC = 0;
+            }
             while (kmax > 4 && lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) kmax -= 4;
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) <= lscqp::kMaxLdsBytes) {
                 e = lscqp_launch_das(&cls, Mx, dx, h->es, cap, threads, kmax, steps, cacheC, stage, screen, d_tab, n, d_hdr, d_rows, d_row_offsets, d_sfc,
-                                     d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
+                                     d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, g_active_io, g_hint_mode, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (dual active-set phase): ") + hipGetErrorString(e));
                 das_ran = true;
             }
@@ -1284,6 +1303,22 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     }
     if (retry == 2 || retry == 3) return rescue();
     return LSCQP_OK;
+}
+
+int lscqp_solve_batch_device_hinted(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
+                                    const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out,
+                                    double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order,
+                                    int32_t* d_active_io, int32_t hint_mode, void* stream) {
+    if (retry < 0 || retry > 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "retry must be 0, 1, 2 or 3");
+    if (hint_mode != LSCQP_HINT_NONE && hint_mode != LSCQP_HINT_AS_GIVEN && hint_mode != LSCQP_HINT_SHIFTED)
+        return fail(LSCQP_ERR_INVALID_ARGUMENT, "hint_mode must be LSCQP_HINT_NONE, _AS_GIVEN or _SHIFTED");
+    g_active_io = d_active_io;
+    g_hint_mode = d_active_io ? hint_mode : LSCQP_HINT_NONE;
+    const int rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
+                                                      d_info_out, retry, d_order, stream, nullptr);
+    g_active_io = nullptr;
+    g_hint_mode = LSCQP_HINT_NONE;
+    return rc;
 }
 
 int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,

@@ -73,13 +73,17 @@ class Swarm:
     """N agents, synchronous replanning every dt, as in MultiSyncSimulator::run (src/multi_sync_simulator.cpp:81-129)."""
 
     def __init__(self, N, M=5, dim=3, n_obs=20, seed=0, dt=0.2, radius=0.15, downwash=2.0, vmax=1.0, amax=2.0,
-                 nominal_velocity=1.0, comm_range=3.0, style="forest", spacing=None, world_margin=2.0):
+                 nominal_velocity=1.0, comm_range=3.0, style="forest", spacing=None, world_margin=2.0, neighbour_order="distance"):
         self.N, self.M, self.dim, self.dt, self.n = N, M, dim, dt, 5
         self.n_obs = min(n_obs, N - 1)
         self.radius, self.downwash = radius, downwash
         self.vmax, self.amax, self.nominal_velocity = vmax, amax, nominal_velocity
         self.comm_range = comm_range
         self.style = style
+        # "distance": nearest first (rounds 1-5's batches).  "id": the same n_obs nearest agents, listed by agent id -- the order the
+        # reference's obstacle list has (broadcastMsgs walks the agents in mission order, src/multi_sync_simulator.cpp:305-352), stable from
+        # replan to replan, which is what a record of active rows carried across replans relies on (lscqp_solve_batch_device_hinted)
+        self.neighbour_order = neighbour_order
         rng = np.random.default_rng(seed)
         self.rng = rng
         # jittered lattice: min separation comfortably above 2.2 r in downwash-scaled coordinates
@@ -129,7 +133,8 @@ class Swarm:
         src/multi_sync_simulator.cpp:319-333)."""
         d = np.abs(self.pos[:, None, :] - self.pos[None, :, :]).max(-1)
         np.fill_diagonal(d, np.inf)
-        return np.argsort(d, axis=1, kind="stable")[:, : self.n_obs]
+        nb = np.argsort(d, axis=1, kind="stable")[:, : self.n_obs]
+        return np.sort(nb, axis=1) if self.neighbour_order == "id" else nb
 
     def build_lsc(self, init, nbr):
         N, M, K = self.N, self.M, self.n_obs
