@@ -90,6 +90,76 @@ def to_dev(torch, a, dev):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
 
+COLD_BYTES = 512 * 1024 * 1024  # >= 2 x the 256 MiB Infinity Cache (/opt/skills/guides/MI355X_MICROARCH.md): see cold_measure
+
+
+def time_calls(torch, calls, warm=3):
+    """Average duration of one call of `calls` (zero-argument callables that enqueue on torch's current stream), back to back between two
+    HIP events; `warm` calls of the list's head first, untimed."""
+    for c in calls[:warm]:
+        c()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for c in calls:
+        c()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / len(calls)
+
+
+def cold_measure(torch, api, sol, desc_kwargs, n, n_obs, tensors, max_copies=1024):
+    """The same batch with NOTHING of it in a cache when a launch reads it.  The hot figures of this file re-solve ONE device-resident batch:
+    from the second launch on its rows come out of L2 / the 256 MiB Infinity Cache (FETCH_SIZE counts those hits as traffic; the guide says to
+    scale past L3 before reading it).  Here K copies of the batch -- inputs AND outputs, K x bytes >= 512 MiB, twice the Infinity Cache --
+    are solved round robin: by the time copy j comes round again, 512 MiB of other copies have passed through every cache level.  One untimed
+    round, then one timed round of K launches (HIP events on the launch stream) of (a) the whole solve call and (b) the dual active-set
+    phase alone (LSCQP_ACTIVE_SET_ONLY: the kernel the roofline is quoted on).  The copies hold the same numbers: the results are the hot
+    run's, bit for bit (checked)."""
+    dh, dr, do, ds, dxi = tensors
+    nv = sol.nv
+    per = sum(int(t.numel() * t.element_size()) for t in (dh, dr, do, ds) if t is not None) + (int(dxi.numel() * 8) if dxi is not None else 0)
+    per_out = n * nv * 8 + n * 8 + n * 4 + n * 32
+    K = int(min(max_copies, max(2, -(-COLD_BYTES // max(per + per_out, 1)))))
+
+    def rep(t):  # K copies in ONE allocation, every copy 256-byte aligned
+        if t is None:
+            return [None] * K
+        b = t.contiguous().view(torch.uint8).reshape(-1)
+        stride = (b.numel() + 255) // 256 * 256
+        big = torch.zeros(K * stride, dtype=torch.uint8, device=t.device)
+        big.view(K, stride)[:, : b.numel()] = b
+        return [big[k * stride: k * stride + b.numel()] for k in range(K)]
+
+    H, R, O, S_, XI = rep(dh), rep(dr), rep(do), rep(ds), rep(dxi)
+    dev = dh.device
+    X = torch.zeros(K, n * nv, dtype=torch.float64, device=dev)
+    OB = torch.zeros(K, n, dtype=torch.float64, device=dev)
+    ST = torch.full((K, n), -1, dtype=torch.int32, device=dev)
+    INF = torch.zeros(K, n * 32, dtype=torch.uint8, device=dev)
+    only = api.Solver(api.make_desc(active_set=api.ACTIVE_SET_ONLY, **desc_kwargs))
+    out = {"copies": K, "bytes_per_copy": per + per_out, "bytes_all_copies": K * (per + per_out)}
+    for tag, sv in (("step_ms", sol), ("kernel_ms", only)):
+        calls = [sv.bind_device(n, n_obs, H[k], R[k], O[k], S_[k], X[k], OB[k], ST[k], INF[k], d_x_init=XI[k]) for k in range(K)]
+        for c in calls:  # one untimed round: every copy has been read once and pushed out again by the K - 1 after it
+            c()
+        torch.cuda.synchronize()
+        out[tag] = time_calls(torch, calls, warm=0)
+        if tag == "step_ms":
+            same = bool(torch.equal(X[0], X[K - 1]) and torch.equal(X[0], X[K // 2]) and torch.equal(ST[0], ST[K - 1]))
+            out["copies_bit_identical"] = same
+            out["non_optimal"] = int((ST[K - 1] != 0).sum().item())
+    only.close()
+    bq = sol.algorithmic_bytes(n_obs)
+    out["frac"] = bq * n / (out["kernel_ms"] * 1e-3) / HBM_PEAK
+    out["frac_step"] = bq * n / (out["step_ms"] * 1e-3) / HBM_PEAK
+    out["achieved_GBps"] = bq * n / (out["kernel_ms"] * 1e-3) / 1e9
+    out["what"] = ("%d copies of the batch (inputs and outputs, %.0f MiB in all: twice the 256 MiB Infinity Cache) solved round robin, one untimed round, "
+                   "then one timed round; kernel_ms = the dual active-set phase alone, step_ms = the whole solve call" % (K, K * (per + per_out) / 2**20))
+    del H, R, O, S_, XI, X, OB, ST, INF
+    return out
+
+
 # BASELINE.json configs at their own shapes (SURVEY.md section 8 size table).  "c1" is the headline (the metric is quoted on it);
 # the others are measured on one GPU in the `configs` section of the JSON line and can be made the timed workload with
 # --config (that is how tools/profile_round.py traces each kernel instance on its own).  `seed`: ONE batch per config -- the `configs`
@@ -110,6 +180,21 @@ CONFIGS = {
                what="configs[4]: 4096 agents x M=5, fp32 PDIP (float32 factorisation, 16-byte rows) with fp64 residual check"),
     "c4_f64": dict(seed=7101, agents=4096, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64",
                    what="configs[4] shape in fp64 (32-byte rows): the comparison the mixed-precision instance is judged against"),
+    # round 6: the same swarms LATER in their exchange (BASELINE's batches are taken 3 replans after hover, when most QPs hold no row at the
+    # optimum; the reference's own missions are busier: log/simulation_..., forest10 mid-mission) and with SURVEY.md 8d's controlled fraction of
+    # infeasible instances.  Checkpoints from tools/loaded_probe.py: the replans where each swarm's step counts peak.
+    "c1_loaded": dict(seed=1000, agents=64, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64", warm_steps=25,
+                      what="configs[1] swarm 25 replans into its exchange"),
+    "c0_loaded": dict(seed=3020, agents=10, segments=10, obs=9, dim=2, style="forest", precision="f64", rows="f64", warm_steps=12,
+                      what="configs[0] forest10 replica 12 replans into its exchange (the class's busiest stretch: > 20 active rows at one agent)"),
+    "c2_loaded": dict(seed=3518, agents=512, segments=6, obs=20, dim=3, style="maze", precision="f64", rows="f64", warm_steps=20,
+                      what="configs[2] dense-maze swarm 20 replans into its exchange"),
+    "c4_loaded": dict(seed=7101, agents=4096, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64", warm_steps=8,
+                      what="configs[4] shape (fp64 rows) 8 replans into its exchange"),
+    "c1_infeasible_1pct": dict(seed=1000, agents=64, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64", infeasible_frac=1 / 64,
+                               what="configs[1] batch with ONE of its 64 instances (1.6 %) made infeasible (SURVEY.md 8d)"),
+    "c4_infeasible_1pct": dict(seed=7101, agents=4096, segments=5, obs=20, dim=3, style="forest", precision="f64", rows="f64", infeasible_frac=0.01,
+                               what="configs[4] shape (fp64 rows) with 1 % of its instances (41) made infeasible (SURVEY.md 8d)"),
 }
 
 
@@ -227,15 +312,39 @@ def oracle_baseline(O, sw, build, M, dim, n_obs_eff, sample, budget_s=2.5, singl
     return out, R, sel
 
 
-def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_seconds=4.0):
+def make_infeasible(api, rows, hdr, n_obs, M, frac, seed):
+    """"a controlled fraction of deliberately infeasible instances (e.g. 1 %: overlapping agents) ... to exercise the
+    status/fallback path" (the reference: QPFAILED, src/traj_optimizer.cpp:143,152 -> the caller keeps initial_traj, src/traj_planner.cpp:767-797).
+    The chosen instances get what two agents INSIDE each other's collision model produce: the rows of their second neighbour become the
+    mirror image of the first neighbour's, 0.4 m apart -- n.c >= b and n.c <= b - 0.4 for every control point -- a row system without a
+    point.  Returns (rows copy, indices)."""
+    N = len(hdr)
+    rng = np.random.default_rng(seed)
+    k = max(1, int(round(frac * N)))
+    sel = np.sort(rng.choice(N, size=k, replace=False))
+    r = np.array(rows, copy=True).reshape(N, n_obs, M * 6)
+    for q in sel:
+        for f in ("nx", "ny", "nz"):
+            r[f][q, 1] = -r[f][q, 0]
+        r["b"][q, 1] = -r["b"][q, 0] + 0.4
+    return r.reshape(-1), sel
+
+
+def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_seconds=4.0, cold=False, phase_off=True):
     """One BASELINE config at its own shape on this GPU: kernel time (HIP events), QP/s, latency percentiles, HBM fraction,
-    iterations, oracle parity + CPU baseline on a bounded sample."""
+    iterations, oracle parity + CPU baseline on a bounded sample.  cfg may carry `warm_steps` (replans after hover before the timed batch is
+    taken: 3 for BASELINE's batches, more for the *_loaded blocks) and `infeasible_frac` (make_infeasible).  phase_off: the same batch with the
+    dual active-set phase switched off as well (the interior-point kernel alone, rounds 1-4) -- `phase_off` in the block.  cold: cold_measure."""
     N, M, dim, n_obs = cfg["agents"], cfg["segments"], cfg["dim"], cfg["obs"]
 
     def factory(sw, **kw):
         return api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **kw))
 
-    sw, sol64, b, (hdr, rows, off, sfc) = make_batch(api, synth, factory, N, M, dim, n_obs, seed=cfg["seed"], style=cfg["style"], warm_steps=3)
+    sw, sol64, b, (hdr, rows, off, sfc) = make_batch(api, synth, factory, N, M, dim, n_obs, seed=cfg["seed"], style=cfg["style"],
+                                                     warm_steps=cfg.get("warm_steps", 3))
+    bad_sel = None
+    if cfg.get("infeasible_frac"):
+        rows, bad_sel = make_infeasible(api, rows, hdr, sw.n_obs, M, cfg["infeasible_frac"], cfg["seed"] + 17)
     kw = {}
     if cfg.get("warm_start") == "tight":
         kw["warm_start"] = api.WARM_TIGHT
@@ -254,23 +363,15 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     dinfo = torch.zeros(N * 32, dtype=torch.uint8, device=dev)
 
     d_order = [None]
+    bound = [sol.bind_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi)]
 
     def call():
         if d_order[0] is not None:  # what a replan does: sort by the previous solve's counts (they are in dinfo), then solve in that order
             sol.order_by_work_device(N, dinfo, d_order[0])
-        sol.solve_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi, d_order=d_order[0])
+        bound[0]()
 
     def timed(k):
-        for _ in range(3):
-            call()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(k):
-            call()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / k
+        return time_calls(torch, [call] * k)
 
     ms_as_given = timed(max(5, reps // 2))
     # the work order a planner has: the agents whose previous QP took the most iterations first (lscqp_order_by_work_device on the info
@@ -281,38 +382,76 @@ def measure_config(torch, api, synth, dev, key, cfg, O=None, reps=20, lat_second
     phase_on = os.environ.get("LSCQP_ACTIVE_SET", "1")[:1] != "0" and os.environ.get("LSCQP_ACTIVE_SET_NOW", "1")[:1] != "0"
     if N > sol.launch_capacity(N, sw.n_obs) and not phase_on:  # (round 5: with the dual active-set phase in front there is no iteration tail to sort)
         d_order[0] = torch.zeros(N, dtype=torch.int32, device=dev)
+        bound[0] = sol.bind_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi, d_order=d_order[0])
         ms = timed(reps)
     else:
         ms = ms_as_given
+    spread = sorted(timed(reps) for _ in range(5))
     # >= 1000 calls where that fits a bounded time (the slowest config, 1024 x M=10, needs ~10 s for them)
     p50, p99, nlat = percentile_latency(torch, call, max_seconds=min(14.0, max(lat_seconds, 1.15e-3 * ms * 1100)))
     info = dinfo.cpu().numpy().view(api.INFO_DTYPE)
     st = dst.cpu().numpy()
     bq = sol.algorithmic_bytes(sw.n_obs)
+    by_as = ((info["flags"] & api.INFO_ACTIVE_SET) != 0) & (st == 0)
     out = {"config": key, "what": cfg["what"], "agents": N, "segments": M, "dim": dim, "lsc_neighbours": sw.n_obs, "style": cfg["style"],
+           "batch_seed": cfg["seed"], "replans_after_hover": cfg.get("warm_steps", 3),
            "precision": cfg["precision"], "rows": cfg["rows"], "rows_per_qp": sol.num_inequalities(sw.n_obs),
            "kernel_ms": ms, "qp_per_s": N / (ms * 1e-3), "latency_ms": {"p50": p50, "p99": p99, "calls": nlat},
+           "ms_spread": {"min": spread[0], "median": spread[2], "max": spread[-1], "repeats": 5, "launches_per_repeat": reps},
            "work_order": ("longest first: lscqp_order_by_work_device on the previous solve's iteration counts, inside every timed call (same batch: "
                           "a perfect hint)") if d_order[0] is not None else "as given (the launch starts every instance at once)",
            "kernel_ms_as_given": ms_as_given, "qp_per_s_as_given": N / (ms_as_given * 1e-3),
            "algorithmic_bytes_per_qp": bq, "hbm_GBps": bq * N / (ms * 1e-3) / 1e9, "hbm_frac": bq * N / (ms * 1e-3) / HBM_PEAK,
            "iters_mean": float(info["iterations"].mean()), "iters_max": int(info["iterations"].max()), "paths": path_stats(api, info, st),
+           "active_set_steps_histogram": np.bincount(np.minimum(info["iterations"][by_as], 64), minlength=1).tolist() if by_as.any() else [],
            "active_set_kernel_ms": active_set_kernel_ms(torch, api, dict(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max,
                                                                        **{k_: v_ for k_, v_ in kw.items() if k_ == "row_format"}), N, sw.n_obs, (dh, dr, do, ds, dxi)),
            "roofline_valu": (valu_roofline(sol, N, sw.n_obs, info["iterations"][((info["flags"] & api.INFO_ACTIVE_SET) == 0) & (st == 0)], ms)
                              if cfg["precision"] == "f64" else None),
            "non_optimal": int((st != 0).sum()), "second_pass": int(((info["flags"] & api.INFO_REPAIRED) != 0).sum()),
-           "floor_accepted": int(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum())}
+           "floor_accepted": int(((info["flags"] & api.INFO_FLOOR_ACCEPTED) != 0).sum()),
+           "statuses": np.bincount(st, minlength=5).tolist()}
+    out["paths"]["proven_infeasible_by_phase"] = int((((info["flags"] & api.INFO_ACTIVE_SET) != 0) & (st == api.STATUS_INFEASIBLE)).sum())
+    x_on = dx.cpu().numpy().reshape(N, nv).copy()
+    if phase_off and phase_on and cfg["precision"] == "f64":
+        # the SAME batch with the phase off: the interior-point kernel alone (rounds 1-4) -- a launch shape where the phase does not pay shows here
+        sol.set_knob("active_set_off", 1)
+        try:
+            off_call = sol.bind_device(N, sw.n_obs, dh, dr, do, ds, dx, dob, dst, dinfo, d_x_init=dxi)
+            ms_off = time_calls(torch, [off_call] * max(5, reps // 2))
+            st_off = dst.cpu().numpy()
+            io = dinfo.cpu().numpy().view(api.INFO_DTYPE)
+            both = (st == 0) & (st_off == 0)
+            out["phase_off"] = {"kernel_ms": ms_off, "qp_per_s": N / (ms_off * 1e-3), "speedup_of_phase": ms_off / ms, "non_optimal": int((st_off != 0).sum()),
+                                "iters_mean": float(io["iterations"].mean()), "iters_max": int(io["iterations"].max()),
+                                "statuses_equal": bool(np.array_equal(st_off != 0, st != 0)),
+                                "fp64_valu": valu_roofline(sol, N, sw.n_obs, io["iterations"][st_off == 0], ms_off),
+                                "max_abs_dx_vs_phase_on": float(np.abs(dx.cpu().numpy().reshape(N, nv) - x_on)[both].max()) if both.any() else None}
+        finally:
+            sol.set_knob("active_set_off", 0)
+        bound[0]()  # (the buffers hold the default path's results again)
+        torch.cuda.synchronize()
+    if bad_sel is not None:
+        out["infeasible"] = {"instances": [int(v) for v in bad_sel[:16]], "count": int(len(bad_sel)), "fraction": float(len(bad_sel)) / N,
+                             "all_reported_non_optimal": bool((st[bad_sel] != 0).all()), "others_optimal": bool((np.delete(st, bad_sel) == 0).all()),
+                             "how": "second neighbour's rows := mirror image of the first neighbour's, 0.4 m apart (two agents inside each other's model)"}
+    if cold and phase_on:
+        try:
+            out["cold"] = cold_measure(torch, api, sol, dict(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max,
+                                                             **{k_: v_ for k_, v_ in kw.items() if k_ == "row_format"}), N, sw.n_obs, (dh, dr, do, ds, dxi))
+        except Exception as ex:  # noqa: BLE001
+            out["cold"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     if O is not None:
         # (rows rounded to float32 are a different problem instance than the oracle's fp64 rows: parity is taken on fp64 rows)
         cpu, R, sel = oracle_baseline(O, sw, b, M, dim, sw.n_obs, sample=64 if M < 10 else 32)
         out["cpu_baseline"] = cpu
-        if cfg["rows"] == "f64":
-            xg, og = dx.cpu().numpy().reshape(N, nv)[sel], dob.cpu().numpy()[sel]
+        if cfg["rows"] == "f64" and bad_sel is None:
+            xg, og = x_on[sel], dob.cpu().numpy()[sel]
             ok = (R["status"] == 0) & (st[sel] == 0)
             if ok.any():
                 out["parity_vs_oracle"] = {"max_abs_dx": float(np.abs(xg - R["x"])[ok].max()), "compared": int(ok.sum()),
-                                           "max_rel_dobj": float((np.abs(og - R["obj"]) / np.maximum(1.0, np.abs(R["obj"])))[ok].max())}
+                                           "max_rel_dobj": float((np.abs(og - R["obj"]) / np.maximum(1.0, np.abs(R["obj"])))[ok].max()),
+                                           "status_disagreements": int(((R["status"] == 0) != (st[sel] == 0)).sum())}
     return out
 
 
@@ -612,6 +751,7 @@ def timed_workload(ctx, a):
     torch, dist, rank, world, dev = ctx.torch, ctx.dist, ctx.rank, ctx.world, ctx.dev
     M, dim, n_obs, N = a.segments, a.dim, a.obs, a.agents
     cfg_seed = CONFIGS[a.config]["seed"]
+    cfg_warm = CONFIGS[a.config].get("warm_steps", 3)
     solver_kw = {}
     if a.precision == "mixed":
         solver_kw["precision"] = api.PRECISION_MIXED
@@ -642,7 +782,7 @@ def timed_workload(ctx, a):
         # ONE swarm for the whole job, built identically on every rank (the config's seed; the warm-up replans are carried by the rank's
         # own GPU, the kernel is deterministic), then cut: rank r owns the contiguous block shard_range(n_glob, world, r) (reference
         # agent order, src/mission.cpp:140-153).  It is the SAME batch the one-GPU `configs` entry of this config solves whole.
-        sw, sol, build, (hdr, rows, off, sfc) = all_ranks(lambda: make_batch(api, synth, warm_factory, n_glob, M, dim, n_obs, seed=cfg_seed, style=a.style, warm_steps=3))
+        sw, sol, build, (hdr, rows, off, sfc) = all_ranks(lambda: make_batch(api, synth, warm_factory, n_glob, M, dim, n_obs, seed=cfg_seed, style=a.style, warm_steps=cfg_warm))
         lo, hi = sharding.shard_range(n_glob, world, rank)
         per = -(-n_glob // world)
         N = hi - lo
@@ -656,7 +796,9 @@ def timed_workload(ctx, a):
     else:
         whole = None
         sw, sol, build, (hdr, rows, off, sfc) = all_ranks(lambda: make_batch(api, synth, warm_factory, N, M, dim, n_obs, seed=cfg_seed + rank,
-                                                                             style=a.style, warm_steps=3))
+                                                                             style=a.style, warm_steps=cfg_warm))
+        if CONFIGS[a.config].get("infeasible_frac"):
+            rows, _ = make_infeasible(api, rows, hdr, sw.n_obs, M, CONFIGS[a.config]["infeasible_frac"], cfg_seed + 17)
         n_glob = world * N
     if solver_kw:
         sol = api.Solver(api.make_desc(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max, **solver_kw))
@@ -702,7 +844,15 @@ def timed_workload(ctx, a):
     def solve_only():
         sol.solve_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit, d_order=d_order[0])
 
+    # the plain step (the solve of BASELINE's metric alone, in the order given): the same C entry with its arguments converted once
+    # (api.Solver.bind_device) -- a 64-QP step lasts ~14 us on the device, and building eleven ctypes pointers per call is of that order
+    plain = not (a.pipeline or a.graph or gather)
+    bound_solve = sol.bind_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit) if plain else None
+
     def step():
+        if plain and d_order[0] is None:
+            bound_solve()
+            return
         if d_order[0] is not None:  # (what a replan does: the previous step's iteration counts are in d_info)
             sol.order_by_work_device(N, d_info, d_order[0])
         if a.pipeline:
@@ -735,6 +885,17 @@ def timed_workload(ctx, a):
             eager_step()
         step = hip_graph.replay  # noqa: F811
 
+    # before the contract's W warm-up steps: untimed steps until the device has been busy for ~0.25 s.  A 20-step timed region of a 14 us
+    # step lasts 0.3 ms -- on a box that has just been handed over the clocks are still ramping through all of it (round 5: the driver's
+    # line was 14 % below the same command's line from a warm process).  Untimed, like the warm-up itself; `clock_warm_steps` says how many.
+    clock_warm_steps = 0
+    if not a.no_clock_warm:
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.25 and clock_warm_steps < 200000:
+            for _ in range(50):
+                step()
+            clock_warm_steps += 50
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -760,6 +921,19 @@ def timed_workload(ctx, a):
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / a.steps  # average launch duration on the launch stream
+    # the run's spread: the same K-step region six more times (barrier + synchronize on both sides each time; `value` stays the FIRST region's,
+    # the contract's); max over ranks per repeat
+    repeats = [elapsed / a.steps * 1e3]
+    for _ in range(0 if a.no_spread else 6):
+        ctx.barrier()
+        torch.cuda.synchronize()
+        t_r = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        ctx.barrier()
+        repeats.append((time.perf_counter() - t_r) / a.steps * 1e3)
+    repeats = [ctx.reduce([r], "max")[0] for r in repeats]
 
     if d_all is not None and not a.pipeline:
         # roofline.kernel_ms is the SOLVE kernel's launch duration: time it without the exchange that shares the step's stream
@@ -865,7 +1039,8 @@ def timed_workload(ctx, a):
                            d_obj=d_obj, d_st=d_st, d_info=d_info, d_all=d_all, elapsed=elapsed, kernel_ms=kernel_ms, status=status, iters=iters,
                            n_bad=n_bad, n_floor=n_floor, iters_mean=it_sum / max(n_agents_seen, 1), iters_max=int(it_max), n_ranks_seen=n_ranks_seen,
                            n_devices_seen=n_devices_seen, n_agents_seen=n_agents_seen, rank_parity=rank_parity, step_lat=step_lat, one_gpu=one_gpu,
-                           solve_only=solve_only, ordered=d_order[0] is not None, paths=paths, das_ms=das_ms)
+                           solve_only=solve_only, ordered=d_order[0] is not None, paths=paths, das_ms=das_ms, repeats=repeats, clock_warm_steps=clock_warm_steps,
+                           solver_kw=solver_kw)
 
 
 def check_ran_as_asked(ctx, a, S):
@@ -986,6 +1161,9 @@ def main():
     ap.add_argument("--no-rank-parity", action="store_true", help="multi-rank runs: skip the per-rank oracle check of each rank's own block")
     ap.add_argument("--no-work-order", action="store_true",
                     help="launch the instances in the order given instead of longest-previous-solve first (lscqp_order_by_work_device)")
+    ap.add_argument("--no-clock-warm", action="store_true", help="skip the untimed ~0.25 s of steps in front of the warm-up (see timed_workload)")
+    ap.add_argument("--no-spread", action="store_true", help="skip the six extra timed repeats of the K-step region (the line's `spread`)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-HBM measurement (512 MiB of batch copies solved round robin)")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
                     help="strong scaling: skip rank 0's solve of the WHOLE batch on its own GPU (config.one_gpu_same_workload)")
     args = ap.parse_args()
@@ -1147,6 +1325,17 @@ def main():
     except Exception:
         pass
     roof.update({"traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "valu": valu})
+    # the same kernel with nothing of its batch in a cache (cold_measure): `frac` above is the batch re-solved in place
+    roof["frac_hot"] = roof["frac"]
+    roof["frac_cold"], roof["cold"] = None, None
+    if world == 1 and not args.no_cold and "das_kernel" in roof["kernel"] and not (args.pipeline or args.graph):
+        try:
+            cm = cold_measure(torch, api, sol, dict(M=M, dim=dim, world_min=sw.world_min, world_max=sw.world_max,
+                                                    **{k_: v_ for k_, v_ in S.solver_kw.items() if k_ == "row_format"}), N, n_obs_eff,
+                              (d_hdr, d_rows, d_off, d_sfc, d_xinit))
+            roof["frac_cold"], roof["cold"] = cm["frac"], cm
+        except Exception as ex:  # noqa: BLE001
+            roof["cold"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     info_h = d_info.cpu().numpy().view(api.INFO_DTYPE)
     rv = (valu_roofline(sol, N, n_obs_eff, iters[((info_h["flags"] & api.INFO_ACTIVE_SET) == 0) & (status == 0)], kernel_ms)
           if args.precision == "f64" else None)
@@ -1180,6 +1369,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f64" if args.precision == "f64" else "f64 iterate and residuals, f32 factorisation",
         "data": "synthetic",
+        "spread": {"ms_per_step": {"min": float(min(S.repeats)), "median": float(np.median(S.repeats)), "max": float(max(S.repeats))},
+                   "value": {"min": n_glob / (max(S.repeats) * 1e-3), "median": n_glob / (float(np.median(S.repeats)) * 1e-3), "max": n_glob / (min(S.repeats) * 1e-3)},
+                   "repeats": len(S.repeats), "what": "the timed K-step region repeated (the first repeat IS `value` / `ms_per_step`); wall clock, synchronised, max over ranks",
+                   "clock_warm_steps_before_warmup": S.clock_warm_steps},
         "config": conf,
         "roofline": roof,
         "roofline_valu": rv,
@@ -1188,6 +1381,24 @@ def main():
                    "what": "iters_*: lscqp_info.iterations over the batch = active-set steps for instances the dual active-set phase finished "
                            "(LSCQP_INFO_ACTIVE_SET), interior-point iterations for the others; `paths` tells them apart"},
     }
+    if world == 1 and args.precision == "f64" and S.das_ms is not None and not (args.pipeline or args.graph):
+        # the kernel BEHIND the phase, measured by this run too (the interior-point kernel north_star names: with the phase on it has nothing to
+        # do on this batch): the same step with the phase switched off -- rounds 1-4's solver -- and its own roof, fp64 vector work
+        sol.set_knob("active_set_off", 1)
+        try:
+            off_call = sol.bind_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit)
+            ms_off = time_calls(torch, [off_call] * 20)
+            io = d_info.cpu().numpy().view(api.INFO_DTYPE)
+            st_off = d_st.cpu().numpy()
+            out["phase_off"] = {"ms_per_step": ms_off, "value": N / (ms_off * 1e-3), "unit": "QP/s", "speedup_of_phase": ms_off / out["ms_per_step"],
+                                "kernel": roof["behind_it"], "non_optimal": int((st_off != 0).sum()), "iters_mean": float(io["iterations"].mean()),
+                                "iters_max": int(io["iterations"].max()), "fp64_valu": valu_roofline(sol, N, n_obs_eff, io["iterations"][st_off == 0], ms_off),
+                                "hbm_frac": roof["algorithmic_bytes_per_qp"] * N / (ms_off * 1e-3) / HBM_PEAK,
+                                "what": "the same batch, the same call, the dual active-set phase switched off: the interior-point kernel alone (HIP events, 20 launches)"}
+        finally:
+            sol.set_knob("active_set_off", 0)
+        S.solve_only()
+        torch.cuda.synchronize()
     if world > 1:
         out["roofline"]["whole_job"] = {"achieved": roof["algorithmic_bytes_per_qp"] * out["value"] / 1e9, "peak": world * HBM_PEAK / 1e9, "unit": "GB/s",
                                         "frac": roof["algorithmic_bytes_per_qp"] * out["value"] / (world * HBM_PEAK),
@@ -1228,10 +1439,12 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import oracle as O  # the checker / CPU baseline, never the thing measured
         sweep = []
-        for key in ("c0", "c2", "c3s", "c3", "c4_f64", "c4"):
+        for key in ("c0", "c2", "c3s", "c3", "c4_f64", "c4", "c1_loaded", "c0_loaded", "c2_loaded", "c4_loaded", "c1_infeasible_1pct", "c4_infeasible_1pct"):
             try:
-                sweep.append(measure_config(torch, api, synth, dev, key, CONFIGS[key], O=O,
-                                            lat_seconds=1.5 if args.no_latency else 4.0))
+                extra = key not in ("c0", "c2", "c3s", "c3", "c4_f64", "c4")
+                sweep.append(measure_config(torch, api, synth, dev, key, CONFIGS[key], O=(O if not key.endswith("_1pct") or True else None),
+                                            lat_seconds=1.0 if (args.no_latency or extra) else 3.0,
+                                            cold=(key in ("c2", "c3", "c4_f64", "c4", "c4_loaded") and not args.no_cold)))
             except Exception as ex:  # one failing shape must not take the headline line with it
                 sweep.append({"config": key, "error": "%s: %s" % (type(ex).__name__, str(ex)[:300])})
         out["configs"] = sweep
@@ -1240,25 +1453,16 @@ def main():
             out["mixed_vs_fp64_at_4096"] = {"fp64_qp_per_s": by["c4_f64"]["qp_per_s"], "mixed_qp_per_s": by["c4"]["qp_per_s"],
                                             "ratio": by["c4"]["qp_per_s"] / by["c4_f64"]["qp_per_s"],
                                             "iters_fp64": by["c4_f64"]["iters_mean"], "iters_mixed": by["c4"]["iters_mean"]}
-        # the optional tight centring of warm starts (lscqp_class_desc.warm_start) on the throughput shape: informational
-        try:
-            tcfg = dict(CONFIGS["c4_f64"], warm_start="tight", what="configs[4] shape in fp64 with LSCQP_WARM_TIGHT")
-            t = measure_config(torch, api, synth, dev, "c4_f64", tcfg, O=None, lat_seconds=1.0)
-            out["tight_warm_start_at_4096"] = {"qp_per_s": t["qp_per_s"], "kernel_ms": t["kernel_ms"], "iters_mean": t["iters_mean"], "iters_max": t["iters_max"],
-                                               "non_optimal": t["non_optimal"], "ratio_to_default": t["qp_per_s"] / by["c4_f64"]["qp_per_s"] if "qp_per_s" in by.get("c4_f64", {}) else None}
-        except Exception as ex:
-            out["tight_warm_start_at_4096"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
-
         # the run-time-shaped kernel (csrc/lscqp_generic.hip: shapes / neighbour counts no compiled instance serves): informational --
         # the headline's class forced onto it, a 64-neighbour batch no compiled instance holds, and a shape that has none (M = 9, DLSC)
         try:
             gk = {}
             os.environ["LSCQP_FORCE_GENERIC"] = "1"
-            t = measure_config(torch, api, synth, dev, "c1", dict(CONFIGS["c1"], what="configs[1] shape forced onto the run-time-shaped kernel"), O=None, lat_seconds=0.5)
+            t = measure_config(torch, api, synth, dev, "c1", dict(CONFIGS["c1"], what="configs[1] shape forced onto the run-time-shaped kernel"), O=None, lat_seconds=0.5, phase_off=False)
             gk["c1_shape_forced"] = {k: t[k] for k in ("kernel_ms", "qp_per_s", "iters_mean", "iters_max", "non_optimal")}
             os.environ.pop("LSCQP_FORCE_GENERIC")
             t = measure_config(torch, api, synth, dev, "n64", dict(agents=128, segments=5, obs=64, dim=3, style="forest", precision="f64", rows="f64", seed=3133,
-                                                                  what="128 agents x M=5 x 64 LSC neighbours (beyond every compiled instance)"), O=None, lat_seconds=0.5)
+                                                                  what="128 agents x M=5 x 64 LSC neighbours (beyond every compiled instance)"), O=None, lat_seconds=0.5, phase_off=False)
             gk["m5_64_neighbours"] = {k: t[k] for k in ("kernel_ms", "qp_per_s", "iters_mean", "iters_max", "non_optimal", "lsc_neighbours")}
             gk["compiled_instance_at_c1"] = by.get("c1", {}).get("kernel_ms") or out["roofline"]["kernel_ms"]
             out["generic_kernel"] = gk

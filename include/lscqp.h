@@ -355,31 +355,6 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                      double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry,
                                      const int32_t* d_order, void* stream);
 
-/* Warm start of the dual active-set phase from the agent's PREVIOUS solve (round 6).  The reference hands the previous plan to every solve
- * (initial_traj, src/traj_planner.cpp:399-411,762) and CPLEX ignores it; here the previous solve's ACTIVE ROWS are what helps: the dual
- * method adds violated rows one at a time, most violated first, and on a loaded swarm it adds and drops 24 - 56 times to reach an optimum
- * that holds 5 - 10 rows (the reference's own forest10 mission) -- while the rows the previous replan's optimum held are, one segment
- * later, mostly the rows this replan's optimum holds.
- *   d_active_io   n x LSCQP_ACTIVE_SLOTS int32, device.  IN: per instance the rows to try first (the record a previous call left; -1: empty
- *                 slot).  OUT: the rows this call's optimum holds, in the phase's own encoding (opaque to the caller; all -1 for an
- *                 instance the phase did not finish).  A fresh buffer is filled with -1 (memset 0xff).
- *   hint_mode     LSCQP_HINT_NONE      the record is written, not read (the first replan)
- *                 LSCQP_HINT_AS_GIVEN  the record is of the same rows (a re-solve of the same instance)
- *                 LSCQP_HINT_SHIFTED   the record is of the plan one segment earlier -- the replanning loop: a row of segment m is tried at
- *                                      segment m - 1 (neighbour slot for slot: keep the neighbour order from replan to replan)
- * It is a PRICING hint and nothing more: while a hinted row is violated, hinted rows are added first (and only they are evaluated -- 32 rows
- * instead of every row of the instance); then the phase goes on as always.  Any order of adding violated rows ends at the same optimum
- * (the QP is strictly convex): a wrong, stale or garbage hint costs steps, never correctness -- every result passes the same verification.
- * lscqp_plan keeps the record from replan to replan by itself.  Other arguments: lscqp_solve_batch_device_ordered's. */
-#define LSCQP_ACTIVE_SLOTS 32
-#define LSCQP_HINT_NONE 0
-#define LSCQP_HINT_AS_GIVEN 1
-#define LSCQP_HINT_SHIFTED 2
-int lscqp_solve_batch_device_hinted(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
-                                    const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out,
-                                    double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order,
-                                    int32_t* d_active_io, int32_t hint_mode, void* stream);
-
 /* ---- multi-GPU: the agent batch over the GPUs of one node, from ONE host process ----------------
  *
  * The reference's host is a single process (one ROS node); within a replan step its N QPs are independent

@@ -17,8 +17,6 @@ PRECISION_F64, PRECISION_MIXED = 0, 1  # lscqp_class_desc.precision
 WARM_DEFAULT, WARM_TIGHT = 0, 1  # lscqp_class_desc.warm_start
 INFO_FLOOR_ACCEPTED, INFO_REPAIRED, INFO_RECENTRED, INFO_REMEMBERED, INFO_SHIFTED, INFO_RESCUED, INFO_ACTIVE_SET = 1, 2, 4, 8, 16, 32, 64  # lscqp_info.flags
 ACTIVE_SET_DEFAULT, ACTIVE_SET_OFF, ACTIVE_SET_ONLY = 0, 1, 2  # lscqp_class_desc.active_set
-ACTIVE_SLOTS = 32  # LSCQP_ACTIVE_SLOTS: ints per instance of the active-row record (lscqp_solve_batch_device_hinted)
-HINT_NONE, HINT_AS_GIVEN, HINT_SHIFTED = 0, 1, 2
 (DAS_WHY_CAPACITY, DAS_WHY_EMPTY_INTERVAL, DAS_WHY_ROWS, DAS_WHY_STEPS, DAS_WHY_NO_STEP, DAS_WHY_PIVOT, DAS_WHY_VERIFICATION,
  DAS_WHY_MULTIPLIER) = range(1, 9)
 PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC, PLANNER_RSFC = 0, 1, 2, 3
@@ -120,8 +118,6 @@ def lib():
         L.lscqp_solve_batch_device_ex.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp]
         L.lscqp_solve_batch_device_ordered.restype = C.c_int
         L.lscqp_solve_batch_device_ordered.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp, vp]
-        L.lscqp_solve_batch_device_hinted.restype = C.c_int
-        L.lscqp_solve_batch_device_hinted.argtypes = [vp, C.c_int64, C.c_int32] + [vp] * 9 + [C.c_int32, vp, vp, C.c_int32, vp]
         L.lscqp_launch_capacity.restype = C.c_int64
         L.lscqp_launch_capacity.argtypes = [vp, C.c_int64, C.c_int32]
         L.lscqp_order_by_cost_device.restype = C.c_int
@@ -248,7 +244,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["lscqp_create", "lscqp_update", "lscqp_destroy", "lscqp_num_variables", "lscqp_num_inequalities",
-                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_solve_batch_device_hinted", "lscqp_order_by_work_device", "lscqp_launch_capacity", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
+                    "lscqp_algorithmic_bytes", "lscqp_solve_batch", "lscqp_solve_batch_stream", "lscqp_solve_batch_device", "lscqp_solve_batch_device_ex", "lscqp_solve_batch_device_ordered", "lscqp_order_by_work_device", "lscqp_launch_capacity", "lscqp_order_by_cost_device", "lscqp_construct_sfc_device_ordered",
                     "lscqp_num_segments", "lscqp_uses_sfc", "lscqp_row_bytes", "lscqp_max_obstacles", "lscqp_prepare_device", "lscqp_comm_prepare", "lscqp_comm_create", "lscqp_comm_destroy", "lscqp_comm_size",
                     "lscqp_comm_device", "lscqp_comm_stream", "lscqp_comm_backend", "lscqp_comm_set_min_agents_per_device",
                     "lscqp_comm_devices_for", "lscqp_comm_devices_for_class", "lscqp_device_fill", "lscqp_comm_shard", "lscqp_shard_range", "lscqp_exchange_schedule", "lscqp_exchange_schedule_padded", "lscqp_comm_synchronize", "lscqp_solve_batch_sharded",
@@ -597,7 +593,7 @@ class Solver:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 
     def bind_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None, d_x_init=None, retry=False,
-                    d_order=None, d_active=None, hint_mode=HINT_NONE):
+                    d_order=None):
         """solve_device with every argument converted ONCE: returns a zero-argument callable that enqueues the same
         lscqp_solve_batch_device_ordered call on the same stream each time it is called (a timed loop then pays for the C entry, not for
         building eleven ctypes pointers per step).  The tensors must stay alive and in place."""
@@ -609,15 +605,10 @@ class Solver:
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
 
-        if d_active is None:
-            fn = lib().lscqp_solve_batch_device_ordered
-            args = (self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x), p(d_obj), p(d_status), p(d_info), int(retry),
-                    p(d_order), C.c_void_p(s.cuda_stream))
-        else:
-            fn = lib().lscqp_solve_batch_device_hinted
-            args = (self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x), p(d_obj), p(d_status), p(d_info), int(retry),
-                    p(d_order), p(d_active), int(hint_mode), C.c_void_p(s.cuda_stream))
-        keep = (d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info, d_x_init, d_order, d_active, s)
+        fn = lib().lscqp_solve_batch_device_ordered
+        args = (self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x), p(d_obj), p(d_status), p(d_info), int(retry),
+                p(d_order), C.c_void_p(s.cuda_stream))
+        keep = (d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info, d_x_init, d_order, s)
 
         def call(_fn=fn, _args=args, _keep=keep):
             rc = _fn(*_args)
@@ -780,7 +771,7 @@ class Solver:
 
     # ---- device-pointer call (torch tensors hold the HBM buffers) --------------------------------------
     def solve_device(self, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_status, d_info=None, stream=None,
-                     d_x_init=None, retry=False, d_order=None, d_active=None, hint_mode=HINT_NONE):
+                     d_x_init=None, retry=False, d_order=None):
         """All arguments are torch CUDA tensors (any dtype; only data_ptr() is used) or None.
         Asynchronous on `stream` (torch.cuda.Stream) or torch's current stream.  retry: lscqp_solve_batch_device_ex's second pass.
         d_order: int32 permutation of 0 .. n-1 (lscqp_solve_batch_device_ordered: the k-th slot of the launch solves instance d_order[k])."""
@@ -793,13 +784,8 @@ class Solver:
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
 
-        if d_active is not None:  # lscqp_solve_batch_device_hinted: int32 (n, ACTIVE_SLOTS) record of active rows, read per hint_mode, written always
-            rc = lib().lscqp_solve_batch_device_hinted(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
-                                                       p(d_obj), p(d_status), p(d_info), int(retry), p(d_order), p(d_active), int(hint_mode),
-                                                       C.c_void_p(s.cuda_stream))
-        else:
-            rc = lib().lscqp_solve_batch_device_ordered(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
-                                                        p(d_obj), p(d_status), p(d_info), int(retry), p(d_order), C.c_void_p(s.cuda_stream))
+        rc = lib().lscqp_solve_batch_device_ordered(self._h, n, n_obs_max, p(d_hdr), p(d_rows), p(d_off), p(d_sfc), p(d_x_init), p(d_x),
+                                                    p(d_obj), p(d_status), p(d_info), int(retry), p(d_order), C.c_void_p(s.cuda_stream))
         if rc != OK:
             raise LscqpError(rc, lib().lscqp_last_error().decode())
 

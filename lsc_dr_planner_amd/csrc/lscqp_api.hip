@@ -39,7 +39,7 @@ extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int 
 extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
                                        int stage_rows, int screen, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows, const uint64_t* row_offsets,
                                        const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out, int32_t* status_out,
-                                       lscqp_info* info_out, int32_t* active_io, int hint_mode, hipStream_t stream);
+                                       lscqp_info* info_out, hipStream_t stream);
 extern "C" int lscqp_generate_lsc_raw_(int mode, int M, int dim, int64_t n_agents, int32_t n_obs, int64_t first_agent,
                                        const double* d_traj, const double* d_own_traj, const int32_t* d_neighbours, const double* d_radius,
                                        const double* d_downwash, const double* d_goal, const double* d_goal_all, int rows_f32,
@@ -1090,10 +1090,6 @@ int lscqp_solve_batch_device_ordered(lscqp_handle h, int64_t n, int32_t n_obs_ma
                                               retry, d_order, stream, nullptr);
 }
 
-// lscqp_solve_batch_device_hinted hands its two extra arguments to the worker through this (the worker's signature is shared with lscqp_comm.hip)
-static thread_local int32_t* g_active_io = nullptr;
-static thread_local int g_hint_mode = 0;
-
 // The worker behind the public device entries.  retry also takes the library's own pass codes: -2 = only the repair pass on the instance of
 // the other elimination order, -3 = only the rescue pass (the host-pointer entries and lscqp_comm.hip run them after looking at the statuses),
 // -10 - r = the interior-point passes of a call with retry = r whose dual active-set phase has ALREADY run (see `deferred`).
@@ -1207,7 +1203,7 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
             while (kmax > 4 && lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) > lscqp::kMaxLdsBytes) kmax -= 4;
             if (lscqp_das_lds_bytes(Mx, dx, kmax, cacheC, stage) <= lscqp::kMaxLdsBytes) {
                 e = lscqp_launch_das(&cls, Mx, dx, h->es, cap, threads, kmax, steps, cacheC, stage, screen, d_tab, n, d_hdr, d_rows, d_row_offsets, d_sfc,
-                                     d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, g_active_io, g_hint_mode, (hipStream_t)stream);
+                                     d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
                 if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (dual active-set phase): ") + hipGetErrorString(e));
                 das_ran = true;
             }
@@ -1303,22 +1299,6 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     }
     if (retry == 2 || retry == 3) return rescue();
     return LSCQP_OK;
-}
-
-int lscqp_solve_batch_device_hinted(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr, const lscqp_row* d_rows,
-                                    const uint64_t* d_row_offsets, const lscqp_box* d_sfc, const double* d_x_init, double* d_x_out,
-                                    double* d_obj_out, int32_t* d_status_out, lscqp_info* d_info_out, int32_t retry, const int32_t* d_order,
-                                    int32_t* d_active_io, int32_t hint_mode, void* stream) {
-    if (retry < 0 || retry > 3) return fail(LSCQP_ERR_INVALID_ARGUMENT, "retry must be 0, 1, 2 or 3");
-    if (hint_mode != LSCQP_HINT_NONE && hint_mode != LSCQP_HINT_AS_GIVEN && hint_mode != LSCQP_HINT_SHIFTED)
-        return fail(LSCQP_ERR_INVALID_ARGUMENT, "hint_mode must be LSCQP_HINT_NONE, _AS_GIVEN or _SHIFTED");
-    g_active_io = d_active_io;
-    g_hint_mode = d_active_io ? hint_mode : LSCQP_HINT_NONE;
-    const int rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out,
-                                                      d_info_out, retry, d_order, stream, nullptr);
-    g_active_io = nullptr;
-    g_hint_mode = LSCQP_HINT_NONE;
-    return rc;
 }
 
 int lscqp_solve_batch_device(lscqp_handle h, int64_t n, int32_t n_obs_max, const lscqp_header* d_hdr,

@@ -222,8 +222,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                                                       const double* __restrict__ tab, int64_t n, const lscqp_header* __restrict__ hdr,
                                                       const lscqp_row* __restrict__ rows, const uint64_t* __restrict__ row_offsets,
                                                       const lscqp_box* __restrict__ sfc, const double* __restrict__ x_init, double* __restrict__ x_out,
-                                                      double* __restrict__ obj_out, int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out,
-                                                      int32_t* __restrict__ active_io, int hint_mode) {
+                                                      double* __restrict__ obj_out, int32_t* __restrict__ status_out, lscqp_info* __restrict__ info_out) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int T = 64 * NW;
     constexpr int kU = SCREEN ? 4 : (NW == 1) ? LSCQP_DAS_KU1 : 4;  // LSC rows in flight per thread (the one-wavefront full form trades them for a third wavefront per SIMD)
@@ -266,12 +265,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     }
     // ---- header, corridor boxes (and the instance's row offset: one memory round trip for all three) -------------------------------
     const uint64_t roff = row_offsets ? row_offsets[q] : 0;
-    // the active rows of the previous solve of this agent (lscqp_solve_batch_device_hinted), lane j of EVERY wavefront holds entry j: a pricing
-    // hint -- rows to try first -- never more than that (any order of adding violated rows ends at the same optimum)
-    constexpr int kHS = LSCQP_ACTIVE_SLOTS;
-    static_assert(kHS == 32 && kMaxK <= kHS, "one lane of a wavefront per slot");
-    int my_hint = -1;
-    if (!SCREEN && active_io && hint_mode != LSCQP_HINT_NONE) my_hint = active_io[q * kHS + (lane & (kHS - 1))];
     // the class's two-sided rows (lscqp_das_build_pairs, behind the tables and the 36 rounding terms): the first four of this thread are asked
     // for NOW -- they depend on nothing the header holds
     constexpr int kPB = 4;
@@ -310,7 +303,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 info_out[q].gap = (double)steps;  // (overwritten by the pass that solves the instance)
             }
         }
-        if (active_io && tid < kHS) active_io[q * kHS + tid] = -1;
     };
     // An instance whose row system has no point, PROVEN inside the phase (an empty interval; a violated row whose normal lies in the span of
     // the active rows' with no multiplier to give way: a Farkas certificate, taken only where the violation is beyond doubt -- the same
@@ -329,7 +321,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 info_out[q].gap = 0.0;
             }
         }
-        if (active_io && tid < kHS) active_io[q * kHS + tid] = -1;
     };
     if (n_obs > cap || n_obs < 0) {  // the kernel instance behind this phase refuses it (LSCQP_STATUS_CAPACITY): its verdict, not ours
         hand_over(0, LSCQP_DAS_WHY_CAPACITY);
@@ -539,71 +530,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                coef[2] * vec[ent_axis(ent[2]) * P + ent_cp(ent[2])];
     };
 
-    // ---- the hint: the previous solve's active rows as row ids of THIS launch ------------------------------------------------------------
-    // Stored form (what write_out leaves in active_io): an LSC row as its id o * P + cp, a two-sided row as 0x40000000 | (id - nL) -- the count
-    // of LSC rows may differ from call to call.  LSCQP_HINT_SHIFTED: the previous solve was of the plan ONE SEGMENT EARLIER (the replanning
-    // loop: initial_traj is the previous plan shifted by a segment, src/traj_planner.cpp:399-411) -- a row of segment m is looked for at segment
-    // m - 1, a row of segment 0 has no successor.  A slot that names no row of this instance (-1, out of range, a dropped row) is skipped.
-    int my_id = -1;  // (lane j of every wavefront: entry j)
-    if (!SCREEN && my_hint >= 0) {
-        const bool sh = hint_mode == LSCQP_HINT_SHIFTED;
-        const int v = my_hint & 0x3fffffff;
-        if (!(my_hint & 0x40000000)) {  // LSC row
-            const int o = fdiv(v, iP), cp = v - o * P - (sh ? 6 : 0);
-            if (o < n_obs && cp >= 3) my_id = o * P + cp;
-        } else {
-            const int r = v >> 1, side = v & 1, oV = NX, oA = oV + dim * 5 * M, oC = oA + dim * 4 * M, NCP = M * (M - 1) / 2;
-            int rn = -1;
-            if (r < oV) {  // interval of a control point
-                const int k_ = fdiv(r, iP), cp = r - k_ * P - (sh ? 6 : 0);
-                if (cp >= 3) rn = k_ * P + cp;
-            } else if (r < oA) {  // velocity row: k * 5M + 5 m + i
-                const int s_ = r - oV, k_ = s_ / (5 * M), rr = s_ - k_ * 5 * M - (sh ? 5 : 0);
-                if (rr >= 0) rn = oV + k_ * 5 * M + rr;
-            } else if (r < oC) {  // acceleration row: k * 4M + 4 m + i
-                const int s_ = r - oA, k_ = s_ / (4 * M), rr = s_ - k_ * 4 * M - (sh ? 4 : 0);
-                if (rr >= 0) rn = oA + k_ * 4 * M + rr;
-            } else if (r < NPAIR && NCP > 0) {  // communication pair (uu, up): c[uu][5] - c[up + 1][0]
-                const int s_ = r - oC, k_ = s_ / NCP, ci = s_ - k_ * NCP;
-                int uu = 1;
-                while (uu * (uu + 1) / 2 <= ci) uu++;
-                int up = ci - uu * (uu - 1) / 2;
-                if (sh) uu--, up--;
-                if (up >= 0 && uu >= 1) rn = oC + k_ * NCP + uu * (uu - 1) / 2 + up;
-            }
-            if (rn >= 0 && rn < NPAIR && (pix_[rn] >> 24) != 0) my_id = nL + 2 * rn + side;
-        }
-    }
-    bool hints_left = !SCREEN && __builtin_amdgcn_ballot_w64(my_id >= 0) != 0;  // (uniform over the workgroup: every wavefront holds the same entries)
-    // the most violated HINTED row at the current point.  Every wavefront evaluates every entry (lane j: entry j) -- the same loads, the same
-    // arithmetic, the same answer in every wavefront: no barrier.
-    auto hinted_pass = [&](double& bv, int& bi) {
-        double sl = 1.0;
-        int id = 0x7fffffff;
-        if (lane < kHS && my_id >= 0) {
-            bool ok = true;
-            Row R;
-            R.ent[0] = R.ent[1] = R.ent[2] = 0;
-            R.coef[0] = R.coef[1] = R.coef[2] = 0.0;
-            R.rhs = 0.0;
-            if (my_id < nL) {
-                double nx, ny, nz, b;
-                ok = load_row(my_id, nx, ny, nz, b);
-                const int cp = my_id - P * fdiv(my_id, iP);
-                R.ent[0] = cp, R.ent[1] = (1 << 16) | cp, R.ent[2] = (2 << 16) | cp;
-                R.coef[0] = nx, R.coef[1] = ny, R.coef[2] = (dim == 3) ? nz : 0.0;
-                R.rhs = b;
-            } else {
-                decode(my_id, R);
-            }
-            const double v = row_dot(R.ent, R.coef, c_) - R.rhs;
-            if (ok && v == v) sl = v, id = my_id;  // (a NaN is the full pass's to find)
-            if (!ok) my_id = -1;
-        }
-        wave_argmin(sl, id);
-        bv = sl, bi = id;
-    };
-
     // ---- one pass over every row: the most violated one (normalised slack, lowest id on ties) and the largest raw violation ---------
     // The FIRST pass consumes the rows requested in the prologue (HBM), asks for the rest four at a time and, in the staged form (small
     // batches: LDS to spare), leaves them translated in LDS; later passes read them from there, or from L2.
@@ -707,16 +633,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         const bool was_first = first_pass;
         double bv;
         int bi;
-        // while a hinted row is violated, only the hinted rows are looked at (<= 32 rows instead of every row of the instance); the FIRST look is
-        // always the full pass -- it consumes the rows requested in the prologue, and most instances of a plan end right there
-        if (!was_first && hints_left) {
-            hinted_pass(bv, bi);
-            if (bv < -kTolP) {
-                best = bv, bid = bi;
-                return;
-            }
-            hints_left = false;
-        }
         pass_local(bv, bi);
         wave_argmin(bv, bi);
         if constexpr (NW > 1) {
@@ -732,13 +648,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             LSCQP_DAS_BARRIER();  // the staged rows are read by other lanes from now on
         }
         if (staged) rows_in_lds = true;
-        if (was_first && hints_left && bv < -kTolP) {  // a violated row exists: a violated HINTED row goes first
-            double hv;
-            int hi;
-            hinted_pass(hv, hi);
-            if (hv < -kTolP) bv = hv, bi = hi;
-            else hints_left = false;
-        }
         best = bv, bid = bi;
     };
 
@@ -944,11 +853,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
                 info_out[q].res_dual = res_d;
                 info_out[q].gap = 0.0;  // complementarity is exact: a row is either in the set (slack 0) or carries no multiplier
             }
-        }
-        // the rows the optimum holds, for the next solve of this agent (lscqp_solve_batch_device_hinted; the stored form: see the hint above)
-        if (active_io && tid < kHS) {
-            const int rid = tid < k ? aint_[4 * tid] : -1;
-            active_io[q * kHS + tid] = rid < 0 ? -1 : (rid < nL ? rid : (0x40000000 | (rid - nL)));
         }
     };
     // PEEL (batches beyond two workgroups per CU; the lean form): the first look stands in front of the loop of steps and a quiet instance
@@ -1390,7 +1294,7 @@ extern "C" int lscqp_das_blocks_per_cu(int M, int dim, int kmax, int rows_f32) {
 extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int dim, int es, int cap, int threads, int kmax, int max_steps, int cacheC,
                                        int stage_rows, int screen, const double* d_tab, int64_t n, const lscqp_header* hdr, const lscqp_row* rows,
                                        const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
-                                       int32_t* status_out, lscqp_info* info_out, int32_t* active_io, int hint_mode, hipStream_t stream) {
+                                       int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
     if (kmax < 1 || kmax > lscqp_das::kMaxK || (threads != 64 && threads != 128 && threads != 256)) return hipErrorInvalidValue;
     const size_t lds = lscqp_das_lds_bytes(M, dim, kmax, cacheC, stage_rows);
     if (lds > lscqp::kMaxLdsBytes) return hipErrorInvalidValue;
@@ -1416,7 +1320,7 @@ extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int di
         const size_t lds_s = lscqp_das_lds_bytes(M, dim, 1, 0, 0);  // (no active rows, no table copy, no staged rows)
 #define LSCQP_DAS_SCREEN(F_)                                                                                                                                  \
     hipLaunchKernelGGL((lscqp_das::das_kernel<1, F_, true>), dim3((unsigned)n), dim3(64), lds_s, stream, *cls, M, dim, es, cap, 1, 0, 0, 0, 0, d_tab, n, hdr, rows, \
-                       row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out, nullptr, 0)
+                       row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out)
         if (f32) LSCQP_DAS_SCREEN(true); else LSCQP_DAS_SCREEN(false);
 #undef LSCQP_DAS_SCREEN
         const hipError_t e = hipGetLastError();
@@ -1425,7 +1329,7 @@ extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int di
     }
 #define LSCQP_DAS_LAUNCH(NW_, F_, PEEL_)                                                                                                                       \
     hipLaunchKernelGGL((lscqp_das::das_kernel<NW_, F_, false, PEEL_>), dim3((unsigned)n), dim3(64 * NW_), lds, stream, *cls, M, dim, es, cap, kmax, max_steps, cacheC, \
-                       stage_rows, behind, d_tab, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out, active_io, hint_mode)
+                       stage_rows, behind, d_tab, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out, info_out)
     if (threads == 64) { if (f32) LSCQP_DAS_LAUNCH(1, true, true); else LSCQP_DAS_LAUNCH(1, false, true); }
     else if (threads == 128) { if (f32) LSCQP_DAS_LAUNCH(2, true, true); else LSCQP_DAS_LAUNCH(2, false, true); }
     else if (!loop_form) { if (f32) LSCQP_DAS_LAUNCH(4, true, true); else LSCQP_DAS_LAUNCH(4, false, true); }

@@ -60,12 +60,35 @@ def pytest_collection_modifyitems(session, config, items):
     items.sort(key=key)  # stable: the order inside a module is the file's own
 
 
+class _TightOracle:
+    """oracle/oracle.py with the CHECKER's setting of round 6: tol = 1e-14 (40 iterations at most; the point of the last iteration is
+    returned as usual).  At its default tol = 1e-11 the oracle itself sits 1.0 - 2.7e-6 m off the optimum on flat instances
+    (profiles/r05_v6_stress_parity.txt) -- looser than the kernel it checks; at 1e-14 it is within ~3e-10 m of its own 1e-15 answer on every
+    fixture of the suite, which is what lets the parity modules hold the dual active-set phase to 1e-8 m (tests/helpers.py: PathTol).
+    Everything else is the module's."""
+
+    TOL, MAX_ITER = 1e-14, 40
+
+    def __init__(self, mod):
+        self._m = mod
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+    def solve(self, cls, agent, lsc=None, sfc=None, tol=None, max_iter=None):
+        return self._m.solve(cls, agent, lsc, sfc, tol=self.TOL if tol is None else tol, max_iter=self.MAX_ITER if max_iter is None else max_iter)
+
+    def solve_batch(self, cls, agents, lsc=None, lsc_off=None, sfc=None, tol=None, max_iter=None, threads=1):
+        return self._m.solve_batch(cls, agents, lsc, lsc_off, sfc, tol=self.TOL if tol is None else tol,
+                                   max_iter=self.MAX_ITER if max_iter is None else max_iter, threads=threads)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
 
     O.build()
-    return O
+    return _TightOracle(O)
 
 
 @pytest.fixture(scope="session")

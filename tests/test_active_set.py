@@ -13,7 +13,7 @@ import pytest
 from tests import helpers as H
 
 OBJ_TOL = 1e-8
-X_TOL = 1e-6
+X_TOL = H.PathTol()  # 1e-8 m for the dual active-set phase, 1e-6 m for the interior-point kernel (tests/helpers.py)
 KKT_TOL = 1e-8
 
 Q_INT = np.array([[720, -1800, 1200, 0, 0, -120], [-1800, 4800, -3600, 0, 600, 0], [1200, -3600, 3600, -1200, 0, 0],
@@ -187,8 +187,10 @@ def test_budget_exhausted_instances_are_solved_by_the_interior_point_kernel(api,
     assert np.array_equal(by_phase, full["info"]["iterations"] == 0)
     assert ((G["info"]["flags"][~by_phase] & api.INFO_REPAIRED) == 0).all() and (G["info"]["iterations"][~by_phase] >= 3).all()
     assert np.array_equal(O1["status"] == 0, by_phase) and (O1["status"][~by_phase] == api.STATUS_ITER_LIMIT).all()
-    assert np.abs(G["x"] - R["x"]).max() <= X_TOL and (np.abs(G["obj"] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))).max() <= OBJ_TOL
-    assert np.abs(G["x"] - full["x"]).max() <= X_TOL
+    # (a batch finished by BOTH kernels: each instance is held to the bar of the kernel that returned it)
+    tol_q = H.x_tol_by_instance(api, G["info"])
+    assert (np.abs(G["x"] - R["x"]).max(axis=1) <= tol_q).all() and (np.abs(G["obj"] - R["obj"]) / np.maximum(1.0, np.abs(R["obj"]))).max() <= OBJ_TOL
+    assert (np.abs(G["x"] - full["x"]).max(axis=1) <= tol_q).all()
 
 
 @pytest.mark.gpu

@@ -14,7 +14,7 @@ import pytest
 from tests import helpers as H
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJ_TOL, KKT_TOL, X_TOL = 1e-8, 1e-8, 1e-6
+OBJ_TOL, KKT_TOL, X_TOL = 1e-8, 1e-8, H.PathTol()  # x: 1e-8 m for the dual active-set phase, 1e-6 m for the interior-point kernel
 
 
 def _bench_batch(api, key):

@@ -8,7 +8,7 @@ import pytest
 
 from tests import helpers as H
 
-OBJ_TOL, KKT_TOL, X_TOL = 1e-8, 1e-8, 1e-6
+OBJ_TOL, KKT_TOL, X_TOL = 1e-8, 1e-8, H.PathTol()  # x: 1e-8 m for the dual active-set phase, 1e-6 m for the interior-point kernel
 COMPILED_ES1 = {(5, 3), (6, 3), (7, 3), (4, 3), (3, 3), (2, 3), (10, 2), (8, 2), (5, 2), (10, 3)}
 COMPILED_ES0 = {(5, 3), (5, 2), (10, 2)}
 

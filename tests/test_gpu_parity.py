@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 OBJ_TOL = 1e-8
 KKT_TOL = 1e-8
-X_TOL = 1e-6
+X_TOL = H.PathTol()  # 1e-8 m for the dual active-set phase, 1e-6 m for the interior-point kernel (tests/helpers.py)
 
 
 def _check_against_oracle(O, cls, G, R, sel=None):
