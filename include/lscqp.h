@@ -110,8 +110,11 @@ typedef struct lscqp_class_desc {
  * over the batch starts every instance at its unconstrained minimiser (three vectors of a per-class table, no factorisation) and adds
  * the violated rows one at a time (Goldfarb-Idnani; csrc/lscqp_das.hip).  What it finishes is marked LSCQP_INFO_ACTIVE_SET and meets
  * the same bar as an interior-point result (1e-9 m on every row, 1e-9 scaled stationarity, multipliers >= 0, exact complementarity);
- * what it does not finish inside its budget (active rows, steps) -- or cannot judge: infeasible row systems, dependent active rows,
- * capacity -- is solved by the interior-point kernel behind it in the same call, on the same stream, exactly as without the phase.
+ * what it does not finish inside its budget (active rows, steps) -- or cannot judge: dependent active rows, capacity, row systems whose
+ * emptiness it cannot prove -- is solved by the interior-point kernel behind it in the same call, on the same stream, exactly as without
+ * the phase.  Round 6: a row system the phase PROVES empty -- an empty interval, or a violated row (by more than 1e-6 m, the interior-point
+ * kernel's own bar) whose normal lies in the span of the active rows' with no multiplier to give way: a Farkas certificate -- is returned
+ * LSCQP_STATUS_INFEASIBLE by the phase itself (LSCQP_INFO_ACTIVE_SET set, res_primal = the violation) and the kernel behind skips it.
  *   LSCQP_ACTIVE_SET_DEFAULT  on
  *   LSCQP_ACTIVE_SET_OFF      the interior-point kernel alone (rounds 1-4; also: LSCQP_ACTIVE_SET=0 in the environment when the handle is
  *                             CREATED -- the library reads its environment in lscqp_create and nowhere else)

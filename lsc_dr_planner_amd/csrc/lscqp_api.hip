@@ -1388,9 +1388,9 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     LSCQP_CK(hipStreamSynchronize(st));
     {
         const int32_t* st_h = (const int32_t*)(hbase + o_st);
-        bool left = false;  // did the phase hand an instance over?  (its mark: ITER_LIMIT with no iterations; anything not OPTIMAL counts)
+        bool left = false;  // did the phase hand an instance over?  (its mark: ITER_LIMIT)
         if (deferred) {
-            for (int64_t q = 0; q < n && !left; q++) left = st_h[q] != LSCQP_STATUS_OPTIMAL;
+            for (int64_t q = 0; q < n && !left; q++) left = st_h[q] == LSCQP_STATUS_ITER_LIMIT;  // (OPTIMAL and a PROVEN INFEASIBLE are final)
             if (left) {
                 rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, -11, nullptr, st, nullptr);
                 if (rc != LSCQP_OK) return rc;

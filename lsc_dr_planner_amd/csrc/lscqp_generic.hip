@@ -145,6 +145,10 @@ __global__ __launch_bounds__(kT) void pdip_generic_kernel(DevClass cls, int M_, 
     if (cls.repair) {
         const int st0 = status_out[q];
         if (st0 == LSCQP_STATUS_OPTIMAL || st0 == LSCQP_STATUS_CAPACITY) return;
+        // (round 6: an instance the dual active-set phase PROVED infeasible -- INFEASIBLE with LSCQP_INFO_ACTIVE_SET -- is finished: the pass right
+        // behind the phase takes only what the phase marked ITER_LIMIT; a later pass recognises the verdict by the flag)
+        if (cls.repair == 3 && st0 != LSCQP_STATUS_ITER_LIMIT) return;
+        if (st0 == LSCQP_STATUS_INFEASIBLE && info_out && (info_out[q].flags & LSCQP_INFO_ACTIVE_SET)) return;
         if (rescue && st0 != LSCQP_STATUS_ITER_LIMIT && st0 != LSCQP_STATUS_NUMERIC) return;
         if (cls.repair != 3) {  // (3: the FIRST interior-point pass, behind the dual active-set phase of lscqp_das.hip)
             flags |= LSCQP_INFO_REPAIRED | (rescue ? LSCQP_INFO_RESCUED : 0);

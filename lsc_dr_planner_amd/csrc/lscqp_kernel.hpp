@@ -509,6 +509,10 @@ __device__ __forceinline__ void lscqp_pdip_one(const DevClass& cls, const int64_
     if (cls.repair) {  // (uniform) what an earlier pass -- or the dual active-set phase in front of this kernel -- finished is skipped before anything is fetched
         const int st_early = status_out[q];
         if (st_early == LSCQP_STATUS_OPTIMAL || st_early == LSCQP_STATUS_CAPACITY) return;
+        // (round 6: an instance the dual active-set phase PROVED infeasible -- INFEASIBLE with LSCQP_INFO_ACTIVE_SET -- is finished: the pass right
+        // behind the phase takes only what the phase marked ITER_LIMIT; a later pass recognises the verdict by the flag)
+        if (cls.repair == 3 && st_early != LSCQP_STATUS_ITER_LIMIT) return;
+        if (st_early == LSCQP_STATUS_INFEASIBLE && info_out && (info_out[q].flags & LSCQP_INFO_ACTIVE_SET)) return;
     }
     {
         const double* hsrc = reinterpret_cast<const double*>(hdr + q);

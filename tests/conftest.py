@@ -61,13 +61,14 @@ def pytest_collection_modifyitems(session, config, items):
 
 
 class _TightOracle:
-    """oracle/oracle.py with the CHECKER's setting of round 6: tol = 1e-14 (40 iterations at most; the point of the last iteration is
-    returned as usual).  At its default tol = 1e-11 the oracle itself sits 1.0 - 2.7e-6 m off the optimum on flat instances
-    (profiles/r05_v6_stress_parity.txt) -- looser than the kernel it checks; at 1e-14 it is within ~3e-10 m of its own 1e-15 answer on every
-    fixture of the suite, which is what lets the parity modules hold the dual active-set phase to 1e-8 m (tests/helpers.py: PathTol).
-    Everything else is the module's."""
+    """oracle/oracle.py with the CHECKER's last step of round 6: every OPTIMAL point replaced by tests/helpers.py: polish_primal -- the optimum of the same row-for-row model by an exact method (null space + least-distance problem +
+    Lawson-Hanson NNLS + one equality-constrained solve on the active rows).  At its default tol = 1e-11 the oracle's interior-point iterate
+    sits up to 2.7e-6 m off the optimum on flat instances (profiles/r05_v6_stress_parity.txt), and a few 1e-8 m off on some instances at ANY
+    tolerance (the reference's log pipeline, case 37: both device kernels reach a lower objective) -- looser than the kernel it checks.
+    The polished point is within ~1e-10 m of a 1e-14 iterate wherever that one is good, and is what lets the parity modules hold the
+    dual active-set phase to 1e-8 m (tests/helpers.py: PathTol).  Objective, multipliers and statuses are the oracle's own."""
 
-    TOL, MAX_ITER = 1e-14, 40
+    TOL, MAX_ITER = 1e-11, 200  # (the module's own defaults: a tighter gap target does not help -- see above -- and costs the hard KATs their convergence)
 
     def __init__(self, mod):
         self._m = mod
@@ -75,12 +76,40 @@ class _TightOracle:
     def __getattr__(self, name):
         return getattr(self._m, name)
 
-    def solve(self, cls, agent, lsc=None, sfc=None, tol=None, max_iter=None):
-        return self._m.solve(cls, agent, lsc, sfc, tol=self.TOL if tol is None else tol, max_iter=self.MAX_ITER if max_iter is None else max_iter)
+    def solve(self, cls, agent, lsc=None, sfc=None, tol=None, max_iter=None, polish=True):
+        import numpy as np
 
-    def solve_batch(self, cls, agents, lsc=None, lsc_off=None, sfc=None, tol=None, max_iter=None, threads=1):
-        return self._m.solve_batch(cls, agents, lsc, lsc_off, sfc, tol=self.TOL if tol is None else tol,
-                                   max_iter=self.MAX_ITER if max_iter is None else max_iter, threads=threads)
+        from tests import helpers as H
+
+        r = self._m.solve(cls, agent, lsc, sfc, tol=self.TOL if tol is None else tol, max_iter=self.MAX_ITER if max_iter is None else max_iter)
+        if polish and r["status"] == 0:
+            x, ok = H.polish_primal(self._m, cls, np.ascontiguousarray(agent).reshape(-1)[:1], lsc, sfc, x0=r["x"])
+            if ok:
+                r["x_interior_point"], r["x"] = r["x"], x
+        return r
+
+    def solve_batch(self, cls, agents, lsc=None, lsc_off=None, sfc=None, tol=None, max_iter=None, threads=1, polish=True):
+        import numpy as np
+
+        from tests import helpers as H
+
+        R = self._m.solve_batch(cls, agents, lsc, lsc_off, sfc, tol=self.TOL if tol is None else tol,
+                                max_iter=self.MAX_ITER if max_iter is None else max_iter, threads=threads)
+        if polish:
+            agents = np.ascontiguousarray(agents)
+            M = cls.M
+            for q in range(len(agents)):
+                if R["status"][q] != 0:
+                    continue
+                lq = None
+                if lsc is not None and lsc_off is not None:
+                    n_rows = int(agents["n_obs"][q]) * M * 6
+                    lq = np.ascontiguousarray(lsc[int(lsc_off[q]): int(lsc_off[q]) + n_rows])
+                sq = None if sfc is None else np.ascontiguousarray(sfc[q * M:(q + 1) * M])
+                x, ok = H.polish_primal(self._m, cls, agents[q:q + 1], lq, sq, x0=R["x"][q])
+                if ok:
+                    R["x"][q] = x
+        return R
 
 
 @pytest.fixture(scope="session")

@@ -183,3 +183,85 @@ def x_tol_by_instance(api, info, active_set=1e-8, interior_point=1e-6):
     import numpy as np
 
     return np.where((info["flags"] & api.INFO_ACTIVE_SET) != 0, active_set, interior_point)
+
+
+def polish_primal(O, cls, ag, lsc, sfc, x0=None):
+    """The checker's last step (round 6): the optimum of the reference's row-for-row model (oracle.assemble) by a method that shares nothing
+    with the device kernels -- and is exact where the oracle's interior-point iterate is not (a few 1e-8 .. 1e-6 m off on flat instances
+    whatever its tolerance: tools/_dbg/pipeline_probe.py, case 37 of the reference's log pipeline, where BOTH device kernels reach a lower
+    objective than the oracle).  Equalities eliminated through an orthonormal null-space basis (SVD); the reduced strictly convex QP
+    min 1/2 z'Hz + g'z, Gz <= h turned into a least-distance problem (y = L'z + L^-1 g, H = LL') and solved by Lawson-Hanson's NNLS
+    formulation (Solving Least Squares Problems, ch. 23: finite, indifferent to degenerate vertices); then ONE equality-constrained solve on
+    the rows NNLS found active, with iterative refinement, kept if it is feasible and its multipliers are non-negative.
+    Returns (x, ok); ok False: NNLS did not settle, or the row system has no point."""
+    from scipy.optimize import nnls
+
+    A = O.assemble(cls, ag, lsc, sfc)
+    P, q, Aeq, beq, G, h, lb, ub = [A[k] for k in ("P", "q", "Aeq", "beq", "G", "h", "lb", "ub")]
+    nv = len(q)
+    il, iu = np.where(np.isfinite(lb))[0], np.where(np.isfinite(ub))[0]
+    El, Eu = np.zeros((len(il), nv)), np.zeros((len(iu), nv))
+    El[np.arange(len(il)), il] = -1.0
+    Eu[np.arange(len(iu)), iu] = 1.0
+    Ga = np.concatenate([G.reshape(-1, nv), El, Eu])  # Ga x <= ha
+    ha = np.concatenate([h.reshape(-1), -lb[il], ub[iu]])
+    nrm = np.linalg.norm(Ga, axis=1)
+    keep = nrm > 0
+    Ga, ha, nrm = Ga[keep], ha[keep], nrm[keep]
+    Ga, ha = Ga / nrm[:, None], ha / nrm
+    U, S, Vt = np.linalg.svd(Aeq, full_matrices=True)
+    rk = int((S > 1e-10 * S.max()).sum()) if len(S) else 0
+    Z = Vt[rk:].T  # x = xp + Z z
+    xp = np.linalg.lstsq(Aeq, beq, rcond=None)[0] if rk else np.zeros(nv)
+    Hz = 2.0 * Z.T @ P @ Z
+    Hz = 0.5 * (Hz + Hz.T)
+    gz = Z.T @ (2.0 * P @ xp + q)
+    Gz, hz = Ga @ Z, ha - Ga @ xp
+    nz = Z.shape[1]
+    L = np.linalg.cholesky(Hz)
+    Lig = np.linalg.solve(L, gz)                       # L^-1 g
+    Aw = -np.linalg.solve(L, Gz.T).T                   # -G L^-T   (rows: A y >= b)
+    bw = -hz - Gz @ np.linalg.solve(L.T, Lig)          # -h - G H^-1 g
+    # With a point x0 known to lie within ~1e-5 m of the optimum (the oracle's iterate), only the rows within 1e-3 m of it can be active: NNLS
+    # runs on those (tens instead of thousands of columns), the result is checked against EVERY row, and a violated row sends the whole
+    # system through (which is also what happens without x0).
+    cols = np.arange(len(hz))
+    if x0 is not None:
+        z0 = Z.T @ (np.asarray(x0, dtype=np.float64) - xp)
+        cols = np.where(hz - Gz @ z0 <= 1e-3)[0]
+    f = np.zeros(nz + 1)
+    f[nz] = 1.0
+    for attempt in range(2):
+        if len(cols) == 0:
+            z, W = -np.linalg.solve(Hz, gz), np.zeros(0, dtype=int)
+        else:
+            E = np.concatenate([Aw[cols].T, bw[cols][None, :]])
+            try:
+                u, _ = nnls(E, f, maxiter=30 * E.shape[1])
+            except RuntimeError:
+                return (None if x0 is None else np.asarray(x0, dtype=np.float64).copy()), False
+            r = E @ u - f
+            if abs(r[nz]) < 1e-14:
+                if len(cols) < len(hz):
+                    cols = np.arange(len(hz))
+                    continue
+                return (None if x0 is None else np.asarray(x0, dtype=np.float64).copy()), False  # no point satisfies the rows
+            y = -r[:nz] / r[nz]
+            z = np.linalg.solve(L.T, y - Lig)
+            W = cols[np.where(u > 1e-13 * max(u.max(), 1e-300))[0]]
+        if len(cols) == len(hz) or (hz - Gz @ z).min() >= -1e-9:
+            break
+        cols = np.arange(len(hz))
+    if len(W):  # the same vertex to working precision: equality-constrained solve on the active rows
+        k = len(W)
+        Kt = np.zeros((nz + k, nz + k))
+        Kt[:nz, :nz] = Hz
+        Kt[:nz, nz:] = Gz[W].T
+        Kt[nz:, :nz] = Gz[W]
+        rhs = np.concatenate([-gz, hz[W]])
+        sol = np.linalg.lstsq(Kt, rhs, rcond=None)[0]
+        sol += np.linalg.lstsq(Kt, rhs - Kt @ sol, rcond=None)[0]
+        z2, lam = sol[:nz], sol[nz:]
+        if (hz - Gz @ z2).min() >= -1e-11 and lam.min() >= -1e-9 * max(1.0, np.abs(lam).max()):
+            z = z2
+    return xp + Z @ z, True

@@ -51,11 +51,31 @@ def test_bench_line_covers_every_baseline_config_at_its_own_shape():
     assert out.returncode == 0, out.stderr[-2000:]
     b = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
     by = {c["config"]: c for c in b["configs"]}
-    assert set(by) == {"c0", "c2", "c3s", "c3", "c4_f64", "c4"}
-    shapes = {"c0": (10, 10, 2), "c2": (512, 6, 3), "c3s": (128, 10, 3), "c3": (1024, 10, 3), "c4_f64": (4096, 5, 3), "c4": (4096, 5, 3)}
+    base = {"c0", "c2", "c3s", "c3", "c4_f64", "c4"}
+    # round 6: the same swarms later in their exchange, and SURVEY 8d's controlled fraction of infeasible instances
+    loaded = {"c1_loaded", "c0_loaded", "c2_loaded", "c4_loaded"}
+    infeasible = {"c1_infeasible_1pct", "c4_infeasible_1pct"}
+    assert set(by) == base | loaded | infeasible
+    shapes = {"c0": (10, 10, 2), "c2": (512, 6, 3), "c3s": (128, 10, 3), "c3": (1024, 10, 3), "c4_f64": (4096, 5, 3), "c4": (4096, 5, 3),
+              "c1_loaded": (64, 5, 3), "c0_loaded": (10, 10, 2), "c2_loaded": (512, 6, 3), "c4_loaded": (4096, 5, 3),
+              "c1_infeasible_1pct": (64, 5, 3), "c4_infeasible_1pct": (4096, 5, 3)}
+    for k in infeasible:  # every instance made infeasible is reported so -- with the phase on and off -- and its neighbours in the batch are solved
+        c = by[k]
+        assert "error" not in c, c
+        assert c["infeasible"]["all_reported_non_optimal"] and c["infeasible"]["others_optimal"] and c["non_optimal"] == c["infeasible"]["count"]
+        assert c["phase_off"]["non_optimal"] == c["infeasible"]["count"] and c["phase_off"]["statuses_equal"]
+    for k in loaded:  # busier than the 3-replan batches, still finished, still the oracle's optimum; the phase on and off agree
+        c = by[k]
+        assert "error" not in c, c
+        quiet = {"c0_loaded": "c0", "c2_loaded": "c2", "c4_loaded": "c4_f64"}.get(k)
+        assert c["paths"]["active_set_steps_mean"] > (by[quiet]["paths"]["active_set_steps_mean"] if quiet else 0.3)
+        assert c["phase_off"]["statuses_equal"] and c["phase_off"]["max_abs_dx_vs_phase_on"] <= 2e-6
     for k, c in by.items():
         assert "error" not in c, c
         assert (c["agents"], c["segments"], c["dim"]) == shapes[k]
+        assert c["ms_spread"]["min"] <= c["ms_spread"]["median"] <= c["ms_spread"]["max"]
+        if k in infeasible:
+            continue
         assert c["non_optimal"] == 0 and c["latency_ms"]["calls"] >= 1 and c["qp_per_s"] > 0 and c["hbm_frac"] > 0
         assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port"
         # both launch orders are in the line; the sorted one only where a launch runs more than one round of workgroups
@@ -63,8 +83,15 @@ def test_bench_line_covers_every_baseline_config_at_its_own_shape():
         assert c["kernel_ms_as_given"] > 0 and "longest first" not in c["work_order"] and c["paths"]["active_set_solved"] > 0
         if c["rows"] == "f64":
             assert c["parity_vs_oracle"]["max_abs_dx"] <= 1e-6 and c["parity_vs_oracle"]["max_rel_dobj"] <= 1e-8
+            assert c["parity_vs_oracle"]["status_disagreements"] == 0
     assert by["c4"]["precision"] == "mixed" and by["c4"]["rows"] == "f32" and by["c3"]["lsc_neighbours"] == 40
     assert b["config"]["baseline_config"] == "c1" and "mixed_vs_fp64_at_4096" in b
+    # the line carries its own spread, the cold-HBM figure beside the hot one, and the kernel behind the phase measured on its own
+    assert b["spread"]["repeats"] >= 5 and b["spread"]["ms_per_step"]["min"] <= b["ms_per_step"] <= b["spread"]["ms_per_step"]["max"]
+    assert b["roofline"]["frac_cold"] > 0 and b["roofline"]["cold"]["copies_bit_identical"] and b["roofline"]["cold"]["bytes_all_copies"] >= 512 * 2**20
+    assert b["phase_off"]["non_optimal"] == 0 and b["phase_off"]["fp64_valu"]["frac_of_78.6e12"] > 0
+    for k in ("c2", "c3", "c4_f64"):
+        assert by[k]["cold"]["frac"] > 0 and by[k]["cold"]["copies_bit_identical"], by[k]["cold"]
     # the whole replan of the forest10 mission as one device chain, eager and as a hipGraph (informational; durations not asserted)
     rc = b["replan_chain"]
     assert "error" not in rc, rc

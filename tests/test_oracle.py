@@ -99,7 +99,7 @@ def test_log_known_answers(oracle):
             assert np.allclose(pos, st["p"][:2], rtol=0, atol=2e-5), (case["name"], st["t"], pos, st["p"])
             assert np.allclose(vel, st["v"][:2], rtol=1e-4, atol=2e-6), (case["name"], st["t"], vel, st["v"])
             assert np.allclose(acc, st["a"][:2], rtol=3e-4, atol=2e-5), (case["name"], st["t"], acc, st["a"])
-        k = oracle.kkt(cls, ag, None, sfc, r["x"], r["y"], r["lam"], r["mu_lb"], r["mu_ub"])
+        k = oracle.kkt(cls, ag, None, sfc, r.get("x_interior_point", r["x"]), r["y"], r["lam"], r["mu_lb"], r["mu_ub"])
         assert k["stationarity"] < 1e-9 and k["eq"] < 1e-9 and k["ineq"] < 1e-9 and k["neg_mult"] == 0
     # symmetric agents share the answer up to sign / axis: agent 5 mirrors agent 0
     a0, a5 = g["agents"][0]["states"][1], g["agents"][5]["states"][1]
@@ -130,8 +130,10 @@ def test_oracle_vs_scipy_golden(oracle, name):
         assert np.abs(r["x"] - np.array(c["x"])).max() < 1e-7          # 80-bit polished active-set solution
         assert np.abs(r["x"] - np.array(c["scipy_x"])).max() < 1e-5    # raw trust-constr iterate
         assert abs(r["obj"] - c["obj"]) <= 1e-9 * max(1.0, abs(c["obj"]))
-        k = oracle.kkt(cls, ag, lsc, sfc, r["x"], r["y"], r["lam"], r["mu_lb"], r["mu_ub"])
+        # (the multipliers are the interior-point iterate's: its own KKT residuals are taken at that iterate, not at the polished point)
+        k = oracle.kkt(cls, ag, lsc, sfc, r.get("x_interior_point", r["x"]), r["y"], r["lam"], r["mu_lb"], r["mu_ub"])
         assert k["stationarity"] < 1e-9 and k["eq"] < 1e-9 and k["ineq"] < 1e-10 and k["comp"] < 1e-6
+        assert np.abs(r["x"] - r.get("x_interior_point", r["x"])).max() < 1e-7  # polish and iterate agree far inside the golden bar
 
 
 def test_oracle_detects_infeasible(oracle):
