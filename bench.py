@@ -108,21 +108,15 @@ def time_calls(torch, calls, warm=3):
     return e0.elapsed_time(e1) / len(calls)
 
 
-def cold_measure(torch, api, sol, desc_kwargs, n, n_obs, tensors, max_copies=1024):
-    """The same batch with NOTHING of it in a cache when a launch reads it.  The hot figures of this file re-solve ONE device-resident batch:
-    from the second launch on its rows come out of L2 / the 256 MiB Infinity Cache (FETCH_SIZE counts those hits as traffic; the guide says to
-    scale past L3 before reading it).  Here K copies of the batch -- inputs AND outputs, K x bytes >= 512 MiB, twice the Infinity Cache --
-    are solved round robin: by the time copy j comes round again, 512 MiB of other copies have passed through every cache level.  One untimed
-    round, then one timed round of K launches (HIP events on the launch stream) of (a) the whole solve call and (b) the dual active-set
-    phase alone (LSCQP_ACTIVE_SET_ONLY: the kernel the roofline is quoted on).  The copies hold the same numbers: the results are the hot
-    run's, bit for bit (checked)."""
+def cold_copies(torch, tensors, n, nv, max_copies=1024):
+    """K copies of a device-resident batch -- inputs (header, rows, offsets, boxes, initial trajectories) AND outputs -- with K x bytes >= 512 MiB
+    (twice the Infinity Cache), every buffer kind in ONE allocation, every copy 256-byte aligned.  Returns (K, bytes per copy, lists of K views)."""
     dh, dr, do, ds, dxi = tensors
-    nv = sol.nv
-    per = sum(int(t.numel() * t.element_size()) for t in (dh, dr, do, ds) if t is not None) + (int(dxi.numel() * 8) if dxi is not None else 0)
+    per = sum(int(t.numel() * t.element_size()) for t in (dh, dr, do, ds) if t is not None) + (int(dxi.numel() * dxi.element_size()) if dxi is not None else 0)
     per_out = n * nv * 8 + n * 8 + n * 4 + n * 32
     K = int(min(max_copies, max(2, -(-COLD_BYTES // max(per + per_out, 1)))))
 
-    def rep(t):  # K copies in ONE allocation, every copy 256-byte aligned
+    def rep(t):
         if t is None:
             return [None] * K
         b = t.contiguous().view(torch.uint8).reshape(-1)
@@ -131,14 +125,26 @@ def cold_measure(torch, api, sol, desc_kwargs, n, n_obs, tensors, max_copies=102
         big.view(K, stride)[:, : b.numel()] = b
         return [big[k * stride: k * stride + b.numel()] for k in range(K)]
 
-    H, R, O, S_, XI = rep(dh), rep(dr), rep(do), rep(ds), rep(dxi)
     dev = dh.device
     X = torch.zeros(K, n * nv, dtype=torch.float64, device=dev)
     OB = torch.zeros(K, n, dtype=torch.float64, device=dev)
     ST = torch.full((K, n), -1, dtype=torch.int32, device=dev)
     INF = torch.zeros(K, n * 32, dtype=torch.uint8, device=dev)
+    return K, per + per_out, (rep(dh), rep(dr), rep(do), rep(ds), rep(dxi), X, OB, ST, INF)
+
+
+def cold_measure(torch, api, sol, desc_kwargs, n, n_obs, tensors, max_copies=1024):
+    """The same batch with NOTHING of it in a cache when a launch reads it.  The hot figures of this file re-solve ONE device-resident batch:
+    from the second launch on its rows come out of L2 / the 256 MiB Infinity Cache (FETCH_SIZE counts those hits as traffic; the guide says to
+    scale past L3 before reading it).  Here K copies of the batch -- inputs AND outputs, K x bytes >= 512 MiB, twice the Infinity Cache --
+    are solved round robin: by the time copy j comes round again, 512 MiB of other copies have passed through every cache level.  One untimed
+    round, then one timed round of K launches (HIP events on the launch stream) of (a) the whole solve call and (b) the dual active-set
+    phase alone (LSCQP_ACTIVE_SET_ONLY: the kernel the roofline is quoted on).  The copies hold the same numbers: the results are the hot
+    run's, bit for bit (checked)."""
+    nv = sol.nv
+    K, per_all, (H, R, O, S_, XI, X, OB, ST, INF) = cold_copies(torch, tensors, n, nv, max_copies)
     only = api.Solver(api.make_desc(active_set=api.ACTIVE_SET_ONLY, **desc_kwargs))
-    out = {"copies": K, "bytes_per_copy": per + per_out, "bytes_all_copies": K * (per + per_out)}
+    out = {"copies": K, "bytes_per_copy": per_all, "bytes_all_copies": K * per_all}
     for tag, sv in (("step_ms", sol), ("kernel_ms", only)):
         calls = [sv.bind_device(n, n_obs, H[k], R[k], O[k], S_[k], X[k], OB[k], ST[k], INF[k], d_x_init=XI[k]) for k in range(K)]
         for c in calls:  # one untimed round: every copy has been read once and pushed out again by the K - 1 after it
@@ -155,7 +161,7 @@ def cold_measure(torch, api, sol, desc_kwargs, n, n_obs, tensors, max_copies=102
     out["frac_step"] = bq * n / (out["step_ms"] * 1e-3) / HBM_PEAK
     out["achieved_GBps"] = bq * n / (out["kernel_ms"] * 1e-3) / 1e9
     out["what"] = ("%d copies of the batch (inputs and outputs, %.0f MiB in all: twice the 256 MiB Infinity Cache) solved round robin, one untimed round, "
-                   "then one timed round; kernel_ms = the dual active-set phase alone, step_ms = the whole solve call" % (K, K * (per + per_out) / 2**20))
+                   "then one timed round; kernel_ms = the dual active-set phase alone, step_ms = the whole solve call" % (K, K * per_all / 2**20))
     del H, R, O, S_, XI, X, OB, ST, INF
     return out
 
@@ -849,7 +855,20 @@ def timed_workload(ctx, a):
     plain = not (a.pipeline or a.graph or gather)
     bound_solve = sol.bind_device(N, n_obs_eff, d_hdr, d_rows, d_off, d_sfc, d_x, d_obj, d_st, d_info, d_x_init=d_xinit) if plain else None
 
+    cold_calls, cold_i = None, [0]
+    if a.cold:
+        # (profiling aid, tools/profile_round.py: the timed steps rotate over K copies of the batch, K x bytes >= 512 MiB -- every launch reads its
+        # rows from HBM, which is what makes rocprofv3's FETCH_SIZE of the launch comparable with the algorithmic bytes; cold_measure)
+        if not plain:
+            raise SystemExit("bench.py: --cold rotates the plain solve step over copies of the batch; not with --pipeline / --graph / a collective")
+        Kc, _, (cH, cR, cO, cS, cXI, cX, cOB, cST, cINF) = cold_copies(torch, (d_hdr, d_rows, d_off, d_sfc, d_xinit), N, nv)
+        cold_calls = [sol.bind_device(N, n_obs_eff, cH[k], cR[k], cO[k], cS[k], cX[k], cOB[k], cST[k], cINF[k], d_x_init=cXI[k]) for k in range(Kc)]
+
     def step():
+        if cold_calls is not None:
+            cold_calls[cold_i[0] % len(cold_calls)]()
+            cold_i[0] += 1
+            return
         if plain and d_order[0] is None:
             bound_solve()
             return
@@ -888,6 +907,12 @@ def timed_workload(ctx, a):
     # before the contract's W warm-up steps: untimed steps until the device has been busy for ~0.25 s.  A 20-step timed region of a 14 us
     # step lasts 0.3 ms -- on a box that has just been handed over the clocks are still ramping through all of it (round 5: the driver's
     # line was 14 % below the same command's line from a warm process).  Untimed, like the warm-up itself; `clock_warm_steps` says how many.
+    if a.calibrate_counters:
+        # known-byte streaming kernels at the row stream's access widths (csrc/lscqp_diag.hip: lscqp_calib), in THIS process: a rocprofv3 --pmc
+        # session around this command measures them with the same counters as the solver's kernels (tools/profile_round.py)
+        rc = api.lib().lscqp_debug_calibrate_(1 << 30, None)
+        if rc != 0:
+            raise SystemExit("bench.py: counter calibration failed: " + api.lib().lscqp_last_error().decode())
     clock_warm_steps = 0
     if not a.no_clock_warm:
         t_w = time.perf_counter()
@@ -949,6 +974,9 @@ def timed_workload(ctx, a):
     my_elapsed = elapsed
     elapsed, kernel_ms = ctx.reduce([elapsed, kernel_ms], "max")
 
+    if cold_calls is not None:
+        solve_only()  # (the timed steps wrote the copies' own output buffers)
+        torch.cuda.synchronize()
     status = d_st.cpu().numpy()
     info = d_info.cpu().numpy().view(api.INFO_DTYPE)
     iters = info["iterations"]
@@ -1166,6 +1194,9 @@ def main():
     ap.add_argument("--no-clock-warm", action="store_true", help="skip the untimed ~0.25 s of steps in front of the warm-up (see timed_workload)")
     ap.add_argument("--no-spread", action="store_true", help="skip the six extra timed repeats of the K-step region (the line's `spread`)")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-HBM measurement (512 MiB of batch copies solved round robin)")
+    ap.add_argument("--cold", action="store_true", help="profiling aid: the timed steps rotate over >= 512 MiB of copies of the batch (every launch reads HBM)")
+    ap.add_argument("--calibrate-counters", action="store_true",
+                    help="profiling aid: launch the known-byte streaming kernels (lscqp_calib) once before the warm-up, for a rocprofv3 --pmc session to see")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
                     help="strong scaling: skip rank 0's solve of the WHOLE batch on its own GPU (config.one_gpu_same_workload)")
     args = ap.parse_args()

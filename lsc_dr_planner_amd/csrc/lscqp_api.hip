@@ -89,6 +89,7 @@ struct Knobs {
     int active_set_off = 0;  // LSCQP_ACTIVE_SET=0 / LSCQP_ACTIVE_SET_NOW=0: rounds 1-4's solver (not for LSCQP_ACTIVE_SET_ONLY handles)
     int check_order = 0;     // LSCQP_CHECK_ORDER=1: d_order is verified to be a permutation (allocates and synchronises)
     int no_queue = 0;        // LSCQP_NO_QUEUE: no persistent workgroups (tools/lpt_probe.py)
+    int behind_scan = 0;     // the interior-point pass behind the phase in the persistent kernels' scan form (DevClass::scan; measured: slower)
     int defer_behind = 1;    // host-pointer entries: the interior-point pass behind the phase only when the phase left something (0: always enqueued)
     int das_threads = -1, das_kmax = -1, das_steps = -1, das_cache = -1, das_stage = -1, das_screen = -1, das_loop = -1;  // -1: the launch policy's value
 };
@@ -599,7 +600,7 @@ int lscqp_debug_set_knob_(lscqp_handle h, const char* name, int value) {
     const std::string n(name);
     Knobs& k = h->knobs;
     int* slot = n == "force_generic" ? &k.force_generic : n == "pin_waves" ? &k.pin_waves : n == "active_set_off" ? &k.active_set_off
-              : n == "check_order" ? &k.check_order : n == "no_queue" ? &k.no_queue : n == "defer_behind" ? &k.defer_behind
+              : n == "check_order" ? &k.check_order : n == "no_queue" ? &k.no_queue : n == "defer_behind" ? &k.defer_behind : n == "behind_scan" ? &k.behind_scan
               : n == "das_threads" ? &k.das_threads : n == "das_kmax" ? &k.das_kmax : n == "das_steps" ? &k.das_steps
               : n == "das_cache" ? &k.das_cache : n == "das_stage" ? &k.das_stage : n == "das_screen" ? &k.das_screen
               : n == "das_loop" ? &k.das_loop : nullptr;
@@ -1277,9 +1278,34 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     }
     cls.repair = first_repair;
     das_in_front = das_ran;
-    with_queue(cls, inst);
+    // Behind the phase the pass usually finds nothing to do, and what it costs then is its launch: n workgroups that load one status each and
+    // leave (4096 x M5: 4.5 us and 33 MB of fetches per call; a mixed-precision class: two such launches, float32 then fp64).  So behind the
+    // phase the pass runs on an fp64 instance of the same capacity that has the PERSIST form, in its scan mode (lscqp_kernel.hpp:
+    // DevClass::scan): at most as many workgroups as the chip holds, each looking through 64 statuses per round trip.  A mixed-precision class
+    // is served by that fp64 instance directly -- the float32 factorisation has nothing to add behind a phase that finishes the easy
+    // instances, and its own second pass would be a third launch.  Without such an instance: as before.
+    const Inst* first = inst;
+    if (das_ran && !kn.behind_scan) {
+        // MEASURED (round 6, profiles/r06_behind_scan.txt): the scan form LOSES -- 64 x M5 14.8 -> 17.3 us per call, 4096 x M5 41.0 -> 42.3 -- the
+        // persistent form of the kernel pays more before its first status load than n one-status workgroups cost.  Off by default (knob
+        // behind_scan); what stays is the mixed-precision class going straight to its fp64 instance behind the phase (one launch instead of two).
+        first = mixed ? inst64 : inst;
+    } else if (das_ran) {
+        const int want = std::min(inst->max_obs, inst64->max_obs);
+        if (!(inst->persist && !inst->mixed)) {
+            const Inst* b = nullptr;
+            for (const Inst& i : kInst)
+                if (i.M == h->desc.M && i.dim == h->desc.dim && i.es == h->es && !i.mixed && i.persist && i.max_obs == want && (!kn.pin_waves || i.waves == kn.pin_waves) &&
+                    (!b || i.waves < b->waves))
+                    b = &i;
+            first = b ? b : (mixed ? inst64 : inst);
+        }
+        cls.scan = (first->persist && !first->mixed) ? 1 : 0;
+    }
+    with_queue(cls, first);
     das_in_front = false;
-    e = inst->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
+    e = first->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, d_x_init, d_x_out, d_obj_out, d_status_out, d_info_out, (hipStream_t)stream);
+    cls.scan = 0;
     if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed: ") + hipGetErrorString(e));
     // Second pass over the batch, same stream, no host round trip: a workgroup whose instance is already OPTIMAL (or was
     // refused for capacity) returns at once.  Mixed precision: the fp64 kernel re-solves what the float32 factorisation could
@@ -1290,11 +1316,15 @@ int lscqp_solve_batch_device_internal_(lscqp_handle h, int64_t n, int32_t n_obs_
     // the natural-order instances of the shapes that have both spill to scratch, and a kernel with a private segment costs ~35 us to
     // launch even when every workgroup returns at once (measured: 38.7 vs 4.6 us per call on the forest10 replica).
     const Inst* alt = retry == 2 ? other_order_instance(inst64, n_obs_max) : nullptr;
-    if (mixed || (retry && (d_x_init || alt))) {
+    if ((mixed && first->mixed) || (retry && (d_x_init || alt))) {
         cls.repair = 1;
-        with_queue(cls, alt ? alt : inst64);
-        e = (alt ? alt : inst64)->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
-                                     d_info_out, (hipStream_t)stream);
+        // (behind the phase the second pass, too, finds nothing on most batches: same instance, same scan form as the first)
+        const Inst* second = alt ? alt : ((das_ran && kn.behind_scan && first->persist && !first->mixed) ? first : inst64);
+        cls.scan = (das_ran && kn.behind_scan && second->persist) ? 1 : 0;
+        with_queue(cls, cls.scan ? nullptr : second);
+        e = second->fn(&cls, n, d_hdr, d_rows, d_row_offsets, d_sfc, (retry ? nullptr : d_x_init), d_x_out, d_obj_out, d_status_out,
+                       d_info_out, (hipStream_t)stream);
+        cls.scan = 0;
         if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("HIP launch failed (second pass): ") + hipGetErrorString(e));
     }
     if (retry == 2 || retry == 3) return rescue();

@@ -427,3 +427,68 @@ int lscqp_dump_instance(lscqp_handle h, const lscqp_header* hdr, const lscqp_row
 }
 
 }  // extern "C"
+
+// ---- counter calibration (library-internal; tools/profile_round.py, bench.py --calibrate-counters) ---------------------------------------
+// rocprofv3's FETCH_SIZE / WRITE_SIZE are derived from the L2's memory-side request counters and, on gfx950, tally wide coalesced reads at
+// a fraction of their bytes (the guide: exactly 1/2 for 16 B/lane; "other access widths and WRITE_SIZE are uncalibrated: calibrate on a
+// known byte count in your own access pattern").  These kernels ARE that known byte count, in the access patterns of the solver's row
+// stream -- every lane reads LB contiguous bytes, a wavefront 64 x LB contiguous bytes, exactly as das_kernel fetches lscqp_row (LB = 32, two
+// dwordx4 per lane) and lscqp_row_f32 (LB = 16) -- over a buffer far larger than the 256 MiB Infinity Cache, launched in the SAME profiled
+// process as the workload so that the same counter session measures both.
+namespace lscqp_calib {
+template <int LB>
+__global__ __launch_bounds__(256) void read_kernel(const char* __restrict__ buf, int64_t n_units, unsigned* __restrict__ sink) {
+    unsigned acc = 0;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x) {
+        const char* p = buf + u * LB;
+        if constexpr (LB == 8) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p);
+            acc ^= v.x ^ v.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < LB / 16; j++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * j);
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // (keeps the loads alive; the buffer holds zeros)
+}
+template <int LB>
+__global__ __launch_bounds__(256) void write_kernel(char* __restrict__ buf, int64_t n_units) {
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_units; u += (int64_t)gridDim.x * blockDim.x) {
+        char* p = buf + u * LB;
+#pragma unroll
+        for (int j = 0; j < LB / 8; j++) *reinterpret_cast<uint2*>(p + 8 * j) = make_uint2((unsigned)u, (unsigned)j);
+    }
+}
+}  // namespace lscqp_calib
+
+// bytes: size of the streamed buffer (>= 512 MiB to defeat the Infinity Cache).  Launches, in this order and each over the WHOLE buffer:
+// read_kernel<8>, <16>, <32>, write_kernel<8>, <16> -- every launch's byte count is exactly `bytes` (rounded down to a multiple of 32).
+extern "C" int lscqp_debug_calibrate_(int64_t bytes, void* stream) {
+    if (bytes < 4096) return fail(LSCQP_ERR_INVALID_ARGUMENT, "calibration buffer too small");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LSCQP_ERR_NO_DEVICE, "no HIP device: lscqp has no CPU fallback");
+    bytes = bytes / 32 * 32;
+    char* buf = nullptr;
+    unsigned* sink = nullptr;
+    if (hipMalloc(&buf, (size_t)bytes) != hipSuccess || hipMalloc(&sink, 64) != hipSuccess) {
+        if (buf) (void)hipFree(buf);
+        return fail(LSCQP_ERR_HIP, "calibration: hipMalloc failed");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(buf, 0, (size_t)bytes, st);
+    (void)hipMemsetAsync(sink, 0, 64, st);
+    const dim3 grid(256 * 16), block(256);
+    hipLaunchKernelGGL(lscqp_calib::read_kernel<8>, grid, block, 0, st, buf, bytes / 8, sink);
+    hipLaunchKernelGGL(lscqp_calib::read_kernel<16>, grid, block, 0, st, buf, bytes / 16, sink);
+    hipLaunchKernelGGL(lscqp_calib::read_kernel<32>, grid, block, 0, st, buf, bytes / 32, sink);
+    hipLaunchKernelGGL(lscqp_calib::write_kernel<8>, grid, block, 0, st, buf, bytes / 8);
+    hipLaunchKernelGGL(lscqp_calib::write_kernel<16>, grid, block, 0, st, buf, bytes / 16);
+    const hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(buf);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(LSCQP_ERR_HIP, std::string("calibration kernels: ") + hipGetErrorString(e));
+    return LSCQP_OK;
+}

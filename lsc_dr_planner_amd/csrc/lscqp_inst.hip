@@ -67,11 +67,20 @@ extern "C" hipError_t LSCQP_FN(const lscqp::DevClass* cls, int64_t n, const lscq
     // (and the instances without a persistent form) keep one instance per workgroup and no queue.
     const int cap = resident[dev].load(std::memory_order_acquire);
     lscqp::DevClass c = *cls;
-    if (kPersist && c.queue != nullptr && cap > 0 && n > (int64_t)cap) {
+    if (kPersist && c.scan && cap > 0) {
+        // behind the dual active-set phase (lscqp_kernel.hpp: DevClass::scan): at most `cap` workgroups scan the statuses for what the phase left
+        c.queue = nullptr;
+        c.order = nullptr;
+        const int64_t g = n < (int64_t)cap ? n : (int64_t)cap;
+        hipLaunchKernelGGL(kernp, dim3((unsigned)g), dim3(C::T), lds, stream, c, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out,
+                           info_out);
+    } else if (kPersist && c.queue != nullptr && cap > 0 && n > (int64_t)cap) {
+        c.scan = 0;
         hipLaunchKernelGGL(kernp, dim3((unsigned)cap), dim3(C::T), lds, stream, c, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out,
                            info_out);
     } else {
         c.queue = nullptr;
+        c.scan = 0;
         hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(C::T), lds, stream, c, n, hdr, rows, row_offsets, sfc, x_init, x_out, obj_out, status_out,
                            info_out);
     }
