@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 if "--build-only" in sys.argv:
     o = "/tmp/lscqp_das_timing.o"
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-DLSCQP_DAS_TIMING", "-c", os.path.join(CSRC, "lscqp_das.hip"), "-o", o])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-DLSCQP_DAS_TIMING=0xffff", "-DLSCQP_DAS_TIMING_MIN_STEPS=%s" % os.environ.get("DAS_TIMING_MIN_STEPS", "0"), "-c", os.path.join(CSRC, "lscqp_das.hip"), "-o", o])
     objs = [f for f in glob.glob(os.path.join(CSRC, "_obj", "*.o")) if os.path.basename(f) != "lscqp_das.o"] + [o]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lpthread"])
     print(OUT)
@@ -38,7 +38,7 @@ for key in [a for a in sys.argv[1:] if not a.startswith("-")] or ["c1", "c0", "c
     cfg = bench.CONFIGS[key]
     N, M, dim = cfg["agents"], cfg["segments"], cfg["dim"]
     sw, sol, build, (hdr, rows, off, sfc) = bench.make_batch(api, synth, lambda s: api.Solver(api.make_desc(M=M, dim=dim, world_min=s.world_min, world_max=s.world_max)),
-                                                             N, M, dim, cfg["obs"], seed=cfg["seed"], style=cfg["style"], warm_steps=3)
+                                                             N, M, dim, cfg["obs"], seed=cfg["seed"], style=cfg["style"], warm_steps=cfg.get("warm_steps", 3))
     t = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) for a in (hdr, rows, off, sfc)]
     d_xi = torch.from_numpy(np.ascontiguousarray(api.x_init_from_swarm(build, dim))).to(dev)
     d_x = torch.zeros(N * sol.nv, dtype=torch.float64, device=dev)
