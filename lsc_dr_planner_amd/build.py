@@ -13,6 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 _AB = os.environ.get("LSCQP_AB", "")  # development: LSCQP_AB=<name> builds liblscqp_<name>.so from its own object directory
 OBJ = os.path.join(HERE, "csrc", "_obj" + ("_" + _AB if _AB else ""))
 LIB = os.path.join(HERE, "liblscqp%s.so" % ("_" + _AB if _AB else ""))
+SYNC_LIB = os.path.join(HERE, "liblscqp%s_sync.so" % ("_" + _AB if _AB else ""))  # the race test's twin (csrc/lscqp_das.hip: LSCQP_DAS_FULL_SYNC)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -disable-promote-alloca-to-vector: the kernel keeps its per-lane row state in small arrays indexed by fully unrolled
 # loops.  AMDGPUPromoteAlloca turns them into 512/1024-bit vector registers BEFORE the loops are unrolled and SROA could
@@ -108,6 +109,11 @@ def build(force=False, verbose=False, jobs=None):
         # the backend fuse across statements as the surrounding code happens to allow -- the kernel's instantiations (row formats, wavefronts
         # per QP, launch forms) then differ in the last bit, and the phase's results are required to be identical across all of them
         tasks.append([HIPCC] + FLAGS + ["-ffp-contract=on", "-c", das_src, "-o", das_o])
+    # the race test's twin of the dual active-set kernel (csrc/lscqp_das.hip: LSCQP_DAS_FULL_SYNC) -> liblscqp_sync.so, linked below from the
+    # product's own objects with this one in place of lscqp_das.o (tests/test_race_twin.py)
+    das_sync_o = os.path.join(OBJ, "lscqp_das_sync.o")
+    if force or _newer(das_sync_o, hdrs + [das_src]):
+        tasks.append([HIPCC] + FLAGS + ["-ffp-contract=on", "-DLSCQP_DAS_FULL_SYNC", "-c", das_src, "-o", das_sync_o])
     diag_o = os.path.join(OBJ, "lscqp_diag.o")
     objs.append(diag_o)
     diag_src = os.path.join(CSRC, "lscqp_diag.hip")
@@ -127,6 +133,8 @@ def build(force=False, verbose=False, jobs=None):
         tasks.append("work table")
     if tasks or not os.path.exists(LIB):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
+    if tasks or not os.path.exists(SYNC_LIB):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SYNC_LIB] + [das_sync_o if o == das_o else o for o in objs] + ["-ldl", "-lpthread"])
     return LIB
 
 

@@ -60,28 +60,22 @@ __host__ __device__ inline int num_pairs(int M, int dim) { return dim * (6 * M +
 // LDS carve of one QP, in doubles.
 struct Layout {
     int P, NX, kmax, NPAIR;
-    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_hs, o_pix, o_W, o_L, o_u, o_r, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_dq, o_C, o_rows, o_tl, n_stage, total;
-    // (nw: wavefronts per QP of the launch -- the one-wavefront form needs no cross-wavefront reduction buffer)
-    __host__ __device__ static Layout make(int M, int dim, int kmax, int cacheC, int stage_rows = 0, int nw = 4) {
+    int o_hdr, o_sfc, o_c, o_cu, o_lam, o_plo, o_phi, o_pix, o_W, o_L, o_u, o_r, o_arhs, o_acoef, o_aint, o_red, o_ctl, o_wb, o_dq, o_C, o_rows, o_tl, n_stage, total;
+    __host__ __device__ static Layout make(int M, int dim, int kmax, int cacheC, int stage_rows = 0) {
         Layout s;
         s.P = 6 * M, s.NX = dim * s.P, s.kmax = kmax, s.NPAIR = num_pairs(M, dim);
         int o = 0;
         auto take = [&](int n) { const int at = o; o += (n + 1) & ~1; return at; };
         s.o_hdr = take(32);
         s.o_sfc = take(6 * M);
-        // (c_: a third, zero axis in 2-D: row evaluation without a branch on dim.  A'u of the verification has no room of its own: it lives in the
-        // free column of W -- slot k, the next candidate's -- while no candidate is pending: 90 doubles that decide between 11 and 12 workgroups per CU)
-        s.o_c = take(3 * s.P), s.o_cu = take(s.NX), s.o_lam = 0;
-        // two-sided rows: packed stencil per row; bounds per row only for the INTERVALS (the first NX rows) -- a velocity / acceleration / pair row's
-        // bounds are -+ one number per (family, axis), kept in hs_ (round 6: 16.3 -> 13.3 KB per QP at M = 5 with 8 active rows, which is what
-        // lets a CU hold 12 one-wavefront workgroups instead of 10: 3072 QPs in ONE round of workgroups)
-        s.o_plo = take(s.NX), s.o_phi = take(s.NX), s.o_hs = take(8), s.o_pix = take((s.NPAIR + 1) / 2);
+        s.o_c = take(3 * s.P), s.o_cu = take(s.NX), s.o_lam = take(s.NX);  // (c_: a third, zero axis in 2-D: row evaluation without a branch on dim)
+        s.o_plo = take(s.NPAIR), s.o_phi = take(s.NPAIR), s.o_pix = take((s.NPAIR + 1) / 2);  // two-sided rows: bounds, packed stencil
         s.o_W = take((kmax + 1) * s.NX);      // w_j = C a_j of the active rows; slot k (the next free one) holds the candidate's
         s.o_L = take(kmax * (kmax + 1));
         s.o_u = take(kmax + 1), s.o_r = take(kmax + 4), s.o_arhs = take(kmax + 1);
         s.o_acoef = take(3 * (kmax + 1));
         s.o_aint = take(2 * (kmax + 1) + 2);  // ints: per active row {id, entry0, entry1, entry2} (+ the candidate); entry = axis << 16 | control point
-        s.o_red = take(nw > 1 ? 2 * 24 : 0);  // cross-wavefront reductions, double buffered
+        s.o_red = take(2 * 24);               // cross-wavefront reductions, double buffered
         s.o_ctl = take(8);
         s.o_wb = take(8);  // world box of the class (a kernel argument indexed with a run-time axis would be fetched through vector memory)
         s.o_dq = take(36);  // the objective's coefficient-rounding term (36 doubles as a kernel argument live in 72 scalar registers the kernel does not have)
@@ -125,6 +119,7 @@ __device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a
 // LDS hand-overs.  Inside ONE wavefront: its LDS operations execute in order, the fences keep the compiler from moving them.  Across the
 // workgroup: s_barrier behind a wait on the LDS counter only -- a __syncthreads() would also wait for every global load in flight, and the
 // rows of the first pass are meant to stay in flight across the barriers of the prologue.
+#ifndef LSCQP_DAS_FULL_SYNC
 #define LSCQP_DAS_WAVE_SYNC()                                   \
     do {                                                        \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
@@ -136,6 +131,26 @@ __device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a
         if constexpr (NW > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
     } while (0)
+#else
+// The TWIN of the race test (tests/test_race_twin.py; lsc_dr_planner_amd/build.py builds liblscqp_sync.so from this file with
+// -DLSCQP_DAS_FULL_SYNC): every hand-over waits for EVERYTHING in flight -- vector memory, LDS, scalar memory -- behind workgroup-scope fences,
+// and the workgroup barrier is the compiler's own __syncthreads().  Slower, and by construction free of the one assumption the product's
+// hand-overs make (LDS-counter waits only, global loads left in flight); the test demands bit-identical results from both.
+#define LSCQP_DAS_WAVE_SYNC()                                           \
+    do {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_wave_barrier();                                \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          \
+    } while (0)
+#define LSCQP_DAS_BARRIER()                                             \
+    do {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        if constexpr (NW > 1) __syncthreads();                          \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          \
+    } while (0)
+#endif
 
 // Development aid: per-phase cycle totals, compiled in only with -DLSCQP_DAS_TIMING (tools/das_timing.py)
 #ifdef LSCQP_DAS_TIMING
@@ -143,7 +158,7 @@ __device__ unsigned long long das_cycles[16];
 // (thread 0 accumulates in LDS and adds to the global totals once, at the end: an atomic behind every probe would be waited for by the next
 // wait on vector memory -- a round trip of microseconds booked on whatever phase comes next)
 #define DAS_T_DECL()                                                                                                                  \
-    unsigned long long* const das_tl_ = reinterpret_cast<unsigned long long*>(smem + Layout::make(M, dim, kmax, cacheC, stage_rows, NW).o_tl); \
+    unsigned long long* const das_tl_ = reinterpret_cast<unsigned long long*>(smem + Layout::make(M, dim, kmax, cacheC, stage_rows).o_tl); \
     if (threadIdx.x == 0)                                                                                                             \
         for (int i_ = 0; i_ < 16; i_++) das_tl_[i_] = 0;                                                                              \
     unsigned long long tprev_ = __builtin_readcyclecounter()
@@ -237,15 +252,15 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     const int64_t q = cls.order ? (int64_t)cls.order[k0] : k0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     DAS_T_DECL();
-    const Layout L = Layout::make(M, dim, kmax, cacheC, stage_rows, NW);
+    const Layout L = Layout::make(M, dim, kmax, cacheC, stage_rows);
     const int P = L.P, NX = L.NX, NPAIR = L.NPAIR;
     double* const H_ = smem + L.o_hdr;
     double* const sfc_ = smem + L.o_sfc;
     double* const c_ = smem + L.o_c;
     double* const cu_ = smem + L.o_cu;
+    double* const lam_ = smem + L.o_lam;
     double* const plo_ = smem + L.o_plo;
     double* const phi_ = smem + L.o_phi;
-    double* const hs_ = smem + L.o_hs;  // [0, 3): velocity bound per axis, [3, 6): acceleration bound per axis, [6]: pair bound (see Layout)
     int* const pix_ = reinterpret_cast<int*>(smem + L.o_pix);  // packed stencil of a two-sided row: type << 24 | first entry index (in 0 .. NX-1) << 12 | second
     double* const W_ = smem + L.o_W;   // [kmax + 1][NX]
     double* const Jm_ = smem + L.o_L;  // [kmax][kmax + 1] J = L^-1, S = A'C A = L L' over the active rows
@@ -409,17 +424,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     // type 0: no row; 1: interval; 2: velocity; 3: acceleration; 4: pair.  Entry indices are positions in c_ (axis * P + control point).
     bool empty = false;
     const double hv_c = dt * 0.2, ha_c = dt * dt * 0.05;
-    if (tid < 7) hs_[tid] = tid < 3 ? Hd->vmax[tid] * hv_c : tid < 6 ? Hd->amax[tid - 3] * ha_c : rho_pair;  // (the very expressions of the rows' bounds below)
-    // bounds of two-sided row r with packed stencil pk: an interval's own pair, or -+ the (family, axis) number
-    auto pair_bounds = [&](int r, int pk, double& lo, double& hi) {
-        const int type = pk >> 24, e0 = (pk >> 12) & 0xfff;
-        const bool iv = r < NX;
-        const int rc = iv ? r : 0;
-        const double li = plo_[rc], hi_i = phi_[rc];
-        const double hs = hs_[type == 2 ? fdiv(e0, iP) : type == 3 ? 3 + fdiv(e0, iP) : 6];
-        lo = iv ? li : -hs;
-        hi = iv ? hi_i : hs;
-    };
     for (int r0 = tid; r0 < NPAIR; r0 += kPB * T) {
         if (r0 != tid) {
 #pragma unroll
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
             hi = fam == 0 ? hi : hs;
             if (r < NPAIR) {
                 if (fam == 0 && (w0 >> 24) != 0 && lo > hi) empty = true;
-                if (r < NX) plo_[r] = lo, phi_[r] = hi;  // (fam == 0 exactly: the intervals are the first NX rows)
+                plo_[r] = lo, phi_[r] = hi;
                 pix_[r] = w0;
             }
         }
@@ -531,9 +535,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         const int s = rid - nL, r = s >> 1, pk = pix_[r];
         const int type = pk >> 24, e0 = (pk >> 12) & 0xfff, e1 = pk & 0xfff;
         const double sg = (s & 1) ? -1.0 : 1.0;
-        double blo, bhi;
-        pair_bounds(r, pk, blo, bhi);
-        R.rhs = (s & 1) ? -bhi : blo;
+        R.rhs = (s & 1) ? -phi_[r] : plo_[r];
         if (type == 1) {
             R.ent[0] = ent_of(e0), R.coef[0] = sg;
         } else if (type == 2) {
@@ -628,9 +630,7 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
         for (int r0 = tid; r0 < NPAIR; r0 += 2 * T) {  // two at a time: their LDS round trips overlap
             const int r1 = r0 + T, r1c = r1 < NPAIR ? r1 : r0;
             const int pk0 = pix_[r0], pk1 = pix_[r1c];
-            double lo0, hi0, lo1, hi1;
-            pair_bounds(r0, pk0, lo0, hi0);
-            pair_bounds(r1c, pk1, lo1, hi1);
+            const double lo0 = plo_[r0], hi0 = phi_[r0], lo1 = plo_[r1c], hi1 = phi_[r1c];
             const double d0 = pair_val(pk0, c_), d1 = pair_val(pk1, c_);
             const bool on0 = (pk0 >> 24) != 0, on1 = (pk1 >> 24) != 0 && r1 < NPAIR;
             see(on0 ? d0 - lo0 : 1.0, nL + 2 * r0);
@@ -751,7 +751,6 @@ __global__ __launch_bounds__(64 * NW, (SCREEN ? LSCQP_DAS_WPES : NW == 1 ? LSCQP
     // as cplex.getObjValue() reports it (as lscqp_kernel.hpp).  Every z thread evaluates the <= 4 control-point rows of Hx it needs itself.
     const int NZA = 3 * (M - 1) + (es ? 1 : 3);
     auto finish_local = [&](int k, double& rd, double& gs, double& part) {
-        double* const lam_ = W_ + (size_t)k * NX;  // (the free column of W: see Layout)
         if (k > 0) {  // A'u, per control point
             for (int e = tid; e < NX; e += T) lam_[e] = 0.0;
             LSCQP_DAS_BARRIER();
@@ -1294,18 +1293,15 @@ extern "C" int lscqp_das_cycles(unsigned long long* out, int reset) {
 }
 #endif
 
-extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int stage_rows) {  // (of the forms with more than one wavefront per QP: the largest)
+extern "C" size_t lscqp_das_lds_bytes(int M, int dim, int kmax, int cacheC, int stage_rows) {
     return sizeof(double) * (size_t)lscqp_das::Layout::make(M, dim, kmax, cacheC, stage_rows).total;
-}
-extern "C" size_t lscqp_das_lds_bytes_nw(int M, int dim, int kmax, int cacheC, int stage_rows, int nw) {
-    return sizeof(double) * (size_t)lscqp_das::Layout::make(M, dim, kmax, cacheC, stage_rows, nw).total;
 }
 
 // workgroups of the one-wavefront form a CU holds at once (registers and the LDS footprint of a launch with `kmax` active rows, no table
 // copy, no staged rows), as the runtime computes it; 0 without a device
 extern "C" int lscqp_das_blocks_per_cu(int M, int dim, int kmax, int rows_f32) {
     int nb = 0;
-    const size_t lds = lscqp_das_lds_bytes_nw(M, dim, kmax, 0, 0, 1);
+    const size_t lds = lscqp_das_lds_bytes(M, dim, kmax, 0, 0);
     const hipError_t e = rows_f32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lscqp_das::das_kernel<1, true, false, true>, 64, lds)
                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lscqp_das::das_kernel<1, false, false, true>, 64, lds);
     return e == hipSuccess ? nb : 0;
@@ -1321,7 +1317,7 @@ extern "C" hipError_t lscqp_launch_das(const lscqp::DevClass* cls, int M, int di
                                        const uint64_t* row_offsets, const lscqp_box* sfc, const double* x_init, double* x_out, double* obj_out,
                                        int32_t* status_out, lscqp_info* info_out, hipStream_t stream) {
     if (kmax < 1 || kmax > lscqp_das::kMaxK || (threads != 64 && threads != 128 && threads != 256)) return hipErrorInvalidValue;
-    const size_t lds = lscqp_das_lds_bytes_nw(M, dim, kmax, cacheC, stage_rows, threads / 64);
+    const size_t lds = lscqp_das_lds_bytes(M, dim, kmax, cacheC, stage_rows);
     if (lds > lscqp::kMaxLdsBytes) return hipErrorInvalidValue;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
