@@ -185,6 +185,9 @@ def x_tol_by_instance(api, info, active_set=1e-8, interior_point=1e-6):
     return np.where((info["flags"] & api.INFO_ACTIVE_SET) != 0, active_set, interior_point)
 
 
+_POLISH_CACHE = {}
+
+
 def polish_primal(O, cls, ag, lsc, sfc, x0=None):
     """The checker's last step (round 6): the optimum of the reference's row-for-row model (oracle.assemble) by a method that shares nothing
     with the device kernels -- and is exact where the oracle's interior-point iterate is not (a few 1e-8 .. 1e-6 m off on flat instances
@@ -209,16 +212,35 @@ def polish_primal(O, cls, ag, lsc, sfc, x0=None):
     keep = nrm > 0
     Ga, ha, nrm = Ga[keep], ha[keep], nrm[keep]
     Ga, ha = Ga / nrm[:, None], ha / nrm
-    U, S, Vt = np.linalg.svd(Aeq, full_matrices=True)
-    rk = int((S > 1e-10 * S.max()).sum()) if len(S) else 0
-    Z = Vt[rk:].T  # x = xp + Z z
-    xp = np.linalg.lstsq(Aeq, beq, rcond=None)[0] if rk else np.zeros(nv)
-    Hz = 2.0 * Z.T @ P @ Z
-    Hz = 0.5 * (Hz + Hz.T)
+    # (the equality rows' matrix and the Hessian are the CLASS's -- per number of terminal segments -- and the same for every instance of a
+    # batch: their factorisations are kept)
+    key = (Aeq.shape, hash(Aeq.tobytes()), hash(P.tobytes()))
+    hit = _POLISH_CACHE.get(key)
+    if hit is None:
+        U, S, Vt = np.linalg.svd(Aeq, full_matrices=True)
+        rk = int((S > 1e-10 * S.max()).sum()) if len(S) else 0
+        Z = Vt[rk:].T  # x = xp + Z z
+        Apinv = np.linalg.pinv(Aeq) if rk else np.zeros((nv, 0))
+        Hz = 2.0 * Z.T @ P @ Z
+        Hz = 0.5 * (Hz + Hz.T)
+        if len(_POLISH_CACHE) > 64:
+            _POLISH_CACHE.clear()
+        hit = _POLISH_CACHE[key] = (rk, Z, Apinv, Hz, np.linalg.cholesky(Hz))
+    rk, Z, Apinv, Hz, L = hit
+    xp = Apinv @ beq if rk else np.zeros(nv)
+    xp = xp + Apinv @ (beq - Aeq @ xp) if rk else xp  # (one refinement: the equalities to rounding)
     gz = Z.T @ (2.0 * P @ xp + q)
+    # (with x0 given only the rows within 1e-3 m of it are carried into the reduced space -- see below -- and the result is checked against every
+    # row in x space: a matrix-vector product instead of the (rows x nv) x (nv x nz) product that dominated this function)
+    all_rows = np.arange(len(ha))
+    if x0 is not None:
+        near = np.where(ha - Ga @ np.asarray(x0, dtype=np.float64) <= 1e-3)[0]
+    else:
+        near = all_rows
+    Ga_full, ha_full = Ga, ha
+    Ga, ha = Ga_full[near], ha_full[near]
     Gz, hz = Ga @ Z, ha - Ga @ xp
     nz = Z.shape[1]
-    L = np.linalg.cholesky(Hz)
     Lig = np.linalg.solve(L, gz)                       # L^-1 g
     Aw = -np.linalg.solve(L, Gz.T).T                   # -G L^-T   (rows: A y >= b)
     bw = -hz - Gz @ np.linalg.solve(L.T, Lig)          # -h - G H^-1 g
@@ -226,9 +248,6 @@ def polish_primal(O, cls, ag, lsc, sfc, x0=None):
     # runs on those (tens instead of thousands of columns), the result is checked against EVERY row, and a violated row sends the whole
     # system through (which is also what happens without x0).
     cols = np.arange(len(hz))
-    if x0 is not None:
-        z0 = Z.T @ (np.asarray(x0, dtype=np.float64) - xp)
-        cols = np.where(hz - Gz @ z0 <= 1e-3)[0]
     f = np.zeros(nz + 1)
     f[nz] = 1.0
     for attempt in range(2):
@@ -242,15 +261,26 @@ def polish_primal(O, cls, ag, lsc, sfc, x0=None):
                 return (None if x0 is None else np.asarray(x0, dtype=np.float64).copy()), False
             r = E @ u - f
             if abs(r[nz]) < 1e-14:
-                if len(cols) < len(hz):
+                if len(near) < len(all_rows):
+                    near = all_rows
+                    Ga, ha = Ga_full, ha_full
+                    Gz, hz = Ga @ Z, ha - Ga @ xp
+                    Aw = -np.linalg.solve(L, Gz.T).T
+                    bw = -hz - Gz @ np.linalg.solve(L.T, Lig)
                     cols = np.arange(len(hz))
                     continue
                 return (None if x0 is None else np.asarray(x0, dtype=np.float64).copy()), False  # no point satisfies the rows
             y = -r[:nz] / r[nz]
             z = np.linalg.solve(L.T, y - Lig)
             W = cols[np.where(u > 1e-13 * max(u.max(), 1e-300))[0]]
-        if len(cols) == len(hz) or (hz - Gz @ z).min() >= -1e-9:
+        if len(near) == len(all_rows) or (ha_full - Ga_full @ (xp + Z @ z)).min() >= -1e-9:
             break
+        # a row outside the neighbourhood of x0 is violated: the whole system
+        near = all_rows
+        Ga, ha = Ga_full, ha_full
+        Gz, hz = Ga @ Z, ha - Ga @ xp
+        Aw = -np.linalg.solve(L, Gz.T).T
+        bw = -hz - Gz @ np.linalg.solve(L.T, Lig)
         cols = np.arange(len(hz))
     if len(W):  # the same vertex to working precision: equality-constrained solve on the active rows
         k = len(W)
