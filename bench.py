@@ -915,8 +915,9 @@ def timed_workload(ctx, a):
             raise SystemExit("bench.py: counter calibration failed: " + api.lib().lscqp_last_error().decode())
     clock_warm_steps = 0
     if not a.no_clock_warm:
+        # (several ranks: a FIXED count -- a step may hold a collective, and ranks that warm by their own clocks would call it unequally often)
         t_w = time.perf_counter()
-        while time.perf_counter() - t_w < 0.25 and clock_warm_steps < 200000:
+        while (clock_warm_steps < 300) if world > 1 else (time.perf_counter() - t_w < 0.25 and clock_warm_steps < 200000):
             for _ in range(50):
                 step()
             clock_warm_steps += 50

@@ -555,7 +555,7 @@ class Comm:
 # The library reads its environment when a handle is CREATED and never afterwards (csrc/lscqp_api.hip: Knobs).  The test suite and bench.py
 # flip these switches between launches of one process, on live handles: this wrapper (test and bench plumbing, not the product) notices a change
 # of the process environment and tells the handle to re-read it through the library-internal lscqp_debug_reload_knobs_.
-_KNOB_ENV = ("LSCQP_FORCE_GENERIC", "LSCQP_WAVES", "LSCQP_ACTIVE_SET", "LSCQP_ACTIVE_SET_NOW", "LSCQP_CHECK_ORDER", "LSCQP_NO_QUEUE", "LSCQP_DEFER_BEHIND")
+_KNOB_ENV = ("LSCQP_FORCE_GENERIC", "LSCQP_WAVES", "LSCQP_ACTIVE_SET", "LSCQP_ACTIVE_SET_NOW", "LSCQP_CHECK_ORDER", "LSCQP_NO_QUEUE", "LSCQP_DEFER_BEHIND", "LSCQP_ZERO_COPY_BYTES")
 
 
 def _knob_env():

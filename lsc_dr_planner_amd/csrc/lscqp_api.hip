@@ -90,6 +90,10 @@ struct Knobs {
     int check_order = 0;     // LSCQP_CHECK_ORDER=1: d_order is verified to be a permutation (allocates and synchronises)
     int no_queue = 0;        // LSCQP_NO_QUEUE: no persistent workgroups (tools/lpt_probe.py)
     int behind_scan = 0;     // the interior-point pass behind the phase in the persistent kernels' scan form (DevClass::scan; measured: slower)
+    // host-pointer entries: a call whose buffers fit in this many bytes runs on the pinned mirror itself (LSCQP_ZERO_COPY_BYTES; 0: always copy).
+    // Measured (tools/_dbg/host_latency.py, MI355X, p50 per call, copies -> mapped): 1 QP 43.9 -> 37.3 us, 4 QPs 46.4 -> 39.0, 16 QPs 58.7 ->
+    // 50.6, 64 QPs (1.4 MB) 110 -> 85; beyond a few MB the DMA engines' bandwidth wins back what their fixed cost loses.
+    int zero_copy_bytes = 4 * 1024 * 1024;
     int defer_behind = 1;    // host-pointer entries: the interior-point pass behind the phase only when the phase left something (0: always enqueued)
     int das_threads = -1, das_kmax = -1, das_steps = -1, das_cache = -1, das_stage = -1, das_screen = -1, das_loop = -1;  // -1: the launch policy's value
 };
@@ -105,6 +109,8 @@ void load_knobs(Knobs& k) {
     k.no_queue = getenv("LSCQP_NO_QUEUE") != nullptr;
     const char* db = getenv("LSCQP_DEFER_BEHIND");
     k.defer_behind = db ? db[0] != '0' : 1;
+    const char* zc = getenv("LSCQP_ZERO_COPY_BYTES");
+    if (zc) k.zero_copy_bytes = atoi(zc);
 }
 
 struct Inst {
@@ -600,7 +606,7 @@ int lscqp_debug_set_knob_(lscqp_handle h, const char* name, int value) {
     const std::string n(name);
     Knobs& k = h->knobs;
     int* slot = n == "force_generic" ? &k.force_generic : n == "pin_waves" ? &k.pin_waves : n == "active_set_off" ? &k.active_set_off
-              : n == "check_order" ? &k.check_order : n == "no_queue" ? &k.no_queue : n == "defer_behind" ? &k.defer_behind : n == "behind_scan" ? &k.behind_scan
+              : n == "check_order" ? &k.check_order : n == "no_queue" ? &k.no_queue : n == "defer_behind" ? &k.defer_behind : n == "zero_copy_bytes" ? &k.zero_copy_bytes : n == "behind_scan" ? &k.behind_scan
               : n == "das_threads" ? &k.das_threads : n == "das_kmax" ? &k.das_kmax : n == "das_steps" ? &k.das_steps
               : n == "das_cache" ? &k.das_cache : n == "das_stage" ? &k.das_stage : n == "das_screen" ? &k.das_screen
               : n == "das_loop" ? &k.das_loop : nullptr;
@@ -1378,8 +1384,12 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     lscqp::SlotGuard sg{*h->pool, h->pool->acquire(total)};
     if (!sg.slot) return fail(LSCQP_ERR_HIP, "staging allocation failed (hipMalloc / hipHostMalloc / stream)");
     hipStream_t st = stream ? (hipStream_t)stream : sg.slot->stream;  // the caller's stream, or the slot's private one
-    char* const dbase = (char*)sg.slot->d;
     char* const hbase = (char*)sg.slot->h;
+    // Round 6: a SMALL call -- the unchanged simulator's one TrajOptimizer::solve at a time (src/multi_sync_simulator.cpp:357-362): 21 KB in,
+    // 0.8 KB out -- runs on the pinned mirror itself: the kernels read their rows from host memory over the link and write the plan back into
+    // it, and the two DMA copies (each a fixed ~8 us of submission and completion around a 1 us transfer) disappear from the call.
+    const bool zero_copy = sg.slot->hd != nullptr && h->knobs.zero_copy_bytes > 0 && total <= (size_t)h->knobs.zero_copy_bytes;
+    char* const dbase = zero_copy ? (char*)sg.slot->hd : (char*)sg.slot->d;
     const size_t o_hdr = 0, o_rows = o_hdr + b_hdr, o_off = o_rows + b_rows, o_sfc = o_off + b_off, o_xi = o_sfc + b_sfc,
                  o_x = b_in, o_obj = o_x + b_x, o_st = o_obj + b_obj, o_info = o_st + b_st;
     lscqp_header* d_hdr = (lscqp_header*)(dbase + o_hdr);
@@ -1402,7 +1412,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     else memset(hbase + o_off, 0, sizeof(uint64_t) * (n + 1));
     if (h->desc.use_sfc) memcpy(hbase + o_sfc, sfc, sizeof(lscqp_box) * n * h->desc.M);
     if (d_xi) memcpy(hbase + o_xi, x_init, sizeof(double) * n * h->nv);
-    LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, st));
+    if (!zero_copy) LSCQP_CK(hipMemcpyAsync(dbase, hbase, b_in, hipMemcpyHostToDevice, st));
     // (retry = 1: instances a warm start did not bring to OPTIMAL are solved once more from the default start by a second pass
     // on the device, before the results are copied back)
     // The interior-point passes behind the dual active-set phase are enqueued with the phase only when the handle's previous host-pointer call
@@ -1414,7 +1424,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
     int rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, 1, nullptr, st,
                                                 speculate ? &deferred : nullptr);
     if (rc != LSCQP_OK) return rc;
-    LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+    if (!zero_copy) LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
     LSCQP_CK(hipStreamSynchronize(st));
     {
         const int32_t* st_h = (const int32_t*)(hbase + o_st);
@@ -1424,7 +1434,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
             if (left) {
                 rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, d_xi, d_x, d_obj, d_st, d_info, -11, nullptr, st, nullptr);
                 if (rc != LSCQP_OK) return rc;
-                LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+                if (!zero_copy) LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
                 LSCQP_CK(hipStreamSynchronize(st));
             }
             if (h->behind_needed) h->behind_needed->store(left ? 1 : 0, std::memory_order_relaxed);
@@ -1445,7 +1455,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
         if (first && other_order_instance(first, n_obs_max)) {
             rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -2, nullptr, st, nullptr);
             if (rc != LSCQP_OK) return rc;
-            LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+            if (!zero_copy) LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));
         }
         // ... and what is STILL at the iteration limit or broke down numerically gets the rescue pass (run-time-shaped kernel, weighted
@@ -1455,7 +1465,7 @@ int lscqp_solve_batch_stream(lscqp_handle h, int64_t n, const lscqp_header* hdr,
         if (lim && n_obs_max <= lscqp_generic_max_obstacles(h->desc.M, h->desc.dim, h->es)) {
             rc = lscqp_solve_batch_device_internal_(h, n, n_obs_max, d_hdr, d_rows, d_off, d_sfc, nullptr, d_x, d_obj, d_st, d_info, -3, nullptr, st, nullptr);
             if (rc != LSCQP_OK) return rc;
-            LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
+            if (!zero_copy) LSCQP_CK(hipMemcpyAsync(hbase + b_in, dbase + b_in, b_out, hipMemcpyDeviceToHost, st));
             LSCQP_CK(hipStreamSynchronize(st));
         }
     }

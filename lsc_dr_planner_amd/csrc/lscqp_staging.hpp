@@ -14,6 +14,7 @@ namespace lscqp {
 struct StageSlot {
     void* d = nullptr;
     void* h = nullptr;
+    void* hd = nullptr;  // the pinned mirror as the DEVICE addresses it (hipHostGetDevicePointer): small calls run on it directly, without copies
     size_t cap = 0;
     int device = -1;
     hipStream_t stream = nullptr;
@@ -50,7 +51,7 @@ public:
         if (bytes > s->cap) {
             if (s->d) (void)hipFree(s->d);
             if (s->h) (void)hipHostFree(s->h);
-            s->d = s->h = nullptr;
+            s->d = s->h = s->hd = nullptr;
             s->cap = 0;
             if (hipMalloc(&s->d, bytes) != hipSuccess) {
                 s->d = nullptr;
@@ -62,6 +63,10 @@ public:
                 s->d = s->h = nullptr;
                 release(s);
                 return nullptr;
+            }
+            if (hipHostGetDevicePointer(&s->hd, s->h, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                s->hd = nullptr;  // (no mapped view: such a slot always copies)
             }
             s->cap = bytes;
         }
