@@ -96,11 +96,14 @@ class _TightOracle:
         R = self._m.solve_batch(cls, agents, lsc, lsc_off, sfc, tol=self.TOL if tol is None else tol,
                                 max_iter=self.MAX_ITER if max_iter is None else max_iter, threads=threads)
         if polish:
+            from concurrent.futures import ThreadPoolExecutor
+
             agents = np.ascontiguousarray(agents)
             M = cls.M
-            for q in range(len(agents)):
+
+            def one(q):
                 if R["status"][q] != 0:
-                    continue
+                    return
                 lq = None
                 if lsc is not None and lsc_off is not None:
                     n_rows = int(agents["n_obs"][q]) * M * 6
@@ -109,6 +112,10 @@ class _TightOracle:
                 x, ok = H.polish_primal(self._m, cls, agents[q:q + 1], lq, sq, x0=R["x"][q])
                 if ok:
                     R["x"][q] = x
+
+            # (dense linear algebra releases the interpreter lock: the instances of a batch are polished side by side)
+            with ThreadPoolExecutor(max_workers=max(1, min(8, len(agents)))) as ex:
+                list(ex.map(one, range(len(agents))))
         return R
 
 

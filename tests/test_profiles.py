@@ -53,3 +53,28 @@ def test_profiles_are_of_the_batches_the_bench_line_reports():
             print("%s %s: rocprofv3 %.1f us (%s), bench line %.1f us" % (tag, key, tl["avg_ns"] / 1e3, pm["kernel"].split("(")[0][-40:], (ev or e["kernel_ms"]) * 1e3))
         seen += 1
     assert seen >= 5, "profile set %s is incomplete (%d configs)" % (tag, seen)
+
+
+def test_round6_profiles_use_one_calibrated_counter_rule():
+    """FETCH_SIZE / WRITE_SIZE calibrated in the SAME rocprofv3 session on known-byte streaming kernels, ONE rule for every
+    config, counters attributed per kernel instantiation, and the cold 4096 x M5 launch moving what the byte model says it moves."""
+    tag = _newest_tag()
+    if tag is None or int(tag[1:3]) < 6:
+        pytest.skip("no round-6 profile set committed yet")
+    hows, seen = set(), 0
+    for f in glob.glob(os.path.join(ROOT, "profiles", tag + "_*_pmc.json")):
+        pm = json.load(open(f))
+        cal = pm["fetch_calibration"]
+        hows.add(cal["how"])
+        # the stack's own behaviour, measured not assumed: half of the bytes of a coalesced read at every width, all of a write
+        for lb, r in cal["all_read_ratios"].items():
+            assert 0.45 <= r <= 0.55, (f, lb, r)
+        assert 0.95 <= cal["write_counted_per_known_byte"] <= 1.05
+        assert set(pm["traffic_per_kernel"]) == set(pm["kernels"]) and pm["traffic_bytes_per_launch"] == pm["traffic_per_kernel"][pm["kernel"]]["traffic"]
+        assert "--cold" in pm["command_cold"] and "--calibrate-counters" in pm["command_cold"]
+        seen += 1
+    assert seen >= 5 and len(hows) == 1, hows
+    c4 = json.load(open(os.path.join(ROOT, "profiles", tag + "_c4_f64_pmc.json")))
+    assert 0.95 <= c4["traffic_over_algorithmic"] <= 1.15, c4["traffic_over_algorithmic"]
+    line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench.json")))
+    assert line["roofline"]["frac_cold"] > 0 and line["spread"]["repeats"] >= 5
