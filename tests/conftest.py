@@ -44,7 +44,7 @@ def solver_path(request, monkeypatch):
 # communicator / closed loop, then the full-size property and stress tests, and LAST the tests that spawn bench.py as a
 # subprocess (they re-check parity through the bench line and cost the most wall-clock per assertion).
 _ORDER = ["test_oracle", "test_abi", "test_row_format", "test_synth", "test_dropin_check",
-          "test_gpu_parity", "test_active_set", "test_kat_3d", "test_shim", "test_generic", "test_mixed_precision", "test_floor_audit", "test_diag",
+          "test_gpu_parity", "test_active_set", "test_round6_host", "test_kat_3d", "test_shim", "test_generic", "test_mixed_precision", "test_floor_audit", "test_diag",
           "test_lscgen", "test_lscmode", "test_prediction", "test_goal", "test_post", "test_sfc",
           "test_plan", "test_closed_loop", "test_comm", "test_dist_cpu", "test_race_twin",
           "test_full_size_properties", "test_stress_gpu", "test_profiles", "test_bench_contract"]
